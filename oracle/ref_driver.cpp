@@ -1,0 +1,175 @@
+// TEST INFRASTRUCTURE ONLY — never linked into the product.
+//
+// Driver for the real reference (sources compiled where they lie under
+// /root/reference by oracle/Makefile; nothing is copied).  It replaces only
+// the reference's `main` (src/main.cpp:145-159, renamed ref_main at compile
+// time) so that
+//   * the transcript of prover messages can be written (see ref_hook.hpp),
+//   * B-fold block-replicated SHA-256 circuits can be fed to the reference's
+//     own DAG_to_layered() without a 224 MB .pws text file and its regex
+//     parser, and
+//   * layeredCircuit::randomize() (src/circuit.cpp:17-41) is reachable
+//     (no CLI reaches it in the reference).
+// Everything downstream of circuit construction is the reference's own code:
+// DAG_to_layered, F::init, subsetInit, prover, verifier::verify.
+//
+// Usage:
+//   ref_run --pws FILE [--blocks B] [--ref-parser] [--pc 0|1] [--dump OUT] [--seed S]
+//   ref_run --randomize LAYERS LOG_SIZE      [--pc 0|1] [--dump OUT] [--seed S]
+#include "verifier.h"
+#include "inputCircuit.hpp"
+#include <fstream>
+#include <string>
+#include <chrono>
+
+vp_ref_state g_vp_ref;
+
+// symbols defined in the reference's src/main.cpp
+extern layeredCircuit c;
+extern std::vector<DAG_gate *> in_circuit_dag;
+void DAG_to_layered();
+void parse(std::ifstream &circuit_in);
+DAG_gate *buildGate(gateType ty, u64 tgt, u64 src0, u64 src1, bool has_constant);
+DAG_gate *buildInput(u64 tgt, u64 src0);
+
+struct pws_gate { gateType ty; u64 tgt, s0, s1; };
+
+// Read a .pws file without regexes.  Same grammar as src/main.cpp:161-168.
+static void read_pws(const char *path, std::vector<u64> &inputs, std::vector<pws_gate> &gates) {
+    FILE *f = fopen(path, "r");
+    if (!f) { perror(path); exit(2); }
+    char line[256];
+    while (fgets(line, sizeof line, f)) {
+        long long t, a, b; char op[16];
+        if (sscanf(line, "P V%lld = I%lld E", &t, &a) == 2) { inputs.push_back(t); continue; }
+        if (sscanf(line, "P O%lld = V%lld E", &t, &a) == 2) continue;
+        if (sscanf(line, "P V%lld = V%lld %15s V%lld E", &t, &a, op, &b) == 4) {
+            gateType ty;
+            if (!strcmp(op, "+")) ty = Add;
+            else if (!strcmp(op, "*")) ty = Mul;
+            else if (!strcmp(op, "XOR")) ty = Xor;
+            else if (!strcmp(op, "minus")) ty = Sub;
+            else if (!strcmp(op, "NAAB")) ty = Naab;
+            else if (!strcmp(op, "NOT")) ty = Not;
+            else { fprintf(stderr, "bad op %s\n", op); exit(2); }
+            gates.push_back({ty, (u64) t, (u64) a, (u64) b});
+            continue;
+        }
+        fprintf(stderr, "unparsed line: %s", line); exit(2);
+    }
+    fclose(f);
+}
+
+// Populate in_circuit_dag with B copies of the DAG: all inputs first (block b
+// input k -> b*nin+k, witness drawn in that order exactly as parse() would on
+// the replicated file), then gates block-major.
+static void populate_replicated(const char *path, int B) {
+    std::vector<u64> inputs; std::vector<pws_gate> gates;
+    read_pws(path, inputs, gates);
+    u64 nin = inputs.size(), ng = gates.size();
+    for (u64 k = 0; k < nin; ++k) if (inputs[k] != k) { fprintf(stderr, "inputs not V0..\n"); exit(2); }
+    for (u64 g = 0; g < ng; ++g) if (gates[g].tgt != nin + g) { fprintf(stderr, "gates not dense\n"); exit(2); }
+    for (int b = 0; b < B; ++b)
+        for (u64 k = 0; k < nin; ++k)
+            buildInput(b * nin + k, random() % virgo::fieldElement::mod);   // src/main.cpp:188
+    auto map = [&](int b, u64 id) { return id < nin ? b * nin + id : (u64) B * nin + b * ng + (id - nin); };
+    for (int b = 0; b < B; ++b)
+        for (u64 g = 0; g < ng; ++g) {
+            auto &x = gates[g];
+            if (x.ty == Not) buildGate(Not, map(b, x.tgt), map(b, x.s0), 0, true);        // src/main.cpp:202
+            else buildGate(x.ty, map(b, x.tgt), map(b, x.s0), map(b, x.s1), false);
+        }
+}
+
+// Streaming 2x64-bit hash of the layered circuit in a canonical serialisation
+// (shared with oracle/vp_oracle.cpp and the product loader's tests).
+struct chash {
+    unsigned long long a = 1469598103934665603ull, b = 0x9e3779b97f4a7c15ull;
+    void u64v(unsigned long long x) {
+        for (int i = 0; i < 8; ++i) { a ^= (x >> (8 * i)) & 0xff; a *= 1099511628211ull; }
+        b = (b ^ x) * 0xff51afd7ed558ccdull; b ^= b >> 32;
+    }
+};
+static void circuit_hash(const layeredCircuit &C, unsigned long long out[2]) {
+    chash h;
+    h.u64v(C.size);
+    for (int i = 0; i < C.size; ++i) {
+        auto &L = C.circuit[i];
+        h.u64v(L.size); h.u64v((long long) L.bitLength);
+        for (u64 g = 0; g < L.size; ++g) {
+            auto &G = L.gates[g];
+            h.u64v((long long) G.ty); h.u64v((long long) G.l); h.u64v(G.u); h.u64v(G.v); h.u64v(G.lv);
+            h.u64v(G.c.real); h.u64v(G.c.img); h.u64v(G.is_assert ? 1 : 0);
+        }
+        h.u64v((long long) L.maxDadBitLength); h.u64v(L.maxDadSize);
+        for (int j = 0; j < i; ++j) {
+            h.u64v(L.dadSize[j]);
+            h.u64v(L.dadSize[j] ? (long long) L.dadBitLength[j] : -1ll);  // (int)log2(0) is UB in the reference
+            for (u64 k = 0; k < L.dadSize[j]; ++k) h.u64v(L.dadId[j][k]);
+        }
+    }
+    out[0] = h.a; out[1] = h.b;
+}
+
+int main(int argc, char **argv) {
+    const char *pws = nullptr, *dump = nullptr;
+    int blocks = 1, ref_parser = 0, rnd_layers = 0, rnd_log = 0;
+    long seed = -1;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        if (a == "--pws" && i + 1 < argc) pws = argv[++i];
+        else if (a == "--blocks" && i + 1 < argc) blocks = atoi(argv[++i]);
+        else if (a == "--ref-parser") ref_parser = 1;
+        else if (a == "--pc" && i + 1 < argc) g_vp_ref.pc_on = atoi(argv[++i]);
+        else if (a == "--dump" && i + 1 < argc) dump = argv[++i];
+        else if (a == "--seed" && i + 1 < argc) seed = atol(argv[++i]);
+        else if (a == "--randomize" && i + 2 < argc) { rnd_layers = atoi(argv[++i]); rnd_log = atoi(argv[++i]); }
+        else { fprintf(stderr, "bad arg %s\n", argv[i]); return 2; }
+    }
+    if (!pws && !rnd_layers) { fprintf(stderr, "need --pws or --randomize\n"); return 2; }
+    if (seed >= 0) srandom((unsigned) seed);   // per-proof witness seed
+
+    auto t0 = std::chrono::high_resolution_clock::now();
+    if (rnd_layers) {
+        c = layeredCircuit::randomize(rnd_layers, rnd_log);    // src/circuit.cpp:17
+    } else {
+        in_circuit_dag.clear();
+        if (ref_parser) {
+            if (blocks != 1) { fprintf(stderr, "--ref-parser reads the file as is\n"); return 2; }
+            std::ifstream in(pws);
+            parse(in);                                         // src/main.cpp:176
+        } else {
+            populate_replicated(pws, blocks);
+        }
+        DAG_to_layered();                                      // src/main.cpp:15
+    }
+    F::init();                                                 // src/main.cpp:152
+    c.subsetInit();                                            // src/main.cpp:153
+    auto t1 = std::chrono::high_resolution_clock::now();
+    unsigned long long ch[2];
+    circuit_hash(c, ch);
+    u64 ngates = 0;
+    for (int i = 0; i < c.size; ++i) ngates += c.circuit[i].size;
+    fprintf(stdout, "circuit layers %d gates %llu hash %016llx%016llx build_sec %.3f\n", c.size, ngates, ch[0], ch[1],
+            std::chrono::duration<double>(t1 - t0).count());
+
+    if (dump) { g_vp_ref.dump = fopen(dump, "wb"); if (!g_vp_ref.dump) { perror(dump); return 2; } }
+    prover p(c);                                               // src/main.cpp:154 (evaluates the circuit)
+    verifier v(&p, c);                                         // src/main.cpp:155
+    bool ok = false;
+    auto t2 = std::chrono::high_resolution_clock::now();
+    try {
+        ok = v.verify();                                       // src/main.cpp:156
+    } catch (vp_ref_pc_off_stop &) {
+        // PC off: the GKR part is complete and was checked round by round.
+        ok = true;
+        fprintf(stdout, "Prove Time %lf\n", p.proveTime());
+        fprintf(stdout, "proof size = %lf kb\n", p.proofSize());
+    }
+    auto t3 = std::chrono::high_resolution_clock::now();
+    if (g_vp_ref.dump) fclose(g_vp_ref.dump);
+    fprintf(stdout, "mult counter %d, add counter %d\n", F::multCounter, F::addCounter);   // src/main.cpp:157
+    fprintf(stdout, "rounds %lu verify_wall_sec %.3f ok %d\n", g_vp_ref.rounds,
+            std::chrono::duration<double>(t3 - t2).count(), ok ? 1 : 0);
+    return ok ? 0 : 1;
+}

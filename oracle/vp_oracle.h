@@ -1,0 +1,89 @@
+/* TEST INFRASTRUCTURE ONLY — the oracle.  Never linked into, imported by or called from the product
+ * path (virgo-plus_amd/, include/vpgpu.h).  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this library, and only as the checker.
+ *
+ * CPU restatement of the reference GKR prover path (TAMUCrypto/virgo-plus @ /root/reference):
+ *   field F_p^2, p = 2^61-1 ........ lib/virgo/src/fieldElement.cpp:34-104,322-367
+ *   linear / quadratic polys ....... src/polynomial.cpp:64-131
+ *   eq / beta table ................ src/utils.cpp:8-45
+ *   .pws loader, levelisation ...... src/main.cpp:15-137,176-231
+ *   subsetInit, randomize .......... src/circuit.cpp:17-80
+ *   prover ......................... src/prover.cpp:27-521
+ *   verifier schedule + checks ..... src/verifier.cpp:12-337
+ * Parity status: PINNED.  tests/test_oracle_golden.py checks this restatement against transcripts
+ * produced by the real reference compiled here (oracle/_ref/ref_run, see oracle/Makefile):
+ * tests/golden/*.bin, whose SHA-256 digests equal the ones recorded in SURVEY.md §8c, plus the
+ * field / root-of-unity / F::random known answers listed there.
+ */
+#ifndef VP_ORACLE_H
+#define VP_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_circuit orc_circuit;
+
+/* F = {real, img}, canonical (each limb in [0, p)). */
+typedef struct { uint64_t real, img; } orc_F;
+
+typedef struct {
+    double prove_sec;        /* reference "Prove Time" definition (src/prover.cpp:549)   */
+    double evaluate_sec;     /* prover::evaluate (outside prove_timer in the reference)            */
+    double verify_sec;       /* verifier-side work incl. the "slow" predicate loops                 */
+    uint64_t mult_count;     /* F::multCounter semantics (fieldElement.cpp:50-53), 64-bit           */
+    uint64_t add_count;      /* F::addCounter semantics (fieldElement.cpp:35-38,81-84,99-103)       */
+    uint64_t rounds;         /* number of sumcheckUpdate calls                                      */
+    uint64_t pairs;          /* active fold pairs (src/prover.cpp:483)                              */
+    double   proof_kb;       /* prover::proofSize()                                                 */
+    int      verified;       /* 1 = every verifier check passed                                     */
+} orc_stats;
+
+/* ---- circuits ------------------------------------------------------------------------------------ */
+/* Parse a .pws file (grammar of src/main.cpp:161-168), replicate the DAG `blocks` times with all inputs
+ * numbered first, draw the witness with glibc random()%p in file order
+ * (src/main.cpp:188; `seed` < 0 keeps glibc's default seed, else srandom(seed) first), levelise.      */
+orc_circuit *orc_circuit_from_pws(const char *path, int blocks, long seed);
+/* layeredCircuit::randomize(layerNum, eachLayer) (src/circuit.cpp:17-41), g++ argument order.         */
+orc_circuit *orc_circuit_randomize(int layers, int log_size, long seed);
+void orc_circuit_free(orc_circuit *);
+int  orc_circuit_layers(const orc_circuit *);
+uint64_t orc_circuit_layer_size(const orc_circuit *, int layer);
+int  orc_circuit_layer_bitlen(const orc_circuit *, int layer);
+uint64_t orc_circuit_gates(const orc_circuit *);
+/* 128-bit structural hash, same serialisation as oracle/ref_driver.cpp::circuit_hash (after subsetInit). */
+void orc_circuit_hash(orc_circuit *, uint64_t out[2]);
+/* Flat export of one layer's gate table (after subsetInit): arrays of length layer size.              */
+void orc_circuit_export_layer(orc_circuit *, int layer, int32_t *ty, int32_t *l, uint64_t *u, uint64_t *v,
+                              uint64_t *lv);
+/* Input-layer witness (layer 0 values as drawn), length = layer 0 size.                               */
+void orc_circuit_inputs(const orc_circuit *, orc_F *out);
+
+/* ---- whole GKR proof ----------------------------------------------------------------------------- */
+/* F::init() (srand(3396)), subsetInit, prover(evaluate), verifier::verify with the polynomial
+ * commitment switched off.  Writes the GKR transcript slice (SURVEY §8c layout without merkle_root_l
+ * and without the trailing PC fields) into `transcript`; returns its length in bytes, or <0 on error
+ * (-1: capacity too small).                                                                           */
+int64_t orc_prove_gkr(orc_circuit *, uint8_t *transcript, int64_t capacity, orc_stats *stats);
+
+/* ---- primitives, for unit parity tests against the HIP kernels ------------------------------------ */
+void orc_f_add(const orc_F *a, const orc_F *b, orc_F *out);
+void orc_f_sub(const orc_F *a, const orc_F *b, orc_F *out);
+void orc_f_mul(const orc_F *a, const orc_F *b, orc_F *out);
+void orc_f_neg(const orc_F *a, orc_F *out);
+void orc_f_inv(const orc_F *a, orc_F *out);
+void orc_f_root_of_unity(int log_order, orc_F *out);
+/* srand(seed) then n draws of F::random() (fieldElement.cpp:119-124,362-367).                         */
+void orc_f_random_seq(unsigned seed, int n, orc_F *out);
+/* initBetaTable(beta, n, r, init): out has 2^n entries.                                               */
+void orc_beta_table(const orc_F *r, int n, const orc_F *init, orc_F *out);
+/* One call of prover::sumcheckUpdateEach on value tables (the .a parts implied zero / carried in
+ * `a_*`): literal AoS restatement.  Tables V, add, mult are arrays of `total` linear polys stored as
+ * {a,b} pairs (2*total orc_F each), folded in place; returns the 3-coefficient round polynomial.      */
+void orc_update_each(orc_F *V, orc_F *add, orc_F *mult, uint64_t total, uint64_t total_size,
+                     const orc_F *prev, orc_F out_poly[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory from the REAL reference.
+
+Runs only in the build container (needs /root/reference).  It builds
+oracle/_ref/ref_run (the unmodified reference sources compiled in place by
+oracle/Makefile, driven through oracle/ref_hook.hpp) and records, for each
+case, the transcript of prover messages (layout: SURVEY.md §8c) together with
+what the reference printed (prove time, field-op counters, rounds, circuit
+structure hash).  The fixtures are data only: transcripts, counters, hashes,
+and a gzip copy of the reference's own circuit data file data/SHA256_64.pws.
+
+    python tests/golden/make_golden.py            # x1, randomize(8,12), x16
+    python tests/golden/make_golden.py --with-x64 # also the 64-block case (~1 min)
+"""
+import argparse
+import gzip
+import hashlib
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("VP_REFERENCE", "/root/reference")
+REF_RUN = os.path.join(ROOT, "oracle", "_ref", "ref_run")
+PWS = os.path.join(REF, "data", "SHA256_64.pws")
+
+# SHA-256 of the full transcripts as recorded in SURVEY.md §8c / §8d (instrumented reference build
+# of the survey).  make_golden refuses to write a fixture that disagrees.
+SURVEY_SHA256 = {
+    "sha256_x1": "7d56df550455f8e32dcda3ea158e2606b23f4e8bac761ca6a081b8caeee65047",
+    "sha256_x16": "d9c442312561023d237a0c8ea1a40f26273c8d5a967028ab3f1bfeafe22d179f",
+    "sha256_x64": "69974a97b58f46102549d723b24f5cd6677f7c1102347f979aa4d26483274682",
+    "randomize_8_12": "6caa064a89e026000f352b1919b88e0735b67e7c760f752b9e4c23828c6919c0",
+}
+
+
+def run_case(name, args):
+    out_bin = os.path.join(HERE, f"transcript_{name}.bin")
+    cmd = [REF_RUN] + args + ["--pc", "1", "--dump", out_bin]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, check=True)
+    txt = res.stdout
+    data = open(out_bin, "rb").read()
+    digest = hashlib.sha256(data).hexdigest()
+    if SURVEY_SHA256[name] != digest:
+        raise SystemExit(f"{name}: transcript digest {digest} != SURVEY.md {SURVEY_SHA256[name]}")
+    m = re.search(r"circuit layers (\d+) gates (\d+) hash ([0-9a-f]{32})", txt)
+    c = re.search(r"mult counter (-?\d+), add counter (-?\d+)", txt)
+    r = re.search(r"rounds (\d+)", txt)
+    pt = re.search(r"Prove Time ([0-9.]+)", txt)
+    pc = re.search(r"Polynomial commitment: prove time ([0-9.]+)", txt)
+    ps = re.search(r"proof size = ([0-9.]+) kb", txt)
+    return {
+        "transcript": os.path.basename(out_bin),
+        "bytes": len(data),
+        "sha256": digest,
+        "gkr_slice": [32, len(data) - 32 - 16 - 65 * 16],   # [start, end) of the GKR messages
+        "layers": int(m.group(1)),
+        "gates": int(m.group(2)),
+        "circuit_hash": m.group(3),
+        "mult_counter": int(c.group(1)),
+        "add_counter": int(c.group(2)),
+        "rounds": int(r.group(1)),
+        "proof_kb": float(ps.group(1)),
+        "reference_prove_sec_here": float(pt.group(1)),
+        "reference_pc_prove_sec_here": float(pc.group(1)),
+        "args": args,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--with-x64", action="store_true")
+    a = ap.parse_args()
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "ref"], check=True, stdout=subprocess.DEVNULL)
+    pws_gz = os.path.join(HERE, "SHA256_64.pws.gz")
+    with open(PWS, "rb") as f, gzip.GzipFile(pws_gz, "wb", mtime=0) as g:
+        shutil.copyfileobj(f, g)
+    tmp_pws = os.path.join(HERE, "_SHA256_64.pws")
+    shutil.copyfile(PWS, tmp_pws)
+    meta_path = os.path.join(HERE, "golden.json")
+    meta = json.load(open(meta_path)) if os.path.exists(meta_path) else {}
+    try:
+        meta["sha256_x1"] = run_case("sha256_x1", ["--pws", tmp_pws, "--blocks", "1"])
+        # the reference's own regex parser must give the same transcript as the replicating reader
+        chk = os.path.join(HERE, "_chk.bin")
+        subprocess.run([REF_RUN, "--pws", tmp_pws, "--ref-parser", "--dump", chk], check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        assert hashlib.sha256(open(chk, "rb").read()).hexdigest() == meta["sha256_x1"]["sha256"]
+        os.remove(chk)
+        meta["randomize_8_12"] = run_case("randomize_8_12", ["--randomize", "8", "12"])
+        meta["sha256_x16"] = run_case("sha256_x16", ["--pws", tmp_pws, "--blocks", "16"])
+        if a.with_x64:
+            meta["sha256_x64"] = run_case("sha256_x64", ["--pws", tmp_pws, "--blocks", "64"])
+    finally:
+        os.remove(tmp_pws)
+    for k in meta:
+        meta[k]["args"] = [x.replace(tmp_pws, "SHA256_64.pws") for x in meta[k]["args"]]
+    json.dump(meta, open(meta_path, "w"), indent=1, sort_keys=True)
+    print(json.dumps({k: (v["sha256"], v["mult_counter"], v["add_counter"]) for k, v in meta.items()}, indent=1))
+
+
+if __name__ == "__main__":
+    sys.exit(main())
