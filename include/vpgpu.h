@@ -1,0 +1,139 @@
+/* vpgpu.h — C ABI of libvpgpu.so, the MI355X (gfx950) device side of the Virgo++ GKR prover.
+ *
+ * The reference (TAMUCrypto/virgo-plus) has no plugin/FFI layer: its seam is the C++ class `prover`
+ * (src/prover.h:12-66) whose only caller is `verifier` (src/verifier.cpp:24,137,151-152,156,203,206,
+ * 220,242,247,261,289,293,308,379).  This header is the FFI that class would bind if its hot loops
+ * lived on a GPU: one entry point per prover method on the sumcheck path.  The host
+ * mirror of the class that calls these functions is virgo-plus_amd/host/vp_prover.{hpp,cpp}; the
+ * binding a reference maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - C linkage, opaque context, plain pointers and sizes; no C++/torch types.
+ *   - Every function returns VP_OK (0) or a negative VP_E* code; the library never exits the process
+ *     (the reference calls exit(EXIT_FAILURE) on a violated assert gate, src/prover.cpp:18-21,211).
+ *   - A field element F of F_p^2, p = 2^61-1, is two little-endian uint64 {real, img}, canonical
+ *     (each < p), exactly the in-memory layout of virgo::fieldElement (lib/virgo/src/fieldElement.hpp:96-97).
+ *   - All buffers passed in are caller-owned host memory and may be freed after the call returns.
+ *   - One context = one GPU = one proof at a time (the reference prover is not re-entrant either).
+ *     Call order is the reference's state machine (SURVEY.md §8b "Threading").
+ */
+#ifndef VPGPU_H
+#define VPGPU_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vp_ctx vp_ctx;
+typedef struct { uint64_t real, img; } vp_F;
+
+enum {
+    VP_OK = 0,
+    VP_EINVAL = -1,      /* bad argument / call out of order                       */
+    VP_EHIP = -2,        /* HIP runtime error (vp_last_error has the string)        */
+    VP_ENOGPU = -3,      /* no usable gfx950 device                                  */
+    VP_EASSERT = -4,     /* an assert gate evaluated to non-zero (prover.cpp:18-21)  */
+    VP_ELIMIT = -5       /* circuit exceeds a compiled-in limit                      */
+};
+
+/* Gate types, same numbering as enum gateType (src/inputCircuit.hpp:13-15). */
+enum { VP_MUL = 0, VP_ADD, VP_SUB, VP_ANTISUB, VP_NAAB, VP_ANTINAAB, VP_INPUT, VP_MULC, VP_ADDC, VP_XOR, VP_NOT, VP_COPY };
+
+/* One circuit layer, structure-of-arrays view of `class layer` / `class gate` (src/circuit.h:11-35)
+ * after layeredCircuit::subsetInit() (src/circuit.cpp:43-80).  Arrays have `size` entries; `c` and
+ * `is_assert` may be NULL when no gate of the layer uses them.  For layer i the dad* arrays have i
+ * entries; dad_id[j] has dad_size[j] entries.  An empty subset has dad_size[j] == 0 and dad_bitlen[j]
+ * is then ignored (the reference stores (int)log2(0) there).                                           */
+typedef struct {
+    uint64_t size;
+    int32_t bit_length;
+    const uint8_t *ty;          /* gate::ty                                  */
+    const int32_t *l;           /* gate::l  (-1 for unary gates)             */
+    const uint32_t *u;          /* gate::u  (for VP_INPUT gates: ignored)    */
+    const uint32_t *v;          /* gate::v                                   */
+    const uint32_t *lv;         /* gate::lv                                  */
+    const vp_F *c;              /* gate::c  (Addc / Mulc constants) or NULL  */
+    const uint8_t *is_assert;   /* gate::is_assert or NULL                   */
+    const uint64_t *dad_size;   /* layer::dadSize[j],      j < layer index   */
+    const int32_t *dad_bitlen;  /* layer::dadBitLength[j]                    */
+    const uint32_t *const *dad_id; /* layer::dadId[j][k]                     */
+} vp_layer_desc;
+
+/* ---- life cycle ---------------------------------------------------------------------------------- */
+int vp_create(int device, vp_ctx **out);
+void vp_destroy(vp_ctx *);
+const char *vp_last_error(const vp_ctx *);     /* static/ctx-owned string, never NULL */
+const char *vp_version(void);
+
+/* prover::prover(const layeredCircuit&) (src/prover.cpp:14) — the circuit is copied to HBM together
+ * with the per-layer target-sorted gate indices the init kernels use.  May be called again to replace
+ * the circuit.                                                                                         */
+int vp_circuit_upload(vp_ctx *, int n_layers, const vp_layer_desc *layers);
+
+/* prover::evaluate() (src/prover.cpp:27-91).  `inputs` are the layer-0 values (size of layer 0).
+ * Returns VP_EASSERT if an assert gate is non-zero.                                                    */
+int vp_evaluate(vp_ctx *, const vp_F *inputs, uint64_t n_inputs);
+/* Copy circuitValue[layer] back (tests / commit_private hand-off).  n = layer size.                    */
+int vp_layer_values(vp_ctx *, int layer, vp_F *out, uint64_t n);
+
+/* prover::Vres(r_0, r_0_size) (src/prover.cpp:99-129): MLE of the output layer at r_0.                 */
+int vp_vres(vp_ctx *, const vp_F *r_0, int r_0_size, vp_F *out);
+
+/* prover::sumcheckInitPhase1(assert_random) for layer `layer` (src/prover.cpp:189-280).  r_liu is the
+ * point the layer's claim is at (bit_length(layer) entries; prover::r_liu in the reference).           */
+int vp_phase1_init(vp_ctx *, int layer, const vp_F *r_liu, const vp_F *assert_random);
+/* prover::sumcheckInitPhase2() (src/prover.cpp:282-367).  r_u = the bit_length(layer-1) challenges of
+ * phase 1; V_u (set by sumcheckFinalize1) is taken from the device.                                    */
+int vp_phase2_init(vp_ctx *, int layer, const vp_F *r_u);
+/* prover::sumcheckInitLiu(s) (src/prover.cpp:369-420).  r_v[k] (k = layer..n_layers-1) points to the
+ * phase-2 challenges of layer k (at least dad_bitlen[k][layer-1] entries, may be NULL if that subset
+ * is empty); s has n_layers-layer+1 used entries.                                                      */
+int vp_liu_init(vp_ctx *, int layer, const vp_F *r_u, const vp_F *const *r_v, const vp_F *s);
+
+/* prover::sumcheckUpdatePhase1 / Phase2 / sumcheckLiuUpdate (src/prover.cpp:422-492): one sumcheck
+ * round over all live tables of the current phase.  out_poly = {a, b, c} of a*x^2 + b*x + c.
+ * Blocks until the round polynomial is on the host.                                                    */
+int vp_round(vp_ctx *, const vp_F *previous_random, vp_F out_poly[3]);
+
+/* prover::sumcheckFinalize1 / Finalize2 / sumcheckLiuFinalize (src/prover.cpp:494-521).  n_claims is
+ * 1 for phase 1 and Liu, `layer` for phase 2.                                                          */
+int vp_finalize(vp_ctx *, const vp_F *previous_random, vp_F *claims, int n_claims);
+
+/* ---- batched mode -------------------------------------------------------------- */
+/* The reference verifier's randomness does not depend on the transcript (plain random(),
+ * lib/virgo/src/fieldElement.cpp:119-124), so the whole GKR part of verifier::verify()
+ * (src/verifier.cpp:144-169) can run on the device without a host round trip per round.  `tape` holds
+ * the verifier's draws in its own order:
+ *   r_0[bl(out)] | for layer i = n-1..1: r_u[max_bl] assert_random[1] r_v[i][maxDadBl(i)] (if any)
+ *                                        sig[n_layers] r_liu[max_bl]
+ * `transcript` receives the GKR slice of the golden layout: Vres | per layer: phase-1
+ * polys, claim_u, phase-2 polys, claims_v[0..i), Liu polys, vr.  Evaluate must have been called.      */
+int vp_prove_gkr(vp_ctx *, const vp_F *tape, uint64_t n_tape, uint8_t *transcript, uint64_t capacity,
+                 uint64_t *n_written);
+/* Number of tape entries / transcript bytes vp_prove_gkr needs for the uploaded circuit.               */
+int vp_gkr_sizes(vp_ctx *, uint64_t *n_tape, uint64_t *n_transcript_bytes);
+
+/* ---- measurement --------------------------------------------------------------------------------- */
+typedef struct {
+    double gkr_ms;            /* device time of the last vp_prove_gkr (hipEvents on the library stream)     */
+    double evaluate_ms;       /* device time of the last vp_evaluate                                        */
+    double fold_ms;           /* sum of durations of the event-bracketed dominant-kernel launches           */
+    uint64_t fold_launches;   /* how many launches were bracketed                                           */
+    uint64_t fold_bytes;      /* their algorithmic bytes (48*(L_in+L_out) per round)         */
+    uint64_t rounds;          /* sumcheck rounds executed                                                   */
+    uint64_t launches;        /* kernel launches of the last proof                                          */
+} vp_stats;
+int vp_get_stats(vp_ctx *, vp_stats *out);
+/* 0: no per-kernel events (default); 1: bracket the dominant kernel's launches with hipEvents.          */
+int vp_set_profiling(vp_ctx *, int level);
+
+/* ---- primitives exported for parity tests (thin wrappers over the device functions) -------------- */
+/* out[i] = a[i] op b[i], op: 0 add, 1 sub, 2 mul (device arithmetic of fieldElement.cpp:34-104).       */
+int vp_test_field(vp_ctx *, int op, const vp_F *a, const vp_F *b, vp_F *out, uint64_t n);
+/* initBetaTable(out, n, r, init) (src/utils.cpp:29-45): out has 2^n entries.                           */
+int vp_test_beta(vp_ctx *, const vp_F *r, int n, const vp_F *init, vp_F *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

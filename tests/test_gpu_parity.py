@@ -1,0 +1,129 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI (libvpgpu.so via libvphost.so), against the
+oracle on the same seeded inputs and against the golden transcripts of the real reference.
+Bar: bit-exact (all arithmetic is integer mod 2^61-1)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+P = (1 << 61) - 1
+
+
+@pytest.fixture(scope="module")
+def ctx(vp):
+    lib = vp.lib_gpu()
+    h = ctypes.c_void_p()
+    rc = lib.vp_create(0, ctypes.byref(h))
+    assert rc == 0, "vp_create failed: the HIP extension must run on the GPU box"
+    yield h
+    lib.vp_destroy(h)
+
+
+def rand_f(rng, n):
+    a = rng.integers(0, P, size=(n, 2), dtype=np.uint64)
+    edge = np.array([[0, 0], [1, 0], [0, 1], [P - 1, P - 1], [P - 1, 0], [0, P - 1], [1 << 60, (1 << 60) + 5]], dtype=np.uint64)
+    a[: len(edge)] = edge
+    return a
+
+
+@pytest.mark.parametrize("op,name", [(0, "orc_f_add"), (1, "orc_f_sub"), (2, "orc_f_mul")])
+def test_field_ops(vp, ob, ctx, op, name):
+    rng = np.random.default_rng(op + 10)
+    n = 4099
+    a, b = rand_f(rng, n), np.roll(rand_f(rng, n), 3, axis=0)
+    out = np.zeros_like(a)
+    assert vp.lib_gpu().vp_test_field(ctx, op, a.ctypes.data, b.ctypes.data, out.ctypes.data, n) == 0
+    exp = np.zeros_like(a)
+    f = getattr(ob.lib(), name)
+    for i in range(n):
+        f(a[i].ctypes.data, b[i].ctypes.data, exp[i].ctypes.data)
+    assert np.array_equal(out, exp)
+    assert vp.lib_gpu().vp_test_field(ctx, op, a.ctypes.data, b.ctypes.data, out.ctypes.data, 0) == 0   # empty input
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 7, 12, 17])
+def test_beta_table(vp, ob, ctx, n):
+    rng = np.random.default_rng(n)
+    r = rng.integers(0, P, size=(max(n, 1), 2), dtype=np.uint64)
+    for init in (np.array([1, 0], dtype=np.uint64), rng.integers(0, P, size=2, dtype=np.uint64)):
+        out = np.zeros((1 << n, 2), dtype=np.uint64)
+        exp = np.zeros_like(out)
+        assert vp.lib_gpu().vp_test_beta(ctx, r.ctypes.data, n, init.ctypes.data, out.ctypes.data) == 0
+        ob.lib().orc_beta_table(r.ctypes.data, n, init.ctypes.data, exp.ctypes.data)
+        assert np.array_equal(out, exp)
+
+
+def _both_modes(vp, c, gold):
+    s = vp.Session(c)
+    tr, res, ok = s.prove_interactive()
+    assert ok, "host verifier rejected the GPU proof"
+    assert tr == gold, "interactive transcript differs"
+    s.draw_tape()
+    tr2, res2 = s.prove_gkr()
+    assert tr2 == gold, "batched transcript differs"
+    ok2, _ = s.check(tr2)
+    assert ok2
+    tr3, _ = s.prove_gkr()            # idempotent: a second pass over the same resident state
+    assert tr3 == gold
+    s.close()
+    return res, res2
+
+
+@pytest.mark.parametrize("name,blocks", [("sha256_x1", 1), ("sha256_x16", 16)])
+def test_sha256_transcript_matches_reference(vp, golden, gold_gkr, pws_path, name, blocks):
+    c = vp.Circuit.from_pws(pws_path, blocks, seed=1)
+    assert c.hash() == golden[name]["circuit_hash"]
+    res, res2 = _both_modes(vp, c, gold_gkr(name))
+    assert res["rounds"] == golden[name]["rounds"] == res2["rounds"]
+    c.close()
+
+
+def test_randomize_transcript_matches_reference(vp, golden, gold_gkr):
+    c = vp.Circuit.randomize(8, 12, seed=1)
+    _both_modes(vp, c, gold_gkr("randomize_8_12"))
+    c.close()
+
+
+def test_sha256_x64_full_size(vp, golden, gold_gkr, pws_path):
+    """BASELINE.json configs[1]: 64-block SHA-256, sumcheck on the GPU, PC off."""
+    c = vp.Circuit.from_pws(pws_path, 64, seed=1)
+    assert c.hash() == golden["sha256_x64"]["circuit_hash"]
+    s = vp.Session(c)
+    s.draw_tape()
+    tr, res = s.prove_gkr()
+    assert tr == gold_gkr("sha256_x64")
+    assert res["rounds"] == golden["sha256_x64"]["rounds"]
+    ok, _ = s.check(tr, skip_predicates=True)
+    assert ok
+    s.close(); c.close()
+
+
+@pytest.mark.parametrize("layers,log_size,seed", [(2, 0, 1), (2, 1, 2), (3, 1, 3), (3, 2, 4), (4, 3, 5), (5, 4, 6), (6, 5, 7),
+                                                   (9, 2, 8), (12, 3, 9), (3, 9, 10), (4, 13, 11)])
+def test_small_and_ragged_circuits_vs_oracle(vp, ob, layers, log_size, seed):
+    """Edge cases: single-entry tables, empty subsets, tables that retire into add_term early,
+    zero-round phases (SURVEY.md §7 'loader quirks')."""
+    c = vp.Circuit.randomize(layers, log_size, seed=seed)
+    oc = ob.Circuit.randomize(layers, log_size, seed=seed)
+    assert c.hash() == oc.hash()
+    gold, st = oc.prove_gkr()
+    assert st["verified"] == 1
+    _both_modes(vp, c, gold)
+    c.close(); oc.close()
+
+
+def test_evaluate_matches_oracle_outputs(vp, ob, pws_path):
+    """circuitValue of the output layer feeds Vres: first 16 transcript bytes; also inputs round-trip."""
+    c = vp.Circuit.from_pws(pws_path, 2, seed=5)
+    oc = ob.Circuit.from_pws(pws_path, 2, seed=5)
+    s = vp.Session(c)
+    vals = s.layer_values(0)
+    exp = np.zeros((oc.layer_size(0), 2), dtype=np.uint64)
+    ob.lib().orc_circuit_inputs(oc.h, exp.ctypes.data)
+    assert np.array_equal(vals, exp)
+    gold, _ = oc.prove_gkr()
+    s.draw_tape()
+    tr, _ = s.prove_gkr()
+    assert tr == gold
+    s.close(); c.close(); oc.close()

@@ -1,0 +1,113 @@
+"""CPU: the oracle (oracle/vp_oracle.cpp) against the fixtures made from the REAL reference
+(tests/golden/make_golden.py) and the known answers recorded in SURVEY.md §8c."""
+import ctypes
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+P = (1 << 61) - 1
+SURVEY_SHA256 = {
+    "sha256_x1": "7d56df550455f8e32dcda3ea158e2606b23f4e8bac761ca6a081b8caeee65047",
+    "sha256_x16": "d9c442312561023d237a0c8ea1a40f26273c8d5a967028ab3f1bfeafe22d179f",
+    "sha256_x64": "69974a97b58f46102549d723b24f5cd6677f7c1102347f979aa4d26483274682",
+    "randomize_8_12": "6caa064a89e026000f352b1919b88e0735b67e7c760f752b9e4c23828c6919c0",
+}
+
+
+def F(re, im):
+    return np.array([re, im], dtype=np.uint64)
+
+
+def call2(ob, fn, a, b):
+    out = np.zeros(2, dtype=np.uint64)
+    getattr(ob.lib(), fn)(a.ctypes.data, b.ctypes.data, out.ctypes.data)
+    return tuple(int(x) for x in out)
+
+
+def call1(ob, fn, a):
+    out = np.zeros(2, dtype=np.uint64)
+    getattr(ob.lib(), fn)(a.ctypes.data, out.ctypes.data)
+    return tuple(int(x) for x in out)
+
+
+def test_fixture_digests_match_survey(golden):
+    from conftest import GOLDEN
+    for name, g in golden.items():
+        data = open(os.path.join(GOLDEN, g["transcript"]), "rb").read()
+        assert hashlib.sha256(data).hexdigest() == SURVEY_SHA256[name] == g["sha256"]
+        assert len(data) == g["bytes"]
+
+
+def test_field_known_answers(ob):
+    # values captured from the compiled reference, SURVEY.md §8c
+    a = F(1234567890123456789, 987654321987654321)
+    b = F(P - 1, 1)
+    assert call2(ob, "orc_f_mul", a, b) == (83620797102582841, 246913568135802468)
+    assert call2(ob, "orc_f_mul", a, a) == (2249395553658566880, 1358570223080517404)
+    assert call1(ob, "orc_f_inv", a) == (665622733565594987, 969236709710989493)
+    assert call1(ob, "orc_f_neg", a) == (1071275119090237162, 1318188687226039630)
+    assert call1(ob, "orc_f_inv", F(2, 0)) == (1152921504606846976, 0)
+
+
+def test_roots_of_unity(ob):
+    exp = {1: (P - 1, 0), 2: (0, P - 1), 3: (1073741824, 2305843008139952127),
+           10: (1311084444718765561, 829995604607609521), 22: (1662087499102352953, 1029856169172585086)}
+    for k, v in exp.items():
+        out = np.zeros(2, dtype=np.uint64)
+        ob.lib().orc_f_root_of_unity(k, out.ctypes.data)
+        assert tuple(int(x) for x in out) == v
+
+
+def test_verifier_random_stream(ob):
+    out = np.zeros((3, 2), dtype=np.uint64)
+    ob.lib().orc_f_random_seq(3396, 3, out.ctypes.data)
+    assert [tuple(int(x) for x in r) for r in out] == [
+        (69318801402563806, 1662776802730791352), (1980605035210677997, 152700460719136691),
+        (1923425296405918794, 2135854949068199597)]
+
+
+def test_field_against_python_bigint(ob):
+    rng = np.random.default_rng(1)
+    edge = [0, 1, 2, P - 1, P - 2, (1 << 60), (1 << 32) - 1, 1 << 32]
+    vals = [(int(x), int(y)) for x in edge for y in edge[:4]]
+    vals += [(int(rng.integers(0, P)), int(rng.integers(0, P))) for _ in range(200)]
+    for (a0, a1), (b0, b1) in zip(vals, vals[7:] + vals[:7]):
+        a, b = F(a0, a1), F(b0, b1)
+        assert call2(ob, "orc_f_mul", a, b) == ((a0 * b0 - a1 * b1) % P, (a0 * b1 + a1 * b0) % P)
+        assert call2(ob, "orc_f_add", a, b) == ((a0 + b0) % P, (a1 + b1) % P)
+        assert call2(ob, "orc_f_sub", a, b) == ((a0 - b0) % P, (a1 - b1) % P)
+
+
+def test_first_messages_x1(gold_gkr):
+    # Vres and the first round polynomial of the single-block proof
+    t = np.frombuffer(gold_gkr("sha256_x1"), dtype=np.uint64)
+    assert tuple(int(x) for x in t[0:2]) == (724662900143931110, 476060367020167324)
+    assert tuple(int(x) for x in t[2:8]) == (2211877472072237705, 669034324121346583, 1128696917772413940,
+                                              606831994937767933, 2150808768970180659, 1905940033194220355)
+
+
+@pytest.mark.parametrize("name,blocks", [("sha256_x1", 1), ("sha256_x16", 16), ("sha256_x64", 64)])
+def test_oracle_transcript_sha256(ob, golden, gold_gkr, pws_path, name, blocks):
+    c = ob.Circuit.from_pws(pws_path, blocks, seed=1)       # glibc's default seed is 1
+    g = golden[name]
+    assert c.layers == g["layers"] and c.gates == g["gates"]
+    assert c.hash() == g["circuit_hash"]
+    tr, st = c.prove_gkr()
+    assert st["verified"] == 1
+    assert tr == gold_gkr(name)
+    assert st["mult_count"] == g["mult_counter"] and st["add_count"] == g["add_counter"]
+    assert st["rounds"] == g["rounds"]
+    assert abs(st["proof_kb"] - g["proof_kb"]) < 1e-9
+    c.close()
+
+
+def test_oracle_transcript_randomize(ob, golden, gold_gkr):
+    c = ob.Circuit.randomize(8, 12, seed=1)
+    g = golden["randomize_8_12"]
+    assert c.hash() == g["circuit_hash"]
+    tr, st = c.prove_gkr()
+    assert st["verified"] == 1 and tr == gold_gkr("randomize_8_12")
+    assert (st["mult_count"], st["add_count"], st["rounds"]) == (g["mult_counter"], g["add_counter"], g["rounds"])
+    c.close()

@@ -1,0 +1,249 @@
+"""virgo-plus_amd — MI355X-native GKR sumcheck prover (Virgo++), Python harness side.
+
+The product is native: ``csrc/`` (HIP kernels + the C ABI of include/vpgpu.h -> libvpgpu.so) and
+``host/`` (C++ mirror of the reference's prover / verifier / circuit-loader API -> libvphost.so and the
+``virgo_plus_run`` CLI).  This module only builds those in-tree and exposes them through ctypes for
+tests/ and bench.py.  There is no CPU fallback: creating a Session without a working gfx950 device and
+the built libraries raises.
+
+The directory name contains a hyphen; load it with ``load()`` from the repo root's ``vp_loader.py`` or
+importlib (see tests/conftest.py).
+"""
+import ctypes
+import os
+import shutil
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG_DIR)
+CSRC = os.path.join(PKG_DIR, "csrc")
+HOST = os.path.join(PKG_DIR, "host")
+LIB_GPU = os.path.join(CSRC, "libvpgpu.so")
+LIB_HOST = os.path.join(HOST, "libvphost.so")
+CLI = os.path.join(HOST, "virgo_plus_run")
+
+GPU_SRC = [os.path.join(CSRC, f) for f in ("vpgpu.hip", "vp_kernels.h", "vp_field.h")] + [
+    os.path.join(ROOT, "include", "vpgpu.h")]
+HOST_SRC = [os.path.join(HOST, f) for f in ("circuit.cpp", "prover.cpp", "verifier.cpp", "vphost.cpp")]
+HOST_HDR = [os.path.join(HOST, f) for f in ("circuit.hpp", "prover.hpp", "verifier.hpp", "vphost.h", "field.hpp",
+                                              "polynomial.hpp")]
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources if os.path.exists(s))
+
+
+def _hipcc():
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    return None
+
+
+def build(force=False, verbose=False):
+    """Compile libvpgpu.so (hipcc, gfx950), libvphost.so and virgo_plus_run (g++) in-tree."""
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    if force or _stale(LIB_GPU, GPU_SRC):
+        hipcc = _hipcc()
+        if hipcc is None:
+            if os.path.exists(LIB_GPU):
+                return  # prebuilt library travelled with the tree (GPU box without a toolchain)
+            raise RuntimeError("hipcc not found and no prebuilt libvpgpu.so")
+        run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+             "-o", LIB_GPU, os.path.join(CSRC, "vpgpu.hip")])
+    if force or _stale(LIB_HOST, HOST_SRC + HOST_HDR + [LIB_GPU]):
+        run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-o", LIB_HOST] + HOST_SRC +
+            ["-L" + CSRC, "-lvpgpu", "-Wl,-rpath,$ORIGIN/../csrc", "-Wl,-rpath,/opt/rocm/lib"])
+    if force or _stale(CLI, [os.path.join(HOST, "virgo_plus_run.cpp"), LIB_HOST]):
+        run(["g++", "-std=c++17", "-O2", "-Wall", "-o", CLI, os.path.join(HOST, "virgo_plus_run.cpp"),
+             "-L" + HOST, "-lvphost", "-L" + CSRC, "-lvpgpu", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/../csrc",
+             "-Wl,-rpath,/opt/rocm/lib"])
+
+
+class VphResult(ctypes.Structure):
+    _fields_ = [("prove_sec", ctypes.c_double), ("gkr_device_ms", ctypes.c_double), ("evaluate_ms", ctypes.c_double),
+                ("verify_sec", ctypes.c_double), ("fold_ms", ctypes.c_double), ("fold_launches", ctypes.c_uint64),
+                ("fold_bytes", ctypes.c_uint64), ("rounds", ctypes.c_uint64), ("launches", ctypes.c_uint64),
+                ("proof_kb", ctypes.c_double), ("verified", ctypes.c_int)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_gpu = None
+_host = None
+
+
+def lib_gpu():
+    """ctypes handle of libvpgpu.so (raises if it is not built)."""
+    global _gpu
+    if _gpu is None:
+        if not os.path.exists(LIB_GPU):
+            raise RuntimeError("libvpgpu.so is not built: run __graft_entry__.build()")
+        L = ctypes.CDLL(LIB_GPU, mode=ctypes.RTLD_GLOBAL)
+        vp = ctypes.c_void_p
+        L.vp_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+        L.vp_destroy.argtypes = [vp]
+        L.vp_last_error.argtypes = [vp]
+        L.vp_last_error.restype = ctypes.c_char_p
+        L.vp_version.restype = ctypes.c_char_p
+        L.vp_test_field.argtypes = [vp, ctypes.c_int, vp, vp, vp, ctypes.c_uint64]
+        L.vp_test_beta.argtypes = [vp, vp, ctypes.c_int, vp, vp]
+        _gpu = L
+    return _gpu
+
+
+def lib_host():
+    """ctypes handle of libvphost.so (raises if it is not built)."""
+    global _host
+    if _host is None:
+        lib_gpu()
+        if not os.path.exists(LIB_HOST):
+            raise RuntimeError("libvphost.so is not built: run __graft_entry__.build()")
+        L = ctypes.CDLL(LIB_HOST)
+        vp = ctypes.c_void_p
+        u64 = ctypes.c_uint64
+        L.vph_circuit_from_pws.restype = vp
+        L.vph_circuit_from_pws.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_long, ctypes.c_char_p, ctypes.c_int]
+        L.vph_circuit_randomize.restype = vp
+        L.vph_circuit_randomize.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_long]
+        L.vph_circuit_free.argtypes = [vp]
+        L.vph_circuit_layers.argtypes = [vp]
+        L.vph_circuit_gates.restype = u64
+        L.vph_circuit_gates.argtypes = [vp]
+        L.vph_circuit_layer_size.restype = u64
+        L.vph_circuit_layer_size.argtypes = [vp, ctypes.c_int]
+        L.vph_circuit_layer_bitlen.argtypes = [vp, ctypes.c_int]
+        L.vph_circuit_hash.argtypes = [vp, ctypes.POINTER(u64)]
+        L.vph_session_create.restype = vp
+        L.vph_session_create.argtypes = [vp, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
+        L.vph_session_free.argtypes = [vp]
+        L.vph_set_profiling.argtypes = [vp, ctypes.c_int]
+        L.vph_layer_values.argtypes = [vp, ctypes.c_int, vp, u64]
+        L.vph_prove_interactive.argtypes = [vp, vp, u64, ctypes.POINTER(u64), ctypes.POINTER(VphResult), ctypes.c_char_p,
+                                            ctypes.c_int]
+        L.vph_draw_tape.argtypes = [vp]
+        L.vph_prove_gkr.argtypes = [vp, vp, u64, ctypes.POINTER(u64), ctypes.POINTER(VphResult), ctypes.c_char_p, ctypes.c_int]
+        L.vph_check.argtypes = [vp, vp, u64, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+        L.vph_verify_transcript.argtypes = [vp, vp, u64, ctypes.c_int]
+        L.vph_transcript_bytes.restype = u64
+        L.vph_transcript_bytes.argtypes = [vp]
+        _host = L
+    return _host
+
+
+class Circuit:
+    """layeredCircuit after subsetInit (host/circuit.hpp)."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise RuntimeError("circuit construction failed")
+        self.h = handle
+
+    @classmethod
+    def from_pws(cls, path, blocks=1, seed=-1):
+        err = ctypes.create_string_buffer(256)
+        h = lib_host().vph_circuit_from_pws(os.fsencode(path), blocks, seed, err, len(err))
+        if not h:
+            raise RuntimeError("from_pws: " + err.value.decode())
+        return cls(h)
+
+    @classmethod
+    def randomize(cls, layers, log_size, seed=-1):
+        return cls(lib_host().vph_circuit_randomize(layers, log_size, seed))
+
+    @property
+    def layers(self):
+        return lib_host().vph_circuit_layers(self.h)
+
+    @property
+    def gates(self):
+        return lib_host().vph_circuit_gates(self.h)
+
+    def layer_size(self, i):
+        return lib_host().vph_circuit_layer_size(self.h, i)
+
+    def layer_bitlen(self, i):
+        return lib_host().vph_circuit_layer_bitlen(self.h, i)
+
+    def hash(self):
+        out = (ctypes.c_uint64 * 2)()
+        lib_host().vph_circuit_hash(self.h, out)
+        return "%016x%016x" % (out[0], out[1])
+
+    def verify_transcript(self, transcript, skip_predicates=False):
+        """Host verifier replay (no GPU): F::init(), draw the tape, check the GKR transcript."""
+        buf = ctypes.create_string_buffer(bytes(transcript), len(transcript))
+        return lib_host().vph_verify_transcript(self.h, ctypes.cast(buf, ctypes.c_void_p), len(transcript),
+                                                1 if skip_predicates else 0) == 0
+
+    def close(self):
+        if self.h:
+            lib_host().vph_circuit_free(self.h)
+            self.h = None
+
+
+class Session:
+    """One prover on one GPU: circuit resident in HBM, witness evaluated on the device."""
+
+    def __init__(self, circuit, device=0):
+        err = ctypes.create_string_buffer(512)
+        self.circuit = circuit
+        self.h = lib_host().vph_session_create(circuit.h, device, err, len(err))
+        if not self.h:
+            raise RuntimeError("Session: " + err.value.decode())
+        self._cap = int(lib_host().vph_transcript_bytes(self.h)) + 4096
+        self._buf = ctypes.create_string_buffer(self._cap)
+
+    def set_profiling(self, level):
+        lib_host().vph_set_profiling(self.h, level)
+
+    def layer_values(self, layer):
+        import numpy as np
+        n = self.circuit.layer_size(layer)
+        out = np.zeros((n, 2), dtype=np.uint64)
+        rc = lib_host().vph_layer_values(self.h, layer, out.ctypes.data, n)
+        if rc:
+            raise RuntimeError("layer_values failed")
+        return out
+
+    def _call(self, fn):
+        n = ctypes.c_uint64(0)
+        res = VphResult()
+        err = ctypes.create_string_buffer(512)
+        rc = fn(self.h, ctypes.cast(self._buf, ctypes.c_void_p), self._cap, ctypes.byref(n), ctypes.byref(res), err, len(err))
+        if rc < 0:
+            raise RuntimeError("prover failed: " + err.value.decode())
+        return self._buf.raw[: n.value], res.as_dict(), rc
+
+    def prove_interactive(self):
+        """F::init() + verifier::verify(): returns (transcript bytes, stats, verified)."""
+        tr, res, rc = self._call(lib_host().vph_prove_interactive)
+        return tr, res, rc == 0
+
+    def draw_tape(self):
+        lib_host().vph_draw_tape(self.h)
+
+    def prove_gkr(self):
+        """One batched device pass from the attached tape: returns (transcript bytes, stats)."""
+        tr, res, _ = self._call(lib_host().vph_prove_gkr)
+        return tr, res
+
+    def check(self, transcript, skip_predicates=False):
+        sec = ctypes.c_double(0)
+        buf = ctypes.create_string_buffer(bytes(transcript), len(transcript))
+        rc = lib_host().vph_check(self.h, ctypes.cast(buf, ctypes.c_void_p), len(transcript), 1 if skip_predicates else 0,
+                                  ctypes.byref(sec))
+        return rc == 0, sec.value
+
+    def close(self):
+        if self.h:
+            lib_host().vph_session_free(self.h)
+            self.h = None

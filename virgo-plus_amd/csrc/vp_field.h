@@ -1,0 +1,63 @@
+// Device/host arithmetic in F = F_p[i]/(i^2+1), p = 2^61-1.
+//
+// Value semantics follow lib/virgo/src/fieldElement.cpp:34-104 of the reference (canonical limbs in
+// [0,p), i^2 = -1), but the computation is laid out for CDNA4: there is no 64x64 multiplier on gfx950,
+// a 64x64->128 product is four v_mad_u64_u32; the three Karatsuba products of an F-multiply are kept
+// as unreduced 128-bit values and only the two output limbs are folded (2^61 == 1 mod p), instead of
+// the reference's reduce-after-every-step sequence.  Results are bit-identical because every output
+// is the canonical representative.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define VP_HD __host__ __device__ __forceinline__
+#else
+#define VP_HD inline
+#endif
+
+namespace vp {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+typedef unsigned __int128 u128;
+
+constexpr u64 P61 = 2305843009213693951ull;
+
+struct alignas(16) F {
+    u64 re, im;
+};
+
+VP_HD F f_make(u64 re, u64 im) { F r; r.re = re; r.im = im; return r; }
+VP_HD F f_zero() { return f_make(0, 0); }
+VP_HD F f_one() { return f_make(1, 0); }
+VP_HD bool f_eq(const F &a, const F &b) { return a.re == b.re && a.im == b.im; }
+VP_HD bool f_is_zero(const F &a) { return (a.re | a.im) == 0; }
+
+VP_HD u64 m_add(u64 a, u64 b) { u64 s = a + b; return s >= P61 ? s - P61 : s; }
+VP_HD u64 m_sub(u64 a, u64 b) { return a >= b ? a - b : a + P61 - b; }
+// x < 2^125 -> canonical
+VP_HD u64 m_red128(u128 x) {
+    u64 lo = (u64) x & P61;
+    u64 hi = (u64) (x >> 61);
+    u64 s = lo + (hi & P61) + (hi >> 61);
+    s = (s & P61) + (s >> 61);
+    return s >= P61 ? s - P61 : s;
+}
+VP_HD u64 m_mul(u64 a, u64 b) { return m_red128((u128) a * b); }
+
+VP_HD F f_add(const F &a, const F &b) { return f_make(m_add(a.re, b.re), m_add(a.im, b.im)); }
+VP_HD F f_sub(const F &a, const F &b) { return f_make(m_sub(a.re, b.re), m_sub(a.im, b.im)); }
+VP_HD F f_neg(const F &a) { return f_make(a.re ? P61 - a.re : 0, a.im ? P61 - a.im : 0); }
+VP_HD F f_dbl(const F &a) { return f_add(a, a); }
+
+VP_HD F f_mul(const F &a, const F &b) {
+    const u128 C = ((u128) P61) << 61;           // multiple of p, >= any product of two canonical limbs
+    u128 ac = (u128) a.re * b.re;
+    u128 bd = (u128) a.im * b.im;
+    u128 cr = (u128) (a.re + a.im) * (b.re + b.im);
+    return f_make(m_red128(ac + C - bd), m_red128(cr + C + C - ac - bd));
+}
+// a + r*(b - a): one fold step of a bookkeeping table (src/prover.cpp:483 eval + interpolate)
+VP_HD F f_lerp(const F &a, const F &b, const F &r) { return f_add(a, f_mul(r, f_sub(b, a))); }
+
+}  // namespace vp

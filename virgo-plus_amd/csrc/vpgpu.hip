@@ -1,0 +1,766 @@
+// libvpgpu.so — host side of the C ABI in include/vpgpu.h: HBM residency of the circuit, the
+// bookkeeping tables and the verifier tape, and the launch sequence of the GKR sumcheck kernels
+// (vp_kernels.h) on one HIP stream.  gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/vpgpu.h"
+#include "vp_kernels.h"
+
+using namespace vp;
+
+static_assert(sizeof(vp_F) == sizeof(F), "vp_F layout");
+
+namespace {
+
+struct Csr {                 // contributions of one layer sorted by target row (see vp_kernels.h K2/K3)
+    u32 n_rows = 0, n_entries = 0, n_heavy = 0, n_chunks = 0;
+    u32 *rowptr = nullptr, *e_g = nullptr, *e_x = nullptr;
+    uint16_t *e_tl = nullptr;
+    u32 *heavy_row = nullptr, *heavy_cptr = nullptr, *chunk_beg = nullptr, *chunk_end = nullptr;
+};
+
+struct LayerDev {
+    u64 size = 0;
+    int bl = 0;
+    F *val = nullptr;                       // circuitValue[i]
+    uint8_t *ty = nullptr; int16_t *gl = nullptr; u32 *gu = nullptr, *gv = nullptr;
+    F *gc = nullptr;
+    u32 n_assert = 0; u32 *assert_idx = nullptr;
+    std::vector<u64> dad_size; std::vector<int> dad_bl; std::vector<u32 *> dad_id;   // j < layer index
+    int max_dad_bl = -1;
+    std::vector<u32> t_off, t_len;          // phase-2 table layout (slots)
+    u32 p2_total = 0;
+    u32 n_gather = 0; u32 *g_slot = nullptr, *g_idx = nullptr; uint8_t *g_layer = nullptr;
+    Csr c1, c2;
+    // Liu: jobs for the layer whose claims are combined on layer (this-1)
+    u32 n_jobs = 0; BetaJob *jobs = nullptr; std::vector<int> job_k, job_h1;
+};
+
+struct SumcheckState {
+    int phase = 0, layer = 0, n_tab = 0, round = 0, total_rounds = 0, has_a = 1;
+    u32 off[VP_MAX_TAB], len0[VP_MAX_TAB], valid0[VP_MAX_TAB];
+    int bl[VP_MAX_TAB];
+    const F *V0 = nullptr, *M0 = nullptr, *A0 = nullptr;     // round-1 sources
+};
+
+struct EvPair { hipEvent_t a, b; u64 bytes; };
+
+}  // namespace
+
+struct vp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err = "";
+    int n_layers = 0, max_bl = 0;
+    std::vector<LayerDev> L;
+    F **d_vals = nullptr;
+    F *beta_g = nullptr, *beta_u = nullptr, *bf = nullptr, *bs = nullptr, *liu_half = nullptr;
+    u32 half_cap = 0;
+    F *tab[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    u32 cap = 0;
+    F *partials = nullptr;
+    F *small = nullptr;          // [0]=0 [1]=1 [2]=add_term [3]=V_u [4..27]=coef [32..95]=scalarV [96..]=chunk partials ptr elsewhere
+    F *chunk_part = nullptr; u32 chunk_cap = 0;
+    F *d_tape = nullptr; u64 n_tape = 0;
+    F *d_tr = nullptr; u64 n_tr = 0;      // transcript in F units
+    F *h_pin = nullptr;                   // pinned: [0..2] poly, [3] vres, [4..4+64) claims
+    int *d_flag = nullptr;
+    bool evaluated = false;
+    SumcheckState sc;
+    // tape / transcript layout
+    std::vector<u64> ru_off, as_off, rv_off, sig_off, rliu_off;
+    // stats
+    int profiling = 0;
+    vp_stats st{};
+    std::vector<EvPair> ev_pool; size_t ev_used = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<void *> allocs;
+
+    F *zero() const { return small; }
+    F *one() const { return small + 1; }
+    F *add_term() const { return small + 2; }
+    F *Vu() const { return small + 3; }
+    F *coef() const { return small + 4; }
+    F *scalarV() const { return small + 32; }
+};
+
+namespace {
+
+#define HIPCHK(x)                                                                                   \
+    do {                                                                                            \
+        hipError_t e_ = (x);                                                                        \
+        if (e_ != hipSuccess) {                                                                     \
+            ctx->err = std::string(#x) + ": " + hipGetErrorString(e_);                              \
+            return VP_EHIP;                                                                         \
+        }                                                                                           \
+    } while (0)
+#define VPCHK(x) do { int r_ = (x); if (r_ != VP_OK) return r_; } while (0)
+
+constexpr u32 MAX_BLOCKS = 2048;     // 256 CUs x 8 resident 256-thread blocks
+
+template <class T>
+int dalloc(vp_ctx *ctx, T **p, size_t n) {
+    *p = nullptr;
+    if (n == 0) n = 1;
+    HIPCHK(hipMalloc((void **) p, n * sizeof(T)));
+    ctx->allocs.push_back((void *) *p);
+    return VP_OK;
+}
+template <class T>
+int dupload(vp_ctx *ctx, T **p, const std::vector<T> &h) {
+    VPCHK(dalloc(ctx, p, h.size()));
+    if (!h.empty()) HIPCHK(hipMemcpy(*p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return VP_OK;
+}
+void free_all(vp_ctx *ctx) {
+    for (void *p : ctx->allocs) (void) hipFree(p);
+    ctx->allocs.clear();
+}
+
+inline u32 nblk(u64 n) { return (u32) ((n + VP_BLOCK - 1) / VP_BLOCK); }
+inline u32 grid_for(u64 n) { return std::max<u32>(1, std::min<u32>(nblk(n), MAX_BLOCKS)); }
+inline int ceil_log2(u64 x) { int b = 0; while ((1ull << b) < x) ++b; return b; }
+inline bool is_unary(int ty) { return ty == VP_ADDC || ty == VP_MULC || ty == VP_COPY || ty == VP_NOT; }
+
+// Build a target-sorted contribution list (counting sort, stable in gate order).
+int build_csr(vp_ctx *ctx, Csr &c, u32 n_rows, const std::vector<u32> &key, const std::vector<u32> &eg,
+              const std::vector<u32> &ex, const std::vector<uint16_t> &etl) {
+    const u32 n = (u32) key.size();
+    std::vector<u32> rowptr(n_rows + 1, 0);
+    for (u32 i = 0; i < n; ++i) ++rowptr[key[i] + 1];
+    for (u32 r = 0; r < n_rows; ++r) rowptr[r + 1] += rowptr[r];
+    std::vector<u32> pos(rowptr.begin(), rowptr.end() - 1), sg(n), sx(n);
+    std::vector<uint16_t> stl(n);
+    for (u32 i = 0; i < n; ++i) { u32 p = pos[key[i]]++; sg[p] = eg[i]; sx[p] = ex[i]; stl[p] = etl[i]; }
+    std::vector<u32> heavy_row, heavy_cptr(1, 0), cb, ce;
+    for (u32 r = 0; r < n_rows; ++r) {
+        u32 b = rowptr[r], e = rowptr[r + 1];
+        if (e - b <= VP_LIGHT_MAX) continue;
+        heavy_row.push_back(r);
+        for (u32 s = b; s < e; s += VP_CHUNK) { cb.push_back(s); ce.push_back(std::min(e, s + VP_CHUNK)); }
+        heavy_cptr.push_back((u32) cb.size());
+    }
+    c.n_rows = n_rows; c.n_entries = n; c.n_heavy = (u32) heavy_row.size(); c.n_chunks = (u32) cb.size();
+    VPCHK(dupload(ctx, &c.rowptr, rowptr));
+    VPCHK(dupload(ctx, &c.e_g, sg));
+    VPCHK(dupload(ctx, &c.e_x, sx));
+    VPCHK(dupload(ctx, &c.e_tl, stl));
+    VPCHK(dupload(ctx, &c.heavy_row, heavy_row));
+    VPCHK(dupload(ctx, &c.heavy_cptr, heavy_cptr));
+    VPCHK(dupload(ctx, &c.chunk_beg, cb));
+    VPCHK(dupload(ctx, &c.chunk_end, ce));
+    ctx->chunk_cap = std::max(ctx->chunk_cap, c.n_chunks);
+    return VP_OK;
+}
+
+void count_launch(vp_ctx *ctx) { ++ctx->st.launches; }
+
+// ---- internal phase drivers (all arguments already on the device tape) -----------------------------
+int run_beta_half(vp_ctx *ctx, const F *r, int n, const F *init) {
+    hipLaunchKernelGGL(k_beta_half, dim3(1), dim3(VP_BLOCK), 0, ctx->stream, r, n, init, ctx->bf, ctx->bs);
+    count_launch(ctx);
+    return VP_OK;
+}
+
+template <int PHASE>
+int run_init_rows(vp_ctx *ctx, const Csr &c, InitArgs &a) {
+    a.rowptr = c.rowptr; a.e_g = c.e_g; a.e_x = c.e_x; a.e_tl = c.e_tl; a.n_rows = c.n_rows;
+    if (c.n_rows) {
+        hipLaunchKernelGGL(k_init_light<PHASE>, dim3(nblk(c.n_rows)), dim3(VP_BLOCK), 0, ctx->stream, a);
+        count_launch(ctx);
+    }
+    if (c.n_chunks) {
+        hipLaunchKernelGGL(k_init_chunks<PHASE>, dim3((c.n_chunks + 3) / 4), dim3(VP_BLOCK), 0, ctx->stream, a,
+                           c.chunk_beg, c.chunk_end, c.n_chunks, ctx->chunk_part);
+        hipLaunchKernelGGL(k_init_combine, dim3((c.n_heavy + 3) / 4), dim3(VP_BLOCK), 0, ctx->stream, c.heavy_row,
+                           c.heavy_cptr, c.n_heavy, ctx->chunk_part, a.M, a.A);
+        count_launch(ctx); count_launch(ctx);
+    }
+    return VP_OK;
+}
+
+int do_phase1_init(vp_ctx *ctx, int i, const F *d_rliu, const F *d_assert) {
+    LayerDev &cur = ctx->L[i], &pre = ctx->L[i - 1];
+    VPCHK(run_beta_half(ctx, d_rliu, cur.bl, ctx->one()));
+    hipLaunchKernelGGL(k_beta_expand, dim3(grid_for(cur.size)), dim3(VP_BLOCK), 0, ctx->stream, ctx->bf, ctx->bs,
+                       cur.bl >> 1, (u32) cur.size, ctx->beta_g);
+    count_launch(ctx);
+    if (cur.n_assert) {
+        hipLaunchKernelGGL(k_scale_entries, dim3(nblk(cur.n_assert)), dim3(VP_BLOCK), 0, ctx->stream, ctx->beta_g,
+                           cur.assert_idx, cur.n_assert, d_assert);
+        count_launch(ctx);
+    }
+    InitArgs a{};
+    a.beta_g = ctx->beta_g; a.beta_u = nullptr; a.vals = ctx->d_vals; a.gc = cur.gc; a.coef = nullptr;
+    a.M = ctx->tab[0][1]; a.A = ctx->tab[0][2];
+    VPCHK(run_init_rows<1>(ctx, cur.c1, a));
+    SumcheckState &s = ctx->sc;
+    s.phase = 1; s.layer = i; s.n_tab = 1; s.round = 0; s.total_rounds = pre.bl; s.has_a = 1;
+    s.off[0] = 0; s.len0[0] = 1u << pre.bl; s.valid0[0] = (u32) pre.size; s.bl[0] = pre.bl;
+    s.V0 = pre.val; s.M0 = ctx->tab[0][1]; s.A0 = ctx->tab[0][2];
+    return VP_OK;
+}
+
+int do_phase2_init(vp_ctx *ctx, int i, const F *d_ru) {
+    LayerDev &cur = ctx->L[i], &pre = ctx->L[i - 1];
+    VPCHK(run_beta_half(ctx, d_ru, pre.bl, ctx->one()));
+    hipLaunchKernelGGL(k_beta_expand, dim3(grid_for(pre.size)), dim3(VP_BLOCK), 0, ctx->stream, ctx->bf, ctx->bs,
+                       pre.bl >> 1, (u32) pre.size, ctx->beta_u);
+    hipLaunchKernelGGL(k_p2_coef, dim3(1), dim3(64), 0, ctx->stream, ctx->Vu(), ctx->coef());
+    hipLaunchKernelGGL(k_zero_f, dim3(1), dim3(64), 0, ctx->stream, ctx->add_term(), 1u);
+    count_launch(ctx); count_launch(ctx); count_launch(ctx);
+    if (cur.n_gather) {
+        hipLaunchKernelGGL(k_p2_gather_v, dim3(nblk(cur.n_gather)), dim3(VP_BLOCK), 0, ctx->stream, cur.g_slot,
+                           cur.g_layer, cur.g_idx, cur.n_gather, ctx->d_vals, ctx->tab[0][0]);
+        count_launch(ctx);
+    }
+    InitArgs a{};
+    a.beta_g = ctx->beta_g; a.beta_u = ctx->beta_u; a.vals = ctx->d_vals; a.gc = cur.gc; a.coef = ctx->coef();
+    a.M = ctx->tab[0][1]; a.A = ctx->tab[0][2];
+    VPCHK(run_init_rows<2>(ctx, cur.c2, a));
+    SumcheckState &s = ctx->sc;
+    s.phase = 2; s.layer = i; s.n_tab = i; s.round = 0; s.total_rounds = cur.max_dad_bl; s.has_a = 1;
+    for (int j = 0; j < i; ++j) {
+        s.off[j] = cur.t_off[j]; s.len0[j] = cur.t_len[j];
+        s.valid0[j] = (u32) cur.dad_size[j];
+        s.bl[j] = cur.dad_size[j] ? cur.dad_bl[j] : 0;
+    }
+    s.V0 = ctx->tab[0][0]; s.M0 = ctx->tab[0][1]; s.A0 = ctx->tab[0][2];
+    return VP_OK;
+}
+
+int do_liu_init(vp_ctx *ctx, int i) {
+    LayerDev &cur = ctx->L[i], &pre = ctx->L[i - 1];
+    hipLaunchKernelGGL(k_beta_half_multi, dim3(cur.n_jobs), dim3(VP_BLOCK), 0, ctx->stream, cur.jobs);
+    hipLaunchKernelGGL(k_zero_f, dim3(1), dim3(64), 0, ctx->stream, ctx->add_term(), 1u);
+    count_launch(ctx); count_launch(ctx);
+    F *M = ctx->tab[0][1];
+    const u32 hc = ctx->half_cap;
+    hipLaunchKernelGGL(k_liu_first, dim3(grid_for(pre.size)), dim3(VP_BLOCK), 0, ctx->stream, ctx->liu_half,
+                       ctx->liu_half + hc, cur.job_h1[0], (u32) pre.size, M);
+    count_launch(ctx);
+    for (u32 q = 1; q < cur.n_jobs; ++q) {
+        const int k = cur.job_k[q];
+        const LayerDev &Lk = ctx->L[k];
+        const u32 n = (u32) Lk.dad_size[i - 1];
+        hipLaunchKernelGGL(k_liu_scatter, dim3(grid_for(n)), dim3(VP_BLOCK), 0, ctx->stream,
+                           ctx->liu_half + 2 * (size_t) q * hc, ctx->liu_half + (2 * (size_t) q + 1) * hc,
+                           cur.job_h1[q], Lk.dad_id[i - 1], n, M);
+        count_launch(ctx);
+    }
+    SumcheckState &s = ctx->sc;
+    s.phase = 3; s.layer = i; s.n_tab = 1; s.round = 0; s.total_rounds = pre.bl; s.has_a = 0;
+    s.off[0] = 0; s.len0[0] = 1u << pre.bl; s.valid0[0] = (u32) pre.size; s.bl[0] = pre.bl;
+    s.V0 = pre.val; s.M0 = M; s.A0 = ctx->tab[0][2];
+    return VP_OK;
+}
+
+// one sumcheck round; rp (device) or rv (by value) is the previous challenge
+int do_round(vp_ctx *ctx, const F *rp, const F &rv, F *poly_dev, F *poly_host) {
+    SumcheckState &s = ctx->sc;
+    const int k = s.round + 1;
+    RoundArgs a{};
+    a.rp = rp; a.rv = rv; a.n_tab = s.n_tab; a.fold = (k >= 2); a.has_a = s.has_a;
+    if (k <= 2) { a.inV = s.V0; a.inM = s.M0; a.inA = s.A0; }
+    else { F **t = ctx->tab[k & 1]; a.inV = t[0]; a.inM = t[1]; a.inA = t[2]; }       // out of round k-1
+    { F **t = ctx->tab[(k + 1) & 1]; a.outV = t[0]; a.outM = t[1]; a.outA = t[2]; }
+    u32 pairs = 0;
+    u64 bytes = 0;
+    for (int j = 0; j < s.n_tab; ++j) {
+        TabDesc &t = a.t[j];
+        t.off = s.off[j];
+        t.pair_start = pairs;
+        if (k == 1) {
+            t.len_in = s.len0[j]; t.valid_in = s.valid0[j];
+            if (t.len_in >= 2) { pairs += (t.valid_in + 1) >> 1; bytes += (u64) t.valid_in * (s.has_a ? 48 : 32); }
+        } else {
+            const int sh = k - 2;
+            t.len_in = sh < 32 ? (s.len0[j] >> sh) : 0;
+            if (t.len_in < 2) { t.len_in = 0; t.valid_in = 0; continue; }
+            t.valid_in = (u32) (((u64) s.valid0[j] + (1ull << sh) - 1) >> sh);
+            const u32 vo = (t.valid_in + 1) >> 1;
+            if ((t.len_in >> 1) >= 2) { pairs += (vo + 1) >> 1; bytes += (u64) (t.valid_in + vo) * (s.has_a ? 48 : 32); }
+        }
+    }
+    a.total_pairs = pairs;
+    u32 grid = 0;
+    if (pairs) {
+        grid = grid_for(pairs);
+        const bool prof = ctx->profiling && pairs >= 32768 && ctx->ev_used < ctx->ev_pool.size();
+        if (prof) hipEventRecord(ctx->ev_pool[ctx->ev_used].a, ctx->stream);
+        hipLaunchKernelGGL(k_round_main, dim3(grid), dim3(VP_BLOCK), 0, ctx->stream, a, ctx->partials);
+        if (prof) { hipEventRecord(ctx->ev_pool[ctx->ev_used].b, ctx->stream); ctx->ev_pool[ctx->ev_used++].bytes = bytes; }
+        count_launch(ctx);
+    }
+    hipLaunchKernelGGL(k_round_final, dim3(1), dim3(VP_BLOCK), 0, ctx->stream, a, ctx->partials, grid, ctx->add_term(),
+                       ctx->scalarV(), poly_dev, poly_host);
+    count_launch(ctx);
+    s.round = k;
+    ++ctx->st.rounds;
+    return VP_OK;
+}
+
+int do_finalize(vp_ctx *ctx, const F *rp, const F &rv, F *claims_dev, F *claims_host) {
+    SumcheckState &s = ctx->sc;
+    FinArgs a{};
+    a.rp = rp; a.rv = rv; a.n_tab = s.n_tab; a.rounds_done = s.round;
+    const int R = s.round;
+    a.curV = (R <= 1) ? s.V0 : ctx->tab[(R + 1) & 1][0];
+    const int sh = R >= 1 ? R - 1 : 0;
+    for (int j = 0; j < s.n_tab; ++j) {
+        a.off[j] = s.off[j]; a.bl[j] = s.bl[j];
+        a.valid[j] = (u32) (((u64) s.valid0[j] + (1ull << sh) - 1) >> sh);
+    }
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, ctx->stream, a, ctx->scalarV(), claims_dev, claims_host,
+                       s.phase == 1 ? ctx->Vu() : nullptr);
+    count_launch(ctx);
+    return VP_OK;
+}
+
+int check_stream(vp_ctx *ctx) {
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipGetLastError());
+    return VP_OK;
+}
+
+void compute_layout(vp_ctx *ctx) {
+    const int n = ctx->n_layers;
+    ctx->ru_off.assign(n, 0); ctx->as_off.assign(n, 0); ctx->rv_off.assign(n, 0);
+    ctx->sig_off.assign(n, 0); ctx->rliu_off.assign(n + 1, 0);
+    u64 off = ctx->L[n - 1].bl;                       // r_0 at offset 0 (src/verifier.cpp:144)
+    u64 tr = 1;                                       // Vres
+    for (int i = n - 1; i >= 1; --i) {
+        ctx->ru_off[i] = off; off += ctx->max_bl;     // verifier.cpp:196
+        ctx->as_off[i] = off; off += 1;               // :202
+        if (ctx->L[i].max_dad_bl != -1) { ctx->rv_off[i] = off; off += ctx->L[i].max_dad_bl; }   // :236
+        ctx->sig_off[i] = off; off += n;              // :278
+        ctx->rliu_off[i] = off; off += ctx->max_bl;   // :279
+        tr += 3 * (u64) ctx->L[i - 1].bl + 1;
+        if (ctx->L[i].max_dad_bl != -1) tr += 3 * (u64) ctx->L[i].max_dad_bl + i;
+        tr += 3 * (u64) ctx->L[i - 1].bl + 1;
+    }
+    ctx->n_tape = off;
+    ctx->n_tr = tr;
+}
+// device address of the point at which layer i's claim lives (prover::r_liu during layer i)
+const F *rliu_ptr(vp_ctx *ctx, int i) {
+    return i == ctx->n_layers - 1 ? ctx->d_tape : ctx->d_tape + ctx->rliu_off[i + 1];
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *vp_version(void) { return "vpgpu 0.1 (gfx950)"; }
+const char *vp_last_error(const vp_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int vp_create(int device, vp_ctx **out) {
+    if (!out) return VP_EINVAL;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return VP_ENOGPU;
+    if (hipSetDevice(device) != hipSuccess) return VP_ENOGPU;
+    vp_ctx *ctx = new vp_ctx();
+    ctx->device = device;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return VP_EHIP; }
+    if (hipHostMalloc((void **) &ctx->h_pin, (4 + VP_MAX_TAB) * sizeof(F), hipHostMallocDefault) != hipSuccess) {
+        delete ctx; return VP_EHIP;
+    }
+    hipEventCreate(&ctx->ev0); hipEventCreate(&ctx->ev1);
+    *out = ctx;
+    return VP_OK;
+}
+
+void vp_destroy(vp_ctx *ctx) {
+    if (!ctx) return;
+    (void) hipSetDevice(ctx->device);
+    (void) hipStreamSynchronize(ctx->stream);
+    free_all(ctx);
+    for (auto &e : ctx->ev_pool) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
+    if (ctx->ev0) (void) hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void) hipEventDestroy(ctx->ev1);
+    if (ctx->h_pin) (void) hipHostFree(ctx->h_pin);
+    (void) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
+    if (!ctx || !ld || n_layers < 2) return VP_EINVAL;
+    if (n_layers > VP_MAX_TAB) { ctx->err = "too many layers"; return VP_ELIMIT; }
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    free_all(ctx);
+    ctx->L.assign(n_layers, LayerDev());
+    ctx->n_layers = n_layers;
+    ctx->evaluated = false;
+    ctx->chunk_cap = 0;
+    int max_bl = 0;
+    for (int i = 0; i < n_layers; ++i) {
+        if (ld[i].size == 0 || ld[i].size > (1ull << 30) || ld[i].bit_length < 0 || ld[i].bit_length > 30 ||
+            (1ull << ld[i].bit_length) < ld[i].size) { ctx->err = "bad layer size"; return VP_ELIMIT; }
+        max_bl = std::max(max_bl, (int) ld[i].bit_length);
+    }
+    ctx->max_bl = max_bl;
+    // ---- validate + per-layer uploads ----
+    for (int i = 0; i < n_layers; ++i) {
+        LayerDev &D = ctx->L[i];
+        const vp_layer_desc &S = ld[i];
+        D.size = S.size; D.bl = S.bit_length;
+        const u64 nval = i == 0 ? (1ull << S.bit_length) : S.size;     // circuitValue[0] is padded (prover.cpp:30)
+        VPCHK(dalloc(ctx, &D.val, nval));
+        if (i == 0) continue;
+        const u32 n = (u32) S.size;
+        std::vector<uint8_t> ty(n); std::vector<int16_t> gl(n); std::vector<u32> gu(n), gv(n), as;
+        bool need_c = false;
+        for (u32 g = 0; g < n; ++g) {
+            const int t = S.ty[g], l = S.l[g];
+            if (t < 0 || t > VP_COPY || t == VP_INPUT) { ctx->err = "bad gate type"; return VP_EINVAL; }
+            if (S.u[g] >= ld[i - 1].size) { ctx->err = "gate.u out of range"; return VP_EINVAL; }
+            if (is_unary(t)) {
+                if (l != -1) { ctx->err = "unary gate with l != -1"; return VP_EINVAL; }
+                if (t == VP_ADDC || t == VP_MULC) need_c = true;
+            } else {
+                if (l < 0 || l >= i || S.v[g] >= ld[l].size) { ctx->err = "gate.v out of range"; return VP_EINVAL; }
+                if (!S.dad_size || S.lv[g] >= S.dad_size[l] || S.dad_id[l][S.lv[g]] != S.v[g]) {
+                    ctx->err = "gate.lv inconsistent with dadId"; return VP_EINVAL;
+                }
+            }
+            ty[g] = (uint8_t) t; gl[g] = (int16_t) l; gu[g] = S.u[g]; gv[g] = is_unary(t) ? 0 : S.v[g];
+            if (S.is_assert && S.is_assert[g]) as.push_back(g);
+        }
+        if (need_c && !S.c) { ctx->err = "Addc/Mulc gates without constants"; return VP_EINVAL; }
+        VPCHK(dupload(ctx, &D.ty, ty)); VPCHK(dupload(ctx, &D.gl, gl));
+        VPCHK(dupload(ctx, &D.gu, gu)); VPCHK(dupload(ctx, &D.gv, gv));
+        if (need_c) {
+            VPCHK(dalloc(ctx, &D.gc, (size_t) n));
+            HIPCHK(hipMemcpy(D.gc, S.c, (size_t) n * sizeof(F), hipMemcpyHostToDevice));
+        }
+        D.n_assert = (u32) as.size();
+        VPCHK(dupload(ctx, &D.assert_idx, as));
+        // dad subsets / phase-2 slot layout
+        D.dad_size.resize(i); D.dad_bl.resize(i); D.dad_id.assign(i, nullptr); D.t_off.resize(i); D.t_len.resize(i);
+        D.max_dad_bl = -1;
+        u32 off = 0;
+        std::vector<u32> g_slot, g_idx; std::vector<uint8_t> g_layer;
+        for (int j = 0; j < i; ++j) {
+            D.dad_size[j] = S.dad_size[j];
+            if (S.dad_size[j] > ld[j].size) { ctx->err = "dadSize too large"; return VP_EINVAL; }
+            D.dad_bl[j] = S.dad_size[j] ? ceil_log2(S.dad_size[j]) : 0;
+            if (S.dad_size[j]) {
+                if (S.dad_bitlen[j] != D.dad_bl[j]) { ctx->err = "dadBitLength mismatch"; return VP_EINVAL; }
+                D.max_dad_bl = std::max(D.max_dad_bl, D.dad_bl[j]);
+                std::vector<u32> ids(S.dad_id[j], S.dad_id[j] + S.dad_size[j]);
+                for (u32 x : ids) if (x >= ld[j].size) { ctx->err = "dadId out of range"; return VP_EINVAL; }
+                VPCHK(dupload(ctx, &D.dad_id[j], ids));
+                for (u32 k = 0; k < ids.size(); ++k) { g_slot.push_back(off + k); g_layer.push_back((uint8_t) j); g_idx.push_back(ids[k]); }
+            } else {
+                g_slot.push_back(off); g_layer.push_back(0xff); g_idx.push_back(0);
+            }
+            D.t_off[j] = off; D.t_len[j] = 1u << D.dad_bl[j];
+            off += D.t_len[j];
+        }
+        D.p2_total = off;
+        D.n_gather = (u32) g_slot.size();
+        VPCHK(dupload(ctx, &D.g_slot, g_slot)); VPCHK(dupload(ctx, &D.g_layer, g_layer)); VPCHK(dupload(ctx, &D.g_idx, g_idx));
+        // contribution lists
+        std::vector<u32> key1(n), key2(n), eg(n), ex1(n), ex2(n);
+        std::vector<uint16_t> etl(n);
+        for (u32 g = 0; g < n; ++g) {
+            const int t = ty[g], l = gl[g];
+            eg[g] = g; ex1[g] = gv[g]; ex2[g] = gu[g];
+            etl[g] = (uint16_t) ((t << 8) | (l < 0 ? 0xff : l));
+            key1[g] = gu[g];
+            key2[g] = is_unary(t) ? D.t_off[i - 1] : D.t_off[l] + S.lv[g];    // prover.cpp:314,342-353
+        }
+        VPCHK(build_csr(ctx, D.c1, (u32) ld[i - 1].size, key1, eg, ex1, etl));
+        VPCHK(build_csr(ctx, D.c2, D.p2_total, key2, eg, ex2, etl));
+    }
+    // ---- shared buffers ----
+    u32 cap = 0;
+    for (int i = 1; i < n_layers; ++i) cap = std::max<u32>(cap, std::max<u32>(1u << ctx->L[i - 1].bl, ctx->L[i].p2_total));
+    ctx->cap = cap;
+    for (int b = 0; b < 2; ++b) for (int t = 0; t < 3; ++t) VPCHK(dalloc(ctx, &ctx->tab[b][t], (size_t) cap));
+    VPCHK(dalloc(ctx, &ctx->beta_g, (size_t) 1 << max_bl));
+    VPCHK(dalloc(ctx, &ctx->beta_u, (size_t) 1 << max_bl));
+    ctx->half_cap = 1u << ((max_bl + 1) / 2);
+    VPCHK(dalloc(ctx, &ctx->bf, (size_t) ctx->half_cap));
+    VPCHK(dalloc(ctx, &ctx->bs, (size_t) ctx->half_cap));
+    VPCHK(dalloc(ctx, &ctx->liu_half, (size_t) 2 * (n_layers + 1) * ctx->half_cap));
+    VPCHK(dalloc(ctx, &ctx->partials, (size_t) 3 * MAX_BLOCKS));
+    VPCHK(dalloc(ctx, &ctx->chunk_part, (size_t) 2 * std::max<u32>(1, ctx->chunk_cap)));
+    VPCHK(dalloc(ctx, &ctx->small, (size_t) 32 + VP_MAX_TAB));
+    VPCHK(dalloc(ctx, &ctx->d_flag, (size_t) 1));
+    {
+        std::vector<F> sm(32 + VP_MAX_TAB, f_zero());
+        sm[1] = f_one();
+        HIPCHK(hipMemcpy(ctx->small, sm.data(), sm.size() * sizeof(F), hipMemcpyHostToDevice));
+        std::vector<F *> vals(n_layers);
+        for (int i = 0; i < n_layers; ++i) vals[i] = ctx->L[i].val;
+        VPCHK(dupload(ctx, &ctx->d_vals, vals));
+    }
+    compute_layout(ctx);
+    VPCHK(dalloc(ctx, &ctx->d_tape, (size_t) ctx->n_tape));
+    VPCHK(dalloc(ctx, &ctx->d_tr, (size_t) ctx->n_tr + 3 + VP_MAX_TAB));
+    HIPCHK(hipMemset(ctx->d_tape, 0, ctx->n_tape * sizeof(F)));
+    // ---- Liu jobs (src/prover.cpp:396,402-414): eq tables over r_u and every later layer's r_v ----
+    for (int i = 1; i < n_layers; ++i) {
+        LayerDev &D = ctx->L[i];
+        std::vector<BetaJob> jobs;
+        const u32 hc = ctx->half_cap;
+        auto add = [&](const F *r, const F *init, int nbits, int k) {
+            BetaJob jb{};
+            const size_t q = jobs.size();
+            jb.r = r; jb.init = init; jb.bf = ctx->liu_half + 2 * q * hc; jb.bs = ctx->liu_half + (2 * q + 1) * hc; jb.n = nbits;
+            jobs.push_back(jb); D.job_k.push_back(k); D.job_h1.push_back(nbits >> 1);
+        };
+        add(ctx->d_tape + ctx->ru_off[i], ctx->d_tape + ctx->sig_off[i], ctx->L[i - 1].bl, -1);
+        for (int k = i; k < n_layers; ++k)
+            if (ctx->L[k].dad_size[i - 1])
+                add(ctx->d_tape + ctx->rv_off[k], ctx->d_tape + ctx->sig_off[i] + (k - i + 1), ctx->L[k].dad_bl[i - 1], k);
+        D.n_jobs = (u32) jobs.size();
+        VPCHK(dupload(ctx, &D.jobs, jobs));
+    }
+    // event pool for the profiled launches
+    if (ctx->ev_pool.empty()) {
+        ctx->ev_pool.resize(1024);
+        for (auto &e : ctx->ev_pool) { hipEventCreate(&e.a); hipEventCreate(&e.b); e.bytes = 0; }
+    }
+    return VP_OK;
+}
+
+int vp_evaluate(vp_ctx *ctx, const vp_F *inputs, uint64_t n_inputs) {
+    if (!ctx || !inputs || ctx->n_layers < 2 || n_inputs != ctx->L[0].size) return VP_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    LayerDev &L0 = ctx->L[0];
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    HIPCHK(hipMemsetAsync(L0.val, 0, (sizeof(F) << L0.bl), ctx->stream));
+    HIPCHK(hipMemcpyAsync(L0.val, inputs, n_inputs * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_flag, 0, sizeof(int), ctx->stream));
+    for (int i = 1; i < ctx->n_layers; ++i) {
+        LayerDev &D = ctx->L[i];
+        hipLaunchKernelGGL(k_evaluate_layer, dim3(nblk(D.size)), dim3(VP_BLOCK), 0, ctx->stream, i, (u32) D.size, D.ty,
+                           D.gl, D.gu, D.gv, D.gc, ctx->d_vals);
+        if (D.n_assert)
+            hipLaunchKernelGGL(k_check_asserts, dim3(nblk(D.n_assert)), dim3(VP_BLOCK), 0, ctx->stream, D.assert_idx,
+                               D.n_assert, D.val, ctx->d_flag);
+    }
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    int flag = 0;
+    HIPCHK(hipMemcpyAsync(&flag, ctx->d_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    VPCHK(check_stream(ctx));
+    float ms = 0;
+    hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+    ctx->st.evaluate_ms = ms;
+    ctx->evaluated = true;
+    HIPCHK(hipMemsetAsync(ctx->add_term(), 0, sizeof(F), ctx->stream));
+    if (flag) { ctx->err = "assert gate is non-zero"; return VP_EASSERT; }
+    return VP_OK;
+}
+
+int vp_layer_values(vp_ctx *ctx, int layer, vp_F *out, uint64_t n) {
+    if (!ctx || !out || layer < 0 || layer >= ctx->n_layers || n > ctx->L[layer].size) return VP_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    VPCHK(check_stream(ctx));
+    HIPCHK(hipMemcpy(out, ctx->L[layer].val, n * sizeof(F), hipMemcpyDeviceToHost));
+    return VP_OK;
+}
+
+static int stage(vp_ctx *ctx, u64 off, const vp_F *src, u64 n) {
+    if (!n) return VP_OK;
+    if (!src || off + n > ctx->n_tape) return VP_EINVAL;
+    HIPCHK(hipMemcpyAsync(ctx->d_tape + off, src, n * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
+    return VP_OK;
+}
+
+int vp_vres(vp_ctx *ctx, const vp_F *r_0, int r_0_size, vp_F *out) {
+    if (!ctx || !ctx->evaluated || !r_0 || !out || r_0_size != ctx->L[ctx->n_layers - 1].bl) return VP_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    VPCHK(stage(ctx, 0, r_0, r_0_size));
+    LayerDev &T = ctx->L[ctx->n_layers - 1];
+    VPCHK(run_beta_half(ctx, ctx->d_tape, T.bl, ctx->one()));
+    hipLaunchKernelGGL(k_vres, dim3(1), dim3(VP_BLOCK), 0, ctx->stream, ctx->bf, ctx->bs, T.bl >> 1, T.val, (u32) T.size,
+                       ctx->d_tr, ctx->h_pin + 3);
+    VPCHK(check_stream(ctx));
+    memcpy(out, ctx->h_pin + 3, sizeof(F));
+    return VP_OK;
+}
+
+int vp_phase1_init(vp_ctx *ctx, int layer, const vp_F *r_liu, const vp_F *assert_random) {
+    if (!ctx || !ctx->evaluated || layer < 1 || layer >= ctx->n_layers || !r_liu || !assert_random) return VP_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    const u64 off = layer == ctx->n_layers - 1 ? 0 : ctx->rliu_off[layer + 1];
+    VPCHK(stage(ctx, off, r_liu, ctx->L[layer].bl));
+    VPCHK(stage(ctx, ctx->as_off[layer], assert_random, 1));
+    VPCHK(do_phase1_init(ctx, layer, ctx->d_tape + off, ctx->d_tape + ctx->as_off[layer]));
+    return check_stream(ctx);
+}
+
+int vp_phase2_init(vp_ctx *ctx, int layer, const vp_F *r_u) {
+    if (!ctx || !ctx->evaluated || layer < 1 || layer >= ctx->n_layers || !r_u) return VP_EINVAL;
+    if (ctx->sc.layer != layer || ctx->L[layer].max_dad_bl == -1) { ctx->err = "phase2 out of order"; return VP_EINVAL; }
+    HIPCHK(hipSetDevice(ctx->device));
+    VPCHK(stage(ctx, ctx->ru_off[layer], r_u, ctx->L[layer - 1].bl));
+    VPCHK(do_phase2_init(ctx, layer, ctx->d_tape + ctx->ru_off[layer]));
+    return check_stream(ctx);
+}
+
+int vp_liu_init(vp_ctx *ctx, int layer, const vp_F *r_u, const vp_F *const *r_v, const vp_F *s) {
+    if (!ctx || !ctx->evaluated || layer < 1 || layer >= ctx->n_layers || !r_u || !s) return VP_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int n = ctx->n_layers;
+    VPCHK(stage(ctx, ctx->ru_off[layer], r_u, ctx->L[layer - 1].bl));
+    VPCHK(stage(ctx, ctx->sig_off[layer], s, n - layer + 1));
+    for (int k = layer; k < n; ++k)
+        if (ctx->L[k].dad_size[layer - 1]) {
+            if (!r_v || !r_v[k]) return VP_EINVAL;
+            VPCHK(stage(ctx, ctx->rv_off[k], r_v[k], ctx->L[k].dad_bl[layer - 1]));
+        }
+    VPCHK(do_liu_init(ctx, layer));
+    return check_stream(ctx);
+}
+
+int vp_round(vp_ctx *ctx, const vp_F *previous_random, vp_F out_poly[3]) {
+    if (!ctx || !previous_random || !out_poly || ctx->sc.phase == 0) return VP_EINVAL;
+    if (ctx->sc.round >= ctx->sc.total_rounds) { ctx->err = "too many rounds"; return VP_EINVAL; }
+    HIPCHK(hipSetDevice(ctx->device));
+    F rv; memcpy(&rv, previous_random, sizeof(F));
+    VPCHK(do_round(ctx, nullptr, rv, ctx->d_tr + ctx->n_tr, ctx->h_pin));
+    VPCHK(check_stream(ctx));
+    memcpy(out_poly, ctx->h_pin, 3 * sizeof(F));
+    return VP_OK;
+}
+
+int vp_finalize(vp_ctx *ctx, const vp_F *previous_random, vp_F *claims, int n_claims) {
+    if (!ctx || !previous_random || !claims || ctx->sc.phase == 0 || n_claims != ctx->sc.n_tab) return VP_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    F rv; memcpy(&rv, previous_random, sizeof(F));
+    VPCHK(do_finalize(ctx, nullptr, rv, ctx->d_tr + ctx->n_tr + 3, ctx->h_pin + 4));
+    VPCHK(check_stream(ctx));
+    memcpy(claims, ctx->h_pin + 4, (size_t) n_claims * sizeof(F));
+    return VP_OK;
+}
+
+int vp_gkr_sizes(vp_ctx *ctx, uint64_t *n_tape, uint64_t *n_bytes) {
+    if (!ctx || ctx->n_layers < 2) return VP_EINVAL;
+    if (n_tape) *n_tape = ctx->n_tape;
+    if (n_bytes) *n_bytes = ctx->n_tr * sizeof(F);
+    return VP_OK;
+}
+
+int vp_prove_gkr(vp_ctx *ctx, const vp_F *tape, uint64_t n_tape, uint8_t *transcript, uint64_t capacity,
+                 uint64_t *n_written) {
+    if (!ctx || !ctx->evaluated || !tape || !transcript || n_tape != ctx->n_tape) return VP_EINVAL;
+    if (capacity < ctx->n_tr * sizeof(F)) return VP_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int n = ctx->n_layers;
+    ctx->st.launches = 0; ctx->st.rounds = 0; ctx->ev_used = 0;
+    HIPCHK(hipMemcpyAsync(ctx->d_tape, tape, n_tape * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->add_term(), 0, sizeof(F), ctx->stream));
+    F *tr = ctx->d_tr;
+    u64 pos = 0;
+    const F zero = f_zero();
+    {   // Vres (verifier.cpp:151)
+        LayerDev &T = ctx->L[n - 1];
+        VPCHK(run_beta_half(ctx, ctx->d_tape, T.bl, ctx->one()));
+        hipLaunchKernelGGL(k_vres, dim3(1), dim3(VP_BLOCK), 0, ctx->stream, ctx->bf, ctx->bs, T.bl >> 1, T.val,
+                           (u32) T.size, tr + pos, (F *) nullptr);
+        count_launch(ctx);
+        pos += 1;
+    }
+    for (int i = n - 1; i >= 1; --i) {
+        const int pbl = ctx->L[i - 1].bl;
+        const F *ru = ctx->d_tape + ctx->ru_off[i];
+        // phase 1 (verifier.cpp:191-229)
+        VPCHK(do_phase1_init(ctx, i, rliu_ptr(ctx, i), ctx->d_tape + ctx->as_off[i]));
+        for (int j = 0; j < pbl; ++j) { VPCHK(do_round(ctx, j ? ru + (j - 1) : ctx->zero(), zero, tr + pos, nullptr)); pos += 3; }
+        VPCHK(do_finalize(ctx, pbl ? ru + (pbl - 1) : ctx->zero(), zero, tr + pos, nullptr));
+        pos += 1;
+        // phase 2 (verifier.cpp:231-270)
+        const int mdb = ctx->L[i].max_dad_bl;
+        if (mdb != -1) {
+            const F *rv = ctx->d_tape + ctx->rv_off[i];
+            VPCHK(do_phase2_init(ctx, i, ru));
+            for (int j = 0; j < mdb; ++j) { VPCHK(do_round(ctx, j ? rv + (j - 1) : ctx->zero(), zero, tr + pos, nullptr)); pos += 3; }
+            VPCHK(do_finalize(ctx, mdb ? rv + (mdb - 1) : ctx->zero(), zero, tr + pos, nullptr));
+            pos += i;
+        }
+        // Liu (verifier.cpp:272-337)
+        const F *rl = ctx->d_tape + ctx->rliu_off[i];
+        VPCHK(do_liu_init(ctx, i));
+        for (int j = 0; j < pbl; ++j) { VPCHK(do_round(ctx, j ? rl + (j - 1) : ctx->zero(), zero, tr + pos, nullptr)); pos += 3; }
+        VPCHK(do_finalize(ctx, pbl ? rl + (pbl - 1) : ctx->zero(), zero, tr + pos, nullptr));
+        pos += 1;
+    }
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    if (pos != ctx->n_tr) { ctx->err = "internal: transcript size"; return VP_EINVAL; }
+    HIPCHK(hipMemcpyAsync(transcript, tr, pos * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
+    VPCHK(check_stream(ctx));
+    float ms = 0;
+    hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+    ctx->st.gkr_ms = ms;
+    ctx->st.fold_ms = 0; ctx->st.fold_bytes = 0; ctx->st.fold_launches = ctx->ev_used;
+    for (size_t e = 0; e < ctx->ev_used; ++e) {
+        float t = 0;
+        hipEventElapsedTime(&t, ctx->ev_pool[e].a, ctx->ev_pool[e].b);
+        ctx->st.fold_ms += t; ctx->st.fold_bytes += ctx->ev_pool[e].bytes;
+    }
+    if (n_written) *n_written = pos * sizeof(F);
+    return VP_OK;
+}
+
+int vp_get_stats(vp_ctx *ctx, vp_stats *out) {
+    if (!ctx || !out) return VP_EINVAL;
+    *out = ctx->st;
+    return VP_OK;
+}
+int vp_set_profiling(vp_ctx *ctx, int level) {
+    if (!ctx) return VP_EINVAL;
+    ctx->profiling = level;
+    return VP_OK;
+}
+
+int vp_test_field(vp_ctx *ctx, int op, const vp_F *a, const vp_F *b, vp_F *out, uint64_t n) {
+    if (!ctx || !a || !b || !out || op < 0 || op > 2) return VP_EINVAL;
+    if (n == 0) return VP_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    F *da = nullptr, *db = nullptr, *dout = nullptr;
+    HIPCHK(hipMalloc((void **) &da, n * sizeof(F)));
+    HIPCHK(hipMalloc((void **) &db, n * sizeof(F)));
+    HIPCHK(hipMalloc((void **) &dout, n * sizeof(F)));
+    HIPCHK(hipMemcpy(da, a, n * sizeof(F), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(db, b, n * sizeof(F), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_test_field, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream, op, da, db, dout, (u64) n);
+    int rc = check_stream(ctx);
+    if (rc == VP_OK && hipMemcpy(out, dout, n * sizeof(F), hipMemcpyDeviceToHost) != hipSuccess) rc = VP_EHIP;
+    (void) hipFree(da); (void) hipFree(db); (void) hipFree(dout);
+    return rc;
+}
+
+int vp_test_beta(vp_ctx *ctx, const vp_F *r, int n, const vp_F *init, vp_F *out) {
+    if (!ctx || !init || !out || n < 0 || n > 28 || (n && !r)) return VP_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    F *dr = nullptr, *dbf = nullptr, *dbs = nullptr, *dout = nullptr;
+    const size_t half = (size_t) 1 << ((n + 1) / 2);
+    HIPCHK(hipMalloc((void **) &dr, (n + 2) * sizeof(F)));
+    HIPCHK(hipMalloc((void **) &dbf, half * sizeof(F)));
+    HIPCHK(hipMalloc((void **) &dbs, half * sizeof(F)));
+    HIPCHK(hipMalloc((void **) &dout, sizeof(F) << n));
+    if (n) HIPCHK(hipMemcpy(dr, r, n * sizeof(F), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dr + n, init, sizeof(F), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_beta_half, dim3(1), dim3(VP_BLOCK), 0, ctx->stream, dr, n, dr + n, dbf, dbs);
+    hipLaunchKernelGGL(k_beta_expand, dim3(grid_for(1ull << n)), dim3(VP_BLOCK), 0, ctx->stream, dbf, dbs, n >> 1,
+                       (u32) (1u << n), dout);
+    int rc = check_stream(ctx);
+    if (rc == VP_OK && hipMemcpy(out, dout, sizeof(F) << n, hipMemcpyDeviceToHost) != hipSuccess) rc = VP_EHIP;
+    (void) hipFree(dr); (void) hipFree(dbf); (void) hipFree(dbs); (void) hipFree(dout);
+    return rc;
+}
+
+}  // extern "C"

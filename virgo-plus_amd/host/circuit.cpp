@@ -1,0 +1,255 @@
+#include "circuit.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+
+static int ceil_log2_u64(u64 x) {
+    int b = 0;
+    while ((1ull << b) < x) ++b;
+    return b;
+}
+
+layeredCircuit layeredCircuit::randomize(int layerNum, int eachLayer) {
+    layeredCircuit c;
+    const u64 gateSize = 1ull << eachLayer;
+    c.circuit.resize(layerNum);
+    c.size = layerNum;
+    for (int i = 0; i < layerNum; ++i) {
+        c.circuit[i].bitLength = eachLayer;
+        c.circuit[i].size = gateSize;
+        c.circuit[i].gates.resize(gateSize);
+    }
+    for (u64 j = 0; j < gateSize; ++j) c.circuit[0].gates[j] = gate(Input, 0, (u64) ::random(), 0, F_ZERO, false);
+    for (int i = 1; i < layerNum; ++i)
+        for (u64 j = 0; j < gateSize; ++j) {
+            const u64 v = ::random() % gateSize;
+            const u64 u = ::random() % gateSize;
+            const int l = (int) (::random() % i);
+            const gateType ty = (::random() & 1) == 0 ? Add : Mul;
+            c.circuit[i].gates[j] = gate(ty, l, u, v, F_ZERO, false);
+        }
+    return c;
+}
+
+void layeredCircuit::subsetInit() {
+    for (int i = 0; i < size; ++i) {
+        layer &L = circuit[i];
+        L.dadBitLength.assign(i, -1);
+        L.dadSize.assign(i, 0);
+        L.dadId.assign(i, std::vector<u64>());
+        L.maxDadBitLength = -1;
+        L.maxDadSize = 0;
+    }
+    // stamp[l][v] = last layer that pulled wire v of layer l into its subset; slot[l][v] = its position
+    std::vector<std::vector<int>> stamp(size);
+    std::vector<std::vector<u64>> slot(size);
+    for (int i = 0; i < size; ++i) { stamp[i].assign(circuit[i].size, 0); slot[i].assign(circuit[i].size, 0); }
+    for (int i = size - 1; i > 0; --i) {
+        layer &L = circuit[i];
+        for (u64 j = L.size; j-- > 0;) {                 // high-to-low: fixes the subset order (circuit.cpp:58)
+            gate &g = L.gates[j];
+            if (g.l < 0) continue;
+            if (stamp[g.l][g.v] != i) {
+                stamp[g.l][g.v] = i;
+                slot[g.l][g.v] = L.dadSize[g.l]++;
+                L.dadId[g.l].push_back(g.v);
+            }
+            g.lv = slot[g.l][g.v];
+        }
+        for (int j = 0; j < i; ++j) {
+            if (!L.dadSize[j]) continue;
+            L.dadBitLength[j] = ceil_log2_u64(L.dadSize[j]);
+            L.maxDadSize = std::max(L.maxDadSize, L.dadSize[j]);
+            L.maxDadBitLength = std::max(L.maxDadBitLength, L.dadBitLength[j]);
+        }
+    }
+}
+
+void layeredCircuit::structuralHash(u64 out[2]) const {
+    u64 a = 1469598103934665603ull, b = 0x9e3779b97f4a7c15ull;
+    auto put = [&](u64 x) {
+        for (int i = 0; i < 8; ++i) { a ^= (x >> (8 * i)) & 0xff; a *= 1099511628211ull; }
+        b = (b ^ x) * 0xff51afd7ed558ccdull; b ^= b >> 32;
+    };
+    put(size);
+    for (int i = 0; i < size; ++i) {
+        const layer &L = circuit[i];
+        put(L.size); put((i64) L.bitLength);
+        for (u64 g = 0; g < L.size; ++g) {
+            const gate &G = L.gates[g];
+            put((i64) G.ty); put((i64) G.l); put(G.u); put(G.v); put(G.lv);
+            put(G.c.real); put(G.c.img); put(G.is_assert ? 1 : 0);
+        }
+        put((i64) L.maxDadBitLength); put(L.maxDadSize);
+        for (int j = 0; j < i; ++j) {
+            put(L.dadSize[j]);
+            put(L.dadSize[j] ? (i64) L.dadBitLength[j] : -1ll);
+            for (u64 k = 0; k < L.dadSize[j]; ++k) put(L.dadId[j][k]);
+        }
+    }
+    out[0] = a; out[1] = b;
+}
+
+namespace vph {
+
+namespace {
+struct Line { gateType ty; u64 tgt, s0, s1; };
+
+// hand-written scanner for "P V<t> = V<a> <op> V<b> E" / "P V<t> = I<k> E" / "P O<k> = V<a> E"
+bool scan_uint(const char *&p, u64 &v) {
+    if (*p < '0' || *p > '9') return false;
+    v = 0;
+    while (*p >= '0' && *p <= '9') v = v * 10 + (u64) (*p++ - '0');
+    return true;
+}
+bool expect(const char *&p, const char *s) {
+    size_t n = strlen(s);
+    if (strncmp(p, s, n)) return false;
+    p += n;
+    return true;
+}
+}  // namespace
+
+bool parse_pws(const std::string &path, int blocks, std::vector<DAG_gate> &dag, std::string *err) {
+    auto fail = [&](const std::string &m) { if (err) *err = m; return false; };
+    FILE *f = fopen(path.c_str(), "r");
+    if (!f) return fail("cannot open " + path);
+    std::vector<u64> inputs;
+    std::vector<Line> gates;
+    char buf[256];
+    u64 lineno = 0;
+    while (fgets(buf, sizeof buf, f)) {
+        ++lineno;
+        const char *p = buf;
+        u64 t, a, b;
+        bool ok = expect(p, "P ");
+        if (ok && *p == 'O') {                                   // output line: parsed and ignored (main.cpp:189)
+            ++p;
+            ok = scan_uint(p, t) && expect(p, " = V") && scan_uint(p, a) && expect(p, " E");
+            if (!ok) break;
+            continue;
+        }
+        ok = ok && expect(p, "V") && scan_uint(p, t) && expect(p, " = ");
+        if (ok && *p == 'I') {
+            ++p;
+            ok = scan_uint(p, a) && expect(p, " E");
+            if (!ok) break;
+            inputs.push_back(t);
+            continue;
+        }
+        ok = ok && expect(p, "V") && scan_uint(p, a) && expect(p, " ");
+        gateType ty = Add;
+        if (ok) {
+            if (expect(p, "+ ")) ty = Add;
+            else if (expect(p, "* ")) ty = Mul;
+            else if (expect(p, "XOR ")) ty = Xor;
+            else if (expect(p, "minus ")) ty = Sub;
+            else if (expect(p, "NAAB ")) ty = Naab;
+            else if (expect(p, "NOT ")) ty = Not;
+            else ok = false;
+        }
+        ok = ok && expect(p, "V") && scan_uint(p, b) && expect(p, " E");
+        if (!ok) { fclose(f); return fail("syntax error at line " + std::to_string(lineno)); }
+        gates.push_back({ty, t, a, b});
+    }
+    if (!feof(f)) { fclose(f); return fail("syntax error at line " + std::to_string(lineno)); }
+    fclose(f);
+    const u64 nin = inputs.size(), ng = gates.size(), B = (u64) blocks;
+    for (u64 k = 0; k < nin; ++k) if (inputs[k] != k) return fail("inputs must be V0..V(n-1) in order");
+    for (u64 g = 0; g < ng; ++g) if (gates[g].tgt != nin + g) return fail("gates must be numbered densely in order");
+    for (u64 g = 0; g < ng; ++g)
+        if (gates[g].s0 >= nin + g || (gates[g].ty != Not && gates[g].s1 >= nin + g)) return fail("forward reference");
+    dag.assign(B * (nin + ng), DAG_gate());
+    for (u64 b = 0; b < B; ++b)
+        for (u64 k = 0; k < nin; ++k) {
+            DAG_gate &d = dag[b * nin + k];
+            d.ty = Input;
+            d.input0 = {'S', (u64) (::random() % F::mod)};      // main.cpp:188 — the witness
+            d.input1 = {'N', 0};
+        }
+    auto id = [&](u64 b, u64 x) { return x < nin ? b * nin + x : B * nin + b * ng + (x - nin); };
+    for (u64 b = 0; b < B; ++b)
+        for (u64 g = 0; g < ng; ++g) {
+            const Line &x = gates[g];
+            DAG_gate &d = dag[id(b, x.tgt)];
+            d.ty = x.ty;
+            d.input0 = {'V', id(b, x.s0)};
+            if (x.ty == Not) d.input1 = {'S', 0};               // main.cpp:202: the second operand is dropped
+            else d.input1 = {'V', id(b, x.s1)};
+        }
+    return true;
+}
+
+layeredCircuit DAG_to_layered(const std::vector<DAG_gate> &dag) {
+    const u64 n = dag.size();
+    // layer = longest path from the inputs.  Kahn's algorithm over the wire edges; a node's level is
+    // final when its last predecessor has been visited (same result as the FIFO walk of main.cpp:39-49).
+    std::vector<int> level(n, 0);
+    std::vector<u64> indeg(n, 0), head(n + 1, 0);
+    for (u64 i = 0; i < n; ++i) {
+        if (dag[i].input0.first == 'V') { ++indeg[i]; ++head[dag[i].input0.second + 1]; }
+        if (dag[i].input1.first == 'V') { ++indeg[i]; ++head[dag[i].input1.second + 1]; }
+    }
+    for (u64 i = 0; i < n; ++i) head[i + 1] += head[i];
+    std::vector<u64> succ(head[n]), fill(head.begin(), head.end() - 1);
+    for (u64 i = 0; i < n; ++i) {
+        if (dag[i].input0.first == 'V') succ[fill[dag[i].input0.second]++] = i;
+        if (dag[i].input1.first == 'V') succ[fill[dag[i].input1.second]++] = i;
+    }
+    std::vector<u64> order;
+    order.reserve(n);
+    for (u64 i = 0; i < n; ++i) if (dag[i].ty == Input) order.push_back(i);
+    int depth = 0;
+    for (u64 q = 0; q < order.size(); ++q) {
+        const u64 x = order[q];
+        depth = std::max(depth, level[x]);
+        for (u64 e = head[x]; e < head[x + 1]; ++e) {
+            const u64 y = succ[e];
+            level[y] = std::max(level[y], level[x] + 1);
+            if (--indeg[y] == 0) order.push_back(y);
+        }
+    }
+    layeredCircuit c;
+    c.size = depth + 1;
+    c.circuit.resize(c.size);
+    std::vector<u64> pos(n);
+    for (u64 i = 0; i < n; ++i) pos[i] = c.circuit[level[i]].size++;       // in-layer index = DAG id order
+    for (int i = 0; i < c.size; ++i) c.circuit[i].gates.resize(c.circuit[i].size);
+    for (u64 i = 0; i < n; ++i) {
+        const DAG_gate &d = dag[i];
+        const int lg = level[i];
+        gate &out = c.circuit[lg].gates[pos[i]];
+        u64 a = d.input0.second, b = d.input1.second;
+        switch (d.ty) {
+            case Mul: case Add: case Xor: case Sub: case Naab: {
+                gateType ty = d.ty;
+                // u must be the operand living in layer lg-1; otherwise swap (and retag the
+                // non-commutative types), main.cpp:73-98
+                if (level[a] < lg - 1) {
+                    std::swap(a, b);
+                    if (ty == Sub) ty = AntiSub;
+                    else if (ty == Naab) ty = AntiNaab;
+                }
+                out = gate(ty, level[b], pos[a], pos[b], F_ZERO, d.is_assert);
+                break;
+            }
+            case Mulc: case Addc:
+                out = gate(d.ty, -1, pos[a], 0, F((long long) b), d.is_assert);
+                break;
+            case Not: case Copy:
+                // main.cpp:104-110 falls through into the Input case: u is the operand's RAW DAG id and
+                // the constant is dropped.  Kept as is: it defines the circuit the goldens were made on.
+                out = gate(d.ty, -1, a, 0, F_ZERO, d.is_assert);
+                break;
+            case Input:
+                out = gate(Input, -1, a, 0, F_ZERO, d.is_assert);        // u carries the input value
+                break;
+            default: break;
+        }
+    }
+    for (int i = 0; i < c.size; ++i) c.circuit[i].bitLength = ceil_log2_u64(c.circuit[i].size);
+    return c;
+}
+
+}  // namespace vph

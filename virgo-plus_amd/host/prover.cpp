@@ -1,0 +1,190 @@
+#include "prover.hpp"
+
+#include <string>
+
+static_assert(sizeof(F) == sizeof(vp_F), "F must be two u64 limbs");
+static inline const vp_F *cF(const F *p) { return reinterpret_cast<const vp_F *>(p); }
+static inline vp_F *mF(F *p) { return reinterpret_cast<vp_F *>(p); }
+
+void prover::check(int rc, const char *what) {
+    if (rc == VP_OK) return;
+    throw std::runtime_error(std::string(what) + " failed (" + std::to_string(rc) + "): " + vp_last_error(ctx));
+}
+
+// src/prover.cpp:14-25.  The circuit tables are flattened to structure-of-arrays and copied to HBM once;
+// the constructor then evaluates the circuit on the device like the reference's constructor does on the
+// CPU.  A violated assert gate surfaces as an exception instead of the reference's exit(EXIT_FAILURE).
+prover::prover(const layeredCircuit &cir, int device) : C(cir) {
+    int rc = vp_create(device, &ctx);
+    if (rc != VP_OK) throw std::runtime_error("vp_create failed (" + std::to_string(rc) + "): no usable MI355X / HIP device");
+    const int n = C.size;
+    std::vector<vp_layer_desc> desc(n);
+    struct Flat {
+        std::vector<uint8_t> ty, as; std::vector<int32_t> l; std::vector<uint32_t> u, v, lv; std::vector<vp_F> c;
+        std::vector<uint64_t> dsz; std::vector<int32_t> dbl; std::vector<std::vector<uint32_t>> did; std::vector<const uint32_t *> dptr;
+    };
+    std::vector<Flat> flat(n);
+    for (int i = 0; i < n; ++i) {
+        const layer &L = C.circuit[i];
+        Flat &f = flat[i];
+        const u64 m = L.size;
+        f.ty.resize(m); f.as.resize(m); f.l.resize(m); f.u.resize(m); f.v.resize(m); f.lv.resize(m);
+        bool any_c = false, any_as = false;
+        for (u64 g = 0; g < m; ++g) {
+            const gate &G = L.gates[g];
+            f.ty[g] = (uint8_t) G.ty; f.l[g] = G.l;
+            f.u[g] = i == 0 ? 0u : (uint32_t) G.u;      // layer 0: u carries the input value, not an index
+            f.v[g] = (uint32_t) G.v; f.lv[g] = (uint32_t) G.lv;
+            f.as[g] = G.is_assert ? 1 : 0;
+            any_as |= G.is_assert;
+            any_c |= (G.ty == Addc || G.ty == Mulc);
+        }
+        if (any_c) {
+            f.c.resize(m);
+            for (u64 g = 0; g < m; ++g) { f.c[g].real = L.gates[g].c.real; f.c[g].img = L.gates[g].c.img; }
+        }
+        f.dsz.assign(L.dadSize.begin(), L.dadSize.end());
+        f.dbl.assign(L.dadBitLength.begin(), L.dadBitLength.end());
+        f.did.resize(L.dadId.size()); f.dptr.resize(L.dadId.size());
+        for (size_t j = 0; j < L.dadId.size(); ++j) {
+            f.did[j].assign(L.dadId[j].begin(), L.dadId[j].end());
+            f.dptr[j] = f.did[j].data();
+        }
+        vp_layer_desc &d = desc[i];
+        d.size = m; d.bit_length = L.bitLength;
+        d.ty = f.ty.data(); d.l = f.l.data(); d.u = f.u.data(); d.v = f.v.data(); d.lv = f.lv.data();
+        d.c = any_c ? f.c.data() : nullptr;
+        d.is_assert = any_as ? f.as.data() : nullptr;
+        d.dad_size = f.dsz.data(); d.dad_bitlen = f.dbl.data(); d.dad_id = f.dptr.data();
+    }
+    check(vp_circuit_upload(ctx, n, desc.data()), "vp_circuit_upload");
+    evaluate();
+}
+
+prover::~prover() { vp_destroy(ctx); }
+
+void prover::evaluate() {      // src/prover.cpp:27-91
+    const layer &L0 = C.circuit[0];
+    std::vector<vp_F> in(L0.size);
+    for (u64 g = 0; g < L0.size; ++g) { F x((long long) L0.gates[g].u); in[g].real = x.real; in[g].img = x.img; }
+    check(vp_evaluate(ctx, in.data(), in.size()), "vp_evaluate");
+}
+
+void prover::init() {          // src/prover.cpp:131-155
+    int max_bl = 0;
+    for (auto &c : C.circuit) max_bl = std::max(max_bl, c.bitLength);
+    r_u.assign(max_bl, F_ZERO);
+    r_liu.assign(max_bl, F_ZERO);
+    r_v.assign(C.size, std::vector<F>());
+    for (int i = 1; i < C.size; ++i)
+        if (C.circuit[i].maxDadBitLength != -1) r_v[i].assign(C.circuit[i].maxDadBitLength, F_ZERO);
+}
+
+F prover::Vres(const std::vector<F>::const_iterator &r_0, int r_0_size) {       // src/prover.cpp:99-129
+    prove_timer.start();
+    F out;
+    check(vp_vres(ctx, cF(&*r_0), r_0_size, mF(&out)), "vp_vres");
+    prove_timer.stop();
+    return out;
+}
+
+void prover::sumcheckInitAll(const std::vector<F>::const_iterator &r_last) {     // src/prover.cpp:162-170
+    prove_timer.start();
+    const int last_bl = C.circuit[C.size - 1].bitLength;
+    sumcheckLayerId = C.size;
+    for (int i = 0; i < last_bl; ++i) r_liu[i] = r_last[i];
+    prove_timer.stop();
+}
+
+void prover::sumcheckInit() { --sumcheckLayerId; }                               // src/prover.cpp:177-184
+
+void prover::sumcheckInitPhase1(const F &assert_random) {                        // src/prover.cpp:189-280
+    prove_timer.start();
+    check(vp_phase1_init(ctx, sumcheckLayerId, cF(r_liu.data()), cF(&assert_random)), "vp_phase1_init");
+    round = 0;
+    prove_timer.stop();
+}
+
+void prover::sumcheckInitPhase2() {                                              // src/prover.cpp:282-367
+    prove_timer.start();
+    check(vp_phase2_init(ctx, sumcheckLayerId, cF(r_u.data())), "vp_phase2_init");
+    round = 0;
+    prove_timer.stop();
+}
+
+void prover::sumcheckInitLiu(std::vector<F>::const_iterator s) {                 // src/prover.cpp:369-420
+    prove_timer.start();
+    std::vector<const vp_F *> rv(C.size, nullptr);
+    for (int k = sumcheckLayerId; k < C.size; ++k) if (!r_v[k].empty()) rv[k] = cF(r_v[k].data());
+    check(vp_liu_init(ctx, sumcheckLayerId, cF(r_u.data()), rv.data(), cF(&*s)), "vp_liu_init");
+    round = 0;
+    prove_timer.stop();
+}
+
+quadratic_poly prover::sumcheckUpdate(const F &previous_random, std::vector<F> &r_arr) {   // src/prover.cpp:436-455
+    prove_timer.start();
+    if (round) r_arr.at(round - 1) = previous_random;
+    ++round;
+    F p[3];
+    check(vp_round(ctx, cF(&previous_random), mF(p)), "vp_round");
+    prove_timer.stop();
+    proof_size += sizeof(F) * 3;
+    return quadratic_poly(p[0], p[1], p[2]);
+}
+quadratic_poly prover::sumcheckUpdatePhase1(const F &r) { return sumcheckUpdate(r, r_u); }
+quadratic_poly prover::sumcheckUpdatePhase2(const F &r) { return sumcheckUpdate(r, r_v[sumcheckLayerId]); }
+quadratic_poly prover::sumcheckLiuUpdate(const F &r) { return sumcheckUpdate(r, r_liu); }
+
+void prover::sumcheckFinalize1(const F &previousRandom, F &claim) {              // src/prover.cpp:494-501
+    prove_timer.start();
+    if (round) r_u[round - 1] = previousRandom;
+    check(vp_finalize(ctx, cF(&previousRandom), mF(&claim), 1), "vp_finalize");
+    prove_timer.stop();
+    proof_size += sizeof(F);
+}
+
+void prover::sumcheckFinalize2(const F &previousRandom, std::vector<F>::iterator claims) {   // src/prover.cpp:504-516
+    prove_timer.start();
+    if (round) r_v[sumcheckLayerId][round - 1] = previousRandom;
+    std::vector<F> tmp(sumcheckLayerId);
+    check(vp_finalize(ctx, cF(&previousRandom), mF(tmp.data()), sumcheckLayerId), "vp_finalize");
+    for (int i = 0; i < sumcheckLayerId; ++i) claims[i] = tmp[i];
+    proof_size += sizeof(F) * sumcheckLayerId;
+    prove_timer.stop();
+}
+
+void prover::sumcheckLiuFinalize(const F &previousRandom, F &claim) {            // src/prover.cpp:518-521
+    if (round) r_liu[round - 1] = previousRandom;
+    check(vp_finalize(ctx, cF(&previousRandom), mF(&claim), 1), "vp_finalize");
+}
+
+void prover::gkrSizes(u64 &n_tape, u64 &n_bytes) {
+    uint64_t a = 0, b = 0;
+    check(vp_gkr_sizes(ctx, &a, &b), "vp_gkr_sizes");
+    n_tape = a; n_bytes = b;
+}
+
+void prover::proveGKR(const std::vector<F> &tape, std::vector<uint8_t> &transcript) {
+    u64 nt, nb;
+    gkrSizes(nt, nb);
+    if (tape.size() != nt) throw std::runtime_error("proveGKR: tape has the wrong length");
+    const size_t at = transcript.size();
+    transcript.resize(at + nb);
+    uint64_t written = 0;
+    prove_timer.start();
+    check(vp_prove_gkr(ctx, cF(tape.data()), nt, transcript.data() + at, nb, &written), "vp_prove_gkr");
+    prove_timer.stop();
+    transcript.resize(at + written);
+}
+
+std::vector<F> prover::layerValues(int layer) {
+    std::vector<F> out(C.circuit[layer].size);
+    check(vp_layer_values(ctx, layer, mF(out.data()), out.size()), "vp_layer_values");
+    return out;
+}
+
+vp_stats prover::stats() {
+    vp_stats s{};
+    check(vp_get_stats(ctx, &s), "vp_get_stats");
+    return s;
+}

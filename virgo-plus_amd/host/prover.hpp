@@ -1,0 +1,75 @@
+// Host mirror of the reference's `class prover` (src/prover.h:12-66): same method names, argument
+// meaning and call-order contract, so the verifier below (and the reference's own verifier.cpp, see
+// INTEGRATION.md) can drive it unchanged.  Every sumcheck method forwards to the C ABI of
+// libvpgpu.so (include/vpgpu.h); no arithmetic on tables happens on the host and there is no CPU
+// fallback: construction throws if the device library cannot run.
+#pragma once
+#include <chrono>
+#include <stdexcept>
+#include <vector>
+
+#include "../../include/vpgpu.h"
+#include "circuit.hpp"
+#include "polynomial.hpp"
+
+class timer {          // accumulate semantics of lib/virgo/src/timer.hpp:11-25
+public:
+    void start() { t0 = std::chrono::high_resolution_clock::now(); }
+    void stop() { total += std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count(); }
+    void clear() { total = 0; }
+    double elapse_sec() const { return total; }
+private:
+    std::chrono::high_resolution_clock::time_point t0;
+    double total = 0;
+};
+
+class prover {
+public:
+    explicit prover(const layeredCircuit &cir, int device = 0);
+    ~prover();
+    prover(const prover &) = delete;
+    prover &operator=(const prover &) = delete;
+
+    void evaluate();
+    void init();
+    void sumcheckInitAll(const std::vector<F>::const_iterator &r_last);
+    void sumcheckInit();
+    void sumcheckInitPhase1(const F &assert_random);
+    void sumcheckInitPhase2();
+    void sumcheckInitLiu(std::vector<F>::const_iterator s);
+
+    quadratic_poly sumcheckUpdatePhase1(const F &previousRandom);
+    quadratic_poly sumcheckUpdatePhase2(const F &previousRandom);
+    quadratic_poly sumcheckLiuUpdate(const F &previousRandom);
+
+    void sumcheckFinalize1(const F &previousRandom, F &claim);
+    void sumcheckFinalize2(const F &previousRandom, std::vector<F>::iterator claims);
+    void sumcheckLiuFinalize(const F &previousRandom, F &claim);
+
+    F Vres(const std::vector<F>::const_iterator &r_0, int r_0_size);
+
+    double proveTime() const { return prove_timer.elapse_sec(); }
+    double proofSize() const { return (double) proof_size / 1024.0; }
+
+    // ---- extensions (not in the reference) ----
+    // Whole GKR part in one device pass; tape = the verifier's draws in its own order
+    // (layout in include/vpgpu.h).  Appends the messages to `transcript`.
+    void proveGKR(const std::vector<F> &tape, std::vector<uint8_t> &transcript);
+    void gkrSizes(u64 &n_tape, u64 &n_transcript_bytes);
+    std::vector<F> layerValues(int layer);
+    vp_ctx *context() { return ctx; }
+    vp_stats stats();
+
+private:
+    quadratic_poly sumcheckUpdate(const F &previous_random, std::vector<F> &r_arr);
+    void check(int rc, const char *what);
+
+    const layeredCircuit &C;
+    vp_ctx *ctx = nullptr;
+    std::vector<F> r_u, r_liu;
+    std::vector<std::vector<F>> r_v;
+    int round = 0;
+    int sumcheckLayerId = 0;
+    timer prove_timer;
+    u64 proof_size = 0;
+};

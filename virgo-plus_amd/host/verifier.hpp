@@ -1,0 +1,65 @@
+// Host verifier: the caller the drop-in prover must satisfy (reference: src/verifier.h, src/verifier.cpp).
+// It stays plain host C++ ("OUT OF SCOPE as a GPU target").  Two ways to run it:
+//   verify()            interactive, exactly the reference's call sequence into `prover` (verifier.cpp:134-169):
+//                       challenges are drawn with F::random() as the prover's messages arrive;
+//   drawTape()+check()  the same checks replayed over a recorded transcript produced by
+//                       prover::proveGKR from a pre-drawn tape (the challenges do not depend on the
+//                       transcript: lib/virgo/src/fieldElement.cpp:119-124).
+// Both record the prover's messages in the golden transcript layout (GKR slice).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "circuit.hpp"
+#include "polynomial.hpp"
+#include "prover.hpp"
+
+class verifier {
+public:
+    verifier(prover *pr, const layeredCircuit &cir);
+
+    bool verify();                                              // interactive (needs pr != nullptr)
+    std::vector<F> drawTape();                                  // the verifier's draws, in its own order
+    bool check(const std::vector<F> &tape, const std::vector<uint8_t> &transcript);   // replay
+
+    const std::vector<uint8_t> &transcript() const { return tr; }
+    const std::vector<F> &tape() const { return tape_; }
+    double verifyTime() const { return verify_timer.elapse_sec(); }
+    bool skip_predicates = false;      // replay only: skip the O(|C|) wiring-predicate check (getFinalValue)
+
+private:
+    bool run();
+    bool verifyPhase1(int layer_id, F &previousSum);
+    bool verifyPhase2(int layer_id, F &previousSum);
+    bool verifyLiu(int layer_id, F &previousSum);
+    void predicatePhase1(int layer_id);
+    void predicatePhase2(int layer_id);
+    F getFinalValue(int layer_id, const F &claim_u, const std::vector<F> &claim_v);
+    bool checkInput(const F &claim);
+
+    F draw();
+    quadratic_poly nextPoly(int phase, const F &prev);
+    F nextF();
+    void putF(const F &x);
+
+    prover *p;
+    const layeredCircuit &C;
+    bool replay = false;
+    const std::vector<F> *rtape = nullptr;
+    const std::vector<uint8_t> *rtr = nullptr;
+    size_t tape_pos = 0, tr_pos = 0;
+    std::vector<F> tape_;
+    std::vector<uint8_t> tr;
+
+    int max_bl = 0;
+    std::vector<F> beta_g, beta_u, beta_v, r_u, r_liu, sig;
+    std::vector<std::vector<F>> r_v;
+    F coeff_l[(int) gateType::SIZE];
+    std::vector<F> coeff_r[(int) gateType::SIZE];
+    F bias, final_claim_u;
+    std::vector<std::vector<F>> final_claims_v;
+    timer verify_timer;
+};
+
+// eq table (reference: src/utils.cpp:29-45), host version used by the verifier only
+void initBetaTable(std::vector<F> &beta_g, int gLength, const std::vector<F>::const_iterator &r, const F &init);

@@ -1,0 +1,157 @@
+#include "vphost.h"
+
+#include <cstring>
+#include <memory>
+#include <string>
+
+#include "circuit.hpp"
+#include "prover.hpp"
+#include "verifier.hpp"
+
+struct vph_circuit { layeredCircuit c; };
+struct vph_session {
+    vph_circuit *circ;
+    std::unique_ptr<prover> p;
+    std::vector<F> tape;
+};
+
+static void set_err(char *err, int errlen, const std::string &m) {
+    if (err && errlen > 0) { strncpy(err, m.c_str(), errlen - 1); err[errlen - 1] = 0; }
+}
+
+extern "C" {
+
+vph_circuit *vph_circuit_from_pws(const char *path, int blocks, long seed, char *err, int errlen) {
+    if (!path || blocks < 1) { set_err(err, errlen, "bad arguments"); return nullptr; }
+    if (seed >= 0) srandom((unsigned) seed);
+    std::vector<DAG_gate> dag;
+    std::string e;
+    if (!vph::parse_pws(path, blocks, dag, &e)) { set_err(err, errlen, e); return nullptr; }
+    vph_circuit *vc = new vph_circuit();
+    vc->c = vph::DAG_to_layered(dag);
+    vc->c.subsetInit();
+    return vc;
+}
+vph_circuit *vph_circuit_randomize(int layers, int log_size, long seed) {
+    if (layers < 2 || log_size < 0 || log_size > 28) return nullptr;
+    if (seed >= 0) srandom((unsigned) seed);
+    vph_circuit *vc = new vph_circuit();
+    vc->c = layeredCircuit::randomize(layers, log_size);
+    vc->c.subsetInit();
+    return vc;
+}
+void vph_circuit_free(vph_circuit *c) { delete c; }
+int vph_circuit_layers(const vph_circuit *c) { return c->c.size; }
+uint64_t vph_circuit_gates(const vph_circuit *c) { u64 n = 0; for (auto &l : c->c.circuit) n += l.size; return n; }
+uint64_t vph_circuit_layer_size(const vph_circuit *c, int layer) { return c->c.circuit[layer].size; }
+int vph_circuit_layer_bitlen(const vph_circuit *c, int layer) { return c->c.circuit[layer].bitLength; }
+void vph_circuit_hash(const vph_circuit *c, uint64_t out[2]) { u64 h[2]; c->c.structuralHash(h); out[0] = h[0]; out[1] = h[1]; }
+
+vph_session *vph_session_create(vph_circuit *c, int device, char *err, int errlen) {
+    if (!c) { set_err(err, errlen, "null circuit"); return nullptr; }
+    try {
+        std::unique_ptr<vph_session> s(new vph_session());
+        s->circ = c;
+        s->p.reset(new prover(c->c, device));
+        return s.release();
+    } catch (const std::exception &e) {
+        set_err(err, errlen, e.what());
+        return nullptr;
+    }
+}
+void vph_session_free(vph_session *s) { delete s; }
+int vph_set_profiling(vph_session *s, int level) { return vp_set_profiling(s->p->context(), level); }
+
+int vph_layer_values(vph_session *s, int layer, uint64_t *out, uint64_t n) {
+    try {
+        std::vector<F> v = s->p->layerValues(layer);
+        if (n > v.size()) return -1;
+        for (u64 i = 0; i < n; ++i) { out[2 * i] = v[i].real; out[2 * i + 1] = v[i].img; }
+        return 0;
+    } catch (const std::exception &) { return -2; }
+}
+
+static void fill(vph_result *res, prover &p, double prove_sec, double verify_sec, bool ok) {
+    if (!res) return;
+    vp_stats st = p.stats();
+    res->prove_sec = prove_sec; res->gkr_device_ms = st.gkr_ms; res->evaluate_ms = st.evaluate_ms;
+    res->verify_sec = verify_sec; res->fold_ms = st.fold_ms; res->fold_launches = st.fold_launches;
+    res->fold_bytes = st.fold_bytes; res->rounds = st.rounds; res->launches = st.launches;
+    res->proof_kb = p.proofSize(); res->verified = ok ? 1 : 0;
+}
+
+int vph_prove_interactive(vph_session *s, uint8_t *transcript, uint64_t capacity, uint64_t *n_written, vph_result *res,
+                          char *err, int errlen) {
+    try {
+        F::init();
+        verifier v(s->p.get(), s->circ->c);
+        const double t0 = s->p->proveTime();
+        const bool ok = v.verify();
+        const auto &tr = v.transcript();
+        if (tr.size() > capacity) { set_err(err, errlen, "transcript buffer too small"); return -1; }
+        memcpy(transcript, tr.data(), tr.size());
+        if (n_written) *n_written = tr.size();
+        fill(res, *s->p, s->p->proveTime() - t0, v.verifyTime(), ok);
+        return ok ? 0 : 1;
+    } catch (const std::exception &e) {
+        set_err(err, errlen, e.what());
+        return -2;
+    }
+}
+
+int vph_draw_tape(vph_session *s) {
+    F::init();
+    verifier v(nullptr, s->circ->c);
+    s->tape = v.drawTape();
+    return 0;
+}
+
+int vph_prove_gkr(vph_session *s, uint8_t *transcript, uint64_t capacity, uint64_t *n_written, vph_result *res, char *err,
+                  int errlen) {
+    try {
+        if (s->tape.empty()) vph_draw_tape(s);
+        std::vector<uint8_t> tr;
+        const double t0 = s->p->proveTime();
+        s->p->proveGKR(s->tape, tr);
+        if (tr.size() > capacity) { set_err(err, errlen, "transcript buffer too small"); return -1; }
+        memcpy(transcript, tr.data(), tr.size());
+        if (n_written) *n_written = tr.size();
+        fill(res, *s->p, s->p->proveTime() - t0, 0, false);
+        return 0;
+    } catch (const std::exception &e) {
+        set_err(err, errlen, e.what());
+        return -2;
+    }
+}
+
+int vph_check(vph_session *s, const uint8_t *transcript, uint64_t n, int skip_predicates, double *verify_sec) {
+    try {
+        verifier v(nullptr, s->circ->c);
+        v.skip_predicates = skip_predicates != 0;
+        std::vector<uint8_t> tr(transcript, transcript + n);
+        timer t; t.start();
+        const bool ok = v.check(s->tape, tr);
+        t.stop();
+        if (verify_sec) *verify_sec = t.elapse_sec();
+        return ok ? 0 : 1;
+    } catch (const std::exception &) { return -2; }
+}
+
+int vph_verify_transcript(vph_circuit *c, const uint8_t *transcript, uint64_t n, int skip_predicates) {
+    try {
+        F::init();
+        verifier v(nullptr, c->c);
+        const std::vector<F> tape = v.drawTape();
+        v.skip_predicates = skip_predicates != 0;
+        std::vector<uint8_t> tr(transcript, transcript + n);
+        return v.check(tape, tr) ? 0 : 1;
+    } catch (const std::exception &) { return 1; }
+}
+
+uint64_t vph_transcript_bytes(vph_session *s) {
+    u64 a = 0, b = 0;
+    s->p->gkrSizes(a, b);
+    return b;
+}
+
+}  // extern "C"

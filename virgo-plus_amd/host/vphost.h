@@ -1,0 +1,65 @@
+/* vphost.h — C entry points of libvphost.so for the Python harness (tests/, bench.py) and other FFI
+ * users: circuit loading, one prover session per GPU, interactive and batched GKR proofs.  Everything
+ * here is host orchestration; the arithmetic runs in libvpgpu.so (include/vpgpu.h).                  */
+#ifndef VPHOST_H
+#define VPHOST_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vph_circuit vph_circuit;
+typedef struct vph_session vph_session;
+
+typedef struct {
+    double prove_sec;        /* reference "Prove Time" definition: host wall clock over the prover-method spans */
+    double gkr_device_ms;    /* hipEvent time of the batched device pass (0 for interactive)                   */
+    double evaluate_ms;      /* device time of circuit evaluation                                              */
+    double verify_sec;       /* host verifier time                                                             */
+    double fold_ms;          /* profiled dominant-kernel launches: total duration ...                          */
+    uint64_t fold_launches;  /* ... count ...                                                                  */
+    uint64_t fold_bytes;     /* ... and algorithmic bytes                                      */
+    uint64_t rounds;
+    uint64_t launches;
+    double proof_kb;
+    int verified;
+} vph_result;
+
+/* seed < 0: keep the process's current glibc random() state (default seed 1 in a fresh process);
+ * else srandom(seed) before the witness is drawn (src/main.cpp:188).                                 */
+vph_circuit *vph_circuit_from_pws(const char *path, int blocks, long seed, char *err, int errlen);
+vph_circuit *vph_circuit_randomize(int layers, int log_size, long seed);
+void vph_circuit_free(vph_circuit *);
+int vph_circuit_layers(const vph_circuit *);
+uint64_t vph_circuit_gates(const vph_circuit *);
+uint64_t vph_circuit_layer_size(const vph_circuit *, int layer);
+int vph_circuit_layer_bitlen(const vph_circuit *, int layer);
+void vph_circuit_hash(const vph_circuit *, uint64_t out[2]);
+
+/* Uploads the circuit to `device` and evaluates it there.  NULL + message on failure (no CPU fallback). */
+vph_session *vph_session_create(vph_circuit *, int device, char *err, int errlen);
+void vph_session_free(vph_session *);
+int vph_set_profiling(vph_session *, int level);
+/* circuitValue[layer] copied back (tests).                                                             */
+int vph_layer_values(vph_session *, int layer, uint64_t *out_pairs, uint64_t n);
+
+/* F::init() (srand(3396)) + verifier::verify(): one device round trip per sumcheck round.              */
+int vph_prove_interactive(vph_session *, uint8_t *transcript, uint64_t capacity, uint64_t *n_written,
+                          vph_result *res, char *err, int errlen);
+/* F::init() + draw the verifier tape once; it stays attached to the session.                           */
+int vph_draw_tape(vph_session *);
+/* One batched GKR proof from the attached tape (a bench "step").                                       */
+int vph_prove_gkr(vph_session *, uint8_t *transcript, uint64_t capacity, uint64_t *n_written, vph_result *res,
+                  char *err, int errlen);
+/* Host verifier replay over a transcript made from the attached tape.  skip_predicates=1 skips the
+ * O(|C|) wiring-predicate sums (the sumcheck and Liu checks still run).                                */
+int vph_check(vph_session *, const uint8_t *transcript, uint64_t n, int skip_predicates, double *verify_sec);
+uint64_t vph_transcript_bytes(vph_session *);
+/* No GPU needed: F::init(), draw the tape for `circuit`, replay the host verifier over `transcript`
+ * (GKR slice).  0 = accepted, 1 = rejected.                                                            */
+int vph_verify_transcript(vph_circuit *, const uint8_t *transcript, uint64_t n, int skip_predicates);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
