@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark: GKR prover seconds and field-ops/s on the SHA-256 64-block circuit
+(BASELINE.json configs[1]: "SHA-256 64-block circuit, 1xMI355X, sumcheck rounds on GPU, Virgo PC off").
+
+A step = one complete GKR proof (Vres + three sumchecks per layer, 691 rounds) by the device prover, with
+the circuit, the witness and the verifier tape already resident in HBM.  Each rank proves its own instance
+(rank r draws its witness after srandom(1 + r); rank 0's instance is the golden one), so N GPUs produce N
+independent proofs per step with no data-path collective ("scaling": "weak").  Rank 0's transcript is
+compared byte for byte with the real reference's golden transcript on every run.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--blocks B] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import gzip
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def dist_setup(n_gpus):
+    """One process per GPU.  The data path has no collective (independent proofs per rank); the control
+    plane (barriers, max-over-ranks of the elapsed time) runs over torch.distributed/gloo."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    return world, rank, local
+
+
+def barrier(world):
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+
+
+def aggregate(world, elapsed, units):
+    """(max elapsed over ranks, total units over ranks)."""
+    if world == 1:
+        return elapsed, units
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([elapsed], dtype=torch.float64)
+    u = torch.tensor([units], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(u, op=dist.ReduceOp.SUM)
+    return float(t.item()), float(u.item())
+
+
+def gpu_sync(device):
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.synchronize(device)
+
+
+def unpack_pws(tmpdir):
+    p = os.path.join(tmpdir, "SHA256_64.pws")
+    with gzip.open(os.path.join(ROOT, "tests", "golden", "SHA256_64.pws.gz"), "rb") as f, open(p, "wb") as g:
+        g.write(f.read())
+    return p
+
+
+def cpu_baseline(pws, blocks, ref_ops):
+    """The reference's CPU prover on this box's host cores (single thread: the reference has no threading).
+    Prefers the REAL reference binary (oracle/_ref/ref_run, built from /root/reference in the build
+    container); falls back to the repo's restatement (oracle/, bit-identical by tests/test_oracle_golden.py)."""
+    ref_run = os.path.join(ROOT, "oracle", "_ref", "ref_run")
+    sample = "one full GKR proof of the same %d-block circuit (PC off), single thread" % blocks
+    if os.path.exists(ref_run):
+        try:
+            out = subprocess.run([ref_run, "--pws", pws, "--blocks", str(blocks), "--pc", "0"], stdout=subprocess.PIPE,
+                                 stderr=subprocess.DEVNULL, text=True, timeout=600)
+            m = re.search(r"Prove Time ([0-9.]+)", out.stdout)
+            c = re.search(r"mult counter (-?\d+), add counter (-?\d+)", out.stdout)
+            if out.returncode == 0 and m and c:
+                sec = float(m.group(1))
+                ops = int(c.group(1)) + int(c.group(2))
+                return {"value": ops / sec, "unit": "field-ops/s", "cores": 1, "kind": "reference", "sample": sample,
+                        "prover_sec": sec, "field_ops": ops}
+        except Exception:
+            pass
+    import oracle_binding as ob
+    c = ob.Circuit.from_pws(pws, blocks, seed=1)
+    _, st = c.prove_gkr()
+    c.close()
+    ops = st["mult_count"] + st["add_count"]
+    return {"value": ops / st["prove_sec"], "unit": "field-ops/s", "cores": 1, "kind": "port", "sample": sample,
+            "prover_sec": st["prove_sec"], "field_ops": ops}
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--blocks", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world, rank, local = dist_setup(a.gpus)
+    import vp_loader
+    vp = vp_loader.load()
+    vp.build()
+    golden = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))
+    gname = "sha256_x%d" % a.blocks
+    with tempfile.TemporaryDirectory() as tmp:
+        pws = unpack_pws(tmp)
+        circ = vp.Circuit.from_pws(pws, a.blocks, seed=1 + rank)
+        sess = vp.Session(circ, device=local)            # raises without the HIP library / GPU
+        sess.draw_tape()
+        for _ in range(a.warmup):
+            sess.prove_gkr()
+        gpu_sync(local)
+        barrier(world)
+        t0 = time.perf_counter()
+        dev_ms = 0.0
+        res = None
+        for k in range(a.steps):
+            if k == a.steps - 1:
+                sess.set_profiling(1)                    # HIP events around the dominant kernel, last timed step
+            tr, res = sess.prove_gkr()
+            dev_ms += res["gkr_device_ms"]
+        gpu_sync(local)
+        barrier(world)
+        elapsed = time.perf_counter() - t0
+        sess.set_profiling(0)
+        elapsed, proofs = aggregate(world, elapsed, float(a.steps))
+
+        bit_exact = None
+        ref_ops = None
+        if gname in golden:
+            g = golden[gname]
+            ref_ops = g["mult_counter"] + g["add_counter"]
+            if rank == 0:
+                gold = open(os.path.join(ROOT, "tests", "golden", g["transcript"]), "rb").read()[g["gkr_slice"][0]:g["gkr_slice"][1]]
+                bit_exact = (tr == gold)
+        ok, _ = sess.check(tr, skip_predicates=True)
+
+        if rank == 0:
+            sec_per_proof_job = elapsed / a.steps                      # wall time of one step (all ranks in parallel)
+            ops_total = (ref_ops or 0) * proofs
+            line = {
+                "metric": "prover sec + field-ops/sec, SHA-256 circuit, 1/2/4/8 MI355X (bit-exact)",
+                "value": ops_total / elapsed if ref_ops else None,
+                "unit": "field-ops/s",
+                "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                "ms_per_step": 1e3 * sec_per_proof_job,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "u64 (F_p^2, p=2^61-1)", "data": "synthetic",
+                "config": {"workload": "SHA-256 %d-block circuit (SHA256_64.pws x%d, %d gates, %d layers), GKR sumcheck on GPU, Virgo PC off"
+                                       % (a.blocks, a.blocks, circ.gates, circ.layers),
+                           "mode": "batched (verifier tape pre-drawn; transcript identical to the interactive run)",
+                           "proofs_per_step": world, "field_ops_per_proof": ref_ops},
+                "prover_sec": sec_per_proof_job,
+                "prover_sec_device": 1e-3 * dev_ms / a.steps,
+                "rounds": res["rounds"], "kernel_launches_per_proof": res["launches"],
+                "bit_exact_vs_reference_golden": bit_exact, "host_verifier_accepts": ok,
+            }
+            if res["fold_launches"]:
+                avg_ms = res["fold_ms"] / res["fold_launches"]
+                gbps = res["fold_bytes"] / (res["fold_ms"] * 1e-3) / 1e9
+                line["roofline"] = {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                    "frac": gbps / HBM_PEAK_GBPS, "traffic": None,
+                                    "kernel": "k_round_main (launches with >= 32768 pairs)",
+                                    "launches": res["fold_launches"], "avg_launch_us": 1e3 * avg_ms,
+                                    "algorithmic_bytes_per_launch": res["fold_bytes"] / res["fold_launches"]}
+            else:
+                line["roofline"] = None
+            if world == 1 and not a.no_cpu_baseline:
+                cb = cpu_baseline(pws, a.blocks, ref_ops)
+                cb["host_cpu"] = cpu_model()
+                cb["host_cores_visible"] = os.cpu_count()
+                line["cpu_baseline"] = cb
+            print(json.dumps(line), flush=True)
+        sess.close()
+        circ.close()
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -618,7 +618,7 @@ struct Prover {
 
     void sumcheckFinalize1(const F &prev, F &claim) {                // prover.cpp:494-501
         prove_timer.start();
-        r_u[round - 1] = prev;
+        if (round) r_u[round - 1] = prev;   // the reference writes r_u[-1] here when layer i-1 has one gate (UB); skipped
         V_u = claim = total[0] ? Vmult[0][0].eval(prev) : Vmult[0][0].b;
         prove_timer.stop();
         proof_size += 16;

@@ -292,9 +292,11 @@ int do_round(vp_ctx *ctx, const F *rp, const F &rv, F *poly_dev, F *poly_host) {
     u32 grid = 0;
     if (pairs) {
         grid = grid_for(pairs);
-        const bool prof = ctx->profiling && pairs >= 32768 && ctx->ev_used < ctx->ev_pool.size();
+        const bool big = pairs >= VP_BIG_PAIRS;
+        const bool prof = ctx->profiling && big && ctx->ev_used < ctx->ev_pool.size();
         if (prof) hipEventRecord(ctx->ev_pool[ctx->ev_used].a, ctx->stream);
-        hipLaunchKernelGGL(k_round_main, dim3(grid), dim3(VP_BLOCK), 0, ctx->stream, a, ctx->partials);
+        if (big) hipLaunchKernelGGL(k_round_main<1>, dim3(grid), dim3(VP_BLOCK), 0, ctx->stream, a, ctx->partials);
+        else hipLaunchKernelGGL(k_round_main<0>, dim3(grid), dim3(VP_BLOCK), 0, ctx->stream, a, ctx->partials);
         if (prof) { hipEventRecord(ctx->ev_pool[ctx->ev_used].b, ctx->stream); ctx->ev_pool[ctx->ev_used++].bytes = bytes; }
         count_launch(ctx);
     }
