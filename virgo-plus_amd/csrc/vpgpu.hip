@@ -581,7 +581,7 @@ static int stage(vp_ctx *ctx, u64 off, const vp_F *src, u64 n) {
 }
 
 int vp_vres(vp_ctx *ctx, const vp_F *r_0, int r_0_size, vp_F *out) {
-    if (!ctx || !ctx->evaluated || !r_0 || !out || r_0_size != ctx->L[ctx->n_layers - 1].bl) return VP_EINVAL;
+    if (!ctx || !ctx->evaluated || !out || r_0_size != ctx->L[ctx->n_layers - 1].bl || (r_0_size && !r_0)) return VP_EINVAL;
     HIPCHK(hipSetDevice(ctx->device));
     VPCHK(stage(ctx, 0, r_0, r_0_size));
     LayerDev &T = ctx->L[ctx->n_layers - 1];
@@ -594,7 +594,8 @@ int vp_vres(vp_ctx *ctx, const vp_F *r_0, int r_0_size, vp_F *out) {
 }
 
 int vp_phase1_init(vp_ctx *ctx, int layer, const vp_F *r_liu, const vp_F *assert_random) {
-    if (!ctx || !ctx->evaluated || layer < 1 || layer >= ctx->n_layers || !r_liu || !assert_random) return VP_EINVAL;
+    if (!ctx || !ctx->evaluated || layer < 1 || layer >= ctx->n_layers || !assert_random) return VP_EINVAL;
+    if (ctx->L[layer].bl && !r_liu) return VP_EINVAL;
     HIPCHK(hipSetDevice(ctx->device));
     const u64 off = layer == ctx->n_layers - 1 ? 0 : ctx->rliu_off[layer + 1];
     VPCHK(stage(ctx, off, r_liu, ctx->L[layer].bl));
@@ -604,7 +605,8 @@ int vp_phase1_init(vp_ctx *ctx, int layer, const vp_F *r_liu, const vp_F *assert
 }
 
 int vp_phase2_init(vp_ctx *ctx, int layer, const vp_F *r_u) {
-    if (!ctx || !ctx->evaluated || layer < 1 || layer >= ctx->n_layers || !r_u) return VP_EINVAL;
+    if (!ctx || !ctx->evaluated || layer < 1 || layer >= ctx->n_layers) return VP_EINVAL;
+    if (ctx->L[layer - 1].bl && !r_u) return VP_EINVAL;
     if (ctx->sc.layer != layer || ctx->L[layer].max_dad_bl == -1) { ctx->err = "phase2 out of order"; return VP_EINVAL; }
     HIPCHK(hipSetDevice(ctx->device));
     VPCHK(stage(ctx, ctx->ru_off[layer], r_u, ctx->L[layer - 1].bl));
@@ -613,7 +615,8 @@ int vp_phase2_init(vp_ctx *ctx, int layer, const vp_F *r_u) {
 }
 
 int vp_liu_init(vp_ctx *ctx, int layer, const vp_F *r_u, const vp_F *const *r_v, const vp_F *s) {
-    if (!ctx || !ctx->evaluated || layer < 1 || layer >= ctx->n_layers || !r_u || !s) return VP_EINVAL;
+    if (!ctx || !ctx->evaluated || layer < 1 || layer >= ctx->n_layers || !s) return VP_EINVAL;
+    if (ctx->L[layer - 1].bl && !r_u) return VP_EINVAL;
     HIPCHK(hipSetDevice(ctx->device));
     const int n = ctx->n_layers;
     VPCHK(stage(ctx, ctx->ru_off[layer], r_u, ctx->L[layer - 1].bl));

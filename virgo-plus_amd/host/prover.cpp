@@ -83,7 +83,7 @@ void prover::init() {          // src/prover.cpp:131-155
 F prover::Vres(const std::vector<F>::const_iterator &r_0, int r_0_size) {       // src/prover.cpp:99-129
     prove_timer.start();
     F out;
-    check(vp_vres(ctx, cF(&*r_0), r_0_size, mF(&out)), "vp_vres");
+    check(vp_vres(ctx, r_0_size ? cF(&*r_0) : nullptr, r_0_size, mF(&out)), "vp_vres");
     prove_timer.stop();
     return out;
 }
