@@ -622,7 +622,7 @@ int vp_liu_init(vp_ctx *ctx, int layer, const vp_F *r_u, const vp_F *const *r_v,
     VPCHK(stage(ctx, ctx->ru_off[layer], r_u, ctx->L[layer - 1].bl));
     VPCHK(stage(ctx, ctx->sig_off[layer], s, n - layer + 1));
     for (int k = layer; k < n; ++k)
-        if (ctx->L[k].dad_size[layer - 1]) {
+        if (ctx->L[k].dad_size[layer - 1] && ctx->L[k].dad_bl[layer - 1]) {
             if (!r_v || !r_v[k]) return VP_EINVAL;
             VPCHK(stage(ctx, ctx->rv_off[k], r_v[k], ctx->L[k].dad_bl[layer - 1]));
         }
