@@ -67,6 +67,18 @@ def _both_modes(vp, c, gold):
     tr3, _ = s.prove_gkr()            # idempotent: a second pass over the same resident state
     assert tr3 == gold
     s.close()
+    # the alternative batched drivers (per-round launches; shuffle-fold + single-CU tail) must agree
+    import os
+    for path in ("simple", "sumfold"):
+        os.environ["VP_GKR_PATH"] = path
+        try:
+            s2 = vp.Session(c)
+            s2.draw_tape()
+            tr4, res4 = s2.prove_gkr()
+            s2.close()
+        finally:
+            del os.environ["VP_GKR_PATH"]
+        assert tr4 == gold, path + " batched transcript differs"
     return res, res2
 
 

@@ -27,15 +27,37 @@ __device__ __forceinline__ F ldF(const F *p) { return *p; }
 // ---------------------------------------------------------------------------------------------------
 // wave / block reductions of field elements (exact: field addition is associative on canonical values)
 // ---------------------------------------------------------------------------------------------------
+// DPP data movement (no LDS round trip): row_shr:n within rows of 16 lanes, then row_bcast:15 / :31.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ u64 dpp_u64(u64 v) {
+    const u32 lo = __builtin_amdgcn_update_dpp(0u, (u32) v, CTRL, ROW_MASK, 0xf, false);
+    const u32 hi = __builtin_amdgcn_update_dpp(0u, (u32) (v >> 32), CTRL, ROW_MASK, 0xf, false);
+    return ((u64) hi << 32) | lo;
+}
+__device__ __forceinline__ u64 m_fold(u64 s) {          // any u64 -> [0, p)
+    s = (s & P61) + (s >> 61);
+    return s >= P61 ? s - P61 : s;
+}
+// Wave-wide sum of canonical field elements; the total lands in LANE 63.  Up to 8 canonical limbs fit a u64
+// unreduced (8 * (2^61 - 1) < 2^64), so three butterfly steps are plain 64-bit adds followed by one fold.
+__device__ __forceinline__ F wave_sum63(F x) {
+    u64 a = x.re, b = x.im;
+    a += dpp_u64<0x111, 0xf>(a); b += dpp_u64<0x111, 0xf>(b);      // row_shr:1
+    a += dpp_u64<0x112, 0xf>(a); b += dpp_u64<0x112, 0xf>(b);      // row_shr:2
+    a += dpp_u64<0x114, 0xf>(a); b += dpp_u64<0x114, 0xf>(b);      // row_shr:4
+    a = m_fold(a); b = m_fold(b);
+    a += dpp_u64<0x118, 0xf>(a); b += dpp_u64<0x118, 0xf>(b);      // row_shr:8   -> lane 15 of each row = row total
+    a += dpp_u64<0x142, 0xa>(a); b += dpp_u64<0x142, 0xa>(b);      // row_bcast:15 into rows 1 and 3
+    a += dpp_u64<0x143, 0xc>(a); b += dpp_u64<0x143, 0xc>(b);      // row_bcast:31 into rows 2 and 3
+    return f_make(m_fold(a), m_fold(b));
+}
+// Same, result broadcast to every lane (readlane 63).
 __device__ __forceinline__ F wave_sum(F x) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        F y;
-        y.re = __shfl_down(x.re, d, 64);
-        y.im = __shfl_down(x.im, d, 64);
-        x = f_add(x, y);
-    }
-    return x;   // lane 0 holds the sum
+    const F t = wave_sum63(x);
+    F r;
+    r.re = ((u64) __builtin_amdgcn_readlane((u32) (t.re >> 32), 63) << 32) | (u32) __builtin_amdgcn_readlane((u32) t.re, 63);
+    r.im = ((u64) __builtin_amdgcn_readlane((u32) (t.im >> 32), 63) << 32) | (u32) __builtin_amdgcn_readlane((u32) t.im, 63);
+    return r;   // every lane holds the sum
 }
 
 // Sum N field elements per thread over a 256-thread block; result valid in thread 0.
@@ -197,7 +219,7 @@ __device__ __forceinline__ void contrib(const InitArgs &a, u32 e, F &m, F &ad) {
     const u32 g = a.e_g[e];
     const u32 x = a.e_x[e];
     const u32 tl = a.e_tl[e];
-    const int ty = tl >> 8;
+    const int ty = (tl >> 8) & 0x7f;                             // bit 15 marks assert gates (batched path)
     if (PHASE == 1) {
         const F t = a.beta_g[g];
         const int l = tl & 0xff;
@@ -489,6 +511,709 @@ __global__ void k_test_field(int op, const F *__restrict__ a, const F *__restric
     u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     o[i] = op == 0 ? f_add(a[i], b[i]) : op == 1 ? f_sub(a[i], b[i]) : f_mul(a[i], b[i]);
+}
+
+}  // namespace vp
+
+// ===================================================================================================
+// Batched path (vp_prove_gkr): every challenge is on the device tape, so one launch can cover several
+// rounds and whole sumcheck tails.  Same field values as the per-round kernels above, fewer bytes
+// and far fewer launches:
+//   * eq tables are never materialised: consumers multiply the two half tables on the fly;
+//   * k_sumfold<R>: a wave takes 64*2^R CONTIGUOUS entries per table (2^R fully coalesced 1 KiB loads),
+//     produces the sums of R rounds and stores the 64 folded entries of round k+R; neighbours are
+//     exchanged with wavefront shuffles (lane ^ 2^s at level s), no LDS staging of table data;
+//   * k_tail: one workgroup runs ALL remaining rounds once the live tables are small, adds the block
+//     partials of the earlier rounds, retires tables into add_term, and emits every round polynomial of
+//     the sumcheck plus the final claims.
+// ===================================================================================================
+namespace vp {
+
+struct Half { const F *bf; const F *bs; int h1; int pad; };
+__device__ __forceinline__ F half_at(const Half &h, u32 i) {
+    return f_mul(h.bf[i & ((1u << h.h1) - 1)], h.bs[i >> h.h1]);
+}
+
+struct InitArgs2 {
+    const u32 *rowptr; const u32 *e_g; const u32 *e_x; const uint16_t *e_tl;
+    Half hg, hu;              // eq(r_liu, .) over layer i, eq(r_u, .) over layer i-1
+    F *const *vals;
+    const F *gc;
+    const F *Vu;              // phase 2
+    const F *assert_r;        // scales beta_g of assert gates (bit 15 of e_tl)
+    F *V, *M, *A;
+    const uint8_t *s_layer; const u32 *s_idx;    // phase 2: slot -> (source layer, index) for the V gather
+    u32 n_rows;
+};
+
+template <int PHASE>
+__device__ __forceinline__ void contrib2(const InitArgs2 &a, u32 e, F &m, F &ad) {
+    const u32 g = a.e_g[e], x = a.e_x[e], tl = a.e_tl[e];
+    const int ty = (tl >> 8) & 0x7f;
+    F t = half_at(a.hg, g);
+    if (tl & 0x8000) t = f_mul(t, *a.assert_r);
+    if (PHASE == 1) {
+        const int l = tl & 0xff;
+        F ty_ = f_zero();
+        if (l != 0xff) ty_ = f_mul(a.vals[l][x], t);
+        switch (ty) {
+            case T_ADD: ad = f_add(ad, ty_); m = f_add(m, t); break;
+            case T_SUB: ad = f_sub(ad, ty_); m = f_add(m, t); break;
+            case T_ANTISUB: ad = f_add(ad, ty_); m = f_sub(m, t); break;
+            case T_MUL: m = f_add(m, ty_); break;
+            case T_NAAB: ad = f_add(ad, ty_); m = f_sub(m, ty_); break;
+            case T_ANTINAAB: m = f_add(m, f_sub(t, ty_)); break;
+            case T_ADDC: ad = f_add(ad, f_mul(a.gc[g], t)); m = f_add(m, t); break;
+            case T_MULC: m = f_add(m, f_mul(a.gc[g], t)); break;
+            case T_COPY: m = f_add(m, t); break;
+            case T_NOT: ad = f_add(ad, t); m = f_sub(m, t); break;
+            case T_XOR: ad = f_add(ad, ty_); m = f_add(m, f_sub(t, f_dbl(ty_))); break;
+            default: break;
+        }
+    } else {
+        t = f_mul(t, half_at(a.hu, x));
+        const F vu = *a.Vu;
+        const F tv = f_mul(t, vu);                         // t * V_u
+        switch (ty) {                                      // SURVEY.md Appendix A, phase-2 column
+            case T_ADD: m = f_add(m, t); ad = f_add(ad, tv); break;
+            case T_SUB: m = f_sub(m, t); ad = f_add(ad, tv); break;
+            case T_ANTISUB: m = f_add(m, t); ad = f_sub(ad, tv); break;
+            case T_MUL: m = f_add(m, tv); break;
+            case T_NAAB: m = f_add(m, f_sub(t, tv)); break;
+            case T_ANTINAAB: m = f_sub(m, tv); ad = f_add(ad, tv); break;
+            case T_XOR: ad = f_add(ad, tv); m = f_add(m, f_sub(t, f_dbl(tv))); break;
+            case T_COPY: ad = f_add(ad, tv); break;
+            case T_NOT: ad = f_add(ad, f_sub(t, tv)); break;
+            case T_ADDC: ad = f_add(ad, f_mul(t, f_add(a.gc[g], vu))); break;
+            case T_MULC: ad = f_add(ad, f_mul(tv, a.gc[g])); break;
+            default: break;
+        }
+    }
+}
+
+template <int PHASE>
+__global__ void __launch_bounds__(VP_BLOCK) k_init2_light(InitArgs2 a) {
+    u32 row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= a.n_rows) return;
+    if (PHASE == 2) {
+        const int l = a.s_layer[row];
+        if (l != 0xfe) a.V[row] = (l == 0xff) ? f_zero() : a.vals[l][a.s_idx[row]];   // 0xfe: padding slot, never read
+    }
+    u32 b = a.rowptr[row], e = a.rowptr[row + 1];
+    if (e - b > VP_LIGHT_MAX) return;
+    F m = f_zero(), ad = f_zero();
+    for (u32 k = b; k < e; ++k) contrib2<PHASE>(a, k, m, ad);
+    a.M[row] = m;
+    a.A[row] = ad;
+}
+
+template <int PHASE>
+__global__ void __launch_bounds__(VP_BLOCK)
+k_init2_chunks(InitArgs2 a, const u32 *__restrict__ chunk_beg, const u32 *__restrict__ chunk_end, u32 n_chunks,
+               F *__restrict__ part) {
+    const u32 c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (c >= n_chunks) return;
+    const int lane = threadIdx.x & 63;
+    F m = f_zero(), ad = f_zero();
+    for (u32 k = chunk_beg[c] + lane; k < chunk_end[c]; k += 64) contrib2<PHASE>(a, k, m, ad);
+    m = wave_sum(m);
+    ad = wave_sum(ad);
+    if (lane == 0) { part[2 * c] = m; part[2 * c + 1] = ad; }
+}
+
+// Liu init as a gather (src/prover.cpp:396-414): for every u of layer i-1 the (later layer, subset
+// position) pairs that point at it were listed at upload; M[u] = s0*eq(r_u,u) + sum eq_q(g).
+__global__ void __launch_bounds__(VP_BLOCK)
+k_liu_gather(const u32 *__restrict__ rowptr, const uint8_t *__restrict__ e_q, const u32 *__restrict__ e_g,
+             const Half *__restrict__ H, u32 size, F *__restrict__ M) {
+    u32 u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= size) return;
+    F m = half_at(H[0], u);
+    for (u32 k = rowptr[u]; k < rowptr[u + 1]; ++k) m = f_add(m, half_at(H[e_q[k]], e_g[k]));
+    M[u] = m;
+}
+
+__global__ void __launch_bounds__(VP_BLOCK)
+k_vres2(Half h, const F *__restrict__ val, u32 size, F *out_dev) {
+    __shared__ F lds[4];
+    F acc[1] = {f_zero()};
+    for (u32 i = threadIdx.x; i < size; i += blockDim.x) acc[0] = f_add(acc[0], f_mul(half_at(h, i), val[i]));
+    block_sum<1>(acc, lds);
+    if (threadIdx.x == 0) *out_dev = acc[0];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_sumfold<R>: R rounds per launch over tables whose length is a multiple of 64*2^R.
+// ---------------------------------------------------------------------------------------------------
+struct SfTab { u32 off, len, valid, chunk_start; };
+struct SfArgs {
+    const F *inV, *inM, *inA;
+    F *outV, *outM, *outA;
+    const F *r;               // r[s] = challenge of the s-th round of this launch
+    F *part;                  // part[(s * part_stride) + block*3 + c]
+    u32 part_stride;
+    u32 total_chunks;
+    int n_tab, has_a;
+    SfTab t[VP_MAX_TAB];
+};
+
+__device__ __forceinline__ F shfl_xor_F(const F &x, int mask) {
+    F y;
+    y.re = __shfl_xor(x.re, mask, 64);
+    y.im = __shfl_xor(x.im, mask, 64);
+    return y;
+}
+
+// One level: regs x[0..2n) -> x[0..n).  Lane keeps the pair (lo, hi) = two neighbouring table entries:
+// lanes with bit s clear take theirs from the even register, the others from the odd register.
+template <int N2>
+__device__ __forceinline__ void sf_pairs(F (&x)[8], int s, int lane, F (&lo)[4], F (&hi)[4]) {
+    const bool up = (lane >> s) & 1;
+#pragma unroll
+    for (int j = 0; j < N2; ++j) {
+        const F A = x[2 * j], B = x[2 * j + 1];
+        const F recv = shfl_xor_F(up ? A : B, 1 << s);
+        lo[j] = up ? recv : A;
+        hi[j] = up ? B : recv;
+    }
+}
+
+template <int R>
+__global__ void __launch_bounds__(VP_BLOCK) k_sumfold(SfArgs a) {
+    constexpr int G = 1 << R;
+    __shared__ F lds[4 * 3 * R];
+    const int lane = threadIdx.x & 63;
+    const u32 wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const u32 n_waves = gridDim.x * (blockDim.x >> 6);
+    F acc[3 * R];
+#pragma unroll
+    for (int i = 0; i < 3 * R; ++i) acc[i] = f_zero();
+    F rr[R];
+#pragma unroll
+    for (int s = 0; s < R; ++s) rr[s] = a.r[s];
+    // final lane -> element offset inside the 64 outputs of a chunk
+    u32 o_fin = (u32) lane >> R;
+#pragma unroll
+    for (int t = 0; t < R; ++t) o_fin += ((lane >> t) & 1u) << (6 - R + t);
+
+    for (u32 c = wave; c < a.total_chunks; c += n_waves) {
+        int j = 0;
+        while (j + 1 < a.n_tab && c >= a.t[j + 1].chunk_start) ++j;
+        const SfTab td = a.t[j];
+        const u32 cl = c - td.chunk_start;
+        const u32 base = td.off + cl * 64 * G, vend = td.off + td.valid;
+        F v[8], m[8], ad[8];
+#pragma unroll
+        for (int q = 0; q < G; ++q) {
+            const u32 idx = base + 64 * q + lane;
+            v[q] = ld_or_zero(a.inV, idx, vend);
+            m[q] = ld_or_zero(a.inM, idx, vend);
+            ad[q] = a.has_a ? ld_or_zero(a.inA, idx, vend) : f_zero();
+        }
+#pragma unroll
+        for (int s = 0; s < R; ++s) {
+            constexpr int dummy = 0; (void) dummy;
+            const int n2 = G >> (s + 1);
+            F vl[4], vh[4], ml[4], mh[4], al[4], ah[4];
+            if (n2 == 4) { sf_pairs<4>(v, s, lane, vl, vh); sf_pairs<4>(m, s, lane, ml, mh); if (a.has_a) sf_pairs<4>(ad, s, lane, al, ah); }
+            else if (n2 == 2) { sf_pairs<2>(v, s, lane, vl, vh); sf_pairs<2>(m, s, lane, ml, mh); if (a.has_a) sf_pairs<2>(ad, s, lane, al, ah); }
+            else { sf_pairs<1>(v, s, lane, vl, vh); sf_pairs<1>(m, s, lane, ml, mh); if (a.has_a) sf_pairs<1>(ad, s, lane, al, ah); }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q >= n2) break;
+                const F dm = f_sub(mh[q], ml[q]), dv = f_sub(vh[q], vl[q]);
+                const F qa = f_mul(dm, dv), qc = f_mul(ml[q], vl[q]), qe = f_mul(mh[q], vh[q]);
+                F lin = f_sub(f_sub(qe, qa), qc), cst = qc;
+                if (a.has_a) { lin = f_add(lin, f_sub(ah[q], al[q])); cst = f_add(cst, al[q]); }
+                acc[3 * s] = f_add(acc[3 * s], qa);
+                acc[3 * s + 1] = f_add(acc[3 * s + 1], lin);
+                acc[3 * s + 2] = f_add(acc[3 * s + 2], cst);
+                v[q] = f_add(vl[q], f_mul(rr[s], dv));
+                m[q] = f_add(ml[q], f_mul(rr[s], dm));
+                if (a.has_a) ad[q] = f_lerp(al[q], ah[q], rr[s]);
+            }
+        }
+        const u32 oi = cl * 64 + o_fin;                    // element of the folded table
+        const u32 vout = (td.valid + G - 1) >> R;
+        if (oi < vout) {
+            a.outV[td.off + oi] = v[0];
+            a.outM[td.off + oi] = m[0];
+            if (a.has_a) a.outA[td.off + oi] = ad[0];
+        }
+    }
+    // block partials
+    const int w = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 3 * R; ++i) acc[i] = wave_sum(acc[i]);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 3 * R; ++i) lds[w * 3 * R + i] = acc[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 * R) {
+        const int i = threadIdx.x;
+        F s = lds[i];
+        for (int k = 1; k < (int) (blockDim.x >> 6); ++k) s = f_add(s, lds[k * 3 * R + i]);
+        a.part[(size_t) (i / 3) * a.part_stride + blockIdx.x * 3 + (i % 3)] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_tail: one workgroup finishes a sumcheck.
+// ---------------------------------------------------------------------------------------------------
+#define VP_TAIL_THREADS 1024
+struct TailTab {
+    u32 off;          // table offset inside the ping-pong buffers
+    u32 len0;         // logical length at round 1
+    u32 valid0;       // valid length at round 1
+    int enter;        // first round (1-based) this kernel handles for the table
+    int cur;          // buffer (0/1) that holds the table at round `enter`
+    int v_from_v0;    // V of round `enter` is read from V0 instead of buf[cur][0] (phase 1 / Liu, enter == 1)
+};
+struct TailArgs {
+    const F *V0;
+    F *buf[2][3];
+    const F *r;                 // r[k-1] = challenge of round k
+    const F *part;              // block partials written by k_sumfold: part[(k-1)*part_stride + b*3 + c]
+    u32 part_stride;
+    int n_tab, rounds, has_a;
+    F *poly_out;                // rounds * 3
+    F *claims_out;              // n_tab
+    F *Vu;                      // phase 1: receives claims[0]
+    uint16_t nblk[32];          // partial blocks per round
+    TailTab t[VP_MAX_TAB];
+};
+
+__global__ void __launch_bounds__(VP_TAIL_THREADS) k_tail(TailArgs a) {
+    __shared__ F lds[16 * 3];
+    __shared__ F s_claim[VP_MAX_TAB];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nth = blockDim.x;
+    if (tid < a.n_tab) s_claim[tid] = f_zero();
+    F at = f_zero();                                        // add_term (thread 0)
+    __syncthreads();
+    // tables that consist of a single entry from the start: their value is the claim (bl == 0)
+    for (int k = 1; k <= (a.rounds > 0 ? a.rounds : 1); ++k) {
+        const bool real_round = k <= a.rounds;
+        const F rk = real_round ? a.r[k - 1] : f_zero();
+        const F rprev = (k >= 2) ? a.r[k - 2] : f_zero();
+        F acc[3] = {f_zero(), f_zero(), f_zero()};
+        if (real_round) {
+            const u32 nb = a.nblk[k - 1];
+            const F *pp = a.part + (size_t) (k - 1) * a.part_stride;
+            for (u32 i = tid; i < nb; i += nth) {
+                acc[0] = f_add(acc[0], pp[3 * i]); acc[1] = f_add(acc[1], pp[3 * i + 1]); acc[2] = f_add(acc[2], pp[3 * i + 2]);
+            }
+        }
+        F retire = f_zero();                                // thread 0: sum of V*M + A of tables retiring this round
+        for (int j = 0; j < a.n_tab; ++j) {
+            const TailTab td = a.t[j];
+            if (k < td.enter) continue;
+            const int sh = k - 1;
+            const u32 len = sh < 32 ? (td.len0 >> sh) : 0;
+            if (len == 0) continue;
+            const u32 valid = (u32) (((unsigned long long) td.valid0 + (1ull << sh) - 1) >> sh);
+            const int cb = td.cur ^ ((k - td.enter) & 1);       // a live table changes buffer every round
+            const F *inV = (td.v_from_v0 && k == td.enter) ? a.V0 + td.off : a.buf[cb][0] + td.off;
+            const F *inM = a.buf[cb][1] + td.off, *inA = a.buf[cb][2] + td.off;
+            if (len == 1) {
+                if (tid == 0) {
+                    // always-initialised single entry (see k_round_final)
+                    const F v = (td.len0 == 1) ? inV[0] : ld_or_zero(inV, 0, valid);
+                    const F m = (td.len0 == 1) ? inM[0] : ld_or_zero(inM, 0, valid);
+                    const F ad = a.has_a ? ((td.len0 == 1) ? inA[0] : ld_or_zero(inA, 0, valid)) : f_zero();
+                    s_claim[j] = v;
+                    if (real_round) retire = f_add(retire, f_add(f_mul(v, m), ad));
+                }
+                continue;
+            }
+            if (!real_round) continue;
+            F *oV = a.buf[cb ^ 1][0] + td.off, *oM = a.buf[cb ^ 1][1] + td.off, *oA = a.buf[cb ^ 1][2] + td.off;
+            const u32 npairs = (valid + 1) >> 1;
+            for (u32 p = tid; p < npairs; p += nth) {
+                const F v0 = ld_or_zero(inV, 2 * p, valid), v1 = ld_or_zero(inV, 2 * p + 1, valid);
+                const F m0 = ld_or_zero(inM, 2 * p, valid), m1 = ld_or_zero(inM, 2 * p + 1, valid);
+                F a0 = f_zero(), a1 = f_zero();
+                if (a.has_a) { a0 = ld_or_zero(inA, 2 * p, valid); a1 = ld_or_zero(inA, 2 * p + 1, valid); }
+                const F dm = f_sub(m1, m0), dv = f_sub(v1, v0);
+                const F qa = f_mul(dm, dv), qc = f_mul(m0, v0), qe = f_mul(m1, v1);
+                acc[0] = f_add(acc[0], qa);
+                acc[1] = f_add(acc[1], f_add(f_sub(f_sub(qe, qa), qc), f_sub(a1, a0)));
+                acc[2] = f_add(acc[2], f_add(qc, a0));
+                const F fv = f_add(v0, f_mul(rk, dv));
+                oV[p] = fv;
+                oM[p] = f_add(m0, f_mul(rk, dm));
+                if (a.has_a) oA[p] = f_lerp(a0, a1, rk);
+                if (len == 2 && k == a.rounds) s_claim[j] = fv;      // the last fold of a full-length table is its claim
+            }
+        }
+        if (!real_round) break;
+        // block reduction of the three coefficients
+#pragma unroll
+        for (int i = 0; i < 3; ++i) acc[i] = wave_sum(acc[i]);
+        if (lane == 0) { lds[w * 3] = acc[0]; lds[w * 3 + 1] = acc[1]; lds[w * 3 + 2] = acc[2]; }
+        __syncthreads();                                    // also publishes the folded tables
+        if (tid == 0) {
+            F s0 = lds[0], s1 = lds[1], s2 = lds[2];
+            for (int q = 1; q < (nth >> 6); ++q) { s0 = f_add(s0, lds[3 * q]); s1 = f_add(s1, lds[3 * q + 1]); s2 = f_add(s2, lds[3 * q + 2]); }
+            if (!f_is_zero(at)) at = f_mul(at, f_sub(f_one(), rprev));
+            at = f_add(at, retire);
+            a.poly_out[3 * (k - 1)] = s0;
+            a.poly_out[3 * (k - 1) + 1] = f_sub(s1, at);
+            a.poly_out[3 * (k - 1) + 2] = f_add(s2, at);
+        }
+        __syncthreads();                                    // lds reuse
+    }
+    // claims: tables shorter than the sumcheck left their value when they retired; a table whose last
+    // fold happened in the final round stored it above; single-entry tables of a zero-round phase too.
+    __syncthreads();
+    if (tid < a.n_tab) {
+        a.claims_out[tid] = s_claim[tid];
+        if (a.Vu && tid == 0) *a.Vu = s_claim[0];
+    }
+}
+
+}  // namespace vp
+
+// ===================================================================================================
+// Segment kernels (default batched path).
+//
+// The cost of this path is integer ALU, not bytes: one F-multiply is ~75 VALU instructions (12 of them
+// v_mad_u64_u32), a lone wave issues one instruction every ~4 cycles, so the dependent chain of a round
+// — not the 288 B per pair — sets the time of every table that does not fill the chip.  Hence:
+//   * k_seg: a workgroup stages a SEGMENT of <= 1024 consecutive entries of V/mult/add in LDS (coalesced
+//     1 KiB wave loads) and runs log2(segment) rounds on it without leaving the CU; ten rounds cost
+//     48 B/entry of HBM reads and 48 B per 1024 entries of writes.  Inside a round the work is split at
+//     F-multiply granularity with WAVE-UNIFORM roles (no divergence): wave role 0: dm*dv + fold V,
+//     1: m0*v0 + fold mult, 2: m1*v1, 3: fold add + its two sums — the chain per round is two multiplies
+//     instead of nine.  Round sums stay in registers (one accumulator per round, rounds unrolled) across
+//     all segments a persistent workgroup processes and are reduced once at the end.
+//   * k_emit: one workgroup finishes the sumcheck: it owns every table that is down to <= 2^e entries
+//     (LDS resident), adds the block partials of the k_seg launches, retires finished tables into
+//     add_term and writes all round polynomials and the claims.
+// ===================================================================================================
+namespace vp {
+
+#define VP_SEG_LOG 10
+#define VP_SEG (1 << VP_SEG_LOG)
+#define VP_SEG_THREADS 512
+#define VP_SEG_SLOTS 128            // 8 waves = 2 groups x 4 roles; a group covers 64 pair slots
+
+struct SegTab {
+    u32 off;          // table offset (same in input and output buffers)
+    u32 valid;        // valid entries of the input table
+    u32 seg_start;    // first global segment index of this table
+    int seg_log;      // log2(segment length) = rounds performed on this table by the launch
+};
+struct SegArgs {
+    const F *inV, *inM, *inA;
+    F *outV, *outM, *outA;
+    const F *r;               // r[s] = challenge of the s-th round of this launch
+    F *part;                  // part[s * part_stride + block * 3 + c]
+    u32 part_stride;
+    u32 total_segs;
+    int n_tab, n_rounds;      // n_rounds = max seg_log
+    SegTab t[VP_MAX_TAB];
+};
+
+template <bool HAS_A>
+__global__ void __launch_bounds__(VP_SEG_THREADS) k_seg(SegArgs a) {
+    __shared__ F bufA[3][VP_SEG];
+    __shared__ F bufB[3][VP_SEG / 2];
+    __shared__ F red[(VP_SEG_THREADS / 64) * 3];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int role = __builtin_amdgcn_readfirstlane(w & 3);       // wave-uniform
+    const u32 slot = (u32) ((w >> 2) * 64 + lane);
+    F acc1[VP_SEG_LOG], acc2[VP_SEG_LOG];                          // role 0-2: acc1 = products; role 3: sums of da / a0
+#pragma unroll
+    for (int s = 0; s < VP_SEG_LOG; ++s) { acc1[s] = f_zero(); acc2[s] = f_zero(); }
+
+    for (u32 seg = blockIdx.x; seg < a.total_segs; seg += gridDim.x) {
+        int j = 0;
+        while (j + 1 < a.n_tab && seg >= a.t[j + 1].seg_start) ++j;
+        const SegTab td = a.t[j];
+        const u32 q = seg - td.seg_start;
+        const int R = td.seg_log;
+        const u32 S = 1u << R;
+        const u32 base = td.off + q * S;
+        const u32 vseg = td.valid > q * S ? min(td.valid - q * S, S) : 0;     // valid entries of this segment
+        for (u32 i = tid; i < S; i += VP_SEG_THREADS) {
+            const bool ok = i < vseg;
+            bufA[0][i] = ok ? a.inV[base + i] : f_zero();
+            bufA[1][i] = ok ? a.inM[base + i] : f_zero();
+            if (HAS_A) bufA[2][i] = ok ? a.inA[base + i] : f_zero();
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < VP_SEG_LOG; ++s) {
+            if (s < R) {
+                const F *sV = (s & 1) ? bufB[0] : bufA[0], *sM = (s & 1) ? bufB[1] : bufA[1], *sA = (s & 1) ? bufB[2] : bufA[2];
+                F *dV = (s & 1) ? bufA[0] : bufB[0], *dM = (s & 1) ? bufA[1] : bufB[1], *dA = (s & 1) ? bufA[2] : bufB[2];
+                const F rs = a.r[s];
+                const u32 n = S >> (s + 1);                                   // pairs of this round
+                const u32 vs = (vseg + (1u << s) - 1) >> s;                   // valid entries of this round
+                const u32 act = (vs + 1) >> 1;                                // pairs that can be non-zero
+                for (u32 p = slot; p < n; p += VP_SEG_SLOTS) {
+                    const bool live = p < act;
+                    if (role == 0) {
+                        F o = f_zero();
+                        if (live) {
+                            const F m0 = sM[2 * p], m1 = sM[2 * p + 1], v0 = sV[2 * p], v1 = sV[2 * p + 1];
+                            const F dv = f_sub(v1, v0);
+                            acc1[s] = f_add(acc1[s], f_mul(f_sub(m1, m0), dv));
+                            o = f_add(v0, f_mul(rs, dv));
+                        }
+                        dV[p] = o;
+                    } else if (role == 1) {
+                        F o = f_zero();
+                        if (live) {
+                            const F m0 = sM[2 * p], m1 = sM[2 * p + 1], v0 = sV[2 * p];
+                            acc1[s] = f_add(acc1[s], f_mul(m0, v0));
+                            o = f_add(m0, f_mul(rs, f_sub(m1, m0)));
+                        }
+                        dM[p] = o;
+                    } else if (role == 2) {
+                        if (live) acc1[s] = f_add(acc1[s], f_mul(sM[2 * p + 1], sV[2 * p + 1]));
+                    } else if (HAS_A) {
+                        F o = f_zero();
+                        if (live) {
+                            const F a0 = sA[2 * p], a1 = sA[2 * p + 1];
+                            const F da = f_sub(a1, a0);
+                            acc1[s] = f_add(acc1[s], da);
+                            acc2[s] = f_add(acc2[s], a0);
+                            o = f_add(a0, f_mul(rs, da));
+                        }
+                        dA[p] = o;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        // the segment is down to one entry per table
+        if (tid < 3 && q * S < td.valid) {
+            const F *fin = (R & 1) ? bufB[tid] : bufA[tid];
+            if (tid == 0) a.outV[td.off + q] = fin[0];
+            else if (tid == 1) a.outM[td.off + q] = fin[0];
+            else if (HAS_A) a.outA[td.off + q] = fin[0];
+        }
+        __syncthreads();
+    }
+    // per-round block partials: lane contributions (a, b, c) by role, one block reduction per round
+#pragma unroll
+    for (int s = 0; s < VP_SEG_LOG; ++s) {
+        if (s < a.n_rounds) {
+            F ca = f_zero(), cb = f_zero(), cc = f_zero();
+            if (role == 0) { ca = acc1[s]; cb = f_neg(acc1[s]); }
+            else if (role == 1) { cb = f_neg(acc1[s]); cc = acc1[s]; }
+            else if (role == 2) { cb = acc1[s]; }
+            else if (HAS_A) { cb = acc1[s]; cc = acc2[s]; }
+            ca = wave_sum(ca); cb = wave_sum(cb); cc = wave_sum(cc);
+            if (lane == 0) { red[w * 3] = ca; red[w * 3 + 1] = cb; red[w * 3 + 2] = cc; }
+            __syncthreads();
+            if (tid < 3) {
+                F x = red[tid];
+                for (int k = 1; k < VP_SEG_THREADS / 64; ++k) x = f_add(x, red[k * 3 + tid]);
+                a.part[(size_t) s * a.part_stride + blockIdx.x * 3 + tid] = x;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_emit: one workgroup closes a sumcheck.
+//   phase 1  all waves in parallel: reduce the block partials the k_seg launches wrote, one round per wave;
+//   phase 2  only for rounds in which a table owned by this kernel has work: pair products + folds on the
+//            LDS-resident tables (wave-uniform roles), wave sums parked in LDS, one barrier per round;
+//   phase 3  totals per (round, coefficient) in parallel, the add_term recurrence (src/prover.cpp:445,
+//            462-467) by one lane, polynomials and claims written out by parallel lanes.
+// ---------------------------------------------------------------------------------------------------
+#define VP_EMIT_THREADS 768         // 12 waves = 4 groups x 3 roles
+#define VP_EMIT_WAVES (VP_EMIT_THREADS / 64)
+#define VP_EMIT_CAP 1280            // LDS entries per buffer per table family (2 x 3 x 1280 x 16 B = 120 KiB)
+struct EmitTab {
+    u32 off;          // offset in the global buffers
+    int enter;        // first round (1-based) handled here
+    u32 len_enter;    // logical length at `enter` (<= 2^emit_log)
+    u32 valid_enter;  // valid entries at `enter`
+    int src;          // global buffer holding the table at `enter` (tab[src]); V from V0 if v_from_v0
+    int v_from_v0;
+    int bl;           // log2 of the table's length at round 1
+    int pad;
+};
+struct EmitArgs {
+    const F *V0;
+    const F *buf[2][3];
+    const F *r;                 // r[k-1] = challenge of round k
+    const F *part; u32 part_stride;
+    int n_tab, rounds, has_a, emit_log;
+    u32 work_mask;              // bit k-1: some table of this kernel has pairs or retires in round k
+    u32 enter_mask;             // bit k-1: some table is loaded from global memory in round k
+    F *poly_out, *claims_out, *Vu;
+    uint16_t nblk[32];
+    EmitTab t[VP_MAX_TAB];
+};
+
+// dynamic LDS: tables [2][3][cap] | psum[32][3] | wred[32][12][3] | claim[64] | retv[64] | atv[32] | retk[64] (int)
+#define VP_EMIT_LDS_EXTRA_F (32 * 3 + 32 * VP_EMIT_WAVES * 3 + VP_MAX_TAB + VP_MAX_TAB + 32)
+__global__ void __launch_bounds__(VP_EMIT_THREADS) k_emit(EmitArgs a) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nth = blockDim.x;
+    const u32 E = 1u << a.emit_log, cap = (u32) a.n_tab * E;
+    F *lbuf = reinterpret_cast<F *>(smem_raw);
+    F *psum = lbuf + (size_t) 6 * cap;
+    F *wred = psum + 32 * 3;
+    F *s_claim = wred + 32 * VP_EMIT_WAVES * 3;
+    F *s_retv = s_claim + VP_MAX_TAB;
+    F *s_at = s_retv + VP_MAX_TAB;
+    int *s_retk = reinterpret_cast<int *>(s_at + 32);
+    auto L = [&](int b, int tbl) { return lbuf + ((size_t) (b * 3 + tbl)) * cap; };
+    const int role = __builtin_amdgcn_readfirstlane(w % 3);
+    const u32 pslot = (u32) ((w / 3) * 64 + lane);
+    const u32 pstride = (u32) (VP_EMIT_WAVES / 3) * 64;
+    if (tid < VP_MAX_TAB) { s_claim[tid] = f_zero(); s_retv[tid] = f_zero(); s_retk[tid] = 0; }
+    // ---- phase 1: block partials of the k_seg launches, one round per wave ----
+    for (int k = w + 1; k <= a.rounds; k += VP_EMIT_WAVES) {
+        const u32 nb = a.nblk[k - 1];
+        F ca = f_zero(), cbv = f_zero(), cc = f_zero();
+        const F *pp = a.part + (size_t) (k - 1) * a.part_stride;
+        for (u32 i = lane; i < nb; i += 64) { ca = f_add(ca, pp[3 * i]); cbv = f_add(cbv, pp[3 * i + 1]); cc = f_add(cc, pp[3 * i + 2]); }
+        ca = wave_sum63(ca); cbv = wave_sum63(cbv); cc = wave_sum63(cc);
+        if (lane == 63) { psum[3 * (k - 1)] = ca; psum[3 * (k - 1) + 1] = cbv; psum[3 * (k - 1) + 2] = cc; }
+    }
+    __syncthreads();
+    // ---- phase 2: rounds with table work ----
+    const int nrounds = a.rounds > 0 ? a.rounds : 1;
+    for (int k = 1; k <= nrounds; ++k) {
+        if (!((a.work_mask >> (k - 1)) & 1u)) continue;                 // uniform
+        const bool real_round = k <= a.rounds;
+        const int cb = k & 1;
+        if ((a.enter_mask >> (k - 1)) & 1u) {
+            for (int j = 0; j < a.n_tab; ++j) {
+                const EmitTab td = a.t[j];
+                if (td.enter != k) continue;
+                const F *gV = td.v_from_v0 ? a.V0 + td.off : a.buf[td.src][0] + td.off;
+                const F *gM = a.buf[td.src][1] + td.off, *gA = a.buf[td.src][2] + td.off;
+                const bool single = td.bl == 0;                          // always-initialised single entry
+                for (u32 i = tid; i < td.len_enter; i += nth) {
+                    const bool ok = single || i < td.valid_enter;
+                    L(cb, 0)[j * E + i] = ok ? gV[i] : f_zero();
+                    L(cb, 1)[j * E + i] = ok ? gM[i] : f_zero();
+                    L(cb, 2)[j * E + i] = (ok && a.has_a) ? gA[i] : f_zero();
+                }
+            }
+            __syncthreads();
+        }
+        F ca = f_zero(), cbv = f_zero(), cc = f_zero();
+        if (real_round) {
+            const F rk = a.r[k - 1];
+            // global pair index -> (table, pair): tables are scanned with wave-uniform lengths
+            for (u32 gp0 = 0;; gp0 += pstride) {
+                const u32 gp = gp0 + pslot;
+                u32 run = 0; int mj = -1; u32 mp = 0; u32 total = 0;
+                for (int j = 0; j < a.n_tab; ++j) {
+                    const EmitTab td = a.t[j];
+                    if (k < td.enter) continue;
+                    const int sh = k - td.enter;
+                    const u32 len = sh < 32 ? (td.len_enter >> sh) : 0;
+                    const u32 np = len >= 2 ? (len >> 1) : 0;
+                    if (gp >= run && gp < run + np) { mj = j; mp = gp - run; }
+                    run += np;
+                }
+                total = run;
+                if (gp0 >= total) break;                                 // uniform
+                if (mj >= 0) {
+                    const int j = mj; const u32 p = mp;
+                    const F *sV = L(cb, 0) + j * E, *sM = L(cb, 1) + j * E, *sA = L(cb, 2) + j * E;
+                    F *dV = L(cb ^ 1, 0) + j * E, *dM = L(cb ^ 1, 1) + j * E, *dA = L(cb ^ 1, 2) + j * E;
+                    if (role == 0) {
+                        const F m0 = sM[2 * p], m1 = sM[2 * p + 1], v0 = sV[2 * p], v1 = sV[2 * p + 1];
+                        const F dv = f_sub(v1, v0), qa = f_mul(f_sub(m1, m0), dv);
+                        ca = f_add(ca, qa); cbv = f_sub(cbv, qa);
+                        dV[p] = f_add(v0, f_mul(rk, dv));
+                    } else if (role == 1) {
+                        const F m0 = sM[2 * p], m1 = sM[2 * p + 1], v0 = sV[2 * p];
+                        const F qc = f_mul(m0, v0);
+                        cc = f_add(cc, qc); cbv = f_sub(cbv, qc);
+                        dM[p] = f_add(m0, f_mul(rk, f_sub(m1, m0)));
+                    } else {
+                        cbv = f_add(cbv, f_mul(sM[2 * p + 1], sV[2 * p + 1]));
+                        F o = f_zero();
+                        if (a.has_a) {
+                            const F a0 = sA[2 * p], a1 = sA[2 * p + 1];
+                            const F da = f_sub(a1, a0);
+                            cbv = f_add(cbv, da); cc = f_add(cc, a0);
+                            o = f_add(a0, f_mul(rk, da));
+                        }
+                        dA[p] = o;
+                    }
+                }
+            }
+        }
+        // single-entry tables: the entry is the claim; in a real round it retires into add_term.  One lane per table.
+        if (w == VP_EMIT_WAVES - 1 && lane < a.n_tab) {
+            const EmitTab td = a.t[lane];
+            if (k >= td.enter) {
+                const int sh = k - td.enter;
+                const u32 len = sh < 32 ? (td.len_enter >> sh) : 0;
+                if (len == 1) {
+                    const F v = L(cb, 0)[lane * E], m = L(cb, 1)[lane * E], ad = L(cb, 2)[lane * E];
+                    s_claim[lane] = v;
+                    if (real_round) { s_retv[lane] = f_add(f_mul(v, m), ad); s_retk[lane] = k; }
+                }
+            }
+        }
+        if (real_round) {
+            ca = wave_sum63(ca); cbv = wave_sum63(cbv); cc = wave_sum63(cc);
+            if (lane == 63) {
+                F *o = wred + ((size_t) (k - 1) * VP_EMIT_WAVES + w) * 3;
+                o[0] = ca; o[1] = cbv; o[2] = cc;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- phase 3 ----
+    if (tid < a.rounds * 3) {
+        const int k = tid / 3, c = tid % 3;
+        F t = psum[3 * k + c];
+        if (!a.nblk[k]) t = f_zero();
+        if ((a.work_mask >> k) & 1u)
+            for (int q = 0; q < VP_EMIT_WAVES; ++q) t = f_add(t, wred[((size_t) k * VP_EMIT_WAVES + q) * 3 + c]);
+        psum[3 * k + c] = t;
+    }
+    if (w == VP_EMIT_WAVES - 1 && lane < a.rounds) {           // retire sum of round lane+1
+        F t = f_zero();
+        for (int j = 0; j < a.n_tab; ++j) if (s_retk[j] == lane + 1) t = f_add(t, s_retv[j]);
+        s_at[lane] = t;
+    }
+    __syncthreads();
+    if (tid == 0) {                                            // add_term recurrence
+        F at = f_zero();
+        for (int k = 1; k <= a.rounds; ++k) {
+            if (k >= 2 && !f_is_zero(at)) at = f_mul(at, f_sub(f_one(), a.r[k - 2]));
+            at = f_add(at, s_at[k - 1]);
+            s_at[k - 1] = at;
+        }
+    }
+    __syncthreads();
+    if (tid < a.rounds * 3) {
+        const int k = tid / 3, c = tid % 3;
+        F t = psum[3 * k + c];
+        if (c == 1) t = f_sub(t, s_at[k]); else if (c == 2) t = f_add(t, s_at[k]);
+        a.poly_out[tid] = t;
+    }
+    if (tid < a.n_tab) {
+        F c = s_claim[tid];
+        if (a.rounds > 0) {
+            const EmitTab td = a.t[tid];
+            if (td.bl == a.rounds) {
+                // as long as the sumcheck: folded to one entry by the last round — here, or already by k_seg
+                if (td.enter > a.rounds) c = td.valid_enter ? (a.buf[td.src][0] + td.off)[0] : f_zero();
+                else c = L((a.rounds + 1) & 1, 0)[tid * E];
+            }
+        }
+        a.claims_out[tid] = c;
+        if (a.Vu && tid == 0) *a.Vu = c;
+    }
 }
 
 }  // namespace vp

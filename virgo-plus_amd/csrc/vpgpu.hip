@@ -40,6 +40,11 @@ struct LayerDev {
     Csr c1, c2;
     // Liu: jobs for the layer whose claims are combined on layer (this-1)
     u32 n_jobs = 0; BetaJob *jobs = nullptr; std::vector<int> job_k, job_h1;
+    // batched path: per-slot V gather map, Liu gather lists, half tables of this layer's sumchecks
+    uint8_t *s_layer = nullptr; u32 *s_idx = nullptr;
+    u32 *lrow = nullptr, *l_g = nullptr; uint8_t *l_q = nullptr;
+    Half hg{}, hu{};
+    Half *liu_H = nullptr;
 };
 
 struct SumcheckState {
@@ -81,6 +86,9 @@ struct vp_ctx {
     std::vector<EvPair> ev_pool; size_t ev_used = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<void *> allocs;
+    BetaJob *all_jobs = nullptr; u32 n_all_jobs = 0; F *half_pool = nullptr;
+    F *part2 = nullptr;                  // [32][MAX_BLOCKS*3] block partials of the batched path
+    int simple_path = 0, sumfold_path = 0;
 
     F *zero() const { return small; }
     F *one() const { return small + 1; }
@@ -375,6 +383,7 @@ int vp_create(int device, vp_ctx **out) {
         delete ctx; return VP_EHIP;
     }
     hipEventCreate(&ctx->ev0); hipEventCreate(&ctx->ev1);
+    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(k_emit), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
     *out = ctx;
     return VP_OK;
 }
@@ -476,7 +485,7 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
         for (u32 g = 0; g < n; ++g) {
             const int t = ty[g], l = gl[g];
             eg[g] = g; ex1[g] = gv[g]; ex2[g] = gu[g];
-            etl[g] = (uint16_t) ((t << 8) | (l < 0 ? 0xff : l));
+            etl[g] = (uint16_t) ((t << 8) | (l < 0 ? 0xff : l) | ((S.is_assert && S.is_assert[g]) ? 0x8000 : 0));
             key1[g] = gu[g];
             key2[g] = is_unary(t) ? D.t_off[i - 1] : D.t_off[l] + S.lv[g];    // prover.cpp:314,342-353
         }
@@ -527,6 +536,74 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
                 add(ctx->d_tape + ctx->rv_off[k], ctx->d_tape + ctx->sig_off[i] + (k - i + 1), ctx->L[k].dad_bl[i - 1], k);
         D.n_jobs = (u32) jobs.size();
         VPCHK(dupload(ctx, &D.jobs, jobs));
+    }
+    // ---- batched path: per-slot gather map, Liu gather lists, one pool of half tables for the whole proof ----
+    {
+        std::vector<BetaJob> jobs;
+        std::vector<size_t> need;            // pool elements per job (bf + bs)
+        auto add_job = [&](const F *r, const F *init, int nbits) {
+            BetaJob jb{}; jb.r = r; jb.init = init; jb.n = nbits;
+            jobs.push_back(jb);
+            need.push_back(((size_t) 1 << (nbits >> 1)) + ((size_t) 1 << (nbits - (nbits >> 1))));
+            return (int) jobs.size() - 1;
+        };
+        std::vector<int> hg_id(n_layers, -1), hu_id(n_layers, -1);
+        std::vector<std::vector<int>> liu_id(n_layers);
+        for (int i = 1; i < n_layers; ++i) {
+            hg_id[i] = add_job(rliu_ptr(ctx, i), ctx->one(), ctx->L[i].bl);
+            hu_id[i] = add_job(ctx->d_tape + ctx->ru_off[i], ctx->one(), ctx->L[i - 1].bl);
+            liu_id[i].push_back(add_job(ctx->d_tape + ctx->ru_off[i], ctx->d_tape + ctx->sig_off[i], ctx->L[i - 1].bl));
+            for (int k = i; k < n_layers; ++k)
+                if (ctx->L[k].dad_size[i - 1])
+                    liu_id[i].push_back(add_job(ctx->d_tape + ctx->rv_off[k], ctx->d_tape + ctx->sig_off[i] + (k - i + 1),
+                                                ctx->L[k].dad_bl[i - 1]));
+        }
+        size_t total = 0;
+        for (size_t q = 0; q < jobs.size(); ++q) total += need[q];
+        VPCHK(dalloc(ctx, &ctx->half_pool, total));
+        size_t at = 0;
+        for (size_t q = 0; q < jobs.size(); ++q) {
+            jobs[q].bf = ctx->half_pool + at;
+            jobs[q].bs = jobs[q].bf + ((size_t) 1 << (jobs[q].n >> 1));
+            at += need[q];
+        }
+        ctx->n_all_jobs = (u32) jobs.size();
+        VPCHK(dupload(ctx, &ctx->all_jobs, jobs));
+        auto half_of = [&](int q) { Half h{}; h.bf = jobs[q].bf; h.bs = jobs[q].bs; h.h1 = jobs[q].n >> 1; return h; };
+        for (int i = 1; i < n_layers; ++i) {
+            LayerDev &D = ctx->L[i];
+            D.hg = half_of(hg_id[i]); D.hu = half_of(hu_id[i]);
+            std::vector<Half> hs;
+            for (int q : liu_id[i]) hs.push_back(half_of(q));
+            VPCHK(dupload(ctx, &D.liu_H, hs));
+            // slot -> source of the phase-2 V value
+            std::vector<uint8_t> sl(D.p2_total, 0xfe); std::vector<u32> si(D.p2_total, 0);
+            for (int j = 0; j < i; ++j) {
+                if (!D.dad_size[j]) { sl[D.t_off[j]] = 0xff; continue; }
+                for (u64 k = 0; k < D.dad_size[j]; ++k) { sl[D.t_off[j] + k] = (uint8_t) j; si[D.t_off[j] + k] = ld[i].dad_id[j][k]; }
+            }
+            VPCHK(dupload(ctx, &D.s_layer, sl)); VPCHK(dupload(ctx, &D.s_idx, si));
+            // Liu gather lists over the wires of layer i-1 (dadId[k][i-1] inverted), counting sort by wire
+            const u32 rows = (u32) ctx->L[i - 1].size;
+            std::vector<u32> rp(rows + 1, 0);
+            int q = 1;
+            for (int k = i; k < n_layers; ++k) {
+                if (!ctx->L[k].dad_size[i - 1]) continue;
+                for (u64 g = 0; g < ctx->L[k].dad_size[i - 1]; ++g) ++rp[ld[k].dad_id[i - 1][g] + 1];
+            }
+            for (u32 r = 0; r < rows; ++r) rp[r + 1] += rp[r];
+            std::vector<u32> pos(rp.begin(), rp.end() - 1), eg(rp[rows]); std::vector<uint8_t> eq(rp[rows]);
+            for (int k = i; k < n_layers; ++k) {
+                if (!ctx->L[k].dad_size[i - 1]) continue;
+                for (u64 g = 0; g < ctx->L[k].dad_size[i - 1]; ++g) { u32 p = pos[ld[k].dad_id[i - 1][g]]++; eg[p] = (u32) g; eq[p] = (uint8_t) q; }
+                ++q;
+            }
+            VPCHK(dupload(ctx, &D.lrow, rp)); VPCHK(dupload(ctx, &D.l_g, eg)); VPCHK(dupload(ctx, &D.l_q, eq));
+        }
+        VPCHK(dalloc(ctx, &ctx->part2, (size_t) 32 * MAX_BLOCKS * 3));
+        const char *pth = getenv("VP_GKR_PATH");
+        ctx->simple_path = (pth && !strcmp(pth, "simple")) ? 1 : 0;
+        ctx->sumfold_path = (pth && !strcmp(pth, "sumfold")) ? 1 : 0;
     }
     // event pool for the profiled launches
     if (ctx->ev_pool.empty()) {
@@ -658,8 +735,13 @@ int vp_gkr_sizes(vp_ctx *ctx, uint64_t *n_tape, uint64_t *n_bytes) {
     return VP_OK;
 }
 
+static int prove_gkr_fused(vp_ctx *ctx, const vp_F *tape, uint64_t n_tape, uint8_t *transcript, uint64_t *n_written);
+
 int vp_prove_gkr(vp_ctx *ctx, const vp_F *tape, uint64_t n_tape, uint8_t *transcript, uint64_t capacity,
                  uint64_t *n_written) {
+    if (!ctx || !ctx->evaluated || !tape || !transcript || n_tape != ctx->n_tape) return VP_EINVAL;
+    if (capacity < ctx->n_tr * sizeof(F)) return VP_EINVAL;
+    if (!ctx->simple_path) return prove_gkr_fused(ctx, tape, n_tape, transcript, n_written);
     if (!ctx || !ctx->evaluated || !tape || !transcript || n_tape != ctx->n_tape) return VP_EINVAL;
     if (capacity < ctx->n_tr * sizeof(F)) return VP_EINVAL;
     HIPCHK(hipSetDevice(ctx->device));
@@ -766,6 +848,278 @@ int vp_test_beta(vp_ctx *ctx, const vp_F *r, int n, const vp_F *init, vp_F *out)
     if (rc == VP_OK && hipMemcpy(out, dout, sizeof(F) << n, hipMemcpyDeviceToHost) != hipSuccess) rc = VP_EHIP;
     (void) hipFree(dr); (void) hipFree(dbf); (void) hipFree(dbs); (void) hipFree(dout);
     return rc;
+}
+
+}  // extern "C"
+
+// =====================================================================================================
+// Batched GKR, fused launches (default path of vp_prove_gkr; VP_GKR_PATH=simple selects the per-round one)
+// =====================================================================================================
+namespace {
+
+constexpr int TAIL_LOG = 9;                  // tables of <= 2^9 entries are finished by k_tail (one CU: ALU-bound beyond that)
+
+struct FusedSumcheck {
+    int n_tab = 0, rounds = 0, has_a = 1, phase = 0;
+    u32 off[VP_MAX_TAB], len0[VP_MAX_TAB], valid0[VP_MAX_TAB];
+    const F *V0 = nullptr;                   // round-1 V source (phase 1 / Liu: circuitValue[i-1]; phase 2: tab[0][0])
+    const F *r = nullptr;                    // r[k-1] = challenge of round k
+    F *poly_out = nullptr, *claims_out = nullptr;
+};
+
+inline int ilog2(u32 x) { int b = 0; while ((1u << (b + 1)) <= x) ++b; return b; }
+
+template <int R>
+void launch_sumfold(vp_ctx *ctx, const SfArgs &a, u32 grid) {
+    hipLaunchKernelGGL(k_sumfold<R>, dim3(grid), dim3(VP_BLOCK), 0, ctx->stream, a);
+}
+
+int run_sumcheck_fused(vp_ctx *ctx, const FusedSumcheck &sc) {
+    TailArgs ta{};
+    ta.V0 = sc.V0;
+    for (int b = 0; b < 2; ++b) for (int t = 0; t < 3; ++t) ta.buf[b][t] = ctx->tab[b][t];
+    ta.r = sc.r; ta.part = ctx->part2; ta.part_stride = MAX_BLOCKS * 3;
+    ta.n_tab = sc.n_tab; ta.rounds = sc.rounds; ta.has_a = sc.has_a;
+    ta.poly_out = sc.poly_out; ta.claims_out = sc.claims_out;
+    ta.Vu = sc.phase == 1 ? ctx->Vu() : nullptr;
+    u32 cur_len[VP_MAX_TAB]; u32 cur_valid[VP_MAX_TAB]; bool in_main[VP_MAX_TAB];
+    for (int j = 0; j < sc.n_tab; ++j) {
+        cur_len[j] = sc.len0[j]; cur_valid[j] = sc.valid0[j];
+        in_main[j] = sc.len0[j] > (1u << TAIL_LOG);
+        ta.t[j].off = sc.off[j]; ta.t[j].len0 = sc.len0[j]; ta.t[j].valid0 = sc.valid0[j];
+        ta.t[j].enter = 1; ta.t[j].cur = 0; ta.t[j].v_from_v0 = (sc.phase != 2) ? 1 : 0;
+    }
+    int k = 1, launch = 0;
+    for (;;) {
+        int R = 3, n_main = 0;
+        for (int j = 0; j < sc.n_tab; ++j)
+            if (in_main[j]) { ++n_main; R = std::min(R, ilog2(cur_len[j]) - TAIL_LOG); }
+        if (!n_main) break;
+        SfArgs a{};
+        if (launch == 0) { a.inV = sc.V0; a.inM = ctx->tab[0][1]; a.inA = ctx->tab[0][2]; }
+        else { F **t = ctx->tab[launch & 1]; a.inV = t[0]; a.inM = t[1]; a.inA = t[2]; }
+        { F **t = ctx->tab[(launch + 1) & 1]; a.outV = t[0]; a.outM = t[1]; a.outA = t[2]; }
+        a.r = sc.r + (k - 1);
+        a.part = ctx->part2 + (size_t) (k - 1) * MAX_BLOCKS * 3;
+        a.part_stride = MAX_BLOCKS * 3;
+        a.has_a = sc.has_a;
+        u32 chunks = 0; int nt = 0; u64 bytes = 0;
+        const u32 per = 64u << R;
+        for (int j = 0; j < sc.n_tab; ++j) {
+            if (!in_main[j]) continue;
+            SfTab &t = a.t[nt++];
+            t.off = sc.off[j]; t.len = cur_len[j]; t.valid = cur_valid[j]; t.chunk_start = chunks;
+            chunks += (cur_valid[j] + per - 1) / per;
+            const u32 vout = (cur_valid[j] + (1u << R) - 1) >> R;
+            bytes += (u64) (cur_valid[j] + vout) * (sc.has_a ? 48 : 32);
+        }
+        a.n_tab = nt; a.total_chunks = chunks;
+        const u32 grid = std::max<u32>(1, std::min<u32>((chunks + 3) / 4, MAX_BLOCKS));
+        const bool prof = ctx->profiling && chunks >= 64 && ctx->ev_used < ctx->ev_pool.size();
+        if (prof) hipEventRecord(ctx->ev_pool[ctx->ev_used].a, ctx->stream);
+        if (R == 3) launch_sumfold<3>(ctx, a, grid); else if (R == 2) launch_sumfold<2>(ctx, a, grid); else launch_sumfold<1>(ctx, a, grid);
+        if (prof) { hipEventRecord(ctx->ev_pool[ctx->ev_used].b, ctx->stream); ctx->ev_pool[ctx->ev_used++].bytes = bytes; }
+        count_launch(ctx);
+        for (int s = 0; s < R; ++s) ta.nblk[k - 1 + s] = (uint16_t) grid;
+        k += R; ++launch;
+        for (int j = 0; j < sc.n_tab; ++j) {
+            if (!in_main[j]) continue;
+            cur_len[j] >>= R;
+            cur_valid[j] = (cur_valid[j] + (1u << R) - 1) >> R;
+            if (cur_len[j] <= (1u << TAIL_LOG)) {
+                in_main[j] = false;
+                ta.t[j].enter = k; ta.t[j].cur = launch & 1;      // out buffer of the launch just issued
+                ta.t[j].v_from_v0 = 0;
+            }
+        }
+    }
+    // size the workgroup to the first-round pairs of the tables it owns (one wave per SIMD is the floor)
+    u32 tail_pairs = 0;
+    for (int j = 0; j < sc.n_tab; ++j) tail_pairs += (std::min<u32>(sc.len0[j], 1u << TAIL_LOG) + 1) / 2;
+    const u32 tail_threads = std::max<u32>(256, std::min<u32>(VP_TAIL_THREADS, (tail_pairs + 63) / 64 * 64));
+    hipLaunchKernelGGL(k_tail, dim3(1), dim3(tail_threads), 0, ctx->stream, ta);
+    count_launch(ctx);
+    ctx->st.rounds += sc.rounds;
+    return VP_OK;
+}
+
+// Segment path: k_seg launches (10 rounds each) until every table is down to <= 2^e entries, then k_emit.
+int run_sumcheck_seg(vp_ctx *ctx, const FusedSumcheck &sc) {
+    if (ctx->sumfold_path) return run_sumcheck_fused(ctx, sc);
+    const int e = sc.n_tab * 64 <= VP_EMIT_CAP ? 6 : sc.n_tab * 32 <= VP_EMIT_CAP ? 5 : 4;
+    const u32 E = 1u << e;
+    EmitArgs ea{};
+    ea.V0 = sc.V0;
+    for (int b = 0; b < 2; ++b) for (int t = 0; t < 3; ++t) ea.buf[b][t] = ctx->tab[b][t];
+    ea.r = sc.r; ea.part = ctx->part2; ea.part_stride = MAX_BLOCKS * 3;
+    ea.n_tab = sc.n_tab; ea.rounds = sc.rounds; ea.has_a = sc.has_a; ea.emit_log = e;
+    ea.poly_out = sc.poly_out; ea.claims_out = sc.claims_out;
+    ea.Vu = sc.phase == 1 ? ctx->Vu() : nullptr;
+    u32 cur_len[VP_MAX_TAB], cur_valid[VP_MAX_TAB];
+    for (int j = 0; j < sc.n_tab; ++j) {
+        cur_len[j] = sc.len0[j]; cur_valid[j] = sc.valid0[j];
+        EmitTab &t = ea.t[j];
+        t.off = sc.off[j]; t.enter = 1; t.len_enter = sc.len0[j]; t.valid_enter = sc.valid0[j];
+        t.src = 0; t.v_from_v0 = (sc.phase != 2) ? 1 : 0; t.bl = ilog2(sc.len0[j]);
+    }
+    int k = 1, launch = 0;
+    for (;;) {
+        SegArgs a{};
+        int nt = 0, n_rounds = 0; u32 segs = 0; u64 bytes = 0;
+        int part_idx[VP_MAX_TAB];
+        for (int j = 0; j < sc.n_tab; ++j) {
+            if (ea.t[j].enter != k || cur_len[j] <= E) continue;       // only tables in lockstep at round k
+            SegTab &t = a.t[nt];
+            t.off = sc.off[j]; t.valid = cur_valid[j]; t.seg_start = segs;
+            t.seg_log = std::min(VP_SEG_LOG, ilog2(cur_len[j]));
+            segs += (cur_valid[j] + (1u << t.seg_log) - 1) >> t.seg_log;
+            n_rounds = std::max(n_rounds, t.seg_log);
+            bytes += (u64) cur_valid[j] * (sc.has_a ? 48 : 32);
+            part_idx[nt++] = j;
+        }
+        if (!nt) break;
+        if (launch == 0) { a.inV = sc.V0; a.inM = ctx->tab[0][1]; a.inA = ctx->tab[0][2]; }
+        else { F **t = ctx->tab[launch & 1]; a.inV = t[0]; a.inM = t[1]; a.inA = t[2]; }
+        { F **t = ctx->tab[(launch + 1) & 1]; a.outV = t[0]; a.outM = t[1]; a.outA = t[2]; }
+        a.r = sc.r + (k - 1);
+        a.part = ctx->part2 + (size_t) (k - 1) * MAX_BLOCKS * 3;
+        a.part_stride = MAX_BLOCKS * 3;
+        a.total_segs = segs; a.n_tab = nt; a.n_rounds = n_rounds;
+        const u32 grid = std::max<u32>(1, std::min<u32>(segs, 512));
+        const bool prof = ctx->profiling && segs >= 256 && ctx->ev_used < ctx->ev_pool.size();
+        if (prof) hipEventRecord(ctx->ev_pool[ctx->ev_used].a, ctx->stream);
+        if (sc.has_a) hipLaunchKernelGGL(k_seg<true>, dim3(grid), dim3(VP_SEG_THREADS), 0, ctx->stream, a);
+        else hipLaunchKernelGGL(k_seg<false>, dim3(grid), dim3(VP_SEG_THREADS), 0, ctx->stream, a);
+        if (prof) { hipEventRecord(ctx->ev_pool[ctx->ev_used].b, ctx->stream); ctx->ev_pool[ctx->ev_used++].bytes = bytes; }
+        count_launch(ctx);
+        for (int s = 0; s < n_rounds; ++s) ea.nblk[k - 1 + s] = (uint16_t) grid;
+        for (int q = 0; q < nt; ++q) {
+            const int j = part_idx[q];
+            const int sl = a.t[q].seg_log;
+            cur_len[j] >>= sl;
+            cur_valid[j] = (cur_valid[j] + (1u << sl) - 1) >> sl;
+            EmitTab &t = ea.t[j];
+            t.enter = k + sl; t.len_enter = cur_len[j]; t.valid_enter = cur_valid[j];
+            t.src = (launch + 1) & 1; t.v_from_v0 = 0;
+        }
+        k += n_rounds; ++launch;
+        if (n_rounds < VP_SEG_LOG) break;                              // every participant is finished
+    }
+    // rounds in which k_emit has table work: pairs while len >= 2, the retire / claim round when len == 1
+    for (int j = 0; j < sc.n_tab; ++j) {
+        const EmitTab &t = ea.t[j];
+        const int last = t.enter + ilog2(std::max<u32>(1, t.len_enter));
+        for (int kk = t.enter; kk <= last && kk <= std::max(sc.rounds, 1); ++kk) ea.work_mask |= 1u << (kk - 1);
+        if (t.enter <= std::max(sc.rounds, 1)) ea.enter_mask |= 1u << (t.enter - 1);
+    }
+    const size_t lds = ((size_t) 6 * sc.n_tab * E + VP_EMIT_LDS_EXTRA_F) * sizeof(F) + VP_MAX_TAB * sizeof(int);
+    hipLaunchKernelGGL(k_emit, dim3(1), dim3(VP_EMIT_THREADS), lds, ctx->stream, ea);
+    count_launch(ctx);
+    ctx->st.rounds += sc.rounds;
+    return VP_OK;
+}
+
+template <int PHASE>
+int run_init2_rows(vp_ctx *ctx, const Csr &c, InitArgs2 &a) {
+    a.rowptr = c.rowptr; a.e_g = c.e_g; a.e_x = c.e_x; a.e_tl = c.e_tl; a.n_rows = c.n_rows;
+    if (c.n_rows) {
+        hipLaunchKernelGGL(k_init2_light<PHASE>, dim3(nblk(c.n_rows)), dim3(VP_BLOCK), 0, ctx->stream, a);
+        count_launch(ctx);
+    }
+    if (c.n_chunks) {
+        hipLaunchKernelGGL(k_init2_chunks<PHASE>, dim3((c.n_chunks + 3) / 4), dim3(VP_BLOCK), 0, ctx->stream, a,
+                           c.chunk_beg, c.chunk_end, c.n_chunks, ctx->chunk_part);
+        hipLaunchKernelGGL(k_init_combine, dim3((c.n_heavy + 3) / 4), dim3(VP_BLOCK), 0, ctx->stream, c.heavy_row,
+                           c.heavy_cptr, c.n_heavy, ctx->chunk_part, a.M, a.A);
+        count_launch(ctx); count_launch(ctx);
+    }
+    return VP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+static int prove_gkr_fused(vp_ctx *ctx, const vp_F *tape, uint64_t n_tape, uint8_t *transcript, uint64_t *n_written) {
+    HIPCHK(hipSetDevice(ctx->device));
+    const int n = ctx->n_layers;
+    ctx->st.launches = 0; ctx->st.rounds = 0; ctx->ev_used = 0;
+    HIPCHK(hipMemcpyAsync(ctx->d_tape, tape, n_tape * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    F *tr = ctx->d_tr;
+    u64 pos = 0;
+    // every eq half table of the proof in one launch (they depend on the tape only)
+    hipLaunchKernelGGL(k_beta_half_multi, dim3(ctx->n_all_jobs), dim3(VP_BLOCK), 0, ctx->stream, ctx->all_jobs);
+    count_launch(ctx);
+    {   // Vres (verifier.cpp:151): eq(r_0, .) is layer n-1's phase-1 table
+        LayerDev &T = ctx->L[n - 1];
+        hipLaunchKernelGGL(k_vres2, dim3(1), dim3(VP_BLOCK), 0, ctx->stream, T.hg, T.val, (u32) T.size, tr + pos);
+        count_launch(ctx);
+        pos += 1;
+    }
+    for (int i = n - 1; i >= 1; --i) {
+        LayerDev &cur = ctx->L[i], &pre = ctx->L[i - 1];
+        const int pbl = pre.bl;
+        // ---- phase 1 ----
+        {
+            InitArgs2 a{};
+            a.hg = cur.hg; a.vals = ctx->d_vals; a.gc = cur.gc; a.assert_r = ctx->d_tape + ctx->as_off[i];
+            a.M = ctx->tab[0][1]; a.A = ctx->tab[0][2];
+            VPCHK(run_init2_rows<1>(ctx, cur.c1, a));
+            FusedSumcheck sc;
+            sc.n_tab = 1; sc.rounds = pbl; sc.has_a = 1; sc.phase = 1;
+            sc.off[0] = 0; sc.len0[0] = 1u << pbl; sc.valid0[0] = (u32) pre.size;
+            sc.V0 = pre.val; sc.r = ctx->d_tape + ctx->ru_off[i];
+            sc.poly_out = tr + pos; sc.claims_out = tr + pos + 3 * (u64) pbl;
+            VPCHK(run_sumcheck_seg(ctx, sc));
+            pos += 3 * (u64) pbl + 1;
+        }
+        // ---- phase 2 ----
+        const int mdb = cur.max_dad_bl;
+        if (mdb != -1) {
+            InitArgs2 a{};
+            a.hg = cur.hg; a.hu = cur.hu; a.vals = ctx->d_vals; a.gc = cur.gc; a.assert_r = ctx->d_tape + ctx->as_off[i];
+            a.Vu = ctx->Vu();
+            a.V = ctx->tab[0][0]; a.M = ctx->tab[0][1]; a.A = ctx->tab[0][2];
+            a.s_layer = cur.s_layer; a.s_idx = cur.s_idx;
+            VPCHK(run_init2_rows<2>(ctx, cur.c2, a));
+            FusedSumcheck sc;
+            sc.n_tab = i; sc.rounds = mdb; sc.has_a = 1; sc.phase = 2;
+            for (int j = 0; j < i; ++j) { sc.off[j] = cur.t_off[j]; sc.len0[j] = cur.t_len[j]; sc.valid0[j] = (u32) cur.dad_size[j]; }
+            sc.V0 = ctx->tab[0][0]; sc.r = ctx->d_tape + ctx->rv_off[i];
+            sc.poly_out = tr + pos; sc.claims_out = tr + pos + 3 * (u64) mdb;
+            VPCHK(run_sumcheck_seg(ctx, sc));
+            pos += 3 * (u64) mdb + i;
+        }
+        // ---- Liu ----
+        {
+            hipLaunchKernelGGL(k_liu_gather, dim3(nblk(pre.size)), dim3(VP_BLOCK), 0, ctx->stream, cur.lrow, cur.l_q,
+                               cur.l_g, cur.liu_H, (u32) pre.size, ctx->tab[0][1]);
+            count_launch(ctx);
+            FusedSumcheck sc;
+            sc.n_tab = 1; sc.rounds = pbl; sc.has_a = 0; sc.phase = 3;
+            sc.off[0] = 0; sc.len0[0] = 1u << pbl; sc.valid0[0] = (u32) pre.size;
+            sc.V0 = pre.val; sc.r = ctx->d_tape + ctx->rliu_off[i];
+            sc.poly_out = tr + pos; sc.claims_out = tr + pos + 3 * (u64) pbl;
+            VPCHK(run_sumcheck_seg(ctx, sc));
+            pos += 3 * (u64) pbl + 1;
+        }
+    }
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    if (pos != ctx->n_tr) { ctx->err = "internal: transcript size"; return VP_EINVAL; }
+    HIPCHK(hipMemcpyAsync(transcript, tr, pos * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
+    VPCHK(check_stream(ctx));
+    float ms = 0;
+    hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+    ctx->st.gkr_ms = ms;
+    ctx->st.fold_ms = 0; ctx->st.fold_bytes = 0; ctx->st.fold_launches = ctx->ev_used;
+    for (size_t e = 0; e < ctx->ev_used; ++e) {
+        float t = 0;
+        hipEventElapsedTime(&t, ctx->ev_pool[e].a, ctx->ev_pool[e].b);
+        ctx->st.fold_ms += t; ctx->st.fold_bytes += ctx->ev_pool[e].bytes;
+    }
+    if (n_written) *n_written = pos * sizeof(F);
+    return VP_OK;
 }
 
 }  // extern "C"
