@@ -895,8 +895,8 @@ namespace vp {
 
 #define VP_SEG_LOG 10
 #define VP_SEG (1 << VP_SEG_LOG)
-#define VP_SEG_THREADS 512
-#define VP_SEG_SLOTS 128            // 8 waves = 2 groups x 4 roles; a group covers 64 pair slots
+#define VP_SEG_THREADS 768          // 12 waves = 4 groups x 3 roles
+#define VP_SEG_SLOTS 256            // a group covers 64 pair slots
 
 struct SegTab {
     u32 off;          // table offset (same in input and output buffers)
@@ -915,17 +915,25 @@ struct SegArgs {
     SegTab t[VP_MAX_TAB];
 };
 
+// Round s of a 1024-entry segment has min(256, 512 >> s) active pair slots; their per-lane accumulators live in
+// LDS at racc_off(s) + slot (767 slots per role in all), so the round loop stays ROLLED: the whole kernel is a
+// few KB of code and stays in the instruction cache (the unrolled version was 62 KB and ran fetch-bound).
+__device__ __forceinline__ u32 racc_off(int s) {
+    return s == 0 ? 0u : s == 1 ? 256u : (768u - (512u >> (s - 1)));     // 0,256,512,640,704,736,752,760,764,766
+}
+
+// Wave-uniform roles, one code path: role t folds table t (0: V, 1: mult, 2: add) and computes one of the three
+// products of the pair: 0: (m1-m0)(v1-v0)   1: m0*v0   2: m1*v1.  Two multiplies per lane and pair.
 template <bool HAS_A>
 __global__ void __launch_bounds__(VP_SEG_THREADS) k_seg(SegArgs a) {
     __shared__ F bufA[3][VP_SEG];
     __shared__ F bufB[3][VP_SEG / 2];
-    __shared__ F red[(VP_SEG_THREADS / 64) * 3];
+    __shared__ F racc[4][768];                                     // [role][slot]; [3] = role 2's second sum (a0)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int role = __builtin_amdgcn_readfirstlane(w & 3);       // wave-uniform
-    const u32 slot = (u32) ((w >> 2) * 64 + lane);
-    F acc1[VP_SEG_LOG], acc2[VP_SEG_LOG];                          // role 0-2: acc1 = products; role 3: sums of da / a0
-#pragma unroll
-    for (int s = 0; s < VP_SEG_LOG; ++s) { acc1[s] = f_zero(); acc2[s] = f_zero(); }
+    const int role = __builtin_amdgcn_readfirstlane(w % 3);
+    const u32 pslot = (u32) ((w / 3) * 64 + lane);
+    for (int i = tid; i < 4 * 768; i += VP_SEG_THREADS) (&racc[0][0])[i] = f_zero();
+    __syncthreads();
 
     for (u32 seg = blockIdx.x; seg < a.total_segs; seg += gridDim.x) {
         int j = 0;
@@ -943,50 +951,37 @@ __global__ void __launch_bounds__(VP_SEG_THREADS) k_seg(SegArgs a) {
             if (HAS_A) bufA[2][i] = ok ? a.inA[base + i] : f_zero();
         }
         __syncthreads();
-#pragma unroll
-        for (int s = 0; s < VP_SEG_LOG; ++s) {
-            if (s < R) {
-                const F *sV = (s & 1) ? bufB[0] : bufA[0], *sM = (s & 1) ? bufB[1] : bufA[1], *sA = (s & 1) ? bufB[2] : bufA[2];
-                F *dV = (s & 1) ? bufA[0] : bufB[0], *dM = (s & 1) ? bufA[1] : bufB[1], *dA = (s & 1) ? bufA[2] : bufB[2];
-                const F rs = a.r[s];
-                const u32 n = S >> (s + 1);                                   // pairs of this round
-                const u32 vs = (vseg + (1u << s) - 1) >> s;                   // valid entries of this round
-                const u32 act = (vs + 1) >> 1;                                // pairs that can be non-zero
-                for (u32 p = slot; p < n; p += VP_SEG_SLOTS) {
-                    const bool live = p < act;
-                    if (role == 0) {
-                        F o = f_zero();
-                        if (live) {
-                            const F m0 = sM[2 * p], m1 = sM[2 * p + 1], v0 = sV[2 * p], v1 = sV[2 * p + 1];
-                            const F dv = f_sub(v1, v0);
-                            acc1[s] = f_add(acc1[s], f_mul(f_sub(m1, m0), dv));
-                            o = f_add(v0, f_mul(rs, dv));
-                        }
-                        dV[p] = o;
-                    } else if (role == 1) {
-                        F o = f_zero();
-                        if (live) {
-                            const F m0 = sM[2 * p], m1 = sM[2 * p + 1], v0 = sV[2 * p];
-                            acc1[s] = f_add(acc1[s], f_mul(m0, v0));
-                            o = f_add(m0, f_mul(rs, f_sub(m1, m0)));
-                        }
-                        dM[p] = o;
-                    } else if (role == 2) {
-                        if (live) acc1[s] = f_add(acc1[s], f_mul(sM[2 * p + 1], sV[2 * p + 1]));
-                    } else if (HAS_A) {
-                        F o = f_zero();
-                        if (live) {
-                            const F a0 = sA[2 * p], a1 = sA[2 * p + 1];
-                            const F da = f_sub(a1, a0);
-                            acc1[s] = f_add(acc1[s], da);
-                            acc2[s] = f_add(acc2[s], a0);
-                            o = f_add(a0, f_mul(rs, da));
-                        }
-                        dA[p] = o;
-                    }
-                }
-                __syncthreads();
+#pragma unroll 1
+        for (int s = 0; s < R; ++s) {
+            const F *src = (s & 1) ? &bufB[0][0] : &bufA[0][0];
+            F *dst = (s & 1) ? &bufA[0][0] : &bufB[0][0];
+            const u32 sstr = (s & 1) ? VP_SEG / 2 : VP_SEG, dstr = (s & 1) ? VP_SEG : VP_SEG / 2;
+            const F rs = a.r[s];
+            const u32 n = S >> (s + 1);                                   // pairs of this round
+            const u32 vs = (vseg + (1u << s) - 1) >> s;                   // valid entries of this round
+            const u32 act = (vs + 1) >> 1;                                // pairs that can be non-zero
+            const bool folds = HAS_A || role != 2;
+            const u32 ai = racc_off(s) + pslot;
+            F acc = f_zero(), acc2 = f_zero();
+            for (u32 p = pslot; p < n; p += VP_SEG_SLOTS) {
+                if (p >= act) { if (folds) dst[role * dstr + p] = f_zero(); continue; }
+                F c0 = f_zero(), c1 = f_zero();
+                if (folds) { c0 = src[role * sstr + 2 * p]; c1 = src[role * sstr + 2 * p + 1]; }
+                const F d = f_sub(c1, c0);
+                F x, y;
+                if (role == 0) { x = f_sub(src[sstr + 2 * p + 1], src[sstr + 2 * p]); y = d; }
+                else if (role == 1) { x = c0; y = src[2 * p]; }
+                else { x = src[sstr + 2 * p + 1]; y = src[2 * p + 1]; }
+                F qv = f_mul(x, y);
+                if (role == 2 && HAS_A) { qv = f_add(qv, d); acc2 = f_add(acc2, c0); }
+                acc = f_add(acc, qv);
+                if (folds) dst[role * dstr + p] = f_add(c0, f_mul(rs, d));
             }
+            if (pslot < n) {
+                racc[role][ai] = f_add(racc[role][ai], acc);
+                if (role == 2 && HAS_A) racc[3][ai] = f_add(racc[3][ai], acc2);
+            }
+            __syncthreads();
         }
         // the segment is down to one entry per table
         if (tid < 3 && q * S < td.valid) {
@@ -997,25 +992,23 @@ __global__ void __launch_bounds__(VP_SEG_THREADS) k_seg(SegArgs a) {
         }
         __syncthreads();
     }
-    // per-round block partials: lane contributions (a, b, c) by role, one block reduction per round
-#pragma unroll
-    for (int s = 0; s < VP_SEG_LOG; ++s) {
-        if (s < a.n_rounds) {
-            F ca = f_zero(), cb = f_zero(), cc = f_zero();
-            if (role == 0) { ca = acc1[s]; cb = f_neg(acc1[s]); }
-            else if (role == 1) { cb = f_neg(acc1[s]); cc = acc1[s]; }
-            else if (role == 2) { cb = acc1[s]; }
-            else if (HAS_A) { cb = acc1[s]; cc = acc2[s]; }
-            ca = wave_sum(ca); cb = wave_sum(cb); cc = wave_sum(cc);
-            if (lane == 0) { red[w * 3] = ca; red[w * 3 + 1] = cb; red[w * 3 + 2] = cc; }
-            __syncthreads();
-            if (tid < 3) {
-                F x = red[tid];
-                for (int k = 1; k < VP_SEG_THREADS / 64; ++k) x = f_add(x, red[k * 3 + tid]);
-                a.part[(size_t) s * a.part_stride + blockIdx.x * 3 + tid] = x;
-            }
-            __syncthreads();
-        }
+    // per-round block partials: wave q sums one (round, array) list of <= 256 slots, then 3 lanes per round combine
+    F *res = &bufA[0][0];                                        // [s][4]
+    for (int t = w; t < a.n_rounds * 4; t += VP_SEG_THREADS / 64) {
+        const int s = t >> 2, arr = t & 3;
+        const u32 cnt = min(256u, 512u >> s), o = racc_off(s);
+        F x = f_zero();
+        for (u32 i = lane; i < cnt; i += 64) x = f_add(x, racc[arr][o + i]);
+        x = wave_sum63(x);
+        if (lane == 63) res[t] = x;
+    }
+    __syncthreads();
+    if (tid < 3 * a.n_rounds) {
+        const int s = tid / 3, c = tid % 3;
+        const F R0 = res[s * 4], R1 = res[s * 4 + 1], R2 = res[s * 4 + 2], R3 = res[s * 4 + 3];
+        // a = sum dm*dv;  b = sum (m1*v1 + da) - a - sum m0*v0;  c = sum m0*v0 + sum a0
+        const F x = c == 0 ? R0 : c == 1 ? f_sub(R2, f_add(R0, R1)) : f_add(R1, R3);
+        a.part[(size_t) s * a.part_stride + blockIdx.x * 3 + c] = x;
     }
 }
 
@@ -1029,6 +1022,7 @@ __global__ void __launch_bounds__(VP_SEG_THREADS) k_seg(SegArgs a) {
 // ---------------------------------------------------------------------------------------------------
 #define VP_EMIT_THREADS 768         // 12 waves = 4 groups x 3 roles
 #define VP_EMIT_WAVES (VP_EMIT_THREADS / 64)
+#define VP_MAX_PD 24
 #define VP_EMIT_CAP 1280            // LDS entries per buffer per table family (2 x 3 x 1280 x 16 B = 120 KiB)
 struct EmitTab {
     u32 off;          // offset in the global buffers
@@ -1049,7 +1043,8 @@ struct EmitArgs {
     u32 work_mask;              // bit k-1: some table of this kernel has pairs or retires in round k
     u32 enter_mask;             // bit k-1: some table is loaded from global memory in round k
     F *poly_out, *claims_out, *Vu;
-    uint16_t nblk[32];
+    int n_pd;                   // launches that left block partials
+    struct { int k0, nr; u32 nblk, off; } pd[VP_MAX_PD];   // rounds k0..k0+nr-1: part[off + s*nblk*3 + b*3 + c]
     EmitTab t[VP_MAX_TAB];
 };
 
@@ -1073,10 +1068,13 @@ __global__ void __launch_bounds__(VP_EMIT_THREADS) k_emit(EmitArgs a) {
     if (tid < VP_MAX_TAB) { s_claim[tid] = f_zero(); s_retv[tid] = f_zero(); s_retk[tid] = 0; }
     // ---- phase 1: block partials of the k_seg launches, one round per wave ----
     for (int k = w + 1; k <= a.rounds; k += VP_EMIT_WAVES) {
-        const u32 nb = a.nblk[k - 1];
         F ca = f_zero(), cbv = f_zero(), cc = f_zero();
-        const F *pp = a.part + (size_t) (k - 1) * a.part_stride;
-        for (u32 i = lane; i < nb; i += 64) { ca = f_add(ca, pp[3 * i]); cbv = f_add(cbv, pp[3 * i + 1]); cc = f_add(cc, pp[3 * i + 2]); }
+        for (int d = 0; d < a.n_pd; ++d) {
+            if (k < a.pd[d].k0 || k >= a.pd[d].k0 + a.pd[d].nr) continue;
+            const u32 nb = a.pd[d].nblk;
+            const F *pp = a.part + a.pd[d].off + (size_t) (k - a.pd[d].k0) * nb * 3;
+            for (u32 i = lane; i < nb; i += 64) { ca = f_add(ca, pp[3 * i]); cbv = f_add(cbv, pp[3 * i + 1]); cc = f_add(cc, pp[3 * i + 2]); }
+        }
         ca = wave_sum63(ca); cbv = wave_sum63(cbv); cc = wave_sum63(cc);
         if (lane == 63) { psum[3 * (k - 1)] = ca; psum[3 * (k - 1) + 1] = cbv; psum[3 * (k - 1) + 2] = cc; }
     }
@@ -1175,7 +1173,6 @@ __global__ void __launch_bounds__(VP_EMIT_THREADS) k_emit(EmitArgs a) {
     if (tid < a.rounds * 3) {
         const int k = tid / 3, c = tid % 3;
         F t = psum[3 * k + c];
-        if (!a.nblk[k]) t = f_zero();
         if ((a.work_mask >> k) & 1u)
             for (int q = 0; q < VP_EMIT_WAVES; ++q) t = f_add(t, wred[((size_t) k * VP_EMIT_WAVES + q) * 3 + c]);
         psum[3 * k + c] = t;

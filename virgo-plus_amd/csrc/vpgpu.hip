@@ -857,6 +857,8 @@ int vp_test_beta(vp_ctx *ctx, const vp_F *r, int n, const vp_F *init, vp_F *out)
 // =====================================================================================================
 namespace {
 
+constexpr int SF_BIG_LOG = 17;               // k_sumfold while some lock-step table has >= 2^17 entries
+constexpr int SF_MIN_LOG = 9;                // ... and every one of them keeps >= 2^9 after the launch
 constexpr int TAIL_LOG = 9;                  // tables of <= 2^9 entries are finished by k_tail (one CU: ALU-bound beyond that)
 
 struct FusedSumcheck {
@@ -943,7 +945,11 @@ int run_sumcheck_fused(vp_ctx *ctx, const FusedSumcheck &sc) {
     return VP_OK;
 }
 
-// Segment path: k_seg launches (10 rounds each) until every table is down to <= 2^e entries, then k_emit.
+// Segment path.  Lock-step set = tables that still have more than 2^e entries at round k.
+//   throughput regime (some table >= 2^17): k_sumfold<3> on the tables with >= 512 entries, and one k_seg
+//       launch that finishes the shorter ones (separate partial region, same rounds);
+//   latency regime: k_seg on the whole set, ten rounds per launch;
+//   k_emit closes the sumcheck.
 int run_sumcheck_seg(vp_ctx *ctx, const FusedSumcheck &sc) {
     if (ctx->sumfold_path) return run_sumcheck_fused(ctx, sc);
     const int e = sc.n_tab * 64 <= VP_EMIT_CAP ? 6 : sc.n_tab * 32 <= VP_EMIT_CAP ? 5 : 4;
@@ -951,7 +957,7 @@ int run_sumcheck_seg(vp_ctx *ctx, const FusedSumcheck &sc) {
     EmitArgs ea{};
     ea.V0 = sc.V0;
     for (int b = 0; b < 2; ++b) for (int t = 0; t < 3; ++t) ea.buf[b][t] = ctx->tab[b][t];
-    ea.r = sc.r; ea.part = ctx->part2; ea.part_stride = MAX_BLOCKS * 3;
+    ea.r = sc.r; ea.part = ctx->part2; ea.part_stride = 0;
     ea.n_tab = sc.n_tab; ea.rounds = sc.rounds; ea.has_a = sc.has_a; ea.emit_log = e;
     ea.poly_out = sc.poly_out; ea.claims_out = sc.claims_out;
     ea.Vu = sc.phase == 1 ? ctx->Vu() : nullptr;
@@ -962,48 +968,88 @@ int run_sumcheck_seg(vp_ctx *ctx, const FusedSumcheck &sc) {
         t.off = sc.off[j]; t.enter = 1; t.len_enter = sc.len0[j]; t.valid_enter = sc.valid0[j];
         t.src = 0; t.v_from_v0 = (sc.phase != 2) ? 1 : 0; t.bl = ilog2(sc.len0[j]);
     }
+    u32 part_used = 0;
+    auto new_part = [&](int k0, int nr, u32 nblk) -> F * {
+        if (ea.n_pd >= VP_MAX_PD || (size_t) part_used + (size_t) nr * nblk * 3 > (size_t) 32 * MAX_BLOCKS * 3) return nullptr;
+        auto &d = ea.pd[ea.n_pd++];
+        d.k0 = k0; d.nr = nr; d.nblk = nblk; d.off = part_used;
+        part_used += (u32) nr * nblk * 3;
+        return ctx->part2 + d.off;
+    };
     int k = 1, launch = 0;
     for (;;) {
+        int L[VP_MAX_TAB], nL = 0; u32 maxlen = 0;
+        for (int j = 0; j < sc.n_tab; ++j)
+            if (ea.t[j].enter == k && cur_len[j] > E) { L[nL++] = j; maxlen = std::max(maxlen, cur_len[j]); }
+        if (!nL) break;
+        const F *inV, *inM, *inA;
+        if (launch == 0) { inV = sc.V0; inM = ctx->tab[0][1]; inA = ctx->tab[0][2]; }
+        else { F **t = ctx->tab[launch & 1]; inV = t[0]; inM = t[1]; inA = t[2]; }
+        F **to = ctx->tab[(launch + 1) & 1];
+        const bool throughput = maxlen >= (1u << SF_BIG_LOG);
+        // ---- k_sumfold<3> on the long tables ----
+        if (throughput) {
+            SfArgs a{};
+            a.inV = inV; a.inM = inM; a.inA = inA; a.outV = to[0]; a.outM = to[1]; a.outA = to[2];
+            a.r = sc.r + (k - 1); a.has_a = sc.has_a;
+            u32 chunks = 0; int nt = 0; u64 bytes = 0;
+            for (int q = 0; q < nL; ++q) {
+                const int j = L[q];
+                if (cur_len[j] < 512) continue;
+                SfTab &t = a.t[nt++];
+                t.off = sc.off[j]; t.len = cur_len[j]; t.valid = cur_valid[j]; t.chunk_start = chunks;
+                chunks += (cur_valid[j] + 511) / 512;
+                bytes += (u64) (cur_valid[j] + ((cur_valid[j] + 7) >> 3)) * (sc.has_a ? 48 : 32);
+            }
+            a.n_tab = nt; a.total_chunks = chunks;
+            const u32 grid = std::max<u32>(1, std::min<u32>((chunks + 3) / 4, MAX_BLOCKS));
+            a.part = new_part(k, 3, grid); a.part_stride = grid * 3;
+            if (!a.part) { ctx->err = "partial buffer exhausted"; return VP_ELIMIT; }
+            const bool prof = ctx->profiling && ctx->ev_used < ctx->ev_pool.size();
+            if (prof) hipEventRecord(ctx->ev_pool[ctx->ev_used].a, ctx->stream);
+            launch_sumfold<3>(ctx, a, grid);
+            if (prof) { hipEventRecord(ctx->ev_pool[ctx->ev_used].b, ctx->stream); ctx->ev_pool[ctx->ev_used++].bytes = bytes; }
+            count_launch(ctx);
+        }
+        // ---- k_seg on the rest (all of the set in the latency regime) ----
         SegArgs a{};
-        int nt = 0, n_rounds = 0; u32 segs = 0; u64 bytes = 0;
-        int part_idx[VP_MAX_TAB];
-        for (int j = 0; j < sc.n_tab; ++j) {
-            if (ea.t[j].enter != k || cur_len[j] <= E) continue;       // only tables in lockstep at round k
+        a.inV = inV; a.inM = inM; a.inA = inA; a.outV = to[0]; a.outM = to[1]; a.outA = to[2];
+        a.r = sc.r + (k - 1);
+        int nt = 0, n_rounds = 0; u32 segs = 0;
+        int seg_j[VP_MAX_TAB];
+        for (int q = 0; q < nL; ++q) {
+            const int j = L[q];
+            if (throughput && cur_len[j] >= 512) continue;
             SegTab &t = a.t[nt];
             t.off = sc.off[j]; t.valid = cur_valid[j]; t.seg_start = segs;
             t.seg_log = std::min(VP_SEG_LOG, ilog2(cur_len[j]));
             segs += (cur_valid[j] + (1u << t.seg_log) - 1) >> t.seg_log;
             n_rounds = std::max(n_rounds, t.seg_log);
-            bytes += (u64) cur_valid[j] * (sc.has_a ? 48 : 32);
-            part_idx[nt++] = j;
+            seg_j[nt++] = j;
         }
-        if (!nt) break;
-        if (launch == 0) { a.inV = sc.V0; a.inM = ctx->tab[0][1]; a.inA = ctx->tab[0][2]; }
-        else { F **t = ctx->tab[launch & 1]; a.inV = t[0]; a.inM = t[1]; a.inA = t[2]; }
-        { F **t = ctx->tab[(launch + 1) & 1]; a.outV = t[0]; a.outM = t[1]; a.outA = t[2]; }
-        a.r = sc.r + (k - 1);
-        a.part = ctx->part2 + (size_t) (k - 1) * MAX_BLOCKS * 3;
-        a.part_stride = MAX_BLOCKS * 3;
-        a.total_segs = segs; a.n_tab = nt; a.n_rounds = n_rounds;
-        const u32 grid = std::max<u32>(1, std::min<u32>(segs, 512));
-        const bool prof = ctx->profiling && segs >= 256 && ctx->ev_used < ctx->ev_pool.size();
-        if (prof) hipEventRecord(ctx->ev_pool[ctx->ev_used].a, ctx->stream);
-        if (sc.has_a) hipLaunchKernelGGL(k_seg<true>, dim3(grid), dim3(VP_SEG_THREADS), 0, ctx->stream, a);
-        else hipLaunchKernelGGL(k_seg<false>, dim3(grid), dim3(VP_SEG_THREADS), 0, ctx->stream, a);
-        if (prof) { hipEventRecord(ctx->ev_pool[ctx->ev_used].b, ctx->stream); ctx->ev_pool[ctx->ev_used++].bytes = bytes; }
-        count_launch(ctx);
-        for (int s = 0; s < n_rounds; ++s) ea.nblk[k - 1 + s] = (uint16_t) grid;
-        for (int q = 0; q < nt; ++q) {
-            const int j = part_idx[q];
-            const int sl = a.t[q].seg_log;
+        if (nt) {
+            a.total_segs = segs; a.n_tab = nt; a.n_rounds = n_rounds;
+            const u32 grid = std::max<u32>(1, std::min<u32>(segs, 512));
+            a.part = new_part(k, n_rounds, grid); a.part_stride = grid * 3;
+            if (!a.part) { ctx->err = "partial buffer exhausted"; return VP_ELIMIT; }
+            if (sc.has_a) hipLaunchKernelGGL(k_seg<true>, dim3(grid), dim3(VP_SEG_THREADS), 0, ctx->stream, a);
+            else hipLaunchKernelGGL(k_seg<false>, dim3(grid), dim3(VP_SEG_THREADS), 0, ctx->stream, a);
+            count_launch(ctx);
+        }
+        // ---- advance ----
+        int step = throughput ? 3 : n_rounds;
+        for (int q = 0; q < nL; ++q) {
+            const int j = L[q];
+            const bool via_sf = throughput && cur_len[j] >= 512;
+            const int sl = via_sf ? 3 : std::min(VP_SEG_LOG, ilog2(cur_len[j]));
             cur_len[j] >>= sl;
             cur_valid[j] = (cur_valid[j] + (1u << sl) - 1) >> sl;
             EmitTab &t = ea.t[j];
             t.enter = k + sl; t.len_enter = cur_len[j]; t.valid_enter = cur_valid[j];
             t.src = (launch + 1) & 1; t.v_from_v0 = 0;
         }
-        k += n_rounds; ++launch;
-        if (n_rounds < VP_SEG_LOG) break;                              // every participant is finished
+        k += step; ++launch;
+        if (!throughput && n_rounds < VP_SEG_LOG) break;               // every table of the set is finished
     }
     // rounds in which k_emit has table work: pairs while len >= 2, the retire / claim round when len == 1
     for (int j = 0; j < sc.n_tab; ++j) {
