@@ -141,15 +141,22 @@ def main():
         dev_ms = 0.0
         res = None
         for k in range(a.steps):
-            if k == a.steps - 1:
-                sess.set_profiling(1)                    # HIP events around the dominant kernel, last timed step
             tr, res = sess.prove_gkr()
             dev_ms += res["gkr_device_ms"]
         gpu_sync(local)
         barrier(world)
         elapsed = time.perf_counter() - t0
-        sess.set_profiling(0)
         elapsed, proofs = aggregate(world, elapsed, float(a.steps))
+        # Roofline pass (outside the timed region, same process, same resident state): the proof is replayed on ONE
+        # stream with HIP events around every launch of the dominant kernel.  In the timed steps the independent
+        # sumchecks overlap on separate streams, which makes per-kernel event times meaningless there.
+        sess.set_profiling(1)
+        tr_p, res_p = sess.prove_gkr()
+        sess.set_profiling(0)
+        assert tr_p == tr
+        for key in ("fold_ms", "fold_launches", "fold_bytes"):
+            res[key] = res_p[key]
+        res["serial_device_ms"] = res_p["gkr_device_ms"]
 
         bit_exact = None
         ref_ops = None
@@ -186,7 +193,8 @@ def main():
                 gbps = res["fold_bytes"] / (res["fold_ms"] * 1e-3) / 1e9
                 line["roofline"] = {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                     "frac": gbps / HBM_PEAK_GBPS, "traffic": None,
-                                    "kernel": "k_round_main (launches with >= 32768 pairs)",
+                                    "kernel": "k_sumfold<3> (every launch; single-stream replay of the same proof)",
+                                    "single_stream_proof_ms": res.get("serial_device_ms"),
                                     "launches": res["fold_launches"], "avg_launch_us": 1e3 * avg_ms,
                                     "algorithmic_bytes_per_launch": res["fold_bytes"] / res["fold_launches"]}
             else:

@@ -58,6 +58,15 @@ struct EvPair { hipEvent_t a, b; u64 bytes; };
 
 }  // namespace
 
+// One in-order chain of the batched proof: its own stream and scratch, so that independent sumchecks
+// (all of them, given the tape, except phase 1 -> phase 2 of the same layer) overlap on the device.
+struct Lane {
+    hipStream_t stream = nullptr;
+    F *tab[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    F *part2 = nullptr, *chunk_part = nullptr, *Vu = nullptr;
+    hipEvent_t done = nullptr;
+};
+
 struct vp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -88,7 +97,10 @@ struct vp_ctx {
     std::vector<void *> allocs;
     BetaJob *all_jobs = nullptr; u32 n_all_jobs = 0; F *half_pool = nullptr;
     F *part2 = nullptr;                  // [32][MAX_BLOCKS*3] block partials of the batched path
-    int simple_path = 0, sumfold_path = 0;
+    int simple_path = 0, sumfold_path = 0, serial = 0;
+    Lane lane0; Lane *ln = nullptr;
+    std::vector<Lane> lanes;          // [2*(i-1)] = phases 1+2 of layer i, [2*(i-1)+1] = Liu of layer i
+    std::vector<hipStream_t> lane_streams; std::vector<hipEvent_t> lane_events; hipEvent_t ev_fork = nullptr;
 
     F *zero() const { return small; }
     F *one() const { return small + 1; }
@@ -397,6 +409,9 @@ void vp_destroy(vp_ctx *ctx) {
     if (ctx->ev0) (void) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void) hipEventDestroy(ctx->ev1);
     if (ctx->h_pin) (void) hipHostFree(ctx->h_pin);
+    for (auto st : ctx->lane_streams) (void) hipStreamDestroy(st);
+    for (auto ev : ctx->lane_events) (void) hipEventDestroy(ev);
+    if (ctx->ev_fork) (void) hipEventDestroy(ctx->ev_fork);
     (void) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -601,6 +616,40 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
             VPCHK(dupload(ctx, &D.lrow, rp)); VPCHK(dupload(ctx, &D.l_g, eg)); VPCHK(dupload(ctx, &D.l_q, eq));
         }
         VPCHK(dalloc(ctx, &ctx->part2, (size_t) 32 * MAX_BLOCKS * 3));
+        // lanes: per-layer scratch for the concurrent chains
+        ctx->lane0.stream = ctx->stream;
+        for (int b = 0; b < 2; ++b) for (int t = 0; t < 3; ++t) ctx->lane0.tab[b][t] = ctx->tab[b][t];
+        ctx->lane0.part2 = ctx->part2; ctx->lane0.chunk_part = ctx->chunk_part; ctx->lane0.Vu = ctx->Vu();
+        ctx->ln = &ctx->lane0;
+        const int n_lanes = 2 * (n_layers - 1);
+        while ((int) ctx->lane_streams.size() < n_lanes) {
+            hipStream_t st; hipEvent_t ev;
+            HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            ctx->lane_streams.push_back(st); ctx->lane_events.push_back(ev);
+        }
+        if (!ctx->ev_fork) HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        ctx->lanes.assign(n_lanes, Lane());
+        F *vus = nullptr;
+        VPCHK(dalloc(ctx, &vus, (size_t) n_layers));
+        for (int i = 1; i < n_layers; ++i) {
+            for (int h = 0; h < 2; ++h) {
+                Lane &ln = ctx->lanes[2 * (i - 1) + h];
+                ln.stream = ctx->lane_streams[2 * (i - 1) + h];
+                ln.done = ctx->lane_events[2 * (i - 1) + h];
+                const size_t capi = h == 0 ? std::max<size_t>((size_t) 1 << ctx->L[i - 1].bl, ctx->L[i].p2_total) : ((size_t) 1 << ctx->L[i - 1].bl);
+                for (int b = 0; b < 2; ++b) for (int t = 0; t < 3; ++t) {
+                    if (h == 1 && t == 2) { ln.tab[b][t] = ctx->tab[0][2]; continue; }     // Liu never touches the add table
+                    VPCHK(dalloc(ctx, &ln.tab[b][t], capi));
+                }
+                VPCHK(dalloc(ctx, &ln.part2, (size_t) 16 * MAX_BLOCKS * 3));
+                const u32 nch = h == 0 ? std::max(ctx->L[i].c1.n_chunks, ctx->L[i].c2.n_chunks) : 0;
+                VPCHK(dalloc(ctx, &ln.chunk_part, (size_t) 2 * std::max<u32>(1, nch)));
+                ln.Vu = vus + i;
+            }
+        }
+        const char *ser = getenv("VP_GKR_SERIAL");
+        ctx->serial = (ser && ser[0] == '1') ? 1 : 0;
         const char *pth = getenv("VP_GKR_PATH");
         ctx->simple_path = (pth && !strcmp(pth, "simple")) ? 1 : 0;
         ctx->sumfold_path = (pth && !strcmp(pth, "sumfold")) ? 1 : 0;
@@ -873,17 +922,17 @@ inline int ilog2(u32 x) { int b = 0; while ((1u << (b + 1)) <= x) ++b; return b;
 
 template <int R>
 void launch_sumfold(vp_ctx *ctx, const SfArgs &a, u32 grid) {
-    hipLaunchKernelGGL(k_sumfold<R>, dim3(grid), dim3(VP_BLOCK), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_sumfold<R>, dim3(grid), dim3(VP_BLOCK), 0, ctx->ln->stream, a);
 }
 
 int run_sumcheck_fused(vp_ctx *ctx, const FusedSumcheck &sc) {
     TailArgs ta{};
     ta.V0 = sc.V0;
-    for (int b = 0; b < 2; ++b) for (int t = 0; t < 3; ++t) ta.buf[b][t] = ctx->tab[b][t];
-    ta.r = sc.r; ta.part = ctx->part2; ta.part_stride = MAX_BLOCKS * 3;
+    for (int b = 0; b < 2; ++b) for (int t = 0; t < 3; ++t) ta.buf[b][t] = ctx->ln->tab[b][t];
+    ta.r = sc.r; ta.part = ctx->ln->part2; ta.part_stride = MAX_BLOCKS * 3;
     ta.n_tab = sc.n_tab; ta.rounds = sc.rounds; ta.has_a = sc.has_a;
     ta.poly_out = sc.poly_out; ta.claims_out = sc.claims_out;
-    ta.Vu = sc.phase == 1 ? ctx->Vu() : nullptr;
+    ta.Vu = sc.phase == 1 ? ctx->ln->Vu : nullptr;
     u32 cur_len[VP_MAX_TAB]; u32 cur_valid[VP_MAX_TAB]; bool in_main[VP_MAX_TAB];
     for (int j = 0; j < sc.n_tab; ++j) {
         cur_len[j] = sc.len0[j]; cur_valid[j] = sc.valid0[j];
@@ -898,11 +947,11 @@ int run_sumcheck_fused(vp_ctx *ctx, const FusedSumcheck &sc) {
             if (in_main[j]) { ++n_main; R = std::min(R, ilog2(cur_len[j]) - TAIL_LOG); }
         if (!n_main) break;
         SfArgs a{};
-        if (launch == 0) { a.inV = sc.V0; a.inM = ctx->tab[0][1]; a.inA = ctx->tab[0][2]; }
-        else { F **t = ctx->tab[launch & 1]; a.inV = t[0]; a.inM = t[1]; a.inA = t[2]; }
-        { F **t = ctx->tab[(launch + 1) & 1]; a.outV = t[0]; a.outM = t[1]; a.outA = t[2]; }
+        if (launch == 0) { a.inV = sc.V0; a.inM = ctx->ln->tab[0][1]; a.inA = ctx->ln->tab[0][2]; }
+        else { F **t = ctx->ln->tab[launch & 1]; a.inV = t[0]; a.inM = t[1]; a.inA = t[2]; }
+        { F **t = ctx->ln->tab[(launch + 1) & 1]; a.outV = t[0]; a.outM = t[1]; a.outA = t[2]; }
         a.r = sc.r + (k - 1);
-        a.part = ctx->part2 + (size_t) (k - 1) * MAX_BLOCKS * 3;
+        a.part = ctx->ln->part2 + (size_t) (k - 1) * MAX_BLOCKS * 3;
         a.part_stride = MAX_BLOCKS * 3;
         a.has_a = sc.has_a;
         u32 chunks = 0; int nt = 0; u64 bytes = 0;
@@ -918,9 +967,9 @@ int run_sumcheck_fused(vp_ctx *ctx, const FusedSumcheck &sc) {
         a.n_tab = nt; a.total_chunks = chunks;
         const u32 grid = std::max<u32>(1, std::min<u32>((chunks + 3) / 4, MAX_BLOCKS));
         const bool prof = ctx->profiling && chunks >= 64 && ctx->ev_used < ctx->ev_pool.size();
-        if (prof) hipEventRecord(ctx->ev_pool[ctx->ev_used].a, ctx->stream);
+        if (prof) hipEventRecord(ctx->ev_pool[ctx->ev_used].a, ctx->ln->stream);
         if (R == 3) launch_sumfold<3>(ctx, a, grid); else if (R == 2) launch_sumfold<2>(ctx, a, grid); else launch_sumfold<1>(ctx, a, grid);
-        if (prof) { hipEventRecord(ctx->ev_pool[ctx->ev_used].b, ctx->stream); ctx->ev_pool[ctx->ev_used++].bytes = bytes; }
+        if (prof) { hipEventRecord(ctx->ev_pool[ctx->ev_used].b, ctx->ln->stream); ctx->ev_pool[ctx->ev_used++].bytes = bytes; }
         count_launch(ctx);
         for (int s = 0; s < R; ++s) ta.nblk[k - 1 + s] = (uint16_t) grid;
         k += R; ++launch;
@@ -939,7 +988,7 @@ int run_sumcheck_fused(vp_ctx *ctx, const FusedSumcheck &sc) {
     u32 tail_pairs = 0;
     for (int j = 0; j < sc.n_tab; ++j) tail_pairs += (std::min<u32>(sc.len0[j], 1u << TAIL_LOG) + 1) / 2;
     const u32 tail_threads = std::max<u32>(256, std::min<u32>(VP_TAIL_THREADS, (tail_pairs + 63) / 64 * 64));
-    hipLaunchKernelGGL(k_tail, dim3(1), dim3(tail_threads), 0, ctx->stream, ta);
+    hipLaunchKernelGGL(k_tail, dim3(1), dim3(tail_threads), 0, ctx->ln->stream, ta);
     count_launch(ctx);
     ctx->st.rounds += sc.rounds;
     return VP_OK;
@@ -956,11 +1005,11 @@ int run_sumcheck_seg(vp_ctx *ctx, const FusedSumcheck &sc) {
     const u32 E = 1u << e;
     EmitArgs ea{};
     ea.V0 = sc.V0;
-    for (int b = 0; b < 2; ++b) for (int t = 0; t < 3; ++t) ea.buf[b][t] = ctx->tab[b][t];
-    ea.r = sc.r; ea.part = ctx->part2; ea.part_stride = 0;
+    for (int b = 0; b < 2; ++b) for (int t = 0; t < 3; ++t) ea.buf[b][t] = ctx->ln->tab[b][t];
+    ea.r = sc.r; ea.part = ctx->ln->part2; ea.part_stride = 0;
     ea.n_tab = sc.n_tab; ea.rounds = sc.rounds; ea.has_a = sc.has_a; ea.emit_log = e;
     ea.poly_out = sc.poly_out; ea.claims_out = sc.claims_out;
-    ea.Vu = sc.phase == 1 ? ctx->Vu() : nullptr;
+    ea.Vu = sc.phase == 1 ? ctx->ln->Vu : nullptr;
     u32 cur_len[VP_MAX_TAB], cur_valid[VP_MAX_TAB];
     for (int j = 0; j < sc.n_tab; ++j) {
         cur_len[j] = sc.len0[j]; cur_valid[j] = sc.valid0[j];
@@ -970,11 +1019,11 @@ int run_sumcheck_seg(vp_ctx *ctx, const FusedSumcheck &sc) {
     }
     u32 part_used = 0;
     auto new_part = [&](int k0, int nr, u32 nblk) -> F * {
-        if (ea.n_pd >= VP_MAX_PD || (size_t) part_used + (size_t) nr * nblk * 3 > (size_t) 32 * MAX_BLOCKS * 3) return nullptr;
+        if (ea.n_pd >= VP_MAX_PD || (size_t) part_used + (size_t) nr * nblk * 3 > (size_t) 16 * MAX_BLOCKS * 3) return nullptr;
         auto &d = ea.pd[ea.n_pd++];
         d.k0 = k0; d.nr = nr; d.nblk = nblk; d.off = part_used;
         part_used += (u32) nr * nblk * 3;
-        return ctx->part2 + d.off;
+        return ctx->ln->part2 + d.off;
     };
     int k = 1, launch = 0;
     for (;;) {
@@ -983,9 +1032,9 @@ int run_sumcheck_seg(vp_ctx *ctx, const FusedSumcheck &sc) {
             if (ea.t[j].enter == k && cur_len[j] > E) { L[nL++] = j; maxlen = std::max(maxlen, cur_len[j]); }
         if (!nL) break;
         const F *inV, *inM, *inA;
-        if (launch == 0) { inV = sc.V0; inM = ctx->tab[0][1]; inA = ctx->tab[0][2]; }
-        else { F **t = ctx->tab[launch & 1]; inV = t[0]; inM = t[1]; inA = t[2]; }
-        F **to = ctx->tab[(launch + 1) & 1];
+        if (launch == 0) { inV = sc.V0; inM = ctx->ln->tab[0][1]; inA = ctx->ln->tab[0][2]; }
+        else { F **t = ctx->ln->tab[launch & 1]; inV = t[0]; inM = t[1]; inA = t[2]; }
+        F **to = ctx->ln->tab[(launch + 1) & 1];
         const bool throughput = maxlen >= (1u << SF_BIG_LOG);
         // ---- k_sumfold<3> on the long tables ----
         if (throughput) {
@@ -1006,9 +1055,9 @@ int run_sumcheck_seg(vp_ctx *ctx, const FusedSumcheck &sc) {
             a.part = new_part(k, 3, grid); a.part_stride = grid * 3;
             if (!a.part) { ctx->err = "partial buffer exhausted"; return VP_ELIMIT; }
             const bool prof = ctx->profiling && ctx->ev_used < ctx->ev_pool.size();
-            if (prof) hipEventRecord(ctx->ev_pool[ctx->ev_used].a, ctx->stream);
+            if (prof) hipEventRecord(ctx->ev_pool[ctx->ev_used].a, ctx->ln->stream);
             launch_sumfold<3>(ctx, a, grid);
-            if (prof) { hipEventRecord(ctx->ev_pool[ctx->ev_used].b, ctx->stream); ctx->ev_pool[ctx->ev_used++].bytes = bytes; }
+            if (prof) { hipEventRecord(ctx->ev_pool[ctx->ev_used].b, ctx->ln->stream); ctx->ev_pool[ctx->ev_used++].bytes = bytes; }
             count_launch(ctx);
         }
         // ---- k_seg on the rest (all of the set in the latency regime) ----
@@ -1032,8 +1081,8 @@ int run_sumcheck_seg(vp_ctx *ctx, const FusedSumcheck &sc) {
             const u32 grid = std::max<u32>(1, std::min<u32>(segs, 512));
             a.part = new_part(k, n_rounds, grid); a.part_stride = grid * 3;
             if (!a.part) { ctx->err = "partial buffer exhausted"; return VP_ELIMIT; }
-            if (sc.has_a) hipLaunchKernelGGL(k_seg<true>, dim3(grid), dim3(VP_SEG_THREADS), 0, ctx->stream, a);
-            else hipLaunchKernelGGL(k_seg<false>, dim3(grid), dim3(VP_SEG_THREADS), 0, ctx->stream, a);
+            if (sc.has_a) hipLaunchKernelGGL(k_seg<true>, dim3(grid), dim3(VP_SEG_THREADS), 0, ctx->ln->stream, a);
+            else hipLaunchKernelGGL(k_seg<false>, dim3(grid), dim3(VP_SEG_THREADS), 0, ctx->ln->stream, a);
             count_launch(ctx);
         }
         // ---- advance ----
@@ -1059,7 +1108,7 @@ int run_sumcheck_seg(vp_ctx *ctx, const FusedSumcheck &sc) {
         if (t.enter <= std::max(sc.rounds, 1)) ea.enter_mask |= 1u << (t.enter - 1);
     }
     const size_t lds = ((size_t) 6 * sc.n_tab * E + VP_EMIT_LDS_EXTRA_F) * sizeof(F) + VP_MAX_TAB * sizeof(int);
-    hipLaunchKernelGGL(k_emit, dim3(1), dim3(VP_EMIT_THREADS), lds, ctx->stream, ea);
+    hipLaunchKernelGGL(k_emit, dim3(1), dim3(VP_EMIT_THREADS), lds, ctx->ln->stream, ea);
     count_launch(ctx);
     ctx->st.rounds += sc.rounds;
     return VP_OK;
@@ -1069,14 +1118,14 @@ template <int PHASE>
 int run_init2_rows(vp_ctx *ctx, const Csr &c, InitArgs2 &a) {
     a.rowptr = c.rowptr; a.e_g = c.e_g; a.e_x = c.e_x; a.e_tl = c.e_tl; a.n_rows = c.n_rows;
     if (c.n_rows) {
-        hipLaunchKernelGGL(k_init2_light<PHASE>, dim3(nblk(c.n_rows)), dim3(VP_BLOCK), 0, ctx->stream, a);
+        hipLaunchKernelGGL(k_init2_light<PHASE>, dim3(nblk(c.n_rows)), dim3(VP_BLOCK), 0, ctx->ln->stream, a);
         count_launch(ctx);
     }
     if (c.n_chunks) {
-        hipLaunchKernelGGL(k_init2_chunks<PHASE>, dim3((c.n_chunks + 3) / 4), dim3(VP_BLOCK), 0, ctx->stream, a,
-                           c.chunk_beg, c.chunk_end, c.n_chunks, ctx->chunk_part);
-        hipLaunchKernelGGL(k_init_combine, dim3((c.n_heavy + 3) / 4), dim3(VP_BLOCK), 0, ctx->stream, c.heavy_row,
-                           c.heavy_cptr, c.n_heavy, ctx->chunk_part, a.M, a.A);
+        hipLaunchKernelGGL(k_init2_chunks<PHASE>, dim3((c.n_chunks + 3) / 4), dim3(VP_BLOCK), 0, ctx->ln->stream, a,
+                           c.chunk_beg, c.chunk_end, c.n_chunks, ctx->ln->chunk_part);
+        hipLaunchKernelGGL(k_init_combine, dim3((c.n_heavy + 3) / 4), dim3(VP_BLOCK), 0, ctx->ln->stream, c.heavy_row,
+                           c.heavy_cptr, c.n_heavy, ctx->ln->chunk_part, a.M, a.A);
         count_launch(ctx); count_launch(ctx);
     }
     return VP_OK;
@@ -1090,69 +1139,97 @@ static int prove_gkr_fused(vp_ctx *ctx, const vp_F *tape, uint64_t n_tape, uint8
     HIPCHK(hipSetDevice(ctx->device));
     const int n = ctx->n_layers;
     ctx->st.launches = 0; ctx->st.rounds = 0; ctx->ev_used = 0;
+    // Given the tape, every sumcheck of the proof is independent of the others except phase 1 -> phase 2 of the
+    // same layer (V_u).  Layer i's phases 1+2 and its Liu sumcheck each get their own lane (stream + scratch);
+    // profiling, the sumfold path and VP_GKR_SERIAL=1 run everything on the main lane instead.
+    const bool serial = ctx->serial || ctx->profiling || ctx->sumfold_path;
+    Lane *main_lane = &ctx->lane0;
+    ctx->ln = main_lane;
     HIPCHK(hipMemcpyAsync(ctx->d_tape, tape, n_tape * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     F *tr = ctx->d_tr;
-    u64 pos = 0;
     // every eq half table of the proof in one launch (they depend on the tape only)
     hipLaunchKernelGGL(k_beta_half_multi, dim3(ctx->n_all_jobs), dim3(VP_BLOCK), 0, ctx->stream, ctx->all_jobs);
     count_launch(ctx);
     {   // Vres (verifier.cpp:151): eq(r_0, .) is layer n-1's phase-1 table
         LayerDev &T = ctx->L[n - 1];
-        hipLaunchKernelGGL(k_vres2, dim3(1), dim3(VP_BLOCK), 0, ctx->stream, T.hg, T.val, (u32) T.size, tr + pos);
+        hipLaunchKernelGGL(k_vres2, dim3(1), dim3(VP_BLOCK), 0, ctx->stream, T.hg, T.val, (u32) T.size, tr);
         count_launch(ctx);
-        pos += 1;
     }
+    if (!serial) {
+        HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
+        for (auto &ln : ctx->lanes) HIPCHK(hipStreamWaitEvent(ln.stream, ctx->ev_fork, 0));
+    }
+    // transcript positions (top layer first, as the verifier consumes them)
+    std::vector<u64> pos_p1(n), pos_p2(n), pos_liu(n);
+    u64 pos = 1;
     for (int i = n - 1; i >= 1; --i) {
+        const u64 pbl = ctx->L[i - 1].bl;
+        pos_p1[i] = pos; pos += 3 * pbl + 1;
+        pos_p2[i] = pos; if (ctx->L[i].max_dad_bl != -1) pos += 3 * (u64) ctx->L[i].max_dad_bl + i;
+        pos_liu[i] = pos; pos += 3 * pbl + 1;
+    }
+    if (pos != ctx->n_tr) { ctx->err = "internal: transcript size"; return VP_EINVAL; }
+    // submit the largest layers first so that the long chains start early
+    std::vector<int> order;
+    for (int i = 1; i < n; ++i) order.push_back(i);
+    if (!serial) std::sort(order.begin(), order.end(), [&](int x, int y) { return ctx->L[x - 1].size + ctx->L[x].size > ctx->L[y - 1].size + ctx->L[y].size; });
+    else std::reverse(order.begin(), order.end());
+    for (int i : order) {
         LayerDev &cur = ctx->L[i], &pre = ctx->L[i - 1];
         const int pbl = pre.bl;
-        // ---- phase 1 ----
+        // ---- Liu (independent of phases 1 and 2) ----
         {
-            InitArgs2 a{};
-            a.hg = cur.hg; a.vals = ctx->d_vals; a.gc = cur.gc; a.assert_r = ctx->d_tape + ctx->as_off[i];
-            a.M = ctx->tab[0][1]; a.A = ctx->tab[0][2];
-            VPCHK(run_init2_rows<1>(ctx, cur.c1, a));
-            FusedSumcheck sc;
-            sc.n_tab = 1; sc.rounds = pbl; sc.has_a = 1; sc.phase = 1;
-            sc.off[0] = 0; sc.len0[0] = 1u << pbl; sc.valid0[0] = (u32) pre.size;
-            sc.V0 = pre.val; sc.r = ctx->d_tape + ctx->ru_off[i];
-            sc.poly_out = tr + pos; sc.claims_out = tr + pos + 3 * (u64) pbl;
-            VPCHK(run_sumcheck_seg(ctx, sc));
-            pos += 3 * (u64) pbl + 1;
-        }
-        // ---- phase 2 ----
-        const int mdb = cur.max_dad_bl;
-        if (mdb != -1) {
-            InitArgs2 a{};
-            a.hg = cur.hg; a.hu = cur.hu; a.vals = ctx->d_vals; a.gc = cur.gc; a.assert_r = ctx->d_tape + ctx->as_off[i];
-            a.Vu = ctx->Vu();
-            a.V = ctx->tab[0][0]; a.M = ctx->tab[0][1]; a.A = ctx->tab[0][2];
-            a.s_layer = cur.s_layer; a.s_idx = cur.s_idx;
-            VPCHK(run_init2_rows<2>(ctx, cur.c2, a));
-            FusedSumcheck sc;
-            sc.n_tab = i; sc.rounds = mdb; sc.has_a = 1; sc.phase = 2;
-            for (int j = 0; j < i; ++j) { sc.off[j] = cur.t_off[j]; sc.len0[j] = cur.t_len[j]; sc.valid0[j] = (u32) cur.dad_size[j]; }
-            sc.V0 = ctx->tab[0][0]; sc.r = ctx->d_tape + ctx->rv_off[i];
-            sc.poly_out = tr + pos; sc.claims_out = tr + pos + 3 * (u64) mdb;
-            VPCHK(run_sumcheck_seg(ctx, sc));
-            pos += 3 * (u64) mdb + i;
-        }
-        // ---- Liu ----
-        {
-            hipLaunchKernelGGL(k_liu_gather, dim3(nblk(pre.size)), dim3(VP_BLOCK), 0, ctx->stream, cur.lrow, cur.l_q,
-                               cur.l_g, cur.liu_H, (u32) pre.size, ctx->tab[0][1]);
+            ctx->ln = serial ? main_lane : &ctx->lanes[2 * (i - 1) + 1];
+            hipLaunchKernelGGL(k_liu_gather, dim3(nblk(pre.size)), dim3(VP_BLOCK), 0, ctx->ln->stream, cur.lrow, cur.l_q,
+                               cur.l_g, cur.liu_H, (u32) pre.size, ctx->ln->tab[0][1]);
             count_launch(ctx);
             FusedSumcheck sc;
             sc.n_tab = 1; sc.rounds = pbl; sc.has_a = 0; sc.phase = 3;
             sc.off[0] = 0; sc.len0[0] = 1u << pbl; sc.valid0[0] = (u32) pre.size;
             sc.V0 = pre.val; sc.r = ctx->d_tape + ctx->rliu_off[i];
-            sc.poly_out = tr + pos; sc.claims_out = tr + pos + 3 * (u64) pbl;
+            sc.poly_out = tr + pos_liu[i]; sc.claims_out = tr + pos_liu[i] + 3 * (u64) pbl;
             VPCHK(run_sumcheck_seg(ctx, sc));
-            pos += 3 * (u64) pbl + 1;
+        }
+        // ---- phase 1 ----
+        ctx->ln = serial ? main_lane : &ctx->lanes[2 * (i - 1)];
+        {
+            InitArgs2 a{};
+            a.hg = cur.hg; a.vals = ctx->d_vals; a.gc = cur.gc; a.assert_r = ctx->d_tape + ctx->as_off[i];
+            a.M = ctx->ln->tab[0][1]; a.A = ctx->ln->tab[0][2];
+            VPCHK(run_init2_rows<1>(ctx, cur.c1, a));
+            FusedSumcheck sc;
+            sc.n_tab = 1; sc.rounds = pbl; sc.has_a = 1; sc.phase = 1;
+            sc.off[0] = 0; sc.len0[0] = 1u << pbl; sc.valid0[0] = (u32) pre.size;
+            sc.V0 = pre.val; sc.r = ctx->d_tape + ctx->ru_off[i];
+            sc.poly_out = tr + pos_p1[i]; sc.claims_out = tr + pos_p1[i] + 3 * (u64) pbl;
+            VPCHK(run_sumcheck_seg(ctx, sc));
+        }
+        // ---- phase 2 (same lane: needs V_u) ----
+        const int mdb = cur.max_dad_bl;
+        if (mdb != -1) {
+            InitArgs2 a{};
+            a.hg = cur.hg; a.hu = cur.hu; a.vals = ctx->d_vals; a.gc = cur.gc; a.assert_r = ctx->d_tape + ctx->as_off[i];
+            a.Vu = ctx->ln->Vu;
+            a.V = ctx->ln->tab[0][0]; a.M = ctx->ln->tab[0][1]; a.A = ctx->ln->tab[0][2];
+            a.s_layer = cur.s_layer; a.s_idx = cur.s_idx;
+            VPCHK(run_init2_rows<2>(ctx, cur.c2, a));
+            FusedSumcheck sc;
+            sc.n_tab = i; sc.rounds = mdb; sc.has_a = 1; sc.phase = 2;
+            for (int j = 0; j < i; ++j) { sc.off[j] = cur.t_off[j]; sc.len0[j] = cur.t_len[j]; sc.valid0[j] = (u32) cur.dad_size[j]; }
+            sc.V0 = ctx->ln->tab[0][0]; sc.r = ctx->d_tape + ctx->rv_off[i];
+            sc.poly_out = tr + pos_p2[i]; sc.claims_out = tr + pos_p2[i] + 3 * (u64) mdb;
+            VPCHK(run_sumcheck_seg(ctx, sc));
+        }
+    }
+    ctx->ln = main_lane;
+    if (!serial) {
+        for (auto &ln : ctx->lanes) {
+            HIPCHK(hipEventRecord(ln.done, ln.stream));
+            HIPCHK(hipStreamWaitEvent(ctx->stream, ln.done, 0));
         }
     }
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
-    if (pos != ctx->n_tr) { ctx->err = "internal: transcript size"; return VP_EINVAL; }
     HIPCHK(hipMemcpyAsync(transcript, tr, pos * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
     VPCHK(check_stream(ctx));
     float ms = 0;
