@@ -113,6 +113,17 @@ int vp_prove_gkr(vp_ctx *, const vp_F *tape, uint64_t n_tape, uint8_t *transcrip
 /* Number of tape entries / transcript bytes vp_prove_gkr needs for the uploaded circuit.               */
 int vp_gkr_sizes(vp_ctx *, uint64_t *n_tape, uint64_t *n_transcript_bytes);
 
+/* ---- Virgo polynomial commitment, commit side ------------------------------------------------------ */
+/* prover::commit_private() (src/prover.cpp:524-530 -> poly_commit_prover::commit_private_array,
+ * lib/virgo/src/poly_commit.h:41-124 -> fri::request_init_commit, fri.cpp:36-139 -> create_tree,
+ * merkle_tree.cpp:7-51): Reed-Solomon encode (rate 1/32) the 64 slices of the input layer, hash the leaf
+ * chains with SHA3-256 and build the Merkle tree; returns the root (merkle_root_l).  The codeword and the
+ * tree stay in HBM for the later openings.  Needs bit_length(layer 0) >= 7 (vpd_verifier.cpp:115);
+ * VP_ELIMIT if a slice is longer than the in-LDS transform handles (2^13 elements in this build).      */
+int vp_commit_private(vp_ctx *, uint8_t root[32]);
+/* Device time of the last vp_commit_private in milliseconds (hipEvents).                               */
+int vp_commit_stats(vp_ctx *, double *commit_ms);
+
 /* ---- measurement --------------------------------------------------------------------------------- */
 typedef struct {
     double gkr_ms;            /* device time of the last vp_prove_gkr (hipEvents on the library stream)     */
@@ -132,6 +143,12 @@ int vp_set_profiling(vp_ctx *, int level);
 int vp_test_field(vp_ctx *, int op, const vp_F *a, const vp_F *b, vp_F *out, uint64_t n);
 /* initBetaTable(out, n, r, init) (src/utils.cpp:29-45): out has 2^n entries.                           */
 int vp_test_beta(vp_ctx *, const vp_F *r, int n, const vp_F *init, vp_F *out);
+/* out[i] = SHA3-256(in[i]) for n 64-byte messages (my_hhash, lib/virgo/src/my_hhash.h:27-33).          */
+int vp_test_sha3(vp_ctx *, const uint8_t *in, uint8_t *out, uint64_t n);
+/* fast_fourier_transform(coefs, coef_len, order) / inverse_fast_fourier_transform(evals, n, n)
+ * (RS_polynomial.cpp:26-220), natural order in and out.  order/coef_len must be 1 or 32 for the forward
+ * transform (the two shapes the commitment uses); sizes up to 2^13 per transform.                      */
+int vp_test_fft(vp_ctx *, const vp_F *coefs, int coef_len, int order, int inverse, vp_F *out);
 
 #ifdef __cplusplus
 }

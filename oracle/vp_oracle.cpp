@@ -1029,3 +1029,163 @@ void orc_update_each(orc_F *V, orc_F *add, orc_F *mult, uint64_t total, uint64_t
 }
 
 }  // extern "C"
+
+// ====================================================================================================
+// Virgo polynomial commitment — commit side.  lib/virgo/src/{RS_polynomial.cpp, poly_commit.h, fri.cpp,
+// merkle_tree.cpp, my_hhash.h}.
+// ====================================================================================================
+namespace {
+
+// ---- SHA3-256 on a 64-byte message (FIPS 202).  The reference links the prebuilt libXKCP.a
+// (my_hhash.h:29); this is the published algorithm, pinned by hashlib and the golden Merkle roots.
+const u64 KECCAK_RC[24] = {
+    0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808aull, 0x8000000080008000ull, 0x000000000000808bull,
+    0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull, 0x000000000000008aull, 0x0000000000000088ull,
+    0x0000000080008009ull, 0x000000008000000aull, 0x000000008000808bull, 0x800000000000008bull, 0x8000000000008089ull,
+    0x8000000000008003ull, 0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800aull, 0x800000008000000aull,
+    0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
+const int KECCAK_ROT[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+inline u64 rotl64(u64 x, int n) { return n ? (x << n) | (x >> (64 - n)) : x; }
+void keccak_f1600(u64 A[25]) {
+    for (int rnd = 0; rnd < 24; ++rnd) {
+        u64 C[5], D[5], B[25];
+        for (int x = 0; x < 5; ++x) C[x] = A[x] ^ A[x + 5] ^ A[x + 10] ^ A[x + 15] ^ A[x + 20];
+        for (int x = 0; x < 5; ++x) D[x] = C[(x + 4) % 5] ^ rotl64(C[(x + 1) % 5], 1);
+        for (int i = 0; i < 25; ++i) A[i] ^= D[i % 5];
+        for (int x = 0; x < 5; ++x)
+            for (int y = 0; y < 5; ++y) B[y + 5 * ((2 * x + 3 * y) % 5)] = rotl64(A[x + 5 * y], KECCAK_ROT[x + 5 * y]);
+        for (int y = 0; y < 5; ++y)
+            for (int x = 0; x < 5; ++x) A[x + 5 * y] = B[x + 5 * y] ^ (~B[(x + 1) % 5 + 5 * y] & B[(x + 2) % 5 + 5 * y]);
+        A[0] ^= KECCAK_RC[rnd];
+    }
+}
+struct Digest { u64 w[4]; };
+Digest hhash(const u64 in[8]) {           // my_hhash: 64 bytes in, 32 bytes out
+    u64 A[25] = {0};
+    for (int i = 0; i < 8; ++i) A[i] = in[i];
+    A[8] ^= 0x06;                          // SHA3 domain bits + first pad bit at byte 64
+    A[16] ^= 0x8000000000000000ull;        // last pad bit at byte 135 (rate = 136)
+    keccak_f1600(A);
+    Digest d; for (int i = 0; i < 4; ++i) d.w[i] = A[i];
+    return d;
+}
+
+// ---- FFT over F_p^2.  Any correct DFT gives the same canonical values as RS_polynomial.cpp:26-157.
+void fft_pow2(vector<F> &a, const F &root) {       // in-place, natural in / natural out, a.size() = power of two
+    const u64 n = a.size();
+    for (u64 i = 1, j = 0; i < n; ++i) {
+        u64 bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) std::swap(a[i], a[j]);
+    }
+    for (u64 len = 2; len <= n; len <<= 1) {
+        F wl = root;
+        for (u64 m = n; m > len; m >>= 1) wl = wl * wl;
+        vector<F> tw(len / 2);
+        tw[0] = F_ONE;
+        for (u64 k = 1; k < len / 2; ++k) tw[k] = tw[k - 1] * wl;
+        for (u64 i = 0; i < n; i += len)
+            for (u64 k = 0; k < len / 2; ++k) {
+                F u = a[i + k], v = a[i + k + len / 2] * tw[k];
+                a[i + k] = u + v;
+                a[i + k + len / 2] = u - v;
+            }
+    }
+}
+int log2_exact(u64 x) { int b = 0; while ((1ull << b) < x) ++b; return b; }
+void fft_eval(const F *coefs, u64 coef_len, u64 order, F *out) {           // fast_fourier_transform
+    vector<F> a(order, F_ZERO);
+    for (u64 i = 0; i < coef_len; ++i) a[i] = coefs[i];
+    fft_pow2(a, root_of_unity(log2_exact(order)));
+    for (u64 i = 0; i < order; ++i) out[i] = a[i];
+}
+void ifft_eval(const F *evals, u64 n, F *out) {                             // inverse_fast_fourier_transform, coef_len == order
+    vector<F> a(evals, evals + n);
+    fft_pow2(a, finv(root_of_unity(log2_exact(n))));
+    const F inv_n = fpow(F((long long) n), (u128) P - 2);                    // RS_polynomial.cpp:214
+    for (u64 i = 0; i < n; ++i) out[i] = a[i] * inv_n;
+}
+
+// ---- Merkle tree (merkle_tree.cpp:7-51): root of 2^k leaf digests.
+Digest merkle_root(vector<Digest> level) {
+    while (level.size() > 1) {
+        vector<Digest> up(level.size() / 2);
+        for (size_t i = 0; i < up.size(); ++i) {
+            u64 in[8];
+            memcpy(in, level[2 * i].w, 32); memcpy(in + 4, level[2 * i + 1].w, 32);
+            up[i] = hhash(in);
+        }
+        level.swap(up);
+    }
+    return level[0];
+}
+
+// leaf hashes of fri::request_init_commit (fri.cpp:95-124): chain over the 64 slices then the mask slice
+vector<Digest> leaf_hashes(const vector<F> &evals /* [65][slice_size] */, u64 slice_size) {
+    const u64 half = slice_size / 2;
+    vector<Digest> leaves(half);
+    for (u64 i = 0; i < half; ++i) {
+        Digest h; memset(&h, 0, sizeof h);
+        for (int s = 0; s < 65; ++s) {
+            const F &x = evals[(u64) s * slice_size + i], &y = evals[(u64) s * slice_size + i + half];
+            u64 in[8] = {x.re, x.im, y.re, y.im, h.w[0], h.w[1], h.w[2], h.w[3]};
+            h = hhash(in);
+        }
+        leaves[i] = h;
+    }
+    return leaves;
+}
+
+// commit_private_array (poly_commit.h:41-124) with the one-element zero mask prover::commit_private passes
+// (src/prover.cpp:526): l_eval[i] = RS encoding (rate 1/32) of slice i of circuitValue[0], mask slice all zero.
+void commit_private_evals(const vector<F> &input, int n_bits, vector<F> &l_eval, u64 &slice_size) {
+    const u64 slice_real = 1ull << (n_bits - 6);
+    slice_size = 1ull << (n_bits - 1);
+    l_eval.assign(65 * slice_size, F_ZERO);
+    vector<F> coef(slice_real);
+    for (int i = 0; i < 64; ++i) {
+        bool all_zero = true;
+        for (u64 j = 0; j < slice_real; ++j) if (input[i * slice_real + j] != F_ZERO) { all_zero = false; break; }
+        if (all_zero) continue;                                              // poly_commit.h:89-99
+        ifft_eval(&input[i * slice_real], slice_real, coef.data());
+        fft_eval(coef.data(), slice_real, slice_size, &l_eval[(u64) i * slice_size]);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+void orc_sha3_256_64(const uint8_t in[64], uint8_t out[32]) {
+    u64 w[8];
+    memcpy(w, in, 64);
+    Digest d = hhash(w);
+    memcpy(out, d.w, 32);
+}
+void orc_fft(const orc_F *coefs, int coef_len, int order, orc_F *out) {
+    vector<F> c(coef_len), o(order);
+    for (int i = 0; i < coef_len; ++i) c[i] = F(coefs[i].real, coefs[i].img);
+    fft_eval(c.data(), coef_len, order, o.data());
+    for (int i = 0; i < order; ++i) { out[i].real = o[i].re; out[i].img = o[i].im; }
+}
+void orc_ifft(const orc_F *evals, int n, orc_F *out) {
+    vector<F> e(n), o(n);
+    for (int i = 0; i < n; ++i) e[i] = F(evals[i].real, evals[i].img);
+    ifft_eval(e.data(), n, o.data());
+    for (int i = 0; i < n; ++i) { out[i].real = o[i].re; out[i].img = o[i].im; }
+}
+int orc_commit_private(orc_circuit *oc, uint8_t root[32]) {
+    const Circuit &C = oc->c;
+    const int n_bits = C.circuit[0].bitLength;
+    if (n_bits < 7) return -1;                                               // vpd_verifier.cpp:115
+    vector<F> input(1ull << n_bits, F_ZERO);                                  // circuitValue[0], padded (prover.cpp:30)
+    for (u64 g = 0; g < C.circuit[0].size; ++g) input[g] = F((long long) C.circuit[0].gates[g].u);
+    vector<F> l_eval; u64 slice_size;
+    commit_private_evals(input, n_bits, l_eval, slice_size);
+    Digest r = merkle_root(leaf_hashes(l_eval, slice_size));
+    memcpy(root, r.w, 32);
+    return 0;
+}
+
+}  // extern "C"

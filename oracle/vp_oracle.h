@@ -83,6 +83,18 @@ void orc_beta_table(const orc_F *r, int n, const orc_F *init, orc_F *out);
 void orc_update_each(orc_F *V, orc_F *add, orc_F *mult, uint64_t total, uint64_t total_size,
                      const orc_F *prev, orc_F out_poly[3]);
 
+/* ---- Virgo polynomial commitment, commit side (lib/virgo/src) ------------------------------------- */
+/* my_hhash (my_hhash.h:27-33): SHA3-256 of exactly 64 bytes (FIPS 202; the reference calls the prebuilt,
+ * source-less libXKCP.a, so the pin is the standard + Python hashlib + the golden Merkle roots).         */
+void orc_sha3_256_64(const uint8_t in[64], uint8_t out[32]);
+/* fast_fourier_transform (RS_polynomial.cpp:26-157): out[k] = sum_j coefs[j] * w^(jk), w = root of order `order`. */
+void orc_fft(const orc_F *coefs, int coef_len, int order, orc_F *out);
+/* inverse_fast_fourier_transform (RS_polynomial.cpp:159-220) with coef_len == order == n.                */
+void orc_ifft(const orc_F *evals, int n, orc_F *out);
+/* prover::commit_private (src/prover.cpp:524-530 -> poly_commit.h:41-124 -> fri.cpp:36-139 ->
+ * merkle_tree.cpp:7-51): Merkle root over the RS-encoded input layer.                                    */
+int orc_commit_private(orc_circuit *, uint8_t root[32]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -139,3 +139,75 @@ def test_evaluate_matches_oracle_outputs(vp, ob, pws_path):
     tr, _ = s.prove_gkr()
     assert tr == gold
     s.close(); c.close(); oc.close()
+
+
+# ---- Virgo polynomial commitment, commit side --------------------------------------------------------------
+def test_sha3_matches_hashlib(vp, ctx):
+    import hashlib
+    rng = np.random.default_rng(5)
+    n = 1000
+    msgs = rng.integers(0, 256, size=(n, 64), dtype=np.uint8)
+    msgs[0] = 0
+    msgs[1] = 255
+    out = np.zeros((n, 32), dtype=np.uint8)
+    assert vp.lib_gpu().vp_test_sha3(ctx, msgs.ctypes.data, out.ctypes.data, n) == 0
+    for i in range(n):
+        assert out[i].tobytes() == hashlib.sha3_256(msgs[i].tobytes()).digest()
+    # known answer recorded from the compiled reference: my_hhash(64 zero bytes)
+    assert out[0].tobytes().hex() == "070fa1ab6fcc557ed14d42941f1967693048551eb9042a8d0a057afbd75e81e0"
+
+
+@pytest.mark.parametrize("ln,ratio", [(0, 1), (1, 1), (3, 32), (3, 1), (7, 32), (10, 1), (13, 32)])
+def test_fft_vs_oracle(vp, ob, ctx, ln, ratio):
+    rng = np.random.default_rng(ln * 7 + ratio)
+    n = 1 << ln
+    c = rng.integers(0, P, size=(n, 2), dtype=np.uint64)
+    out = np.zeros((n * ratio, 2), dtype=np.uint64)
+    exp = np.zeros_like(out)
+    assert vp.lib_gpu().vp_test_fft(ctx, c.ctypes.data, n, n * ratio, 0, out.ctypes.data) == 0
+    ob.lib().orc_fft.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    ob.lib().orc_fft(c.ctypes.data, n, n * ratio, exp.ctypes.data)
+    assert np.array_equal(out, exp)
+    if ratio == 1:      # inverse round trip and parity
+        back = np.zeros_like(c)
+        assert vp.lib_gpu().vp_test_fft(ctx, out.ctypes.data, n, n, 1, back.ctypes.data) == 0
+        assert np.array_equal(back, c)
+
+
+def test_fft_known_answer(vp, ctx):
+    # c_i = (i+1, 2i+3), i < 8, evaluated on the order-32 group
+    c = np.array([[i + 1, 2 * i + 3] for i in range(8)], dtype=np.uint64)
+    # the commitment only uses ratios 1 and 32; 8 -> 32 is ratio 4, so embed: evaluate 8 coefficients padded to... use the
+    # ratio-32 shape on a 1-coefficient-per-... (not expressible) -> check through the oracle-equivalent ratio 1 on 32 padded coefs
+    pad = np.zeros((32, 2), dtype=np.uint64)
+    pad[:8] = c
+    out = np.zeros((32, 2), dtype=np.uint64)
+    assert vp.lib_gpu().vp_test_fft(ctx, pad.ctypes.data, 32, 32, 0, out.ctypes.data) == 0
+    assert tuple(int(x) for x in out[0]) == (36, 80)
+    assert tuple(int(x) for x in out[1]) == (617377187976651873, 1655836513184006865)
+    assert tuple(int(x) for x in out[31]) == (107673715198561662, 1973828267175406033)
+
+
+@pytest.mark.parametrize("name,blocks", [("sha256_x1", 1), ("sha256_x16", 16), ("sha256_x64", 64)])
+def test_commit_private_root_matches_reference(vp, golden, pws_path, name, blocks):
+    """merkle_root_l: first 32 bytes of the real reference's transcript."""
+    from conftest import GOLDEN
+    import os
+    c = vp.Circuit.from_pws(pws_path, blocks, seed=1)
+    s = vp.Session(c)
+    root, ms = s.commit_private()
+    gold = open(os.path.join(GOLDEN, golden[name]["transcript"]), "rb").read()[:32]
+    assert root == gold
+    root2, _ = s.commit_private()          # idempotent
+    assert root2 == gold
+    s.close(); c.close()
+
+
+def test_commit_private_randomize(vp, golden):
+    from conftest import GOLDEN
+    import os
+    c = vp.Circuit.randomize(8, 12, seed=1)
+    s = vp.Session(c)
+    root, _ = s.commit_private()
+    assert root == open(os.path.join(GOLDEN, golden["randomize_8_12"]["transcript"]), "rb").read()[:32]
+    s.close(); c.close()

@@ -111,3 +111,74 @@ def test_oracle_transcript_randomize(ob, golden, gold_gkr):
     assert st["verified"] == 1 and tr == gold_gkr("randomize_8_12")
     assert (st["mult_count"], st["add_count"], st["rounds"]) == (g["mult_counter"], g["add_counter"], g["rounds"])
     c.close()
+
+
+# ---- Virgo polynomial commitment, commit side (oracle/vp_oracle.cpp second half) ---------------------------------
+def test_oracle_sha3_is_fips202(ob):
+    rng = np.random.default_rng(3)
+    L = ob.lib()
+    L.orc_sha3_256_64.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+    msgs = [bytes(64), bytes(range(64)), b"\xff" * 64] + [rng.integers(0, 256, 64, dtype=np.uint8).tobytes() for _ in range(50)]
+    for m in msgs:
+        out = ctypes.create_string_buffer(32)
+        L.orc_sha3_256_64(m, out)
+        assert out.raw == hashlib.sha3_256(m).digest()
+    # my_hhash(64 zero bytes) as computed by the compiled reference (libXKCP)
+    assert hashlib.sha3_256(bytes(64)).hexdigest() == "070fa1ab6fcc557ed14d42941f1967693048551eb9042a8d0a057afbd75e81e0"
+
+
+def test_oracle_fft_known_answer_and_round_trip(ob):
+    L = ob.lib()
+    L.orc_fft.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    L.orc_ifft.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    c = np.array([[i + 1, 2 * i + 3] for i in range(8)], dtype=np.uint64)
+    o = np.zeros((32, 2), dtype=np.uint64)
+    L.orc_fft(c.ctypes.data, 8, 32, o.ctypes.data)              # values from the compiled reference, SURVEY.md §8c
+    assert tuple(int(x) for x in o[0]) == (36, 80)
+    assert tuple(int(x) for x in o[1]) == (617377187976651873, 1655836513184006865)
+    assert tuple(int(x) for x in o[31]) == (107673715198561662, 1973828267175406033)
+    rng = np.random.default_rng(9)
+    x = rng.integers(0, P, size=(64, 2), dtype=np.uint64)
+    e = np.zeros_like(x); back = np.zeros_like(x)
+    L.orc_fft(x.ctypes.data, 64, 64, e.ctypes.data)
+    L.orc_ifft(e.ctypes.data, 64, back.ctypes.data)
+    assert np.array_equal(back, x)
+    # definition check on a small size: out[k] = sum_j c_j w^(jk)
+    w = np.zeros(2, dtype=np.uint64); L.orc_f_root_of_unity(3, w.ctypes.data)
+    def fmul(a, b): return ((a[0] * b[0] - a[1] * b[1]) % P, (a[0] * b[1] + a[1] * b[0]) % P)
+    o8 = np.zeros((8, 2), dtype=np.uint64)
+    L.orc_fft(c.ctypes.data, 8, 8, o8.ctypes.data)
+    wk = (1, 0)
+    for k in range(8):
+        acc, p = (0, 0), (1, 0)
+        for j in range(8):
+            t = fmul((int(c[j][0]), int(c[j][1])), p)
+            acc = ((acc[0] + t[0]) % P, (acc[1] + t[1]) % P)
+            p = fmul(p, wk)
+        assert tuple(int(v) for v in o8[k]) == acc
+        wk = fmul(wk, (int(w[0]), int(w[1])))
+
+
+@pytest.mark.parametrize("name,blocks", [("sha256_x1", 1), ("sha256_x16", 16)])
+def test_oracle_commit_private_root(ob, golden, pws_path, name, blocks):
+    from conftest import GOLDEN
+    L = ob.lib()
+    L.orc_commit_private.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+    c = ob.Circuit.from_pws(pws_path, blocks, seed=1)
+    r = ctypes.create_string_buffer(32)
+    assert L.orc_commit_private(c.h, r) == 0
+    assert r.raw == open(os.path.join(GOLDEN, golden[name]["transcript"]), "rb").read()[:32]
+    if blocks == 1:
+        assert r.raw.hex() == "b8b3a141ac9144df9ff7f837784044d9832101b76a72de58a92d359918586efc"
+    c.close()
+
+
+def test_oracle_commit_private_root_randomize(ob, golden):
+    from conftest import GOLDEN
+    L = ob.lib()
+    L.orc_commit_private.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+    c = ob.Circuit.randomize(8, 12, seed=1)
+    r = ctypes.create_string_buffer(32)
+    assert L.orc_commit_private(c.h, r) == 0
+    assert r.raw == open(os.path.join(GOLDEN, golden["randomize_8_12"]["transcript"]), "rb").read()[:32]
+    c.close()

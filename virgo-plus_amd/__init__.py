@@ -96,6 +96,8 @@ def lib_gpu():
         L.vp_version.restype = ctypes.c_char_p
         L.vp_test_field.argtypes = [vp, ctypes.c_int, vp, vp, vp, ctypes.c_uint64]
         L.vp_test_beta.argtypes = [vp, vp, ctypes.c_int, vp, vp]
+        L.vp_test_sha3.argtypes = [vp, vp, vp, ctypes.c_uint64]
+        L.vp_test_fft.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
         _gpu = L
     return _gpu
 
@@ -133,6 +135,7 @@ def lib_host():
         L.vph_prove_gkr.argtypes = [vp, vp, u64, ctypes.POINTER(u64), ctypes.POINTER(VphResult), ctypes.c_char_p, ctypes.c_int]
         L.vph_check.argtypes = [vp, vp, u64, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
         L.vph_verify_transcript.argtypes = [vp, vp, u64, ctypes.c_int]
+        L.vph_commit_private.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_double), ctypes.c_char_p, ctypes.c_int]
         L.vph_transcript_bytes.restype = u64
         L.vph_transcript_bytes.argtypes = [vp]
         _host = L
@@ -235,6 +238,16 @@ class Session:
         """One batched device pass from the attached tape: returns (transcript bytes, stats)."""
         tr, res, _ = self._call(lib_host().vph_prove_gkr)
         return tr, res
+
+    def commit_private(self):
+        """prover::commit_private(): (32-byte Merkle root, device milliseconds)."""
+        root = ctypes.create_string_buffer(32)
+        ms = ctypes.c_double(0)
+        err = ctypes.create_string_buffer(512)
+        rc = lib_host().vph_commit_private(self.h, ctypes.cast(root, ctypes.c_void_p), ctypes.byref(ms), err, len(err))
+        if rc:
+            raise RuntimeError("commit_private failed: " + err.value.decode())
+        return root.raw, ms.value
 
     def check(self, transcript, skip_predicates=False):
         sec = ctypes.c_double(0)

@@ -1214,3 +1214,168 @@ __global__ void __launch_bounds__(VP_EMIT_THREADS) k_emit(EmitArgs a) {
 }
 
 }  // namespace vp
+
+// ===================================================================================================
+// Virgo polynomial commitment, commit side (reference: lib/virgo/src/RS_polynomial.cpp, poly_commit.h,
+// fri.cpp, merkle_tree.cpp, my_hhash.h).
+// ===================================================================================================
+namespace vp {
+
+// ---- K7: NTT over F_p^2 ------------------------------------------------------------------------------
+// One table of roots for the whole commitment: RT[j] = w^j, j < M/2, w = root of unity of order M = 2^lm
+// (fieldElement::getRootOfUnity, fieldElement.cpp:237-249).  w^(M/2) = -1, so any power and any inverse
+// power is one load and possibly one negation; smaller orders use strided indices.
+__device__ __forceinline__ F root_pow(const F *__restrict__ RT, u32 half_m, u32 e /* < 2*half_m */) {
+    return e < half_m ? RT[e] : f_neg(RT[e - half_m]);
+}
+__global__ void __launch_bounds__(VP_BLOCK)
+k_root_table_step(F *RT, u32 have /* entries already filled, power of two */, F step /* w^have */) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < have) RT[have + i] = f_mul(RT[i], step);
+}
+
+// Batched in-LDS radix-2 NTT of size N = 2^ln <= 8192, one workgroup per transform (blockIdx.x = row,
+// blockIdx.y = coset).  DIT: bit-reversed load, ln butterfly stages with one barrier each, natural-order store.
+//   forward LDE mode (inverse = 0): input row `coef + row*N`, element j is first multiplied by w_M^(j*coset)
+//       (the coset twist), and the N outputs are the evaluations at w_M^(32*a + coset): out[(row*ncoset + coset)*N + a].
+//       A rate-1/32 Reed-Solomon encoding (fast_fourier_transform(coefs, N, 32N), RS_polynomial.cpp:26) is therefore
+//       32 independent size-N transforms whose stores are fully coalesced; the codeword is kept COSET-MAJOR.
+//   inverse mode: out[row*N + k] = N^-1 * sum_j in[row*N + j] * w_N^(-jk)   (inverse_fast_fourier_transform, :159-220).
+struct NttArgs {
+    const F *in; F *out;
+    const F *RT; u32 half_m; int lm;      // root table of order M = 2^lm
+    int ln;                               // transform size N = 2^ln
+    int inverse;
+    u32 in_stride;                        // elements between consecutive input rows
+    F inv_n;                              // inverse mode: N^-1
+};
+__global__ void __launch_bounds__(1024) k_ntt_lds(NttArgs a) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    F *L = reinterpret_cast<F *>(smem_raw);
+    const u32 N = 1u << a.ln, row = blockIdx.x, coset = blockIdx.y, tid = threadIdx.x, nth = blockDim.x;
+    const u32 M = 2 * a.half_m;
+    const u32 wstride = M >> a.ln;                          // w_N = w_M^wstride
+    const F *src = a.in + (size_t) row * a.in_stride;
+    for (u32 j = tid; j < N; j += nth) {
+        F x = src[j];
+        if (!a.inverse && coset) x = f_mul(x, root_pow(a.RT, a.half_m, (j * coset) & (M - 1)));
+        L[a.ln ? (__brev(j) >> (32 - a.ln)) : 0u] = x;
+    }
+    __syncthreads();
+    for (int s = 1; s <= a.ln; ++s) {
+        const u32 half = 1u << (s - 1);
+        const u32 tw = (N >> s) * wstride;                 // exponent step of this stage in units of w_M
+        for (u32 idx = tid; idx < N / 2; idx += nth) {
+            const u32 k = idx & (half - 1), i0 = ((idx >> (s - 1)) << s) | k, i1 = i0 + half;
+            u32 e = k * tw;                                 // < M/2
+            if (a.inverse) e = e ? M - e : 0;               // w^-e
+            const F w = root_pow(a.RT, a.half_m, e);
+            const F u = L[i0], v = f_mul(L[i1], w);
+            L[i0] = f_add(u, v);
+            L[i1] = f_sub(u, v);
+        }
+        __syncthreads();
+    }
+    F *dst = a.inverse ? a.out + (size_t) row * N : a.out + ((size_t) row * gridDim.y + coset) * N;
+    for (u32 k = tid; k < N; k += nth) dst[k] = a.inverse ? f_mul(L[k], a.inv_n) : L[k];
+}
+
+// ---- K8: SHA3-256 on 64-byte messages (my_hhash.h:27-33; FIPS 202), leaf chains and Merkle levels -------
+struct Dig { u64 w[4]; };
+__device__ __forceinline__ u64 rotl64(u64 x, int n) { return (x << n) | (x >> (64 - n)); }
+__device__ __forceinline__ void keccak_f1600(u64 (&A)[25]) {
+    const u64 RC[24] = {
+        0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808aull, 0x8000000080008000ull, 0x000000000000808bull,
+        0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull, 0x000000000000008aull, 0x0000000000000088ull,
+        0x0000000080008009ull, 0x000000008000000aull, 0x000000008000808bull, 0x800000000000008bull, 0x8000000000008089ull,
+        0x8000000000008003ull, 0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800aull, 0x800000008000000aull,
+        0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
+#pragma unroll 1
+    for (int rnd = 0; rnd < 24; ++rnd) {
+        u64 C0 = A[0] ^ A[5] ^ A[10] ^ A[15] ^ A[20], C1 = A[1] ^ A[6] ^ A[11] ^ A[16] ^ A[21];
+        u64 C2 = A[2] ^ A[7] ^ A[12] ^ A[17] ^ A[22], C3 = A[3] ^ A[8] ^ A[13] ^ A[18] ^ A[23];
+        u64 C4 = A[4] ^ A[9] ^ A[14] ^ A[19] ^ A[24];
+        const u64 D0 = C4 ^ rotl64(C1, 1), D1 = C0 ^ rotl64(C2, 1), D2 = C1 ^ rotl64(C3, 1), D3 = C2 ^ rotl64(C4, 1), D4 = C3 ^ rotl64(C0, 1);
+#pragma unroll
+        for (int y = 0; y < 25; y += 5) { A[y] ^= D0; A[y + 1] ^= D1; A[y + 2] ^= D2; A[y + 3] ^= D3; A[y + 4] ^= D4; }
+        // rho + pi
+        u64 B[25];
+        B[0] = A[0];
+        B[10] = rotl64(A[1], 1);   B[20] = rotl64(A[2], 62);  B[5] = rotl64(A[3], 28);   B[15] = rotl64(A[4], 27);
+        B[16] = rotl64(A[5], 36);  B[1] = rotl64(A[6], 44);   B[11] = rotl64(A[7], 6);   B[21] = rotl64(A[8], 55);
+        B[6] = rotl64(A[9], 20);   B[7] = rotl64(A[10], 3);   B[17] = rotl64(A[11], 10); B[2] = rotl64(A[12], 43);
+        B[12] = rotl64(A[13], 25); B[22] = rotl64(A[14], 39); B[23] = rotl64(A[15], 41); B[8] = rotl64(A[16], 45);
+        B[18] = rotl64(A[17], 15); B[3] = rotl64(A[18], 21);  B[13] = rotl64(A[19], 8);  B[14] = rotl64(A[20], 18);
+        B[24] = rotl64(A[21], 2);  B[9] = rotl64(A[22], 61);  B[19] = rotl64(A[23], 56); B[4] = rotl64(A[24], 14);
+        // chi
+#pragma unroll
+        for (int y = 0; y < 25; y += 5) {
+            A[y] = B[y] ^ (~B[y + 1] & B[y + 2]);
+            A[y + 1] = B[y + 1] ^ (~B[y + 2] & B[y + 3]);
+            A[y + 2] = B[y + 2] ^ (~B[y + 3] & B[y + 4]);
+            A[y + 3] = B[y + 3] ^ (~B[y + 4] & B[y]);
+            A[y + 4] = B[y + 4] ^ (~B[y] & B[y + 1]);
+        }
+        A[0] ^= RC[rnd];
+    }
+}
+// h' = SHA3-256(m0..m3 || h)   — the 64-byte block of the leaf chains and of the Merkle nodes
+__device__ __forceinline__ Dig hhash64(u64 m0, u64 m1, u64 m2, u64 m3, const Dig &h) {
+    u64 A[25];
+#pragma unroll
+    for (int i = 0; i < 25; ++i) A[i] = 0;
+    A[0] = m0; A[1] = m1; A[2] = m2; A[3] = m3; A[4] = h.w[0]; A[5] = h.w[1]; A[6] = h.w[2]; A[7] = h.w[3];
+    A[8] = 0x06;                                 // domain bits + first pad bit (byte 64)
+    A[16] = 0x8000000000000000ull;               // last pad bit (byte 135, rate 136)
+    keccak_f1600(A);
+    Dig d; d.w[0] = A[0]; d.w[1] = A[1]; d.w[2] = A[2]; d.w[3] = A[3];
+    return d;
+}
+
+// Leaf hashes of fri::request_init_commit (fri.cpp:95-124): leaf j chains the 64 slices' pairs
+// (cw[s][j], cw[s][j + half]) and then the mask slice's pair (all zero here, src/prover.cpp:526).
+// The codeword is coset-major: cw[(s*32 + b)*N + a] = value at position 32a + b; position j + half is (a + N/2, b).
+// Thread t -> (b, a) with a fastest (coalesced loads); the digest goes to the natural leaf index 32a + b.
+__global__ void __launch_bounds__(VP_BLOCK)
+k_leaf_hash(const F *__restrict__ cw, u32 N, int n_slices, Dig *__restrict__ leaves) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 halfN = N >> 1;
+    if (t >= 32 * halfN) return;
+    const u32 a = t % halfN, b = t / halfN;
+    Dig h; h.w[0] = h.w[1] = h.w[2] = h.w[3] = 0;
+    for (int s = 0; s < n_slices; ++s) {
+        const F *row = cw + ((size_t) s * 32 + b) * N;
+        const F x = row[a], y = row[a + halfN];
+        h = hhash64(x.re, x.im, y.re, y.im, h);
+    }
+    h = hhash64(0, 0, 0, 0, h);                       // mask slice (zero polynomial)
+    leaves[32 * a + b] = h;
+}
+
+// One Merkle level (merkle_tree.cpp:40-50): parent[i] = H(child[2i] || child[2i+1]); heap layout, root at index 1.
+__global__ void __launch_bounds__(VP_BLOCK) k_merkle_level(Dig *tree, u32 level_start, u32 count) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const Dig l = tree[2 * (level_start + i)], r = tree[2 * (level_start + i) + 1];
+    tree[level_start + i] = hhash64(l.w[0], l.w[1], l.w[2], l.w[3], r);
+}
+// The top of the tree (<= 1024 leaves at `level_start`) in one workgroup.
+__global__ void __launch_bounds__(VP_BLOCK) k_merkle_top(Dig *tree, u32 count) {
+    for (u32 c = count >> 1; c >= 1; c >>= 1) {
+        for (u32 i = threadIdx.x; i < c; i += blockDim.x) {
+            const Dig l = tree[2 * (c + i)], r = tree[2 * (c + i) + 1];
+            tree[c + i] = hhash64(l.w[0], l.w[1], l.w[2], l.w[3], r);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void k_test_sha3(const u64 *__restrict__ in, u64 *__restrict__ out, u32 n) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Dig h; h.w[0] = in[8 * i + 4]; h.w[1] = in[8 * i + 5]; h.w[2] = in[8 * i + 6]; h.w[3] = in[8 * i + 7];
+    Dig d = hhash64(in[8 * i], in[8 * i + 1], in[8 * i + 2], in[8 * i + 3], h);
+    out[4 * i] = d.w[0]; out[4 * i + 1] = d.w[1]; out[4 * i + 2] = d.w[2]; out[4 * i + 3] = d.w[3];
+}
+
+}  // namespace vp

@@ -96,6 +96,9 @@ struct vp_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<void *> allocs;
     BetaJob *all_jobs = nullptr; u32 n_all_jobs = 0; F *half_pool = nullptr;
+    // polynomial commitment
+    F *pc_rt = nullptr, *pc_coef = nullptr, *pc_cw = nullptr; Dig *pc_tree = nullptr; int pc_lm = -1; double commit_ms = 0;
+
     F *part2 = nullptr;                  // [32][MAX_BLOCKS*3] block partials of the batched path
     int simple_path = 0, sumfold_path = 0, serial = 0;
     Lane lane0; Lane *ln = nullptr;
@@ -396,6 +399,7 @@ int vp_create(int device, vp_ctx **out) {
     }
     hipEventCreate(&ctx->ev0); hipEventCreate(&ctx->ev1);
     (void) hipFuncSetAttribute(reinterpret_cast<const void *>(k_emit), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
     *out = ctx;
     return VP_OK;
 }
@@ -426,6 +430,7 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
     ctx->n_layers = n_layers;
     ctx->evaluated = false;
     ctx->chunk_cap = 0;
+    ctx->pc_rt = ctx->pc_coef = ctx->pc_cw = nullptr; ctx->pc_tree = nullptr; ctx->pc_lm = -1;
     int max_bl = 0;
     for (int i = 0; i < n_layers; ++i) {
         if (ld[i].size == 0 || ld[i].size > (1ull << 30) || ld[i].bit_length < 0 || ld[i].bit_length > 30 ||
@@ -1243,6 +1248,148 @@ static int prove_gkr_fused(vp_ctx *ctx, const vp_F *tape, uint64_t n_tape, uint8
     }
     if (n_written) *n_written = pos * sizeof(F);
     return VP_OK;
+}
+
+}  // extern "C"
+
+// =====================================================================================================
+// Virgo polynomial commitment — commit side
+// =====================================================================================================
+namespace {
+
+constexpr int PC_MAX_LN = 13;            // largest in-LDS transform (2^13 x 16 B = 128 KiB)
+
+F host_pow(F x, unsigned __int128 e) { F r = f_one(); while (e) { if (e & 1) r = f_mul(r, x); x = f_mul(x, x); e >>= 1; } return r; }
+F host_root_of_unity(int log_order) {    // fieldElement::getRootOfUnity (fieldElement.cpp:237-249)
+    F r = f_make(2147483648ull, 1033321771269002680ull);
+    for (int i = 0; i < 62 - log_order; ++i) r = f_mul(r, r);
+    return r;
+}
+F host_inv_real(u64 x) { return host_pow(f_make(x, 0), (unsigned __int128) P61 - 2); }   // RS_polynomial.cpp:214
+
+// RT[j] = w^j for j < M/2, M = 2^lm (doubling, one small launch per level; done once per circuit)
+int pc_root_table(vp_ctx *ctx, int lm) {
+    if (ctx->pc_lm == lm && ctx->pc_rt) return VP_OK;
+    const u32 half = 1u << (lm - 1);
+    VPCHK(dalloc(ctx, &ctx->pc_rt, (size_t) half));
+    const F one = f_one();
+    HIPCHK(hipMemcpyAsync(ctx->pc_rt, &one, sizeof(F), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    F step = host_root_of_unity(lm);                    // w^(2^s)
+    for (u32 have = 1; have < half; have <<= 1) {
+        hipLaunchKernelGGL(k_root_table_step, dim3(nblk(have)), dim3(VP_BLOCK), 0, ctx->stream, ctx->pc_rt, have, step);
+        step = f_mul(step, step);
+    }
+    ctx->pc_lm = lm;
+    return VP_OK;
+}
+
+int pc_launch_ntt(vp_ctx *ctx, const F *in, F *out, int ln, int lm, int inverse, u32 rows, u32 cosets, u32 in_stride) {
+    NttArgs a{};
+    a.in = in; a.out = out; a.RT = ctx->pc_rt; a.half_m = 1u << (lm - 1); a.lm = lm; a.ln = ln; a.inverse = inverse;
+    a.in_stride = in_stride; a.inv_n = inverse ? host_inv_real(1ull << ln) : f_one();
+    const u32 threads = std::max<u32>(64, std::min<u32>(1024, (1u << ln) / 2));
+    hipLaunchKernelGGL(k_ntt_lds, dim3(rows, cosets), dim3(threads), sizeof(F) << ln, ctx->stream, a);
+    return VP_OK;
+}
+
+int pc_merkle(vp_ctx *ctx, Dig *tree, u32 n_leaves) {    // leaves already at tree[n_leaves .. 2 n_leaves)
+    u32 c = n_leaves >> 1;
+    for (; c > 512; c >>= 1)
+        hipLaunchKernelGGL(k_merkle_level, dim3(nblk(c)), dim3(VP_BLOCK), 0, ctx->stream, tree, c, c);
+    if (c >= 1) hipLaunchKernelGGL(k_merkle_top, dim3(1), dim3(VP_BLOCK), 0, ctx->stream, tree, 2 * c);
+    return VP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vp_commit_private(vp_ctx *ctx, uint8_t root[32]) {
+    if (!ctx || !ctx->evaluated || !root) return VP_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int n = ctx->L[0].bl;
+    if (n < 7) { ctx->err = "input layer too small for the commitment (bit length < 7)"; return VP_EINVAL; }
+    const int ln = n - 6, lm = n - 1;                     // slice_real_ele_cnt = 2^ln, slice_size = 2^lm (poly_commit.h:48-49)
+    if (ln > PC_MAX_LN) { ctx->err = "slice longer than the in-LDS transform"; return VP_ELIMIT; }
+    const u32 N = 1u << ln, M = 1u << lm;
+    VPCHK(pc_root_table(ctx, lm));
+    if (!ctx->pc_coef) {
+        VPCHK(dalloc(ctx, &ctx->pc_coef, (size_t) 64 * N));
+        VPCHK(dalloc(ctx, &ctx->pc_cw, (size_t) 64 * M));
+        VPCHK(dalloc(ctx, &ctx->pc_tree, (size_t) M));    // 2 * (M/2) digests, heap layout
+    }
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    // l_coef = iFFT of each slice; l_eval = its evaluations on the 2^lm-th roots (poly_commit.h:101-107)
+    VPCHK(pc_launch_ntt(ctx, ctx->L[0].val, ctx->pc_coef, ln, lm, 1, 64, 1, N));
+    VPCHK(pc_launch_ntt(ctx, ctx->pc_coef, ctx->pc_cw, ln, lm, 0, 64, 32, N));
+    // leaf chains + tree (fri.cpp:95-127)
+    const u32 n_leaves = M >> 1;
+    hipLaunchKernelGGL(k_leaf_hash, dim3(nblk(n_leaves)), dim3(VP_BLOCK), 0, ctx->stream, ctx->pc_cw, N, 64, ctx->pc_tree + n_leaves);
+    VPCHK(pc_merkle(ctx, ctx->pc_tree, n_leaves));
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    HIPCHK(hipMemcpyAsync(root, ctx->pc_tree + 1, 32, hipMemcpyDeviceToHost, ctx->stream));
+    VPCHK(check_stream(ctx));
+    float ms = 0;
+    hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+    ctx->commit_ms = ms;
+    return VP_OK;
+}
+
+int vp_commit_stats(vp_ctx *ctx, double *commit_ms) {
+    if (!ctx || !commit_ms) return VP_EINVAL;
+    *commit_ms = ctx->commit_ms;
+    return VP_OK;
+}
+
+int vp_test_sha3(vp_ctx *ctx, const uint8_t *in, uint8_t *out, uint64_t n) {
+    if (!ctx || !in || !out) return VP_EINVAL;
+    if (!n) return VP_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    u64 *di = nullptr, *dout = nullptr;
+    HIPCHK(hipMalloc((void **) &di, n * 64));
+    HIPCHK(hipMalloc((void **) &dout, n * 32));
+    HIPCHK(hipMemcpy(di, in, n * 64, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_test_sha3, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream, di, dout, (u32) n);
+    int rc = check_stream(ctx);
+    if (rc == VP_OK && hipMemcpy(out, dout, n * 32, hipMemcpyDeviceToHost) != hipSuccess) rc = VP_EHIP;
+    (void) hipFree(di); (void) hipFree(dout);
+    return rc;
+}
+
+int vp_test_fft(vp_ctx *ctx, const vp_F *coefs, int coef_len, int order, int inverse, vp_F *out) {
+    if (!ctx || !coefs || !out || coef_len < 1 || (coef_len & (coef_len - 1))) return VP_EINVAL;
+    if (order != coef_len && order != 32 * coef_len) return VP_EINVAL;
+    if (inverse && order != coef_len) return VP_EINVAL;
+    int ln = 0; while ((1 << ln) < coef_len) ++ln;
+    if (ln > PC_MAX_LN) return VP_ELIMIT;
+    int lo = 0; while ((1 << lo) < order) ++lo;
+    HIPCHK(hipSetDevice(ctx->device));
+    // private root table of order max(order, 2)
+    const int lm = std::max(lo, 1);
+    F *save_rt = ctx->pc_rt; int save_lm = ctx->pc_lm;
+    ctx->pc_rt = nullptr; ctx->pc_lm = -1;
+    int rc = pc_root_table(ctx, lm);
+    F *din = nullptr, *dcw = nullptr;
+    const u32 cosets = (u32) (order / coef_len);
+    if (rc == VP_OK && hipMalloc((void **) &din, sizeof(F) * coef_len) != hipSuccess) rc = VP_EHIP;
+    if (rc == VP_OK && hipMalloc((void **) &dcw, sizeof(F) * order) != hipSuccess) rc = VP_EHIP;
+    if (rc == VP_OK && hipMemcpy(din, coefs, sizeof(F) * coef_len, hipMemcpyHostToDevice) != hipSuccess) rc = VP_EHIP;
+    std::vector<F> tmp(order);
+    if (rc == VP_OK) {
+        pc_launch_ntt(ctx, din, dcw, ln, lm, inverse, 1, inverse ? 1 : cosets, coef_len);
+        rc = check_stream(ctx);
+    }
+    if (rc == VP_OK && hipMemcpy(tmp.data(), dcw, sizeof(F) * order, hipMemcpyDeviceToHost) != hipSuccess) rc = VP_EHIP;
+    if (rc == VP_OK) {                                    // coset-major -> natural order
+        F *o = reinterpret_cast<F *>(out);
+        for (u32 b = 0; b < cosets; ++b) for (int a = 0; a < coef_len; ++a) o[(size_t) a * cosets + b] = tmp[(size_t) b * coef_len + a];
+        if (inverse) for (int a = 0; a < coef_len; ++a) o[a] = tmp[a];
+    }
+    if (din) (void) hipFree(din);
+    if (dcw) (void) hipFree(dcw);
+    ctx->pc_rt = save_rt; ctx->pc_lm = save_lm;           // the temporary table stays in ctx->allocs until the next upload
+    return rc;
 }
 
 }  // extern "C"

@@ -158,6 +158,13 @@ void prover::sumcheckLiuFinalize(const F &previousRandom, F &claim) {           
     check(vp_finalize(ctx, cF(&previousRandom), mF(&claim), 1), "vp_finalize");
 }
 
+prover::hhash_digest prover::commit_private() {      // src/prover.cpp:524-530 (mask = one zero element)
+    hhash_digest d;
+    check(vp_commit_private(ctx, d.b), "vp_commit_private");
+    return d;
+}
+double prover::commitDeviceMs() { double ms = 0; check(vp_commit_stats(ctx, &ms), "vp_commit_stats"); return ms; }
+
 void prover::gkrSizes(u64 &n_tape, u64 &n_bytes) {
     uint64_t a = 0, b = 0;
     check(vp_gkr_sizes(ctx, &a, &b), "vp_gkr_sizes");

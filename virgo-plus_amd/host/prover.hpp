@@ -48,6 +48,11 @@ public:
 
     F Vres(const std::vector<F>::const_iterator &r_0, int r_0_size);
 
+    // Virgo polynomial commitment (reference: `#ifdef USE_VIRGO` block of src/prover.h:38-43)
+    struct hhash_digest { unsigned char b[32]; };
+    hhash_digest commit_private();                       // src/prover.cpp:524-530
+    double commitDeviceMs();
+
     double proveTime() const { return prove_timer.elapse_sec(); }
     double proofSize() const { return (double) proof_size / 1024.0; }
 

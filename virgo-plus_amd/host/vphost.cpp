@@ -137,6 +137,18 @@ int vph_check(vph_session *s, const uint8_t *transcript, uint64_t n, int skip_pr
     } catch (const std::exception &) { return -2; }
 }
 
+int vph_commit_private(vph_session *s, uint8_t root[32], double *ms, char *err, int errlen) {
+    try {
+        prover::hhash_digest d = s->p->commit_private();
+        memcpy(root, d.b, 32);
+        if (ms) *ms = s->p->commitDeviceMs();
+        return 0;
+    } catch (const std::exception &e) {
+        set_err(err, errlen, e.what());
+        return -2;
+    }
+}
+
 int vph_verify_transcript(vph_circuit *c, const uint8_t *transcript, uint64_t n, int skip_predicates) {
     try {
         F::init();

@@ -55,6 +55,8 @@ int vph_prove_gkr(vph_session *, uint8_t *transcript, uint64_t capacity, uint64_
  * O(|C|) wiring-predicate sums (the sumcheck and Liu checks still run).                                */
 int vph_check(vph_session *, const uint8_t *transcript, uint64_t n, int skip_predicates, double *verify_sec);
 uint64_t vph_transcript_bytes(vph_session *);
+/* prover::commit_private(): Merkle root of the RS-encoded input layer (merkle_root_l); device ms via *ms. */
+int vph_commit_private(vph_session *, uint8_t root[32], double *ms, char *err, int errlen);
 /* No GPU needed: F::init(), draw the tape for `circuit`, replay the host verifier over `transcript`
  * (GKR slice).  0 = accepted, 1 = rejected.                                                            */
 int vph_verify_transcript(vph_circuit *, const uint8_t *transcript, uint64_t n, int skip_predicates);
