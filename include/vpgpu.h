@@ -121,7 +121,14 @@ int vp_gkr_sizes(vp_ctx *, uint64_t *n_tape, uint64_t *n_transcript_bytes);
  * tree stay in HBM for the later openings.  Needs bit_length(layer 0) >= 7 (vpd_verifier.cpp:115);
  * VP_ELIMIT if a slice is longer than the in-LDS transform handles (2^13 elements in this build).      */
 int vp_commit_private(vp_ctx *, uint8_t root[32]);
-/* Device time of the last vp_commit_private in milliseconds (hipEvents).                               */
+/* prover::commit_public(pub, inner_product_sum, mask, all_sum) (src/prover.cpp:542-546 ->
+ * poly_commit_prover::commit_public_array, poly_commit.h:126-349 -> fri::request_init_commit(.., 1)):
+ * `pub` has 2^bit_length(layer 0) entries (the verifier's eq table, src/verifier.cpp:368-369).  Outputs
+ * the inner product <circuitValue[0], pub> (input_0), all_sum[0..65) and the Merkle root of the quotient
+ * codewords h (merkle_root_h).  vp_commit_private must have run.                                       */
+int vp_commit_public(vp_ctx *, const vp_F *pub, uint64_t n_pub, vp_F *inner_product_sum, vp_F all_sum[65],
+                     uint8_t root_h[32]);
+/* Device time of the last vp_commit_private / vp_commit_public in milliseconds (hipEvents).            */
 int vp_commit_stats(vp_ctx *, double *commit_ms);
 
 /* ---- measurement --------------------------------------------------------------------------------- */

@@ -1189,3 +1189,84 @@ int orc_commit_private(orc_circuit *oc, uint8_t root[32]) {
 }
 
 }  // extern "C"
+
+// ---- commit_public_array (poly_commit.h:126-349) with zero masks ---------------------------------------
+namespace {
+struct PublicOut { F inner; F all_sum[65]; Digest root_h; };
+void commit_public_core(const vector<F> &input, const vector<F> &pub, int n_bits, u64 n_used, PublicOut &out) {
+    const u64 N = 1ull << (n_bits - 6);
+    vector<F> l_eval, q_eval; u64 M;
+    commit_private_evals(input, n_bits, l_eval, M);                       // the prover still holds l_eval (poly_commit.cpp:4-13)
+    commit_private_evals(pub, n_bits, q_eval, M);                         // poly_commit.h:163-176 (no all-zero shortcut there; same values)
+    out.inner = F_ZERO;                                                    // prover::inner_prod, src/prover.cpp:532-540
+    for (u64 i = 0; i < n_used; ++i) out.inner = out.inner + input[i] * pub[i];
+    vector<F> h_arr(65 * M, F_ZERO), lq_eval(2 * N), lq_coef(2 * N), h_coef(N);
+    for (int i = 0; i < 64; ++i) {
+        bool all_zero = true;
+        const u64 step = M / (2 * N);
+        for (u64 j = 0; j < 2 * N; ++j) {
+            lq_eval[j] = l_eval[(u64) i * M + j * step] * q_eval[(u64) i * M + j * step];
+            if (lq_eval[j] != F_ZERO) all_zero = false;
+        }
+        if (all_zero) { out.all_sum[i] = F_ZERO; continue; }
+        ifft_eval(lq_eval.data(), 2 * N, lq_coef.data());
+        for (u64 j = 0; j < N; ++j) h_coef[j] = lq_coef[j + N];
+        fft_eval(h_coef.data(), N, M, &h_arr[(u64) i * M]);
+        out.all_sum[i] = (lq_coef[0] + h_coef[0]) * F((long long) N);      // poly_commit.h:323
+    }
+    out.all_sum[64] = F_ZERO;                                              // mask slice: zero polynomial (:262)
+    out.root_h = merkle_root(leaf_hashes(h_arr, M));
+}
+}  // namespace
+
+extern "C" {
+
+int orc_commit_public(const orc_F *input, const orc_F *pub, int n_bits, uint64_t n_used, orc_F *inner, orc_F *all_sum,
+                      uint8_t root_h[32]) {
+    if (n_bits < 7) return -1;
+    const u64 n = 1ull << n_bits;
+    vector<F> in(n), pb(n);
+    for (u64 i = 0; i < n; ++i) { in[i] = F(input[i].real, input[i].img); pb[i] = F(pub[i].real, pub[i].img); }
+    PublicOut o;
+    commit_public_core(in, pb, n_bits, n_used, o);
+    inner->real = o.inner.re; inner->img = o.inner.im;
+    for (int i = 0; i < 65; ++i) { all_sum[i].real = o.all_sum[i].re; all_sum[i].img = o.all_sum[i].im; }
+    memcpy(root_h, o.root_h.w, 32);
+    return 0;
+}
+
+int64_t orc_prove_full(orc_circuit *oc, uint8_t *transcript, int64_t capacity, orc_stats *st) {
+    srand(3396);
+    g_cnt = Counter();
+    subset_init(oc->c);
+    const Circuit &C = oc->c;
+    const int n_bits = C.circuit[0].bitLength;
+    if (n_bits < 7) return -2;
+    Prover p(C);
+    vector<unsigned char> out;
+    {   // merkle_root_l (verifier.cpp:137)
+        uint8_t root[32];
+        orc_commit_private(oc, root);
+        out.insert(out.end(), root, root + 32);
+    }
+    Verifier v(&p, C, &out);
+    bool ok = v.verify_gkr();
+    // verifyPoly (verifier.cpp:363-379): the public vector is eq(r_liu, .) over the input layer
+    vector<F> pub;
+    init_beta_table(pub, n_bits, v.r_liu.data(), F_ONE);
+    PublicOut po;
+    commit_public_core(p.circuitValue[0], pub, n_bits, C.circuit[0].size, po);
+    out.insert(out.end(), (unsigned char *) po.root_h.w, (unsigned char *) po.root_h.w + 32);
+    v.putF(po.inner);
+    for (int i = 0; i < 65; ++i) v.putF(po.all_sum[i]);
+    if (st) {
+        st->prove_sec = p.prove_timer.total; st->evaluate_sec = p.evaluate_sec; st->verify_sec = v.vt.total;
+        st->mult_count = g_cnt.mul; st->add_count = g_cnt.add; st->rounds = p.rounds; st->pairs = p.pairs;
+        st->proof_kb = (double) p.proof_size / 1024.0; st->verified = ok ? 1 : 0;
+    }
+    if ((int64_t) out.size() > capacity) return -1;
+    memcpy(transcript, out.data(), out.size());
+    return (int64_t) out.size();
+}
+
+}  // extern "C"

@@ -94,6 +94,14 @@ void orc_ifft(const orc_F *evals, int n, orc_F *out);
 /* prover::commit_private (src/prover.cpp:524-530 -> poly_commit.h:41-124 -> fri.cpp:36-139 ->
  * merkle_tree.cpp:7-51): Merkle root over the RS-encoded input layer.                                    */
 int orc_commit_private(orc_circuit *, uint8_t root[32]);
+/* The whole protocol up to and including prover::commit_public (src/verifier.cpp:134-169,363-379 ->
+ * src/prover.cpp:542-546 -> poly_commit.h:126-349): writes the FULL golden layout
+ * merkle_root_l | GKR slice | merkle_root_h | input_0 | all_sum[65].  Returns the length or <0.           */
+int64_t orc_prove_full(orc_circuit *, uint8_t *transcript, int64_t capacity, orc_stats *stats);
+/* commit_public_array on caller-supplied arrays (unit parity for the device kernels): input and pub have
+ * 2^n_bits entries; outputs inner product, all_sum[65], root_h.                                          */
+int orc_commit_public(const orc_F *input, const orc_F *pub, int n_bits, uint64_t n_used, orc_F *inner, orc_F *all_sum,
+                      uint8_t root_h[32]);
 
 #ifdef __cplusplus
 }

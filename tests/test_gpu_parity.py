@@ -211,3 +211,52 @@ def test_commit_private_randomize(vp, golden):
     root, _ = s.commit_private()
     assert root == open(os.path.join(GOLDEN, golden["randomize_8_12"]["transcript"]), "rb").read()[:32]
     s.close(); c.close()
+
+
+@pytest.mark.parametrize("name,blocks", [("sha256_x1", 1), ("sha256_x16", 16), ("sha256_x64", 64)])
+@pytest.mark.parametrize("batched", [False, True])
+def test_full_transcript_with_commitment_matches_reference(vp, golden, pws_path, name, blocks, batched):
+    """merkle_root_l | GKR | merkle_root_h | input_0 | all_sum[65]: the complete golden transcript, whose SHA-256
+    equals the digest recorded in SURVEY.md §8c."""
+    import hashlib, os
+    from conftest import GOLDEN
+    if blocks == 64 and not batched:
+        pytest.skip("the interactive 64-block run spends seconds in the host verifier's predicate loops")
+    c = vp.Circuit.from_pws(pws_path, blocks, seed=1)
+    s = vp.Session(c)
+    tr, ok = s.prove_full(batched=batched)
+    gold = open(os.path.join(GOLDEN, golden[name]["transcript"]), "rb").read()
+    assert ok
+    assert tr == gold
+    assert hashlib.sha256(tr).hexdigest() == golden[name]["sha256"]
+    s.close(); c.close()
+
+
+def test_full_transcript_randomize(vp, golden):
+    import os
+    from conftest import GOLDEN
+    c = vp.Circuit.randomize(8, 12, seed=1)
+    s = vp.Session(c)
+    tr, ok = s.prove_full(batched=True)
+    assert ok and tr == open(os.path.join(GOLDEN, golden["randomize_8_12"]["transcript"]), "rb").read()
+    s.close(); c.close()
+
+
+def test_commit_public_vs_oracle_random_vector(vp, ob, pws_path):
+    """commit_public on an arbitrary public vector (not an eq table) against the oracle's restatement."""
+    c = vp.Circuit.from_pws(pws_path, 1, seed=9)
+    oc = ob.Circuit.from_pws(pws_path, 1, seed=9)
+    s = vp.Session(c)
+    s.commit_private()
+    n_bits = c.layer_bitlen(0)
+    rng = np.random.default_rng(4)
+    pub = rng.integers(0, P, size=(1 << n_bits, 2), dtype=np.uint64)
+    pub[5] = 0
+    root_h, inner, all_sum, _ = s.commit_public(pub)
+    inp = np.zeros((1 << n_bits, 2), dtype=np.uint64)
+    ob.lib().orc_circuit_inputs(oc.h, inp.ctypes.data)
+    e_inner = np.zeros(2, dtype=np.uint64); e_all = np.zeros((65, 2), dtype=np.uint64); e_root = ctypes.create_string_buffer(32)
+    ob.lib().orc_commit_public.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p]
+    assert ob.lib().orc_commit_public(inp.ctypes.data, pub.ctypes.data, n_bits, oc.layer_size(0), e_inner.ctypes.data, e_all.ctypes.data, e_root) == 0
+    assert inner == e_inner.tobytes() and all_sum == e_all.tobytes() and root_h == e_root.raw
+    s.close(); c.close(); oc.close()

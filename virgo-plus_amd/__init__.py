@@ -135,6 +135,8 @@ def lib_host():
         L.vph_prove_gkr.argtypes = [vp, vp, u64, ctypes.POINTER(u64), ctypes.POINTER(VphResult), ctypes.c_char_p, ctypes.c_int]
         L.vph_check.argtypes = [vp, vp, u64, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
         L.vph_verify_transcript.argtypes = [vp, vp, u64, ctypes.c_int]
+        L.vph_commit_public.argtypes = [vp, vp, u64, vp, ctypes.POINTER(ctypes.c_double), ctypes.c_char_p, ctypes.c_int]
+        L.vph_prove_full.argtypes = [vp, vp, u64, ctypes.POINTER(u64), ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
         L.vph_commit_private.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_double), ctypes.c_char_p, ctypes.c_int]
         L.vph_transcript_bytes.restype = u64
         L.vph_transcript_bytes.argtypes = [vp]
@@ -248,6 +250,30 @@ class Session:
         if rc:
             raise RuntimeError("commit_private failed: " + err.value.decode())
         return root.raw, ms.value
+
+    def commit_public(self, pub):
+        """prover::commit_public on a (2^n, 2) uint64 array: (root_h, input_0 bytes, all_sum bytes, device ms)."""
+        import numpy as np
+        pub = np.ascontiguousarray(pub, dtype=np.uint64)
+        out = ctypes.create_string_buffer(32 + 16 + 65 * 16)
+        ms = ctypes.c_double(0)
+        err = ctypes.create_string_buffer(512)
+        rc = lib_host().vph_commit_public(self.h, pub.ctypes.data, pub.shape[0], ctypes.cast(out, ctypes.c_void_p), ctypes.byref(ms),
+                                          err, len(err))
+        if rc:
+            raise RuntimeError("commit_public failed: " + err.value.decode())
+        return out.raw[:32], out.raw[32:48], out.raw[48:], ms.value
+
+    def prove_full(self, batched=False):
+        """commit_private + GKR + commit_public: the full golden transcript layout; returns (bytes, verified)."""
+        cap = self._cap + 32 + 32 + 16 + 65 * 16
+        buf = ctypes.create_string_buffer(cap)
+        n = ctypes.c_uint64(0)
+        err = ctypes.create_string_buffer(512)
+        rc = lib_host().vph_prove_full(self.h, ctypes.cast(buf, ctypes.c_void_p), cap, ctypes.byref(n), 1 if batched else 0, err, len(err))
+        if rc < 0:
+            raise RuntimeError("prove_full failed: " + err.value.decode())
+        return buf.raw[: n.value], rc == 0
 
     def check(self, transcript, skip_predicates=False):
         sec = ctypes.c_double(0)

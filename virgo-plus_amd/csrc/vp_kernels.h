@@ -1379,3 +1379,50 @@ __global__ void k_test_sha3(const u64 *__restrict__ in, u64 *__restrict__ out, u
 }
 
 }  // namespace vp
+
+// ---- commit_public (poly_commit.h:126-349) -------------------------------------------------------------
+namespace vp {
+
+// Products l*q on the two cosets the quotient needs: positions 16*j, j < 2N, are coset 0 (j even) and coset 16
+// (j odd) of the coset-major codewords.  P[(2i)*N + a] = l_i*q_i at w_M^(32a), P[(2i+1)*N + a] at w_M^(32a+16).
+__global__ void __launch_bounds__(VP_BLOCK)
+k_pc_products(const F *__restrict__ lcw, const F *__restrict__ qcw, u32 N, F *__restrict__ P) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 128 * N) return;
+    const u32 a = t % N, r = t / N, i = r >> 1, b = (r & 1) ? 16 : 0;
+    const size_t src = ((size_t) i * 32 + b) * N + a;
+    P[t] = f_mul(lcw[src], qcw[src]);
+}
+// With l*q = L + x^N H (deg L, H < N):  S = iNTT_N(products on coset 0) = L + H,  T_j * w_2N^-j = L_j - H_j for
+// T = iNTT_N(products on coset 16).  h_coef = H = (S - D)/2  (poly_commit.h:283-287 takes the upper half of a 2N-point
+// inverse transform; this is the same polynomial from two N-point ones), all_sum = (lq_coef[0] + h_coef[0]) * N = S_0 * N.
+__global__ void __launch_bounds__(VP_BLOCK)
+k_pc_quotient(const F *__restrict__ ST, u32 N, const F *__restrict__ RT, u32 half_m, F inv2, F n_as_f, F *__restrict__ H,
+              F *__restrict__ all_sum) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 64 * N) return;
+    const u32 j = t % N, i = t / N;
+    const F S = ST[(size_t) (2 * i) * N + j], T = ST[(size_t) (2 * i + 1) * N + j];
+    const u32 M = 2 * half_m;
+    const u32 e = (16 * j) & (M - 1);                          // w_2N = w_M^16
+    const F D = f_mul(T, root_pow(RT, half_m, e ? M - e : 0));
+    H[t] = f_mul(f_sub(S, D), inv2);
+    if (j == 0) all_sum[i] = f_mul(S, n_as_f);
+}
+// prover::inner_prod (src/prover.cpp:532-540)
+__global__ void __launch_bounds__(VP_BLOCK) k_pc_dot(const F *__restrict__ x, const F *__restrict__ y, u32 n, F *part) {
+    __shared__ F lds[4];
+    F acc[1] = {f_zero()};
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) acc[0] = f_add(acc[0], f_mul(x[i], y[i]));
+    block_sum<1>(acc, lds);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc[0];
+}
+__global__ void __launch_bounds__(VP_BLOCK) k_pc_sum_parts(const F *__restrict__ part, u32 n, F *out) {
+    __shared__ F lds[4];
+    F acc[1] = {f_zero()};
+    for (u32 i = threadIdx.x; i < n; i += blockDim.x) acc[0] = f_add(acc[0], part[i]);
+    block_sum<1>(acc, lds);
+    if (threadIdx.x == 0) *out = acc[0];
+}
+
+}  // namespace vp

@@ -98,6 +98,7 @@ struct vp_ctx {
     BetaJob *all_jobs = nullptr; u32 n_all_jobs = 0; F *half_pool = nullptr;
     // polynomial commitment
     F *pc_rt = nullptr, *pc_coef = nullptr, *pc_cw = nullptr; Dig *pc_tree = nullptr; int pc_lm = -1; double commit_ms = 0;
+    F *pc_pub = nullptr, *pc_qcw = nullptr, *pc_hcw = nullptr, *pc_tmp = nullptr, *pc_small = nullptr; Dig *pc_tree_h = nullptr; bool pc_private_done = false;
 
     F *part2 = nullptr;                  // [32][MAX_BLOCKS*3] block partials of the batched path
     int simple_path = 0, sumfold_path = 0, serial = 0;
@@ -431,6 +432,7 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
     ctx->evaluated = false;
     ctx->chunk_cap = 0;
     ctx->pc_rt = ctx->pc_coef = ctx->pc_cw = nullptr; ctx->pc_tree = nullptr; ctx->pc_lm = -1;
+    ctx->pc_pub = ctx->pc_qcw = ctx->pc_hcw = ctx->pc_tmp = ctx->pc_small = nullptr; ctx->pc_tree_h = nullptr; ctx->pc_private_done = false;
     int max_bl = 0;
     for (int i = 0; i < n_layers; ++i) {
         if (ld[i].size == 0 || ld[i].size > (1ull << 30) || ld[i].bit_length < 0 || ld[i].bit_length > 30 ||
@@ -1329,6 +1331,55 @@ int vp_commit_private(vp_ctx *ctx, uint8_t root[32]) {
     VPCHK(pc_merkle(ctx, ctx->pc_tree, n_leaves));
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
     HIPCHK(hipMemcpyAsync(root, ctx->pc_tree + 1, 32, hipMemcpyDeviceToHost, ctx->stream));
+    VPCHK(check_stream(ctx));
+    float ms = 0;
+    hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+    ctx->commit_ms = ms;
+    ctx->pc_private_done = true;
+    return VP_OK;
+}
+
+int vp_commit_public(vp_ctx *ctx, const vp_F *pub, uint64_t n_pub, vp_F *inner, vp_F all_sum[65], uint8_t root_h[32]) {
+    if (!ctx || !ctx->evaluated || !ctx->pc_private_done || !pub || !inner || !all_sum || !root_h) return VP_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int n = ctx->L[0].bl;
+    if (n_pub != (1ull << n)) return VP_EINVAL;
+    const int ln = n - 6, lm = n - 1;
+    const u32 N = 1u << ln, M = 1u << lm;
+    if (!ctx->pc_pub) {
+        VPCHK(dalloc(ctx, &ctx->pc_pub, (size_t) 1 << n));
+        VPCHK(dalloc(ctx, &ctx->pc_qcw, (size_t) 64 * M));
+        VPCHK(dalloc(ctx, &ctx->pc_hcw, (size_t) 64 * M));
+        VPCHK(dalloc(ctx, &ctx->pc_tmp, (size_t) 3 * 128 * N));           // products | S,T | H
+        VPCHK(dalloc(ctx, &ctx->pc_small, (size_t) 1024 + 80));
+        VPCHK(dalloc(ctx, &ctx->pc_tree_h, (size_t) M));
+    }
+    HIPCHK(hipMemcpyAsync(ctx->pc_pub, pub, sizeof(F) << n, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    F *P = ctx->pc_tmp, *ST = ctx->pc_tmp + (size_t) 128 * N, *H = ctx->pc_tmp + (size_t) 256 * N;
+    F *parts = ctx->pc_small, *d_inner = ctx->pc_small + 1024, *d_all = ctx->pc_small + 1025;
+    // input_0 = <circuitValue[0], pub>
+    const u32 used = (u32) ctx->L[0].size, g = std::min<u32>(1024, nblk(used));
+    hipLaunchKernelGGL(k_pc_dot, dim3(g), dim3(VP_BLOCK), 0, ctx->stream, ctx->L[0].val, ctx->pc_pub, used, parts);
+    hipLaunchKernelGGL(k_pc_sum_parts, dim3(1), dim3(VP_BLOCK), 0, ctx->stream, parts, g, d_inner);
+    // q_eval: the public vector encoded like the private one (poly_commit.h:163-176)
+    VPCHK(pc_launch_ntt(ctx, ctx->pc_pub, ctx->pc_coef, ln, lm, 1, 64, 1, N));
+    VPCHK(pc_launch_ntt(ctx, ctx->pc_coef, ctx->pc_qcw, ln, lm, 0, 64, 32, N));
+    // quotient h of l*q by x^N - 1, per slice (poly_commit.h:264-293)
+    hipLaunchKernelGGL(k_pc_products, dim3(nblk((u64) 128 * N)), dim3(VP_BLOCK), 0, ctx->stream, ctx->pc_cw, ctx->pc_qcw, N, P);
+    VPCHK(pc_launch_ntt(ctx, P, ST, ln, lm, 1, 128, 1, N));
+    hipLaunchKernelGGL(k_zero_f, dim3(1), dim3(128), 0, ctx->stream, d_all, 65u);
+    hipLaunchKernelGGL(k_pc_quotient, dim3(nblk((u64) 64 * N)), dim3(VP_BLOCK), 0, ctx->stream, ST, N, ctx->pc_rt, M >> 1,
+                       host_inv_real(2), f_make(N, 0), H, d_all);
+    VPCHK(pc_launch_ntt(ctx, H, ctx->pc_hcw, ln, lm, 0, 64, 32, N));
+    // second oracle: leaf chains + tree over h (fri.cpp:36-139 with oracle_indicator = 1)
+    const u32 n_leaves = M >> 1;
+    hipLaunchKernelGGL(k_leaf_hash, dim3(nblk(n_leaves)), dim3(VP_BLOCK), 0, ctx->stream, ctx->pc_hcw, N, 64, ctx->pc_tree_h + n_leaves);
+    VPCHK(pc_merkle(ctx, ctx->pc_tree_h, n_leaves));
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    HIPCHK(hipMemcpyAsync(root_h, ctx->pc_tree_h + 1, 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(inner, d_inner, sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(all_sum, d_all, 65 * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
     VPCHK(check_stream(ctx));
     float ms = 0;
     hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);

@@ -163,6 +163,12 @@ prover::hhash_digest prover::commit_private() {      // src/prover.cpp:524-530 (
     check(vp_commit_private(ctx, d.b), "vp_commit_private");
     return d;
 }
+prover::hhash_digest prover::commit_public(std::vector<F> &pub, F &inner_product_sum, std::vector<F> &all_sum) {
+    hhash_digest d;
+    all_sum.resize(65);
+    check(vp_commit_public(ctx, cF(pub.data()), pub.size(), mF(&inner_product_sum), mF(all_sum.data()), d.b), "vp_commit_public");
+    return d;
+}
 double prover::commitDeviceMs() { double ms = 0; check(vp_commit_stats(ctx, &ms), "vp_commit_stats"); return ms; }
 
 void prover::gkrSizes(u64 &n_tape, u64 &n_bytes) {

@@ -51,6 +51,8 @@ public:
     // Virgo polynomial commitment (reference: `#ifdef USE_VIRGO` block of src/prover.h:38-43)
     struct hhash_digest { unsigned char b[32]; };
     hhash_digest commit_private();                       // src/prover.cpp:524-530
+    // src/prover.cpp:542-546 (the mask argument of the reference is the one-element zero vector and is implied)
+    hhash_digest commit_public(std::vector<F> &pub, F &inner_product_sum, std::vector<F> &all_sum);
     double commitDeviceMs();
 
     double proveTime() const { return prove_timer.elapse_sec(); }

@@ -24,6 +24,7 @@ public:
 
     const std::vector<uint8_t> &transcript() const { return tr; }
     const std::vector<F> &tape() const { return tape_; }
+    const std::vector<F> &finalPoint() const { return r_liu; }     // r_liu after the last Liu sumcheck: where the input MLE is opened
     double verifyTime() const { return verify_timer.elapse_sec(); }
     bool skip_predicates = false;      // replay only: skip the O(|C|) wiring-predicate check (getFinalValue)
 

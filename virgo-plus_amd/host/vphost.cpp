@@ -149,6 +149,61 @@ int vph_commit_private(vph_session *s, uint8_t root[32], double *ms, char *err, 
     }
 }
 
+int vph_commit_public(vph_session *s, const uint64_t *pub_pairs, uint64_t n_pub, uint8_t *out, double *ms, char *err, int errlen) {
+    try {
+        std::vector<F> pub(n_pub), all_sum;
+        for (u64 i = 0; i < n_pub; ++i) { pub[i].real = pub_pairs[2 * i]; pub[i].img = pub_pairs[2 * i + 1]; }
+        F inner;
+        prover::hhash_digest d = s->p->commit_public(pub, inner, all_sum);
+        memcpy(out, d.b, 32);
+        memcpy(out + 32, &inner, 16);
+        memcpy(out + 48, all_sum.data(), 65 * 16);
+        if (ms) *ms = s->p->commitDeviceMs();
+        return 0;
+    } catch (const std::exception &e) {
+        set_err(err, errlen, e.what());
+        return -2;
+    }
+}
+
+int vph_prove_full(vph_session *s, uint8_t *transcript, uint64_t capacity, uint64_t *n_written, int batched, char *err, int errlen) {
+    try {
+        F::init();
+        std::vector<uint8_t> out;
+        prover::hhash_digest rl = s->p->commit_private();                      // verifier.cpp:137
+        out.insert(out.end(), rl.b, rl.b + 32);
+        verifier v(batched ? nullptr : s->p.get(), s->circ->c);
+        bool ok;
+        if (batched) {
+            std::vector<F> tape = v.drawTape();
+            std::vector<uint8_t> tr;
+            s->p->proveGKR(tape, tr);
+            ok = v.check(tape, tr);
+        } else {
+            ok = v.verify();
+        }
+        out.insert(out.end(), v.transcript().begin(), v.transcript().end());
+        // verifyPoly (verifier.cpp:363-379): the public vector is eq(r_liu, .) over the input layer
+        std::vector<F> pub;
+        initBetaTable(pub, s->circ->c.circuit[0].bitLength, v.finalPoint().begin(), F_ONE);
+        pub.resize(1ull << s->circ->c.circuit[0].bitLength);
+        F inner; std::vector<F> all_sum;
+        prover::hhash_digest rh = s->p->commit_public(pub, inner, all_sum);
+        out.insert(out.end(), rh.b, rh.b + 32);
+        const uint8_t *ib = reinterpret_cast<const uint8_t *>(&inner);
+        out.insert(out.end(), ib, ib + 16);
+        const uint8_t *ab = reinterpret_cast<const uint8_t *>(all_sum.data());
+        out.insert(out.end(), ab, ab + 65 * 16);
+        if (out.size() > capacity) { set_err(err, errlen, "transcript buffer too small"); return -1; }
+        memcpy(transcript, out.data(), out.size());
+        if (n_written) *n_written = out.size();
+        return ok ? 0 : 1;
+    } catch (const std::exception &e) {
+        set_err(err, errlen, e.what());
+        return -2;
+    }
+}
+
 int vph_verify_transcript(vph_circuit *c, const uint8_t *transcript, uint64_t n, int skip_predicates) {
     try {
         F::init();

@@ -57,6 +57,14 @@ int vph_check(vph_session *, const uint8_t *transcript, uint64_t n, int skip_pre
 uint64_t vph_transcript_bytes(vph_session *);
 /* prover::commit_private(): Merkle root of the RS-encoded input layer (merkle_root_l); device ms via *ms. */
 int vph_commit_private(vph_session *, uint8_t root[32], double *ms, char *err, int errlen);
+/* prover::commit_public on a caller-supplied public vector of 2^bit_length(layer 0) elements ({real,img} pairs).
+ * out = root_h[32] | input_0[16] | all_sum[65*16]  (the tail of the golden transcript layout).         */
+int vph_commit_public(vph_session *, const uint64_t *pub_pairs, uint64_t n_pub, uint8_t out[32 + 16 + 65 * 16], double *ms,
+                      char *err, int errlen);
+/* The whole protocol of verifier::verify() up to commit_public (src/verifier.cpp:134-169,363-379), interactive
+ * GKR: writes merkle_root_l | GKR slice | merkle_root_h | input_0 | all_sum[65] — the golden layout.   */
+int vph_prove_full(vph_session *, uint8_t *transcript, uint64_t capacity, uint64_t *n_written, int batched, char *err,
+                   int errlen);
 /* No GPU needed: F::init(), draw the tape for `circuit`, replay the host verifier over `transcript`
  * (GKR slice).  0 = accepted, 1 = rejected.                                                            */
 int vph_verify_transcript(vph_circuit *, const uint8_t *transcript, uint64_t n, int skip_predicates);
