@@ -128,7 +128,15 @@ int vp_commit_private(vp_ctx *, uint8_t root[32]);
  * codewords h (merkle_root_h).  vp_commit_private must have run.                                       */
 int vp_commit_public(vp_ctx *, const vp_F *pub, uint64_t n_pub, vp_F *inner_product_sum, vp_F all_sum[65],
                      uint8_t root_h[32]);
-/* Device time of the last vp_commit_private / vp_commit_public in milliseconds (hipEvents).            */
+/* fri::commit_phase_step(r) (lib/virgo/src/fri.cpp:289-424), called n-6 times by poly_commit_prover::commit_phase
+ * (vpd_verifier.cpp:44-74): fold the current codewords of all slices by r, hash the new leaves, build the Merkle
+ * tree, return its root.  The first call builds the virtual oracle (poly_commit.h:294-318) from the data
+ * vp_commit_public left in HBM.  VP_EINVAL once the codeword is down to 32 values per slice.            */
+int vp_fri_step(vp_ctx *, const vp_F *r, uint8_t root[32]);
+/* fri::commit_phase_final() (fri.cpp:426-431): the last codeword, 2048 elements in the reference's interleaved
+ * layout [i << 7 | slice << 1 | hi], i < 16.                                                            */
+int vp_fri_final(vp_ctx *, vp_F *final_code);
+/* Device time of the last vp_commit_private / vp_commit_public / vp_fri_step in milliseconds (hipEvents). */
 int vp_commit_stats(vp_ctx *, double *commit_ms);
 
 /* ---- measurement --------------------------------------------------------------------------------- */

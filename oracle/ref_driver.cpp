@@ -23,6 +23,22 @@
 #include <chrono>
 
 vp_ref_state g_vp_ref;
+static FILE *g_fri_dump = nullptr;
+
+// fri::commit_phase_step (lib/virgo/src/fri.cpp:289-424) is compiled as ref_commit_phase_step (oracle/Makefile);
+// this wrapper keeps its name and records (challenge, Merkle root) of every FRI commit step.
+namespace virgo { namespace fri {
+__hhash_digest ref_commit_phase_step(fieldElement r);
+__hhash_digest commit_phase_step(fieldElement r) {
+    __hhash_digest d = ref_commit_phase_step(r);
+    if (g_fri_dump) {
+        unsigned long long w[2] = {r.real, r.img};
+        fwrite(w, 8, 2, g_fri_dump);
+        fwrite(&d, 32, 1, g_fri_dump);
+    }
+    return d;
+}
+} }
 
 // symbols defined in the reference's src/main.cpp
 extern layeredCircuit c;
@@ -123,6 +139,7 @@ int main(int argc, char **argv) {
         else if (a == "--pc" && i + 1 < argc) g_vp_ref.pc_on = atoi(argv[++i]);
         else if (a == "--dump" && i + 1 < argc) dump = argv[++i];
         else if (a == "--seed" && i + 1 < argc) seed = atol(argv[++i]);
+        else if (a == "--dump-fri" && i + 1 < argc) { g_fri_dump = fopen(argv[++i], "wb"); if (!g_fri_dump) { perror("dump-fri"); return 2; } }
         else if (a == "--randomize" && i + 2 < argc) { rnd_layers = atoi(argv[++i]); rnd_log = atoi(argv[++i]); }
         else { fprintf(stderr, "bad arg %s\n", argv[i]); return 2; }
     }
@@ -168,6 +185,17 @@ int main(int argc, char **argv) {
     }
     auto t3 = std::chrono::high_resolution_clock::now();
     if (g_vp_ref.dump) fclose(g_vp_ref.dump);
+    if (g_fri_dump) {
+        // final codeword of the commit phase (fri::commit_phase_final, fri.cpp:426-431): 32 values per slice,
+        // interleaved [i << 7 | slice << 1 | hi] for i < 16, followed by the mask codeword (32 values)
+        using namespace virgo;
+        const int last = fri::current_step_no - 1;
+        if (last >= 0) {
+            for (int k = 0; k < 16 * 128; ++k) { unsigned long long w[2] = {fri::cpd.rs_codeword[last][k].real, fri::cpd.rs_codeword[last][k].img}; fwrite(w, 8, 2, g_fri_dump); }
+            for (int k = 0; k < 32; ++k) { unsigned long long w[2] = {fri::cpd.rs_codeword_msk[last][k].real, fri::cpd.rs_codeword_msk[last][k].img}; fwrite(w, 8, 2, g_fri_dump); }
+        }
+        fclose(g_fri_dump);
+    }
     fprintf(stdout, "mult counter %d, add counter %d\n", F::multCounter, F::addCounter);   // src/main.cpp:157
     fprintf(stdout, "rounds %lu verify_wall_sec %.3f ok %d\n", g_vp_ref.rounds,
             std::chrono::duration<double>(t3 - t2).count(), ok ? 1 : 0);

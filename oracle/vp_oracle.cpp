@@ -866,7 +866,7 @@ bool read_pws(const char *path, vector<u64> &inputs, vector<PwsGate> &gates) {
 
 }  // namespace
 
-struct orc_circuit { Circuit c; };
+struct orc_circuit { Circuit c; std::vector<F> last_point; };
 
 extern "C" {
 
@@ -1193,7 +1193,7 @@ int orc_commit_private(orc_circuit *oc, uint8_t root[32]) {
 // ---- commit_public_array (poly_commit.h:126-349) with zero masks ---------------------------------------
 namespace {
 struct PublicOut { F inner; F all_sum[65]; Digest root_h; };
-void commit_public_core(const vector<F> &input, const vector<F> &pub, int n_bits, u64 n_used, PublicOut &out) {
+void commit_public_core(const vector<F> &input, const vector<F> &pub, int n_bits, u64 n_used, PublicOut &out, vector<F> *vo = nullptr) {
     const u64 N = 1ull << (n_bits - 6);
     vector<F> l_eval, q_eval; u64 M;
     commit_private_evals(input, n_bits, l_eval, M);                       // the prover still holds l_eval (poly_commit.cpp:4-13)
@@ -1201,6 +1201,8 @@ void commit_public_core(const vector<F> &input, const vector<F> &pub, int n_bits
     out.inner = F_ZERO;                                                    // prover::inner_prod, src/prover.cpp:532-540
     for (u64 i = 0; i < n_used; ++i) out.inner = out.inner + input[i] * pub[i];
     vector<F> h_arr(65 * M, F_ZERO), lq_eval(2 * N), lq_coef(2 * N), h_coef(N);
+    if (vo) vo->assign(64 * M, F_ZERO);
+    const F rou = root_of_unity(log2_exact(M)), inv_rou = finv(rou), rou_n = fpow(rou, N);
     for (int i = 0; i < 64; ++i) {
         bool all_zero = true;
         const u64 step = M / (2 * N);
@@ -1213,6 +1215,16 @@ void commit_public_core(const vector<F> &input, const vector<F> &pub, int n_bits
         for (u64 j = 0; j < N; ++j) h_coef[j] = lq_coef[j + N];
         fft_eval(h_coef.data(), N, M, &h_arr[(u64) i * M]);
         out.all_sum[i] = (lq_coef[0] + h_coef[0]) * F((long long) N);      // poly_commit.h:323
+        if (vo) {                                                          // virtual oracle, poly_commit.h:294-318
+            F x_n = F_ONE, inv_x = F((long long) N);
+            const F const_sum = F_ZERO - (lq_coef[0] + h_coef[0]);
+            for (u64 j = 0; j < M; ++j) {
+                const F g = l_eval[(u64) i * M + j] * q_eval[(u64) i * M + j] - (x_n - F_ONE) * h_arr[(u64) i * M + j];
+                (*vo)[(u64) i * M + j] = (g + const_sum) * inv_x;
+                inv_x = inv_x * inv_rou;
+                x_n = x_n * rou_n;
+            }
+        }
     }
     out.all_sum[64] = F_ZERO;                                              // mask slice: zero polynomial (:262)
     out.root_h = merkle_root(leaf_hashes(h_arr, M));
@@ -1254,6 +1266,7 @@ int64_t orc_prove_full(orc_circuit *oc, uint8_t *transcript, int64_t capacity, o
     // verifyPoly (verifier.cpp:363-379): the public vector is eq(r_liu, .) over the input layer
     vector<F> pub;
     init_beta_table(pub, n_bits, v.r_liu.data(), F_ONE);
+    oc->last_point.assign(v.r_liu.begin(), v.r_liu.begin() + n_bits);
     PublicOut po;
     commit_public_core(p.circuitValue[0], pub, n_bits, C.circuit[0].size, po);
     out.insert(out.end(), (unsigned char *) po.root_h.w, (unsigned char *) po.root_h.w + 32);
@@ -1270,3 +1283,54 @@ int64_t orc_prove_full(orc_circuit *oc, uint8_t *transcript, int64_t capacity, o
 }
 
 }  // extern "C"
+
+extern "C" int orc_fri_commit(const orc_F *input, const orc_F *pub, int n_bits, const orc_F *r, uint8_t *roots, orc_F *final_code) {
+    if (n_bits < 7) return -1;
+    const u64 n = 1ull << n_bits;
+    vector<F> in(n), pb(n), vo;
+    for (u64 i = 0; i < n; ++i) { in[i] = F(input[i].real, input[i].img); pb[i] = F(pub[i].real, pub[i].img); }
+    PublicOut po;
+    commit_public_core(in, pb, n_bits, n, po, &vo);
+    u64 M = 1ull << (n_bits - 1);
+    const int steps = n_bits - 6;
+    const F inv2 = finv(F(2ll));
+    vector<F> cur = vo;                                                   // [64][M]
+    F w = root_of_unity(log2_exact(M));
+    for (int k = 0; k < steps; ++k) {
+        const F rk(r[k].real, r[k].img);
+        const u64 half = M / 2;
+        const F inv_w = finv(w);
+        vector<F> nxt(64 * half);
+        F inv_mu = F_ONE;                                                 // w^-i  (L_group[(M - i) & (M - 1)], fri.cpp:322)
+        for (u64 i = 0; i < half; ++i) {
+            const F c = inv_mu * rk;
+            for (int s = 0; s < 64; ++s) {
+                const F a = cur[(u64) s * M + i], b = cur[(u64) s * M + i + half];
+                nxt[(u64) s * half + i] = inv2 * ((a + b) + c * (a - b));  // fri.cpp:327-329
+            }
+            inv_mu = inv_mu * inv_w;
+        }
+        // leaves of the new codeword: pairs (i, i + half/2) chained over the slices, then the (zero) mask pair
+        vector<F> padded(65 * half, F_ZERO);
+        std::copy(nxt.begin(), nxt.end(), padded.begin());
+        Digest root = merkle_root(leaf_hashes(padded, half));
+        memcpy(roots + 32 * k, root.w, 32);
+        cur.swap(nxt);
+        M = half;
+        w = w * w;
+    }
+    for (u64 i = 0; i < 16; ++i)
+        for (int s = 0; s < 64; ++s)
+            for (int hi = 0; hi < 2; ++hi) {
+                const F x = cur[(u64) s * 32 + i + 16 * hi];
+                orc_F &o = final_code[(i << 7) | (s << 1) | hi];
+                o.real = x.re; o.img = x.im;
+            }
+    return 0;
+}
+
+extern "C" int orc_last_point(const orc_circuit *oc, orc_F *out, int n) {
+    if ((int) oc->last_point.size() < n) return -1;
+    for (int i = 0; i < n; ++i) { out[i].real = oc->last_point[i].re; out[i].img = oc->last_point[i].im; }
+    return 0;
+}

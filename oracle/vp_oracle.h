@@ -103,6 +103,15 @@ int64_t orc_prove_full(orc_circuit *, uint8_t *transcript, int64_t capacity, orc
 int orc_commit_public(const orc_F *input, const orc_F *pub, int n_bits, uint64_t n_used, orc_F *inner, orc_F *all_sum,
                       uint8_t root_h[32]);
 
+/* FRI commit phase on the virtual oracle (poly_commit.h:294-318 builds it; poly_commit_prover::commit_phase,
+ * vpd_verifier.cpp:44-74, loops fri::commit_phase_step, fri.cpp:289-424).  `r` are the n_bits-6 fold challenges
+ * (the reference draws them with F::random() inside commit_phase; tests feed the recorded ones).  roots gets one
+ * 32-byte Merkle root per step; final_code the last codeword in the reference's interleaved layout
+ * [i << 7 | slice << 1 | hi], i < 16 (2048 elements).                                                     */
+/* The point the input layer is opened at (r_liu after the last Liu sumcheck) of the last orc_prove_full run.  */
+int orc_last_point(const orc_circuit *, orc_F *out, int n);
+int orc_fri_commit(const orc_F *input, const orc_F *pub, int n_bits, const orc_F *r, uint8_t *roots, orc_F *final_code);
+
 #ifdef __cplusplus
 }
 #endif

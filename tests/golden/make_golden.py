@@ -40,7 +40,8 @@ SURVEY_SHA256 = {
 
 def run_case(name, args):
     out_bin = os.path.join(HERE, f"transcript_{name}.bin")
-    cmd = [REF_RUN] + args + ["--pc", "1", "--dump", out_bin]
+    fri_bin = os.path.join(HERE, f"fri_{name}.bin")
+    cmd = [REF_RUN] + args + ["--pc", "1", "--dump", out_bin, "--dump-fri", fri_bin]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, check=True)
     txt = res.stdout
     data = open(out_bin, "rb").read()
@@ -53,7 +54,12 @@ def run_case(name, args):
     pt = re.search(r"Prove Time ([0-9.]+)", txt)
     pc = re.search(r"Polynomial commitment: prove time ([0-9.]+)", txt)
     ps = re.search(r"proof size = ([0-9.]+) kb", txt)
+    fri = open(fri_bin, "rb").read()
+    n_steps = (len(fri) - (16 * 128 + 32) * 16) // 48
     return {
+        "fri": os.path.basename(fri_bin),           # n_steps x (challenge[16] | root[32]) | final codeword[2048 F] | mask codeword[32 F]
+        "fri_steps": n_steps,
+        "fri_sha256": hashlib.sha256(fri).hexdigest(),
         "transcript": os.path.basename(out_bin),
         "bytes": len(data),
         "sha256": digest,

@@ -260,3 +260,42 @@ def test_commit_public_vs_oracle_random_vector(vp, ob, pws_path):
     assert ob.lib().orc_commit_public(inp.ctypes.data, pub.ctypes.data, n_bits, oc.layer_size(0), e_inner.ctypes.data, e_all.ctypes.data, e_root) == 0
     assert inner == e_inner.tobytes() and all_sum == e_all.tobytes() and root_h == e_root.raw
     s.close(); c.close(); oc.close()
+
+
+def _fri_golden(golden, name):
+    import os
+    from conftest import GOLDEN
+    g = golden[name]
+    fri = open(os.path.join(GOLDEN, g["fri"]), "rb").read()
+    st = g["fri_steps"]
+    rec = np.frombuffer(fri[: 48 * st], dtype=np.uint64).reshape(st, 6)
+    r = np.ascontiguousarray(rec[:, :2])
+    roots = b"".join(rec[i, 2:].tobytes() for i in range(st))
+    fin = np.frombuffer(fri[48 * st: 48 * st + 2048 * 16], dtype=np.uint64).reshape(2048, 2)
+    return r, roots, fin
+
+
+@pytest.mark.parametrize("name,blocks", [("sha256_x1", 1), ("sha256_x16", 16), ("sha256_x64", 64)])
+def test_fri_commit_phase_matches_reference(vp, golden, pws_path, name, blocks):
+    """Every FRI Merkle root and the final codeword of the real reference, given its recorded fold challenges."""
+    c = vp.Circuit.from_pws(pws_path, blocks, seed=1)
+    s = vp.Session(c)
+    tr, ok = s.prove_full(batched=True)             # leaves l, q (-> virtual oracle) and h in HBM
+    assert ok
+    r, roots_gold, fin_gold = _fri_golden(golden, name)
+    roots, fin = s.fri_commit(r)
+    assert roots == roots_gold
+    assert np.array_equal(fin, fin_gold)
+    with pytest.raises(RuntimeError):               # the commit phase is over
+        s.fri_commit(r[:1])
+    s.close(); c.close()
+
+
+def test_fri_commit_phase_randomize(vp, golden):
+    c = vp.Circuit.randomize(8, 12, seed=1)
+    s = vp.Session(c)
+    s.prove_full(batched=True)
+    r, roots_gold, fin_gold = _fri_golden(golden, "randomize_8_12")
+    roots, fin = s.fri_commit(r)
+    assert roots == roots_gold and np.array_equal(fin, fin_gold)
+    s.close(); c.close()

@@ -182,3 +182,49 @@ def test_oracle_commit_private_root_randomize(ob, golden):
     assert L.orc_commit_private(c.h, r) == 0
     assert r.raw == open(os.path.join(GOLDEN, golden["randomize_8_12"]["transcript"]), "rb").read()[:32]
     c.close()
+
+
+def _fri_case(ob, golden, name, c):
+    """Oracle full proof + FRI commit phase against the real reference's recorded FRI steps."""
+    from conftest import GOLDEN
+    L = ob.lib()
+    L.orc_fri_commit.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    L.orc_prove_full.restype = ctypes.c_int64
+    L.orc_prove_full.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+    L.orc_last_point.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    g = golden[name]
+    buf = ctypes.create_string_buffer(1 << 20)
+    n = L.orc_prove_full(c.h, buf, len(buf), None)
+    gold = open(os.path.join(GOLDEN, g["transcript"]), "rb").read()
+    assert buf.raw[:n] == gold and hashlib.sha256(buf.raw[:n]).hexdigest() == SURVEY_SHA256[name]
+    nb = L.orc_circuit_layer_bitlen(c.h, 0)
+    pt = np.zeros((nb, 2), np.uint64)
+    assert L.orc_last_point(c.h, pt.ctypes.data, nb) == 0
+    one = np.array([1, 0], np.uint64)
+    pub = np.zeros((1 << nb, 2), np.uint64)
+    L.orc_beta_table(pt.ctypes.data, nb, one.ctypes.data, pub.ctypes.data)
+    inp = np.zeros((1 << nb, 2), np.uint64)
+    L.orc_circuit_inputs(c.h, inp.ctypes.data)
+    fri = open(os.path.join(GOLDEN, g["fri"]), "rb").read()
+    st = g["fri_steps"]
+    assert st == nb - 6
+    rec = np.frombuffer(fri[:48 * st], dtype=np.uint64).reshape(st, 6)
+    r = np.ascontiguousarray(rec[:, :2])
+    roots = ctypes.create_string_buffer(32 * st)
+    fin = np.zeros((2048, 2), np.uint64)
+    assert L.orc_fri_commit(inp.ctypes.data, pub.ctypes.data, nb, r.ctypes.data, roots, fin.ctypes.data) == 0
+    assert roots.raw == b"".join(rec[i, 2:].tobytes() for i in range(st))
+    assert np.array_equal(fin, np.frombuffer(fri[48 * st:48 * st + 2048 * 16], dtype=np.uint64).reshape(2048, 2))
+    assert not np.frombuffer(fri[48 * st + 2048 * 16:], dtype=np.uint64).any()      # mask codeword is zero
+
+
+def test_oracle_full_transcript_and_fri_x1(ob, golden, pws_path):
+    c = ob.Circuit.from_pws(pws_path, 1, seed=1)
+    _fri_case(ob, golden, "sha256_x1", c)
+    c.close()
+
+
+def test_oracle_full_transcript_and_fri_randomize(ob, golden):
+    c = ob.Circuit.randomize(8, 12, seed=1)
+    _fri_case(ob, golden, "randomize_8_12", c)
+    c.close()

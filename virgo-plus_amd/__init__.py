@@ -137,6 +137,7 @@ def lib_host():
         L.vph_verify_transcript.argtypes = [vp, vp, u64, ctypes.c_int]
         L.vph_commit_public.argtypes = [vp, vp, u64, vp, ctypes.POINTER(ctypes.c_double), ctypes.c_char_p, ctypes.c_int]
         L.vph_prove_full.argtypes = [vp, vp, u64, ctypes.POINTER(u64), ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
+        L.vph_fri_commit.argtypes = [vp, vp, ctypes.c_int, vp, vp, ctypes.c_char_p, ctypes.c_int]
         L.vph_commit_private.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_double), ctypes.c_char_p, ctypes.c_int]
         L.vph_transcript_bytes.restype = u64
         L.vph_transcript_bytes.argtypes = [vp]
@@ -274,6 +275,18 @@ class Session:
         if rc < 0:
             raise RuntimeError("prove_full failed: " + err.value.decode())
         return buf.raw[: n.value], rc == 0
+
+    def fri_commit(self, r):
+        """FRI commit phase with the given fold challenges ((steps, 2) uint64): (roots bytes, final codeword (2048, 2))."""
+        import numpy as np
+        r = np.ascontiguousarray(r, dtype=np.uint64)
+        roots = ctypes.create_string_buffer(32 * r.shape[0])
+        fin = np.zeros((2048, 2), dtype=np.uint64)
+        err = ctypes.create_string_buffer(512)
+        rc = lib_host().vph_fri_commit(self.h, r.ctypes.data, r.shape[0], ctypes.cast(roots, ctypes.c_void_p), fin.ctypes.data, err, len(err))
+        if rc:
+            raise RuntimeError("fri_commit failed: " + err.value.decode())
+        return roots.raw, fin
 
     def check(self, transcript, skip_predicates=False):
         sec = ctypes.c_double(0)

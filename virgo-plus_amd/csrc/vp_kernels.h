@@ -1407,7 +1407,7 @@ k_pc_quotient(const F *__restrict__ ST, u32 N, const F *__restrict__ RT, u32 hal
     const u32 e = (16 * j) & (M - 1);                          // w_2N = w_M^16
     const F D = f_mul(T, root_pow(RT, half_m, e ? M - e : 0));
     H[t] = f_mul(f_sub(S, D), inv2);
-    if (j == 0) all_sum[i] = f_mul(S, n_as_f);
+    if (j == 0) { all_sum[i] = f_mul(S, n_as_f); all_sum[80 + i] = S; }     // [80..144): S_0 = lq_coef[0] + h_coef[0]
 }
 // prover::inner_prod (src/prover.cpp:532-540)
 __global__ void __launch_bounds__(VP_BLOCK) k_pc_dot(const F *__restrict__ x, const F *__restrict__ y, u32 n, F *part) {
@@ -1423,6 +1423,57 @@ __global__ void __launch_bounds__(VP_BLOCK) k_pc_sum_parts(const F *__restrict__
     for (u32 i = threadIdx.x; i < n; i += blockDim.x) acc[0] = f_add(acc[0], part[i]);
     block_sum<1>(acc, lds);
     if (threadIdx.x == 0) *out = acc[0];
+}
+
+}  // namespace vp
+
+// ---- virtual oracle + K9: FRI commit phase (poly_commit.h:294-318, fri.cpp:289-424) ------------------------
+namespace vp {
+
+// vo = (l*q - (x^N - 1)*h + const_i) * N * x^-1 at x = w_M^(32a+b); x^N = w_32^b depends on the coset only.
+// Written in place over the q codeword (same coset-major index).
+__global__ void __launch_bounds__(VP_BLOCK)
+k_pc_virtual_oracle(const F *__restrict__ lcw, F *__restrict__ qcw, const F *__restrict__ hcw, const F *__restrict__ S0, u32 N,
+                    const F *__restrict__ RT, u32 half_m, F n_as_f) {
+    const size_t t = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t M = 2 * (size_t) half_m;
+    if (t >= 64 * M) return;
+    const u32 a = (u32) (t % N), b = (u32) ((t / N) % 32), i = (u32) (t / M);
+    const u32 k = 32 * a + b;
+    const F xn_m1 = f_sub(root_pow(RT, half_m, (u32) ((size_t) b * N) & (u32) (M - 1)), f_one());   // w_M^(N*b) - 1
+    const F g = f_sub(f_mul(lcw[t], qcw[t]), f_mul(xn_m1, hcw[t]));
+    const F inv_x = f_mul(n_as_f, root_pow(RT, half_m, k ? (u32) M - k : 0));
+    qcw[t] = f_mul(f_sub(g, S0[i]), inv_x);
+}
+
+// One FRI fold of all 64 slices: out[s][b][a] = 1/2 ((p + q) + mu^-1 r (p - q)), p = in[s][b][a], q = in[s][b][a + Nk/2],
+// mu = w_k^(32a+b) with w_k = w_M^(2^k) the generator of the current domain (fri.cpp:312-331).
+__global__ void __launch_bounds__(VP_BLOCK)
+k_fri_fold(const F *__restrict__ in, F *__restrict__ out, u32 Nk, int k, const F *__restrict__ RT, u32 half_m, F r, F inv2) {
+    const size_t t = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 No = Nk >> 1;                                   // per-coset length of the output (>= 1)
+    if (t >= (size_t) 64 * 32 * No) return;
+    const u32 a = (u32) (t % No), sb = (u32) (t / No);        // sb = slice * 32 + coset
+    const u32 b = sb & 31;
+    const u32 M = 2 * half_m;
+    const u32 e = (u32) ((((unsigned long long) (32 * a + b)) << k) & (M - 1));
+    const F inv_mu = root_pow(RT, half_m, e ? M - e : 0);
+    F p, q;
+    if (Nk >= 2) { p = in[(size_t) sb * Nk + a]; q = in[(size_t) sb * Nk + a + No]; }
+    else { p = f_zero(); q = f_zero(); }
+    out[t] = f_mul(inv2, f_add(f_add(p, q), f_mul(f_mul(inv_mu, r), f_sub(p, q))));
+}
+// The last fold leaves ONE value per coset (32 per slice); its 16 leaves pair coset b with coset b + 16.
+__global__ void k_leaf_hash_final(const F *__restrict__ cw, int n_slices, Dig *__restrict__ leaves) {
+    const u32 j = threadIdx.x;
+    if (j >= 16) return;
+    Dig h; h.w[0] = h.w[1] = h.w[2] = h.w[3] = 0;
+    for (int s = 0; s < n_slices; ++s) {
+        const F x = cw[(size_t) s * 32 + j], y = cw[(size_t) s * 32 + j + 16];
+        h = hhash64(x.re, x.im, y.re, y.im, h);
+    }
+    h = hhash64(0, 0, 0, 0, h);
+    leaves[j] = h;
 }
 
 }  // namespace vp

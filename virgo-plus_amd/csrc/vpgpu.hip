@@ -99,6 +99,7 @@ struct vp_ctx {
     // polynomial commitment
     F *pc_rt = nullptr, *pc_coef = nullptr, *pc_cw = nullptr; Dig *pc_tree = nullptr; int pc_lm = -1; double commit_ms = 0;
     F *pc_pub = nullptr, *pc_qcw = nullptr, *pc_hcw = nullptr, *pc_tmp = nullptr, *pc_small = nullptr; Dig *pc_tree_h = nullptr; bool pc_private_done = false;
+    F *pc_fri[2] = {nullptr, nullptr}; Dig *pc_fri_tree = nullptr; int fri_step = -1; size_t fri_tree_used = 0; bool pc_public_done = false;
 
     F *part2 = nullptr;                  // [32][MAX_BLOCKS*3] block partials of the batched path
     int simple_path = 0, sumfold_path = 0, serial = 0;
@@ -433,6 +434,7 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
     ctx->chunk_cap = 0;
     ctx->pc_rt = ctx->pc_coef = ctx->pc_cw = nullptr; ctx->pc_tree = nullptr; ctx->pc_lm = -1;
     ctx->pc_pub = ctx->pc_qcw = ctx->pc_hcw = ctx->pc_tmp = ctx->pc_small = nullptr; ctx->pc_tree_h = nullptr; ctx->pc_private_done = false;
+    ctx->pc_fri[0] = ctx->pc_fri[1] = nullptr; ctx->pc_fri_tree = nullptr; ctx->fri_step = -1; ctx->pc_public_done = false;
     int max_bl = 0;
     for (int i = 0; i < n_layers; ++i) {
         if (ld[i].size == 0 || ld[i].size > (1ull << 30) || ld[i].bit_length < 0 || ld[i].bit_length > 30 ||
@@ -1351,7 +1353,7 @@ int vp_commit_public(vp_ctx *ctx, const vp_F *pub, uint64_t n_pub, vp_F *inner, 
         VPCHK(dalloc(ctx, &ctx->pc_qcw, (size_t) 64 * M));
         VPCHK(dalloc(ctx, &ctx->pc_hcw, (size_t) 64 * M));
         VPCHK(dalloc(ctx, &ctx->pc_tmp, (size_t) 3 * 128 * N));           // products | S,T | H
-        VPCHK(dalloc(ctx, &ctx->pc_small, (size_t) 1024 + 80));
+        VPCHK(dalloc(ctx, &ctx->pc_small, (size_t) 1024 + 160));
         VPCHK(dalloc(ctx, &ctx->pc_tree_h, (size_t) M));
     }
     HIPCHK(hipMemcpyAsync(ctx->pc_pub, pub, sizeof(F) << n, hipMemcpyHostToDevice, ctx->stream));
@@ -1384,6 +1386,61 @@ int vp_commit_public(vp_ctx *ctx, const vp_F *pub, uint64_t n_pub, vp_F *inner, 
     float ms = 0;
     hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
     ctx->commit_ms = ms;
+    ctx->pc_public_done = true; ctx->fri_step = -1;
+    return VP_OK;
+}
+
+int vp_fri_step(vp_ctx *ctx, const vp_F *r, uint8_t root[32]) {
+    if (!ctx || !ctx->pc_public_done || !r || !root) return VP_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int n = ctx->L[0].bl, ln = n - 6, lm = n - 1;
+    const u32 N = 1u << ln, M = 1u << lm;
+    if (!ctx->pc_fri[0]) {
+        VPCHK(dalloc(ctx, &ctx->pc_fri[0], (size_t) 64 * (M / 2)));
+        VPCHK(dalloc(ctx, &ctx->pc_fri[1], (size_t) 64 * std::max<u32>(M / 4, 32)));
+        VPCHK(dalloc(ctx, &ctx->pc_fri_tree, (size_t) M));
+    }
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    if (ctx->fri_step < 0) {
+        // virtual oracle in place over the q codeword; S_0 per slice sits behind all_sum in pc_small
+        hipLaunchKernelGGL(k_pc_virtual_oracle, dim3(nblk((u64) 64 * M)), dim3(VP_BLOCK), 0, ctx->stream, ctx->pc_cw, ctx->pc_qcw,
+                           ctx->pc_hcw, ctx->pc_small + 1025 + 80, N, ctx->pc_rt, M >> 1, f_make(N, 0));
+        ctx->fri_step = 0; ctx->fri_tree_used = 0;
+    }
+    const int k = ctx->fri_step;
+    if (k >= ln) { ctx->err = "FRI commit phase already finished"; return VP_EINVAL; }
+    const u32 Nk = N >> k, No = Nk >> 1;
+    const F *in = k == 0 ? ctx->pc_qcw : ctx->pc_fri[(k - 1) & 1];
+    F *out = ctx->pc_fri[k & 1];
+    F rf; memcpy(&rf, r, sizeof(F));
+    hipLaunchKernelGGL(k_fri_fold, dim3(nblk((u64) 64 * 32 * No)), dim3(VP_BLOCK), 0, ctx->stream, in, out, Nk, k, ctx->pc_rt, M >> 1, rf,
+                       host_inv_real(2));
+    // leaves of the folded codeword (M_{k+1} / 2 of them) + tree
+    const u32 n_leaves = 16 * No;
+    Dig *tree = ctx->pc_fri_tree + ctx->fri_tree_used;
+    if (No >= 2) hipLaunchKernelGGL(k_leaf_hash, dim3(nblk(n_leaves)), dim3(VP_BLOCK), 0, ctx->stream, out, No, 64, tree + n_leaves);
+    else hipLaunchKernelGGL(k_leaf_hash_final, dim3(1), dim3(64), 0, ctx->stream, out, 64, tree + n_leaves);
+    VPCHK(pc_merkle(ctx, tree, n_leaves));
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    HIPCHK(hipMemcpyAsync(root, tree + 1, 32, hipMemcpyDeviceToHost, ctx->stream));
+    VPCHK(check_stream(ctx));
+    ctx->fri_tree_used += 2 * (size_t) n_leaves;
+    ctx->fri_step = k + 1;
+    float ms = 0;
+    hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+    ctx->commit_ms = ms;
+    return VP_OK;
+}
+
+int vp_fri_final(vp_ctx *ctx, vp_F *final_code) {
+    if (!ctx || !final_code || !ctx->pc_public_done) return VP_EINVAL;
+    const int ln = ctx->L[0].bl - 6;
+    if (ctx->fri_step != ln) { ctx->err = "FRI commit phase not finished"; return VP_EINVAL; }
+    HIPCHK(hipSetDevice(ctx->device));
+    std::vector<F> cw(64 * 32);
+    HIPCHK(hipMemcpy(cw.data(), ctx->pc_fri[(ln - 1) & 1], cw.size() * sizeof(F), hipMemcpyDeviceToHost));
+    F *o = reinterpret_cast<F *>(final_code);
+    for (u32 i = 0; i < 16; ++i) for (u32 s = 0; s < 64; ++s) for (u32 hi = 0; hi < 2; ++hi) o[(i << 7) | (s << 1) | hi] = cw[s * 32 + i + 16 * hi];
     return VP_OK;
 }
 

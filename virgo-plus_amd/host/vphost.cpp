@@ -166,6 +166,18 @@ int vph_commit_public(vph_session *s, const uint64_t *pub_pairs, uint64_t n_pub,
     }
 }
 
+int vph_fri_commit(vph_session *s, const uint64_t *r_pairs, int n_steps, uint8_t *roots, uint64_t *final_pairs, char *err, int errlen) {
+    vp_ctx *ctx = s->p->context();
+    for (int k = 0; k < n_steps; ++k) {
+        vp_F r; r.real = r_pairs[2 * k]; r.img = r_pairs[2 * k + 1];
+        int rc = vp_fri_step(ctx, &r, roots + 32 * k);
+        if (rc != VP_OK) { set_err(err, errlen, std::string("vp_fri_step: ") + vp_last_error(ctx)); return rc; }
+    }
+    int rc = vp_fri_final(ctx, reinterpret_cast<vp_F *>(final_pairs));
+    if (rc != VP_OK) { set_err(err, errlen, std::string("vp_fri_final: ") + vp_last_error(ctx)); return rc; }
+    return 0;
+}
+
 int vph_prove_full(vph_session *s, uint8_t *transcript, uint64_t capacity, uint64_t *n_written, int batched, char *err, int errlen) {
     try {
         F::init();

@@ -61,6 +61,10 @@ int vph_commit_private(vph_session *, uint8_t root[32], double *ms, char *err, i
  * out = root_h[32] | input_0[16] | all_sum[65*16]  (the tail of the golden transcript layout).         */
 int vph_commit_public(vph_session *, const uint64_t *pub_pairs, uint64_t n_pub, uint8_t out[32 + 16 + 65 * 16], double *ms,
                       char *err, int errlen);
+/* poly_commit_prover::commit_phase (vpd_verifier.cpp:44-74) with caller-supplied fold challenges: n_steps calls of
+ * fri::commit_phase_step, then commit_phase_final.  roots: 32 bytes per step; final_code: 2048 {real,img} pairs.
+ * commit_public (or vph_prove_full) must have run on this session.                                       */
+int vph_fri_commit(vph_session *, const uint64_t *r_pairs, int n_steps, uint8_t *roots, uint64_t *final_pairs, char *err, int errlen);
 /* The whole protocol of verifier::verify() up to commit_public (src/verifier.cpp:134-169,363-379), interactive
  * GKR: writes merkle_root_l | GKR slice | merkle_root_h | input_0 | all_sum[65] — the golden layout.   */
 int vph_prove_full(vph_session *, uint8_t *transcript, uint64_t capacity, uint64_t *n_written, int batched, char *err,
