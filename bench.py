@@ -120,6 +120,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--blocks", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--with-pc", action="store_true", help="also time the Virgo commitment (commit_private + commit_public + FRI commit phase)")
     a = ap.parse_args()
 
     world, rank, local = dist_setup(a.gpus)
@@ -158,6 +159,30 @@ def main():
             res[key] = res_p[key]
         res["serial_device_ms"] = res_p["gkr_device_ms"]
 
+        pc = None
+        if a.with_pc and rank == 0:
+            # BASELINE.json configs[2] flavour: the commitment's commit side on the GPU (not part of `value`)
+            import numpy as np
+            t1 = time.perf_counter()
+            full, okf = sess.prove_full(batched=True)
+            t_full = time.perf_counter() - t1
+            gname_ = "sha256_x%d" % a.blocks
+            pc = {"full_proof_wall_sec": t_full, "full_transcript_verified": okf}
+            if gname_ in golden:
+                from conftest import GOLDEN
+                gg = golden[gname_]
+                pc["full_transcript_bit_exact"] = (full == open(os.path.join(GOLDEN, gg["transcript"]), "rb").read())
+                fri = open(os.path.join(GOLDEN, gg["fri"]), "rb").read()
+                st = gg["fri_steps"]
+                rec = np.frombuffer(fri[:48 * st], dtype=np.uint64).reshape(st, 6)
+                t2 = time.perf_counter()
+                roots, fin = sess.fri_commit(np.ascontiguousarray(rec[:, :2]))
+                pc["fri_commit_wall_sec"] = time.perf_counter() - t2
+                pc["fri_roots_bit_exact"] = (roots == b"".join(rec[i, 2:].tobytes() for i in range(st)))
+            t3 = time.perf_counter(); _, ms_priv = sess.commit_private(); pc["commit_private_device_ms"] = ms_priv
+            pc["commit_private_wall_sec"] = time.perf_counter() - t3
+            pc["reference_pc_prove_sec_build_container"] = golden.get(gname_, {}).get("reference_pc_prove_sec_here")
+
         bit_exact = None
         ref_ops = None
         if gname in golden:
@@ -191,14 +216,24 @@ def main():
             if res["fold_launches"]:
                 avg_ms = res["fold_ms"] / res["fold_launches"]
                 gbps = res["fold_bytes"] / (res["fold_ms"] * 1e-3) / 1e9
+                traffic = None
+                try:        # PMC pass of the same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs), committed summary
+                    pm = json.load(open(os.path.join(ROOT, "profiles", "r01_b_pmc_summary_b64.json")))
+                    if a.blocks == 64:
+                        traffic = pm["k_sumfold3_avg_hbm_bytes_per_launch"]
+                except Exception:
+                    pass
                 line["roofline"] = {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                    "frac": gbps / HBM_PEAK_GBPS, "traffic": None,
+                                    "frac": gbps / HBM_PEAK_GBPS, "traffic": traffic,
+                                    "traffic_source": "profiles/r01_b_pmc_summary_b64.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)" if traffic else None,
                                     "kernel": "k_sumfold<3> (every launch; single-stream replay of the same proof)",
                                     "single_stream_proof_ms": res.get("serial_device_ms"),
                                     "launches": res["fold_launches"], "avg_launch_us": 1e3 * avg_ms,
                                     "algorithmic_bytes_per_launch": res["fold_bytes"] / res["fold_launches"]}
             else:
                 line["roofline"] = None
+            if pc is not None:
+                line["polynomial_commitment"] = pc
             if world == 1 and not a.no_cpu_baseline:
                 cb = cpu_baseline(pws, a.blocks, ref_ops)
                 cb["host_cpu"] = cpu_model()
