@@ -157,7 +157,7 @@ def test_sha3_matches_hashlib(vp, ctx):
     assert out[0].tobytes().hex() == "070fa1ab6fcc557ed14d42941f1967693048551eb9042a8d0a057afbd75e81e0"
 
 
-@pytest.mark.parametrize("ln,ratio", [(0, 1), (1, 1), (3, 32), (3, 1), (7, 32), (10, 1), (13, 32)])
+@pytest.mark.parametrize("ln,ratio", [(0, 1), (1, 1), (3, 32), (3, 1), (7, 32), (10, 1), (13, 32), (14, 1), (14, 32), (15, 32), (16, 1), (17, 1)])
 def test_fft_vs_oracle(vp, ob, ctx, ln, ratio):
     rng = np.random.default_rng(ln * 7 + ratio)
     n = 1 << ln
@@ -299,3 +299,30 @@ def test_fri_commit_phase_randomize(vp, golden):
     roots, fin = s.fri_commit(r)
     assert roots == roots_gold and np.array_equal(fin, fin_gold)
     s.close(); c.close()
+
+
+def test_commitment_with_split_transforms_vs_oracle(vp, ob, pws_path):
+    """128 blocks: slices of 2^14 elements, beyond the in-LDS transform -> split path.  No golden at this size:
+    compare commit_private / commit_public with the oracle's restatement on the same witness and public vector."""
+    c = vp.Circuit.from_pws(pws_path, 128, seed=3)
+    oc = ob.Circuit.from_pws(pws_path, 128, seed=3)
+    assert c.hash() == oc.hash()
+    s = vp.Session(c)
+    root, _ = s.commit_private()
+    L = ob.lib()
+    L.orc_commit_private.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+    er = ctypes.create_string_buffer(32)
+    assert L.orc_commit_private(oc.h, er) == 0
+    assert root == er.raw
+    n_bits = c.layer_bitlen(0)
+    assert n_bits - 6 == 14
+    rng = np.random.default_rng(8)
+    pub = rng.integers(0, P, size=(1 << n_bits, 2), dtype=np.uint64)
+    root_h, inner, all_sum, _ = s.commit_public(pub)
+    inp = np.zeros((1 << n_bits, 2), dtype=np.uint64)
+    L.orc_circuit_inputs(oc.h, inp.ctypes.data)
+    e_inner = np.zeros(2, dtype=np.uint64); e_all = np.zeros((65, 2), dtype=np.uint64); e_root = ctypes.create_string_buffer(32)
+    L.orc_commit_public.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p]
+    assert L.orc_commit_public(inp.ctypes.data, pub.ctypes.data, n_bits, oc.layer_size(0), e_inner.ctypes.data, e_all.ctypes.data, e_root) == 0
+    assert inner == e_inner.tobytes() and all_sum == e_all.tobytes() and root_h == e_root.raw
+    s.close(); c.close(); oc.close()

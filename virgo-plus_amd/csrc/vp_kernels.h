@@ -1477,3 +1477,82 @@ __global__ void k_leaf_hash_final(const F *__restrict__ cw, int n_slices, Dig *_
 }
 
 }  // namespace vp
+
+// ---- transforms longer than the LDS (2^13 < N <= 2^17): N = N1 * N2 with N1 = 2^l1 <= 16, N2 = 2^13 --------
+// j = j1*N2 + j2, k = k1 + N1*k2:  w_N^(jk) = w_N1^(j1 k1) * w_N^(j2 k1) * w_N2^(j2 k2).
+//   k_ntt_split : per j2 an N1-point transform over the N1 rows (stride N2) in registers + the w_N^(j2 k1) twiddle
+//                 (+ the coset twist for the encoder), written as [k1][j2] — every access coalesced;
+//   k_ntt_lds   : N1 contiguous N2-point transforms per row (existing kernel, rows = original rows * N1);
+//   k_ntt_unsplit: [k1][k2] -> natural k1 + N1*k2 through an LDS tile (+ the 1/N scale of the inverse).
+namespace vp {
+
+struct SplitArgs {
+    const F *in; F *out;
+    const F *RT; u32 half_m;      // root table of order M
+    int ln, l1;                   // N = 2^ln, N1 = 2^l1
+    int inverse;
+    u32 in_stride;                // elements between input rows
+    u32 ncoset;                   // forward: number of cosets (blockIdx.z = coset); inverse: 1
+};
+template <int L1>
+__global__ void __launch_bounds__(VP_BLOCK) k_ntt_split(SplitArgs a) {
+    constexpr u32 N1 = 1u << L1;
+    const u32 N = 1u << a.ln, N2 = N >> L1, M = 2 * a.half_m;
+    const u32 j2 = blockIdx.x * blockDim.x + threadIdx.x, row = blockIdx.y, coset = blockIdx.z;
+    if (j2 >= N2) return;
+    const u32 wN = M >> a.ln;                                  // w_N = w_M^wN
+    const F *src = a.in + (size_t) row * a.in_stride;
+    F x[N1];
+#pragma unroll
+    for (u32 j1 = 0; j1 < N1; ++j1) {
+        const u32 j = j1 * N2 + j2;
+        F v = src[j];
+        if (!a.inverse && coset) v = f_mul(v, root_pow(a.RT, a.half_m, (u32) (((unsigned long long) j * coset) & (M - 1))));
+        x[j1] = v;
+    }
+    // N1-point DFT, decimation in frequency in registers: natural in, bit-reversed out
+#pragma unroll
+    for (int s = L1; s >= 1; --s) {
+        const u32 half = 1u << (s - 1);
+#pragma unroll
+        for (u32 idx = 0; idx < N1 / 2; ++idx) {
+            const u32 k = idx & (half - 1), i0 = ((idx >> (s - 1)) << s) | k, i1 = i0 + half;
+            u32 e = (k * (N1 >> s)) * (M >> L1);               // w_N1^(k * N1/2^s) in units of w_M
+            if (a.inverse) e = e ? M - e : 0;
+            const F u = x[i0], v = x[i1];
+            x[i0] = f_add(u, v);
+            x[i1] = f_mul(f_sub(u, v), root_pow(a.RT, a.half_m, e));
+        }
+    }
+    F *dst = a.out + ((size_t) row * a.ncoset + coset) * N;
+#pragma unroll
+    for (u32 p = 0; p < N1; ++p) {
+        const u32 k1 = __brev(p) >> (32 - (L1 ? L1 : 1)) >> (L1 ? 0 : 1);     // bit reversal of p in L1 bits
+        u32 e = (u32) (((unsigned long long) j2 * k1 * wN) & (M - 1));         // w_N^(j2 k1)
+        if (a.inverse) e = e ? M - e : 0;
+        dst[(size_t) k1 * N2 + j2] = f_mul(x[p], root_pow(a.RT, a.half_m, e));
+    }
+}
+
+// in: [rows][N1][N2] (k1-major), out: [rows][N] natural (k = k1 + N1*k2); tile of 64 k2 x N1 k1 through LDS
+__global__ void __launch_bounds__(VP_BLOCK)
+k_ntt_unsplit(const F *__restrict__ in, F *__restrict__ out, int ln, int l1, F scale, int do_scale) {
+    __shared__ F tile[16][65];
+    const u32 N = 1u << ln, N1 = 1u << l1, N2 = N >> l1;
+    const u32 row = blockIdx.y, k2_0 = blockIdx.x * 64;
+    const F *src = in + (size_t) row * N;
+    F *dst = out + (size_t) row * N;
+    for (u32 t = threadIdx.x; t < N1 * 64; t += blockDim.x) {
+        const u32 k1 = t / 64, c = t % 64;
+        tile[k1][c] = src[(size_t) k1 * N2 + k2_0 + c];
+    }
+    __syncthreads();
+    for (u32 t = threadIdx.x; t < N1 * 64; t += blockDim.x) {
+        const u32 c = t / N1, k1 = t % N1;
+        F v = tile[k1][c];
+        if (do_scale) v = f_mul(v, scale);
+        dst[(size_t) (k2_0 + c) * N1 + k1] = v;
+    }
+}
+
+}  // namespace vp

@@ -99,6 +99,7 @@ struct vp_ctx {
     // polynomial commitment
     F *pc_rt = nullptr, *pc_coef = nullptr, *pc_cw = nullptr; Dig *pc_tree = nullptr; int pc_lm = -1; double commit_ms = 0;
     F *pc_pub = nullptr, *pc_qcw = nullptr, *pc_hcw = nullptr, *pc_tmp = nullptr, *pc_small = nullptr; Dig *pc_tree_h = nullptr; bool pc_private_done = false;
+    F *pc_scr = nullptr; size_t pc_scr_cap = 0;
     F *pc_fri[2] = {nullptr, nullptr}; Dig *pc_fri_tree = nullptr; int fri_step = -1; size_t fri_tree_used = 0; bool pc_public_done = false;
 
     F *part2 = nullptr;                  // [32][MAX_BLOCKS*3] block partials of the batched path
@@ -434,6 +435,7 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
     ctx->chunk_cap = 0;
     ctx->pc_rt = ctx->pc_coef = ctx->pc_cw = nullptr; ctx->pc_tree = nullptr; ctx->pc_lm = -1;
     ctx->pc_pub = ctx->pc_qcw = ctx->pc_hcw = ctx->pc_tmp = ctx->pc_small = nullptr; ctx->pc_tree_h = nullptr; ctx->pc_private_done = false;
+    ctx->pc_scr = nullptr; ctx->pc_scr_cap = 0;
     ctx->pc_fri[0] = ctx->pc_fri[1] = nullptr; ctx->pc_fri_tree = nullptr; ctx->fri_step = -1; ctx->pc_public_done = false;
     int max_bl = 0;
     for (int i = 0; i < n_layers; ++i) {
@@ -1288,12 +1290,48 @@ int pc_root_table(vp_ctx *ctx, int lm) {
     return VP_OK;
 }
 
+constexpr int PC_MAX_LN_SPLIT = 17;      // with the register split in front: N1 <= 16
+
+// rows transforms of size 2^ln.  forward: `cosets` twisted copies (coset-major output [row][coset][N]); inverse: scaled
+// by 1/N.  Sizes above 2^13 go through k_ntt_split -> k_ntt_lds (N1 x 2^13) -> k_ntt_unsplit and need `scratch`
+// (rows * cosets * N elements, twice).
 int pc_launch_ntt(vp_ctx *ctx, const F *in, F *out, int ln, int lm, int inverse, u32 rows, u32 cosets, u32 in_stride) {
+    if (ln <= PC_MAX_LN) {
+        NttArgs a{};
+        a.in = in; a.out = out; a.RT = ctx->pc_rt; a.half_m = 1u << (lm - 1); a.lm = lm; a.ln = ln; a.inverse = inverse;
+        a.in_stride = in_stride; a.inv_n = inverse ? host_inv_real(1ull << ln) : f_one();
+        const u32 threads = std::max<u32>(64, std::min<u32>(1024, (1u << ln) / 2));
+        hipLaunchKernelGGL(k_ntt_lds, dim3(rows, cosets), dim3(threads), sizeof(F) << ln, ctx->stream, a);
+        return VP_OK;
+    }
+    const int l1 = ln - PC_MAX_LN;                       // 1..4
+    const u32 N = 1u << ln, N2 = 1u << PC_MAX_LN, nc = inverse ? 1 : cosets;
+    const size_t total = (size_t) rows * nc * N;
+    if (ctx->pc_scr_cap < 2 * total) {
+        VPCHK(dalloc(ctx, &ctx->pc_scr, 2 * total));
+        ctx->pc_scr_cap = 2 * total;
+    }
+    F *s1 = ctx->pc_scr, *s2 = ctx->pc_scr + total;
+    SplitArgs sa{};
+    sa.in = in; sa.out = s1; sa.RT = ctx->pc_rt; sa.half_m = 1u << (lm - 1); sa.ln = ln; sa.l1 = l1; sa.inverse = inverse;
+    sa.in_stride = in_stride; sa.ncoset = nc;
+    const dim3 g1(nblk(N2), rows, nc);
+    if (l1 == 1) hipLaunchKernelGGL(k_ntt_split<1>, g1, dim3(VP_BLOCK), 0, ctx->stream, sa);
+    else if (l1 == 2) hipLaunchKernelGGL(k_ntt_split<2>, g1, dim3(VP_BLOCK), 0, ctx->stream, sa);
+    else if (l1 == 3) hipLaunchKernelGGL(k_ntt_split<3>, g1, dim3(VP_BLOCK), 0, ctx->stream, sa);
+    else hipLaunchKernelGGL(k_ntt_split<4>, g1, dim3(VP_BLOCK), 0, ctx->stream, sa);
+    // N1 contiguous N2-point transforms per (row, coset): plain (untwisted, unscaled) forward / inverse kernels
     NttArgs a{};
-    a.in = in; a.out = out; a.RT = ctx->pc_rt; a.half_m = 1u << (lm - 1); a.lm = lm; a.ln = ln; a.inverse = inverse;
-    a.in_stride = in_stride; a.inv_n = inverse ? host_inv_real(1ull << ln) : f_one();
-    const u32 threads = std::max<u32>(64, std::min<u32>(1024, (1u << ln) / 2));
-    hipLaunchKernelGGL(k_ntt_lds, dim3(rows, cosets), dim3(threads), sizeof(F) << ln, ctx->stream, a);
+    a.in = s1; a.out = s2; a.RT = ctx->pc_rt; a.half_m = 1u << (lm - 1); a.lm = lm; a.ln = PC_MAX_LN; a.inverse = inverse;
+    a.in_stride = N2; a.inv_n = f_one();
+    const u32 sub_rows = rows * nc << l1;
+    for (u32 r0 = 0; r0 < sub_rows; r0 += 32768) {      // gridDim.x limit safety
+        NttArgs b = a;
+        b.in = s1 + (size_t) r0 * N2; b.out = s2 + (size_t) r0 * N2;
+        hipLaunchKernelGGL(k_ntt_lds, dim3(std::min<u32>(32768, sub_rows - r0), 1), dim3(1024), sizeof(F) << PC_MAX_LN, ctx->stream, b);
+    }
+    hipLaunchKernelGGL(k_ntt_unsplit, dim3(N2 / 64, rows * nc), dim3(VP_BLOCK), 0, ctx->stream, s2, out, ln, l1,
+                       inverse ? host_inv_real(1ull << ln) : f_one(), inverse);
     return VP_OK;
 }
 
@@ -1315,7 +1353,7 @@ int vp_commit_private(vp_ctx *ctx, uint8_t root[32]) {
     const int n = ctx->L[0].bl;
     if (n < 7) { ctx->err = "input layer too small for the commitment (bit length < 7)"; return VP_EINVAL; }
     const int ln = n - 6, lm = n - 1;                     // slice_real_ele_cnt = 2^ln, slice_size = 2^lm (poly_commit.h:48-49)
-    if (ln > PC_MAX_LN) { ctx->err = "slice longer than the in-LDS transform"; return VP_ELIMIT; }
+    if (ln > PC_MAX_LN_SPLIT) { ctx->err = "slice longer than 2^17 elements"; return VP_ELIMIT; }
     const u32 N = 1u << ln, M = 1u << lm;
     VPCHK(pc_root_table(ctx, lm));
     if (!ctx->pc_coef) {
@@ -1470,7 +1508,7 @@ int vp_test_fft(vp_ctx *ctx, const vp_F *coefs, int coef_len, int order, int inv
     if (order != coef_len && order != 32 * coef_len) return VP_EINVAL;
     if (inverse && order != coef_len) return VP_EINVAL;
     int ln = 0; while ((1 << ln) < coef_len) ++ln;
-    if (ln > PC_MAX_LN) return VP_ELIMIT;
+    if (ln > PC_MAX_LN_SPLIT) return VP_ELIMIT;
     int lo = 0; while ((1 << lo) < order) ++lo;
     HIPCHK(hipSetDevice(ctx->device));
     // private root table of order max(order, 2)
