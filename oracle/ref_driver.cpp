@@ -128,7 +128,7 @@ static void circuit_hash(const layeredCircuit &C, unsigned long long out[2]) {
 }
 
 int main(int argc, char **argv) {
-    const char *pws = nullptr, *dump = nullptr;
+    const char *pws = nullptr, *dump = nullptr, *custom = nullptr;
     int blocks = 1, ref_parser = 0, rnd_layers = 0, rnd_log = 0;
     long seed = -1;
     for (int i = 1; i < argc; ++i) {
@@ -141,13 +141,37 @@ int main(int argc, char **argv) {
         else if (a == "--seed" && i + 1 < argc) seed = atol(argv[++i]);
         else if (a == "--dump-fri" && i + 1 < argc) { g_fri_dump = fopen(argv[++i], "wb"); if (!g_fri_dump) { perror("dump-fri"); return 2; } }
         else if (a == "--randomize" && i + 2 < argc) { rnd_layers = atoi(argv[++i]); rnd_log = atoi(argv[++i]); }
+        else if (a == "--custom" && i + 1 < argc) custom = argv[++i];
         else { fprintf(stderr, "bad arg %s\n", argv[i]); return 2; }
     }
-    if (!pws && !rnd_layers) { fprintf(stderr, "need --pws or --randomize\n"); return 2; }
+    if (!pws && !rnd_layers && !custom) { fprintf(stderr, "need --pws, --randomize or --custom\n"); return 2; }
     if (seed >= 0) srandom((unsigned) seed);   // per-proof witness seed
 
     auto t0 = std::chrono::high_resolution_clock::now();
-    if (rnd_layers) {
+    if (custom) {
+        // flat circuit file written by tests/golden/make_golden.py (tests/custom_circuits.py): int32 n_layers,
+        // u64 sizes[n], then per gate: i32 ty, i32 l, u64 u, u64 v, u64 c.real, u64 c.img, u8 is_assert
+        FILE *f = fopen(custom, "rb");
+        if (!f) { perror(custom); return 2; }
+        int nl = 0;
+        if (fread(&nl, 4, 1, f) != 1) return 2;
+        std::vector<u64> sz(nl);
+        if (fread(sz.data(), 8, nl, f) != (size_t) nl) return 2;
+        c.size = nl; c.circuit.resize(nl);
+        for (int i = 0; i < nl; ++i) {
+            auto &L = c.circuit[i];
+            L.size = sz[i]; L.gates.resize(sz[i]);
+            L.bitLength = 0; while ((1ULL << L.bitLength) < L.size) ++L.bitLength;
+            for (u64 g = 0; g < sz[i]; ++g) {
+                int ty, l; u64 u, v, cr, ci; unsigned char as;
+                if (fread(&ty, 4, 1, f) != 1 || fread(&l, 4, 1, f) != 1 || fread(&u, 8, 1, f) != 1 || fread(&v, 8, 1, f) != 1 ||
+                    fread(&cr, 8, 1, f) != 1 || fread(&ci, 8, 1, f) != 1 || fread(&as, 1, 1, f) != 1) return 2;
+                F cc; cc.real = cr; cc.img = ci;
+                L.gates[g] = gate((gateType) ty, l, u, v, cc, as != 0);
+            }
+        }
+        fclose(f);
+    } else if (rnd_layers) {
         c = layeredCircuit::randomize(rnd_layers, rnd_log);    // src/circuit.cpp:17
     } else {
         in_circuit_dag.clear();

@@ -675,9 +675,11 @@ struct Verifier {
     void putF(const F &x) { u64 w[2] = {x.re, x.im}; const unsigned char *b = (const unsigned char *) w; out->insert(out->end(), b, b + 16); }
     void putQ(const Quad &q) { putF(q.a); putF(q.b); putF(q.c); }
 
+    F assert_random;
     void predicatePhase1(int layer_id) {                             // verifier.cpp:50-90
         const Layer &cur = C.circuit[layer_id];
         init_beta_table(beta_g, cur.bitLength, r_liu.data(), F_ONE);
+        for (u64 g = 0; g < cur.size; ++g) if (cur.gates[g].is_assert) beta_g[g] *= assert_random;     // verifier.cpp:53-54
         init_beta_table(beta_u, C.circuit[layer_id - 1].bitLength, r_u.data(), F_ONE);
         coeff_l[Copy] = coeff_l[Not] = coeff_l[Addc] = coeff_l[Mulc] = F_ZERO;
         bias = F_ZERO;
@@ -721,7 +723,7 @@ struct Verifier {
         const Layer &pre = C.circuit[layer_id - 1];
         for (auto &x : r_u) x = frandom();
         F previousRandom = F_ZERO;
-        F assert_random = frandom();
+        assert_random = frandom();
         p->sumcheckInitPhase1(assert_random);
         for (int j = 0; j < pre.bitLength; ++j) {
             Quad poly = p->sumcheckUpdatePhase1(previousRandom);
@@ -919,6 +921,23 @@ orc_circuit *orc_circuit_randomize(int layers, int log_size, long seed) {   // c
     return oc;
 }
 
+orc_circuit *orc_circuit_custom(int n_layers, const uint64_t *layer_sizes, const int32_t *ty, const int32_t *l, const uint64_t *u,
+                                const uint64_t *v, const uint64_t *c_pairs, const uint8_t *is_assert) {
+    orc_circuit *oc = new orc_circuit();
+    Circuit &c = oc->c;
+    c.size = n_layers;
+    c.circuit.assign(n_layers, Layer());
+    u64 at = 0;
+    for (int i = 0; i < n_layers; ++i) {
+        Layer &L = c.circuit[i];
+        L.size = layer_sizes[i];
+        L.bitLength = ceil_log2(L.size);
+        L.gates.resize(L.size);
+        for (u64 g = 0; g < L.size; ++g, ++at)
+            L.gates[g] = Gate(ty[at], l[at], u[at], v[at], F(c_pairs[2 * at], c_pairs[2 * at + 1]), is_assert[at] != 0);
+    }
+    return oc;
+}
 void orc_circuit_free(orc_circuit *c) { delete c; }
 int orc_circuit_layers(const orc_circuit *c) { return c->c.size; }
 uint64_t orc_circuit_layer_size(const orc_circuit *c, int layer) { return c->c.circuit[layer].size; }

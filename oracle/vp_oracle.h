@@ -46,6 +46,11 @@ typedef struct {
 orc_circuit *orc_circuit_from_pws(const char *path, int blocks, long seed);
 /* layeredCircuit::randomize(layerNum, eachLayer) (src/circuit.cpp:17-41), g++ argument order.         */
 orc_circuit *orc_circuit_randomize(int layers, int log_size, long seed);
+/* Arbitrary layered circuit (tests of gate types the .pws loader never emits: Addc, Mulc, Copy, AntiNaab, assert
+ * gates).  Flat arrays over all gates in layer order; layer_sizes[n_layers]; for layer 0 `u` carries the input value.
+ * c_pairs: {real,img} per gate (used by Addc/Mulc).                                                       */
+orc_circuit *orc_circuit_custom(int n_layers, const uint64_t *layer_sizes, const int32_t *ty, const int32_t *l, const uint64_t *u,
+                                const uint64_t *v, const uint64_t *c_pairs, const uint8_t *is_assert);
 void orc_circuit_free(orc_circuit *);
 int  orc_circuit_layers(const orc_circuit *);
 uint64_t orc_circuit_layer_size(const orc_circuit *, int layer);

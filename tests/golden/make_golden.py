@@ -30,6 +30,14 @@ PWS = os.path.join(REF, "data", "SHA256_64.pws")
 
 # SHA-256 of the full transcripts as recorded in SURVEY.md §8c / §8d (instrumented reference build
 # of the survey).  make_golden refuses to write a fixture that disagrees.
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+# custom circuits (all gate types + assert gates; tests/custom_circuits.py): name -> (seed, layer sizes).  Input layers of
+# > 512 gates: the commitment needs bit length >= 7 (vpd_verifier.cpp:115), and the reference's own FFT only works for
+# transforms of >= 8 points (RS_polynomial.cpp:104-133: for order 4 the `dep == 1` loop runs zero times and stale scratch is
+# read), i.e. slices of >= 8 elements = input bit length >= 9.  Below that its Merkle roots are not a function of the input.
+CUSTOM = {"custom_a": (101, [600, 180, 150, 300, 64, 9]), "custom_b": (102, [1500, 2100, 900, 4100, 700])}
+
 SURVEY_SHA256 = {
     "sha256_x1": "7d56df550455f8e32dcda3ea158e2606b23f4e8bac761ca6a081b8caeee65047",
     "sha256_x16": "d9c442312561023d237a0c8ea1a40f26273c8d5a967028ab3f1bfeafe22d179f",
@@ -46,7 +54,7 @@ def run_case(name, args):
     txt = res.stdout
     data = open(out_bin, "rb").read()
     digest = hashlib.sha256(data).hexdigest()
-    if SURVEY_SHA256[name] != digest:
+    if name in SURVEY_SHA256 and SURVEY_SHA256[name] != digest:
         raise SystemExit(f"{name}: transcript digest {digest} != SURVEY.md {SURVEY_SHA256[name]}")
     m = re.search(r"circuit layers (\d+) gates (\d+) hash ([0-9a-f]{32})", txt)
     c = re.search(r"mult counter (-?\d+), add counter (-?\d+)", txt)
@@ -99,12 +107,25 @@ def main():
         os.remove(chk)
         meta["randomize_8_12"] = run_case("randomize_8_12", ["--randomize", "8", "12"])
         meta["sha256_x16"] = run_case("sha256_x16", ["--pws", tmp_pws, "--blocks", "16"])
+        import struct
+        import custom_circuits as cc
+        for cname, (seed, sizes) in CUSTOM.items():
+            szs, ty, l, u, v, c, asr = cc.make(seed, sizes)
+            path = os.path.join(HERE, "_%s.circ" % cname)
+            with open(path, "wb") as f:
+                f.write(struct.pack("<i", len(szs)))
+                f.write(szs.tobytes())
+                for g in range(len(ty)):
+                    f.write(struct.pack("<iiQQQQB", int(ty[g]), int(l[g]), int(u[g]), int(v[g]), int(c[g][0]), int(c[g][1]), int(asr[g])))
+            meta[cname] = run_case(cname, ["--custom", path])
+            meta[cname]["custom"] = {"seed": seed, "sizes": sizes}
+            os.remove(path)
         if a.with_x64:
             meta["sha256_x64"] = run_case("sha256_x64", ["--pws", tmp_pws, "--blocks", "64"])
     finally:
         os.remove(tmp_pws)
     for k in meta:
-        meta[k]["args"] = [x.replace(tmp_pws, "SHA256_64.pws") for x in meta[k]["args"]]
+        meta[k]["args"] = [os.path.basename(x) if x.startswith(HERE) else x for x in meta[k]["args"]]
     json.dump(meta, open(meta_path, "w"), indent=1, sort_keys=True)
     print(json.dumps({k: (v["sha256"], v["mult_counter"], v["add_counter"]) for k, v in meta.items()}, indent=1))
 

@@ -359,3 +359,52 @@ def test_sha256_x256_size_independent_properties(vp, pws_path):
     ok_bad, _ = s.check(bytes(bad), skip_predicates=True)
     assert not ok_bad
     s.close(); c.close()
+
+
+@pytest.mark.parametrize("seed,sizes", [(1, [40, 33, 50, 17]), (2, [200, 180, 150, 300, 64, 9]), (3, [1500, 2100, 900, 4100, 700]),
+                                        (4, [5, 3, 2, 1]), (5, [70000, 50000, 30000])])
+def test_all_gate_types_and_assert_gates_vs_oracle(vp, ob, seed, sizes):
+    """Addc / Mulc / Copy / AntiNaab / AntiSub and assert gates are in the reference's API (src/prover.cpp:49-87,
+    229-272,319-360,209-212) but in none of its data sets: random circuits with all types, device vs oracle."""
+    import custom_circuits as cc
+    args = cc.make(seed, sizes)
+    c = vp.Circuit.custom(*args)
+    oc = ob.Circuit.custom(*args)
+    assert c.hash() == oc.hash()
+    gold, st = oc.prove_gkr()
+    assert st["verified"] == 1
+    _both_modes(vp, c, gold)
+    c.close(); oc.close()
+
+
+def test_violated_assert_gate_is_reported(vp):
+    """The reference exits the process when an assert gate is non-zero (src/prover.cpp:18-21); the library returns
+    VP_EASSERT through the host constructor instead."""
+    import custom_circuits as cc
+    sizes, ty, l, u, v, c, a = cc.make(7, [16, 16, 8], with_asserts=False)
+    a[20] = 1                                   # some layer-1 gate with a (surely) non-zero value
+    circ = vp.Circuit.custom(sizes, ty, l, u, v, c, a)
+    with pytest.raises(RuntimeError, match="assert"):
+        vp.Session(circ)
+    circ.close()
+
+
+@pytest.mark.parametrize("name", ["custom_a", "custom_b"])
+def test_all_gate_types_full_protocol_vs_reference(vp, golden, name):
+    """The real reference's transcript (GKR + commitment) and FRI steps on circuits with every gate type and assert gates."""
+    import os
+    import custom_circuits as cc
+    from conftest import GOLDEN
+    g = golden[name]
+    c = vp.Circuit.custom(*cc.make(g["custom"]["seed"], g["custom"]["sizes"]))
+    assert c.hash() == g["circuit_hash"]
+    gold = open(os.path.join(GOLDEN, g["transcript"]), "rb").read()
+    _both_modes(vp, c, gold[g["gkr_slice"][0]:g["gkr_slice"][1]])
+    s = vp.Session(c)
+    for batched in (False, True):
+        tr, ok = s.prove_full(batched=batched)
+        assert ok and tr == gold
+    r, roots_gold, fin_gold = _fri_golden(golden, name)
+    roots, fin = s.fri_commit(r)
+    assert roots == roots_gold and np.array_equal(fin, fin_gold)
+    s.close(); c.close()

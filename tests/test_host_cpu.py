@@ -93,3 +93,15 @@ def test_host_verifier_replay_randomize(vp, gold_gkr):
     c = vp.Circuit.randomize(8, 12, seed=1)
     assert c.verify_transcript(gold_gkr("randomize_8_12"))
     c.close()
+
+
+def test_custom_circuit_structures_agree(vp, ob):
+    import custom_circuits as cc
+    args = cc.make(11, [30, 20, 25, 7])
+    c = vp.Circuit.custom(*args)
+    oc = ob.Circuit.custom(*args)
+    assert c.hash() == oc.hash()
+    tr, st = oc.prove_gkr()
+    assert st["verified"] == 1
+    assert c.verify_transcript(tr)          # host verifier (incl. assert-gate predicate) accepts the oracle's proof
+    c.close(); oc.close()

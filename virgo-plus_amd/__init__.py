@@ -116,6 +116,8 @@ def lib_host():
         L.vph_circuit_from_pws.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_long, ctypes.c_char_p, ctypes.c_int]
         L.vph_circuit_randomize.restype = vp
         L.vph_circuit_randomize.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_long]
+        L.vph_circuit_custom.restype = vp
+        L.vph_circuit_custom.argtypes = [ctypes.c_int] + [vp] * 7
         L.vph_circuit_free.argtypes = [vp]
         L.vph_circuit_layers.argtypes = [vp]
         L.vph_circuit_gates.restype = u64
@@ -164,6 +166,15 @@ class Circuit:
     @classmethod
     def randomize(cls, layers, log_size, seed=-1):
         return cls(lib_host().vph_circuit_randomize(layers, log_size, seed))
+
+    @classmethod
+    def custom(cls, layer_sizes, ty, l, u, v, c_pairs, is_assert):
+        """Arbitrary layered circuit from flat numpy arrays (see vphost.h)."""
+        import numpy as np
+        a = [np.ascontiguousarray(layer_sizes, np.uint64), np.ascontiguousarray(ty, np.int32), np.ascontiguousarray(l, np.int32),
+             np.ascontiguousarray(u, np.uint64), np.ascontiguousarray(v, np.uint64), np.ascontiguousarray(c_pairs, np.uint64),
+             np.ascontiguousarray(is_assert, np.uint8)]
+        return cls(lib_host().vph_circuit_custom(len(a[0]), *[x.ctypes.data for x in a]))
 
     @property
     def layers(self):

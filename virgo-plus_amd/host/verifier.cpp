@@ -120,7 +120,7 @@ bool verifier::verifyPhase1(int layer_id, F &previousSum) {      // verifier.cpp
     const layer &pre = C.circuit[layer_id - 1];
     for (auto &x : r_u) x = draw();
     F previousRandom = F_ZERO;
-    const F assert_random = draw();
+    assert_random = draw();
     if (!replay) p->sumcheckInitPhase1(assert_random);
     for (int j = 0; j < pre.bitLength; ++j) {
         const quadratic_poly poly = nextPoly(1, previousRandom);
@@ -201,6 +201,7 @@ bool verifier::verifyLiu(int layer_id, F &previousSum) {         // verifier.cpp
 void verifier::predicatePhase1(int layer_id) {                   // verifier.cpp:50-56,63-90
     const layer &cur = C.circuit[layer_id];
     initBetaTable(beta_g, cur.bitLength, r_liu.begin(), F_ONE);
+    for (u64 g = 0; g < cur.size; ++g) if (cur.gates[g].is_assert) beta_g[g] *= assert_random;        // verifier.cpp:53-54
     initBetaTable(beta_u, C.circuit[layer_id - 1].bitLength, r_u.begin(), F_ONE);
     for (int t : {(int) Copy, (int) Not, (int) Addc, (int) Mulc}) coeff_l[t] = F_ZERO;
     bias = F_ZERO;

@@ -57,7 +57,7 @@ private:
     std::vector<std::vector<F>> r_v;
     F coeff_l[(int) gateType::SIZE];
     std::vector<F> coeff_r[(int) gateType::SIZE];
-    F bias, final_claim_u;
+    F bias, final_claim_u, assert_random;
     std::vector<std::vector<F>> final_claims_v;
     timer verify_timer;
 };

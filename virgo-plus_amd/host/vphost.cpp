@@ -40,6 +40,27 @@ vph_circuit *vph_circuit_randomize(int layers, int log_size, long seed) {
     vc->c.subsetInit();
     return vc;
 }
+vph_circuit *vph_circuit_custom(int n_layers, const uint64_t *layer_sizes, const int32_t *ty, const int32_t *l, const uint64_t *u,
+                                const uint64_t *v, const uint64_t *c_pairs, const uint8_t *is_assert) {
+    vph_circuit *vc = new vph_circuit();
+    layeredCircuit &c = vc->c;
+    c.size = n_layers;
+    c.circuit.resize(n_layers);
+    u64 at = 0;
+    for (int i = 0; i < n_layers; ++i) {
+        layer &L = c.circuit[i];
+        L.size = layer_sizes[i];
+        L.bitLength = 0;
+        while ((1ull << L.bitLength) < L.size) ++L.bitLength;
+        L.gates.resize(L.size);
+        for (u64 g = 0; g < L.size; ++g, ++at) {
+            F cc; cc.real = c_pairs[2 * at]; cc.img = c_pairs[2 * at + 1];
+            L.gates[g] = gate((gateType) ty[at], l[at], u[at], v[at], cc, is_assert[at] != 0);
+        }
+    }
+    c.subsetInit();
+    return vc;
+}
 void vph_circuit_free(vph_circuit *c) { delete c; }
 int vph_circuit_layers(const vph_circuit *c) { return c->c.size; }
 uint64_t vph_circuit_gates(const vph_circuit *c) { u64 n = 0; for (auto &l : c->c.circuit) n += l.size; return n; }

@@ -29,6 +29,9 @@ typedef struct {
  * else srandom(seed) before the witness is drawn (src/main.cpp:188).                                 */
 vph_circuit *vph_circuit_from_pws(const char *path, int blocks, long seed, char *err, int errlen);
 vph_circuit *vph_circuit_randomize(int layers, int log_size, long seed);
+/* Arbitrary layered circuit from flat arrays (all gate types of enum gateType, constants, assert gates); subsetInit runs. */
+vph_circuit *vph_circuit_custom(int n_layers, const uint64_t *layer_sizes, const int32_t *ty, const int32_t *l, const uint64_t *u,
+                                const uint64_t *v, const uint64_t *c_pairs, const uint8_t *is_assert);
 void vph_circuit_free(vph_circuit *);
 int vph_circuit_layers(const vph_circuit *);
 uint64_t vph_circuit_gates(const vph_circuit *);
