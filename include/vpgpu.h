@@ -136,6 +136,11 @@ int vp_fri_step(vp_ctx *, const vp_F *r, uint8_t root[32]);
 /* fri::commit_phase_final() (fri.cpp:426-431): the last codeword, 2048 elements in the reference's interleaved
  * layout [i << 7 | slice << 1 | hi], i < 16.                                                            */
 int vp_fri_final(vp_ctx *, vp_F *final_code);
+/* fri::request_init_value_with_merkle (fri.cpp:148-205; oracle 0 = l, 1 = h) and fri::request_step_commit
+ * (fri.cpp:229-287; oracle 2 + level): open leaf `leaf` of a committed oracle.  values: 65 pairs (64 slices, then the
+ * mask pair) = the two codeword entries of the leaf per slice; path: depth+1 digests, path[k] = sibling at height k,
+ * path[depth] = the leaf digest (the reference's com_hhash layout).  *path_len receives depth + 1.           */
+int vp_fri_open(vp_ctx *, int oracle, uint64_t leaf, vp_F values[130], uint8_t *path, int path_capacity, int *path_len);
 /* Device time of the last vp_commit_private / vp_commit_public / vp_fri_step in milliseconds (hipEvents). */
 int vp_commit_stats(vp_ctx *, double *commit_ms);
 

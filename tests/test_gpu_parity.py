@@ -408,3 +408,41 @@ def test_all_gate_types_full_protocol_vs_reference(vp, golden, name):
     roots, fin = s.fri_commit(r)
     assert roots == roots_gold and np.array_equal(fin, fin_gold)
     s.close(); c.close()
+
+
+@pytest.mark.parametrize("name,blocks", [("sha256_x1", 1), ("sha256_x16", 16)])
+def test_complete_protocol_with_commitment_verification(vp, golden, pws_path, name, blocks):
+    """verifier::verify() end to end (src/verifier.cpp:134-189): commit_private, interactive GKR, commit_public, FRI
+    commit phase, 33 query repetitions answered by vp_fri_open and checked by the host verifier.  The transcript up to
+    all_sum is the real reference's; the FRI part uses fresh challenges (the reference's come after its fft_gkr draws)."""
+    import os
+    from conftest import GOLDEN
+    c = vp.Circuit.from_pws(pws_path, blocks, seed=1)
+    s = vp.Session(c)
+    tr, ok, times = s.prove_and_verify_full(reps=33)
+    assert ok
+    assert tr == open(os.path.join(GOLDEN, golden[name]["transcript"]), "rb").read()
+    s.close(); c.close()
+
+
+def test_complete_protocol_custom_gates(vp, golden):
+    import os
+    import custom_circuits as cc
+    from conftest import GOLDEN
+    g = golden["custom_b"]
+    c = vp.Circuit.custom(*cc.make(g["custom"]["seed"], g["custom"]["sizes"]))
+    s = vp.Session(c)
+    tr, ok, _ = s.prove_and_verify_full(reps=8)
+    assert ok and tr == open(os.path.join(GOLDEN, g["transcript"]), "rb").read()
+    s.close(); c.close()
+
+
+def test_cli_runs_the_reference_flow(vp, pws_path):
+    """virgo_plus_run <file.pws> (the reference's command line, script/run.sh:11): whole protocol on the GPU, the
+    reference's result lines on stdout."""
+    import subprocess
+    out = subprocess.run([vp.CLI, pws_path], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert "Verification pass" in out.stderr
+    for key in ("Input size 7226", "Prove Time", "verify time", "proof size", "Polynomial commitment: prove time"):
+        assert key in out.stdout

@@ -105,3 +105,16 @@ def test_custom_circuit_structures_agree(vp, ob):
     assert st["verified"] == 1
     assert c.verify_transcript(tr)          # host verifier (incl. assert-gate predicate) accepts the oracle's proof
     c.close(); oc.close()
+
+
+def test_host_sha3_is_fips202(vp):
+    import hashlib
+    import numpy as np
+    rng = np.random.default_rng(12)
+    n = 200
+    msgs = rng.integers(0, 256, size=(n, 64), dtype=np.uint8)
+    msgs[0] = 0
+    out = np.zeros((n, 32), dtype=np.uint8)
+    vp.lib_host().vph_test_sha3(msgs.ctypes.data, out.ctypes.data, n)
+    for i in range(n):
+        assert out[i].tobytes() == hashlib.sha3_256(msgs[i].tobytes()).digest()

@@ -139,6 +139,8 @@ def lib_host():
         L.vph_verify_transcript.argtypes = [vp, vp, u64, ctypes.c_int]
         L.vph_commit_public.argtypes = [vp, vp, u64, vp, ctypes.POINTER(ctypes.c_double), ctypes.c_char_p, ctypes.c_int]
         L.vph_prove_full.argtypes = [vp, vp, u64, ctypes.POINTER(u64), ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
+        L.vph_prove_and_verify_full.argtypes = [vp, ctypes.c_int, vp, u64, ctypes.POINTER(u64)] + [ctypes.POINTER(ctypes.c_double)] * 3 + [ctypes.c_char_p, ctypes.c_int]
+        L.vph_test_sha3.argtypes = [vp, vp, u64]
         L.vph_fri_commit.argtypes = [vp, vp, ctypes.c_int, vp, vp, ctypes.c_char_p, ctypes.c_int]
         L.vph_commit_private.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_double), ctypes.c_char_p, ctypes.c_int]
         L.vph_transcript_bytes.restype = u64
@@ -286,6 +288,19 @@ class Session:
         if rc < 0:
             raise RuntimeError("prove_full failed: " + err.value.decode())
         return buf.raw[: n.value], rc == 0
+
+    def prove_and_verify_full(self, reps=33):
+        """The complete protocol incl. commitment verification: (transcript bytes, accepted, times dict)."""
+        cap = self._cap + 32 + 32 + 16 + 65 * 16
+        buf = ctypes.create_string_buffer(cap)
+        n = ctypes.c_uint64(0)
+        t = [ctypes.c_double(0) for _ in range(3)]
+        err = ctypes.create_string_buffer(512)
+        rc = lib_host().vph_prove_and_verify_full(self.h, reps, ctypes.cast(buf, ctypes.c_void_p), cap, ctypes.byref(n),
+                                                  ctypes.byref(t[0]), ctypes.byref(t[1]), ctypes.byref(t[2]), err, len(err))
+        if rc < 0:
+            raise RuntimeError("prove_and_verify_full failed: " + err.value.decode())
+        return buf.raw[: n.value], rc == 0, {"gkr_prove_sec": t[0].value, "pc_prove_sec": t[1].value, "verify_sec": t[2].value}
 
     def fri_commit(self, r):
         """FRI commit phase with the given fold challenges ((steps, 2) uint64): (roots bytes, final codeword (2048, 2))."""

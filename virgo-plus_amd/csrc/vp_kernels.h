@@ -678,8 +678,8 @@ __device__ __forceinline__ void sf_pairs(F (&x)[8], int s, int lane, F (&lo)[4],
     }
 }
 
-template <int R>
-__global__ void __launch_bounds__(VP_BLOCK) k_sumfold(SfArgs a) {
+template <int R, int MINW>
+__global__ void __launch_bounds__(VP_BLOCK, MINW) k_sumfold(SfArgs a) {
     constexpr int G = 1 << R;
     __shared__ F lds[4 * 3 * R];
     const int lane = threadIdx.x & 63;
@@ -722,15 +722,18 @@ __global__ void __launch_bounds__(VP_BLOCK) k_sumfold(SfArgs a) {
             for (int q = 0; q < 4; ++q) {
                 if (q >= n2) break;
                 const F dm = f_sub(mh[q], ml[q]), dv = f_sub(vh[q], vl[q]);
-                const F qa = f_mul(dm, dv), qc = f_mul(ml[q], vl[q]), qe = f_mul(mh[q], vh[q]);
-                F lin = f_sub(f_sub(qe, qa), qc), cst = qc;
-                if (a.has_a) { lin = f_add(lin, f_sub(ah[q], al[q])); cst = f_add(cst, al[q]); }
-                acc[3 * s] = f_add(acc[3 * s], qa);
-                acc[3 * s + 1] = f_add(acc[3 * s + 1], lin);
-                acc[3 * s + 2] = f_add(acc[3 * s + 2], cst);
+                // X += dm*dv, Y += m1*v1 + a1, Z += m0*v0 + a0: the round polynomial is (X, Y - X - Z, Z), combined once
+                // per block instead of per pair
+                acc[3 * s] = f_add(acc[3 * s], f_mul(dm, dv));
+                F e1 = f_mul(mh[q], vh[q]), e0 = f_mul(ml[q], vl[q]);
+                if (a.has_a) {
+                    e1 = f_add(e1, ah[q]); e0 = f_add(e0, al[q]);
+                    ad[q] = f_lerp(al[q], ah[q], rr[s]);
+                }
+                acc[3 * s + 1] = f_add(acc[3 * s + 1], e1);
+                acc[3 * s + 2] = f_add(acc[3 * s + 2], e0);
                 v[q] = f_add(vl[q], f_mul(rr[s], dv));
                 m[q] = f_add(ml[q], f_mul(rr[s], dm));
-                if (a.has_a) ad[q] = f_lerp(al[q], ah[q], rr[s]);
             }
         }
         const u32 oi = cl * 64 + o_fin;                    // element of the folded table
@@ -750,11 +753,14 @@ __global__ void __launch_bounds__(VP_BLOCK) k_sumfold(SfArgs a) {
         for (int i = 0; i < 3 * R; ++i) lds[w * 3 * R + i] = acc[i];
     }
     __syncthreads();
-    if (threadIdx.x < 3 * R) {
-        const int i = threadIdx.x;
-        F s = lds[i];
-        for (int k = 1; k < (int) (blockDim.x >> 6); ++k) s = f_add(s, lds[k * 3 * R + i]);
-        a.part[(size_t) (i / 3) * a.part_stride + blockIdx.x * 3 + (i % 3)] = s;
+    if (threadIdx.x < R) {
+        const int s = threadIdx.x;
+        F X = lds[3 * s], Y = lds[3 * s + 1], Z = lds[3 * s + 2];
+        for (int k = 1; k < (int) (blockDim.x >> 6); ++k) {
+            X = f_add(X, lds[k * 3 * R + 3 * s]); Y = f_add(Y, lds[k * 3 * R + 3 * s + 1]); Z = f_add(Z, lds[k * 3 * R + 3 * s + 2]);
+        }
+        F *o = a.part + (size_t) s * a.part_stride + blockIdx.x * 3;
+        o[0] = X; o[1] = f_sub(f_sub(Y, X), Z); o[2] = Z;
     }
 }
 
@@ -1555,4 +1561,30 @@ k_ntt_unsplit(const F *__restrict__ in, F *__restrict__ out, int ln, int l1, F s
     }
 }
 
+}  // namespace vp
+
+// ---- openings (fri::request_init_value_with_merkle, fri.cpp:148-205; fri::request_step_commit, :229-287) ----
+namespace vp {
+// One leaf of a committed oracle: the 64 slice pairs + the (zero) mask pair, and the Merkle path from the leaf up.
+// Coset-major codeword with Nc values per coset: leaf i = 32a + b holds (cw[s][b][a], cw[s][b][a + Nc/2]); for Nc == 1
+// (last FRI level) leaf j < 16 holds (cw[s][j], cw[s][j + 16]).
+__global__ void k_pc_open(const F *__restrict__ cw, u32 Nc, const Dig *__restrict__ tree, u32 n_leaves, u32 leaf,
+                          F *__restrict__ vals /* 65*2 */, Dig *__restrict__ path /* depth+1 */) {
+    const u32 t = threadIdx.x;
+    if (t < 64) {
+        F x, y;
+        if (Nc >= 2) { const u32 a = leaf >> 5, b = leaf & 31; const F *row = cw + ((size_t) t * 32 + b) * Nc; x = row[a]; y = row[a + (Nc >> 1)]; }
+        else { x = cw[(size_t) t * 32 + leaf]; y = cw[(size_t) t * 32 + leaf + 16]; }
+        vals[2 * t] = x; vals[2 * t + 1] = y;
+    } else if (t == 64) {
+        vals[128] = f_zero(); vals[129] = f_zero();
+    }
+    // path[k] = sibling at height k (k < depth), path[depth] = the leaf digest itself (the reference's com_hhash layout)
+    u32 depth = 0;
+    while ((1u << depth) < n_leaves) ++depth;
+    if (t <= depth) {
+        if (t == depth) path[t] = tree[n_leaves + leaf];
+        else path[t] = tree[((n_leaves + leaf) >> t) ^ 1];
+    }
+}
 }  // namespace vp

@@ -100,6 +100,7 @@ struct vp_ctx {
     F *pc_rt = nullptr, *pc_coef = nullptr, *pc_cw = nullptr; Dig *pc_tree = nullptr; int pc_lm = -1; double commit_ms = 0;
     F *pc_pub = nullptr, *pc_qcw = nullptr, *pc_hcw = nullptr, *pc_tmp = nullptr, *pc_small = nullptr; Dig *pc_tree_h = nullptr; bool pc_private_done = false;
     F *pc_scr = nullptr; size_t pc_scr_cap = 0;
+    F *pc_fri_all = nullptr; std::vector<size_t> fri_cw_off, fri_tree_off; F *pc_open_buf = nullptr;
     F *pc_fri[2] = {nullptr, nullptr}; Dig *pc_fri_tree = nullptr; int fri_step = -1; size_t fri_tree_used = 0; bool pc_public_done = false;
 
     F *part2 = nullptr;                  // [32][MAX_BLOCKS*3] block partials of the batched path
@@ -435,7 +436,7 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
     ctx->chunk_cap = 0;
     ctx->pc_rt = ctx->pc_coef = ctx->pc_cw = nullptr; ctx->pc_tree = nullptr; ctx->pc_lm = -1;
     ctx->pc_pub = ctx->pc_qcw = ctx->pc_hcw = ctx->pc_tmp = ctx->pc_small = nullptr; ctx->pc_tree_h = nullptr; ctx->pc_private_done = false;
-    ctx->pc_scr = nullptr; ctx->pc_scr_cap = 0;
+    ctx->pc_scr = nullptr; ctx->pc_scr_cap = 0; ctx->pc_fri_all = nullptr; ctx->pc_open_buf = nullptr; ctx->fri_cw_off.clear(); ctx->fri_tree_off.clear();
     ctx->pc_fri[0] = ctx->pc_fri[1] = nullptr; ctx->pc_fri_tree = nullptr; ctx->fri_step = -1; ctx->pc_public_done = false;
     int max_bl = 0;
     for (int i = 0; i < n_layers; ++i) {
@@ -933,7 +934,10 @@ inline int ilog2(u32 x) { int b = 0; while ((1u << (b + 1)) <= x) ++b; return b;
 
 template <int R>
 void launch_sumfold(vp_ctx *ctx, const SfArgs &a, u32 grid) {
-    hipLaunchKernelGGL(k_sumfold<R>, dim3(grid), dim3(VP_BLOCK), 0, ctx->ln->stream, a);
+    static const int minw = getenv("VP_SF_MINW") ? atoi(getenv("VP_SF_MINW")) : 1;
+    if (minw >= 3) hipLaunchKernelGGL((k_sumfold<R, 3>), dim3(grid), dim3(VP_BLOCK), 0, ctx->ln->stream, a);
+    else if (minw == 2) hipLaunchKernelGGL((k_sumfold<R, 2>), dim3(grid), dim3(VP_BLOCK), 0, ctx->ln->stream, a);
+    else hipLaunchKernelGGL((k_sumfold<R, 1>), dim3(grid), dim3(VP_BLOCK), 0, ctx->ln->stream, a);
 }
 
 int run_sumcheck_fused(vp_ctx *ctx, const FusedSumcheck &sc) {
@@ -1433,9 +1437,8 @@ int vp_fri_step(vp_ctx *ctx, const vp_F *r, uint8_t root[32]) {
     HIPCHK(hipSetDevice(ctx->device));
     const int n = ctx->L[0].bl, ln = n - 6, lm = n - 1;
     const u32 N = 1u << ln, M = 1u << lm;
-    if (!ctx->pc_fri[0]) {
-        VPCHK(dalloc(ctx, &ctx->pc_fri[0], (size_t) 64 * (M / 2)));
-        VPCHK(dalloc(ctx, &ctx->pc_fri[1], (size_t) 64 * std::max<u32>(M / 4, 32)));
+    if (!ctx->pc_fri_all) {
+        VPCHK(dalloc(ctx, &ctx->pc_fri_all, (size_t) 64 * M));            // every level's codeword is kept for the openings
         VPCHK(dalloc(ctx, &ctx->pc_fri_tree, (size_t) M));
     }
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
@@ -1444,12 +1447,17 @@ int vp_fri_step(vp_ctx *ctx, const vp_F *r, uint8_t root[32]) {
         hipLaunchKernelGGL(k_pc_virtual_oracle, dim3(nblk((u64) 64 * M)), dim3(VP_BLOCK), 0, ctx->stream, ctx->pc_cw, ctx->pc_qcw,
                            ctx->pc_hcw, ctx->pc_small + 1025 + 80, N, ctx->pc_rt, M >> 1, f_make(N, 0));
         ctx->fri_step = 0; ctx->fri_tree_used = 0;
+        ctx->fri_cw_off.clear(); ctx->fri_tree_off.clear();
     }
     const int k = ctx->fri_step;
     if (k >= ln) { ctx->err = "FRI commit phase already finished"; return VP_EINVAL; }
     const u32 Nk = N >> k, No = Nk >> 1;
-    const F *in = k == 0 ? ctx->pc_qcw : ctx->pc_fri[(k - 1) & 1];
-    F *out = ctx->pc_fri[k & 1];
+    size_t cw_off = 0;
+    for (int q = 0; q < k; ++q) cw_off += (size_t) 64 * 32 * (N >> (q + 1));
+    const F *in = k == 0 ? ctx->pc_qcw : ctx->pc_fri_all + ctx->fri_cw_off[k - 1];
+    F *out = ctx->pc_fri_all + cw_off;
+    ctx->fri_cw_off.push_back(cw_off);
+    ctx->fri_tree_off.push_back(ctx->fri_tree_used);
     F rf; memcpy(&rf, r, sizeof(F));
     hipLaunchKernelGGL(k_fri_fold, dim3(nblk((u64) 64 * 32 * No)), dim3(VP_BLOCK), 0, ctx->stream, in, out, Nk, k, ctx->pc_rt, M >> 1, rf,
                        host_inv_real(2));
@@ -1476,9 +1484,36 @@ int vp_fri_final(vp_ctx *ctx, vp_F *final_code) {
     if (ctx->fri_step != ln) { ctx->err = "FRI commit phase not finished"; return VP_EINVAL; }
     HIPCHK(hipSetDevice(ctx->device));
     std::vector<F> cw(64 * 32);
-    HIPCHK(hipMemcpy(cw.data(), ctx->pc_fri[(ln - 1) & 1], cw.size() * sizeof(F), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(cw.data(), ctx->pc_fri_all + ctx->fri_cw_off[ln - 1], cw.size() * sizeof(F), hipMemcpyDeviceToHost));
     F *o = reinterpret_cast<F *>(final_code);
     for (u32 i = 0; i < 16; ++i) for (u32 s = 0; s < 64; ++s) for (u32 hi = 0; hi < 2; ++hi) o[(i << 7) | (s << 1) | hi] = cw[s * 32 + i + 16 * hi];
+    return VP_OK;
+}
+
+int vp_fri_open(vp_ctx *ctx, int oracle, uint64_t leaf, vp_F values[130], uint8_t *path, int path_capacity, int *path_len) {
+    if (!ctx || !values || !path || !path_len || oracle < 0) return VP_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int n = ctx->L[0].bl, ln = n - 6, lm = n - 1;
+    const u32 N = 1u << ln, M = 1u << lm;
+    const F *cw; const Dig *tree; u32 Nc, n_leaves;
+    if (oracle == 0) { if (!ctx->pc_private_done) return VP_EINVAL; cw = ctx->pc_cw; tree = ctx->pc_tree; Nc = N; n_leaves = M >> 1; }
+    else if (oracle == 1) { if (!ctx->pc_public_done) return VP_EINVAL; cw = ctx->pc_hcw; tree = ctx->pc_tree_h; Nc = N; n_leaves = M >> 1; }
+    else {
+        const int lvl = oracle - 2;
+        if (lvl >= ctx->fri_step || lvl >= (int) ctx->fri_cw_off.size()) { ctx->err = "FRI level not committed yet"; return VP_EINVAL; }
+        cw = ctx->pc_fri_all + ctx->fri_cw_off[lvl]; tree = ctx->pc_fri_tree + ctx->fri_tree_off[lvl];
+        Nc = N >> (lvl + 1); n_leaves = 16 * Nc;
+    }
+    if (leaf >= n_leaves) return VP_EINVAL;
+    int depth = 0; while ((1u << depth) < n_leaves) ++depth;
+    if (path_capacity < 32 * (depth + 1)) return VP_EINVAL;
+    if (!ctx->pc_open_buf) VPCHK(dalloc(ctx, &ctx->pc_open_buf, (size_t) 130 + 2 * 40));
+    Dig *dpath = reinterpret_cast<Dig *>(ctx->pc_open_buf + 130);
+    hipLaunchKernelGGL(k_pc_open, dim3(1), dim3(128), 0, ctx->stream, cw, Nc, tree, n_leaves, (u32) leaf, ctx->pc_open_buf, dpath);
+    HIPCHK(hipMemcpyAsync(values, ctx->pc_open_buf, 130 * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(path, dpath, 32 * (size_t) (depth + 1), hipMemcpyDeviceToHost, ctx->stream));
+    VPCHK(check_stream(ctx));
+    *path_len = depth + 1;
     return VP_OK;
 }
 

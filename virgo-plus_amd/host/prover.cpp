@@ -169,6 +169,23 @@ prover::hhash_digest prover::commit_public(std::vector<F> &pub, F &inner_product
     check(vp_commit_public(ctx, cF(pub.data()), pub.size(), mF(&inner_product_sum), mF(all_sum.data()), d.b), "vp_commit_public");
     return d;
 }
+prover::hhash_digest prover::friStep(const F &r) {
+    hhash_digest d;
+    check(vp_fri_step(ctx, cF(&r), d.b), "vp_fri_step");
+    return d;
+}
+std::vector<F> prover::friFinal() {
+    std::vector<F> out(2048);
+    check(vp_fri_final(ctx, mF(out.data())), "vp_fri_final");
+    return out;
+}
+void prover::friOpen(int oracle, u64 leaf, std::vector<F> &values, std::vector<hhash_digest> &path) {
+    values.resize(130);
+    path.resize(40);
+    int len = 0;
+    check(vp_fri_open(ctx, oracle, leaf, mF(values.data()), path[0].b, 40 * 32, &len), "vp_fri_open");
+    path.resize(len);
+}
 double prover::commitDeviceMs() { double ms = 0; check(vp_commit_stats(ctx, &ms), "vp_commit_stats"); return ms; }
 
 void prover::gkrSizes(u64 &n_tape, u64 &n_bytes) {

@@ -53,6 +53,11 @@ public:
     hhash_digest commit_private();                       // src/prover.cpp:524-530
     // src/prover.cpp:542-546 (the mask argument of the reference is the one-element zero vector and is implied)
     hhash_digest commit_public(std::vector<F> &pub, F &inner_product_sum, std::vector<F> &all_sum);
+    // poly_commit_prover::commit_phase pieces (vpd_verifier.cpp:44-74 -> fri::commit_phase_step / commit_phase_final)
+    hhash_digest friStep(const F &r);
+    std::vector<F> friFinal();                           // 2048 elements, reference layout [i << 7 | slice << 1 | hi]
+    // fri::request_init_value_with_merkle (oracle 0 = l, 1 = h) / fri::request_step_commit (oracle 2 + level)
+    void friOpen(int oracle, u64 leaf, std::vector<F> &values /* 130 */, std::vector<hhash_digest> &path);
     double commitDeviceMs();
 
     double proveTime() const { return prove_timer.elapse_sec(); }

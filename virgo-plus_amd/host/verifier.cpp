@@ -113,6 +113,8 @@ bool verifier::run() {                          // verifier.cpp:134-169 (GKR par
         }
         if (!verifyLiu(i, previousSum)) return false;
     }
+    last_claim = previousSum;
+    if (input_check_by_commitment) return true;      // verifyPoly checks the claim against the committed input instead
     return checkInput(previousSum);
 }
 
@@ -258,4 +260,181 @@ bool verifier::checkInput(const F &claim) {
     for (u64 g = 0; g < L0.size; ++g) acc = acc + beta[g] * F((long long) L0.gates[g].u);
     if (acc != claim) { fprintf(stderr, "Verification fail, final input check fail.\n"); return false; }
     return true;
+}
+
+// ====================================================================================================
+// Polynomial-commitment verification (reference: verifier::verifyPoly, src/verifier.cpp:348-389, and
+// poly_commit_verifier::verify_poly_commitment, lib/virgo/src/vpd_verifier.cpp:76-328).  Host C++: the verifier is
+// not a GPU target; the prover side of every step runs through the C ABI.
+// ====================================================================================================
+namespace {
+
+void host_fft(std::vector<F> &a, const F &root) {          // in place, natural order, a.size() = 2^k
+    const u64 n = a.size();
+    for (u64 i = 1, j = 0; i < n; ++i) {
+        u64 bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) std::swap(a[i], a[j]);
+    }
+    for (u64 len = 2; len <= n; len <<= 1) {
+        F wl = root;
+        for (u64 m = n; m > len; m >>= 1) wl = wl * wl;
+        for (u64 i = 0; i < n; i += len) {
+            F w = F_ONE;
+            for (u64 k = 0; k < len / 2; ++k) {
+                const F u = a[i + k], v = a[i + k + len / 2] * w;
+                a[i + k] = u + v;
+                a[i + k + len / 2] = u - v;
+                w = w * wl;
+            }
+        }
+    }
+}
+int log2u(u64 x) { int b = 0; while ((1ull << b) < x) ++b; return b; }
+vph::hhash_digest dig(const prover::hhash_digest &d) { vph::hhash_digest r; memcpy(r.w, d.b, 32); return r; }
+
+}  // namespace
+
+// Recompute the leaf chain from the opened values (fri.cpp:96-124) and walk the path to the root (vpd_verifier.cpp:9-40).
+bool verifier::checkOpening(const vph::hhash_digest &root, u64 leaf, const std::vector<F> &vals,
+                            const std::vector<prover::hhash_digest> &path) {
+    if (vals.size() != 130 || path.empty()) return false;
+    vph::hhash_digest h; memset(&h, 0, sizeof h);
+    for (int s = 0; s < 65; ++s) {
+        const uint64_t m[4] = {vals[2 * s].real, vals[2 * s].img, vals[2 * s + 1].real, vals[2 * s + 1].img};
+        h = vph::hhash(m, h);
+    }
+    const size_t depth = path.size() - 1;
+    if (h != dig(path[depth])) return false;
+    u64 pos = leaf;
+    for (size_t k = 0; k < depth; ++k) {
+        const vph::hhash_digest sib = dig(path[k]);
+        h = (pos & 1) ? vph::hhash(sib.w, h) : vph::hhash(h.w, sib);
+        pos >>= 1;
+    }
+    return h == root;
+}
+
+bool verifier::verifyPoly(const prover::hhash_digest &root_l_raw, const F &claim, int reps) {
+    const int n = C.circuit[0].bitLength;
+    if (n < 7) { fprintf(stderr, "commitment needs an input layer of at least 2^7 wires\n"); return false; }
+    const int ln = n - 6, lm = n - 1;
+    const u64 N = 1ull << ln, M = 1ull << lm;
+    const vph::hhash_digest root_l = dig(root_l_raw);
+    // public vector = eq(r_liu, .) over the input layer (verifier.cpp:368-369), and its slices in coefficient form
+    // (public_array_prepare_generic, verifier.cpp:348-361)
+    poly_timer.start();
+    std::vector<F> pub;
+    initBetaTable(pub, n, r_liu.begin(), F_ONE);
+    pub.resize(1ull << n);
+    std::vector<std::vector<F>> q_coef(64, std::vector<F>(N));
+    {
+        const F inv_root = F::getRootOfUnity(ln).inv();
+        const F inv_n = F::fastPow(F((long long) N), (unsigned __int128) F::mod - 2);
+        for (int j = 0; j < 64; ++j) {
+            std::vector<F> a(pub.begin() + j * N, pub.begin() + (j + 1) * N);
+            host_fft(a, inv_root);
+            for (u64 k = 0; k < N; ++k) q_coef[j][k] = a[k] * inv_n;
+        }
+    }
+    poly_timer.stop();
+    // prover: second oracle
+    poly_prove_timer.start();
+    F input_0;
+    std::vector<F> all_sum;
+    const prover::hhash_digest root_h_raw = p->commit_public(pub, input_0, all_sum);
+    poly_prove_timer.stop();
+    full_tr.insert(full_tr.end(), root_h_raw.b, root_h_raw.b + 32);
+    { const uint8_t *b = reinterpret_cast<const uint8_t *>(&input_0); full_tr.insert(full_tr.end(), b, b + 16); }
+    { const uint8_t *b = reinterpret_cast<const uint8_t *>(all_sum.data()); full_tr.insert(full_tr.end(), b, b + 65 * 16); }
+    const vph::hhash_digest root_h = dig(root_h_raw);
+    poly_timer.start();
+    if (claim != input_0) { fprintf(stderr, "Verification fail, final input check fail.\n"); return false; }   // verifier.cpp:383
+    {   // the slice sums must add up to the claimed inner product
+        F s = F_ZERO;
+        for (int j = 0; j < 65; ++j) s = s + all_sum[j];
+        if (s != input_0) { fprintf(stderr, "commitment: slice sums do not match the inner product\n"); return false; }
+    }
+    poly_timer.stop();
+    // FRI commit phase (vpd_verifier.cpp:44-74): the fold challenges are drawn here
+    std::vector<F> fr(ln);
+    std::vector<vph::hhash_digest> roots(ln);
+    poly_prove_timer.start();
+    for (int k = 0; k < ln; ++k) { fr[k] = F::random(); roots[k] = dig(p->friStep(fr[k])); }
+    const std::vector<F> final_code = p->friFinal();
+    poly_prove_timer.stop();
+    poly_timer.start();
+    // the last codeword must be constant on its 32-point domain, per slice (vpd_verifier.cpp:309-324)
+    std::vector<F> final_val(64);
+    for (int s = 0; s < 64; ++s) {
+        final_val[s] = final_code[(0 << 7) | (s << 1) | 0];
+        for (int i = 0; i < 16; ++i)
+            for (int hi = 0; hi < 2; ++hi)
+                if (final_code[(i << 7) | (s << 1) | hi] != final_val[s]) { fprintf(stderr, "Fri rs code check fail\n"); return false; }
+    }
+    const F w = F::getRootOfUnity(lm), inv2 = F(2ll).inv(), Nf((long long) N);
+    std::vector<F> vl, vh, vb;
+    std::vector<prover::hhash_digest> pl, ph, pb;
+    for (int rep = 0; rep < reps; ++rep) {
+        // query point x0 = w^(pow/2), pow even in [N, M) (vpd_verifier.cpp:119-123)
+        u64 pw;
+        do { pw = (u64) rand() % M; } while (pw < N || (pw & 1));
+        const u64 s0 = pw / 2;                                   // leaf of the two first oracles; x1 = -x0 sits in the same leaf
+        poly_timer.stop(); poly_prove_timer.start();
+        p->friOpen(0, s0, vl, pl);
+        p->friOpen(1, s0, vh, ph);
+        poly_prove_timer.stop(); poly_timer.start();
+        if (!checkOpening(root_l, s0, vl, pl) || !checkOpening(root_h, s0, vh, ph)) { fprintf(stderr, "commitment: Merkle opening rejected\n"); return false; }
+        const F x0 = F::fastPow(w, s0), x1 = F_ZERO - x0;
+        const F x0n = F::fastPow(x0, N), x1n = F::fastPow(x1, N);
+        const F inv_x0 = x0.inv(), inv_x1 = F_ZERO - inv_x0;
+        // virtual oracle values at x0 and x1 for every slice (poly_commit.h:301-318 on the prover side)
+        std::vector<F> cur0(64), cur1(64);
+        for (int j = 0; j < 64; ++j) {
+            F q0 = F_ZERO, q1 = F_ZERO;                          // q_j(x) by Horner from the coefficient form
+            for (u64 k = N; k-- > 0;) { q0 = q0 * x0 + q_coef[j][k]; q1 = q1 * x1 + q_coef[j][k]; }
+            cur0[j] = ((vl[2 * j] * q0 - (x0n - F_ONE) * vh[2 * j]) * Nf - all_sum[j]) * inv_x0;
+            cur1[j] = ((vl[2 * j + 1] * q1 - (x1n - F_ONE) * vh[2 * j + 1]) * Nf - all_sum[j]) * inv_x1;
+        }
+        // fold consistency level by level (vpd_verifier.cpp:167-306)
+        u64 D = M;                                               // domain size of the codeword cur0/cur1 come from
+        u64 t = s0;                                              // cur0 is its value at index t, cur1 at t + D/2
+        for (int k = 0; k < ln; ++k) {
+            const F inv_mu = F::fastPow(F::fastPow(w, 1ull << k), t).inv();      // (w_D^t)^-1, w_D = w^(2^k)
+            const u64 Dn = D / 2;                                // next domain size; the folded value sits at index t
+            const u64 leaf = t % (Dn / 2);
+            poly_timer.stop(); poly_prove_timer.start();
+            p->friOpen(2 + k, leaf, vb, pb);
+            poly_prove_timer.stop(); poly_timer.start();
+            if (!checkOpening(roots[k], leaf, vb, pb)) { fprintf(stderr, "commitment: FRI Merkle opening rejected (level %d)\n", k); return false; }
+            const bool upper = t >= Dn / 2;
+            for (int j = 0; j < 64; ++j) {
+                const F expect = inv2 * ((cur0[j] + cur1[j]) + inv_mu * fr[k] * (cur0[j] - cur1[j]));
+                if (expect != vb[2 * j + (upper ? 1 : 0)]) { fprintf(stderr, "Fri check consistency %d round fail\n", k); return false; }
+                cur0[j] = vb[2 * j]; cur1[j] = vb[2 * j + 1];
+            }
+            D = Dn; t = leaf;
+        }
+        for (int j = 0; j < 64; ++j)
+            if (cur0[j] != final_val[j] || cur1[j] != final_val[j]) { fprintf(stderr, "Fri final codeword mismatch\n"); return false; }
+    }
+    poly_timer.stop();
+    return true;
+}
+
+bool verifier::verifyFull(int reps) {
+    if (!p) throw std::runtime_error("verifyFull(): no prover attached");
+    full_tr.clear();
+    poly_prove_timer.start();
+    const prover::hhash_digest root_l = p->commit_private();               // verifier.cpp:137
+    poly_prove_timer.stop();
+    full_tr.insert(full_tr.end(), root_l.b, root_l.b + 32);
+    replay = false; tape_.clear(); tr.clear();
+    input_check_by_commitment = true;
+    const bool ok = run();
+    input_check_by_commitment = false;
+    full_tr.insert(full_tr.end(), tr.begin(), tr.end());
+    if (!ok) return false;
+    return verifyPoly(root_l, last_claim, reps);
 }

@@ -13,12 +13,20 @@
 #include "circuit.hpp"
 #include "polynomial.hpp"
 #include "prover.hpp"
+#include "sha3.hpp"
 
 class verifier {
 public:
     verifier(prover *pr, const layeredCircuit &cir);
 
-    bool verify();                                              // interactive (needs pr != nullptr)
+    bool verify();                                              // interactive GKR (needs pr != nullptr)
+    // The complete protocol of the reference's verifier::verify() (src/verifier.cpp:134-189): commit_private, GKR,
+    // verifyPoly = commit_public + FRI commit phase + `reps` query repetitions (vpd_verifier.cpp:76-328; the
+    // reference hard-codes 33).  fullTranscript() is then merkle_root_l | GKR | merkle_root_h | input_0 | all_sum[65].
+    bool verifyFull(int reps = 33);
+    const std::vector<uint8_t> &fullTranscript() const { return full_tr; }
+    double polyVerifyTime() const { return poly_timer.elapse_sec(); }
+    double polyProveTime() const { return poly_prove_timer.elapse_sec(); }
     std::vector<F> drawTape();                                  // the verifier's draws, in its own order
     bool check(const std::vector<F> &tape, const std::vector<uint8_t> &transcript);   // replay
 
@@ -37,6 +45,8 @@ private:
     void predicatePhase2(int layer_id);
     F getFinalValue(int layer_id, const F &claim_u, const std::vector<F> &claim_v);
     bool checkInput(const F &claim);
+    bool verifyPoly(const prover::hhash_digest &root_l, const F &claim, int reps);
+    bool checkOpening(const vph::hhash_digest &root, u64 leaf, const std::vector<F> &vals, const std::vector<prover::hhash_digest> &path);
 
     F draw();
     quadratic_poly nextPoly(int phase, const F &prev);
@@ -59,7 +69,10 @@ private:
     std::vector<F> coeff_r[(int) gateType::SIZE];
     F bias, final_claim_u, assert_random;
     std::vector<std::vector<F>> final_claims_v;
-    timer verify_timer;
+    timer verify_timer, poly_timer, poly_prove_timer;
+    std::vector<uint8_t> full_tr;
+    bool input_check_by_commitment = false;
+    F last_claim;
 };
 
 // eq table (reference: src/utils.cpp:29-45), host version used by the verifier only

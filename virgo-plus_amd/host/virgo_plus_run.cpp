@@ -1,7 +1,7 @@
 // Command-line driver with the reference's interface (src/main.cpp:145-159):
 //     virgo_plus_run <file.pws> [--blocks B] [--batched] [--device D] [--dump transcript.bin]
 // Loads the circuit, runs the GKR proof on the GPU against the host verifier and prints the
-// reference's result lines.  (Polynomial commitment: not part of this build yet.)
+// reference's result lines (interactive mode runs the whole protocol incl. the Virgo commitment and its verification).
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -31,13 +31,19 @@ int main(int argc, char **argv) {
         prover p(c, device);
         bool ok;
         std::vector<uint8_t> tr;
-        double vt = 0;
+        double vt = 0, pc_pt = -1;
         if (batched) {
             verifier v(nullptr, c);
             std::vector<F> tape = v.drawTape();
             p.proveGKR(tape, tr);
             ok = v.check(tape, tr);
             vt = v.verifyTime();
+        } else if (c.circuit[0].bitLength >= 7) {
+            verifier v(&p, c);                       // the reference's flow: commitment on (src/verifier.cpp:134-189)
+            ok = v.verifyFull();
+            tr = v.fullTranscript();
+            vt = v.verifyTime() + v.polyVerifyTime();
+            pc_pt = v.polyProveTime();
         } else {
             verifier v(&p, c);
             ok = v.verify();
@@ -50,6 +56,7 @@ int main(int argc, char **argv) {
         fprintf(stdout, "Prove Time %lf\n", p.proveTime());
         fprintf(stdout, "verify time %lf\n", vt);
         fprintf(stdout, "proof size = %lf kb\n", batched ? tr.size() / 1024.0 : p.proofSize());
+        if (pc_pt >= 0) fprintf(stdout, "Polynomial commitment: prove time %lf\n", pc_pt);
         if (dump) { FILE *f = fopen(dump, "wb"); if (f) { fwrite(tr.data(), 1, tr.size(), f); fclose(f); } }
     } catch (const std::exception &e) {
         fprintf(stderr, "error: %s\n", e.what());

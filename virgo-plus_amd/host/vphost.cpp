@@ -187,6 +187,37 @@ int vph_commit_public(vph_session *s, const uint64_t *pub_pairs, uint64_t n_pub,
     }
 }
 
+int vph_prove_and_verify_full(vph_session *s, int reps, uint8_t *transcript, uint64_t capacity, uint64_t *n_written,
+                              double *gkr_prove_sec, double *pc_prove_sec, double *verify_sec, char *err, int errlen) {
+    try {
+        F::init();
+        verifier v(s->p.get(), s->circ->c);
+        const double t0 = s->p->proveTime();
+        const bool ok = v.verifyFull(reps);
+        const auto &tr = v.fullTranscript();
+        if (tr.size() > capacity) { set_err(err, errlen, "transcript buffer too small"); return -1; }
+        memcpy(transcript, tr.data(), tr.size());
+        if (n_written) *n_written = tr.size();
+        if (gkr_prove_sec) *gkr_prove_sec = s->p->proveTime() - t0;
+        if (pc_prove_sec) *pc_prove_sec = v.polyProveTime();
+        if (verify_sec) *verify_sec = v.verifyTime() + v.polyVerifyTime();
+        return ok ? 0 : 1;
+    } catch (const std::exception &e) {
+        set_err(err, errlen, e.what());
+        return -2;
+    }
+}
+
+void vph_test_sha3(const uint8_t *in, uint8_t *out, uint64_t n) {
+    for (uint64_t i = 0; i < n; ++i) {
+        uint64_t m[8];
+        memcpy(m, in + 64 * i, 64);
+        vph::hhash_digest prev; memcpy(prev.w, m + 4, 32);
+        vph::hhash_digest d = vph::hhash(m, prev);
+        memcpy(out + 32 * i, d.w, 32);
+    }
+}
+
 int vph_fri_commit(vph_session *s, const uint64_t *r_pairs, int n_steps, uint8_t *roots, uint64_t *final_pairs, char *err, int errlen) {
     vp_ctx *ctx = s->p->context();
     for (int k = 0; k < n_steps; ++k) {

@@ -64,6 +64,14 @@ int vph_commit_private(vph_session *, uint8_t root[32], double *ms, char *err, i
  * out = root_h[32] | input_0[16] | all_sum[65*16]  (the tail of the golden transcript layout).         */
 int vph_commit_public(vph_session *, const uint64_t *pub_pairs, uint64_t n_pub, uint8_t out[32 + 16 + 65 * 16], double *ms,
                       char *err, int errlen);
+/* The COMPLETE protocol with polynomial-commitment verification (verifier::verify, src/verifier.cpp:134-189):
+ * commit_private, interactive GKR, commit_public, FRI commit phase with fresh challenges, `reps` query repetitions
+ * answered through vp_fri_open and checked on the host.  Returns 0 = accepted, 1 = rejected.  transcript = the golden
+ * layout (identical to the reference's up to all_sum); times in seconds.                                  */
+int vph_prove_and_verify_full(vph_session *, int reps, uint8_t *transcript, uint64_t capacity, uint64_t *n_written,
+                              double *gkr_prove_sec, double *pc_prove_sec, double *verify_sec, char *err, int errlen);
+/* my_hhash on the host (verifier side): SHA3-256 of n 64-byte messages.                                   */
+void vph_test_sha3(const uint8_t *in, uint8_t *out, uint64_t n);
 /* poly_commit_prover::commit_phase (vpd_verifier.cpp:44-74) with caller-supplied fold challenges: n_steps calls of
  * fri::commit_phase_step, then commit_phase_final.  roots: 32 bytes per step; final_code: 2048 {real,img} pairs.
  * commit_public (or vph_prove_full) must have run on this session.                                       */
