@@ -275,10 +275,9 @@ k_init_chunks(InitArgs a, const u32 *__restrict__ chunk_beg, const u32 *__restri
     if (lane == 0) { part[2 * c] = m; part[2 * c + 1] = ad; }
 }
 
-__global__ void __launch_bounds__(VP_BLOCK)
-k_init_combine(const u32 *__restrict__ heavy_row, const u32 *__restrict__ heavy_cptr, u32 n_heavy,
-               const F *__restrict__ part, F *M, F *A) {
-    const u32 h = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+__device__ __forceinline__ void init_combine_body(const u32 *__restrict__ heavy_row, const u32 *__restrict__ heavy_cptr, u32 n_heavy,
+                                                  const F *__restrict__ part, F *M, F *A, u32 bid) {
+    const u32 h = bid * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (h >= n_heavy) return;
     const int lane = threadIdx.x & 63;
     F m = f_zero(), ad = f_zero();
@@ -290,6 +289,9 @@ k_init_combine(const u32 *__restrict__ heavy_row, const u32 *__restrict__ heavy_
     ad = wave_sum(ad);
     if (lane == 0) { M[heavy_row[h]] = m; A[heavy_row[h]] = ad; }
 }
+__global__ void __launch_bounds__(VP_BLOCK)
+k_init_combine(const u32 *__restrict__ heavy_row, const u32 *__restrict__ heavy_cptr, u32 n_heavy,
+               const F *__restrict__ part, F *M, F *A) { init_combine_body(heavy_row, heavy_cptr, n_heavy, part, M, A, blockIdx.x); }
 
 // phase-2 per-type coefficients from V_u (device scalar set by finalize of phase 1)
 __global__ void k_p2_coef(const F *__restrict__ Vu, F *coef) {
@@ -592,8 +594,8 @@ __device__ __forceinline__ void contrib2(const InitArgs2 &a, u32 e, F &m, F &ad)
 }
 
 template <int PHASE>
-__global__ void __launch_bounds__(VP_BLOCK) k_init2_light(InitArgs2 a) {
-    u32 row = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void init2_light_body(const InitArgs2 &a, u32 bid) {
+    u32 row = bid * blockDim.x + threadIdx.x;
     if (row >= a.n_rows) return;
     if (PHASE == 2) {
         const int l = a.s_layer[row];
@@ -606,12 +608,13 @@ __global__ void __launch_bounds__(VP_BLOCK) k_init2_light(InitArgs2 a) {
     a.M[row] = m;
     a.A[row] = ad;
 }
+template <int PHASE>
+__global__ void __launch_bounds__(VP_BLOCK) k_init2_light(InitArgs2 a) { init2_light_body<PHASE>(a, blockIdx.x); }
 
 template <int PHASE>
-__global__ void __launch_bounds__(VP_BLOCK)
-k_init2_chunks(InitArgs2 a, const u32 *__restrict__ chunk_beg, const u32 *__restrict__ chunk_end, u32 n_chunks,
-               F *__restrict__ part) {
-    const u32 c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+__device__ __forceinline__ void init2_chunks_body(const InitArgs2 &a, const u32 *__restrict__ chunk_beg, const u32 *__restrict__ chunk_end,
+                                                  u32 n_chunks, F *__restrict__ part, u32 bid) {
+    const u32 c = bid * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (c >= n_chunks) return;
     const int lane = threadIdx.x & 63;
     F m = f_zero(), ad = f_zero();
@@ -620,18 +623,24 @@ k_init2_chunks(InitArgs2 a, const u32 *__restrict__ chunk_beg, const u32 *__rest
     ad = wave_sum(ad);
     if (lane == 0) { part[2 * c] = m; part[2 * c + 1] = ad; }
 }
+template <int PHASE>
+__global__ void __launch_bounds__(VP_BLOCK)
+k_init2_chunks(InitArgs2 a, const u32 *__restrict__ chunk_beg, const u32 *__restrict__ chunk_end, u32 n_chunks,
+               F *__restrict__ part) { init2_chunks_body<PHASE>(a, chunk_beg, chunk_end, n_chunks, part, blockIdx.x); }
 
 // Liu init as a gather (src/prover.cpp:396-414): for every u of layer i-1 the (later layer, subset
 // position) pairs that point at it were listed at upload; M[u] = s0*eq(r_u,u) + sum eq_q(g).
-__global__ void __launch_bounds__(VP_BLOCK)
-k_liu_gather(const u32 *__restrict__ rowptr, const uint8_t *__restrict__ e_q, const u32 *__restrict__ e_g,
-             const Half *__restrict__ H, u32 size, F *__restrict__ M) {
-    u32 u = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void liu_gather_body(const u32 *__restrict__ rowptr, const uint8_t *__restrict__ e_q, const u32 *__restrict__ e_g,
+                                                const Half *__restrict__ H, u32 size, F *__restrict__ M, u32 bid) {
+    u32 u = bid * blockDim.x + threadIdx.x;
     if (u >= size) return;
     F m = half_at(H[0], u);
     for (u32 k = rowptr[u]; k < rowptr[u + 1]; ++k) m = f_add(m, half_at(H[e_q[k]], e_g[k]));
     M[u] = m;
 }
+__global__ void __launch_bounds__(VP_BLOCK)
+k_liu_gather(const u32 *__restrict__ rowptr, const uint8_t *__restrict__ e_q, const u32 *__restrict__ e_g,
+             const Half *__restrict__ H, u32 size, F *__restrict__ M) { liu_gather_body(rowptr, e_q, e_g, H, size, M, blockIdx.x); }
 
 __global__ void __launch_bounds__(VP_BLOCK)
 k_vres2(Half h, const F *__restrict__ val, u32 size, F *out_dev) {
@@ -654,6 +663,7 @@ struct SfArgs {
     u32 part_stride;
     u32 total_chunks;
     int n_tab, has_a;
+    u32 nblk;                 // batched launches: blocks given to this job
     SfTab t[VP_MAX_TAB];
 };
 
@@ -762,6 +772,122 @@ __global__ void __launch_bounds__(VP_BLOCK, MINW) k_sumfold(SfArgs a) {
         F *o = a.part + (size_t) s * a.part_stride + blockIdx.x * 3;
         o[0] = X; o[1] = f_sub(f_sub(Y, X), Z); o[2] = Z;
     }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_sumfold3b: the same three rounds per launch, laid out for parallelism instead of per-lane work.
+//
+// k_sumfold<3> gives a lane 8 entries of each table (7 dependent pair steps, ~250 VGPRs): a 2^20-entry table
+// is only 2048 waves, two per SIMD, and the kernel runs at the latency of its own dependency chain.  Here a
+// 256-thread workgroup takes the same 512-entry chunk: round k+0 is one pair per thread (entries 2t, 2t+1
+// as one 32-byte load per table), the 256 folded entries go through LDS, round k+1 runs on the first two
+// waves, round k+2 on the first.  Idle waves issue nothing, so the instruction count is that of the dense
+// schedule, but a chunk exposes 4x the waves, a thread holds 6 entries instead of 24 (~100 VGPRs, 5 waves
+// per SIMD), and the sums are accumulated unreduced (one fold per chunk, not one canonical add per pair).
+//
+// Lazy arithmetic used below (values are limbs of F):
+//   d = x1 + p - x0            in [0, 2p]           (x0, x1 canonical)
+//   a*b + c  with a, b in [0, 2p], c in [0, p]:  re = a.re*b.re + 4p*2^61 - a.im*b.im + c.re < 2^125,
+//                                                im = a.re*b.im + a.im*b.re + c.im          < 2^125,
+//   both inside m_red128's domain; every stored value is canonical, so results are bit-identical to the
+//   strict sequence.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ F f_sub_lazy(const F &a, const F &b) { return f_make(a.re + P61 - b.re, a.im + P61 - b.im); }
+__device__ __forceinline__ F f_mad_lazy(const F &a, const F &b, const F &c) {
+    const u128 C4 = ((u128) P61) << 63;
+    const u128 re = (u128) a.re * b.re + C4 - (u128) a.im * b.im + c.re;
+    const u128 im = (u128) a.re * b.im + (u128) a.im * b.re + c.im;
+    return f_make(m_red128(re), m_red128(im));
+}
+struct Lz { u64 re, im; };                                           // unreduced sum of canonical values
+__device__ __forceinline__ void lz_add(Lz &s, const F &x) { s.re += x.re; s.im += x.im; }
+__device__ __forceinline__ void lz_fold(Lz &s) { s.re = (s.re & P61) + (s.re >> 61); s.im = (s.im & P61) + (s.im >> 61); }
+__device__ __forceinline__ F lz_canon(const Lz &s) { return f_make(m_fold(s.re), m_fold(s.im)); }
+
+// one pair of one table family: sums into (X, Y, Z) = (sum dm*dv, sum m1*v1 + a1, sum m0*v0 + a0), folds with r
+template <bool HAS_A>
+__device__ __forceinline__ void sf_pair_step(const F &v0, const F &v1, const F &m0, const F &m1, const F &a0, const F &a1,
+                                             const F &r, Lz &X, Lz &Y, Lz &Z, F &vo, F &mo, F &ao) {
+    const F dv = f_sub_lazy(v1, v0), dm = f_sub_lazy(m1, m0);
+    lz_add(X, f_mad_lazy(dm, dv, f_zero()));
+    lz_add(Y, f_mad_lazy(m1, v1, HAS_A ? a1 : f_zero()));
+    lz_add(Z, f_mad_lazy(m0, v0, HAS_A ? a0 : f_zero()));
+    vo = f_mad_lazy(r, dv, v0);
+    mo = f_mad_lazy(r, dm, m0);
+    if (HAS_A) ao = f_mad_lazy(r, f_sub_lazy(a1, a0), a0);
+}
+
+struct Sf3bLds { F s1[3][256]; F s2[3][128]; F red[4][9]; };
+template <bool HAS_A>
+__device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb, Sf3bLds &sm) {
+    F (&s1)[3][256] = sm.s1; F (&s2)[3][128] = sm.s2; F (&red)[4][9] = sm.red;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    Lz acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) acc[i].re = acc[i].im = 0;
+    const F r0 = a.r[0], r1 = a.r[1], r2 = a.r[2];
+    for (u32 c = bid; c < a.total_chunks; c += nb) {
+        int j = 0;
+        while (j + 1 < a.n_tab && c >= a.t[j + 1].chunk_start) ++j;
+        const SfTab td = a.t[j];
+        const u32 cl = c - td.chunk_start;
+        const u32 i0 = td.off + cl * 512 + 2 * t, vend = td.off + td.valid;
+        {   // round k: one pair per thread
+            const F v0 = ld_or_zero(a.inV, i0, vend), v1 = ld_or_zero(a.inV, i0 + 1, vend);
+            const F m0 = ld_or_zero(a.inM, i0, vend), m1 = ld_or_zero(a.inM, i0 + 1, vend);
+            F a0 = f_zero(), a1 = f_zero();
+            if (HAS_A) { a0 = ld_or_zero(a.inA, i0, vend); a1 = ld_or_zero(a.inA, i0 + 1, vend); }
+            F vo, mo, ao = f_zero();
+            sf_pair_step<HAS_A>(v0, v1, m0, m1, a0, a1, r0, acc[0], acc[1], acc[2], vo, mo, ao);
+            s1[0][t] = vo; s1[1][t] = mo;
+            if (HAS_A) s1[2][t] = ao;
+        }
+        __syncthreads();
+        if (w < 2) {   // round k+1: 128 pairs
+            F vo, mo, ao = f_zero();
+            sf_pair_step<HAS_A>(s1[0][2 * t], s1[0][2 * t + 1], s1[1][2 * t], s1[1][2 * t + 1],
+                                HAS_A ? s1[2][2 * t] : f_zero(), HAS_A ? s1[2][2 * t + 1] : f_zero(), r1,
+                                acc[3], acc[4], acc[5], vo, mo, ao);
+            s2[0][t] = vo; s2[1][t] = mo;
+            if (HAS_A) s2[2][t] = ao;
+        }
+        __syncthreads();
+        if (w == 0) {  // round k+2: 64 pairs, results are the folded table
+            F vo, mo, ao = f_zero();
+            sf_pair_step<HAS_A>(s2[0][2 * t], s2[0][2 * t + 1], s2[1][2 * t], s2[1][2 * t + 1],
+                                HAS_A ? s2[2][2 * t] : f_zero(), HAS_A ? s2[2][2 * t + 1] : f_zero(), r2,
+                                acc[6], acc[7], acc[8], vo, mo, ao);
+            const u32 oi = cl * 64 + t;
+            if (oi < ((td.valid + 7) >> 3)) {
+                a.outV[td.off + oi] = vo;
+                a.outM[td.off + oi] = mo;
+                if (HAS_A) a.outA[td.off + oi] = ao;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) lz_fold(acc[i]);
+    }
+    // block partials: rounds k+1 and k+2 only have contributions in waves 0-1 and 0
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        if (i >= 3 && w >= 2) break;
+        if (i >= 6 && w >= 1) break;
+        const F x = wave_sum63(lz_canon(acc[i]));
+        if (lane == 63) red[w][i] = x;
+    }
+    __syncthreads();
+    if (t < 3) {
+        const int nw = t == 0 ? 4 : t == 1 ? 2 : 1;
+        F X = red[0][3 * t], Y = red[0][3 * t + 1], Z = red[0][3 * t + 2];
+        for (int k = 1; k < nw; ++k) { X = f_add(X, red[k][3 * t]); Y = f_add(Y, red[k][3 * t + 1]); Z = f_add(Z, red[k][3 * t + 2]); }
+        F *o = a.part + (size_t) t * a.part_stride + bid * 3;
+        o[0] = X; o[1] = f_sub(f_sub(Y, X), Z); o[2] = Z;
+    }
+}
+template <bool HAS_A>
+__global__ void __launch_bounds__(VP_BLOCK, 4) k_sumfold3b(SfArgs a) {
+    __shared__ Sf3bLds sm;
+    sumfold3b_body<HAS_A>(a, blockIdx.x, gridDim.x, sm);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -918,6 +1044,7 @@ struct SegArgs {
     u32 part_stride;
     u32 total_segs;
     int n_tab, n_rounds;      // n_rounds = max seg_log
+    int has_a; u32 nblk;      // batched launches: table family has an add array; blocks given to this job
     SegTab t[VP_MAX_TAB];
 };
 
@@ -930,18 +1057,17 @@ __device__ __forceinline__ u32 racc_off(int s) {
 
 // Wave-uniform roles, one code path: role t folds table t (0: V, 1: mult, 2: add) and computes one of the three
 // products of the pair: 0: (m1-m0)(v1-v0)   1: m0*v0   2: m1*v1.  Two multiplies per lane and pair.
+struct SegLds { F bufA[3][VP_SEG]; F bufB[3][VP_SEG / 2]; F racc[4][768]; };   // racc: [role][slot]; [3] = role 2's second sum (a0)
 template <bool HAS_A>
-__global__ void __launch_bounds__(VP_SEG_THREADS) k_seg(SegArgs a) {
-    __shared__ F bufA[3][VP_SEG];
-    __shared__ F bufB[3][VP_SEG / 2];
-    __shared__ F racc[4][768];                                     // [role][slot]; [3] = role 2's second sum (a0)
+__device__ __forceinline__ void seg_body(const SegArgs &a, u32 bid, u32 nb, SegLds &sm) {
+    F (&bufA)[3][VP_SEG] = sm.bufA; F (&bufB)[3][VP_SEG / 2] = sm.bufB; F (&racc)[4][768] = sm.racc;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int role = __builtin_amdgcn_readfirstlane(w % 3);
     const u32 pslot = (u32) ((w / 3) * 64 + lane);
     for (int i = tid; i < 4 * 768; i += VP_SEG_THREADS) (&racc[0][0])[i] = f_zero();
     __syncthreads();
 
-    for (u32 seg = blockIdx.x; seg < a.total_segs; seg += gridDim.x) {
+    for (u32 seg = bid; seg < a.total_segs; seg += nb) {
         int j = 0;
         while (j + 1 < a.n_tab && seg >= a.t[j + 1].seg_start) ++j;
         const SegTab td = a.t[j];
@@ -1014,8 +1140,13 @@ __global__ void __launch_bounds__(VP_SEG_THREADS) k_seg(SegArgs a) {
         const F R0 = res[s * 4], R1 = res[s * 4 + 1], R2 = res[s * 4 + 2], R3 = res[s * 4 + 3];
         // a = sum dm*dv;  b = sum (m1*v1 + da) - a - sum m0*v0;  c = sum m0*v0 + sum a0
         const F x = c == 0 ? R0 : c == 1 ? f_sub(R2, f_add(R0, R1)) : f_add(R1, R3);
-        a.part[(size_t) s * a.part_stride + blockIdx.x * 3 + c] = x;
+        a.part[(size_t) s * a.part_stride + bid * 3 + c] = x;
     }
+}
+template <bool HAS_A>
+__global__ void __launch_bounds__(VP_SEG_THREADS) k_seg(SegArgs a) {
+    __shared__ SegLds sm;
+    seg_body<HAS_A>(a, blockIdx.x, gridDim.x, sm);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1056,8 +1187,7 @@ struct EmitArgs {
 
 // dynamic LDS: tables [2][3][cap] | psum[32][3] | wred[32][12][3] | claim[64] | retv[64] | atv[32] | retk[64] (int)
 #define VP_EMIT_LDS_EXTRA_F (32 * 3 + 32 * VP_EMIT_WAVES * 3 + VP_MAX_TAB + VP_MAX_TAB + 32)
-__global__ void __launch_bounds__(VP_EMIT_THREADS) k_emit(EmitArgs a) {
-    extern __shared__ __align__(16) unsigned char smem_raw[];
+__device__ __forceinline__ void emit_body(const EmitArgs &a, unsigned char *smem_raw) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nth = blockDim.x;
     const u32 E = 1u << a.emit_log, cap = (u32) a.n_tab * E;
     F *lbuf = reinterpret_cast<F *>(smem_raw);
@@ -1217,6 +1347,61 @@ __global__ void __launch_bounds__(VP_EMIT_THREADS) k_emit(EmitArgs a) {
         a.claims_out[tid] = c;
         if (a.Vu && tid == 0) *a.Vu = c;
     }
+}
+__global__ void __launch_bounds__(VP_EMIT_THREADS) k_emit(EmitArgs a) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    emit_body(a, smem_raw);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Batched ("plan") launches.  Every argument of every launch of a proof depends on the circuit only (the
+// challenges are read from the device tape), so the job descriptors are built once per circuit, kept in
+// device memory, and one launch runs the same kernel body for MANY independent sumchecks: block b looks up
+// (job, block-in-job) in a map.  The hardware runs at most a handful of kernels at a time; with ~40
+// independent sumchecks per proof, batching them side by side is what fills the chip.
+// ---------------------------------------------------------------------------------------------------
+struct BlkMap { u32 job, bid; };
+struct LightJob { InitArgs2 a; int phase; int pad; };
+struct ChunkJob { InitArgs2 a; const u32 *chunk_beg; const u32 *chunk_end; F *part; u32 n_chunks; int phase; };
+struct CombineJob { const u32 *heavy_row; const u32 *heavy_cptr; const F *part; F *M; F *A; u32 n_heavy; int pad; };
+struct GatherJob { const u32 *rowptr; const uint8_t *e_q; const u32 *e_g; const Half *H; F *M; u32 size; int pad; };
+
+__global__ void __launch_bounds__(VP_BLOCK) k_light_multi(const LightJob *__restrict__ jobs, const BlkMap *__restrict__ map) {
+    const BlkMap m = map[blockIdx.x];
+    const LightJob &j = jobs[m.job];
+    if (j.phase == 1) init2_light_body<1>(j.a, m.bid); else init2_light_body<2>(j.a, m.bid);
+}
+__global__ void __launch_bounds__(VP_BLOCK) k_chunks_multi(const ChunkJob *__restrict__ jobs, const BlkMap *__restrict__ map) {
+    const BlkMap m = map[blockIdx.x];
+    const ChunkJob &j = jobs[m.job];
+    if (j.phase == 1) init2_chunks_body<1>(j.a, j.chunk_beg, j.chunk_end, j.n_chunks, j.part, m.bid);
+    else init2_chunks_body<2>(j.a, j.chunk_beg, j.chunk_end, j.n_chunks, j.part, m.bid);
+}
+__global__ void __launch_bounds__(VP_BLOCK) k_combine_multi(const CombineJob *__restrict__ jobs, const BlkMap *__restrict__ map) {
+    const BlkMap m = map[blockIdx.x];
+    const CombineJob &j = jobs[m.job];
+    init_combine_body(j.heavy_row, j.heavy_cptr, j.n_heavy, j.part, j.M, j.A, m.bid);
+}
+__global__ void __launch_bounds__(VP_BLOCK) k_gather_multi(const GatherJob *__restrict__ jobs, const BlkMap *__restrict__ map) {
+    const BlkMap m = map[blockIdx.x];
+    const GatherJob &j = jobs[m.job];
+    liu_gather_body(j.rowptr, j.e_q, j.e_g, j.H, j.size, j.M, m.bid);
+}
+__global__ void __launch_bounds__(VP_BLOCK, 4) k_sumfold3b_multi(const SfArgs *__restrict__ jobs, const BlkMap *__restrict__ map) {
+    __shared__ Sf3bLds sm;
+    const BlkMap m = map[blockIdx.x];
+    const SfArgs &a = jobs[m.job];
+    if (a.has_a) sumfold3b_body<true>(a, m.bid, a.nblk, sm); else sumfold3b_body<false>(a, m.bid, a.nblk, sm);
+}
+__global__ void __launch_bounds__(VP_SEG_THREADS) k_seg_multi(const SegArgs *__restrict__ jobs, const BlkMap *__restrict__ map) {
+    __shared__ SegLds sm;
+    const BlkMap m = map[blockIdx.x];
+    const SegArgs &a = jobs[m.job];
+    if (a.has_a) seg_body<true>(a, m.bid, a.nblk, sm); else seg_body<false>(a, m.bid, a.nblk, sm);
+}
+__global__ void __launch_bounds__(VP_EMIT_THREADS) k_emit_multi(const EmitArgs *__restrict__ jobs) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    emit_body(jobs[blockIdx.x], smem_raw);
 }
 
 }  // namespace vp

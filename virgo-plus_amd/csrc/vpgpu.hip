@@ -67,6 +67,27 @@ struct Lane {
     hipEvent_t done = nullptr;
 };
 
+// Batched launch plan of the GKR part (see vp_kernels.h "Batched launches"): recorded once per circuit by running the
+// per-sumcheck drivers in record mode (same code that launches directly on the lane path), then merged step by step.
+enum { NK_LIGHT = 0, NK_GATHER, NK_CHUNKS, NK_COMBINE, NK_SF, NK_SEG, NK_EMIT, NK_COUNT };
+struct PStep { int kind; u32 idx, grid, lds; u64 bytes; int rounds; };
+struct PlanRec {
+    std::vector<LightJob> light; std::vector<GatherJob> gather; std::vector<ChunkJob> chunks; std::vector<CombineJob> combine;
+    std::vector<SfArgs> sf; std::vector<SegArgs> seg; std::vector<EmitArgs> emit;
+    std::vector<std::vector<PStep>> chains; int cur = -1;
+    void push(int kind, u32 idx, u32 grid, u32 lds = 0, u64 bytes = 0) { chains[cur].push_back(PStep{kind, idx, grid, lds, bytes, 0}); }
+};
+struct PNode { int kind = 0, step = 0, stream = 0; u32 first = 0, count = 0, grid = 0, lds = 0, map_off = 0; u64 bytes = 0;
+               std::vector<int> deps; hipEvent_t ev = nullptr; bool record = false; };
+struct Plan {
+    std::vector<PNode> nodes;
+    LightJob *d_light = nullptr; GatherJob *d_gather = nullptr; ChunkJob *d_chunks = nullptr; CombineJob *d_combine = nullptr;
+    SfArgs *d_sf = nullptr; SegArgs *d_seg = nullptr; EmitArgs *d_emit = nullptr; BlkMap *d_map = nullptr;
+    hipStream_t streams[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_root = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+    u64 rounds = 0; int n_steps = 0;
+};
+
 struct vp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -108,6 +129,10 @@ struct vp_ctx {
     Lane lane0; Lane *ln = nullptr;
     std::vector<Lane> lanes;          // [2*(i-1)] = phases 1+2 of layer i, [2*(i-1)+1] = Liu of layer i
     std::vector<hipStream_t> lane_streams; std::vector<hipEvent_t> lane_events; hipEvent_t ev_fork = nullptr;
+    PlanRec *rec = nullptr;           // non-null while the drivers run in record mode
+    Plan *plan = nullptr; int plan_path = 1;   // VP_GKR_PATH=lanes: one stream per sumcheck chain instead of the plan
+    // hipGraph of the concurrent GKR submission (per circuit; VP_GKR_GRAPH=0 submits the launches directly)
+    hipGraphExec_t gkr_graph = nullptr; int use_graph = 1; bool graph_failed = false; u64 graph_launches = 0, graph_rounds = 0;
 
     F *zero() const { return small; }
     F *one() const { return small + 1; }
@@ -408,10 +433,14 @@ int vp_create(int device, vp_ctx **out) {
     return VP_OK;
 }
 
+static void free_plan(vp_ctx *ctx);
+
 void vp_destroy(vp_ctx *ctx) {
     if (!ctx) return;
     (void) hipSetDevice(ctx->device);
     (void) hipStreamSynchronize(ctx->stream);
+    if (ctx->gkr_graph) (void) hipGraphExecDestroy(ctx->gkr_graph);
+    free_plan(ctx);
     free_all(ctx);
     for (auto &e : ctx->ev_pool) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
     if (ctx->ev0) (void) hipEventDestroy(ctx->ev0);
@@ -429,6 +458,9 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
     if (n_layers > VP_MAX_TAB) { ctx->err = "too many layers"; return VP_ELIMIT; }
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ctx->gkr_graph) { (void) hipGraphExecDestroy(ctx->gkr_graph); ctx->gkr_graph = nullptr; }
+    ctx->graph_failed = false;
+    free_plan(ctx);
     free_all(ctx);
     ctx->L.assign(n_layers, LayerDev());
     ctx->n_layers = n_layers;
@@ -634,7 +666,7 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
         ctx->lane0.part2 = ctx->part2; ctx->lane0.chunk_part = ctx->chunk_part; ctx->lane0.Vu = ctx->Vu();
         ctx->ln = &ctx->lane0;
         const int n_lanes = 2 * (n_layers - 1);
-        while ((int) ctx->lane_streams.size() < n_lanes) {
+        while ((int) ctx->lane_streams.size() < std::max(n_lanes, 3)) {
             hipStream_t st; hipEvent_t ev;
             HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
             HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -662,9 +694,12 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
         }
         const char *ser = getenv("VP_GKR_SERIAL");
         ctx->serial = (ser && ser[0] == '1') ? 1 : 0;
+        const char *gr = getenv("VP_GKR_GRAPH");
+        ctx->use_graph = (gr && gr[0] == '0') ? 0 : 1;
         const char *pth = getenv("VP_GKR_PATH");
         ctx->simple_path = (pth && !strcmp(pth, "simple")) ? 1 : 0;
         ctx->sumfold_path = (pth && !strcmp(pth, "sumfold")) ? 1 : 0;
+        ctx->plan_path = (pth && !strcmp(pth, "lanes")) ? 0 : 1;
     }
     // event pool for the profiled launches
     if (ctx->ev_pool.empty()) {
@@ -1066,12 +1101,18 @@ int run_sumcheck_seg(vp_ctx *ctx, const FusedSumcheck &sc) {
                 bytes += (u64) (cur_valid[j] + ((cur_valid[j] + 7) >> 3)) * (sc.has_a ? 48 : 32);
             }
             a.n_tab = nt; a.total_chunks = chunks;
-            const u32 grid = std::max<u32>(1, std::min<u32>((chunks + 3) / 4, MAX_BLOCKS));
+            static const int sf3b = getenv("VP_SF3B") ? atoi(getenv("VP_SF3B")) : 1;
+            static const u32 sf3b_grid = getenv("VP_SF3B_GRID") ? (u32) atoi(getenv("VP_SF3B_GRID")) : MAX_BLOCKS;
+            const u32 grid = (sf3b || ctx->rec) ? std::max<u32>(1, std::min<u32>(chunks, std::min<u32>(sf3b_grid, MAX_BLOCKS)))
+                                  : std::max<u32>(1, std::min<u32>((chunks + 3) / 4, MAX_BLOCKS));
             a.part = new_part(k, 3, grid); a.part_stride = grid * 3;
             if (!a.part) { ctx->err = "partial buffer exhausted"; return VP_ELIMIT; }
-            const bool prof = ctx->profiling && ctx->ev_used < ctx->ev_pool.size();
+            const bool prof = !ctx->rec && ctx->profiling && ctx->ev_used < ctx->ev_pool.size();
             if (prof) hipEventRecord(ctx->ev_pool[ctx->ev_used].a, ctx->ln->stream);
-            launch_sumfold<3>(ctx, a, grid);
+            if (ctx->rec) { a.nblk = grid; ctx->rec->sf.push_back(a); ctx->rec->push(NK_SF, (u32) ctx->rec->sf.size() - 1, grid, 0, bytes); }
+            else if (!sf3b) launch_sumfold<3>(ctx, a, grid);
+            else if (sc.has_a) hipLaunchKernelGGL(k_sumfold3b<true>, dim3(grid), dim3(VP_BLOCK), 0, ctx->ln->stream, a);
+            else hipLaunchKernelGGL(k_sumfold3b<false>, dim3(grid), dim3(VP_BLOCK), 0, ctx->ln->stream, a);
             if (prof) { hipEventRecord(ctx->ev_pool[ctx->ev_used].b, ctx->ln->stream); ctx->ev_pool[ctx->ev_used++].bytes = bytes; }
             count_launch(ctx);
         }
@@ -1096,7 +1137,9 @@ int run_sumcheck_seg(vp_ctx *ctx, const FusedSumcheck &sc) {
             const u32 grid = std::max<u32>(1, std::min<u32>(segs, 512));
             a.part = new_part(k, n_rounds, grid); a.part_stride = grid * 3;
             if (!a.part) { ctx->err = "partial buffer exhausted"; return VP_ELIMIT; }
-            if (sc.has_a) hipLaunchKernelGGL(k_seg<true>, dim3(grid), dim3(VP_SEG_THREADS), 0, ctx->ln->stream, a);
+            a.has_a = sc.has_a; a.nblk = grid;
+            if (ctx->rec) { ctx->rec->seg.push_back(a); ctx->rec->push(NK_SEG, (u32) ctx->rec->seg.size() - 1, grid); }
+            else if (sc.has_a) hipLaunchKernelGGL(k_seg<true>, dim3(grid), dim3(VP_SEG_THREADS), 0, ctx->ln->stream, a);
             else hipLaunchKernelGGL(k_seg<false>, dim3(grid), dim3(VP_SEG_THREADS), 0, ctx->ln->stream, a);
             count_launch(ctx);
         }
@@ -1123,7 +1166,8 @@ int run_sumcheck_seg(vp_ctx *ctx, const FusedSumcheck &sc) {
         if (t.enter <= std::max(sc.rounds, 1)) ea.enter_mask |= 1u << (t.enter - 1);
     }
     const size_t lds = ((size_t) 6 * sc.n_tab * E + VP_EMIT_LDS_EXTRA_F) * sizeof(F) + VP_MAX_TAB * sizeof(int);
-    hipLaunchKernelGGL(k_emit, dim3(1), dim3(VP_EMIT_THREADS), lds, ctx->ln->stream, ea);
+    if (ctx->rec) { ctx->rec->emit.push_back(ea); ctx->rec->push(NK_EMIT, (u32) ctx->rec->emit.size() - 1, 1, (u32) lds); ctx->rec->chains[ctx->rec->cur].back().rounds = sc.rounds; }
+    else hipLaunchKernelGGL(k_emit, dim3(1), dim3(VP_EMIT_THREADS), lds, ctx->ln->stream, ea);
     count_launch(ctx);
     ctx->st.rounds += sc.rounds;
     return VP_OK;
@@ -1132,6 +1176,17 @@ int run_sumcheck_seg(vp_ctx *ctx, const FusedSumcheck &sc) {
 template <int PHASE>
 int run_init2_rows(vp_ctx *ctx, const Csr &c, InitArgs2 &a) {
     a.rowptr = c.rowptr; a.e_g = c.e_g; a.e_x = c.e_x; a.e_tl = c.e_tl; a.n_rows = c.n_rows;
+    if (ctx->rec) {
+        PlanRec &R = *ctx->rec;
+        if (c.n_rows) { LightJob j{}; j.a = a; j.phase = PHASE; R.light.push_back(j); R.push(NK_LIGHT, (u32) R.light.size() - 1, nblk(c.n_rows)); }
+        if (c.n_chunks) {
+            ChunkJob j{}; j.a = a; j.chunk_beg = c.chunk_beg; j.chunk_end = c.chunk_end; j.part = ctx->ln->chunk_part; j.n_chunks = c.n_chunks; j.phase = PHASE;
+            R.chunks.push_back(j); R.push(NK_CHUNKS, (u32) R.chunks.size() - 1, (c.n_chunks + 3) / 4);
+            CombineJob q{}; q.heavy_row = c.heavy_row; q.heavy_cptr = c.heavy_cptr; q.part = ctx->ln->chunk_part; q.M = a.M; q.A = a.A; q.n_heavy = c.n_heavy;
+            R.combine.push_back(q); R.push(NK_COMBINE, (u32) R.combine.size() - 1, (c.n_heavy + 3) / 4);
+        }
+        return VP_OK;
+    }
     if (c.n_rows) {
         hipLaunchKernelGGL(k_init2_light<PHASE>, dim3(nblk(c.n_rows)), dim3(VP_BLOCK), 0, ctx->ln->stream, a);
         count_launch(ctx);
@@ -1150,28 +1205,26 @@ int run_init2_rows(vp_ctx *ctx, const Csr &c, InitArgs2 &a) {
 
 extern "C" {
 
-static int prove_gkr_fused(vp_ctx *ctx, const vp_F *tape, uint64_t n_tape, uint8_t *transcript, uint64_t *n_written) {
-    HIPCHK(hipSetDevice(ctx->device));
+// Every launch of the GKR part (all lanes, fork and join included), in submission order.  No host synchronisation and no
+// host-dependent argument in here: the same sequence is what the hipGraph of the proof captures.
+static int submit_gkr(vp_ctx *ctx, bool serial) {
     const int n = ctx->n_layers;
-    ctx->st.launches = 0; ctx->st.rounds = 0; ctx->ev_used = 0;
     // Given the tape, every sumcheck of the proof is independent of the others except phase 1 -> phase 2 of the
     // same layer (V_u).  Layer i's phases 1+2 and its Liu sumcheck each get their own lane (stream + scratch);
     // profiling, the sumfold path and VP_GKR_SERIAL=1 run everything on the main lane instead.
-    const bool serial = ctx->serial || ctx->profiling || ctx->sumfold_path;
     Lane *main_lane = &ctx->lane0;
     ctx->ln = main_lane;
-    HIPCHK(hipMemcpyAsync(ctx->d_tape, tape, n_tape * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     F *tr = ctx->d_tr;
     // every eq half table of the proof in one launch (they depend on the tape only)
-    hipLaunchKernelGGL(k_beta_half_multi, dim3(ctx->n_all_jobs), dim3(VP_BLOCK), 0, ctx->stream, ctx->all_jobs);
-    count_launch(ctx);
-    {   // Vres (verifier.cpp:151): eq(r_0, .) is layer n-1's phase-1 table
+    if (!ctx->rec) {
+        hipLaunchKernelGGL(k_beta_half_multi, dim3(ctx->n_all_jobs), dim3(VP_BLOCK), 0, ctx->stream, ctx->all_jobs);
+        count_launch(ctx);
+        // Vres (verifier.cpp:151): eq(r_0, .) is layer n-1's phase-1 table
         LayerDev &T = ctx->L[n - 1];
         hipLaunchKernelGGL(k_vres2, dim3(1), dim3(VP_BLOCK), 0, ctx->stream, T.hg, T.val, (u32) T.size, tr);
         count_launch(ctx);
     }
-    if (!serial) {
+    if (!serial && !ctx->rec) {
         HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
         for (auto &ln : ctx->lanes) HIPCHK(hipStreamWaitEvent(ln.stream, ctx->ev_fork, 0));
     }
@@ -1196,6 +1249,11 @@ static int prove_gkr_fused(vp_ctx *ctx, const vp_F *tape, uint64_t n_tape, uint8
         // ---- Liu (independent of phases 1 and 2) ----
         {
             ctx->ln = serial ? main_lane : &ctx->lanes[2 * (i - 1) + 1];
+            if (ctx->rec) {
+                ctx->rec->cur = 2 * (i - 1) + 1;
+                GatherJob j{}; j.rowptr = cur.lrow; j.e_q = cur.l_q; j.e_g = cur.l_g; j.H = cur.liu_H; j.M = ctx->ln->tab[0][1]; j.size = (u32) pre.size;
+                ctx->rec->gather.push_back(j); ctx->rec->push(NK_GATHER, (u32) ctx->rec->gather.size() - 1, nblk(pre.size));
+            } else
             hipLaunchKernelGGL(k_liu_gather, dim3(nblk(pre.size)), dim3(VP_BLOCK), 0, ctx->ln->stream, cur.lrow, cur.l_q,
                                cur.l_g, cur.liu_H, (u32) pre.size, ctx->ln->tab[0][1]);
             count_launch(ctx);
@@ -1208,6 +1266,7 @@ static int prove_gkr_fused(vp_ctx *ctx, const vp_F *tape, uint64_t n_tape, uint8
         }
         // ---- phase 1 ----
         ctx->ln = serial ? main_lane : &ctx->lanes[2 * (i - 1)];
+        if (ctx->rec) ctx->rec->cur = 2 * (i - 1);
         {
             InitArgs2 a{};
             a.hg = cur.hg; a.vals = ctx->d_vals; a.gc = cur.gc; a.assert_r = ctx->d_tape + ctx->as_off[i];
@@ -1238,11 +1297,178 @@ static int prove_gkr_fused(vp_ctx *ctx, const vp_F *tape, uint64_t n_tape, uint8
         }
     }
     ctx->ln = main_lane;
-    if (!serial) {
+    if (!serial && !ctx->rec) {
         for (auto &ln : ctx->lanes) {
             HIPCHK(hipEventRecord(ln.done, ln.stream));
             HIPCHK(hipStreamWaitEvent(ctx->stream, ln.done, 0));
         }
+    }
+    return VP_OK;
+}
+
+// ---- plan: record, merge, upload ---------------------------------------------------------------------
+static void free_plan(vp_ctx *ctx) {
+    if (!ctx->plan) return;
+    for (auto &nd : ctx->plan->nodes) if (nd.ev) (void) hipEventDestroy(nd.ev);
+    if (ctx->plan->ev_root) (void) hipEventDestroy(ctx->plan->ev_root);
+    for (int q = 0; q < 4; ++q) if (ctx->plan->ev_join[q]) (void) hipEventDestroy(ctx->plan->ev_join[q]);
+    delete ctx->plan;                       // device arrays are owned by ctx->allocs
+    ctx->plan = nullptr;
+}
+
+// Chains = the lanes of the stream path (Liu of layer i; phases 1+2 of layer i).  Step t of the plan holds the t-th launch
+// of every chain; launches of one kernel kind inside a step become ONE node.  A node depends on the nodes that hold the
+// previous launch of each of its chains, nothing else.
+static int build_plan(vp_ctx *ctx) {
+    free_plan(ctx);
+    PlanRec rec;
+    rec.chains.assign(ctx->lanes.size(), {});
+    ctx->rec = &rec;
+    const vp_stats keep = ctx->st;
+    ctx->st.rounds = 0;
+    int rc = submit_gkr(ctx, false);
+    ctx->rec = nullptr;
+    const u64 rounds = ctx->st.rounds;
+    ctx->st = keep;
+    if (rc != VP_OK) return rc;
+    Plan *P = new Plan();
+    ctx->plan = P;
+    P->rounds = rounds;
+    static const int kind_stream[NK_COUNT] = {0, 0, 0, 0, 1, 2, 3};
+    size_t T = 0;
+    for (auto &c : rec.chains) T = std::max(T, c.size());
+    P->n_steps = (int) T;
+    std::vector<LightJob> light; std::vector<GatherJob> gather; std::vector<ChunkJob> chunks; std::vector<CombineJob> combine;
+    std::vector<SfArgs> sf; std::vector<SegArgs> seg; std::vector<EmitArgs> emit;
+    std::vector<BlkMap> map;
+    std::vector<std::vector<int>> node_of(rec.chains.size());          // [chain][step] -> node
+    for (auto &v : node_of) v.assign(T, -1);
+    for (size_t t = 0; t < T; ++t) {
+        for (int kind = 0; kind < NK_COUNT; ++kind) {
+            PNode nd; nd.kind = kind; nd.step = (int) t; nd.stream = kind_stream[kind]; nd.map_off = (u32) map.size();
+            u32 first = 0;
+            switch (kind) {
+                case NK_LIGHT: first = (u32) light.size(); break; case NK_GATHER: first = (u32) gather.size(); break;
+                case NK_CHUNKS: first = (u32) chunks.size(); break; case NK_COMBINE: first = (u32) combine.size(); break;
+                case NK_SF: first = (u32) sf.size(); break; case NK_SEG: first = (u32) seg.size(); break;
+                default: first = (u32) emit.size(); break;
+            }
+            nd.first = first;
+            for (size_t c = 0; c < rec.chains.size(); ++c) {
+                if (t >= rec.chains[c].size() || rec.chains[c][t].kind != kind) continue;
+                const PStep &st = rec.chains[c][t];
+                const u32 job = first + nd.count;
+                switch (kind) {
+                    case NK_LIGHT: light.push_back(rec.light[st.idx]); break; case NK_GATHER: gather.push_back(rec.gather[st.idx]); break;
+                    case NK_CHUNKS: chunks.push_back(rec.chunks[st.idx]); break; case NK_COMBINE: combine.push_back(rec.combine[st.idx]); break;
+                    case NK_SF: sf.push_back(rec.sf[st.idx]); break; case NK_SEG: seg.push_back(rec.seg[st.idx]); break;
+                    default: emit.push_back(rec.emit[st.idx]); break;
+                }
+                if (kind != NK_EMIT) for (u32 b = 0; b < st.grid; ++b) map.push_back(BlkMap{job - first, b});
+                nd.grid += st.grid; nd.lds = std::max(nd.lds, st.lds); nd.bytes += st.bytes; ++nd.count;
+                node_of[c][t] = (int) P->nodes.size();
+                if (t > 0 && node_of[c][t - 1] >= 0) {
+                    const int d = node_of[c][t - 1];
+                    if (std::find(nd.deps.begin(), nd.deps.end(), d) == nd.deps.end()) nd.deps.push_back(d);
+                }
+            }
+            if (nd.count) P->nodes.push_back(nd);
+        }
+    }
+    for (auto &nd : P->nodes)
+        for (int d : nd.deps) if (P->nodes[d].stream != nd.stream) P->nodes[d].record = true;
+    for (auto &nd : P->nodes) HIPCHK(hipEventCreateWithFlags(&nd.ev, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&P->ev_root, hipEventDisableTiming));
+    for (int q = 0; q < 4; ++q) HIPCHK(hipEventCreateWithFlags(&P->ev_join[q], hipEventDisableTiming));
+    VPCHK(dupload(ctx, &P->d_light, light)); VPCHK(dupload(ctx, &P->d_gather, gather)); VPCHK(dupload(ctx, &P->d_chunks, chunks));
+    VPCHK(dupload(ctx, &P->d_combine, combine)); VPCHK(dupload(ctx, &P->d_sf, sf)); VPCHK(dupload(ctx, &P->d_seg, seg));
+    VPCHK(dupload(ctx, &P->d_emit, emit)); VPCHK(dupload(ctx, &P->d_map, map));
+    P->streams[0] = ctx->stream;
+    for (int q = 1; q < 4; ++q) P->streams[q] = ctx->lane_streams[q - 1];
+    return VP_OK;
+}
+
+static void launch_node(const Plan &P, const PNode &nd, hipStream_t st) {
+    const BlkMap *mp = P.d_map + nd.map_off;
+    switch (nd.kind) {
+        case NK_LIGHT: hipLaunchKernelGGL(k_light_multi, dim3(nd.grid), dim3(VP_BLOCK), 0, st, P.d_light + nd.first, mp); break;
+        case NK_GATHER: hipLaunchKernelGGL(k_gather_multi, dim3(nd.grid), dim3(VP_BLOCK), 0, st, P.d_gather + nd.first, mp); break;
+        case NK_CHUNKS: hipLaunchKernelGGL(k_chunks_multi, dim3(nd.grid), dim3(VP_BLOCK), 0, st, P.d_chunks + nd.first, mp); break;
+        case NK_COMBINE: hipLaunchKernelGGL(k_combine_multi, dim3(nd.grid), dim3(VP_BLOCK), 0, st, P.d_combine + nd.first, mp); break;
+        case NK_SF: hipLaunchKernelGGL(k_sumfold3b_multi, dim3(nd.grid), dim3(VP_BLOCK), 0, st, P.d_sf + nd.first, mp); break;
+        case NK_SEG: hipLaunchKernelGGL(k_seg_multi, dim3(nd.grid), dim3(VP_SEG_THREADS), 0, st, P.d_seg + nd.first, mp); break;
+        default: hipLaunchKernelGGL(k_emit_multi, dim3(nd.count), dim3(VP_EMIT_THREADS), nd.lds, st, P.d_emit + nd.first); break;
+    }
+}
+
+// Replays the plan: four streams (init kernels | k_sumfold3b | k_seg | k_emit), events only where a node's predecessor
+// ran on another stream.  single = everything on the main stream in step order (profiling: the k_sumfold3b nodes are
+// bracketed with events).
+static int submit_plan(vp_ctx *ctx, bool single) {
+    Plan &P = *ctx->plan;
+    const int n = ctx->n_layers;
+    hipLaunchKernelGGL(k_beta_half_multi, dim3(ctx->n_all_jobs), dim3(VP_BLOCK), 0, ctx->stream, ctx->all_jobs);
+    {
+        LayerDev &T = ctx->L[n - 1];
+        hipLaunchKernelGGL(k_vres2, dim3(1), dim3(VP_BLOCK), 0, ctx->stream, T.hg, T.val, (u32) T.size, ctx->d_tr);
+    }
+    ctx->st.launches += 2 + P.nodes.size();
+    ctx->st.rounds += P.rounds;
+    if (!single) {
+        HIPCHK(hipEventRecord(P.ev_root, ctx->stream));
+        for (int q = 1; q < 4; ++q) HIPCHK(hipStreamWaitEvent(P.streams[q], P.ev_root, 0));
+    }
+    for (auto &nd : P.nodes) {
+        hipStream_t st = single ? ctx->stream : P.streams[nd.stream];
+        if (!single) for (int d : nd.deps) if (P.nodes[d].stream != nd.stream) HIPCHK(hipStreamWaitEvent(st, P.nodes[d].ev, 0));
+        const bool prof = single && ctx->profiling && nd.kind == NK_SF && ctx->ev_used < ctx->ev_pool.size();
+        if (prof) hipEventRecord(ctx->ev_pool[ctx->ev_used].a, st);
+        launch_node(P, nd, st);
+        if (prof) { hipEventRecord(ctx->ev_pool[ctx->ev_used].b, st); ctx->ev_pool[ctx->ev_used++].bytes = nd.bytes; }
+        if (!single && nd.record) HIPCHK(hipEventRecord(nd.ev, st));
+    }
+    if (!single) {
+        for (int q = 1; q < 4; ++q) {
+            HIPCHK(hipEventRecord(P.ev_join[q], P.streams[q]));
+            HIPCHK(hipStreamWaitEvent(ctx->stream, P.ev_join[q], 0));
+        }
+    }
+    return VP_OK;
+}
+
+static int prove_gkr_fused(vp_ctx *ctx, const vp_F *tape, uint64_t n_tape, uint8_t *transcript, uint64_t *n_written) {
+    HIPCHK(hipSetDevice(ctx->device));
+    const bool use_plan = ctx->plan_path && !ctx->sumfold_path;
+    const bool serial = ctx->serial || ctx->profiling || ctx->sumfold_path;
+    F *tr = ctx->d_tr;
+    const u64 pos = ctx->n_tr;
+    ctx->ev_used = 0;
+    if (use_plan && !ctx->plan) VPCHK(build_plan(ctx));
+    HIPCHK(hipMemcpyAsync(ctx->d_tape, tape, n_tape * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
+    // The launch sequence depends on the circuit only (the tape is read on the device), so the concurrent form is
+    // captured once per circuit into a hipGraph and replayed: one submission instead of ~170, every lane starts at once.
+    if (ctx->use_graph && !serial && !ctx->gkr_graph && !ctx->graph_failed) {
+        ctx->st.launches = 0; ctx->st.rounds = 0;
+        hipGraph_t g = nullptr;
+        int rc = VP_OK;
+        if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed) != hipSuccess) rc = VP_EHIP;
+        if (rc == VP_OK) {
+            rc = use_plan ? submit_plan(ctx, false) : submit_gkr(ctx, false);
+            if (hipStreamEndCapture(ctx->stream, &g) != hipSuccess || !g) rc = rc == VP_OK ? VP_EHIP : rc;
+        }
+        if (rc == VP_OK && hipGraphInstantiate(&ctx->gkr_graph, g, nullptr, nullptr, 0) != hipSuccess) { ctx->gkr_graph = nullptr; rc = VP_EHIP; }
+        if (g) (void) hipGraphDestroy(g);
+        if (rc == VP_ELIMIT || rc == VP_EINVAL) return rc;
+        if (rc != VP_OK) { (void) hipGetLastError(); ctx->graph_failed = true; }     // run the launches directly instead
+        ctx->graph_launches = ctx->st.launches; ctx->graph_rounds = ctx->st.rounds;
+    }
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    if (ctx->use_graph && !serial && ctx->gkr_graph) {
+        HIPCHK(hipGraphLaunch(ctx->gkr_graph, ctx->stream));
+        ctx->st.launches = ctx->graph_launches; ctx->st.rounds = ctx->graph_rounds;
+    } else {
+        ctx->st.launches = 0; ctx->st.rounds = 0;
+        if (use_plan) VPCHK(submit_plan(ctx, serial)); else VPCHK(submit_gkr(ctx, serial));
     }
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
     HIPCHK(hipMemcpyAsync(transcript, tr, pos * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
