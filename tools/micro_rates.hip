@@ -65,6 +65,12 @@ __device__ __forceinline__ F f_addw(const F &a, const F &b) {
     u64 s = a.re + b.re, t = a.im + b.im;
     return f_make((s & P61) + (s >> 61), (t & P61) + (t >> 61));
 }
+__device__ __forceinline__ F f_mad_lazy_p(const F &a, const F &b, const F &c) {
+    const u128 C4 = ((u128) P61) << 63;
+    const u128 re = (u128) a.re * b.re + C4 - (u128) a.im * b.im + c.re;
+    const u128 im = (u128) a.re * b.im + (u128) a.im * b.re + c.im;
+    return f_make(m_red128(re), m_red128(im));
+}
 // the product's field multiply: 4 independent chains per lane
 template <int V> __global__ void __launch_bounds__(256) k_fmul(F *out, F seed) {
     F x[4];
@@ -81,6 +87,9 @@ template <int V> __global__ void __launch_bounds__(256) k_fmul(F *out, F seed) {
             else if (V == 5) x[j] = f_mulKw(x[j], y);
             else if (V == 6) x[j] = f_addw(x[j], y);
             else if (V == 7) x[j] = f_sub(x[j], y);
+            else if (V == 8) x[j] = f_mad_lazy_p(x[j], y, x[(j + 1) & 3]);
+            else if (V == 9) x[j] = f_mad31(x[j], y, x[(j + 1) & 3]);
+            else if (V == 10) x[j] = f_mad31(x[j], y, f_zero());
         }
     }
     F s = f_zero();
@@ -105,10 +114,10 @@ int main() {
         double winst = (double) blocks * 4 * ITER * 8; double cyc = ms * 1e-3 * ghz * 1e9 * cus * 4 / winst; \
         printf("%-24s %8.3f ms  %6.2f cycles per wave-instruction per SIMD\n", names[OP], ms, cyc); }
     RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9)
-    const char *fn[] = {"f_mul", "f_lerp", "f_add", "f_mul4 (schoolbook)", "f_mul4w (weak red)", "f_mulKw (karatsuba weak)", "f_addw (weak)", "f_sub"};
+    const char *fn[] = {"f_mul", "f_lerp", "f_add", "f_mul4 (schoolbook)", "f_mul4w (weak red)", "f_mulKw (karatsuba weak)", "f_addw (weak)", "f_sub", "f_mad_lazy (a*b+c, 128-bit)", "f_mad31 (a*b+c)", "f_mad31 (a*b)"};
 #define RUNF(V) { double ms = time_ms([&] { hipLaunchKernelGGL(k_fmul<V>, dim3(blocks), dim3(256), 0, 0, of, f_make(123456789123ull, 987654321987ull)); }); \
         double ops = (double) blocks * 256 * ITER * 4; double cyc = ms * 1e-3 * ghz * 1e9 * cus * 4 / (ops / 64); \
         printf("%-24s %8.3f ms  %7.1f SIMD-cycles per wave-op   %.3e ops/s\n", fn[V], ms, cyc, ops / (ms * 1e-3)); }
-    RUNF(0) RUNF(1) RUNF(2) RUNF(3) RUNF(4) RUNF(5) RUNF(6) RUNF(7)
+    RUNF(0) RUNF(1) RUNF(2) RUNF(3) RUNF(4) RUNF(5) RUNF(6) RUNF(7) RUNF(8) RUNF(9) RUNF(10)
     return 0;
 }

@@ -18,7 +18,7 @@ namespace vp {
 #define VP_MAX_TAB 64          // max bookkeeping-table families per sumcheck (= max circuit depth)
 #define VP_BLOCK 256
 #define VP_LIGHT_MAX 16        // rows with more contributions than this go through the chunked path
-#define VP_CHUNK 2048          // contributions per wave in the chunked path
+#define VP_CHUNK 512           // contributions per wave in the chunked path (8 per lane: short chains, many waves)
 
 enum { T_MUL = 0, T_ADD, T_SUB, T_ANTISUB, T_NAAB, T_ANTINAAB, T_INPUT, T_MULC, T_ADDC, T_XOR, T_NOT, T_COPY };
 
@@ -787,18 +787,11 @@ __global__ void __launch_bounds__(VP_BLOCK, MINW) k_sumfold(SfArgs a) {
 //
 // Lazy arithmetic used below (values are limbs of F):
 //   d = x1 + p - x0            in [0, 2p]           (x0, x1 canonical)
-//   a*b + c  with a, b in [0, 2p], c in [0, p]:  re = a.re*b.re + 4p*2^61 - a.im*b.im + c.re < 2^125,
-//                                                im = a.re*b.im + a.im*b.re + c.im          < 2^125,
-//   both inside m_red128's domain; every stored value is canonical, so results are bit-identical to the
-//   strict sequence.
+//   a*b + c  with a, b in [0, 2p], c in [0, p]:  f_mad31 (vp_field.h), canonical result; every stored value
+//   is canonical, so results are bit-identical to the strict sequence.
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ F f_sub_lazy(const F &a, const F &b) { return f_make(a.re + P61 - b.re, a.im + P61 - b.im); }
-__device__ __forceinline__ F f_mad_lazy(const F &a, const F &b, const F &c) {
-    const u128 C4 = ((u128) P61) << 63;
-    const u128 re = (u128) a.re * b.re + C4 - (u128) a.im * b.im + c.re;
-    const u128 im = (u128) a.re * b.im + (u128) a.im * b.re + c.im;
-    return f_make(m_red128(re), m_red128(im));
-}
+__device__ __forceinline__ F f_mad_lazy(const F &a, const F &b, const F &c) { return f_mad31(a, b, c); }
 struct Lz { u64 re, im; };                                           // unreduced sum of canonical values
 __device__ __forceinline__ void lz_add(Lz &s, const F &x) { s.re += x.re; s.im += x.im; }
 __device__ __forceinline__ void lz_fold(Lz &s) { s.re = (s.re & P61) + (s.re >> 61); s.im = (s.im & P61) + (s.im >> 61); }
@@ -1361,15 +1354,17 @@ __global__ void __launch_bounds__(VP_EMIT_THREADS) k_emit(EmitArgs a) {
 // independent sumchecks per proof, batching them side by side is what fills the chip.
 // ---------------------------------------------------------------------------------------------------
 struct BlkMap { u32 job, bid; };
-struct LightJob { InitArgs2 a; int phase; int pad; };
+struct GatherJob { const u32 *rowptr; const uint8_t *e_q; const u32 *e_g; const Half *H; F *M; u32 size; int pad; };
+struct LightJob { InitArgs2 a; GatherJob g; int phase; int pad; };     // phase 0: Liu gather (g), 1 / 2: phase inits (a)
 struct ChunkJob { InitArgs2 a; const u32 *chunk_beg; const u32 *chunk_end; F *part; u32 n_chunks; int phase; };
 struct CombineJob { const u32 *heavy_row; const u32 *heavy_cptr; const F *part; F *M; F *A; u32 n_heavy; int pad; };
-struct GatherJob { const u32 *rowptr; const uint8_t *e_q; const u32 *e_g; const Half *H; F *M; u32 size; int pad; };
 
 __global__ void __launch_bounds__(VP_BLOCK) k_light_multi(const LightJob *__restrict__ jobs, const BlkMap *__restrict__ map) {
     const BlkMap m = map[blockIdx.x];
     const LightJob &j = jobs[m.job];
-    if (j.phase == 1) init2_light_body<1>(j.a, m.bid); else init2_light_body<2>(j.a, m.bid);
+    if (j.phase == 1) init2_light_body<1>(j.a, m.bid);
+    else if (j.phase == 2) init2_light_body<2>(j.a, m.bid);
+    else liu_gather_body(j.g.rowptr, j.g.e_q, j.g.e_g, j.g.H, j.g.size, j.g.M, m.bid);
 }
 __global__ void __launch_bounds__(VP_BLOCK) k_chunks_multi(const ChunkJob *__restrict__ jobs, const BlkMap *__restrict__ map) {
     const BlkMap m = map[blockIdx.x];
@@ -1381,11 +1376,6 @@ __global__ void __launch_bounds__(VP_BLOCK) k_combine_multi(const CombineJob *__
     const BlkMap m = map[blockIdx.x];
     const CombineJob &j = jobs[m.job];
     init_combine_body(j.heavy_row, j.heavy_cptr, j.n_heavy, j.part, j.M, j.A, m.bid);
-}
-__global__ void __launch_bounds__(VP_BLOCK) k_gather_multi(const GatherJob *__restrict__ jobs, const BlkMap *__restrict__ map) {
-    const BlkMap m = map[blockIdx.x];
-    const GatherJob &j = jobs[m.job];
-    liu_gather_body(j.rowptr, j.e_q, j.e_g, j.H, j.size, j.M, m.bid);
 }
 __global__ void __launch_bounds__(VP_BLOCK, 4) k_sumfold3b_multi(const SfArgs *__restrict__ jobs, const BlkMap *__restrict__ map) {
     __shared__ Sf3bLds sm;

@@ -69,10 +69,10 @@ struct Lane {
 
 // Batched launch plan of the GKR part (see vp_kernels.h "Batched launches"): recorded once per circuit by running the
 // per-sumcheck drivers in record mode (same code that launches directly on the lane path), then merged step by step.
-enum { NK_LIGHT = 0, NK_GATHER, NK_CHUNKS, NK_COMBINE, NK_SF, NK_SEG, NK_EMIT, NK_COUNT };
+enum { NK_LIGHT = 0, NK_CHUNKS, NK_COMBINE, NK_SF, NK_SEG, NK_EMIT, NK_COUNT };
 struct PStep { int kind; u32 idx, grid, lds; u64 bytes; int rounds; };
 struct PlanRec {
-    std::vector<LightJob> light; std::vector<GatherJob> gather; std::vector<ChunkJob> chunks; std::vector<CombineJob> combine;
+    std::vector<LightJob> light; std::vector<ChunkJob> chunks; std::vector<CombineJob> combine;
     std::vector<SfArgs> sf; std::vector<SegArgs> seg; std::vector<EmitArgs> emit;
     std::vector<std::vector<PStep>> chains; int cur = -1;
     void push(int kind, u32 idx, u32 grid, u32 lds = 0, u64 bytes = 0) { chains[cur].push_back(PStep{kind, idx, grid, lds, bytes, 0}); }
@@ -81,7 +81,7 @@ struct PNode { int kind = 0, step = 0, stream = 0; u32 first = 0, count = 0, gri
                std::vector<int> deps; hipEvent_t ev = nullptr; bool record = false; };
 struct Plan {
     std::vector<PNode> nodes;
-    LightJob *d_light = nullptr; GatherJob *d_gather = nullptr; ChunkJob *d_chunks = nullptr; CombineJob *d_combine = nullptr;
+    LightJob *d_light = nullptr; ChunkJob *d_chunks = nullptr; CombineJob *d_combine = nullptr;
     SfArgs *d_sf = nullptr; SegArgs *d_seg = nullptr; EmitArgs *d_emit = nullptr; BlkMap *d_map = nullptr;
     hipStream_t streams[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_root = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -1102,7 +1102,7 @@ int run_sumcheck_seg(vp_ctx *ctx, const FusedSumcheck &sc) {
             }
             a.n_tab = nt; a.total_chunks = chunks;
             static const int sf3b = getenv("VP_SF3B") ? atoi(getenv("VP_SF3B")) : 1;
-            static const u32 sf3b_grid = getenv("VP_SF3B_GRID") ? (u32) atoi(getenv("VP_SF3B_GRID")) : MAX_BLOCKS;
+            static const u32 sf3b_grid = getenv("VP_SF3B_GRID") ? (u32) atoi(getenv("VP_SF3B_GRID")) : 512;
             const u32 grid = (sf3b || ctx->rec) ? std::max<u32>(1, std::min<u32>(chunks, std::min<u32>(sf3b_grid, MAX_BLOCKS)))
                                   : std::max<u32>(1, std::min<u32>((chunks + 3) / 4, MAX_BLOCKS));
             a.part = new_part(k, 3, grid); a.part_stride = grid * 3;
@@ -1251,8 +1251,9 @@ static int submit_gkr(vp_ctx *ctx, bool serial) {
             ctx->ln = serial ? main_lane : &ctx->lanes[2 * (i - 1) + 1];
             if (ctx->rec) {
                 ctx->rec->cur = 2 * (i - 1) + 1;
-                GatherJob j{}; j.rowptr = cur.lrow; j.e_q = cur.l_q; j.e_g = cur.l_g; j.H = cur.liu_H; j.M = ctx->ln->tab[0][1]; j.size = (u32) pre.size;
-                ctx->rec->gather.push_back(j); ctx->rec->push(NK_GATHER, (u32) ctx->rec->gather.size() - 1, nblk(pre.size));
+                LightJob j{}; j.phase = 0;
+                j.g.rowptr = cur.lrow; j.g.e_q = cur.l_q; j.g.e_g = cur.l_g; j.g.H = cur.liu_H; j.g.M = ctx->ln->tab[0][1]; j.g.size = (u32) pre.size;
+                ctx->rec->light.push_back(j); ctx->rec->push(NK_LIGHT, (u32) ctx->rec->light.size() - 1, nblk(pre.size));
             } else
             hipLaunchKernelGGL(k_liu_gather, dim3(nblk(pre.size)), dim3(VP_BLOCK), 0, ctx->ln->stream, cur.lrow, cur.l_q,
                                cur.l_g, cur.liu_H, (u32) pre.size, ctx->ln->tab[0][1]);
@@ -1334,11 +1335,11 @@ static int build_plan(vp_ctx *ctx) {
     Plan *P = new Plan();
     ctx->plan = P;
     P->rounds = rounds;
-    static const int kind_stream[NK_COUNT] = {0, 0, 0, 0, 1, 2, 3};
+    static const int kind_stream[NK_COUNT] = {0, 0, 0, 1, 2, 3};
     size_t T = 0;
     for (auto &c : rec.chains) T = std::max(T, c.size());
     P->n_steps = (int) T;
-    std::vector<LightJob> light; std::vector<GatherJob> gather; std::vector<ChunkJob> chunks; std::vector<CombineJob> combine;
+    std::vector<LightJob> light; std::vector<ChunkJob> chunks; std::vector<CombineJob> combine;
     std::vector<SfArgs> sf; std::vector<SegArgs> seg; std::vector<EmitArgs> emit;
     std::vector<BlkMap> map;
     std::vector<std::vector<int>> node_of(rec.chains.size());          // [chain][step] -> node
@@ -1348,7 +1349,7 @@ static int build_plan(vp_ctx *ctx) {
             PNode nd; nd.kind = kind; nd.step = (int) t; nd.stream = kind_stream[kind]; nd.map_off = (u32) map.size();
             u32 first = 0;
             switch (kind) {
-                case NK_LIGHT: first = (u32) light.size(); break; case NK_GATHER: first = (u32) gather.size(); break;
+                case NK_LIGHT: first = (u32) light.size(); break;
                 case NK_CHUNKS: first = (u32) chunks.size(); break; case NK_COMBINE: first = (u32) combine.size(); break;
                 case NK_SF: first = (u32) sf.size(); break; case NK_SEG: first = (u32) seg.size(); break;
                 default: first = (u32) emit.size(); break;
@@ -1359,7 +1360,7 @@ static int build_plan(vp_ctx *ctx) {
                 const PStep &st = rec.chains[c][t];
                 const u32 job = first + nd.count;
                 switch (kind) {
-                    case NK_LIGHT: light.push_back(rec.light[st.idx]); break; case NK_GATHER: gather.push_back(rec.gather[st.idx]); break;
+                    case NK_LIGHT: light.push_back(rec.light[st.idx]); break;
                     case NK_CHUNKS: chunks.push_back(rec.chunks[st.idx]); break; case NK_COMBINE: combine.push_back(rec.combine[st.idx]); break;
                     case NK_SF: sf.push_back(rec.sf[st.idx]); break; case NK_SEG: seg.push_back(rec.seg[st.idx]); break;
                     default: emit.push_back(rec.emit[st.idx]); break;
@@ -1380,7 +1381,7 @@ static int build_plan(vp_ctx *ctx) {
     for (auto &nd : P->nodes) HIPCHK(hipEventCreateWithFlags(&nd.ev, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&P->ev_root, hipEventDisableTiming));
     for (int q = 0; q < 4; ++q) HIPCHK(hipEventCreateWithFlags(&P->ev_join[q], hipEventDisableTiming));
-    VPCHK(dupload(ctx, &P->d_light, light)); VPCHK(dupload(ctx, &P->d_gather, gather)); VPCHK(dupload(ctx, &P->d_chunks, chunks));
+    VPCHK(dupload(ctx, &P->d_light, light)); VPCHK(dupload(ctx, &P->d_chunks, chunks));
     VPCHK(dupload(ctx, &P->d_combine, combine)); VPCHK(dupload(ctx, &P->d_sf, sf)); VPCHK(dupload(ctx, &P->d_seg, seg));
     VPCHK(dupload(ctx, &P->d_emit, emit)); VPCHK(dupload(ctx, &P->d_map, map));
     P->streams[0] = ctx->stream;
@@ -1392,7 +1393,6 @@ static void launch_node(const Plan &P, const PNode &nd, hipStream_t st) {
     const BlkMap *mp = P.d_map + nd.map_off;
     switch (nd.kind) {
         case NK_LIGHT: hipLaunchKernelGGL(k_light_multi, dim3(nd.grid), dim3(VP_BLOCK), 0, st, P.d_light + nd.first, mp); break;
-        case NK_GATHER: hipLaunchKernelGGL(k_gather_multi, dim3(nd.grid), dim3(VP_BLOCK), 0, st, P.d_gather + nd.first, mp); break;
         case NK_CHUNKS: hipLaunchKernelGGL(k_chunks_multi, dim3(nd.grid), dim3(VP_BLOCK), 0, st, P.d_chunks + nd.first, mp); break;
         case NK_COMBINE: hipLaunchKernelGGL(k_combine_multi, dim3(nd.grid), dim3(VP_BLOCK), 0, st, P.d_combine + nd.first, mp); break;
         case NK_SF: hipLaunchKernelGGL(k_sumfold3b_multi, dim3(nd.grid), dim3(VP_BLOCK), 0, st, P.d_sf + nd.first, mp); break;
@@ -1451,12 +1451,17 @@ static int prove_gkr_fused(vp_ctx *ctx, const vp_F *tape, uint64_t n_tape, uint8
         ctx->st.launches = 0; ctx->st.rounds = 0;
         hipGraph_t g = nullptr;
         int rc = VP_OK;
+        static const bool dbg = getenv("VP_DEBUG") != nullptr;
+        if (dbg) fprintf(stderr, "[vp] capture begin\n");
         if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed) != hipSuccess) rc = VP_EHIP;
         if (rc == VP_OK) {
             rc = use_plan ? submit_plan(ctx, false) : submit_gkr(ctx, false);
+            if (dbg) fprintf(stderr, "[vp] submitted rc=%d\n", rc);
             if (hipStreamEndCapture(ctx->stream, &g) != hipSuccess || !g) rc = rc == VP_OK ? VP_EHIP : rc;
+            if (dbg) fprintf(stderr, "[vp] capture end rc=%d g=%p\n", rc, (void *) g);
         }
         if (rc == VP_OK && hipGraphInstantiate(&ctx->gkr_graph, g, nullptr, nullptr, 0) != hipSuccess) { ctx->gkr_graph = nullptr; rc = VP_EHIP; }
+        if (dbg) fprintf(stderr, "[vp] instantiated rc=%d\n", rc);
         if (g) (void) hipGraphDestroy(g);
         if (rc == VP_ELIMIT || rc == VP_EINVAL) return rc;
         if (rc != VP_OK) { (void) hipGetLastError(); ctx->graph_failed = true; }     // run the launches directly instead
