@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+PMC_SUMMARY = "r01_e_pmc_summary_b64.json"   # made by tools/pmc_summary.py from three rocprofv3 --pmc passes of this script
 
 
 def dist_setup(n_gpus):
@@ -232,15 +233,15 @@ def main():
                 gbps = res["fold_bytes"] / (res["fold_ms"] * 1e-3) / 1e9
                 traffic = None
                 try:        # PMC pass of the same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs), committed summary
-                    pm = json.load(open(os.path.join(ROOT, "profiles", "r01_b_pmc_summary_b64.json")))
+                    pm = json.load(open(os.path.join(ROOT, "profiles", PMC_SUMMARY)))
                     if a.blocks == 64:
-                        traffic = pm["k_sumfold3_avg_hbm_bytes_per_launch"]
+                        traffic = pm["sumfold_avg_hbm_bytes_per_launch"]
                 except Exception:
                     pass
                 line["roofline"] = {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                     "frac": gbps / HBM_PEAK_GBPS, "traffic": traffic,
-                                    "traffic_source": "profiles/r01_b_pmc_summary_b64.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)" if traffic else None,
-                                    "kernel": "k_sumfold<3> (every launch; single-stream replay of the same proof)",
+                                    "traffic_source": "profiles/%s (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)" % PMC_SUMMARY if traffic else None,
+                                    "kernel": "k_sumfold3b_multi (every launch; single-stream replay of the same proof)",
                                     "single_stream_proof_ms": res.get("serial_device_ms"),
                                     "launches": res["fold_launches"], "avg_launch_us": 1e3 * avg_ms,
                                     "algorithmic_bytes_per_launch": res["fold_bytes"] / res["fold_launches"]}

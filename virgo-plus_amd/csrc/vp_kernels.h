@@ -810,14 +810,18 @@ __device__ __forceinline__ void sf_pair_step(const F &v0, const F &v1, const F &
     if (HAS_A) ao = f_mad_lazy(r, f_sub_lazy(a1, a0), a0);
 }
 
-struct Sf3bLds { F s1[3][256]; F s2[3][128]; F red[4][9]; };
+struct Sf3bLds { F s1[3][256]; F s2[3][128]; F red[4][9]; Lz acc2[3][128]; Lz acc3[3][64]; };   // acc2/acc3: per-thread sums of rounds k+1, k+2
 template <bool HAS_A>
 __device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb, Sf3bLds &sm) {
     F (&s1)[3][256] = sm.s1; F (&s2)[3][128] = sm.s2; F (&red)[4][9] = sm.red;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    Lz acc[9];
+    // round k sums stay in registers; those of rounds k+1 / k+2 (first two waves / first wave only) live in LDS, one
+    // private slot per thread, so that the kernel fits 128 VGPRs (4 waves per SIMD) without scratch
+    Lz acc[3];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) acc[i].re = acc[i].im = 0;
+    for (int i = 0; i < 3; ++i) acc[i].re = acc[i].im = 0;
+    if (t < 128) { for (int i = 0; i < 3; ++i) { sm.acc2[i][t].re = 0; sm.acc2[i][t].im = 0; } }
+    if (t < 64) { for (int i = 0; i < 3; ++i) { sm.acc3[i][t].re = 0; sm.acc3[i][t].im = 0; } }
     const F r0 = a.r[0], r1 = a.r[1], r2 = a.r[2];
     for (u32 c = bid; c < a.total_chunks; c += nb) {
         int j = 0;
@@ -838,18 +842,24 @@ __device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb,
         __syncthreads();
         if (w < 2) {   // round k+1: 128 pairs
             F vo, mo, ao = f_zero();
+            Lz x = sm.acc2[0][t], y = sm.acc2[1][t], z = sm.acc2[2][t];
             sf_pair_step<HAS_A>(s1[0][2 * t], s1[0][2 * t + 1], s1[1][2 * t], s1[1][2 * t + 1],
                                 HAS_A ? s1[2][2 * t] : f_zero(), HAS_A ? s1[2][2 * t + 1] : f_zero(), r1,
-                                acc[3], acc[4], acc[5], vo, mo, ao);
+                                x, y, z, vo, mo, ao);
+            lz_fold(x); lz_fold(y); lz_fold(z);
+            sm.acc2[0][t] = x; sm.acc2[1][t] = y; sm.acc2[2][t] = z;
             s2[0][t] = vo; s2[1][t] = mo;
             if (HAS_A) s2[2][t] = ao;
         }
         __syncthreads();
         if (w == 0) {  // round k+2: 64 pairs, results are the folded table
             F vo, mo, ao = f_zero();
+            Lz x = sm.acc3[0][t], y = sm.acc3[1][t], z = sm.acc3[2][t];
             sf_pair_step<HAS_A>(s2[0][2 * t], s2[0][2 * t + 1], s2[1][2 * t], s2[1][2 * t + 1],
                                 HAS_A ? s2[2][2 * t] : f_zero(), HAS_A ? s2[2][2 * t + 1] : f_zero(), r2,
-                                acc[6], acc[7], acc[8], vo, mo, ao);
+                                x, y, z, vo, mo, ao);
+            lz_fold(x); lz_fold(y); lz_fold(z);
+            sm.acc3[0][t] = x; sm.acc3[1][t] = y; sm.acc3[2][t] = z;
             const u32 oi = cl * 64 + t;
             if (oi < ((td.valid + 7) >> 3)) {
                 a.outV[td.off + oi] = vo;
@@ -858,14 +868,15 @@ __device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb,
             }
         }
 #pragma unroll
-        for (int i = 0; i < 9; ++i) lz_fold(acc[i]);
+        for (int i = 0; i < 3; ++i) lz_fold(acc[i]);
     }
     // block partials: rounds k+1 and k+2 only have contributions in waves 0-1 and 0
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
         if (i >= 3 && w >= 2) break;
         if (i >= 6 && w >= 1) break;
-        const F x = wave_sum63(lz_canon(acc[i]));
+        const Lz v = i < 3 ? acc[i] : i < 6 ? sm.acc2[i - 3][t] : sm.acc3[i - 6][t];
+        const F x = wave_sum63(lz_canon(v));
         if (lane == 63) red[w][i] = x;
     }
     __syncthreads();

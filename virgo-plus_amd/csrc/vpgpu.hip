@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -105,6 +106,7 @@ struct vp_ctx {
     F *d_tape = nullptr; u64 n_tape = 0;
     F *d_tr = nullptr; u64 n_tr = 0;      // transcript in F units
     F *h_pin = nullptr;                   // pinned: [0..2] poly, [3] vres, [4..4+64) claims
+    F *h_io = nullptr; size_t h_io_cap = 0;   // pinned staging of the batched path: tape in, transcript out
     int *d_flag = nullptr;
     bool evaluated = false;
     SumcheckState sc;
@@ -446,6 +448,7 @@ void vp_destroy(vp_ctx *ctx) {
     if (ctx->ev0) (void) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void) hipEventDestroy(ctx->ev1);
     if (ctx->h_pin) (void) hipHostFree(ctx->h_pin);
+    if (ctx->h_io) (void) hipHostFree(ctx->h_io);
     for (auto st : ctx->lane_streams) (void) hipStreamDestroy(st);
     for (auto ev : ctx->lane_events) (void) hipEventDestroy(ev);
     if (ctx->ev_fork) (void) hipEventDestroy(ctx->ev_fork);
@@ -1438,13 +1441,23 @@ static int submit_plan(vp_ctx *ctx, bool single) {
 
 static int prove_gkr_fused(vp_ctx *ctx, const vp_F *tape, uint64_t n_tape, uint8_t *transcript, uint64_t *n_written) {
     HIPCHK(hipSetDevice(ctx->device));
+    static const bool dbg_t = getenv("VP_DEBUG") != nullptr;
+    const auto t_in = std::chrono::steady_clock::now();
     const bool use_plan = ctx->plan_path && !ctx->sumfold_path;
     const bool serial = ctx->serial || ctx->profiling || ctx->sumfold_path;
     F *tr = ctx->d_tr;
     const u64 pos = ctx->n_tr;
     ctx->ev_used = 0;
     if (use_plan && !ctx->plan) VPCHK(build_plan(ctx));
-    HIPCHK(hipMemcpyAsync(ctx->d_tape, tape, n_tape * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
+    // pinned staging: pageable copies would be staged synchronously by the runtime on both sides of the proof
+    if (ctx->h_io_cap < n_tape + pos) {
+        if (ctx->h_io) (void) hipHostFree(ctx->h_io);
+        ctx->h_io = nullptr; ctx->h_io_cap = 0;
+        HIPCHK(hipHostMalloc((void **) &ctx->h_io, (n_tape + pos) * sizeof(F), hipHostMallocDefault));
+        ctx->h_io_cap = n_tape + pos;
+    }
+    memcpy(ctx->h_io, tape, n_tape * sizeof(F));
+    HIPCHK(hipMemcpyAsync(ctx->d_tape, ctx->h_io, n_tape * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
     // The launch sequence depends on the circuit only (the tape is read on the device), so the concurrent form is
     // captured once per circuit into a hipGraph and replayed: one submission instead of ~170, every lane starts at once.
     if (ctx->use_graph && !serial && !ctx->gkr_graph && !ctx->graph_failed) {
@@ -1476,8 +1489,15 @@ static int prove_gkr_fused(vp_ctx *ctx, const vp_F *tape, uint64_t n_tape, uint8
         if (use_plan) VPCHK(submit_plan(ctx, serial)); else VPCHK(submit_gkr(ctx, serial));
     }
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
-    HIPCHK(hipMemcpyAsync(transcript, tr, pos * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->h_io + n_tape, tr, pos * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
+    const auto t_sub = std::chrono::steady_clock::now();
     VPCHK(check_stream(ctx));
+    if (dbg_t) {
+        const auto t_done = std::chrono::steady_clock::now();
+        fprintf(stderr, "[vp] prove_gkr host: submit %.1f us, wait %.1f us\n", std::chrono::duration<double, std::micro>(t_sub - t_in).count(),
+                std::chrono::duration<double, std::micro>(t_done - t_sub).count());
+    }
+    memcpy(transcript, ctx->h_io + n_tape, pos * sizeof(F));
     float ms = 0;
     hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
     ctx->st.gkr_ms = ms;
