@@ -84,7 +84,7 @@ struct Plan {
     std::vector<PNode> nodes;
     LightJob *d_light = nullptr; ChunkJob *d_chunks = nullptr; CombineJob *d_combine = nullptr;
     SfArgs *d_sf = nullptr; SegArgs *d_seg = nullptr; EmitArgs *d_emit = nullptr; BlkMap *d_map = nullptr;
-    hipStream_t streams[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t streams[4] = {nullptr, nullptr, nullptr, nullptr};   // [0] = ctx->stream; [1..3] owned: fold (low priority), seg, emit (high)
     hipEvent_t ev_root = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     u64 rounds = 0; int n_steps = 0;
 };
@@ -1316,6 +1316,7 @@ static void free_plan(vp_ctx *ctx) {
     for (auto &nd : ctx->plan->nodes) if (nd.ev) (void) hipEventDestroy(nd.ev);
     if (ctx->plan->ev_root) (void) hipEventDestroy(ctx->plan->ev_root);
     for (int q = 0; q < 4; ++q) if (ctx->plan->ev_join[q]) (void) hipEventDestroy(ctx->plan->ev_join[q]);
+    for (int q = 1; q < 4; ++q) if (ctx->plan->streams[q]) (void) hipStreamDestroy(ctx->plan->streams[q]);
     delete ctx->plan;                       // device arrays are owned by ctx->allocs
     ctx->plan = nullptr;
 }
@@ -1387,8 +1388,9 @@ static int build_plan(vp_ctx *ctx) {
     VPCHK(dupload(ctx, &P->d_light, light)); VPCHK(dupload(ctx, &P->d_chunks, chunks));
     VPCHK(dupload(ctx, &P->d_combine, combine)); VPCHK(dupload(ctx, &P->d_sf, sf)); VPCHK(dupload(ctx, &P->d_seg, seg));
     VPCHK(dupload(ctx, &P->d_emit, emit)); VPCHK(dupload(ctx, &P->d_map, map));
+    // streams owned by the plan (stream priorities were measured: no effect under hipGraph replay, harmful on direct submission)
     P->streams[0] = ctx->stream;
-    for (int q = 1; q < 4; ++q) P->streams[q] = ctx->lane_streams[q - 1];
+    for (int q = 1; q < 4; ++q) HIPCHK(hipStreamCreateWithFlags(&P->streams[q], hipStreamNonBlocking));
     return VP_OK;
 }
 
