@@ -1377,6 +1377,25 @@ __global__ void __launch_bounds__(VP_BLOCK) k_light_multi(const LightJob *__rest
     else if (j.phase == 2) init2_light_body<2>(j.a, m.bid);
     else liu_gather_body(j.g.rowptr, j.g.e_q, j.g.e_g, j.g.H, j.g.size, j.g.M, m.bid);
 }
+// V_u = V(r_u) = sum_u eq(r_u, u) * V[u] (what phase 1's last fold leaves in the V table, src/prover.cpp:494-500) as an inner
+// product: with it phase 2 of a layer no longer waits for phase 1's sumcheck, every sumcheck of the proof is independent.
+struct DotJob { Half h; const F *val; F *part; F *out; u32 size, nblk; };
+__global__ void __launch_bounds__(VP_BLOCK) k_dot_multi(const DotJob *__restrict__ jobs, const BlkMap *__restrict__ map) {
+    __shared__ F lds[4];
+    const BlkMap m = map[blockIdx.x];
+    const DotJob &j = jobs[m.job];
+    F acc[1] = {f_zero()};
+    for (u32 i = m.bid * blockDim.x + threadIdx.x; i < j.size; i += j.nblk * blockDim.x) acc[0] = f_add(acc[0], f_mul(half_at(j.h, i), j.val[i]));
+    block_sum<1>(acc, lds);
+    if (threadIdx.x == 0) j.part[m.bid] = acc[0];
+}
+__global__ void __launch_bounds__(64) k_dotfin_multi(const DotJob *__restrict__ jobs) {
+    const DotJob &j = jobs[blockIdx.x];
+    F x = f_zero();
+    for (u32 i = threadIdx.x; i < j.nblk; i += 64) x = f_add(x, j.part[i]);
+    x = wave_sum63(x);
+    if (threadIdx.x == 63) *j.out = x;
+}
 __global__ void __launch_bounds__(VP_BLOCK) k_chunks_multi(const ChunkJob *__restrict__ jobs, const BlkMap *__restrict__ map) {
     const BlkMap m = map[blockIdx.x];
     const ChunkJob &j = jobs[m.job];

@@ -70,10 +70,10 @@ struct Lane {
 
 // Batched launch plan of the GKR part (see vp_kernels.h "Batched launches"): recorded once per circuit by running the
 // per-sumcheck drivers in record mode (same code that launches directly on the lane path), then merged step by step.
-enum { NK_LIGHT = 0, NK_CHUNKS, NK_COMBINE, NK_SF, NK_SEG, NK_EMIT, NK_COUNT };
+enum { NK_LIGHT = 0, NK_CHUNKS, NK_COMBINE, NK_DOT, NK_DOTFIN, NK_SF, NK_SEG, NK_EMIT, NK_COUNT };
 struct PStep { int kind; u32 idx, grid, lds; u64 bytes; int rounds; };
 struct PlanRec {
-    std::vector<LightJob> light; std::vector<ChunkJob> chunks; std::vector<CombineJob> combine;
+    std::vector<LightJob> light; std::vector<ChunkJob> chunks; std::vector<CombineJob> combine; std::vector<DotJob> dot;
     std::vector<SfArgs> sf; std::vector<SegArgs> seg; std::vector<EmitArgs> emit;
     std::vector<std::vector<PStep>> chains; int cur = -1;
     void push(int kind, u32 idx, u32 grid, u32 lds = 0, u64 bytes = 0) { chains[cur].push_back(PStep{kind, idx, grid, lds, bytes, 0}); }
@@ -82,7 +82,7 @@ struct PNode { int kind = 0, step = 0, stream = 0; u32 first = 0, count = 0, gri
                std::vector<int> deps; hipEvent_t ev = nullptr; bool record = false; };
 struct Plan {
     std::vector<PNode> nodes;
-    LightJob *d_light = nullptr; ChunkJob *d_chunks = nullptr; CombineJob *d_combine = nullptr;
+    DotJob *d_dot = nullptr, *d_dotfin = nullptr; LightJob *d_light = nullptr; ChunkJob *d_chunks = nullptr; CombineJob *d_combine = nullptr;
     SfArgs *d_sf = nullptr; SegArgs *d_seg = nullptr; EmitArgs *d_emit = nullptr; BlkMap *d_map = nullptr;
     hipStream_t streams[4] = {nullptr, nullptr, nullptr, nullptr};   // [0] = ctx->stream; [1..3] owned: fold (low priority), seg, emit (high)
     hipEvent_t ev_root = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -676,7 +676,7 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
             ctx->lane_streams.push_back(st); ctx->lane_events.push_back(ev);
         }
         if (!ctx->ev_fork) HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-        ctx->lanes.assign(n_lanes, Lane());
+        ctx->lanes.assign(n_lanes + (n_layers - 1), Lane());      // [n_lanes + i-1]: phase 2 of layer i when it runs as its own chain (plan path)
         F *vus = nullptr;
         VPCHK(dalloc(ctx, &vus, (size_t) n_layers));
         for (int i = 1; i < n_layers; ++i) {
@@ -692,6 +692,14 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
                 VPCHK(dalloc(ctx, &ln.part2, (size_t) 16 * MAX_BLOCKS * 3));
                 const u32 nch = h == 0 ? std::max(ctx->L[i].c1.n_chunks, ctx->L[i].c2.n_chunks) : 0;
                 VPCHK(dalloc(ctx, &ln.chunk_part, (size_t) 2 * std::max<u32>(1, nch)));
+                ln.Vu = vus + i;
+            }
+            if (ctx->L[i].max_dad_bl != -1) {
+                Lane &ln = ctx->lanes[n_lanes + (i - 1)];
+                ln.stream = ctx->stream;
+                for (int b = 0; b < 2; ++b) for (int t = 0; t < 3; ++t) VPCHK(dalloc(ctx, &ln.tab[b][t], std::max<size_t>(1, ctx->L[i].p2_total)));
+                VPCHK(dalloc(ctx, &ln.part2, (size_t) 16 * MAX_BLOCKS * 3));
+                VPCHK(dalloc(ctx, &ln.chunk_part, (size_t) 2 * std::max<u32>(1, ctx->L[i].c2.n_chunks)));
                 ln.Vu = vus + i;
             }
         }
@@ -1062,7 +1070,7 @@ int run_sumcheck_seg(vp_ctx *ctx, const FusedSumcheck &sc) {
     ea.r = sc.r; ea.part = ctx->ln->part2; ea.part_stride = 0;
     ea.n_tab = sc.n_tab; ea.rounds = sc.rounds; ea.has_a = sc.has_a; ea.emit_log = e;
     ea.poly_out = sc.poly_out; ea.claims_out = sc.claims_out;
-    ea.Vu = sc.phase == 1 ? ctx->ln->Vu : nullptr;
+    ea.Vu = (sc.phase == 1 && !ctx->rec) ? ctx->ln->Vu : nullptr;      // plan path: V_u is k_dot_multi's
     u32 cur_len[VP_MAX_TAB], cur_valid[VP_MAX_TAB];
     for (int j = 0; j < sc.n_tab; ++j) {
         cur_len[j] = sc.len0[j]; cur_valid[j] = sc.valid0[j];
@@ -1229,7 +1237,7 @@ static int submit_gkr(vp_ctx *ctx, bool serial) {
     }
     if (!serial && !ctx->rec) {
         HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
-        for (auto &ln : ctx->lanes) HIPCHK(hipStreamWaitEvent(ln.stream, ctx->ev_fork, 0));
+        for (int q = 0; q < 2 * (n - 1); ++q) HIPCHK(hipStreamWaitEvent(ctx->lanes[q].stream, ctx->ev_fork, 0));
     }
     // transcript positions (top layer first, as the verifier consumes them)
     std::vector<u64> pos_p1(n), pos_p2(n), pos_liu(n);
@@ -1286,6 +1294,16 @@ static int submit_gkr(vp_ctx *ctx, bool serial) {
         // ---- phase 2 (same lane: needs V_u) ----
         const int mdb = cur.max_dad_bl;
         if (mdb != -1) {
+            if (ctx->rec) {
+                // own chain: V_u comes from an inner product instead of phase 1's last fold
+                const int li = 2 * (n - 1) + (i - 1);
+                ctx->ln = &ctx->lanes[li]; ctx->rec->cur = li;
+                DotJob d{}; d.h = cur.hu; d.val = pre.val; d.part = ctx->ln->part2; d.out = ctx->ln->Vu; d.size = (u32) pre.size;
+                d.nblk = std::max<u32>(1, std::min<u32>(nblk(pre.size), 128));
+                ctx->rec->dot.push_back(d);
+                ctx->rec->push(NK_DOT, (u32) ctx->rec->dot.size() - 1, d.nblk);
+                ctx->rec->push(NK_DOTFIN, (u32) ctx->rec->dot.size() - 1, 1);
+            }
             InitArgs2 a{};
             a.hg = cur.hg; a.hu = cur.hu; a.vals = ctx->d_vals; a.gc = cur.gc; a.assert_r = ctx->d_tape + ctx->as_off[i];
             a.Vu = ctx->ln->Vu;
@@ -1302,7 +1320,8 @@ static int submit_gkr(vp_ctx *ctx, bool serial) {
     }
     ctx->ln = main_lane;
     if (!serial && !ctx->rec) {
-        for (auto &ln : ctx->lanes) {
+        for (int q = 0; q < 2 * (n - 1); ++q) {
+            Lane &ln = ctx->lanes[q];
             HIPCHK(hipEventRecord(ln.done, ln.stream));
             HIPCHK(hipStreamWaitEvent(ctx->stream, ln.done, 0));
         }
@@ -1339,11 +1358,11 @@ static int build_plan(vp_ctx *ctx) {
     Plan *P = new Plan();
     ctx->plan = P;
     P->rounds = rounds;
-    static const int kind_stream[NK_COUNT] = {0, 0, 0, 1, 2, 3};
+    static const int kind_stream[NK_COUNT] = {0, 0, 0, 0, 0, 1, 2, 3};
     size_t T = 0;
     for (auto &c : rec.chains) T = std::max(T, c.size());
     P->n_steps = (int) T;
-    std::vector<LightJob> light; std::vector<ChunkJob> chunks; std::vector<CombineJob> combine;
+    std::vector<LightJob> light; std::vector<ChunkJob> chunks; std::vector<CombineJob> combine; std::vector<DotJob> dot, dotfin;
     std::vector<SfArgs> sf; std::vector<SegArgs> seg; std::vector<EmitArgs> emit;
     std::vector<BlkMap> map;
     std::vector<std::vector<int>> node_of(rec.chains.size());          // [chain][step] -> node
@@ -1353,7 +1372,7 @@ static int build_plan(vp_ctx *ctx) {
             PNode nd; nd.kind = kind; nd.step = (int) t; nd.stream = kind_stream[kind]; nd.map_off = (u32) map.size();
             u32 first = 0;
             switch (kind) {
-                case NK_LIGHT: first = (u32) light.size(); break;
+                case NK_LIGHT: first = (u32) light.size(); break; case NK_DOT: first = (u32) dot.size(); break; case NK_DOTFIN: first = (u32) dotfin.size(); break;
                 case NK_CHUNKS: first = (u32) chunks.size(); break; case NK_COMBINE: first = (u32) combine.size(); break;
                 case NK_SF: first = (u32) sf.size(); break; case NK_SEG: first = (u32) seg.size(); break;
                 default: first = (u32) emit.size(); break;
@@ -1364,12 +1383,12 @@ static int build_plan(vp_ctx *ctx) {
                 const PStep &st = rec.chains[c][t];
                 const u32 job = first + nd.count;
                 switch (kind) {
-                    case NK_LIGHT: light.push_back(rec.light[st.idx]); break;
+                    case NK_LIGHT: light.push_back(rec.light[st.idx]); break; case NK_DOT: dot.push_back(rec.dot[st.idx]); break; case NK_DOTFIN: dotfin.push_back(rec.dot[st.idx]); break;
                     case NK_CHUNKS: chunks.push_back(rec.chunks[st.idx]); break; case NK_COMBINE: combine.push_back(rec.combine[st.idx]); break;
                     case NK_SF: sf.push_back(rec.sf[st.idx]); break; case NK_SEG: seg.push_back(rec.seg[st.idx]); break;
                     default: emit.push_back(rec.emit[st.idx]); break;
                 }
-                if (kind != NK_EMIT) for (u32 b = 0; b < st.grid; ++b) map.push_back(BlkMap{job - first, b});
+                if (kind != NK_EMIT && kind != NK_DOTFIN) for (u32 b = 0; b < st.grid; ++b) map.push_back(BlkMap{job - first, b});
                 nd.grid += st.grid; nd.lds = std::max(nd.lds, st.lds); nd.bytes += st.bytes; ++nd.count;
                 node_of[c][t] = (int) P->nodes.size();
                 if (t > 0 && node_of[c][t - 1] >= 0) {
@@ -1385,6 +1404,7 @@ static int build_plan(vp_ctx *ctx) {
     for (auto &nd : P->nodes) HIPCHK(hipEventCreateWithFlags(&nd.ev, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&P->ev_root, hipEventDisableTiming));
     for (int q = 0; q < 4; ++q) HIPCHK(hipEventCreateWithFlags(&P->ev_join[q], hipEventDisableTiming));
+    VPCHK(dupload(ctx, &P->d_dot, dot)); VPCHK(dupload(ctx, &P->d_dotfin, dotfin));
     VPCHK(dupload(ctx, &P->d_light, light)); VPCHK(dupload(ctx, &P->d_chunks, chunks));
     VPCHK(dupload(ctx, &P->d_combine, combine)); VPCHK(dupload(ctx, &P->d_sf, sf)); VPCHK(dupload(ctx, &P->d_seg, seg));
     VPCHK(dupload(ctx, &P->d_emit, emit)); VPCHK(dupload(ctx, &P->d_map, map));
@@ -1398,6 +1418,8 @@ static void launch_node(const Plan &P, const PNode &nd, hipStream_t st) {
     const BlkMap *mp = P.d_map + nd.map_off;
     switch (nd.kind) {
         case NK_LIGHT: hipLaunchKernelGGL(k_light_multi, dim3(nd.grid), dim3(VP_BLOCK), 0, st, P.d_light + nd.first, mp); break;
+        case NK_DOT: hipLaunchKernelGGL(k_dot_multi, dim3(nd.grid), dim3(VP_BLOCK), 0, st, P.d_dot + nd.first, mp); break;
+        case NK_DOTFIN: hipLaunchKernelGGL(k_dotfin_multi, dim3(nd.count), dim3(64), 0, st, P.d_dotfin + nd.first); break;
         case NK_CHUNKS: hipLaunchKernelGGL(k_chunks_multi, dim3(nd.grid), dim3(VP_BLOCK), 0, st, P.d_chunks + nd.first, mp); break;
         case NK_COMBINE: hipLaunchKernelGGL(k_combine_multi, dim3(nd.grid), dim3(VP_BLOCK), 0, st, P.d_combine + nd.first, mp); break;
         case NK_SF: hipLaunchKernelGGL(k_sumfold3b_multi, dim3(nd.grid), dim3(VP_BLOCK), 0, st, P.d_sf + nd.first, mp); break;
