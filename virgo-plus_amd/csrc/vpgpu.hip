@@ -1365,8 +1365,24 @@ static int build_plan(vp_ctx *ctx) {
     std::vector<LightJob> light; std::vector<ChunkJob> chunks; std::vector<CombineJob> combine; std::vector<DotJob> dot, dotfin;
     std::vector<SfArgs> sf; std::vector<SegArgs> seg; std::vector<EmitArgs> emit;
     std::vector<BlkMap> map;
-    std::vector<std::vector<int>> node_of(rec.chains.size());          // [chain][step] -> node
-    for (auto &v : node_of) v.assign(T, -1);
+    // Placement of a chain's launches on the global step axis: its init and fold launches start at step 0 (the throughput
+    // work of every chain is available to the device from the beginning), its closing k_seg / k_emit launches are aligned
+    // at the END, so that those of all chains fall into the same few steps (one node each instead of a tail of small,
+    // serialised ones).  VP_PLAN_ALIGN=left|right: everything at the start / at the end.
+    static const char *al = getenv("VP_PLAN_ALIGN");
+    const bool align_left = al && !strcmp(al, "left"), align_right = al && !strcmp(al, "right");
+    std::vector<std::vector<size_t>> pos(rec.chains.size());
+    for (size_t c = 0; c < rec.chains.size(); ++c) {
+        const auto &ch = rec.chains[c];
+        size_t suf = ch.size();
+        while (suf > 0 && (ch[suf - 1].kind == NK_SEG || ch[suf - 1].kind == NK_EMIT)) --suf;
+        if (align_left) suf = ch.size();
+        if (align_right) suf = 0;
+        pos[c].resize(ch.size());
+        for (size_t k = 0; k < ch.size(); ++k) pos[c][k] = k < suf ? k : T - (ch.size() - k);
+    }
+    std::vector<size_t> cursor(rec.chains.size(), 0);
+    std::vector<int> last_node(rec.chains.size(), -1);
     for (size_t t = 0; t < T; ++t) {
         for (int kind = 0; kind < NK_COUNT; ++kind) {
             PNode nd; nd.kind = kind; nd.step = (int) t; nd.stream = kind_stream[kind]; nd.map_off = (u32) map.size();
@@ -1379,8 +1395,9 @@ static int build_plan(vp_ctx *ctx) {
             }
             nd.first = first;
             for (size_t c = 0; c < rec.chains.size(); ++c) {
-                if (t >= rec.chains[c].size() || rec.chains[c][t].kind != kind) continue;
-                const PStep &st = rec.chains[c][t];
+                const size_t k = cursor[c];
+                if (k >= rec.chains[c].size() || pos[c][k] != t || rec.chains[c][k].kind != kind) continue;
+                const PStep &st = rec.chains[c][k];
                 const u32 job = first + nd.count;
                 switch (kind) {
                     case NK_LIGHT: light.push_back(rec.light[st.idx]); break; case NK_DOT: dot.push_back(rec.dot[st.idx]); break; case NK_DOTFIN: dotfin.push_back(rec.dot[st.idx]); break;
@@ -1390,14 +1407,14 @@ static int build_plan(vp_ctx *ctx) {
                 }
                 if (kind != NK_EMIT && kind != NK_DOTFIN) for (u32 b = 0; b < st.grid; ++b) map.push_back(BlkMap{job - first, b});
                 nd.grid += st.grid; nd.lds = std::max(nd.lds, st.lds); nd.bytes += st.bytes; ++nd.count;
-                node_of[c][t] = (int) P->nodes.size();
-                if (t > 0 && node_of[c][t - 1] >= 0) {
-                    const int d = node_of[c][t - 1];
-                    if (std::find(nd.deps.begin(), nd.deps.end(), d) == nd.deps.end()) nd.deps.push_back(d);
-                }
+                if (last_node[c] >= 0 && std::find(nd.deps.begin(), nd.deps.end(), last_node[c]) == nd.deps.end()) nd.deps.push_back(last_node[c]);
+                last_node[c] = -2 - (int) P->nodes.size();          // provisional: this node (index fixed below)
             }
             if (nd.count) P->nodes.push_back(nd);
         }
+        // advance the chains placed in this step
+        for (size_t c = 0; c < rec.chains.size(); ++c)
+            if (last_node[c] <= -2) { last_node[c] = -2 - last_node[c]; ++cursor[c]; }
     }
     for (auto &nd : P->nodes)
         for (int d : nd.deps) if (P->nodes[d].stream != nd.stream) P->nodes[d].record = true;
