@@ -1096,7 +1096,8 @@ int run_sumcheck_seg(vp_ctx *ctx, const FusedSumcheck &sc) {
         if (launch == 0) { inV = sc.V0; inM = ctx->ln->tab[0][1]; inA = ctx->ln->tab[0][2]; }
         else { F **t = ctx->ln->tab[launch & 1]; inV = t[0]; inM = t[1]; inA = t[2]; }
         F **to = ctx->ln->tab[(launch + 1) & 1];
-        const bool throughput = maxlen >= (1u << SF_BIG_LOG);
+        static const int sf_big_plan = getenv("VP_SF_BIG_LOG") ? atoi(getenv("VP_SF_BIG_LOG")) : SF_BIG_LOG;
+        const bool throughput = maxlen >= (1u << (ctx->rec ? sf_big_plan : SF_BIG_LOG));
         // ---- k_sumfold<3> on the long tables ----
         if (throughput) {
             SfArgs a{};
