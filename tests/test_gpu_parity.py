@@ -67,9 +67,10 @@ def _both_modes(vp, c, gold):
     tr3, _ = s.prove_gkr()            # idempotent: a second pass over the same resident state
     assert tr3 == gold
     s.close()
-    # the alternative batched drivers (per-round launches; shuffle-fold + single-CU tail) must agree
+    # the alternative batched drivers (per-round launches; shuffle-fold + single-CU tail; one stream per sumcheck chain
+    # instead of the batched launch plan) must agree
     import os
-    for path in ("simple", "sumfold"):
+    for path in ("simple", "sumfold", "lanes"):
         os.environ["VP_GKR_PATH"] = path
         try:
             s2 = vp.Session(c)
