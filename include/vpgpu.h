@@ -133,6 +133,12 @@ int vp_commit_public(vp_ctx *, const vp_F *pub, uint64_t n_pub, vp_F *inner_prod
  * tree, return its root.  The first call builds the virtual oracle (poly_commit.h:294-318) from the data
  * vp_commit_public left in HBM.  VP_EINVAL once the codeword is down to 32 values per slice.            */
 int vp_fri_step(vp_ctx *, const vp_F *r, uint8_t root[32]);
+/* The same n_steps calls of fri::commit_phase_step in ONE device pass (extension, like vp_prove_gkr: valid because the
+ * reference verifier's challenges do not depend on the transcript, fieldElement.cpp:119-124): r[0..n_steps) in, the
+ * n_steps Merkle roots out (32 bytes each, in step order).  Folds run back to back; the leaves of all levels are hashed
+ * by one launch and the trees are built level by level across all of them.  Must start from a fresh vp_commit_public
+ * (not after vp_fri_step); afterwards vp_fri_final / vp_fri_open behave as after n_steps vp_fri_step calls.          */
+int vp_fri_commit(vp_ctx *, const vp_F *r, int n_steps, uint8_t *roots);
 /* fri::commit_phase_final() (fri.cpp:426-431): the last codeword, 2048 elements in the reference's interleaved
  * layout [i << 7 | slice << 1 | hi], i < 16.                                                            */
 int vp_fri_final(vp_ctx *, vp_F *final_code);

@@ -276,19 +276,21 @@ def _fri_golden(golden, name):
     return r, roots, fin
 
 
+@pytest.mark.parametrize("batched", [True, False])
 @pytest.mark.parametrize("name,blocks", [("sha256_x1", 1), ("sha256_x16", 16), ("sha256_x64", 64)])
-def test_fri_commit_phase_matches_reference(vp, golden, pws_path, name, blocks):
-    """Every FRI Merkle root and the final codeword of the real reference, given its recorded fold challenges."""
+def test_fri_commit_phase_matches_reference(vp, golden, pws_path, name, blocks, batched):
+    """Every FRI Merkle root and the final codeword of the real reference, given its recorded fold challenges: all steps in
+    one device pass (vp_fri_commit) and one vp_fri_step per challenge."""
     c = vp.Circuit.from_pws(pws_path, blocks, seed=1)
     s = vp.Session(c)
     tr, ok = s.prove_full(batched=True)             # leaves l, q (-> virtual oracle) and h in HBM
     assert ok
     r, roots_gold, fin_gold = _fri_golden(golden, name)
-    roots, fin = s.fri_commit(r)
+    roots, fin = s.fri_commit(r, batched=batched)
     assert roots == roots_gold
     assert np.array_equal(fin, fin_gold)
     with pytest.raises(RuntimeError):               # the commit phase is over
-        s.fri_commit(r[:1])
+        s.fri_commit(r[:1], batched=batched)
     s.close(); c.close()
 
 

@@ -142,6 +142,7 @@ def lib_host():
         L.vph_prove_and_verify_full.argtypes = [vp, ctypes.c_int, vp, u64, ctypes.POINTER(u64)] + [ctypes.POINTER(ctypes.c_double)] * 3 + [ctypes.c_char_p, ctypes.c_int]
         L.vph_test_sha3.argtypes = [vp, vp, u64]
         L.vph_fri_commit.argtypes = [vp, vp, ctypes.c_int, vp, vp, ctypes.c_char_p, ctypes.c_int]
+        L.vph_fri_commit_batched.argtypes = [vp, vp, ctypes.c_int, vp, vp, ctypes.c_char_p, ctypes.c_int]
         L.vph_commit_private.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_double), ctypes.c_char_p, ctypes.c_int]
         L.vph_transcript_bytes.restype = u64
         L.vph_transcript_bytes.argtypes = [vp]
@@ -302,14 +303,16 @@ class Session:
             raise RuntimeError("prove_and_verify_full failed: " + err.value.decode())
         return buf.raw[: n.value], rc == 0, {"gkr_prove_sec": t[0].value, "pc_prove_sec": t[1].value, "verify_sec": t[2].value}
 
-    def fri_commit(self, r):
-        """FRI commit phase with the given fold challenges ((steps, 2) uint64): (roots bytes, final codeword (2048, 2))."""
+    def fri_commit(self, r, batched=True):
+        """FRI commit phase with the given fold challenges ((steps, 2) uint64): (roots bytes, final codeword (2048, 2)).
+        batched: all steps in one device pass (vp_fri_commit); otherwise one vp_fri_step per challenge."""
         import numpy as np
         r = np.ascontiguousarray(r, dtype=np.uint64)
         roots = ctypes.create_string_buffer(32 * r.shape[0])
         fin = np.zeros((2048, 2), dtype=np.uint64)
         err = ctypes.create_string_buffer(512)
-        rc = lib_host().vph_fri_commit(self.h, r.ctypes.data, r.shape[0], ctypes.cast(roots, ctypes.c_void_p), fin.ctypes.data, err, len(err))
+        fn = lib_host().vph_fri_commit_batched if batched else lib_host().vph_fri_commit
+        rc = fn(self.h, r.ctypes.data, r.shape[0], ctypes.cast(roots, ctypes.c_void_p), fin.ctypes.data, err, len(err))
         if rc:
             raise RuntimeError("fri_commit failed: " + err.value.decode())
         return roots.raw, fin

@@ -1564,6 +1564,49 @@ k_leaf_hash(const F *__restrict__ cw, u32 N, int n_slices, Dig *__restrict__ lea
 }
 
 // One Merkle level (merkle_tree.cpp:40-50): parent[i] = H(child[2i] || child[2i+1]); heap layout, root at index 1.
+// Batched commit phase (vp_fri_commit): with every challenge known up front the folds of all levels run back to back, and
+// ONE launch hashes the leaves of all levels — the 65 chained Keccak-f of a leaf are a fixed latency (~0.8 ms for a lone
+// wave) that the per-step path pays once per level.
+#define VP_FRI_MAX 32
+struct FriLeafArgs { const F *cw[VP_FRI_MAX]; Dig *leaves[VP_FRI_MAX]; u32 N[VP_FRI_MAX]; u32 blk_start[VP_FRI_MAX + 1]; int n; };
+__global__ void __launch_bounds__(VP_BLOCK) k_leaf_hash_multi(FriLeafArgs a) {
+    int j = 0;
+    while (j + 1 < a.n && blockIdx.x >= a.blk_start[j + 1]) ++j;
+    const u32 t = (blockIdx.x - a.blk_start[j]) * blockDim.x + threadIdx.x;
+    const u32 N = a.N[j], halfN = N >> 1;
+    if (t >= 32 * halfN) return;
+    const u32 p = t % halfN, b = t / halfN;
+    const F *cw = a.cw[j];
+    Dig h; h.w[0] = h.w[1] = h.w[2] = h.w[3] = 0;
+    for (int s = 0; s < 64; ++s) {
+        const F *row = cw + ((size_t) s * 32 + b) * N;
+        const F x = row[p], y = row[p + halfN];
+        h = hhash64(x.re, x.im, y.re, y.im, h);
+    }
+    h = hhash64(0, 0, 0, 0, h);
+    a.leaves[j][32 * p + b] = h;
+}
+struct MerkleArgs { Dig *tree[VP_FRI_MAX]; u32 count[VP_FRI_MAX]; u32 blk_start[VP_FRI_MAX + 1]; int n; };
+__global__ void __launch_bounds__(VP_BLOCK) k_merkle_level_multi(MerkleArgs a) {
+    int j = 0;
+    while (j + 1 < a.n && blockIdx.x >= a.blk_start[j + 1]) ++j;
+    const u32 i = (blockIdx.x - a.blk_start[j]) * blockDim.x + threadIdx.x, c = a.count[j];
+    if (i >= c) return;
+    Dig *tree = a.tree[j];
+    const Dig l = tree[2 * (c + i)], r = tree[2 * (c + i) + 1];
+    tree[c + i] = hhash64(l.w[0], l.w[1], l.w[2], l.w[3], r);
+}
+__global__ void __launch_bounds__(VP_BLOCK) k_merkle_top_multi(MerkleArgs a, Dig *roots) {     // one workgroup per tree
+    Dig *tree = a.tree[blockIdx.x];
+    for (u32 c = a.count[blockIdx.x] >> 1; c >= 1; c >>= 1) {
+        for (u32 i = threadIdx.x; i < c; i += blockDim.x) {
+            const Dig l = tree[2 * (c + i)], r = tree[2 * (c + i) + 1];
+            tree[c + i] = hhash64(l.w[0], l.w[1], l.w[2], l.w[3], r);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) roots[blockIdx.x] = tree[1];
+}
 __global__ void __launch_bounds__(VP_BLOCK) k_merkle_level(Dig *tree, u32 level_start, u32 count) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;

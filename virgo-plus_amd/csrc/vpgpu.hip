@@ -124,6 +124,7 @@ struct vp_ctx {
     F *pc_pub = nullptr, *pc_qcw = nullptr, *pc_hcw = nullptr, *pc_tmp = nullptr, *pc_small = nullptr; Dig *pc_tree_h = nullptr; bool pc_private_done = false;
     F *pc_scr = nullptr; size_t pc_scr_cap = 0;
     F *pc_fri_all = nullptr; std::vector<size_t> fri_cw_off, fri_tree_off; F *pc_open_buf = nullptr;
+    Dig *pc_fri_roots = nullptr;
     F *pc_fri[2] = {nullptr, nullptr}; Dig *pc_fri_tree = nullptr; int fri_step = -1; size_t fri_tree_used = 0; bool pc_public_done = false;
 
     F *part2 = nullptr;                  // [32][MAX_BLOCKS*3] block partials of the batched path
@@ -472,7 +473,7 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
     ctx->pc_rt = ctx->pc_coef = ctx->pc_cw = nullptr; ctx->pc_tree = nullptr; ctx->pc_lm = -1;
     ctx->pc_pub = ctx->pc_qcw = ctx->pc_hcw = ctx->pc_tmp = ctx->pc_small = nullptr; ctx->pc_tree_h = nullptr; ctx->pc_private_done = false;
     ctx->pc_scr = nullptr; ctx->pc_scr_cap = 0; ctx->pc_fri_all = nullptr; ctx->pc_open_buf = nullptr; ctx->fri_cw_off.clear(); ctx->fri_tree_off.clear();
-    ctx->pc_fri[0] = ctx->pc_fri[1] = nullptr; ctx->pc_fri_tree = nullptr; ctx->fri_step = -1; ctx->pc_public_done = false;
+    ctx->pc_fri[0] = ctx->pc_fri[1] = nullptr; ctx->pc_fri_tree = nullptr; ctx->pc_fri_roots = nullptr; ctx->fri_step = -1; ctx->pc_public_done = false;
     int max_bl = 0;
     for (int i = 0; i < n_layers; ++i) {
         if (ld[i].size == 0 || ld[i].size > (1ull << 30) || ld[i].bit_length < 0 || ld[i].bit_length > 30 ||
@@ -1765,6 +1766,78 @@ int vp_fri_step(vp_ctx *ctx, const vp_F *r, uint8_t root[32]) {
     VPCHK(check_stream(ctx));
     ctx->fri_tree_used += 2 * (size_t) n_leaves;
     ctx->fri_step = k + 1;
+    float ms = 0;
+    hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+    ctx->commit_ms = ms;
+    return VP_OK;
+}
+
+int vp_fri_commit(vp_ctx *ctx, const vp_F *r, int n_steps, uint8_t *roots) {
+    if (!ctx || !ctx->pc_public_done || !r || !roots || n_steps < 1) return VP_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int n = ctx->L[0].bl, ln = n - 6, lm = n - 1;
+    const u32 N = 1u << ln, M = 1u << lm;
+    if (ctx->fri_step >= 0 && ctx->fri_step != 0) { ctx->err = "vp_fri_commit after vp_fri_step"; return VP_EINVAL; }
+    if (n_steps > ln || n_steps > VP_FRI_MAX) { ctx->err = "too many FRI steps"; return VP_EINVAL; }
+    if (!ctx->pc_fri_all) {
+        VPCHK(dalloc(ctx, &ctx->pc_fri_all, (size_t) 64 * M));
+        VPCHK(dalloc(ctx, &ctx->pc_fri_tree, (size_t) M));
+    }
+    Dig *d_roots = nullptr;
+    if (!ctx->pc_fri_roots) VPCHK(dalloc(ctx, &ctx->pc_fri_roots, (size_t) VP_FRI_MAX));
+    d_roots = ctx->pc_fri_roots;
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    hipLaunchKernelGGL(k_pc_virtual_oracle, dim3(nblk((u64) 64 * M)), dim3(VP_BLOCK), 0, ctx->stream, ctx->pc_cw, ctx->pc_qcw,
+                       ctx->pc_hcw, ctx->pc_small + 1025 + 80, N, ctx->pc_rt, M >> 1, f_make(N, 0));
+    ctx->fri_step = 0; ctx->fri_tree_used = 0;
+    ctx->fri_cw_off.clear(); ctx->fri_tree_off.clear();
+    // folds of every level, back to back
+    FriLeafArgs la{}; MerkleArgs ma{};
+    u32 blocks = 0; size_t cw_off = 0;
+    int last_small = -1;
+    for (int k = 0; k < n_steps; ++k) {
+        const u32 Nk = N >> k, No = Nk >> 1;
+        const F *in = k == 0 ? ctx->pc_qcw : ctx->pc_fri_all + ctx->fri_cw_off[k - 1];
+        F *out = ctx->pc_fri_all + cw_off;
+        ctx->fri_cw_off.push_back(cw_off);
+        ctx->fri_tree_off.push_back(ctx->fri_tree_used);
+        F rf; memcpy(&rf, r + k, sizeof(F));
+        hipLaunchKernelGGL(k_fri_fold, dim3(nblk((u64) 64 * 32 * No)), dim3(VP_BLOCK), 0, ctx->stream, in, out, Nk, k, ctx->pc_rt, M >> 1, rf,
+                           host_inv_real(2));
+        const u32 n_leaves = 16 * No;
+        Dig *tree = ctx->pc_fri_tree + ctx->fri_tree_used;
+        ma.tree[k] = tree; ma.count[k] = n_leaves;
+        if (No >= 2) {
+            la.cw[la.n] = out; la.leaves[la.n] = tree + n_leaves; la.N[la.n] = No; la.blk_start[la.n] = blocks;
+            blocks += nblk(n_leaves); ++la.n;
+        } else last_small = k;
+        cw_off += (size_t) 64 * 32 * No;
+        ctx->fri_tree_used += 2 * (size_t) n_leaves;
+    }
+    la.blk_start[la.n] = blocks;
+    if (la.n) hipLaunchKernelGGL(k_leaf_hash_multi, dim3(blocks), dim3(VP_BLOCK), 0, ctx->stream, la);
+    if (last_small >= 0)
+        hipLaunchKernelGGL(k_leaf_hash_final, dim3(1), dim3(64), 0, ctx->stream, ctx->pc_fri_all + ctx->fri_cw_off[last_small], 64,
+                           ma.tree[last_small] + ma.count[last_small]);
+    // Merkle trees of all levels, one launch per height while some tree still has more than 512 nodes at it
+    for (;;) {
+        MerkleArgs lv{}; u32 b = 0;
+        for (int k = 0; k < n_steps; ++k) {
+            const u32 c = ma.count[k] >> 1;
+            if (c <= 512) continue;
+            lv.tree[lv.n] = ma.tree[k]; lv.count[lv.n] = c; lv.blk_start[lv.n] = b; b += nblk(c); ++lv.n;
+            ma.count[k] = c;
+        }
+        if (!lv.n) break;
+        lv.blk_start[lv.n] = b;
+        hipLaunchKernelGGL(k_merkle_level_multi, dim3(b), dim3(VP_BLOCK), 0, ctx->stream, lv);
+    }
+    ma.n = n_steps;
+    hipLaunchKernelGGL(k_merkle_top_multi, dim3(n_steps), dim3(VP_BLOCK), 0, ctx->stream, ma, d_roots);
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    HIPCHK(hipMemcpyAsync(roots, d_roots, (size_t) 32 * n_steps, hipMemcpyDeviceToHost, ctx->stream));
+    VPCHK(check_stream(ctx));
+    ctx->fri_step = n_steps;
     float ms = 0;
     hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
     ctx->commit_ms = ms;

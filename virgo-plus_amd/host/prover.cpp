@@ -174,6 +174,11 @@ prover::hhash_digest prover::friStep(const F &r) {
     check(vp_fri_step(ctx, cF(&r), d.b), "vp_fri_step");
     return d;
 }
+std::vector<prover::hhash_digest> prover::friCommit(const std::vector<F> &r) {
+    std::vector<hhash_digest> d(r.size());
+    check(vp_fri_commit(ctx, cF(r.data()), (int) r.size(), d[0].b), "vp_fri_commit");
+    return d;
+}
 std::vector<F> prover::friFinal() {
     std::vector<F> out(2048);
     check(vp_fri_final(ctx, mF(out.data())), "vp_fri_final");

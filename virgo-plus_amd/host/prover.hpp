@@ -55,6 +55,7 @@ public:
     hhash_digest commit_public(std::vector<F> &pub, F &inner_product_sum, std::vector<F> &all_sum);
     // poly_commit_prover::commit_phase pieces (vpd_verifier.cpp:44-74 -> fri::commit_phase_step / commit_phase_final)
     hhash_digest friStep(const F &r);
+    std::vector<hhash_digest> friCommit(const std::vector<F> &r);   // every step in one device pass (challenges are transcript-independent)
     std::vector<F> friFinal();                           // 2048 elements, reference layout [i << 7 | slice << 1 | hi]
     // fri::request_init_value_with_merkle (oracle 0 = l, 1 = h) / fri::request_step_commit (oracle 2 + level)
     void friOpen(int oracle, u64 leaf, std::vector<F> &values /* 130 */, std::vector<hhash_digest> &path);

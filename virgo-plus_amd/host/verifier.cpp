@@ -361,7 +361,12 @@ bool verifier::verifyPoly(const prover::hhash_digest &root_l_raw, const F &claim
     std::vector<F> fr(ln);
     std::vector<vph::hhash_digest> roots(ln);
     poly_prove_timer.start();
-    for (int k = 0; k < ln; ++k) { fr[k] = F::random(); roots[k] = dig(p->friStep(fr[k])); }
+    if (fri_batched) {          // same draws in the same order; the device runs the whole commit phase in one pass
+        for (int k = 0; k < ln; ++k) fr[k] = F::random();
+        const auto ds = p->friCommit(fr);
+        for (int k = 0; k < ln; ++k) roots[k] = dig(ds[k]);
+    } else
+        for (int k = 0; k < ln; ++k) { fr[k] = F::random(); roots[k] = dig(p->friStep(fr[k])); }
     const std::vector<F> final_code = p->friFinal();
     poly_prove_timer.stop();
     poly_timer.start();

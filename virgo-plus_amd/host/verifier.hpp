@@ -24,6 +24,7 @@ public:
     // verifyPoly = commit_public + FRI commit phase + `reps` query repetitions (vpd_verifier.cpp:76-328; the
     // reference hard-codes 33).  fullTranscript() is then merkle_root_l | GKR | merkle_root_h | input_0 | all_sum[65].
     bool verifyFull(int reps = 33);
+    bool fri_batched = true;        // FRI commit phase as one device pass (prover::friCommit) instead of one friStep per challenge
     const std::vector<uint8_t> &fullTranscript() const { return full_tr; }
     double polyVerifyTime() const { return poly_timer.elapse_sec(); }
     double polyProveTime() const { return poly_prove_timer.elapse_sec(); }

@@ -230,6 +230,15 @@ int vph_fri_commit(vph_session *s, const uint64_t *r_pairs, int n_steps, uint8_t
     return 0;
 }
 
+int vph_fri_commit_batched(vph_session *s, const uint64_t *r_pairs, int n_steps, uint8_t *roots, uint64_t *final_pairs, char *err, int errlen) {
+    vp_ctx *ctx = s->p->context();
+    int rc = vp_fri_commit(ctx, reinterpret_cast<const vp_F *>(r_pairs), n_steps, roots);
+    if (rc != VP_OK) { set_err(err, errlen, std::string("vp_fri_commit: ") + vp_last_error(ctx)); return rc; }
+    rc = vp_fri_final(ctx, reinterpret_cast<vp_F *>(final_pairs));
+    if (rc != VP_OK) { set_err(err, errlen, std::string("vp_fri_final: ") + vp_last_error(ctx)); return rc; }
+    return 0;
+}
+
 int vph_prove_full(vph_session *s, uint8_t *transcript, uint64_t capacity, uint64_t *n_written, int batched, char *err, int errlen) {
     try {
         F::init();

@@ -76,6 +76,8 @@ void vph_test_sha3(const uint8_t *in, uint8_t *out, uint64_t n);
  * fri::commit_phase_step, then commit_phase_final.  roots: 32 bytes per step; final_code: 2048 {real,img} pairs.
  * commit_public (or vph_prove_full) must have run on this session.                                       */
 int vph_fri_commit(vph_session *, const uint64_t *r_pairs, int n_steps, uint8_t *roots, uint64_t *final_pairs, char *err, int errlen);
+/* same through vp_fri_commit: every step in one device pass */
+int vph_fri_commit_batched(vph_session *, const uint64_t *r_pairs, int n_steps, uint8_t *roots, uint64_t *final_pairs, char *err, int errlen);
 /* The whole protocol of verifier::verify() up to commit_public (src/verifier.cpp:134-169,363-379), interactive
  * GKR: writes merkle_root_l | GKR slice | merkle_root_h | input_0 | all_sum[65] — the golden layout.   */
 int vph_prove_full(vph_session *, uint8_t *transcript, uint64_t capacity, uint64_t *n_written, int batched, char *err,
