@@ -364,6 +364,23 @@ def test_sha256_x256_size_independent_properties(vp, pws_path):
     s.close(); c.close()
 
 
+def test_randomize_16_20_synthetic_config(vp):
+    """BASELINE.json configs[4] / SURVEY §8d config 5: layeredCircuit::randomize(16, 20) = 16 layers of 2^20 random Mul/Add
+    gates (2^24 gates).  Too large for the oracle in test time: the interactive and the batched device proofs must be
+    byte-identical, and the host verifier (all sumcheck / Liu identities + the input-layer check) must accept."""
+    c = vp.Circuit.randomize(16, 20, seed=1)
+    s = vp.Session(c)
+    tr, res, ok = s.prove_interactive()
+    assert ok
+    s.draw_tape()
+    tr2, res2 = s.prove_gkr()
+    assert tr2 == tr
+    assert res["rounds"] == res2["rounds"]
+    ok2, _ = s.check(tr2, skip_predicates=True)
+    assert ok2
+    s.close(); c.close()
+
+
 @pytest.mark.parametrize("seed,sizes", [(1, [40, 33, 50, 17]), (2, [200, 180, 150, 300, 64, 9]), (3, [1500, 2100, 900, 4100, 700]),
                                         (4, [5, 3, 2, 1]), (5, [70000, 50000, 30000])])
 def test_all_gate_types_and_assert_gates_vs_oracle(vp, ob, seed, sizes):
