@@ -139,7 +139,9 @@ def main():
     with tempfile.TemporaryDirectory() as tmp:
         pws = unpack_pws(tmp)
         circ = vp.Circuit.from_pws(pws, a.blocks, seed=1 + rank)
+        t_up = time.perf_counter()
         sess = vp.Session(circ, device=local)            # raises without the HIP library / GPU
+        upload_sec = time.perf_counter() - t_up
         sess.draw_tape()
         for _ in range(a.warmup):
             sess.prove_gkr()
@@ -165,6 +167,16 @@ def main():
         for key in ("fold_ms", "fold_launches", "fold_bytes"):
             res[key] = res_p[key]
         res["serial_device_ms"] = res_p["gkr_device_ms"]
+
+        interactive = None
+        if rank == 0:
+            # the drop-in path of the reference's own call pattern (one vp_round per verifier message), outside the timed region
+            t_i = time.perf_counter()
+            tr_i, res_i, ok_i = sess.prove_interactive()
+            interactive = {"prover_sec": res_i["prove_sec"], "wall_sec_with_host_verifier": time.perf_counter() - t_i,
+                           "transcript_equals_batched": tr_i == tr, "verified": ok_i,
+                           "note": "reference definition of Prove Time (sum of prover-method spans), one launch + sync per round"}
+            sess.draw_tape()
 
         pc = None
         if a.with_pc and rank == 0:
@@ -227,6 +239,7 @@ def main():
                 "prover_sec_device": 1e-3 * dev_ms / a.steps,
                 "rounds": res["rounds"], "kernel_launches_per_proof": res["launches"],
                 "bit_exact_vs_reference_golden": bit_exact, "host_verifier_accepts": ok,
+                "interactive_path": interactive, "circuit_upload_sec": upload_sec,
             }
             if res["fold_launches"]:
                 avg_ms = res["fold_ms"] / res["fold_launches"]
