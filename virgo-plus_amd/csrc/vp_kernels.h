@@ -1366,7 +1366,9 @@ __global__ void __launch_bounds__(VP_EMIT_THREADS) k_emit(EmitArgs a) {
 // ---------------------------------------------------------------------------------------------------
 struct BlkMap { u32 job, bid; };
 struct GatherJob { const u32 *rowptr; const uint8_t *e_q; const u32 *e_g; const Half *H; F *M; u32 size; int pad; };
-struct LightJob { InitArgs2 a; GatherJob g; int phase; int pad; };     // phase 0: Liu gather (g), 1 / 2: phase inits (a)
+// phase 0: Liu gather (g), 1 / 2: phase inits (a).  A phase-1 job can carry the inner product V_u = sum_u eq(r_u,u) V[u]
+// of its layer (same rows u): one more coalesced load and two multiplies in a kernel that waits on gathers anyway.
+struct LightJob { InitArgs2 a; GatherJob g; Half dot_h; const F *dot_val; F *dot_part; int phase; u32 dot_size; };
 struct ChunkJob { InitArgs2 a; const u32 *chunk_beg; const u32 *chunk_end; F *part; u32 n_chunks; int phase; };
 struct CombineJob { const u32 *heavy_row; const u32 *heavy_cptr; const F *part; F *M; F *A; u32 n_heavy; int pad; };
 
@@ -1376,6 +1378,13 @@ __global__ void __launch_bounds__(VP_BLOCK) k_light_multi(const LightJob *__rest
     if (j.phase == 1) init2_light_body<1>(j.a, m.bid);
     else if (j.phase == 2) init2_light_body<2>(j.a, m.bid);
     else liu_gather_body(j.g.rowptr, j.g.e_q, j.g.e_g, j.g.H, j.g.size, j.g.M, m.bid);
+    if (j.phase == 1 && j.dot_part) {                           // uniform per workgroup
+        __shared__ F lds[4];
+        const u32 row = m.bid * blockDim.x + threadIdx.x;
+        F acc[1] = {row < j.dot_size ? f_mul(half_at(j.dot_h, row), j.dot_val[row]) : f_zero()};
+        block_sum<1>(acc, lds);
+        if (threadIdx.x == 0) j.dot_part[m.bid] = acc[0];
+    }
 }
 // V_u = V(r_u) = sum_u eq(r_u, u) * V[u] (what phase 1's last fold leaves in the V table, src/prover.cpp:494-500) as an inner
 // product: with it phase 2 of a layer no longer waits for phase 1's sumcheck, every sumcheck of the proof is independent.
@@ -1389,12 +1398,13 @@ __global__ void __launch_bounds__(VP_BLOCK) k_dot_multi(const DotJob *__restrict
     block_sum<1>(acc, lds);
     if (threadIdx.x == 0) j.part[m.bid] = acc[0];
 }
-__global__ void __launch_bounds__(64) k_dotfin_multi(const DotJob *__restrict__ jobs) {
+__global__ void __launch_bounds__(VP_BLOCK) k_dotfin_multi(const DotJob *__restrict__ jobs) {
+    __shared__ F lds[4];
     const DotJob &j = jobs[blockIdx.x];
-    F x = f_zero();
-    for (u32 i = threadIdx.x; i < j.nblk; i += 64) x = f_add(x, j.part[i]);
-    x = wave_sum63(x);
-    if (threadIdx.x == 63) *j.out = x;
+    F acc[1] = {f_zero()};
+    for (u32 i = threadIdx.x; i < j.nblk; i += blockDim.x) acc[0] = f_add(acc[0], j.part[i]);
+    block_sum<1>(acc, lds);
+    if (threadIdx.x == 0) *j.out = acc[0];
 }
 __global__ void __launch_bounds__(VP_BLOCK) k_chunks_multi(const ChunkJob *__restrict__ jobs, const BlkMap *__restrict__ map) {
     const BlkMap m = map[blockIdx.x];

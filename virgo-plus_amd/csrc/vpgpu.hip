@@ -64,19 +64,19 @@ struct EvPair { hipEvent_t a, b; u64 bytes; };
 struct Lane {
     hipStream_t stream = nullptr;
     F *tab[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
-    F *part2 = nullptr, *chunk_part = nullptr, *Vu = nullptr;
+    F *part2 = nullptr, *chunk_part = nullptr, *Vu = nullptr, *dot_part = nullptr;
     hipEvent_t done = nullptr;
 };
 
 // Batched launch plan of the GKR part (see vp_kernels.h "Batched launches"): recorded once per circuit by running the
 // per-sumcheck drivers in record mode (same code that launches directly on the lane path), then merged step by step.
 enum { NK_LIGHT = 0, NK_CHUNKS, NK_COMBINE, NK_DOT, NK_DOTFIN, NK_SF, NK_SEG, NK_EMIT, NK_COUNT };
-struct PStep { int kind; u32 idx, grid, lds; u64 bytes; int rounds; };
+struct PStep { int kind; u32 idx, grid, lds; u64 bytes; int rounds; int xchain; };   // kind -1: placeholder step; xchain: also wait for that chain's latest node
 struct PlanRec {
     std::vector<LightJob> light; std::vector<ChunkJob> chunks; std::vector<CombineJob> combine; std::vector<DotJob> dot;
     std::vector<SfArgs> sf; std::vector<SegArgs> seg; std::vector<EmitArgs> emit;
     std::vector<std::vector<PStep>> chains; int cur = -1;
-    void push(int kind, u32 idx, u32 grid, u32 lds = 0, u64 bytes = 0) { chains[cur].push_back(PStep{kind, idx, grid, lds, bytes, 0}); }
+    void push(int kind, u32 idx, u32 grid, u32 lds = 0, u64 bytes = 0) { chains[cur].push_back(PStep{kind, idx, grid, lds, bytes, 0, -1}); }
 };
 struct PNode { int kind = 0, step = 0, stream = 0; u32 first = 0, count = 0, grid = 0, lds = 0, map_off = 0; u64 bytes = 0;
                std::vector<int> deps; hipEvent_t ev = nullptr; bool record = false; };
@@ -133,6 +133,7 @@ struct vp_ctx {
     std::vector<Lane> lanes;          // [2*(i-1)] = phases 1+2 of layer i, [2*(i-1)+1] = Liu of layer i
     std::vector<hipStream_t> lane_streams; std::vector<hipEvent_t> lane_events; hipEvent_t ev_fork = nullptr;
     PlanRec *rec = nullptr;           // non-null while the drivers run in record mode
+    DotJob rec_dot{};                 // record mode: the V_u inner product the next phase-1 init job carries
     Plan *plan = nullptr; int plan_path = 1;   // VP_GKR_PATH=lanes: one stream per sumcheck chain instead of the plan
     // hipGraph of the concurrent GKR submission (per circuit; VP_GKR_GRAPH=0 submits the launches directly)
     hipGraphExec_t gkr_graph = nullptr; int use_graph = 1; bool graph_failed = false; u64 graph_launches = 0, graph_rounds = 0;
@@ -701,6 +702,7 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
                 for (int b = 0; b < 2; ++b) for (int t = 0; t < 3; ++t) VPCHK(dalloc(ctx, &ln.tab[b][t], std::max<size_t>(1, ctx->L[i].p2_total)));
                 VPCHK(dalloc(ctx, &ln.part2, (size_t) 16 * MAX_BLOCKS * 3));
                 VPCHK(dalloc(ctx, &ln.chunk_part, (size_t) 2 * std::max<u32>(1, ctx->L[i].c2.n_chunks)));
+                VPCHK(dalloc(ctx, &ln.dot_part, (size_t) nblk(ctx->L[i - 1].size) + 1));      // V_u block partials of the phase-1 init launch
                 ln.Vu = vus + i;
             }
         }
@@ -1191,7 +1193,16 @@ int run_init2_rows(vp_ctx *ctx, const Csr &c, InitArgs2 &a) {
     a.rowptr = c.rowptr; a.e_g = c.e_g; a.e_x = c.e_x; a.e_tl = c.e_tl; a.n_rows = c.n_rows;
     if (ctx->rec) {
         PlanRec &R = *ctx->rec;
-        if (c.n_rows) { LightJob j{}; j.a = a; j.phase = PHASE; R.light.push_back(j); R.push(NK_LIGHT, (u32) R.light.size() - 1, nblk(c.n_rows)); }
+        if (c.n_rows) {
+            LightJob j{}; j.a = a; j.phase = PHASE;
+            u32 rows = c.n_rows;
+            if (PHASE == 1 && ctx->rec_dot.part) {              // the launch covers every wire of the layer, not only the rows with contributions
+                rows = std::max<u32>(rows, ctx->rec_dot.size);
+                j.dot_h = ctx->rec_dot.h; j.dot_val = ctx->rec_dot.val; j.dot_part = ctx->rec_dot.part; j.dot_size = ctx->rec_dot.size;
+                ctx->rec_dot.nblk = nblk(rows);
+            }
+            R.light.push_back(j); R.push(NK_LIGHT, (u32) R.light.size() - 1, nblk(rows));
+        }
         if (c.n_chunks) {
             ChunkJob j{}; j.a = a; j.chunk_beg = c.chunk_beg; j.chunk_end = c.chunk_end; j.part = ctx->ln->chunk_part; j.n_chunks = c.n_chunks; j.phase = PHASE;
             R.chunks.push_back(j); R.push(NK_CHUNKS, (u32) R.chunks.size() - 1, (c.n_chunks + 3) / 4);
@@ -1285,6 +1296,12 @@ static int submit_gkr(vp_ctx *ctx, bool serial) {
             InitArgs2 a{};
             a.hg = cur.hg; a.vals = ctx->d_vals; a.gc = cur.gc; a.assert_r = ctx->d_tape + ctx->as_off[i];
             a.M = ctx->ln->tab[0][1]; a.A = ctx->ln->tab[0][2];
+            ctx->rec_dot = DotJob{};
+            if (ctx->rec && cur.max_dad_bl != -1 && cur.c1.n_rows) {
+                Lane &p2 = ctx->lanes[2 * (n - 1) + (i - 1)];
+                ctx->rec_dot.h = cur.hu; ctx->rec_dot.val = pre.val; ctx->rec_dot.part = p2.dot_part;
+                ctx->rec_dot.out = p2.Vu; ctx->rec_dot.size = (u32) pre.size;
+            }
             VPCHK(run_init2_rows<1>(ctx, cur.c1, a));
             FusedSumcheck sc;
             sc.n_tab = 1; sc.rounds = pbl; sc.has_a = 1; sc.phase = 1;
@@ -1300,11 +1317,19 @@ static int submit_gkr(vp_ctx *ctx, bool serial) {
                 // own chain: V_u comes from an inner product instead of phase 1's last fold
                 const int li = 2 * (n - 1) + (i - 1);
                 ctx->ln = &ctx->lanes[li]; ctx->rec->cur = li;
-                DotJob d{}; d.h = cur.hu; d.val = pre.val; d.part = ctx->ln->part2; d.out = ctx->ln->Vu; d.size = (u32) pre.size;
-                d.nblk = std::max<u32>(1, std::min<u32>(nblk(pre.size), 128));
-                ctx->rec->dot.push_back(d);
-                ctx->rec->push(NK_DOT, (u32) ctx->rec->dot.size() - 1, d.nblk);
-                ctx->rec->push(NK_DOTFIN, (u32) ctx->rec->dot.size() - 1, 1);
+                if (ctx->rec_dot.part && ctx->rec_dot.nblk) {
+                    // the phase-1 init launch of this layer left the block partials: wait for it (placeholder step), then combine
+                    ctx->rec->dot.push_back(ctx->rec_dot);
+                    ctx->rec->chains[li].push_back(PStep{-1, 0, 0, 0, 0, 0, -1});
+                    ctx->rec->push(NK_DOTFIN, (u32) ctx->rec->dot.size() - 1, 1);
+                    ctx->rec->chains[li].back().xchain = 2 * (i - 1);
+                } else {
+                    DotJob d{}; d.h = cur.hu; d.val = pre.val; d.part = ctx->ln->part2; d.out = ctx->ln->Vu; d.size = (u32) pre.size;
+                    d.nblk = std::max<u32>(1, std::min<u32>(nblk(pre.size), 128));
+                    ctx->rec->dot.push_back(d);
+                    ctx->rec->push(NK_DOT, (u32) ctx->rec->dot.size() - 1, d.nblk);
+                    ctx->rec->push(NK_DOTFIN, (u32) ctx->rec->dot.size() - 1, 1);
+                }
             }
             InitArgs2 a{};
             a.hg = cur.hg; a.hu = cur.hu; a.vals = ctx->d_vals; a.gc = cur.gc; a.assert_r = ctx->d_tape + ctx->as_off[i];
@@ -1384,8 +1409,10 @@ static int build_plan(vp_ctx *ctx) {
         for (size_t k = 0; k < ch.size(); ++k) pos[c][k] = k < suf ? k : T - (ch.size() - k);
     }
     std::vector<size_t> cursor(rec.chains.size(), 0);
-    std::vector<int> last_node(rec.chains.size(), -1);
+    std::vector<int> last_node(rec.chains.size(), -1), pending(rec.chains.size(), -1);
     for (size_t t = 0; t < T; ++t) {
+        for (size_t c = 0; c < rec.chains.size(); ++c)            // placeholder steps only consume their slot
+            if (cursor[c] < rec.chains[c].size() && pos[c][cursor[c]] == t && rec.chains[c][cursor[c]].kind < 0) ++cursor[c];
         for (int kind = 0; kind < NK_COUNT; ++kind) {
             PNode nd; nd.kind = kind; nd.step = (int) t; nd.stream = kind_stream[kind]; nd.map_off = (u32) map.size();
             u32 first = 0;
@@ -1410,13 +1437,18 @@ static int build_plan(vp_ctx *ctx) {
                 if (kind != NK_EMIT && kind != NK_DOTFIN) for (u32 b = 0; b < st.grid; ++b) map.push_back(BlkMap{job - first, b});
                 nd.grid += st.grid; nd.lds = std::max(nd.lds, st.lds); nd.bytes += st.bytes; ++nd.count;
                 if (last_node[c] >= 0 && std::find(nd.deps.begin(), nd.deps.end(), last_node[c]) == nd.deps.end()) nd.deps.push_back(last_node[c]);
-                last_node[c] = -2 - (int) P->nodes.size();          // provisional: this node (index fixed below)
+                if (st.xchain >= 0) {
+                    const int x = last_node[st.xchain];
+                    if (x < 0) { ctx->err = "internal: plan cross dependency not placed yet"; return VP_EINVAL; }
+                    if (std::find(nd.deps.begin(), nd.deps.end(), x) == nd.deps.end()) nd.deps.push_back(x);
+                }
+                pending[c] = (int) P->nodes.size();                  // this node (pushed below); becomes last_node at the end of the step
             }
             if (nd.count) P->nodes.push_back(nd);
         }
         // advance the chains placed in this step
         for (size_t c = 0; c < rec.chains.size(); ++c)
-            if (last_node[c] <= -2) { last_node[c] = -2 - last_node[c]; ++cursor[c]; }
+            if (pending[c] >= 0) { last_node[c] = pending[c]; pending[c] = -1; ++cursor[c]; }
     }
     for (auto &nd : P->nodes)
         for (int d : nd.deps) if (P->nodes[d].stream != nd.stream) P->nodes[d].record = true;
@@ -1438,7 +1470,7 @@ static void launch_node(const Plan &P, const PNode &nd, hipStream_t st) {
     switch (nd.kind) {
         case NK_LIGHT: hipLaunchKernelGGL(k_light_multi, dim3(nd.grid), dim3(VP_BLOCK), 0, st, P.d_light + nd.first, mp); break;
         case NK_DOT: hipLaunchKernelGGL(k_dot_multi, dim3(nd.grid), dim3(VP_BLOCK), 0, st, P.d_dot + nd.first, mp); break;
-        case NK_DOTFIN: hipLaunchKernelGGL(k_dotfin_multi, dim3(nd.count), dim3(64), 0, st, P.d_dotfin + nd.first); break;
+        case NK_DOTFIN: hipLaunchKernelGGL(k_dotfin_multi, dim3(nd.count), dim3(VP_BLOCK), 0, st, P.d_dotfin + nd.first); break;
         case NK_CHUNKS: hipLaunchKernelGGL(k_chunks_multi, dim3(nd.grid), dim3(VP_BLOCK), 0, st, P.d_chunks + nd.first, mp); break;
         case NK_COMBINE: hipLaunchKernelGGL(k_combine_multi, dim3(nd.grid), dim3(VP_BLOCK), 0, st, P.d_combine + nd.first, mp); break;
         case NK_SF: hipLaunchKernelGGL(k_sumfold3b_multi, dim3(nd.grid), dim3(VP_BLOCK), 0, st, P.d_sf + nd.first, mp); break;
