@@ -154,6 +154,27 @@ k_beta_half(const F *__restrict__ r, int n, const F *__restrict__ init, F *bf, F
 // Several independent half-table builds in one launch (block b builds table b): used by the Liu init,
 // which needs one eq table per later layer (src/prover.cpp:402-414).
 struct BetaJob { const F *r; const F *init; F *bf; F *bs; int n; int pad; };
+// Closed form of the same tables: entry j = init * prod_i (bit i of j ? r_i : 1 - r_i).  No level-by-level barriers: a
+// thread owns its entries and runs <= 15 dependent multiplies (the level-synchronous build below spends ~2 us per level
+// on a barrier and a lone multiply: 25 us at the head of every proof, with the rest of the chip idle).
+__global__ void __launch_bounds__(VP_BLOCK) k_beta_half_direct(const BetaJob *__restrict__ jobs, u32 blocks_per_job) {
+    __shared__ F sr[32], snr[32];                       // r_i and 1 - r_i
+    const BetaJob jb = jobs[blockIdx.x / blocks_per_job];
+    const u32 part = blockIdx.x % blocks_per_job;
+    const int h1 = jb.n >> 1, h2 = jb.n - h1;
+    const u32 total = (1u << h1) + (1u << h2);
+    if (part * blockDim.x >= total) return;             // uniform per workgroup
+    if ((int) threadIdx.x < jb.n) { const F ri = jb.r[threadIdx.x]; sr[threadIdx.x] = ri; snr[threadIdx.x] = f_sub(f_one(), ri); }
+    __syncthreads();
+    const u32 j = part * blockDim.x + threadIdx.x;
+    if (j >= total) return;
+    const bool second = j >= (1u << h1);
+    const u32 idx = second ? j - (1u << h1) : j;
+    const int nb = second ? h2 : h1, base = second ? h1 : 0;
+    F e = second ? f_one() : *jb.init;
+    for (int i = 0; i < nb; ++i) e = f_mul(e, ((idx >> i) & 1u) ? sr[base + i] : snr[base + i]);
+    (second ? jb.bs : jb.bf)[idx] = e;
+}
 __global__ void __launch_bounds__(VP_BLOCK) k_beta_half_multi(const BetaJob *__restrict__ jobs) {
     BetaJob jb = jobs[blockIdx.x];
     const int h1 = jb.n >> 1, h2 = jb.n - h1;

@@ -118,7 +118,7 @@ struct vp_ctx {
     std::vector<EvPair> ev_pool; size_t ev_used = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<void *> allocs;
-    BetaJob *all_jobs = nullptr; u32 n_all_jobs = 0; F *half_pool = nullptr;
+    BetaJob *all_jobs = nullptr; u32 n_all_jobs = 0, beta_bpj = 1; F *half_pool = nullptr;
     // polynomial commitment
     F *pc_rt = nullptr, *pc_coef = nullptr, *pc_cw = nullptr; Dig *pc_tree = nullptr; int pc_lm = -1; double commit_ms = 0;
     F *pc_pub = nullptr, *pc_qcw = nullptr, *pc_hcw = nullptr, *pc_tmp = nullptr, *pc_small = nullptr; Dig *pc_tree_h = nullptr; bool pc_private_done = false;
@@ -632,6 +632,8 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
             at += need[q];
         }
         ctx->n_all_jobs = (u32) jobs.size();
+        ctx->beta_bpj = 1;
+        for (auto &jb : jobs) ctx->beta_bpj = std::max<u32>(ctx->beta_bpj, nblk(((u64) 1 << (jb.n >> 1)) + ((u64) 1 << (jb.n - (jb.n >> 1)))));
         VPCHK(dupload(ctx, &ctx->all_jobs, jobs));
         auto half_of = [&](int q) { Half h{}; h.bf = jobs[q].bf; h.bs = jobs[q].bs; h.h1 = jobs[q].n >> 1; return h; };
         for (int i = 1; i < n_layers; ++i) {
@@ -1373,12 +1375,21 @@ static void free_plan(vp_ctx *ctx) {
 static int build_plan(vp_ctx *ctx) {
     free_plan(ctx);
     PlanRec rec;
-    rec.chains.assign(ctx->lanes.size(), {});
+    rec.chains.assign(ctx->lanes.size() + 1, {});
     ctx->rec = &rec;
     const vp_stats keep = ctx->st;
     ctx->st.rounds = 0;
     int rc = submit_gkr(ctx, false);
     ctx->rec = nullptr;
+    {   // Vres (verifier.cpp:151) = <eq(r_0, .), output layer>: one more inner-product chain instead of a lone workgroup up front
+        LayerDev &T = ctx->L[ctx->n_layers - 1];
+        DotJob d{}; d.h = T.hg; d.val = T.val; d.part = ctx->partials; d.out = ctx->d_tr; d.size = (u32) T.size;
+        d.nblk = std::max<u32>(1, std::min<u32>(nblk(T.size), 128));
+        rec.dot.push_back(d);
+        rec.cur = (int) ctx->lanes.size();
+        rec.push(NK_DOT, (u32) rec.dot.size() - 1, d.nblk);
+        rec.push(NK_DOTFIN, (u32) rec.dot.size() - 1, 1);
+    }
     const u64 rounds = ctx->st.rounds;
     ctx->st = keep;
     if (rc != VP_OK) return rc;
@@ -1484,13 +1495,8 @@ static void launch_node(const Plan &P, const PNode &nd, hipStream_t st) {
 // bracketed with events).
 static int submit_plan(vp_ctx *ctx, bool single) {
     Plan &P = *ctx->plan;
-    const int n = ctx->n_layers;
-    hipLaunchKernelGGL(k_beta_half_multi, dim3(ctx->n_all_jobs), dim3(VP_BLOCK), 0, ctx->stream, ctx->all_jobs);
-    {
-        LayerDev &T = ctx->L[n - 1];
-        hipLaunchKernelGGL(k_vres2, dim3(1), dim3(VP_BLOCK), 0, ctx->stream, T.hg, T.val, (u32) T.size, ctx->d_tr);
-    }
-    ctx->st.launches += 2 + P.nodes.size();
+    hipLaunchKernelGGL(k_beta_half_direct, dim3(ctx->n_all_jobs * ctx->beta_bpj), dim3(VP_BLOCK), 0, ctx->stream, ctx->all_jobs, ctx->beta_bpj);
+    ctx->st.launches += 1 + P.nodes.size();
     ctx->st.rounds += P.rounds;
     if (!single) {
         HIPCHK(hipEventRecord(P.ev_root, ctx->stream));
