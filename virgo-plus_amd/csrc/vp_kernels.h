@@ -1050,7 +1050,9 @@ __global__ void __launch_bounds__(VP_TAIL_THREADS) k_tail(TailArgs a) {
 // ===================================================================================================
 namespace vp {
 
-#define VP_SEG_LOG 10
+#ifndef VP_SEG_LOG
+#define VP_SEG_LOG 10           // 1024-entry segments (120 KB of LDS, one workgroup per CU); 9 = 512 entries, two per CU, was measured: no gain
+#endif
 #define VP_SEG (1 << VP_SEG_LOG)
 #define VP_SEG_THREADS 768          // 12 waves = 4 groups x 3 roles
 #define VP_SEG_SLOTS 256            // a group covers 64 pair slots
@@ -1076,20 +1078,24 @@ struct SegArgs {
 // Round s of a 1024-entry segment has min(256, 512 >> s) active pair slots; their per-lane accumulators live in
 // LDS at racc_off(s) + slot (767 slots per role in all), so the round loop stays ROLLED: the whole kernel is a
 // few KB of code and stays in the instruction cache (the unrolled version was 62 KB and ran fetch-bound).
-__device__ __forceinline__ u32 racc_off(int s) {
-    return s == 0 ? 0u : s == 1 ? 256u : (768u - (512u >> (s - 1)));     // 0,256,512,640,704,736,752,760,764,766
+#define VP_SEG_RACC (VP_SEG_LOG >= 9 ? 256 * (VP_SEG_LOG - 9) + 512 : VP_SEG / 2)      /* slots per role: sum of racc_cnt over the rounds (+1) */
+__device__ __forceinline__ u32 racc_cnt(int s) { return min(256u, (u32) (VP_SEG / 2) >> s); }       // active pair slots of round s
+__device__ __forceinline__ u32 racc_off(int s) {                     // sum of racc_cnt over earlier rounds
+    u32 o = 0;
+    for (int q = 0; q < s; ++q) o += racc_cnt(q);
+    return o;                                                        // SEG 1024: 0,256,512,640,...,766   SEG 512: 0,256,384,...,510
 }
 
 // Wave-uniform roles, one code path: role t folds table t (0: V, 1: mult, 2: add) and computes one of the three
 // products of the pair: 0: (m1-m0)(v1-v0)   1: m0*v0   2: m1*v1.  Two multiplies per lane and pair.
-struct SegLds { F bufA[3][VP_SEG]; F bufB[3][VP_SEG / 2]; F racc[4][768]; };   // racc: [role][slot]; [3] = role 2's second sum (a0)
+struct SegLds { F bufA[3][VP_SEG]; F bufB[3][VP_SEG / 2]; F racc[4][VP_SEG_RACC]; };   // racc: [role][slot]; [3] = role 2's second sum (a0)
 template <bool HAS_A>
 __device__ __forceinline__ void seg_body(const SegArgs &a, u32 bid, u32 nb, SegLds &sm) {
-    F (&bufA)[3][VP_SEG] = sm.bufA; F (&bufB)[3][VP_SEG / 2] = sm.bufB; F (&racc)[4][768] = sm.racc;
+    F (&bufA)[3][VP_SEG] = sm.bufA; F (&bufB)[3][VP_SEG / 2] = sm.bufB; F (&racc)[4][VP_SEG_RACC] = sm.racc;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int role = __builtin_amdgcn_readfirstlane(w % 3);
     const u32 pslot = (u32) ((w / 3) * 64 + lane);
-    for (int i = tid; i < 4 * 768; i += VP_SEG_THREADS) (&racc[0][0])[i] = f_zero();
+    for (int i = tid; i < 4 * VP_SEG_RACC; i += VP_SEG_THREADS) (&racc[0][0])[i] = f_zero();
     __syncthreads();
 
     for (u32 seg = bid; seg < a.total_segs; seg += nb) {
@@ -1153,7 +1159,7 @@ __device__ __forceinline__ void seg_body(const SegArgs &a, u32 bid, u32 nb, SegL
     F *res = &bufA[0][0];                                        // [s][4]
     for (int t = w; t < a.n_rounds * 4; t += VP_SEG_THREADS / 64) {
         const int s = t >> 2, arr = t & 3;
-        const u32 cnt = min(256u, 512u >> s), o = racc_off(s);
+        const u32 cnt = racc_cnt(s), o = racc_off(s);
         F x = f_zero();
         for (u32 i = lane; i < cnt; i += 64) x = f_add(x, racc[arr][o + i]);
         x = wave_sum63(x);
