@@ -219,6 +219,12 @@ def main():
                 gold = open(os.path.join(ROOT, "tests", "golden", g["transcript"]), "rb").read()[g["gkr_slice"][0]:g["gkr_slice"][1]]
                 bit_exact = (tr == gold)
         ok, _ = sess.check(tr, skip_predicates=True)
+        verify = None
+        if rank == 0:      # the verifier's side of the same proof (outside the timed region): O(|C|) predicate loops on host vs on the GPU
+            ok_h, sec_h = sess.check(tr)
+            ok_d, sec_d = sess.check(tr, device_predicates=True)
+            verify = {"host_predicates_sec": sec_h, "device_predicates_sec": sec_d, "accepted": bool(ok_h and ok_d),
+                      "note": "verifier.cpp:50-113 on the device via vp_predicates; Liu gr / input MLE loops stay on the host"}
 
         if rank == 0:
             sec_per_proof_job = elapsed / a.steps                      # wall time of one step (all ranks in parallel)
@@ -239,7 +245,7 @@ def main():
                 "prover_sec_device": 1e-3 * dev_ms / a.steps,
                 "rounds": res["rounds"], "kernel_launches_per_proof": res["launches"],
                 "bit_exact_vs_reference_golden": bit_exact, "host_verifier_accepts": ok,
-                "interactive_path": interactive, "circuit_upload_sec": upload_sec,
+                "interactive_path": interactive, "circuit_upload_sec": upload_sec, "verifier": verify,
             }
             if res["fold_launches"]:
                 avg_ms = res["fold_ms"] / res["fold_launches"]

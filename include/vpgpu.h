@@ -150,6 +150,16 @@ int vp_fri_open(vp_ctx *, int oracle, uint64_t leaf, vp_F values[130], uint8_t *
 /* Device time of the last vp_commit_private / vp_commit_public / vp_fri_step in milliseconds (hipEvents). */
 int vp_commit_stats(vp_ctx *, double *commit_ms);
 
+/* ---- verifier side ------------------------------------------------------------------------------- */
+/* The verifier's O(|C|) wiring-predicate loops for one layer (verifier::betaInitPhase1/2, predicatePhase1/2,
+ * src/verifier.cpp:50-113) on the uploaded circuit: r_g = r_liu (bit_length(layer) entries, beta_g; assert gates scaled by
+ * assert_random), r_u (bit_length(layer-1) entries), r_v (n_v = maxDadBitLength(layer) entries, 0 when the layer has no
+ * phase 2).  out[0..5) = coeff_l[Copy], coeff_l[Not], coeff_l[Addc], coeff_l[Mulc], bias — WITHOUT the factor beta_v[0]
+ * that predicatePhase2 applies (verifier.cpp:95-96); out[5 + t*layer + l] = coeff_r[type t][l], t in the order Add, Sub,
+ * AntiSub, Mul, Naab, AntiNaab, Xor, l < layer.  n_out must be 5 + 7*layer.                                            */
+int vp_predicates(vp_ctx *, int layer, const vp_F *r_g, const vp_F *assert_random, const vp_F *r_u, const vp_F *r_v, int n_v,
+                  vp_F *out, uint64_t n_out);
+
 /* ---- measurement --------------------------------------------------------------------------------- */
 typedef struct {
     double gkr_ms;            /* device time of the last vp_prove_gkr (hipEvents on the library stream)     */

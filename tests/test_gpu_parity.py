@@ -397,6 +397,39 @@ def test_all_gate_types_and_assert_gates_vs_oracle(vp, ob, seed, sizes):
     c.close(); oc.close()
 
 
+@pytest.mark.parametrize("seed,sizes", [(2, [200, 180, 150, 300, 64, 9]), (3, [1500, 2100, 900, 4100, 700]), (4, [5, 3, 2, 1])])
+def test_device_predicates_all_gate_types(vp, seed, sizes):
+    """The verifier's wiring-predicate sums computed on the device (vp_predicates; verifier.cpp:50-113) must make the
+    host verifier accept exactly what it accepts with its own loops — circuits with every gate type and assert gates —
+    and reject a transcript with one final claim altered (the final-value check consumes all predicate sums)."""
+    import custom_circuits as cc
+    c = vp.Circuit.custom(*cc.make(seed, sizes))
+    s = vp.Session(c)
+    s.draw_tape()
+    tr, _ = s.prove_gkr()
+    ok_host, _ = s.check(tr)
+    ok_dev, _ = s.check(tr, device_predicates=True)
+    assert ok_host and ok_dev
+    bad = bytearray(tr); bad[-8] ^= 1            # last vr: only the predicate-based checks of the layers below see it
+    ok_bad_host, _ = s.check(bytes(bad))
+    ok_bad_dev, _ = s.check(bytes(bad), device_predicates=True)
+    assert not ok_bad_host and not ok_bad_dev
+    s.close(); c.close()
+
+
+def test_device_predicates_sha256_x64(vp, pws_path):
+    """64 blocks: the device predicate path accepts the proof; timing of both paths is printed by bench.py."""
+    c = vp.Circuit.from_pws(pws_path, 64, seed=1)
+    s = vp.Session(c)
+    s.draw_tape()
+    tr, _ = s.prove_gkr()
+    ok_dev, sec_dev = s.check(tr, device_predicates=True)
+    assert ok_dev
+    bad = bytearray(tr); bad[len(tr) // 2] ^= 16
+    assert not s.check(bytes(bad), device_predicates=True)[0]
+    s.close(); c.close()
+
+
 def test_violated_assert_gate_is_reported(vp):
     """The reference exits the process when an assert gate is non-zero (src/prover.cpp:18-21); the library returns
     VP_EASSERT through the host constructor instead."""

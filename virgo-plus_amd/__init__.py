@@ -317,11 +317,13 @@ class Session:
             raise RuntimeError("fri_commit failed: " + err.value.decode())
         return roots.raw, fin
 
-    def check(self, transcript, skip_predicates=False):
+    def check(self, transcript, skip_predicates=False, device_predicates=False):
+        """Replay the transcript through the host verifier: (accepted, seconds).  device_predicates: the O(|C|) wiring-predicate
+        loops (verifier.cpp:50-113) run on the GPU (vp_predicates) instead of the host."""
         sec = ctypes.c_double(0)
         buf = ctypes.create_string_buffer(bytes(transcript), len(transcript))
-        rc = lib_host().vph_check(self.h, ctypes.cast(buf, ctypes.c_void_p), len(transcript), 1 if skip_predicates else 0,
-                                  ctypes.byref(sec))
+        rc = lib_host().vph_check(self.h, ctypes.cast(buf, ctypes.c_void_p), len(transcript),
+                                  (1 if skip_predicates else 0) | (2 if device_predicates else 0), ctypes.byref(sec))
         return rc == 0, sec.value
 
     def close(self):

@@ -1413,6 +1413,43 @@ __global__ void __launch_bounds__(VP_BLOCK) k_light_multi(const LightJob *__rest
         if (threadIdx.x == 0) j.dot_part[m.bid] = acc[0];
     }
 }
+// Verifier-side wiring predicates (reference: verifier::betaInitPhase1/2 + predicatePhase1/2, src/verifier.cpp:50-113): for
+// layer i,  coeff_l[t] = sum over unary gates g of type t of beta_g[g] beta_u[u_g] (x c_g for Mulc),  bias = the Addc sum
+// x c_g,  coeff_r[t][l] = sum over binary gates of type t with second operand in layer l of beta_g[g] beta_u[u_g] beta_v[lv_g].
+// The gates of a layer are listed by bucket at upload; a wave sums a piece of <= 512 gates, a second launch adds the
+// pieces of each bucket.  flag bit 0: assert gate (beta_g scaled), bits 1-2: class (0 binary, 1 unary, 2 unary x c).
+struct PredArgs {
+    const u32 *idx; const uint8_t *flag; const u32 *chunk_beg; const u32 *chunk_end; u32 n_chunks;
+    Half hg, hu, hv;
+    const u32 *gu; const u32 *glv; const F *gc; const F *assert_r; F *part;
+};
+__global__ void __launch_bounds__(VP_BLOCK) k_pred_chunks(PredArgs a) {
+    const u32 c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (c >= a.n_chunks) return;
+    const int lane = threadIdx.x & 63;
+    F acc = f_zero();
+    for (u32 k = a.chunk_beg[c] + lane; k < a.chunk_end[c]; k += 64) {
+        const u32 g = a.idx[k];
+        const int fl = a.flag[k], cls = fl >> 1;
+        F t = f_mul(half_at(a.hg, g), half_at(a.hu, a.gu[g]));
+        if (fl & 1) t = f_mul(t, *a.assert_r);
+        if (cls == 0) t = f_mul(t, half_at(a.hv, a.glv[g]));
+        else if (cls == 2) t = f_mul(t, a.gc[g]);
+        acc = f_add(acc, t);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) a.part[c] = acc;
+}
+__global__ void __launch_bounds__(VP_BLOCK) k_pred_combine(const u32 *__restrict__ bucket_cptr, u32 n_buckets, const F *__restrict__ part, F *__restrict__ out) {
+    const u32 b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (b >= n_buckets) return;
+    const int lane = threadIdx.x & 63;
+    F acc = f_zero();
+    for (u32 c = bucket_cptr[b] + lane; c < bucket_cptr[b + 1]; c += 64) acc = f_add(acc, part[c]);
+    acc = wave_sum(acc);
+    if (lane == 0) out[b] = acc;
+}
+
 // V_u = V(r_u) = sum_u eq(r_u, u) * V[u] (what phase 1's last fold leaves in the V table, src/prover.cpp:494-500) as an inner
 // product: with it phase 2 of a layer no longer waits for phase 1's sumcheck, every sumcheck of the proof is independent.
 struct DotJob { Half h; const F *val; F *part; F *out; u32 size, nblk; };

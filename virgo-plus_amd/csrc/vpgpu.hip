@@ -46,6 +46,9 @@ struct LayerDev {
     u32 *lrow = nullptr, *l_g = nullptr; uint8_t *l_q = nullptr;
     Half hg{}, hu{};
     Half *liu_H = nullptr;
+    // verifier-side predicates (vp_predicates): gates listed by bucket, pieces of <= 512
+    u32 *p_idx = nullptr, *p_cbeg = nullptr, *p_cend = nullptr, *p_bptr = nullptr, *glv = nullptr; uint8_t *p_flag = nullptr;
+    u32 p_chunks = 0, p_buckets = 0;
 };
 
 struct SumcheckState {
@@ -132,6 +135,7 @@ struct vp_ctx {
     Lane lane0; Lane *ln = nullptr;
     std::vector<Lane> lanes;          // [2*(i-1)] = phases 1+2 of layer i, [2*(i-1)+1] = Liu of layer i
     std::vector<hipStream_t> lane_streams; std::vector<hipEvent_t> lane_events; hipEvent_t ev_fork = nullptr;
+    F *pred_r = nullptr, *pred_pool = nullptr, *pred_part = nullptr, *pred_out = nullptr; BetaJob *pred_jobs = nullptr; u32 pred_bpj = 1;   // vp_predicates scratch
     PlanRec *rec = nullptr;           // non-null while the drivers run in record mode
     DotJob rec_dot{};                 // record mode: the V_u inner product the next phase-1 init job carries
     Plan *plan = nullptr; int plan_path = 1;   // VP_GKR_PATH=lanes: one stream per sumcheck chain instead of the plan
@@ -471,6 +475,7 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
     ctx->n_layers = n_layers;
     ctx->evaluated = false;
     ctx->chunk_cap = 0;
+    ctx->pred_r = ctx->pred_pool = ctx->pred_part = ctx->pred_out = nullptr; ctx->pred_jobs = nullptr;
     ctx->pc_rt = ctx->pc_coef = ctx->pc_cw = nullptr; ctx->pc_tree = nullptr; ctx->pc_lm = -1;
     ctx->pc_pub = ctx->pc_qcw = ctx->pc_hcw = ctx->pc_tmp = ctx->pc_small = nullptr; ctx->pc_tree_h = nullptr; ctx->pc_private_done = false;
     ctx->pc_scr = nullptr; ctx->pc_scr_cap = 0; ctx->pc_fri_all = nullptr; ctx->pc_open_buf = nullptr; ctx->fri_cw_off.clear(); ctx->fri_tree_off.clear();
@@ -518,6 +523,34 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
         }
         D.n_assert = (u32) as.size();
         VPCHK(dupload(ctx, &D.assert_idx, as));
+        {   // predicate buckets: 0 Copy, 1 Not, 2 Addc, 3 Mulc (x c), 4 bias (Addc x c), 5 + tyidx * i + l for the binary types
+            static const int tyidx[12] = {3, 0, 1, 2, 4, 5, -1, -1, -1, 6, -1, -1};     // Mul Add Sub AntiSub Naab AntiNaab . . . Xor
+            const u32 nbk = 5 + 7 * (u32) i;
+            std::vector<std::vector<u32>> bk(nbk);
+            for (u32 g = 0; g < n; ++g) {
+                const int t = ty[g];
+                if (t == VP_COPY) bk[0].push_back(g);
+                else if (t == VP_NOT) bk[1].push_back(g);
+                else if (t == VP_ADDC) { bk[2].push_back(g); bk[4].push_back(g); }
+                else if (t == VP_MULC) bk[3].push_back(g);
+                else bk[5 + (u32) tyidx[t] * i + (u32) gl[g]].push_back(g);
+            }
+            std::vector<u32> pidx, cbeg, cend, bptr(1, 0), glv(n, 0);
+            std::vector<uint8_t> pflag;
+            std::vector<uint8_t> isas(n, 0);
+            for (u32 g : as) isas[g] = 1;
+            for (u32 g = 0; g < n; ++g) if (!is_unary(ty[g])) glv[g] = S.lv[g];
+            for (u32 b = 0; b < nbk; ++b) {
+                const u32 start = (u32) pidx.size();
+                const int cls = b >= 5 ? 0 : (b == 3 || b == 4) ? 2 : 1;
+                for (u32 g : bk[b]) { pidx.push_back(g); pflag.push_back((uint8_t) ((cls << 1) | isas[g])); }
+                for (u32 q = start; q < pidx.size(); q += 512) { cbeg.push_back(q); cend.push_back(std::min<u32>((u32) pidx.size(), q + 512)); }
+                bptr.push_back((u32) cbeg.size());
+            }
+            D.p_chunks = (u32) cbeg.size(); D.p_buckets = nbk;
+            VPCHK(dupload(ctx, &D.p_idx, pidx)); VPCHK(dupload(ctx, &D.p_flag, pflag)); VPCHK(dupload(ctx, &D.p_cbeg, cbeg));
+            VPCHK(dupload(ctx, &D.p_cend, cend)); VPCHK(dupload(ctx, &D.p_bptr, bptr)); VPCHK(dupload(ctx, &D.glv, glv));
+        }
         // dad subsets / phase-2 slot layout
         D.dad_size.resize(i); D.dad_bl.resize(i); D.dad_id.assign(i, nullptr); D.t_off.resize(i); D.t_len.resize(i);
         D.max_dad_bl = -1;
@@ -767,6 +800,53 @@ static int stage(vp_ctx *ctx, u64 off, const vp_F *src, u64 n) {
     if (!src || off + n > ctx->n_tape) return VP_EINVAL;
     HIPCHK(hipMemcpyAsync(ctx->d_tape + off, src, n * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
     return VP_OK;
+}
+
+int vp_predicates(vp_ctx *ctx, int layer, const vp_F *r_g, const vp_F *assert_random, const vp_F *r_u, const vp_F *r_v, int n_v,
+                  vp_F *out, uint64_t n_out) {
+    if (!ctx || layer < 1 || layer >= ctx->n_layers || !assert_random || !out) return VP_EINVAL;
+    LayerDev &D = ctx->L[layer], &pre = ctx->L[layer - 1];
+    if ((D.bl > 0 && !r_g) || (pre.bl > 0 && !r_u)) return VP_EINVAL;       // zero-variable layers have no challenges
+    if (n_v < 0 || n_v > 31 || (n_v > 0 && !r_v) || n_out != D.p_buckets) { ctx->err = "vp_predicates: bad sizes"; return VP_EINVAL; }
+    HIPCHK(hipSetDevice(ctx->device));
+    // scratch: challenges, three pairs of half tables, piece sums, bucket sums (sized for the largest layer, once)
+    if (!ctx->pred_r) {
+        u32 max_chunks = 1, max_buckets = 1;
+        for (int i = 1; i < ctx->n_layers; ++i) { max_chunks = std::max(max_chunks, ctx->L[i].p_chunks); max_buckets = std::max(max_buckets, ctx->L[i].p_buckets); }
+        VPCHK(dalloc(ctx, &ctx->pred_r, (size_t) 3 * 32 + 2));
+        VPCHK(dalloc(ctx, &ctx->pred_pool, (size_t) 3 * 2 * ((size_t) 1 << 16)));
+        VPCHK(dalloc(ctx, &ctx->pred_part, (size_t) max_chunks));
+        VPCHK(dalloc(ctx, &ctx->pred_out, (size_t) max_buckets));
+        VPCHK(dalloc(ctx, &ctx->pred_jobs, (size_t) 3));
+    }
+    const int n_g = D.bl, n_u = pre.bl;
+    if (n_g > 31 || n_u > 31) { ctx->err = "vp_predicates: layer too large"; return VP_ELIMIT; }
+    std::vector<F> h(3 * 32 + 2, f_zero());
+    if (n_g) memcpy(h.data(), r_g, (size_t) n_g * sizeof(F));
+    if (n_u) memcpy(h.data() + 32, r_u, (size_t) n_u * sizeof(F));
+    if (n_v) memcpy(h.data() + 64, r_v, (size_t) n_v * sizeof(F));
+    h[96] = f_one(); memcpy(&h[97], assert_random, sizeof(F));
+    HIPCHK(hipMemcpyAsync(ctx->pred_r, h.data(), h.size() * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
+    BetaJob jb[3];
+    const int nn[3] = {n_g, n_u, n_v};
+    Half hh[3];
+    u32 bpj = 1;
+    for (int q = 0; q < 3; ++q) {
+        jb[q].r = ctx->pred_r + 32 * q; jb[q].init = ctx->pred_r + 96; jb[q].n = nn[q]; jb[q].pad = 0;
+        jb[q].bf = ctx->pred_pool + (size_t) q * 2 * ((size_t) 1 << 16); jb[q].bs = jb[q].bf + ((size_t) 1 << (nn[q] >> 1));
+        hh[q].bf = jb[q].bf; hh[q].bs = jb[q].bs; hh[q].h1 = nn[q] >> 1; hh[q].pad = 0;
+        bpj = std::max<u32>(bpj, nblk(((u64) 1 << (nn[q] >> 1)) + ((u64) 1 << (nn[q] - (nn[q] >> 1)))));
+    }
+    HIPCHK(hipMemcpyAsync(ctx->pred_jobs, jb, sizeof(jb), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));          // h and jb are stack/heap temporaries
+    hipLaunchKernelGGL(k_beta_half_direct, dim3(3 * bpj), dim3(VP_BLOCK), 0, ctx->stream, ctx->pred_jobs, bpj);
+    PredArgs a{};
+    a.idx = D.p_idx; a.flag = D.p_flag; a.chunk_beg = D.p_cbeg; a.chunk_end = D.p_cend; a.n_chunks = D.p_chunks;
+    a.hg = hh[0]; a.hu = hh[1]; a.hv = hh[2]; a.gu = D.gu; a.glv = D.glv; a.gc = D.gc; a.assert_r = ctx->pred_r + 97; a.part = ctx->pred_part;
+    if (D.p_chunks) hipLaunchKernelGGL(k_pred_chunks, dim3((D.p_chunks + 3) / 4), dim3(VP_BLOCK), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_pred_combine, dim3((D.p_buckets + 3) / 4), dim3(VP_BLOCK), 0, ctx->stream, D.p_bptr, D.p_buckets, ctx->pred_part, ctx->pred_out);
+    HIPCHK(hipMemcpyAsync(out, ctx->pred_out, (size_t) D.p_buckets * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
+    return check_stream(ctx);
 }
 
 int vp_vres(vp_ctx *ctx, const vp_F *r_0, int r_0_size, vp_F *out) {

@@ -169,6 +169,13 @@ prover::hhash_digest prover::commit_public(std::vector<F> &pub, F &inner_product
     check(vp_commit_public(ctx, cF(pub.data()), pub.size(), mF(&inner_product_sum), mF(all_sum.data()), d.b), "vp_commit_public");
     return d;
 }
+std::vector<F> prover::predicates(int layer, const std::vector<F> &r_g, const F &assert_random, const std::vector<F> &r_u,
+                                  const std::vector<F> &r_v, int n_v) {
+    std::vector<F> out(5 + 7 * (size_t) layer);
+    check(vp_predicates(ctx, layer, cF(r_g.data()), cF(&assert_random), cF(r_u.data()), n_v ? cF(r_v.data()) : nullptr, n_v,
+                        mF(out.data()), out.size()), "vp_predicates");
+    return out;
+}
 prover::hhash_digest prover::friStep(const F &r) {
     hhash_digest d;
     check(vp_fri_step(ctx, cF(&r), d.b), "vp_fri_step");

@@ -54,6 +54,9 @@ public:
     // src/prover.cpp:542-546 (the mask argument of the reference is the one-element zero vector and is implied)
     hhash_digest commit_public(std::vector<F> &pub, F &inner_product_sum, std::vector<F> &all_sum);
     // poly_commit_prover::commit_phase pieces (vpd_verifier.cpp:44-74 -> fri::commit_phase_step / commit_phase_final)
+    // verifier-side wiring predicates of one layer on the device (vp_predicates): 5 + 7*layer sums, see include/vpgpu.h
+    std::vector<F> predicates(int layer, const std::vector<F> &r_g, const F &assert_random, const std::vector<F> &r_u,
+                              const std::vector<F> &r_v, int n_v);
     hhash_digest friStep(const F &r);
     std::vector<hhash_digest> friCommit(const std::vector<F> &r);   // every step in one device pass (challenges are transcript-independent)
     std::vector<F> friFinal();                           // 2048 elements, reference layout [i << 7 | slice << 1 | hi]

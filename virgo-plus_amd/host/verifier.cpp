@@ -200,8 +200,24 @@ bool verifier::verifyLiu(int layer_id, F &previousSum) {         // verifier.cpp
     return true;
 }
 
+// device version of predicatePhase1 + predicatePhase2: one vp_predicates call per layer
+void verifier::predicatesOnDevice(int layer_id, bool with_phase2) {
+    const layer &cur = C.circuit[layer_id];
+    const int n_v = with_phase2 ? cur.maxDadBitLength : 0;
+    std::vector<F> rg(r_liu.begin(), r_liu.begin() + cur.bitLength), ru(r_u.begin(), r_u.begin() + C.circuit[layer_id - 1].bitLength);
+    const std::vector<F> out = pred_dev->predicates(layer_id, rg, assert_random, ru, r_v[layer_id], n_v);
+    F bv0 = F_ONE;                                   // beta_v[0] = prod (1 - r_v[j]) (verifier.cpp:95-96)
+    for (int j = 0; j < n_v; ++j) bv0 = bv0 * (F_ONE - r_v[layer_id][j]);
+    coeff_l[Copy] = out[0] * bv0; coeff_l[Not] = out[1] * bv0; coeff_l[Addc] = out[2] * bv0; coeff_l[Mulc] = out[3] * bv0;
+    bias = out[4] * bv0;
+    static const int order[7] = {(int) Add, (int) Sub, (int) AntiSub, (int) Mul, (int) Naab, (int) AntiNaab, (int) Xor};
+    for (int t = 0; t < 7; ++t)
+        for (int l = 0; l < layer_id; ++l) coeff_r[order[t]][l] = with_phase2 ? out[5 + (size_t) t * layer_id + l] : F_ZERO;
+}
+
 void verifier::predicatePhase1(int layer_id) {                   // verifier.cpp:50-56,63-90
     const layer &cur = C.circuit[layer_id];
+    if (pred_dev) { if (cur.maxDadBitLength == -1) predicatesOnDevice(layer_id, false); return; }
     initBetaTable(beta_g, cur.bitLength, r_liu.begin(), F_ONE);
     for (u64 g = 0; g < cur.size; ++g) if (cur.gates[g].is_assert) beta_g[g] *= assert_random;        // verifier.cpp:53-54
     initBetaTable(beta_u, C.circuit[layer_id - 1].bitLength, r_u.begin(), F_ONE);
@@ -225,6 +241,7 @@ void verifier::predicatePhase1(int layer_id) {                   // verifier.cpp
 
 void verifier::predicatePhase2(int layer_id) {                   // verifier.cpp:58-61,92-113
     const layer &cur = C.circuit[layer_id];
+    if (pred_dev) { predicatesOnDevice(layer_id, true); return; }
     initBetaTable(beta_v, cur.maxDadBitLength, r_v[layer_id].begin(), F_ONE);
     for (int t : {(int) Copy, (int) Not, (int) Addc, (int) Mulc}) coeff_l[t] *= beta_v[0];
     bias *= beta_v[0];

@@ -24,6 +24,7 @@ public:
     // verifyPoly = commit_public + FRI commit phase + `reps` query repetitions (vpd_verifier.cpp:76-328; the
     // reference hard-codes 33).  fullTranscript() is then merkle_root_l | GKR | merkle_root_h | input_0 | all_sum[65].
     bool verifyFull(int reps = 33);
+    prover *pred_dev = nullptr;     // when set, the O(|C|) predicate loops run on the device (prover::predicates) instead of the host
     bool fri_batched = true;        // FRI commit phase as one device pass (prover::friCommit) instead of one friStep per challenge
     const std::vector<uint8_t> &fullTranscript() const { return full_tr; }
     double polyVerifyTime() const { return poly_timer.elapse_sec(); }
@@ -44,6 +45,7 @@ private:
     bool verifyLiu(int layer_id, F &previousSum);
     void predicatePhase1(int layer_id);
     void predicatePhase2(int layer_id);
+    void predicatesOnDevice(int layer_id, bool with_phase2);
     F getFinalValue(int layer_id, const F &claim_u, const std::vector<F> &claim_v);
     bool checkInput(const F &claim);
     bool verifyPoly(const prover::hhash_digest &root_l, const F &claim, int reps);

@@ -148,7 +148,8 @@ int vph_prove_gkr(vph_session *s, uint8_t *transcript, uint64_t capacity, uint64
 int vph_check(vph_session *s, const uint8_t *transcript, uint64_t n, int skip_predicates, double *verify_sec) {
     try {
         verifier v(nullptr, s->circ->c);
-        v.skip_predicates = skip_predicates != 0;
+        v.skip_predicates = (skip_predicates & 1) != 0;
+        if (skip_predicates & 2) v.pred_dev = s->p.get();          // bit 1: predicate loops on the device
         std::vector<uint8_t> tr(transcript, transcript + n);
         timer t; t.start();
         const bool ok = v.check(s->tape, tr);
