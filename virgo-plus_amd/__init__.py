@@ -22,7 +22,7 @@ LIB_GPU = os.path.join(CSRC, "libvpgpu.so")
 LIB_HOST = os.path.join(HOST, "libvphost.so")
 CLI = os.path.join(HOST, "virgo_plus_run")
 
-GPU_SRC = [os.path.join(CSRC, f) for f in ("vpgpu.hip", "vp_kernels.h", "vp_field.h")] + [
+GPU_SRC = [os.path.join(CSRC, f) for f in ("vpgpu.hip", "vpgpu_batched.inc", "vpgpu_pc.inc", "vp_kernels.h", "vp_kernels_round.h", "vp_kernels_batch.h", "vp_kernels_plan.h", "vp_kernels_pc.h", "vp_field.h")] + [
     os.path.join(ROOT, "include", "vpgpu.h")]
 HOST_SRC = [os.path.join(HOST, f) for f in ("circuit.cpp", "prover.cpp", "verifier.cpp", "vphost.cpp")]
 HOST_HDR = [os.path.join(HOST, f) for f in ("circuit.hpp", "prover.hpp", "verifier.hpp", "vphost.h", "field.hpp",

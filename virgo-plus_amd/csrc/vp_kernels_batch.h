@@ -1,0 +1,497 @@
+// Batched path, part 1: init kernels without materialised eq tables, the register/shuffle fold k_sumfold<R>, the block-cooperative fold k_sumfold3b, the single-workgroup tail k_tail.
+// Part of the single translation unit vpgpu.hip (see vp_kernels.h for the overall layout rules).
+#pragma once
+#include "vp_kernels_round.h"
+
+// ===================================================================================================
+// Batched path (vp_prove_gkr): every challenge is on the device tape, so one launch can cover several
+// rounds and whole sumcheck tails.  Same field values as the per-round kernels above, fewer bytes
+// and far fewer launches:
+//   * eq tables are never materialised: consumers multiply the two half tables on the fly;
+//   * k_sumfold<R>: a wave takes 64*2^R CONTIGUOUS entries per table (2^R fully coalesced 1 KiB loads),
+//     produces the sums of R rounds and stores the 64 folded entries of round k+R; neighbours are
+//     exchanged with wavefront shuffles (lane ^ 2^s at level s), no LDS staging of table data;
+//   * k_tail: one workgroup runs ALL remaining rounds once the live tables are small, adds the block
+//     partials of the earlier rounds, retires tables into add_term, and emits every round polynomial of
+//     the sumcheck plus the final claims.
+// ===================================================================================================
+namespace vp {
+
+struct Half { const F *bf; const F *bs; int h1; int pad; };
+__device__ __forceinline__ F half_at(const Half &h, u32 i) {
+    return f_mul(h.bf[i & ((1u << h.h1) - 1)], h.bs[i >> h.h1]);
+}
+
+struct InitArgs2 {
+    const u32 *rowptr; const u32 *e_g; const u32 *e_x; const uint16_t *e_tl;
+    Half hg, hu;              // eq(r_liu, .) over layer i, eq(r_u, .) over layer i-1
+    F *const *vals;
+    const F *gc;
+    const F *Vu;              // phase 2
+    const F *assert_r;        // scales beta_g of assert gates (bit 15 of e_tl)
+    F *V, *M, *A;
+    const uint8_t *s_layer; const u32 *s_idx;    // phase 2: slot -> (source layer, index) for the V gather
+    u32 n_rows;
+};
+
+template <int PHASE>
+__device__ __forceinline__ void contrib2(const InitArgs2 &a, u32 e, F &m, F &ad) {
+    const u32 g = a.e_g[e], x = a.e_x[e], tl = a.e_tl[e];
+    const int ty = (tl >> 8) & 0x7f;
+    F t = half_at(a.hg, g);
+    if (tl & 0x8000) t = f_mul(t, *a.assert_r);
+    if (PHASE == 1) {
+        const int l = tl & 0xff;
+        F ty_ = f_zero();
+        if (l != 0xff) ty_ = f_mul(a.vals[l][x], t);
+        switch (ty) {
+            case T_ADD: ad = f_add(ad, ty_); m = f_add(m, t); break;
+            case T_SUB: ad = f_sub(ad, ty_); m = f_add(m, t); break;
+            case T_ANTISUB: ad = f_add(ad, ty_); m = f_sub(m, t); break;
+            case T_MUL: m = f_add(m, ty_); break;
+            case T_NAAB: ad = f_add(ad, ty_); m = f_sub(m, ty_); break;
+            case T_ANTINAAB: m = f_add(m, f_sub(t, ty_)); break;
+            case T_ADDC: ad = f_add(ad, f_mul(a.gc[g], t)); m = f_add(m, t); break;
+            case T_MULC: m = f_add(m, f_mul(a.gc[g], t)); break;
+            case T_COPY: m = f_add(m, t); break;
+            case T_NOT: ad = f_add(ad, t); m = f_sub(m, t); break;
+            case T_XOR: ad = f_add(ad, ty_); m = f_add(m, f_sub(t, f_dbl(ty_))); break;
+            default: break;
+        }
+    } else {
+        t = f_mul(t, half_at(a.hu, x));
+        const F vu = *a.Vu;
+        const F tv = f_mul(t, vu);                         // t * V_u
+        switch (ty) {                                      // SURVEY.md Appendix A, phase-2 column
+            case T_ADD: m = f_add(m, t); ad = f_add(ad, tv); break;
+            case T_SUB: m = f_sub(m, t); ad = f_add(ad, tv); break;
+            case T_ANTISUB: m = f_add(m, t); ad = f_sub(ad, tv); break;
+            case T_MUL: m = f_add(m, tv); break;
+            case T_NAAB: m = f_add(m, f_sub(t, tv)); break;
+            case T_ANTINAAB: m = f_sub(m, tv); ad = f_add(ad, tv); break;
+            case T_XOR: ad = f_add(ad, tv); m = f_add(m, f_sub(t, f_dbl(tv))); break;
+            case T_COPY: ad = f_add(ad, tv); break;
+            case T_NOT: ad = f_add(ad, f_sub(t, tv)); break;
+            case T_ADDC: ad = f_add(ad, f_mul(t, f_add(a.gc[g], vu))); break;
+            case T_MULC: ad = f_add(ad, f_mul(tv, a.gc[g])); break;
+            default: break;
+        }
+    }
+}
+
+template <int PHASE>
+__device__ __forceinline__ void init2_light_body(const InitArgs2 &a, u32 bid) {
+    u32 row = bid * blockDim.x + threadIdx.x;
+    if (row >= a.n_rows) return;
+    if (PHASE == 2) {
+        const int l = a.s_layer[row];
+        if (l != 0xfe) a.V[row] = (l == 0xff) ? f_zero() : a.vals[l][a.s_idx[row]];   // 0xfe: padding slot, never read
+    }
+    u32 b = a.rowptr[row], e = a.rowptr[row + 1];
+    if (e - b > VP_LIGHT_MAX) return;
+    F m = f_zero(), ad = f_zero();
+    for (u32 k = b; k < e; ++k) contrib2<PHASE>(a, k, m, ad);
+    a.M[row] = m;
+    a.A[row] = ad;
+}
+template <int PHASE>
+__global__ void __launch_bounds__(VP_BLOCK) k_init2_light(InitArgs2 a) { init2_light_body<PHASE>(a, blockIdx.x); }
+
+template <int PHASE>
+__device__ __forceinline__ void init2_chunks_body(const InitArgs2 &a, const u32 *__restrict__ chunk_beg, const u32 *__restrict__ chunk_end,
+                                                  u32 n_chunks, F *__restrict__ part, u32 bid) {
+    const u32 c = bid * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (c >= n_chunks) return;
+    const int lane = threadIdx.x & 63;
+    F m = f_zero(), ad = f_zero();
+    for (u32 k = chunk_beg[c] + lane; k < chunk_end[c]; k += 64) contrib2<PHASE>(a, k, m, ad);
+    m = wave_sum(m);
+    ad = wave_sum(ad);
+    if (lane == 0) { part[2 * c] = m; part[2 * c + 1] = ad; }
+}
+template <int PHASE>
+__global__ void __launch_bounds__(VP_BLOCK)
+k_init2_chunks(InitArgs2 a, const u32 *__restrict__ chunk_beg, const u32 *__restrict__ chunk_end, u32 n_chunks,
+               F *__restrict__ part) { init2_chunks_body<PHASE>(a, chunk_beg, chunk_end, n_chunks, part, blockIdx.x); }
+
+// Liu init as a gather (src/prover.cpp:396-414): for every u of layer i-1 the (later layer, subset
+// position) pairs that point at it were listed at upload; M[u] = s0*eq(r_u,u) + sum eq_q(g).
+__device__ __forceinline__ void liu_gather_body(const u32 *__restrict__ rowptr, const uint8_t *__restrict__ e_q, const u32 *__restrict__ e_g,
+                                                const Half *__restrict__ H, u32 size, F *__restrict__ M, u32 bid) {
+    u32 u = bid * blockDim.x + threadIdx.x;
+    if (u >= size) return;
+    F m = half_at(H[0], u);
+    for (u32 k = rowptr[u]; k < rowptr[u + 1]; ++k) m = f_add(m, half_at(H[e_q[k]], e_g[k]));
+    M[u] = m;
+}
+__global__ void __launch_bounds__(VP_BLOCK)
+k_liu_gather(const u32 *__restrict__ rowptr, const uint8_t *__restrict__ e_q, const u32 *__restrict__ e_g,
+             const Half *__restrict__ H, u32 size, F *__restrict__ M) { liu_gather_body(rowptr, e_q, e_g, H, size, M, blockIdx.x); }
+
+__global__ void __launch_bounds__(VP_BLOCK)
+k_vres2(Half h, const F *__restrict__ val, u32 size, F *out_dev) {
+    __shared__ F lds[4];
+    F acc[1] = {f_zero()};
+    for (u32 i = threadIdx.x; i < size; i += blockDim.x) acc[0] = f_add(acc[0], f_mul(half_at(h, i), val[i]));
+    block_sum<1>(acc, lds);
+    if (threadIdx.x == 0) *out_dev = acc[0];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_sumfold<R>: R rounds per launch over tables whose length is a multiple of 64*2^R.
+// ---------------------------------------------------------------------------------------------------
+struct SfTab { u32 off, len, valid, chunk_start; };
+struct SfArgs {
+    const F *inV, *inM, *inA;
+    F *outV, *outM, *outA;
+    const F *r;               // r[s] = challenge of the s-th round of this launch
+    F *part;                  // part[(s * part_stride) + block*3 + c]
+    u32 part_stride;
+    u32 total_chunks;
+    int n_tab, has_a;
+    u32 nblk;                 // batched launches: blocks given to this job
+    SfTab t[VP_MAX_TAB];
+};
+
+__device__ __forceinline__ F shfl_xor_F(const F &x, int mask) {
+    F y;
+    y.re = __shfl_xor(x.re, mask, 64);
+    y.im = __shfl_xor(x.im, mask, 64);
+    return y;
+}
+
+// One level: regs x[0..2n) -> x[0..n).  Lane keeps the pair (lo, hi) = two neighbouring table entries:
+// lanes with bit s clear take theirs from the even register, the others from the odd register.
+template <int N2>
+__device__ __forceinline__ void sf_pairs(F (&x)[8], int s, int lane, F (&lo)[4], F (&hi)[4]) {
+    const bool up = (lane >> s) & 1;
+#pragma unroll
+    for (int j = 0; j < N2; ++j) {
+        const F A = x[2 * j], B = x[2 * j + 1];
+        const F recv = shfl_xor_F(up ? A : B, 1 << s);
+        lo[j] = up ? recv : A;
+        hi[j] = up ? B : recv;
+    }
+}
+
+template <int R, int MINW>
+__global__ void __launch_bounds__(VP_BLOCK, MINW) k_sumfold(SfArgs a) {
+    constexpr int G = 1 << R;
+    __shared__ F lds[4 * 3 * R];
+    const int lane = threadIdx.x & 63;
+    const u32 wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const u32 n_waves = gridDim.x * (blockDim.x >> 6);
+    F acc[3 * R];
+#pragma unroll
+    for (int i = 0; i < 3 * R; ++i) acc[i] = f_zero();
+    F rr[R];
+#pragma unroll
+    for (int s = 0; s < R; ++s) rr[s] = a.r[s];
+    // final lane -> element offset inside the 64 outputs of a chunk
+    u32 o_fin = (u32) lane >> R;
+#pragma unroll
+    for (int t = 0; t < R; ++t) o_fin += ((lane >> t) & 1u) << (6 - R + t);
+
+    for (u32 c = wave; c < a.total_chunks; c += n_waves) {
+        int j = 0;
+        while (j + 1 < a.n_tab && c >= a.t[j + 1].chunk_start) ++j;
+        const SfTab td = a.t[j];
+        const u32 cl = c - td.chunk_start;
+        const u32 base = td.off + cl * 64 * G, vend = td.off + td.valid;
+        F v[8], m[8], ad[8];
+#pragma unroll
+        for (int q = 0; q < G; ++q) {
+            const u32 idx = base + 64 * q + lane;
+            v[q] = ld_or_zero(a.inV, idx, vend);
+            m[q] = ld_or_zero(a.inM, idx, vend);
+            ad[q] = a.has_a ? ld_or_zero(a.inA, idx, vend) : f_zero();
+        }
+#pragma unroll
+        for (int s = 0; s < R; ++s) {
+            constexpr int dummy = 0; (void) dummy;
+            const int n2 = G >> (s + 1);
+            F vl[4], vh[4], ml[4], mh[4], al[4], ah[4];
+            if (n2 == 4) { sf_pairs<4>(v, s, lane, vl, vh); sf_pairs<4>(m, s, lane, ml, mh); if (a.has_a) sf_pairs<4>(ad, s, lane, al, ah); }
+            else if (n2 == 2) { sf_pairs<2>(v, s, lane, vl, vh); sf_pairs<2>(m, s, lane, ml, mh); if (a.has_a) sf_pairs<2>(ad, s, lane, al, ah); }
+            else { sf_pairs<1>(v, s, lane, vl, vh); sf_pairs<1>(m, s, lane, ml, mh); if (a.has_a) sf_pairs<1>(ad, s, lane, al, ah); }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q >= n2) break;
+                const F dm = f_sub(mh[q], ml[q]), dv = f_sub(vh[q], vl[q]);
+                // X += dm*dv, Y += m1*v1 + a1, Z += m0*v0 + a0: the round polynomial is (X, Y - X - Z, Z), combined once
+                // per block instead of per pair
+                acc[3 * s] = f_add(acc[3 * s], f_mul(dm, dv));
+                F e1 = f_mul(mh[q], vh[q]), e0 = f_mul(ml[q], vl[q]);
+                if (a.has_a) {
+                    e1 = f_add(e1, ah[q]); e0 = f_add(e0, al[q]);
+                    ad[q] = f_lerp(al[q], ah[q], rr[s]);
+                }
+                acc[3 * s + 1] = f_add(acc[3 * s + 1], e1);
+                acc[3 * s + 2] = f_add(acc[3 * s + 2], e0);
+                v[q] = f_add(vl[q], f_mul(rr[s], dv));
+                m[q] = f_add(ml[q], f_mul(rr[s], dm));
+            }
+        }
+        const u32 oi = cl * 64 + o_fin;                    // element of the folded table
+        const u32 vout = (td.valid + G - 1) >> R;
+        if (oi < vout) {
+            a.outV[td.off + oi] = v[0];
+            a.outM[td.off + oi] = m[0];
+            if (a.has_a) a.outA[td.off + oi] = ad[0];
+        }
+    }
+    // block partials
+    const int w = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 3 * R; ++i) acc[i] = wave_sum(acc[i]);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 3 * R; ++i) lds[w * 3 * R + i] = acc[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < R) {
+        const int s = threadIdx.x;
+        F X = lds[3 * s], Y = lds[3 * s + 1], Z = lds[3 * s + 2];
+        for (int k = 1; k < (int) (blockDim.x >> 6); ++k) {
+            X = f_add(X, lds[k * 3 * R + 3 * s]); Y = f_add(Y, lds[k * 3 * R + 3 * s + 1]); Z = f_add(Z, lds[k * 3 * R + 3 * s + 2]);
+        }
+        F *o = a.part + (size_t) s * a.part_stride + blockIdx.x * 3;
+        o[0] = X; o[1] = f_sub(f_sub(Y, X), Z); o[2] = Z;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_sumfold3b: the same three rounds per launch, laid out for parallelism instead of per-lane work.
+//
+// k_sumfold<3> gives a lane 8 entries of each table (7 dependent pair steps, ~250 VGPRs): a 2^20-entry table
+// is only 2048 waves, two per SIMD, and the kernel runs at the latency of its own dependency chain.  Here a
+// 256-thread workgroup takes the same 512-entry chunk: round k+0 is one pair per thread (entries 2t, 2t+1
+// as one 32-byte load per table), the 256 folded entries go through LDS, round k+1 runs on the first two
+// waves, round k+2 on the first.  Idle waves issue nothing, so the instruction count is that of the dense
+// schedule, but a chunk exposes 4x the waves, a thread holds 6 entries instead of 24 (~100 VGPRs, 5 waves
+// per SIMD), and the sums are accumulated unreduced (one fold per chunk, not one canonical add per pair).
+//
+// Lazy arithmetic used below (values are limbs of F):
+//   d = x1 + p - x0            in [0, 2p]           (x0, x1 canonical)
+//   a*b + c  with a, b in [0, 2p], c in [0, p]:  f_mad31 (vp_field.h), canonical result; every stored value
+//   is canonical, so results are bit-identical to the strict sequence.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ F f_sub_lazy(const F &a, const F &b) { return f_make(a.re + P61 - b.re, a.im + P61 - b.im); }
+__device__ __forceinline__ F f_mad_lazy(const F &a, const F &b, const F &c) { return f_mad31(a, b, c); }
+struct Lz { u64 re, im; };                                           // unreduced sum of canonical values
+__device__ __forceinline__ void lz_add(Lz &s, const F &x) { s.re += x.re; s.im += x.im; }
+__device__ __forceinline__ void lz_fold(Lz &s) { s.re = (s.re & P61) + (s.re >> 61); s.im = (s.im & P61) + (s.im >> 61); }
+__device__ __forceinline__ F lz_canon(const Lz &s) { return f_make(m_fold(s.re), m_fold(s.im)); }
+
+// one pair of one table family: sums into (X, Y, Z) = (sum dm*dv, sum m1*v1 + a1, sum m0*v0 + a0), folds with r
+template <bool HAS_A>
+__device__ __forceinline__ void sf_pair_step(const F &v0, const F &v1, const F &m0, const F &m1, const F &a0, const F &a1,
+                                             const F &r, Lz &X, Lz &Y, Lz &Z, F &vo, F &mo, F &ao) {
+    const F dv = f_sub_lazy(v1, v0), dm = f_sub_lazy(m1, m0);
+    lz_add(X, f_mad_lazy(dm, dv, f_zero()));
+    lz_add(Y, f_mad_lazy(m1, v1, HAS_A ? a1 : f_zero()));
+    lz_add(Z, f_mad_lazy(m0, v0, HAS_A ? a0 : f_zero()));
+    vo = f_mad_lazy(r, dv, v0);
+    mo = f_mad_lazy(r, dm, m0);
+    if (HAS_A) ao = f_mad_lazy(r, f_sub_lazy(a1, a0), a0);
+}
+
+struct Sf3bLds { F s1[3][256]; F s2[3][128]; F red[4][9]; Lz acc2[3][128]; Lz acc3[3][64]; };   // acc2/acc3: per-thread sums of rounds k+1, k+2
+template <bool HAS_A>
+__device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb, Sf3bLds &sm) {
+    F (&s1)[3][256] = sm.s1; F (&s2)[3][128] = sm.s2; F (&red)[4][9] = sm.red;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    // round k sums stay in registers; those of rounds k+1 / k+2 (first two waves / first wave only) live in LDS, one
+    // private slot per thread, so that the kernel fits 128 VGPRs (4 waves per SIMD) without scratch
+    Lz acc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) acc[i].re = acc[i].im = 0;
+    if (t < 128) { for (int i = 0; i < 3; ++i) { sm.acc2[i][t].re = 0; sm.acc2[i][t].im = 0; } }
+    if (t < 64) { for (int i = 0; i < 3; ++i) { sm.acc3[i][t].re = 0; sm.acc3[i][t].im = 0; } }
+    const F r0 = a.r[0], r1 = a.r[1], r2 = a.r[2];
+    for (u32 c = bid; c < a.total_chunks; c += nb) {
+        int j = 0;
+        while (j + 1 < a.n_tab && c >= a.t[j + 1].chunk_start) ++j;
+        const SfTab td = a.t[j];
+        const u32 cl = c - td.chunk_start;
+        const u32 i0 = td.off + cl * 512 + 2 * t, vend = td.off + td.valid;
+        {   // round k: one pair per thread
+            const F v0 = ld_or_zero(a.inV, i0, vend), v1 = ld_or_zero(a.inV, i0 + 1, vend);
+            const F m0 = ld_or_zero(a.inM, i0, vend), m1 = ld_or_zero(a.inM, i0 + 1, vend);
+            F a0 = f_zero(), a1 = f_zero();
+            if (HAS_A) { a0 = ld_or_zero(a.inA, i0, vend); a1 = ld_or_zero(a.inA, i0 + 1, vend); }
+            F vo, mo, ao = f_zero();
+            sf_pair_step<HAS_A>(v0, v1, m0, m1, a0, a1, r0, acc[0], acc[1], acc[2], vo, mo, ao);
+            s1[0][t] = vo; s1[1][t] = mo;
+            if (HAS_A) s1[2][t] = ao;
+        }
+        __syncthreads();
+        if (w < 2) {   // round k+1: 128 pairs
+            F vo, mo, ao = f_zero();
+            Lz x = sm.acc2[0][t], y = sm.acc2[1][t], z = sm.acc2[2][t];
+            sf_pair_step<HAS_A>(s1[0][2 * t], s1[0][2 * t + 1], s1[1][2 * t], s1[1][2 * t + 1],
+                                HAS_A ? s1[2][2 * t] : f_zero(), HAS_A ? s1[2][2 * t + 1] : f_zero(), r1,
+                                x, y, z, vo, mo, ao);
+            lz_fold(x); lz_fold(y); lz_fold(z);
+            sm.acc2[0][t] = x; sm.acc2[1][t] = y; sm.acc2[2][t] = z;
+            s2[0][t] = vo; s2[1][t] = mo;
+            if (HAS_A) s2[2][t] = ao;
+        }
+        __syncthreads();
+        if (w == 0) {  // round k+2: 64 pairs, results are the folded table
+            F vo, mo, ao = f_zero();
+            Lz x = sm.acc3[0][t], y = sm.acc3[1][t], z = sm.acc3[2][t];
+            sf_pair_step<HAS_A>(s2[0][2 * t], s2[0][2 * t + 1], s2[1][2 * t], s2[1][2 * t + 1],
+                                HAS_A ? s2[2][2 * t] : f_zero(), HAS_A ? s2[2][2 * t + 1] : f_zero(), r2,
+                                x, y, z, vo, mo, ao);
+            lz_fold(x); lz_fold(y); lz_fold(z);
+            sm.acc3[0][t] = x; sm.acc3[1][t] = y; sm.acc3[2][t] = z;
+            const u32 oi = cl * 64 + t;
+            if (oi < ((td.valid + 7) >> 3)) {
+                a.outV[td.off + oi] = vo;
+                a.outM[td.off + oi] = mo;
+                if (HAS_A) a.outA[td.off + oi] = ao;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) lz_fold(acc[i]);
+    }
+    // block partials: rounds k+1 and k+2 only have contributions in waves 0-1 and 0
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        if (i >= 3 && w >= 2) break;
+        if (i >= 6 && w >= 1) break;
+        const Lz v = i < 3 ? acc[i] : i < 6 ? sm.acc2[i - 3][t] : sm.acc3[i - 6][t];
+        const F x = wave_sum63(lz_canon(v));
+        if (lane == 63) red[w][i] = x;
+    }
+    __syncthreads();
+    if (t < 3) {
+        const int nw = t == 0 ? 4 : t == 1 ? 2 : 1;
+        F X = red[0][3 * t], Y = red[0][3 * t + 1], Z = red[0][3 * t + 2];
+        for (int k = 1; k < nw; ++k) { X = f_add(X, red[k][3 * t]); Y = f_add(Y, red[k][3 * t + 1]); Z = f_add(Z, red[k][3 * t + 2]); }
+        F *o = a.part + (size_t) t * a.part_stride + bid * 3;
+        o[0] = X; o[1] = f_sub(f_sub(Y, X), Z); o[2] = Z;
+    }
+}
+template <bool HAS_A>
+__global__ void __launch_bounds__(VP_BLOCK, 4) k_sumfold3b(SfArgs a) {
+    __shared__ Sf3bLds sm;
+    sumfold3b_body<HAS_A>(a, blockIdx.x, gridDim.x, sm);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_tail: one workgroup finishes a sumcheck.
+// ---------------------------------------------------------------------------------------------------
+#define VP_TAIL_THREADS 1024
+struct TailTab {
+    u32 off;          // table offset inside the ping-pong buffers
+    u32 len0;         // logical length at round 1
+    u32 valid0;       // valid length at round 1
+    int enter;        // first round (1-based) this kernel handles for the table
+    int cur;          // buffer (0/1) that holds the table at round `enter`
+    int v_from_v0;    // V of round `enter` is read from V0 instead of buf[cur][0] (phase 1 / Liu, enter == 1)
+};
+struct TailArgs {
+    const F *V0;
+    F *buf[2][3];
+    const F *r;                 // r[k-1] = challenge of round k
+    const F *part;              // block partials written by k_sumfold: part[(k-1)*part_stride + b*3 + c]
+    u32 part_stride;
+    int n_tab, rounds, has_a;
+    F *poly_out;                // rounds * 3
+    F *claims_out;              // n_tab
+    F *Vu;                      // phase 1: receives claims[0]
+    uint16_t nblk[32];          // partial blocks per round
+    TailTab t[VP_MAX_TAB];
+};
+
+__global__ void __launch_bounds__(VP_TAIL_THREADS) k_tail(TailArgs a) {
+    __shared__ F lds[16 * 3];
+    __shared__ F s_claim[VP_MAX_TAB];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nth = blockDim.x;
+    if (tid < a.n_tab) s_claim[tid] = f_zero();
+    F at = f_zero();                                        // add_term (thread 0)
+    __syncthreads();
+    // tables that consist of a single entry from the start: their value is the claim (bl == 0)
+    for (int k = 1; k <= (a.rounds > 0 ? a.rounds : 1); ++k) {
+        const bool real_round = k <= a.rounds;
+        const F rk = real_round ? a.r[k - 1] : f_zero();
+        const F rprev = (k >= 2) ? a.r[k - 2] : f_zero();
+        F acc[3] = {f_zero(), f_zero(), f_zero()};
+        if (real_round) {
+            const u32 nb = a.nblk[k - 1];
+            const F *pp = a.part + (size_t) (k - 1) * a.part_stride;
+            for (u32 i = tid; i < nb; i += nth) {
+                acc[0] = f_add(acc[0], pp[3 * i]); acc[1] = f_add(acc[1], pp[3 * i + 1]); acc[2] = f_add(acc[2], pp[3 * i + 2]);
+            }
+        }
+        F retire = f_zero();                                // thread 0: sum of V*M + A of tables retiring this round
+        for (int j = 0; j < a.n_tab; ++j) {
+            const TailTab td = a.t[j];
+            if (k < td.enter) continue;
+            const int sh = k - 1;
+            const u32 len = sh < 32 ? (td.len0 >> sh) : 0;
+            if (len == 0) continue;
+            const u32 valid = (u32) (((unsigned long long) td.valid0 + (1ull << sh) - 1) >> sh);
+            const int cb = td.cur ^ ((k - td.enter) & 1);       // a live table changes buffer every round
+            const F *inV = (td.v_from_v0 && k == td.enter) ? a.V0 + td.off : a.buf[cb][0] + td.off;
+            const F *inM = a.buf[cb][1] + td.off, *inA = a.buf[cb][2] + td.off;
+            if (len == 1) {
+                if (tid == 0) {
+                    // always-initialised single entry (see k_round_final)
+                    const F v = (td.len0 == 1) ? inV[0] : ld_or_zero(inV, 0, valid);
+                    const F m = (td.len0 == 1) ? inM[0] : ld_or_zero(inM, 0, valid);
+                    const F ad = a.has_a ? ((td.len0 == 1) ? inA[0] : ld_or_zero(inA, 0, valid)) : f_zero();
+                    s_claim[j] = v;
+                    if (real_round) retire = f_add(retire, f_add(f_mul(v, m), ad));
+                }
+                continue;
+            }
+            if (!real_round) continue;
+            F *oV = a.buf[cb ^ 1][0] + td.off, *oM = a.buf[cb ^ 1][1] + td.off, *oA = a.buf[cb ^ 1][2] + td.off;
+            const u32 npairs = (valid + 1) >> 1;
+            for (u32 p = tid; p < npairs; p += nth) {
+                const F v0 = ld_or_zero(inV, 2 * p, valid), v1 = ld_or_zero(inV, 2 * p + 1, valid);
+                const F m0 = ld_or_zero(inM, 2 * p, valid), m1 = ld_or_zero(inM, 2 * p + 1, valid);
+                F a0 = f_zero(), a1 = f_zero();
+                if (a.has_a) { a0 = ld_or_zero(inA, 2 * p, valid); a1 = ld_or_zero(inA, 2 * p + 1, valid); }
+                const F dm = f_sub(m1, m0), dv = f_sub(v1, v0);
+                const F qa = f_mul(dm, dv), qc = f_mul(m0, v0), qe = f_mul(m1, v1);
+                acc[0] = f_add(acc[0], qa);
+                acc[1] = f_add(acc[1], f_add(f_sub(f_sub(qe, qa), qc), f_sub(a1, a0)));
+                acc[2] = f_add(acc[2], f_add(qc, a0));
+                const F fv = f_add(v0, f_mul(rk, dv));
+                oV[p] = fv;
+                oM[p] = f_add(m0, f_mul(rk, dm));
+                if (a.has_a) oA[p] = f_lerp(a0, a1, rk);
+                if (len == 2 && k == a.rounds) s_claim[j] = fv;      // the last fold of a full-length table is its claim
+            }
+        }
+        if (!real_round) break;
+        // block reduction of the three coefficients
+#pragma unroll
+        for (int i = 0; i < 3; ++i) acc[i] = wave_sum(acc[i]);
+        if (lane == 0) { lds[w * 3] = acc[0]; lds[w * 3 + 1] = acc[1]; lds[w * 3 + 2] = acc[2]; }
+        __syncthreads();                                    // also publishes the folded tables
+        if (tid == 0) {
+            F s0 = lds[0], s1 = lds[1], s2 = lds[2];
+            for (int q = 1; q < (nth >> 6); ++q) { s0 = f_add(s0, lds[3 * q]); s1 = f_add(s1, lds[3 * q + 1]); s2 = f_add(s2, lds[3 * q + 2]); }
+            if (!f_is_zero(at)) at = f_mul(at, f_sub(f_one(), rprev));
+            at = f_add(at, retire);
+            a.poly_out[3 * (k - 1)] = s0;
+            a.poly_out[3 * (k - 1) + 1] = f_sub(s1, at);
+            a.poly_out[3 * (k - 1) + 2] = f_add(s2, at);
+        }
+        __syncthreads();                                    // lds reuse
+    }
+    // claims: tables shorter than the sumcheck left their value when they retired; a table whose last
+    // fold happened in the final round stored it above; single-entry tables of a zero-round phase too.
+    __syncthreads();
+    if (tid < a.n_tab) {
+        a.claims_out[tid] = s_claim[tid];
+        if (a.Vu && tid == 0) *a.Vu = s_claim[0];
+    }
+}
+
+}  // namespace vp

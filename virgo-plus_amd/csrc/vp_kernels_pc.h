@@ -1,0 +1,415 @@
+// Virgo polynomial commitment kernels: NTT, Keccak-f[1600] / SHA3-256, leaf hashes, Merkle trees, quotient, virtual oracle, FRI fold, openings.
+// Part of the single translation unit vpgpu.hip (see vp_kernels.h for the overall layout rules).
+#pragma once
+#include "vp_kernels_round.h"
+
+// ===================================================================================================
+// Virgo polynomial commitment, commit side (reference: lib/virgo/src/RS_polynomial.cpp, poly_commit.h,
+// fri.cpp, merkle_tree.cpp, my_hhash.h).
+// ===================================================================================================
+namespace vp {
+
+// ---- K7: NTT over F_p^2 ------------------------------------------------------------------------------
+// One table of roots for the whole commitment: RT[j] = w^j, j < M/2, w = root of unity of order M = 2^lm
+// (fieldElement::getRootOfUnity, fieldElement.cpp:237-249).  w^(M/2) = -1, so any power and any inverse
+// power is one load and possibly one negation; smaller orders use strided indices.
+__device__ __forceinline__ F root_pow(const F *__restrict__ RT, u32 half_m, u32 e /* < 2*half_m */) {
+    return e < half_m ? RT[e] : f_neg(RT[e - half_m]);
+}
+__global__ void __launch_bounds__(VP_BLOCK)
+k_root_table_step(F *RT, u32 have /* entries already filled, power of two */, F step /* w^have */) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < have) RT[have + i] = f_mul(RT[i], step);
+}
+
+// Batched in-LDS radix-2 NTT of size N = 2^ln <= 8192, one workgroup per transform (blockIdx.x = row,
+// blockIdx.y = coset).  DIT: bit-reversed load, ln butterfly stages with one barrier each, natural-order store.
+//   forward LDE mode (inverse = 0): input row `coef + row*N`, element j is first multiplied by w_M^(j*coset)
+//       (the coset twist), and the N outputs are the evaluations at w_M^(32*a + coset): out[(row*ncoset + coset)*N + a].
+//       A rate-1/32 Reed-Solomon encoding (fast_fourier_transform(coefs, N, 32N), RS_polynomial.cpp:26) is therefore
+//       32 independent size-N transforms whose stores are fully coalesced; the codeword is kept COSET-MAJOR.
+//   inverse mode: out[row*N + k] = N^-1 * sum_j in[row*N + j] * w_N^(-jk)   (inverse_fast_fourier_transform, :159-220).
+struct NttArgs {
+    const F *in; F *out;
+    const F *RT; u32 half_m; int lm;      // root table of order M = 2^lm
+    int ln;                               // transform size N = 2^ln
+    int inverse;
+    u32 in_stride;                        // elements between consecutive input rows
+    F inv_n;                              // inverse mode: N^-1
+};
+__global__ void __launch_bounds__(1024) k_ntt_lds(NttArgs a) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    F *L = reinterpret_cast<F *>(smem_raw);
+    const u32 N = 1u << a.ln, row = blockIdx.x, coset = blockIdx.y, tid = threadIdx.x, nth = blockDim.x;
+    const u32 M = 2 * a.half_m;
+    const u32 wstride = M >> a.ln;                          // w_N = w_M^wstride
+    const F *src = a.in + (size_t) row * a.in_stride;
+    for (u32 j = tid; j < N; j += nth) {
+        F x = src[j];
+        if (!a.inverse && coset) x = f_mul(x, root_pow(a.RT, a.half_m, (j * coset) & (M - 1)));
+        L[a.ln ? (__brev(j) >> (32 - a.ln)) : 0u] = x;
+    }
+    __syncthreads();
+    for (int s = 1; s <= a.ln; ++s) {
+        const u32 half = 1u << (s - 1);
+        const u32 tw = (N >> s) * wstride;                 // exponent step of this stage in units of w_M
+        for (u32 idx = tid; idx < N / 2; idx += nth) {
+            const u32 k = idx & (half - 1), i0 = ((idx >> (s - 1)) << s) | k, i1 = i0 + half;
+            u32 e = k * tw;                                 // < M/2
+            if (a.inverse) e = e ? M - e : 0;               // w^-e
+            const F w = root_pow(a.RT, a.half_m, e);
+            const F u = L[i0], v = f_mul(L[i1], w);
+            L[i0] = f_add(u, v);
+            L[i1] = f_sub(u, v);
+        }
+        __syncthreads();
+    }
+    F *dst = a.inverse ? a.out + (size_t) row * N : a.out + ((size_t) row * gridDim.y + coset) * N;
+    for (u32 k = tid; k < N; k += nth) dst[k] = a.inverse ? f_mul(L[k], a.inv_n) : L[k];
+}
+
+// ---- K8: SHA3-256 on 64-byte messages (my_hhash.h:27-33; FIPS 202), leaf chains and Merkle levels -------
+struct Dig { u64 w[4]; };
+__device__ __forceinline__ u64 rotl64(u64 x, int n) { return (x << n) | (x >> (64 - n)); }
+__device__ __forceinline__ void keccak_f1600(u64 (&A)[25]) {
+    const u64 RC[24] = {
+        0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808aull, 0x8000000080008000ull, 0x000000000000808bull,
+        0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull, 0x000000000000008aull, 0x0000000000000088ull,
+        0x0000000080008009ull, 0x000000008000000aull, 0x000000008000808bull, 0x800000000000008bull, 0x8000000000008089ull,
+        0x8000000000008003ull, 0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800aull, 0x800000008000000aull,
+        0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
+#pragma unroll 1
+    for (int rnd = 0; rnd < 24; ++rnd) {
+        u64 C0 = A[0] ^ A[5] ^ A[10] ^ A[15] ^ A[20], C1 = A[1] ^ A[6] ^ A[11] ^ A[16] ^ A[21];
+        u64 C2 = A[2] ^ A[7] ^ A[12] ^ A[17] ^ A[22], C3 = A[3] ^ A[8] ^ A[13] ^ A[18] ^ A[23];
+        u64 C4 = A[4] ^ A[9] ^ A[14] ^ A[19] ^ A[24];
+        const u64 D0 = C4 ^ rotl64(C1, 1), D1 = C0 ^ rotl64(C2, 1), D2 = C1 ^ rotl64(C3, 1), D3 = C2 ^ rotl64(C4, 1), D4 = C3 ^ rotl64(C0, 1);
+#pragma unroll
+        for (int y = 0; y < 25; y += 5) { A[y] ^= D0; A[y + 1] ^= D1; A[y + 2] ^= D2; A[y + 3] ^= D3; A[y + 4] ^= D4; }
+        // rho + pi
+        u64 B[25];
+        B[0] = A[0];
+        B[10] = rotl64(A[1], 1);   B[20] = rotl64(A[2], 62);  B[5] = rotl64(A[3], 28);   B[15] = rotl64(A[4], 27);
+        B[16] = rotl64(A[5], 36);  B[1] = rotl64(A[6], 44);   B[11] = rotl64(A[7], 6);   B[21] = rotl64(A[8], 55);
+        B[6] = rotl64(A[9], 20);   B[7] = rotl64(A[10], 3);   B[17] = rotl64(A[11], 10); B[2] = rotl64(A[12], 43);
+        B[12] = rotl64(A[13], 25); B[22] = rotl64(A[14], 39); B[23] = rotl64(A[15], 41); B[8] = rotl64(A[16], 45);
+        B[18] = rotl64(A[17], 15); B[3] = rotl64(A[18], 21);  B[13] = rotl64(A[19], 8);  B[14] = rotl64(A[20], 18);
+        B[24] = rotl64(A[21], 2);  B[9] = rotl64(A[22], 61);  B[19] = rotl64(A[23], 56); B[4] = rotl64(A[24], 14);
+        // chi
+#pragma unroll
+        for (int y = 0; y < 25; y += 5) {
+            A[y] = B[y] ^ (~B[y + 1] & B[y + 2]);
+            A[y + 1] = B[y + 1] ^ (~B[y + 2] & B[y + 3]);
+            A[y + 2] = B[y + 2] ^ (~B[y + 3] & B[y + 4]);
+            A[y + 3] = B[y + 3] ^ (~B[y + 4] & B[y]);
+            A[y + 4] = B[y + 4] ^ (~B[y] & B[y + 1]);
+        }
+        A[0] ^= RC[rnd];
+    }
+}
+// h' = SHA3-256(m0..m3 || h)   — the 64-byte block of the leaf chains and of the Merkle nodes
+__device__ __forceinline__ Dig hhash64(u64 m0, u64 m1, u64 m2, u64 m3, const Dig &h) {
+    u64 A[25];
+#pragma unroll
+    for (int i = 0; i < 25; ++i) A[i] = 0;
+    A[0] = m0; A[1] = m1; A[2] = m2; A[3] = m3; A[4] = h.w[0]; A[5] = h.w[1]; A[6] = h.w[2]; A[7] = h.w[3];
+    A[8] = 0x06;                                 // domain bits + first pad bit (byte 64)
+    A[16] = 0x8000000000000000ull;               // last pad bit (byte 135, rate 136)
+    keccak_f1600(A);
+    Dig d; d.w[0] = A[0]; d.w[1] = A[1]; d.w[2] = A[2]; d.w[3] = A[3];
+    return d;
+}
+
+// Leaf hashes of fri::request_init_commit (fri.cpp:95-124): leaf j chains the 64 slices' pairs
+// (cw[s][j], cw[s][j + half]) and then the mask slice's pair (all zero here, src/prover.cpp:526).
+// The codeword is coset-major: cw[(s*32 + b)*N + a] = value at position 32a + b; position j + half is (a + N/2, b).
+// Thread t -> (b, a) with a fastest (coalesced loads); the digest goes to the natural leaf index 32a + b.
+__global__ void __launch_bounds__(VP_BLOCK)
+k_leaf_hash(const F *__restrict__ cw, u32 N, int n_slices, Dig *__restrict__ leaves) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 halfN = N >> 1;
+    if (t >= 32 * halfN) return;
+    const u32 a = t % halfN, b = t / halfN;
+    Dig h; h.w[0] = h.w[1] = h.w[2] = h.w[3] = 0;
+    for (int s = 0; s < n_slices; ++s) {
+        const F *row = cw + ((size_t) s * 32 + b) * N;
+        const F x = row[a], y = row[a + halfN];
+        h = hhash64(x.re, x.im, y.re, y.im, h);
+    }
+    h = hhash64(0, 0, 0, 0, h);                       // mask slice (zero polynomial)
+    leaves[32 * a + b] = h;
+}
+
+// One Merkle level (merkle_tree.cpp:40-50): parent[i] = H(child[2i] || child[2i+1]); heap layout, root at index 1.
+// Batched commit phase (vp_fri_commit): with every challenge known up front the folds of all levels run back to back, and
+// ONE launch hashes the leaves of all levels — the 65 chained Keccak-f of a leaf are a fixed latency (~0.8 ms for a lone
+// wave) that the per-step path pays once per level.
+#define VP_FRI_MAX 32
+struct FriLeafArgs { const F *cw[VP_FRI_MAX]; Dig *leaves[VP_FRI_MAX]; u32 N[VP_FRI_MAX]; u32 blk_start[VP_FRI_MAX + 1]; int n; };
+__global__ void __launch_bounds__(VP_BLOCK) k_leaf_hash_multi(FriLeafArgs a) {
+    int j = 0;
+    while (j + 1 < a.n && blockIdx.x >= a.blk_start[j + 1]) ++j;
+    const u32 t = (blockIdx.x - a.blk_start[j]) * blockDim.x + threadIdx.x;
+    const u32 N = a.N[j], halfN = N >> 1;
+    if (t >= 32 * halfN) return;
+    const u32 p = t % halfN, b = t / halfN;
+    const F *cw = a.cw[j];
+    Dig h; h.w[0] = h.w[1] = h.w[2] = h.w[3] = 0;
+    for (int s = 0; s < 64; ++s) {
+        const F *row = cw + ((size_t) s * 32 + b) * N;
+        const F x = row[p], y = row[p + halfN];
+        h = hhash64(x.re, x.im, y.re, y.im, h);
+    }
+    h = hhash64(0, 0, 0, 0, h);
+    a.leaves[j][32 * p + b] = h;
+}
+struct MerkleArgs { Dig *tree[VP_FRI_MAX]; u32 count[VP_FRI_MAX]; u32 blk_start[VP_FRI_MAX + 1]; int n; };
+__global__ void __launch_bounds__(VP_BLOCK) k_merkle_level_multi(MerkleArgs a) {
+    int j = 0;
+    while (j + 1 < a.n && blockIdx.x >= a.blk_start[j + 1]) ++j;
+    const u32 i = (blockIdx.x - a.blk_start[j]) * blockDim.x + threadIdx.x, c = a.count[j];
+    if (i >= c) return;
+    Dig *tree = a.tree[j];
+    const Dig l = tree[2 * (c + i)], r = tree[2 * (c + i) + 1];
+    tree[c + i] = hhash64(l.w[0], l.w[1], l.w[2], l.w[3], r);
+}
+__global__ void __launch_bounds__(VP_BLOCK) k_merkle_top_multi(MerkleArgs a, Dig *roots) {     // one workgroup per tree
+    Dig *tree = a.tree[blockIdx.x];
+    for (u32 c = a.count[blockIdx.x] >> 1; c >= 1; c >>= 1) {
+        for (u32 i = threadIdx.x; i < c; i += blockDim.x) {
+            const Dig l = tree[2 * (c + i)], r = tree[2 * (c + i) + 1];
+            tree[c + i] = hhash64(l.w[0], l.w[1], l.w[2], l.w[3], r);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) roots[blockIdx.x] = tree[1];
+}
+__global__ void __launch_bounds__(VP_BLOCK) k_merkle_level(Dig *tree, u32 level_start, u32 count) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const Dig l = tree[2 * (level_start + i)], r = tree[2 * (level_start + i) + 1];
+    tree[level_start + i] = hhash64(l.w[0], l.w[1], l.w[2], l.w[3], r);
+}
+// The top of the tree (<= 1024 leaves at `level_start`) in one workgroup.
+__global__ void __launch_bounds__(VP_BLOCK) k_merkle_top(Dig *tree, u32 count) {
+    for (u32 c = count >> 1; c >= 1; c >>= 1) {
+        for (u32 i = threadIdx.x; i < c; i += blockDim.x) {
+            const Dig l = tree[2 * (c + i)], r = tree[2 * (c + i) + 1];
+            tree[c + i] = hhash64(l.w[0], l.w[1], l.w[2], l.w[3], r);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void k_test_sha3(const u64 *__restrict__ in, u64 *__restrict__ out, u32 n) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Dig h; h.w[0] = in[8 * i + 4]; h.w[1] = in[8 * i + 5]; h.w[2] = in[8 * i + 6]; h.w[3] = in[8 * i + 7];
+    Dig d = hhash64(in[8 * i], in[8 * i + 1], in[8 * i + 2], in[8 * i + 3], h);
+    out[4 * i] = d.w[0]; out[4 * i + 1] = d.w[1]; out[4 * i + 2] = d.w[2]; out[4 * i + 3] = d.w[3];
+}
+
+}  // namespace vp
+
+// ---- commit_public (poly_commit.h:126-349) -------------------------------------------------------------
+namespace vp {
+
+// Products l*q on the two cosets the quotient needs: positions 16*j, j < 2N, are coset 0 (j even) and coset 16
+// (j odd) of the coset-major codewords.  P[(2i)*N + a] = l_i*q_i at w_M^(32a), P[(2i+1)*N + a] at w_M^(32a+16).
+__global__ void __launch_bounds__(VP_BLOCK)
+k_pc_products(const F *__restrict__ lcw, const F *__restrict__ qcw, u32 N, F *__restrict__ P) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 128 * N) return;
+    const u32 a = t % N, r = t / N, i = r >> 1, b = (r & 1) ? 16 : 0;
+    const size_t src = ((size_t) i * 32 + b) * N + a;
+    P[t] = f_mul(lcw[src], qcw[src]);
+}
+// With l*q = L + x^N H (deg L, H < N):  S = iNTT_N(products on coset 0) = L + H,  T_j * w_2N^-j = L_j - H_j for
+// T = iNTT_N(products on coset 16).  h_coef = H = (S - D)/2  (poly_commit.h:283-287 takes the upper half of a 2N-point
+// inverse transform; this is the same polynomial from two N-point ones), all_sum = (lq_coef[0] + h_coef[0]) * N = S_0 * N.
+__global__ void __launch_bounds__(VP_BLOCK)
+k_pc_quotient(const F *__restrict__ ST, u32 N, const F *__restrict__ RT, u32 half_m, F inv2, F n_as_f, F *__restrict__ H,
+              F *__restrict__ all_sum) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 64 * N) return;
+    const u32 j = t % N, i = t / N;
+    const F S = ST[(size_t) (2 * i) * N + j], T = ST[(size_t) (2 * i + 1) * N + j];
+    const u32 M = 2 * half_m;
+    const u32 e = (16 * j) & (M - 1);                          // w_2N = w_M^16
+    const F D = f_mul(T, root_pow(RT, half_m, e ? M - e : 0));
+    H[t] = f_mul(f_sub(S, D), inv2);
+    if (j == 0) { all_sum[i] = f_mul(S, n_as_f); all_sum[80 + i] = S; }     // [80..144): S_0 = lq_coef[0] + h_coef[0]
+}
+// prover::inner_prod (src/prover.cpp:532-540)
+__global__ void __launch_bounds__(VP_BLOCK) k_pc_dot(const F *__restrict__ x, const F *__restrict__ y, u32 n, F *part) {
+    __shared__ F lds[4];
+    F acc[1] = {f_zero()};
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) acc[0] = f_add(acc[0], f_mul(x[i], y[i]));
+    block_sum<1>(acc, lds);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc[0];
+}
+__global__ void __launch_bounds__(VP_BLOCK) k_pc_sum_parts(const F *__restrict__ part, u32 n, F *out) {
+    __shared__ F lds[4];
+    F acc[1] = {f_zero()};
+    for (u32 i = threadIdx.x; i < n; i += blockDim.x) acc[0] = f_add(acc[0], part[i]);
+    block_sum<1>(acc, lds);
+    if (threadIdx.x == 0) *out = acc[0];
+}
+
+}  // namespace vp
+
+// ---- virtual oracle + K9: FRI commit phase (poly_commit.h:294-318, fri.cpp:289-424) ------------------------
+namespace vp {
+
+// vo = (l*q - (x^N - 1)*h + const_i) * N * x^-1 at x = w_M^(32a+b); x^N = w_32^b depends on the coset only.
+// Written in place over the q codeword (same coset-major index).
+__global__ void __launch_bounds__(VP_BLOCK)
+k_pc_virtual_oracle(const F *__restrict__ lcw, F *__restrict__ qcw, const F *__restrict__ hcw, const F *__restrict__ S0, u32 N,
+                    const F *__restrict__ RT, u32 half_m, F n_as_f) {
+    const size_t t = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t M = 2 * (size_t) half_m;
+    if (t >= 64 * M) return;
+    const u32 a = (u32) (t % N), b = (u32) ((t / N) % 32), i = (u32) (t / M);
+    const u32 k = 32 * a + b;
+    const F xn_m1 = f_sub(root_pow(RT, half_m, (u32) ((size_t) b * N) & (u32) (M - 1)), f_one());   // w_M^(N*b) - 1
+    const F g = f_sub(f_mul(lcw[t], qcw[t]), f_mul(xn_m1, hcw[t]));
+    const F inv_x = f_mul(n_as_f, root_pow(RT, half_m, k ? (u32) M - k : 0));
+    qcw[t] = f_mul(f_sub(g, S0[i]), inv_x);
+}
+
+// One FRI fold of all 64 slices: out[s][b][a] = 1/2 ((p + q) + mu^-1 r (p - q)), p = in[s][b][a], q = in[s][b][a + Nk/2],
+// mu = w_k^(32a+b) with w_k = w_M^(2^k) the generator of the current domain (fri.cpp:312-331).
+__global__ void __launch_bounds__(VP_BLOCK)
+k_fri_fold(const F *__restrict__ in, F *__restrict__ out, u32 Nk, int k, const F *__restrict__ RT, u32 half_m, F r, F inv2) {
+    const size_t t = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 No = Nk >> 1;                                   // per-coset length of the output (>= 1)
+    if (t >= (size_t) 64 * 32 * No) return;
+    const u32 a = (u32) (t % No), sb = (u32) (t / No);        // sb = slice * 32 + coset
+    const u32 b = sb & 31;
+    const u32 M = 2 * half_m;
+    const u32 e = (u32) ((((unsigned long long) (32 * a + b)) << k) & (M - 1));
+    const F inv_mu = root_pow(RT, half_m, e ? M - e : 0);
+    F p, q;
+    if (Nk >= 2) { p = in[(size_t) sb * Nk + a]; q = in[(size_t) sb * Nk + a + No]; }
+    else { p = f_zero(); q = f_zero(); }
+    out[t] = f_mul(inv2, f_add(f_add(p, q), f_mul(f_mul(inv_mu, r), f_sub(p, q))));
+}
+// The last fold leaves ONE value per coset (32 per slice); its 16 leaves pair coset b with coset b + 16.
+__global__ void k_leaf_hash_final(const F *__restrict__ cw, int n_slices, Dig *__restrict__ leaves) {
+    const u32 j = threadIdx.x;
+    if (j >= 16) return;
+    Dig h; h.w[0] = h.w[1] = h.w[2] = h.w[3] = 0;
+    for (int s = 0; s < n_slices; ++s) {
+        const F x = cw[(size_t) s * 32 + j], y = cw[(size_t) s * 32 + j + 16];
+        h = hhash64(x.re, x.im, y.re, y.im, h);
+    }
+    h = hhash64(0, 0, 0, 0, h);
+    leaves[j] = h;
+}
+
+}  // namespace vp
+
+// ---- transforms longer than the LDS (2^13 < N <= 2^17): N = N1 * N2 with N1 = 2^l1 <= 16, N2 = 2^13 --------
+// j = j1*N2 + j2, k = k1 + N1*k2:  w_N^(jk) = w_N1^(j1 k1) * w_N^(j2 k1) * w_N2^(j2 k2).
+//   k_ntt_split : per j2 an N1-point transform over the N1 rows (stride N2) in registers + the w_N^(j2 k1) twiddle
+//                 (+ the coset twist for the encoder), written as [k1][j2] — every access coalesced;
+//   k_ntt_lds   : N1 contiguous N2-point transforms per row (existing kernel, rows = original rows * N1);
+//   k_ntt_unsplit: [k1][k2] -> natural k1 + N1*k2 through an LDS tile (+ the 1/N scale of the inverse).
+namespace vp {
+
+struct SplitArgs {
+    const F *in; F *out;
+    const F *RT; u32 half_m;      // root table of order M
+    int ln, l1;                   // N = 2^ln, N1 = 2^l1
+    int inverse;
+    u32 in_stride;                // elements between input rows
+    u32 ncoset;                   // forward: number of cosets (blockIdx.z = coset); inverse: 1
+};
+template <int L1>
+__global__ void __launch_bounds__(VP_BLOCK) k_ntt_split(SplitArgs a) {
+    constexpr u32 N1 = 1u << L1;
+    const u32 N = 1u << a.ln, N2 = N >> L1, M = 2 * a.half_m;
+    const u32 j2 = blockIdx.x * blockDim.x + threadIdx.x, row = blockIdx.y, coset = blockIdx.z;
+    if (j2 >= N2) return;
+    const u32 wN = M >> a.ln;                                  // w_N = w_M^wN
+    const F *src = a.in + (size_t) row * a.in_stride;
+    F x[N1];
+#pragma unroll
+    for (u32 j1 = 0; j1 < N1; ++j1) {
+        const u32 j = j1 * N2 + j2;
+        F v = src[j];
+        if (!a.inverse && coset) v = f_mul(v, root_pow(a.RT, a.half_m, (u32) (((unsigned long long) j * coset) & (M - 1))));
+        x[j1] = v;
+    }
+    // N1-point DFT, decimation in frequency in registers: natural in, bit-reversed out
+#pragma unroll
+    for (int s = L1; s >= 1; --s) {
+        const u32 half = 1u << (s - 1);
+#pragma unroll
+        for (u32 idx = 0; idx < N1 / 2; ++idx) {
+            const u32 k = idx & (half - 1), i0 = ((idx >> (s - 1)) << s) | k, i1 = i0 + half;
+            u32 e = (k * (N1 >> s)) * (M >> L1);               // w_N1^(k * N1/2^s) in units of w_M
+            if (a.inverse) e = e ? M - e : 0;
+            const F u = x[i0], v = x[i1];
+            x[i0] = f_add(u, v);
+            x[i1] = f_mul(f_sub(u, v), root_pow(a.RT, a.half_m, e));
+        }
+    }
+    F *dst = a.out + ((size_t) row * a.ncoset + coset) * N;
+#pragma unroll
+    for (u32 p = 0; p < N1; ++p) {
+        const u32 k1 = __brev(p) >> (32 - (L1 ? L1 : 1)) >> (L1 ? 0 : 1);     // bit reversal of p in L1 bits
+        u32 e = (u32) (((unsigned long long) j2 * k1 * wN) & (M - 1));         // w_N^(j2 k1)
+        if (a.inverse) e = e ? M - e : 0;
+        dst[(size_t) k1 * N2 + j2] = f_mul(x[p], root_pow(a.RT, a.half_m, e));
+    }
+}
+
+// in: [rows][N1][N2] (k1-major), out: [rows][N] natural (k = k1 + N1*k2); tile of 64 k2 x N1 k1 through LDS
+__global__ void __launch_bounds__(VP_BLOCK)
+k_ntt_unsplit(const F *__restrict__ in, F *__restrict__ out, int ln, int l1, F scale, int do_scale) {
+    __shared__ F tile[16][65];
+    const u32 N = 1u << ln, N1 = 1u << l1, N2 = N >> l1;
+    const u32 row = blockIdx.y, k2_0 = blockIdx.x * 64;
+    const F *src = in + (size_t) row * N;
+    F *dst = out + (size_t) row * N;
+    for (u32 t = threadIdx.x; t < N1 * 64; t += blockDim.x) {
+        const u32 k1 = t / 64, c = t % 64;
+        tile[k1][c] = src[(size_t) k1 * N2 + k2_0 + c];
+    }
+    __syncthreads();
+    for (u32 t = threadIdx.x; t < N1 * 64; t += blockDim.x) {
+        const u32 c = t / N1, k1 = t % N1;
+        F v = tile[k1][c];
+        if (do_scale) v = f_mul(v, scale);
+        dst[(size_t) (k2_0 + c) * N1 + k1] = v;
+    }
+}
+
+}  // namespace vp
+
+// ---- openings (fri::request_init_value_with_merkle, fri.cpp:148-205; fri::request_step_commit, :229-287) ----
+namespace vp {
+// One leaf of a committed oracle: the 64 slice pairs + the (zero) mask pair, and the Merkle path from the leaf up.
+// Coset-major codeword with Nc values per coset: leaf i = 32a + b holds (cw[s][b][a], cw[s][b][a + Nc/2]); for Nc == 1
+// (last FRI level) leaf j < 16 holds (cw[s][j], cw[s][j + 16]).
+__global__ void k_pc_open(const F *__restrict__ cw, u32 Nc, const Dig *__restrict__ tree, u32 n_leaves, u32 leaf,
+                          F *__restrict__ vals /* 65*2 */, Dig *__restrict__ path /* depth+1 */) {
+    const u32 t = threadIdx.x;
+    if (t < 64) {
+        F x, y;
+        if (Nc >= 2) { const u32 a = leaf >> 5, b = leaf & 31; const F *row = cw + ((size_t) t * 32 + b) * Nc; x = row[a]; y = row[a + (Nc >> 1)]; }
+        else { x = cw[(size_t) t * 32 + leaf]; y = cw[(size_t) t * 32 + leaf + 16]; }
+        vals[2 * t] = x; vals[2 * t + 1] = y;
+    } else if (t == 64) {
+        vals[128] = f_zero(); vals[129] = f_zero();
+    }
+    // path[k] = sibling at height k (k < depth), path[depth] = the leaf digest itself (the reference's com_hhash layout)
+    u32 depth = 0;
+    while ((1u << depth) < n_leaves) ++depth;
+    if (t <= depth) {
+        if (t == depth) path[t] = tree[n_leaves + leaf];
+        else path[t] = tree[((n_leaves + leaf) >> t) ^ 1];
+    }
+}
+}  // namespace vp

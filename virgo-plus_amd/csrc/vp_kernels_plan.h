@@ -1,0 +1,473 @@
+// Batched path, part 2: segment kernel k_seg, closing kernel k_emit, and the batched ("plan") launches that run one kernel body for many independent sumchecks.
+// Part of the single translation unit vpgpu.hip (see vp_kernels.h for the overall layout rules).
+#pragma once
+#include "vp_kernels_batch.h"
+
+// ===================================================================================================
+// Segment kernels (default batched path).
+//
+// The cost of this path is integer ALU, not bytes: one F-multiply is ~75 VALU instructions (12 of them
+// v_mad_u64_u32), a lone wave issues one instruction every ~4 cycles, so the dependent chain of a round
+// — not the 288 B per pair — sets the time of every table that does not fill the chip.  Hence:
+//   * k_seg: a workgroup stages a SEGMENT of <= 1024 consecutive entries of V/mult/add in LDS (coalesced
+//     1 KiB wave loads) and runs log2(segment) rounds on it without leaving the CU; ten rounds cost
+//     48 B/entry of HBM reads and 48 B per 1024 entries of writes.  Inside a round the work is split at
+//     F-multiply granularity with WAVE-UNIFORM roles (no divergence): wave role 0: dm*dv + fold V,
+//     1: m0*v0 + fold mult, 2: m1*v1, 3: fold add + its two sums — the chain per round is two multiplies
+//     instead of nine.  Round sums stay in registers (one accumulator per round, rounds unrolled) across
+//     all segments a persistent workgroup processes and are reduced once at the end.
+//   * k_emit: one workgroup finishes the sumcheck: it owns every table that is down to <= 2^e entries
+//     (LDS resident), adds the block partials of the k_seg launches, retires finished tables into
+//     add_term and writes all round polynomials and the claims.
+// ===================================================================================================
+namespace vp {
+
+#ifndef VP_SEG_LOG
+#define VP_SEG_LOG 10           // 1024-entry segments (120 KB of LDS, one workgroup per CU); 9 = 512 entries, two per CU, was measured: no gain
+#endif
+#define VP_SEG (1 << VP_SEG_LOG)
+#define VP_SEG_THREADS 768          // 12 waves = 4 groups x 3 roles
+#define VP_SEG_SLOTS 256            // a group covers 64 pair slots
+
+struct SegTab {
+    u32 off;          // table offset (same in input and output buffers)
+    u32 valid;        // valid entries of the input table
+    u32 seg_start;    // first global segment index of this table
+    int seg_log;      // log2(segment length) = rounds performed on this table by the launch
+};
+struct SegArgs {
+    const F *inV, *inM, *inA;
+    F *outV, *outM, *outA;
+    const F *r;               // r[s] = challenge of the s-th round of this launch
+    F *part;                  // part[s * part_stride + block * 3 + c]
+    u32 part_stride;
+    u32 total_segs;
+    int n_tab, n_rounds;      // n_rounds = max seg_log
+    int has_a; u32 nblk;      // batched launches: table family has an add array; blocks given to this job
+    SegTab t[VP_MAX_TAB];
+};
+
+// Round s of a 1024-entry segment has min(256, 512 >> s) active pair slots; their per-lane accumulators live in
+// LDS at racc_off(s) + slot (767 slots per role in all), so the round loop stays ROLLED: the whole kernel is a
+// few KB of code and stays in the instruction cache (the unrolled version was 62 KB and ran fetch-bound).
+#define VP_SEG_RACC (VP_SEG_LOG >= 9 ? 256 * (VP_SEG_LOG - 9) + 512 : VP_SEG / 2)      /* slots per role: sum of racc_cnt over the rounds (+1) */
+__device__ __forceinline__ u32 racc_cnt(int s) { return min(256u, (u32) (VP_SEG / 2) >> s); }       // active pair slots of round s
+__device__ __forceinline__ u32 racc_off(int s) {                     // sum of racc_cnt over earlier rounds
+    u32 o = 0;
+    for (int q = 0; q < s; ++q) o += racc_cnt(q);
+    return o;                                                        // SEG 1024: 0,256,512,640,...,766   SEG 512: 0,256,384,...,510
+}
+
+// Wave-uniform roles, one code path: role t folds table t (0: V, 1: mult, 2: add) and computes one of the three
+// products of the pair: 0: (m1-m0)(v1-v0)   1: m0*v0   2: m1*v1.  Two multiplies per lane and pair.
+struct SegLds { F bufA[3][VP_SEG]; F bufB[3][VP_SEG / 2]; F racc[4][VP_SEG_RACC]; };   // racc: [role][slot]; [3] = role 2's second sum (a0)
+template <bool HAS_A>
+__device__ __forceinline__ void seg_body(const SegArgs &a, u32 bid, u32 nb, SegLds &sm) {
+    F (&bufA)[3][VP_SEG] = sm.bufA; F (&bufB)[3][VP_SEG / 2] = sm.bufB; F (&racc)[4][VP_SEG_RACC] = sm.racc;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int role = __builtin_amdgcn_readfirstlane(w % 3);
+    const u32 pslot = (u32) ((w / 3) * 64 + lane);
+    for (int i = tid; i < 4 * VP_SEG_RACC; i += VP_SEG_THREADS) (&racc[0][0])[i] = f_zero();
+    __syncthreads();
+
+    for (u32 seg = bid; seg < a.total_segs; seg += nb) {
+        int j = 0;
+        while (j + 1 < a.n_tab && seg >= a.t[j + 1].seg_start) ++j;
+        const SegTab td = a.t[j];
+        const u32 q = seg - td.seg_start;
+        const int R = td.seg_log;
+        const u32 S = 1u << R;
+        const u32 base = td.off + q * S;
+        const u32 vseg = td.valid > q * S ? min(td.valid - q * S, S) : 0;     // valid entries of this segment
+        for (u32 i = tid; i < S; i += VP_SEG_THREADS) {
+            const bool ok = i < vseg;
+            bufA[0][i] = ok ? a.inV[base + i] : f_zero();
+            bufA[1][i] = ok ? a.inM[base + i] : f_zero();
+            if (HAS_A) bufA[2][i] = ok ? a.inA[base + i] : f_zero();
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int s = 0; s < R; ++s) {
+            const F *src = (s & 1) ? &bufB[0][0] : &bufA[0][0];
+            F *dst = (s & 1) ? &bufA[0][0] : &bufB[0][0];
+            const u32 sstr = (s & 1) ? VP_SEG / 2 : VP_SEG, dstr = (s & 1) ? VP_SEG : VP_SEG / 2;
+            const F rs = a.r[s];
+            const u32 n = S >> (s + 1);                                   // pairs of this round
+            const u32 vs = (vseg + (1u << s) - 1) >> s;                   // valid entries of this round
+            const u32 act = (vs + 1) >> 1;                                // pairs that can be non-zero
+            const bool folds = HAS_A || role != 2;
+            const u32 ai = racc_off(s) + pslot;
+            F acc = f_zero(), acc2 = f_zero();
+            for (u32 p = pslot; p < n; p += VP_SEG_SLOTS) {
+                if (p >= act) { if (folds) dst[role * dstr + p] = f_zero(); continue; }
+                F c0 = f_zero(), c1 = f_zero();
+                if (folds) { c0 = src[role * sstr + 2 * p]; c1 = src[role * sstr + 2 * p + 1]; }
+                const F d = f_sub(c1, c0);
+                F x, y;
+                if (role == 0) { x = f_sub(src[sstr + 2 * p + 1], src[sstr + 2 * p]); y = d; }
+                else if (role == 1) { x = c0; y = src[2 * p]; }
+                else { x = src[sstr + 2 * p + 1]; y = src[2 * p + 1]; }
+                F qv = f_mul(x, y);
+                if (role == 2 && HAS_A) { qv = f_add(qv, d); acc2 = f_add(acc2, c0); }
+                acc = f_add(acc, qv);
+                if (folds) dst[role * dstr + p] = f_add(c0, f_mul(rs, d));
+            }
+            if (pslot < n) {
+                racc[role][ai] = f_add(racc[role][ai], acc);
+                if (role == 2 && HAS_A) racc[3][ai] = f_add(racc[3][ai], acc2);
+            }
+            __syncthreads();
+        }
+        // the segment is down to one entry per table
+        if (tid < 3 && q * S < td.valid) {
+            const F *fin = (R & 1) ? bufB[tid] : bufA[tid];
+            if (tid == 0) a.outV[td.off + q] = fin[0];
+            else if (tid == 1) a.outM[td.off + q] = fin[0];
+            else if (HAS_A) a.outA[td.off + q] = fin[0];
+        }
+        __syncthreads();
+    }
+    // per-round block partials: wave q sums one (round, array) list of <= 256 slots, then 3 lanes per round combine
+    F *res = &bufA[0][0];                                        // [s][4]
+    for (int t = w; t < a.n_rounds * 4; t += VP_SEG_THREADS / 64) {
+        const int s = t >> 2, arr = t & 3;
+        const u32 cnt = racc_cnt(s), o = racc_off(s);
+        F x = f_zero();
+        for (u32 i = lane; i < cnt; i += 64) x = f_add(x, racc[arr][o + i]);
+        x = wave_sum63(x);
+        if (lane == 63) res[t] = x;
+    }
+    __syncthreads();
+    if (tid < 3 * a.n_rounds) {
+        const int s = tid / 3, c = tid % 3;
+        const F R0 = res[s * 4], R1 = res[s * 4 + 1], R2 = res[s * 4 + 2], R3 = res[s * 4 + 3];
+        // a = sum dm*dv;  b = sum (m1*v1 + da) - a - sum m0*v0;  c = sum m0*v0 + sum a0
+        const F x = c == 0 ? R0 : c == 1 ? f_sub(R2, f_add(R0, R1)) : f_add(R1, R3);
+        a.part[(size_t) s * a.part_stride + bid * 3 + c] = x;
+    }
+}
+template <bool HAS_A>
+__global__ void __launch_bounds__(VP_SEG_THREADS) k_seg(SegArgs a) {
+    __shared__ SegLds sm;
+    seg_body<HAS_A>(a, blockIdx.x, gridDim.x, sm);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_emit: one workgroup closes a sumcheck.
+//   phase 1  all waves in parallel: reduce the block partials the k_seg launches wrote, one round per wave;
+//   phase 2  only for rounds in which a table owned by this kernel has work: pair products + folds on the
+//            LDS-resident tables (wave-uniform roles), wave sums parked in LDS, one barrier per round;
+//   phase 3  totals per (round, coefficient) in parallel, the add_term recurrence (src/prover.cpp:445,
+//            462-467) by one lane, polynomials and claims written out by parallel lanes.
+// ---------------------------------------------------------------------------------------------------
+#define VP_EMIT_THREADS 768         // 12 waves = 4 groups x 3 roles
+#define VP_EMIT_WAVES (VP_EMIT_THREADS / 64)
+#define VP_MAX_PD 24
+#define VP_EMIT_CAP 1280            // LDS entries per buffer per table family (2 x 3 x 1280 x 16 B = 120 KiB)
+struct EmitTab {
+    u32 off;          // offset in the global buffers
+    int enter;        // first round (1-based) handled here
+    u32 len_enter;    // logical length at `enter` (<= 2^emit_log)
+    u32 valid_enter;  // valid entries at `enter`
+    int src;          // global buffer holding the table at `enter` (tab[src]); V from V0 if v_from_v0
+    int v_from_v0;
+    int bl;           // log2 of the table's length at round 1
+    int pad;
+};
+struct EmitArgs {
+    const F *V0;
+    const F *buf[2][3];
+    const F *r;                 // r[k-1] = challenge of round k
+    const F *part; u32 part_stride;
+    int n_tab, rounds, has_a, emit_log;
+    u32 work_mask;              // bit k-1: some table of this kernel has pairs or retires in round k
+    u32 enter_mask;             // bit k-1: some table is loaded from global memory in round k
+    F *poly_out, *claims_out, *Vu;
+    int n_pd;                   // launches that left block partials
+    struct { int k0, nr; u32 nblk, off; } pd[VP_MAX_PD];   // rounds k0..k0+nr-1: part[off + s*nblk*3 + b*3 + c]
+    EmitTab t[VP_MAX_TAB];
+};
+
+// dynamic LDS: tables [2][3][cap] | psum[32][3] | wred[32][12][3] | claim[64] | retv[64] | atv[32] | retk[64] (int)
+#define VP_EMIT_LDS_EXTRA_F (32 * 3 + 32 * VP_EMIT_WAVES * 3 + VP_MAX_TAB + VP_MAX_TAB + 32)
+__device__ __forceinline__ void emit_body(const EmitArgs &a, unsigned char *smem_raw) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nth = blockDim.x;
+    const u32 E = 1u << a.emit_log, cap = (u32) a.n_tab * E;
+    F *lbuf = reinterpret_cast<F *>(smem_raw);
+    F *psum = lbuf + (size_t) 6 * cap;
+    F *wred = psum + 32 * 3;
+    F *s_claim = wred + 32 * VP_EMIT_WAVES * 3;
+    F *s_retv = s_claim + VP_MAX_TAB;
+    F *s_at = s_retv + VP_MAX_TAB;
+    int *s_retk = reinterpret_cast<int *>(s_at + 32);
+    auto L = [&](int b, int tbl) { return lbuf + ((size_t) (b * 3 + tbl)) * cap; };
+    const int role = __builtin_amdgcn_readfirstlane(w % 3);
+    const u32 pslot = (u32) ((w / 3) * 64 + lane);
+    const u32 pstride = (u32) (VP_EMIT_WAVES / 3) * 64;
+    if (tid < VP_MAX_TAB) { s_claim[tid] = f_zero(); s_retv[tid] = f_zero(); s_retk[tid] = 0; }
+    // ---- phase 1: block partials of the k_seg launches, one round per wave ----
+    for (int k = w + 1; k <= a.rounds; k += VP_EMIT_WAVES) {
+        F ca = f_zero(), cbv = f_zero(), cc = f_zero();
+        for (int d = 0; d < a.n_pd; ++d) {
+            if (k < a.pd[d].k0 || k >= a.pd[d].k0 + a.pd[d].nr) continue;
+            const u32 nb = a.pd[d].nblk;
+            const F *pp = a.part + a.pd[d].off + (size_t) (k - a.pd[d].k0) * nb * 3;
+            for (u32 i = lane; i < nb; i += 64) { ca = f_add(ca, pp[3 * i]); cbv = f_add(cbv, pp[3 * i + 1]); cc = f_add(cc, pp[3 * i + 2]); }
+        }
+        ca = wave_sum63(ca); cbv = wave_sum63(cbv); cc = wave_sum63(cc);
+        if (lane == 63) { psum[3 * (k - 1)] = ca; psum[3 * (k - 1) + 1] = cbv; psum[3 * (k - 1) + 2] = cc; }
+    }
+    __syncthreads();
+    // ---- phase 2: rounds with table work ----
+    const int nrounds = a.rounds > 0 ? a.rounds : 1;
+    for (int k = 1; k <= nrounds; ++k) {
+        if (!((a.work_mask >> (k - 1)) & 1u)) continue;                 // uniform
+        const bool real_round = k <= a.rounds;
+        const int cb = k & 1;
+        if ((a.enter_mask >> (k - 1)) & 1u) {
+            for (int j = 0; j < a.n_tab; ++j) {
+                const EmitTab td = a.t[j];
+                if (td.enter != k) continue;
+                const F *gV = td.v_from_v0 ? a.V0 + td.off : a.buf[td.src][0] + td.off;
+                const F *gM = a.buf[td.src][1] + td.off, *gA = a.buf[td.src][2] + td.off;
+                const bool single = td.bl == 0;                          // always-initialised single entry
+                for (u32 i = tid; i < td.len_enter; i += nth) {
+                    const bool ok = single || i < td.valid_enter;
+                    L(cb, 0)[j * E + i] = ok ? gV[i] : f_zero();
+                    L(cb, 1)[j * E + i] = ok ? gM[i] : f_zero();
+                    L(cb, 2)[j * E + i] = (ok && a.has_a) ? gA[i] : f_zero();
+                }
+            }
+            __syncthreads();
+        }
+        F ca = f_zero(), cbv = f_zero(), cc = f_zero();
+        if (real_round) {
+            const F rk = a.r[k - 1];
+            // global pair index -> (table, pair): tables are scanned with wave-uniform lengths
+            for (u32 gp0 = 0;; gp0 += pstride) {
+                const u32 gp = gp0 + pslot;
+                u32 run = 0; int mj = -1; u32 mp = 0; u32 total = 0;
+                for (int j = 0; j < a.n_tab; ++j) {
+                    const EmitTab td = a.t[j];
+                    if (k < td.enter) continue;
+                    const int sh = k - td.enter;
+                    const u32 len = sh < 32 ? (td.len_enter >> sh) : 0;
+                    const u32 np = len >= 2 ? (len >> 1) : 0;
+                    if (gp >= run && gp < run + np) { mj = j; mp = gp - run; }
+                    run += np;
+                }
+                total = run;
+                if (gp0 >= total) break;                                 // uniform
+                if (mj >= 0) {
+                    const int j = mj; const u32 p = mp;
+                    const F *sV = L(cb, 0) + j * E, *sM = L(cb, 1) + j * E, *sA = L(cb, 2) + j * E;
+                    F *dV = L(cb ^ 1, 0) + j * E, *dM = L(cb ^ 1, 1) + j * E, *dA = L(cb ^ 1, 2) + j * E;
+                    if (role == 0) {
+                        const F m0 = sM[2 * p], m1 = sM[2 * p + 1], v0 = sV[2 * p], v1 = sV[2 * p + 1];
+                        const F dv = f_sub(v1, v0), qa = f_mul(f_sub(m1, m0), dv);
+                        ca = f_add(ca, qa); cbv = f_sub(cbv, qa);
+                        dV[p] = f_add(v0, f_mul(rk, dv));
+                    } else if (role == 1) {
+                        const F m0 = sM[2 * p], m1 = sM[2 * p + 1], v0 = sV[2 * p];
+                        const F qc = f_mul(m0, v0);
+                        cc = f_add(cc, qc); cbv = f_sub(cbv, qc);
+                        dM[p] = f_add(m0, f_mul(rk, f_sub(m1, m0)));
+                    } else {
+                        cbv = f_add(cbv, f_mul(sM[2 * p + 1], sV[2 * p + 1]));
+                        F o = f_zero();
+                        if (a.has_a) {
+                            const F a0 = sA[2 * p], a1 = sA[2 * p + 1];
+                            const F da = f_sub(a1, a0);
+                            cbv = f_add(cbv, da); cc = f_add(cc, a0);
+                            o = f_add(a0, f_mul(rk, da));
+                        }
+                        dA[p] = o;
+                    }
+                }
+            }
+        }
+        // single-entry tables: the entry is the claim; in a real round it retires into add_term.  One lane per table.
+        if (w == VP_EMIT_WAVES - 1 && lane < a.n_tab) {
+            const EmitTab td = a.t[lane];
+            if (k >= td.enter) {
+                const int sh = k - td.enter;
+                const u32 len = sh < 32 ? (td.len_enter >> sh) : 0;
+                if (len == 1) {
+                    const F v = L(cb, 0)[lane * E], m = L(cb, 1)[lane * E], ad = L(cb, 2)[lane * E];
+                    s_claim[lane] = v;
+                    if (real_round) { s_retv[lane] = f_add(f_mul(v, m), ad); s_retk[lane] = k; }
+                }
+            }
+        }
+        if (real_round) {
+            ca = wave_sum63(ca); cbv = wave_sum63(cbv); cc = wave_sum63(cc);
+            if (lane == 63) {
+                F *o = wred + ((size_t) (k - 1) * VP_EMIT_WAVES + w) * 3;
+                o[0] = ca; o[1] = cbv; o[2] = cc;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- phase 3 ----
+    if (tid < a.rounds * 3) {
+        const int k = tid / 3, c = tid % 3;
+        F t = psum[3 * k + c];
+        if ((a.work_mask >> k) & 1u)
+            for (int q = 0; q < VP_EMIT_WAVES; ++q) t = f_add(t, wred[((size_t) k * VP_EMIT_WAVES + q) * 3 + c]);
+        psum[3 * k + c] = t;
+    }
+    if (w == VP_EMIT_WAVES - 1 && lane < a.rounds) {           // retire sum of round lane+1
+        F t = f_zero();
+        for (int j = 0; j < a.n_tab; ++j) if (s_retk[j] == lane + 1) t = f_add(t, s_retv[j]);
+        s_at[lane] = t;
+    }
+    __syncthreads();
+    if (tid == 0) {                                            // add_term recurrence
+        F at = f_zero();
+        for (int k = 1; k <= a.rounds; ++k) {
+            if (k >= 2 && !f_is_zero(at)) at = f_mul(at, f_sub(f_one(), a.r[k - 2]));
+            at = f_add(at, s_at[k - 1]);
+            s_at[k - 1] = at;
+        }
+    }
+    __syncthreads();
+    if (tid < a.rounds * 3) {
+        const int k = tid / 3, c = tid % 3;
+        F t = psum[3 * k + c];
+        if (c == 1) t = f_sub(t, s_at[k]); else if (c == 2) t = f_add(t, s_at[k]);
+        a.poly_out[tid] = t;
+    }
+    if (tid < a.n_tab) {
+        F c = s_claim[tid];
+        if (a.rounds > 0) {
+            const EmitTab td = a.t[tid];
+            if (td.bl == a.rounds) {
+                // as long as the sumcheck: folded to one entry by the last round — here, or already by k_seg
+                if (td.enter > a.rounds) c = td.valid_enter ? (a.buf[td.src][0] + td.off)[0] : f_zero();
+                else c = L((a.rounds + 1) & 1, 0)[tid * E];
+            }
+        }
+        a.claims_out[tid] = c;
+        if (a.Vu && tid == 0) *a.Vu = c;
+    }
+}
+__global__ void __launch_bounds__(VP_EMIT_THREADS) k_emit(EmitArgs a) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    emit_body(a, smem_raw);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Batched ("plan") launches.  Every argument of every launch of a proof depends on the circuit only (the
+// challenges are read from the device tape), so the job descriptors are built once per circuit, kept in
+// device memory, and one launch runs the same kernel body for MANY independent sumchecks: block b looks up
+// (job, block-in-job) in a map.  The hardware runs at most a handful of kernels at a time; with ~40
+// independent sumchecks per proof, batching them side by side is what fills the chip.
+// ---------------------------------------------------------------------------------------------------
+struct BlkMap { u32 job, bid; };
+struct GatherJob { const u32 *rowptr; const uint8_t *e_q; const u32 *e_g; const Half *H; F *M; u32 size; int pad; };
+// phase 0: Liu gather (g), 1 / 2: phase inits (a).  A phase-1 job can carry the inner product V_u = sum_u eq(r_u,u) V[u]
+// of its layer (same rows u): one more coalesced load and two multiplies in a kernel that waits on gathers anyway.
+struct LightJob { InitArgs2 a; GatherJob g; Half dot_h; const F *dot_val; F *dot_part; int phase; u32 dot_size; };
+struct ChunkJob { InitArgs2 a; const u32 *chunk_beg; const u32 *chunk_end; F *part; u32 n_chunks; int phase; };
+struct CombineJob { const u32 *heavy_row; const u32 *heavy_cptr; const F *part; F *M; F *A; u32 n_heavy; int pad; };
+
+__global__ void __launch_bounds__(VP_BLOCK) k_light_multi(const LightJob *__restrict__ jobs, const BlkMap *__restrict__ map) {
+    const BlkMap m = map[blockIdx.x];
+    const LightJob &j = jobs[m.job];
+    if (j.phase == 1) init2_light_body<1>(j.a, m.bid);
+    else if (j.phase == 2) init2_light_body<2>(j.a, m.bid);
+    else liu_gather_body(j.g.rowptr, j.g.e_q, j.g.e_g, j.g.H, j.g.size, j.g.M, m.bid);
+    if (j.phase == 1 && j.dot_part) {                           // uniform per workgroup
+        __shared__ F lds[4];
+        const u32 row = m.bid * blockDim.x + threadIdx.x;
+        F acc[1] = {row < j.dot_size ? f_mul(half_at(j.dot_h, row), j.dot_val[row]) : f_zero()};
+        block_sum<1>(acc, lds);
+        if (threadIdx.x == 0) j.dot_part[m.bid] = acc[0];
+    }
+}
+// Verifier-side wiring predicates (reference: verifier::betaInitPhase1/2 + predicatePhase1/2, src/verifier.cpp:50-113): for
+// layer i,  coeff_l[t] = sum over unary gates g of type t of beta_g[g] beta_u[u_g] (x c_g for Mulc),  bias = the Addc sum
+// x c_g,  coeff_r[t][l] = sum over binary gates of type t with second operand in layer l of beta_g[g] beta_u[u_g] beta_v[lv_g].
+// The gates of a layer are listed by bucket at upload; a wave sums a piece of <= 512 gates, a second launch adds the
+// pieces of each bucket.  flag bit 0: assert gate (beta_g scaled), bits 1-2: class (0 binary, 1 unary, 2 unary x c).
+struct PredArgs {
+    const u32 *idx; const uint8_t *flag; const u32 *chunk_beg; const u32 *chunk_end; u32 n_chunks;
+    Half hg, hu, hv;
+    const u32 *gu; const u32 *glv; const F *gc; const F *assert_r; F *part;
+};
+__global__ void __launch_bounds__(VP_BLOCK) k_pred_chunks(PredArgs a) {
+    const u32 c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (c >= a.n_chunks) return;
+    const int lane = threadIdx.x & 63;
+    F acc = f_zero();
+    for (u32 k = a.chunk_beg[c] + lane; k < a.chunk_end[c]; k += 64) {
+        const u32 g = a.idx[k];
+        const int fl = a.flag[k], cls = fl >> 1;
+        F t = f_mul(half_at(a.hg, g), half_at(a.hu, a.gu[g]));
+        if (fl & 1) t = f_mul(t, *a.assert_r);
+        if (cls == 0) t = f_mul(t, half_at(a.hv, a.glv[g]));
+        else if (cls == 2) t = f_mul(t, a.gc[g]);
+        acc = f_add(acc, t);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) a.part[c] = acc;
+}
+__global__ void __launch_bounds__(VP_BLOCK) k_pred_combine(const u32 *__restrict__ bucket_cptr, u32 n_buckets, const F *__restrict__ part, F *__restrict__ out) {
+    const u32 b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (b >= n_buckets) return;
+    const int lane = threadIdx.x & 63;
+    F acc = f_zero();
+    for (u32 c = bucket_cptr[b] + lane; c < bucket_cptr[b + 1]; c += 64) acc = f_add(acc, part[c]);
+    acc = wave_sum(acc);
+    if (lane == 0) out[b] = acc;
+}
+
+// V_u = V(r_u) = sum_u eq(r_u, u) * V[u] (what phase 1's last fold leaves in the V table, src/prover.cpp:494-500) as an inner
+// product: with it phase 2 of a layer no longer waits for phase 1's sumcheck, every sumcheck of the proof is independent.
+struct DotJob { Half h; const F *val; F *part; F *out; u32 size, nblk; };
+__global__ void __launch_bounds__(VP_BLOCK) k_dot_multi(const DotJob *__restrict__ jobs, const BlkMap *__restrict__ map) {
+    __shared__ F lds[4];
+    const BlkMap m = map[blockIdx.x];
+    const DotJob &j = jobs[m.job];
+    F acc[1] = {f_zero()};
+    for (u32 i = m.bid * blockDim.x + threadIdx.x; i < j.size; i += j.nblk * blockDim.x) acc[0] = f_add(acc[0], f_mul(half_at(j.h, i), j.val[i]));
+    block_sum<1>(acc, lds);
+    if (threadIdx.x == 0) j.part[m.bid] = acc[0];
+}
+__global__ void __launch_bounds__(VP_BLOCK) k_dotfin_multi(const DotJob *__restrict__ jobs) {
+    __shared__ F lds[4];
+    const DotJob &j = jobs[blockIdx.x];
+    F acc[1] = {f_zero()};
+    for (u32 i = threadIdx.x; i < j.nblk; i += blockDim.x) acc[0] = f_add(acc[0], j.part[i]);
+    block_sum<1>(acc, lds);
+    if (threadIdx.x == 0) *j.out = acc[0];
+}
+__global__ void __launch_bounds__(VP_BLOCK) k_chunks_multi(const ChunkJob *__restrict__ jobs, const BlkMap *__restrict__ map) {
+    const BlkMap m = map[blockIdx.x];
+    const ChunkJob &j = jobs[m.job];
+    if (j.phase == 1) init2_chunks_body<1>(j.a, j.chunk_beg, j.chunk_end, j.n_chunks, j.part, m.bid);
+    else init2_chunks_body<2>(j.a, j.chunk_beg, j.chunk_end, j.n_chunks, j.part, m.bid);
+}
+__global__ void __launch_bounds__(VP_BLOCK) k_combine_multi(const CombineJob *__restrict__ jobs, const BlkMap *__restrict__ map) {
+    const BlkMap m = map[blockIdx.x];
+    const CombineJob &j = jobs[m.job];
+    init_combine_body(j.heavy_row, j.heavy_cptr, j.n_heavy, j.part, j.M, j.A, m.bid);
+}
+__global__ void __launch_bounds__(VP_BLOCK, 4) k_sumfold3b_multi(const SfArgs *__restrict__ jobs, const BlkMap *__restrict__ map) {
+    __shared__ Sf3bLds sm;
+    const BlkMap m = map[blockIdx.x];
+    const SfArgs &a = jobs[m.job];
+    if (a.has_a) sumfold3b_body<true>(a, m.bid, a.nblk, sm); else sumfold3b_body<false>(a, m.bid, a.nblk, sm);
+}
+__global__ void __launch_bounds__(VP_SEG_THREADS) k_seg_multi(const SegArgs *__restrict__ jobs, const BlkMap *__restrict__ map) {
+    __shared__ SegLds sm;
+    const BlkMap m = map[blockIdx.x];
+    const SegArgs &a = jobs[m.job];
+    if (a.has_a) seg_body<true>(a, m.bid, a.nblk, sm); else seg_body<false>(a, m.bid, a.nblk, sm);
+}
+__global__ void __launch_bounds__(VP_EMIT_THREADS) k_emit_multi(const EmitArgs *__restrict__ jobs) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    emit_body(jobs[blockIdx.x], smem_raw);
+}
+
+}  // namespace vp

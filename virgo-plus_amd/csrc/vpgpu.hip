@@ -1044,1017 +1044,5 @@ int vp_test_beta(vp_ctx *ctx, const vp_F *r, int n, const vp_F *init, vp_F *out)
 
 }  // extern "C"
 
-// =====================================================================================================
-// Batched GKR, fused launches (default path of vp_prove_gkr; VP_GKR_PATH=simple selects the per-round one)
-// =====================================================================================================
-namespace {
-
-constexpr int SF_BIG_LOG = 17;               // k_sumfold while some lock-step table has >= 2^17 entries
-constexpr int SF_MIN_LOG = 9;                // ... and every one of them keeps >= 2^9 after the launch
-constexpr int TAIL_LOG = 9;                  // tables of <= 2^9 entries are finished by k_tail (one CU: ALU-bound beyond that)
-
-struct FusedSumcheck {
-    int n_tab = 0, rounds = 0, has_a = 1, phase = 0;
-    u32 off[VP_MAX_TAB], len0[VP_MAX_TAB], valid0[VP_MAX_TAB];
-    const F *V0 = nullptr;                   // round-1 V source (phase 1 / Liu: circuitValue[i-1]; phase 2: tab[0][0])
-    const F *r = nullptr;                    // r[k-1] = challenge of round k
-    F *poly_out = nullptr, *claims_out = nullptr;
-};
-
-inline int ilog2(u32 x) { int b = 0; while ((1u << (b + 1)) <= x) ++b; return b; }
-
-template <int R>
-void launch_sumfold(vp_ctx *ctx, const SfArgs &a, u32 grid) {
-    static const int minw = getenv("VP_SF_MINW") ? atoi(getenv("VP_SF_MINW")) : 1;
-    if (minw >= 3) hipLaunchKernelGGL((k_sumfold<R, 3>), dim3(grid), dim3(VP_BLOCK), 0, ctx->ln->stream, a);
-    else if (minw == 2) hipLaunchKernelGGL((k_sumfold<R, 2>), dim3(grid), dim3(VP_BLOCK), 0, ctx->ln->stream, a);
-    else hipLaunchKernelGGL((k_sumfold<R, 1>), dim3(grid), dim3(VP_BLOCK), 0, ctx->ln->stream, a);
-}
-
-int run_sumcheck_fused(vp_ctx *ctx, const FusedSumcheck &sc) {
-    TailArgs ta{};
-    ta.V0 = sc.V0;
-    for (int b = 0; b < 2; ++b) for (int t = 0; t < 3; ++t) ta.buf[b][t] = ctx->ln->tab[b][t];
-    ta.r = sc.r; ta.part = ctx->ln->part2; ta.part_stride = MAX_BLOCKS * 3;
-    ta.n_tab = sc.n_tab; ta.rounds = sc.rounds; ta.has_a = sc.has_a;
-    ta.poly_out = sc.poly_out; ta.claims_out = sc.claims_out;
-    ta.Vu = sc.phase == 1 ? ctx->ln->Vu : nullptr;
-    u32 cur_len[VP_MAX_TAB]; u32 cur_valid[VP_MAX_TAB]; bool in_main[VP_MAX_TAB];
-    for (int j = 0; j < sc.n_tab; ++j) {
-        cur_len[j] = sc.len0[j]; cur_valid[j] = sc.valid0[j];
-        in_main[j] = sc.len0[j] > (1u << TAIL_LOG);
-        ta.t[j].off = sc.off[j]; ta.t[j].len0 = sc.len0[j]; ta.t[j].valid0 = sc.valid0[j];
-        ta.t[j].enter = 1; ta.t[j].cur = 0; ta.t[j].v_from_v0 = (sc.phase != 2) ? 1 : 0;
-    }
-    int k = 1, launch = 0;
-    for (;;) {
-        int R = 3, n_main = 0;
-        for (int j = 0; j < sc.n_tab; ++j)
-            if (in_main[j]) { ++n_main; R = std::min(R, ilog2(cur_len[j]) - TAIL_LOG); }
-        if (!n_main) break;
-        SfArgs a{};
-        if (launch == 0) { a.inV = sc.V0; a.inM = ctx->ln->tab[0][1]; a.inA = ctx->ln->tab[0][2]; }
-        else { F **t = ctx->ln->tab[launch & 1]; a.inV = t[0]; a.inM = t[1]; a.inA = t[2]; }
-        { F **t = ctx->ln->tab[(launch + 1) & 1]; a.outV = t[0]; a.outM = t[1]; a.outA = t[2]; }
-        a.r = sc.r + (k - 1);
-        a.part = ctx->ln->part2 + (size_t) (k - 1) * MAX_BLOCKS * 3;
-        a.part_stride = MAX_BLOCKS * 3;
-        a.has_a = sc.has_a;
-        u32 chunks = 0; int nt = 0; u64 bytes = 0;
-        const u32 per = 64u << R;
-        for (int j = 0; j < sc.n_tab; ++j) {
-            if (!in_main[j]) continue;
-            SfTab &t = a.t[nt++];
-            t.off = sc.off[j]; t.len = cur_len[j]; t.valid = cur_valid[j]; t.chunk_start = chunks;
-            chunks += (cur_valid[j] + per - 1) / per;
-            const u32 vout = (cur_valid[j] + (1u << R) - 1) >> R;
-            bytes += (u64) (cur_valid[j] + vout) * (sc.has_a ? 48 : 32);
-        }
-        a.n_tab = nt; a.total_chunks = chunks;
-        const u32 grid = std::max<u32>(1, std::min<u32>((chunks + 3) / 4, MAX_BLOCKS));
-        const bool prof = ctx->profiling && chunks >= 64 && ctx->ev_used < ctx->ev_pool.size();
-        if (prof) hipEventRecord(ctx->ev_pool[ctx->ev_used].a, ctx->ln->stream);
-        if (R == 3) launch_sumfold<3>(ctx, a, grid); else if (R == 2) launch_sumfold<2>(ctx, a, grid); else launch_sumfold<1>(ctx, a, grid);
-        if (prof) { hipEventRecord(ctx->ev_pool[ctx->ev_used].b, ctx->ln->stream); ctx->ev_pool[ctx->ev_used++].bytes = bytes; }
-        count_launch(ctx);
-        for (int s = 0; s < R; ++s) ta.nblk[k - 1 + s] = (uint16_t) grid;
-        k += R; ++launch;
-        for (int j = 0; j < sc.n_tab; ++j) {
-            if (!in_main[j]) continue;
-            cur_len[j] >>= R;
-            cur_valid[j] = (cur_valid[j] + (1u << R) - 1) >> R;
-            if (cur_len[j] <= (1u << TAIL_LOG)) {
-                in_main[j] = false;
-                ta.t[j].enter = k; ta.t[j].cur = launch & 1;      // out buffer of the launch just issued
-                ta.t[j].v_from_v0 = 0;
-            }
-        }
-    }
-    // size the workgroup to the first-round pairs of the tables it owns (one wave per SIMD is the floor)
-    u32 tail_pairs = 0;
-    for (int j = 0; j < sc.n_tab; ++j) tail_pairs += (std::min<u32>(sc.len0[j], 1u << TAIL_LOG) + 1) / 2;
-    const u32 tail_threads = std::max<u32>(256, std::min<u32>(VP_TAIL_THREADS, (tail_pairs + 63) / 64 * 64));
-    hipLaunchKernelGGL(k_tail, dim3(1), dim3(tail_threads), 0, ctx->ln->stream, ta);
-    count_launch(ctx);
-    ctx->st.rounds += sc.rounds;
-    return VP_OK;
-}
-
-// Segment path.  Lock-step set = tables that still have more than 2^e entries at round k.
-//   throughput regime (some table >= 2^17): k_sumfold<3> on the tables with >= 512 entries, and one k_seg
-//       launch that finishes the shorter ones (separate partial region, same rounds);
-//   latency regime: k_seg on the whole set, ten rounds per launch;
-//   k_emit closes the sumcheck.
-int run_sumcheck_seg(vp_ctx *ctx, const FusedSumcheck &sc) {
-    if (ctx->sumfold_path) return run_sumcheck_fused(ctx, sc);
-    const int e = sc.n_tab * 64 <= VP_EMIT_CAP ? 6 : sc.n_tab * 32 <= VP_EMIT_CAP ? 5 : 4;
-    const u32 E = 1u << e;
-    EmitArgs ea{};
-    ea.V0 = sc.V0;
-    for (int b = 0; b < 2; ++b) for (int t = 0; t < 3; ++t) ea.buf[b][t] = ctx->ln->tab[b][t];
-    ea.r = sc.r; ea.part = ctx->ln->part2; ea.part_stride = 0;
-    ea.n_tab = sc.n_tab; ea.rounds = sc.rounds; ea.has_a = sc.has_a; ea.emit_log = e;
-    ea.poly_out = sc.poly_out; ea.claims_out = sc.claims_out;
-    ea.Vu = (sc.phase == 1 && !ctx->rec) ? ctx->ln->Vu : nullptr;      // plan path: V_u is k_dot_multi's
-    u32 cur_len[VP_MAX_TAB], cur_valid[VP_MAX_TAB];
-    for (int j = 0; j < sc.n_tab; ++j) {
-        cur_len[j] = sc.len0[j]; cur_valid[j] = sc.valid0[j];
-        EmitTab &t = ea.t[j];
-        t.off = sc.off[j]; t.enter = 1; t.len_enter = sc.len0[j]; t.valid_enter = sc.valid0[j];
-        t.src = 0; t.v_from_v0 = (sc.phase != 2) ? 1 : 0; t.bl = ilog2(sc.len0[j]);
-    }
-    u32 part_used = 0;
-    auto new_part = [&](int k0, int nr, u32 nblk) -> F * {
-        if (ea.n_pd >= VP_MAX_PD || (size_t) part_used + (size_t) nr * nblk * 3 > (size_t) 16 * MAX_BLOCKS * 3) return nullptr;
-        auto &d = ea.pd[ea.n_pd++];
-        d.k0 = k0; d.nr = nr; d.nblk = nblk; d.off = part_used;
-        part_used += (u32) nr * nblk * 3;
-        return ctx->ln->part2 + d.off;
-    };
-    int k = 1, launch = 0;
-    for (;;) {
-        int L[VP_MAX_TAB], nL = 0; u32 maxlen = 0;
-        for (int j = 0; j < sc.n_tab; ++j)
-            if (ea.t[j].enter == k && cur_len[j] > E) { L[nL++] = j; maxlen = std::max(maxlen, cur_len[j]); }
-        if (!nL) break;
-        const F *inV, *inM, *inA;
-        if (launch == 0) { inV = sc.V0; inM = ctx->ln->tab[0][1]; inA = ctx->ln->tab[0][2]; }
-        else { F **t = ctx->ln->tab[launch & 1]; inV = t[0]; inM = t[1]; inA = t[2]; }
-        F **to = ctx->ln->tab[(launch + 1) & 1];
-        static const int sf_big_plan = getenv("VP_SF_BIG_LOG") ? atoi(getenv("VP_SF_BIG_LOG")) : SF_BIG_LOG;
-        const bool throughput = maxlen >= (1u << (ctx->rec ? sf_big_plan : SF_BIG_LOG));
-        // ---- k_sumfold<3> on the long tables ----
-        if (throughput) {
-            SfArgs a{};
-            a.inV = inV; a.inM = inM; a.inA = inA; a.outV = to[0]; a.outM = to[1]; a.outA = to[2];
-            a.r = sc.r + (k - 1); a.has_a = sc.has_a;
-            u32 chunks = 0; int nt = 0; u64 bytes = 0;
-            for (int q = 0; q < nL; ++q) {
-                const int j = L[q];
-                if (cur_len[j] < 512) continue;
-                SfTab &t = a.t[nt++];
-                t.off = sc.off[j]; t.len = cur_len[j]; t.valid = cur_valid[j]; t.chunk_start = chunks;
-                chunks += (cur_valid[j] + 511) / 512;
-                bytes += (u64) (cur_valid[j] + ((cur_valid[j] + 7) >> 3)) * (sc.has_a ? 48 : 32);
-            }
-            a.n_tab = nt; a.total_chunks = chunks;
-            static const int sf3b = getenv("VP_SF3B") ? atoi(getenv("VP_SF3B")) : 1;
-            static const u32 sf3b_grid = getenv("VP_SF3B_GRID") ? (u32) atoi(getenv("VP_SF3B_GRID")) : 512;
-            const u32 grid = (sf3b || ctx->rec) ? std::max<u32>(1, std::min<u32>(chunks, std::min<u32>(sf3b_grid, MAX_BLOCKS)))
-                                  : std::max<u32>(1, std::min<u32>((chunks + 3) / 4, MAX_BLOCKS));
-            a.part = new_part(k, 3, grid); a.part_stride = grid * 3;
-            if (!a.part) { ctx->err = "partial buffer exhausted"; return VP_ELIMIT; }
-            const bool prof = !ctx->rec && ctx->profiling && ctx->ev_used < ctx->ev_pool.size();
-            if (prof) hipEventRecord(ctx->ev_pool[ctx->ev_used].a, ctx->ln->stream);
-            if (ctx->rec) { a.nblk = grid; ctx->rec->sf.push_back(a); ctx->rec->push(NK_SF, (u32) ctx->rec->sf.size() - 1, grid, 0, bytes); }
-            else if (!sf3b) launch_sumfold<3>(ctx, a, grid);
-            else if (sc.has_a) hipLaunchKernelGGL(k_sumfold3b<true>, dim3(grid), dim3(VP_BLOCK), 0, ctx->ln->stream, a);
-            else hipLaunchKernelGGL(k_sumfold3b<false>, dim3(grid), dim3(VP_BLOCK), 0, ctx->ln->stream, a);
-            if (prof) { hipEventRecord(ctx->ev_pool[ctx->ev_used].b, ctx->ln->stream); ctx->ev_pool[ctx->ev_used++].bytes = bytes; }
-            count_launch(ctx);
-        }
-        // ---- k_seg on the rest (all of the set in the latency regime) ----
-        SegArgs a{};
-        a.inV = inV; a.inM = inM; a.inA = inA; a.outV = to[0]; a.outM = to[1]; a.outA = to[2];
-        a.r = sc.r + (k - 1);
-        int nt = 0, n_rounds = 0; u32 segs = 0;
-        int seg_j[VP_MAX_TAB];
-        for (int q = 0; q < nL; ++q) {
-            const int j = L[q];
-            if (throughput && cur_len[j] >= 512) continue;
-            SegTab &t = a.t[nt];
-            t.off = sc.off[j]; t.valid = cur_valid[j]; t.seg_start = segs;
-            t.seg_log = std::min(VP_SEG_LOG, ilog2(cur_len[j]));
-            segs += (cur_valid[j] + (1u << t.seg_log) - 1) >> t.seg_log;
-            n_rounds = std::max(n_rounds, t.seg_log);
-            seg_j[nt++] = j;
-        }
-        if (nt) {
-            a.total_segs = segs; a.n_tab = nt; a.n_rounds = n_rounds;
-            const u32 grid = std::max<u32>(1, std::min<u32>(segs, 512));
-            a.part = new_part(k, n_rounds, grid); a.part_stride = grid * 3;
-            if (!a.part) { ctx->err = "partial buffer exhausted"; return VP_ELIMIT; }
-            a.has_a = sc.has_a; a.nblk = grid;
-            if (ctx->rec) { ctx->rec->seg.push_back(a); ctx->rec->push(NK_SEG, (u32) ctx->rec->seg.size() - 1, grid); }
-            else if (sc.has_a) hipLaunchKernelGGL(k_seg<true>, dim3(grid), dim3(VP_SEG_THREADS), 0, ctx->ln->stream, a);
-            else hipLaunchKernelGGL(k_seg<false>, dim3(grid), dim3(VP_SEG_THREADS), 0, ctx->ln->stream, a);
-            count_launch(ctx);
-        }
-        // ---- advance ----
-        int step = throughput ? 3 : n_rounds;
-        for (int q = 0; q < nL; ++q) {
-            const int j = L[q];
-            const bool via_sf = throughput && cur_len[j] >= 512;
-            const int sl = via_sf ? 3 : std::min(VP_SEG_LOG, ilog2(cur_len[j]));
-            cur_len[j] >>= sl;
-            cur_valid[j] = (cur_valid[j] + (1u << sl) - 1) >> sl;
-            EmitTab &t = ea.t[j];
-            t.enter = k + sl; t.len_enter = cur_len[j]; t.valid_enter = cur_valid[j];
-            t.src = (launch + 1) & 1; t.v_from_v0 = 0;
-        }
-        k += step; ++launch;
-        if (!throughput && n_rounds < VP_SEG_LOG) break;               // every table of the set is finished
-    }
-    // rounds in which k_emit has table work: pairs while len >= 2, the retire / claim round when len == 1
-    for (int j = 0; j < sc.n_tab; ++j) {
-        const EmitTab &t = ea.t[j];
-        const int last = t.enter + ilog2(std::max<u32>(1, t.len_enter));
-        for (int kk = t.enter; kk <= last && kk <= std::max(sc.rounds, 1); ++kk) ea.work_mask |= 1u << (kk - 1);
-        if (t.enter <= std::max(sc.rounds, 1)) ea.enter_mask |= 1u << (t.enter - 1);
-    }
-    const size_t lds = ((size_t) 6 * sc.n_tab * E + VP_EMIT_LDS_EXTRA_F) * sizeof(F) + VP_MAX_TAB * sizeof(int);
-    if (ctx->rec) { ctx->rec->emit.push_back(ea); ctx->rec->push(NK_EMIT, (u32) ctx->rec->emit.size() - 1, 1, (u32) lds); ctx->rec->chains[ctx->rec->cur].back().rounds = sc.rounds; }
-    else hipLaunchKernelGGL(k_emit, dim3(1), dim3(VP_EMIT_THREADS), lds, ctx->ln->stream, ea);
-    count_launch(ctx);
-    ctx->st.rounds += sc.rounds;
-    return VP_OK;
-}
-
-template <int PHASE>
-int run_init2_rows(vp_ctx *ctx, const Csr &c, InitArgs2 &a) {
-    a.rowptr = c.rowptr; a.e_g = c.e_g; a.e_x = c.e_x; a.e_tl = c.e_tl; a.n_rows = c.n_rows;
-    if (ctx->rec) {
-        PlanRec &R = *ctx->rec;
-        if (c.n_rows) {
-            LightJob j{}; j.a = a; j.phase = PHASE;
-            u32 rows = c.n_rows;
-            if (PHASE == 1 && ctx->rec_dot.part) {              // the launch covers every wire of the layer, not only the rows with contributions
-                rows = std::max<u32>(rows, ctx->rec_dot.size);
-                j.dot_h = ctx->rec_dot.h; j.dot_val = ctx->rec_dot.val; j.dot_part = ctx->rec_dot.part; j.dot_size = ctx->rec_dot.size;
-                ctx->rec_dot.nblk = nblk(rows);
-            }
-            R.light.push_back(j); R.push(NK_LIGHT, (u32) R.light.size() - 1, nblk(rows));
-        }
-        if (c.n_chunks) {
-            ChunkJob j{}; j.a = a; j.chunk_beg = c.chunk_beg; j.chunk_end = c.chunk_end; j.part = ctx->ln->chunk_part; j.n_chunks = c.n_chunks; j.phase = PHASE;
-            R.chunks.push_back(j); R.push(NK_CHUNKS, (u32) R.chunks.size() - 1, (c.n_chunks + 3) / 4);
-            CombineJob q{}; q.heavy_row = c.heavy_row; q.heavy_cptr = c.heavy_cptr; q.part = ctx->ln->chunk_part; q.M = a.M; q.A = a.A; q.n_heavy = c.n_heavy;
-            R.combine.push_back(q); R.push(NK_COMBINE, (u32) R.combine.size() - 1, (c.n_heavy + 3) / 4);
-        }
-        return VP_OK;
-    }
-    if (c.n_rows) {
-        hipLaunchKernelGGL(k_init2_light<PHASE>, dim3(nblk(c.n_rows)), dim3(VP_BLOCK), 0, ctx->ln->stream, a);
-        count_launch(ctx);
-    }
-    if (c.n_chunks) {
-        hipLaunchKernelGGL(k_init2_chunks<PHASE>, dim3((c.n_chunks + 3) / 4), dim3(VP_BLOCK), 0, ctx->ln->stream, a,
-                           c.chunk_beg, c.chunk_end, c.n_chunks, ctx->ln->chunk_part);
-        hipLaunchKernelGGL(k_init_combine, dim3((c.n_heavy + 3) / 4), dim3(VP_BLOCK), 0, ctx->ln->stream, c.heavy_row,
-                           c.heavy_cptr, c.n_heavy, ctx->ln->chunk_part, a.M, a.A);
-        count_launch(ctx); count_launch(ctx);
-    }
-    return VP_OK;
-}
-
-}  // namespace
-
-extern "C" {
-
-// Every launch of the GKR part (all lanes, fork and join included), in submission order.  No host synchronisation and no
-// host-dependent argument in here: the same sequence is what the hipGraph of the proof captures.
-static int submit_gkr(vp_ctx *ctx, bool serial) {
-    const int n = ctx->n_layers;
-    // Given the tape, every sumcheck of the proof is independent of the others except phase 1 -> phase 2 of the
-    // same layer (V_u).  Layer i's phases 1+2 and its Liu sumcheck each get their own lane (stream + scratch);
-    // profiling, the sumfold path and VP_GKR_SERIAL=1 run everything on the main lane instead.
-    Lane *main_lane = &ctx->lane0;
-    ctx->ln = main_lane;
-    F *tr = ctx->d_tr;
-    // every eq half table of the proof in one launch (they depend on the tape only)
-    if (!ctx->rec) {
-        hipLaunchKernelGGL(k_beta_half_multi, dim3(ctx->n_all_jobs), dim3(VP_BLOCK), 0, ctx->stream, ctx->all_jobs);
-        count_launch(ctx);
-        // Vres (verifier.cpp:151): eq(r_0, .) is layer n-1's phase-1 table
-        LayerDev &T = ctx->L[n - 1];
-        hipLaunchKernelGGL(k_vres2, dim3(1), dim3(VP_BLOCK), 0, ctx->stream, T.hg, T.val, (u32) T.size, tr);
-        count_launch(ctx);
-    }
-    if (!serial && !ctx->rec) {
-        HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
-        for (int q = 0; q < 2 * (n - 1); ++q) HIPCHK(hipStreamWaitEvent(ctx->lanes[q].stream, ctx->ev_fork, 0));
-    }
-    // transcript positions (top layer first, as the verifier consumes them)
-    std::vector<u64> pos_p1(n), pos_p2(n), pos_liu(n);
-    u64 pos = 1;
-    for (int i = n - 1; i >= 1; --i) {
-        const u64 pbl = ctx->L[i - 1].bl;
-        pos_p1[i] = pos; pos += 3 * pbl + 1;
-        pos_p2[i] = pos; if (ctx->L[i].max_dad_bl != -1) pos += 3 * (u64) ctx->L[i].max_dad_bl + i;
-        pos_liu[i] = pos; pos += 3 * pbl + 1;
-    }
-    if (pos != ctx->n_tr) { ctx->err = "internal: transcript size"; return VP_EINVAL; }
-    // submit the largest layers first so that the long chains start early
-    std::vector<int> order;
-    for (int i = 1; i < n; ++i) order.push_back(i);
-    if (!serial) std::sort(order.begin(), order.end(), [&](int x, int y) { return ctx->L[x - 1].size + ctx->L[x].size > ctx->L[y - 1].size + ctx->L[y].size; });
-    else std::reverse(order.begin(), order.end());
-    for (int i : order) {
-        LayerDev &cur = ctx->L[i], &pre = ctx->L[i - 1];
-        const int pbl = pre.bl;
-        // ---- Liu (independent of phases 1 and 2) ----
-        {
-            ctx->ln = serial ? main_lane : &ctx->lanes[2 * (i - 1) + 1];
-            if (ctx->rec) {
-                ctx->rec->cur = 2 * (i - 1) + 1;
-                LightJob j{}; j.phase = 0;
-                j.g.rowptr = cur.lrow; j.g.e_q = cur.l_q; j.g.e_g = cur.l_g; j.g.H = cur.liu_H; j.g.M = ctx->ln->tab[0][1]; j.g.size = (u32) pre.size;
-                ctx->rec->light.push_back(j); ctx->rec->push(NK_LIGHT, (u32) ctx->rec->light.size() - 1, nblk(pre.size));
-            } else
-            hipLaunchKernelGGL(k_liu_gather, dim3(nblk(pre.size)), dim3(VP_BLOCK), 0, ctx->ln->stream, cur.lrow, cur.l_q,
-                               cur.l_g, cur.liu_H, (u32) pre.size, ctx->ln->tab[0][1]);
-            count_launch(ctx);
-            FusedSumcheck sc;
-            sc.n_tab = 1; sc.rounds = pbl; sc.has_a = 0; sc.phase = 3;
-            sc.off[0] = 0; sc.len0[0] = 1u << pbl; sc.valid0[0] = (u32) pre.size;
-            sc.V0 = pre.val; sc.r = ctx->d_tape + ctx->rliu_off[i];
-            sc.poly_out = tr + pos_liu[i]; sc.claims_out = tr + pos_liu[i] + 3 * (u64) pbl;
-            VPCHK(run_sumcheck_seg(ctx, sc));
-        }
-        // ---- phase 1 ----
-        ctx->ln = serial ? main_lane : &ctx->lanes[2 * (i - 1)];
-        if (ctx->rec) ctx->rec->cur = 2 * (i - 1);
-        {
-            InitArgs2 a{};
-            a.hg = cur.hg; a.vals = ctx->d_vals; a.gc = cur.gc; a.assert_r = ctx->d_tape + ctx->as_off[i];
-            a.M = ctx->ln->tab[0][1]; a.A = ctx->ln->tab[0][2];
-            ctx->rec_dot = DotJob{};
-            if (ctx->rec && cur.max_dad_bl != -1 && cur.c1.n_rows) {
-                Lane &p2 = ctx->lanes[2 * (n - 1) + (i - 1)];
-                ctx->rec_dot.h = cur.hu; ctx->rec_dot.val = pre.val; ctx->rec_dot.part = p2.dot_part;
-                ctx->rec_dot.out = p2.Vu; ctx->rec_dot.size = (u32) pre.size;
-            }
-            VPCHK(run_init2_rows<1>(ctx, cur.c1, a));
-            FusedSumcheck sc;
-            sc.n_tab = 1; sc.rounds = pbl; sc.has_a = 1; sc.phase = 1;
-            sc.off[0] = 0; sc.len0[0] = 1u << pbl; sc.valid0[0] = (u32) pre.size;
-            sc.V0 = pre.val; sc.r = ctx->d_tape + ctx->ru_off[i];
-            sc.poly_out = tr + pos_p1[i]; sc.claims_out = tr + pos_p1[i] + 3 * (u64) pbl;
-            VPCHK(run_sumcheck_seg(ctx, sc));
-        }
-        // ---- phase 2 (same lane: needs V_u) ----
-        const int mdb = cur.max_dad_bl;
-        if (mdb != -1) {
-            if (ctx->rec) {
-                // own chain: V_u comes from an inner product instead of phase 1's last fold
-                const int li = 2 * (n - 1) + (i - 1);
-                ctx->ln = &ctx->lanes[li]; ctx->rec->cur = li;
-                if (ctx->rec_dot.part && ctx->rec_dot.nblk) {
-                    // the phase-1 init launch of this layer left the block partials: wait for it (placeholder step), then combine
-                    ctx->rec->dot.push_back(ctx->rec_dot);
-                    ctx->rec->chains[li].push_back(PStep{-1, 0, 0, 0, 0, 0, -1});
-                    ctx->rec->push(NK_DOTFIN, (u32) ctx->rec->dot.size() - 1, 1);
-                    ctx->rec->chains[li].back().xchain = 2 * (i - 1);
-                } else {
-                    DotJob d{}; d.h = cur.hu; d.val = pre.val; d.part = ctx->ln->part2; d.out = ctx->ln->Vu; d.size = (u32) pre.size;
-                    d.nblk = std::max<u32>(1, std::min<u32>(nblk(pre.size), 128));
-                    ctx->rec->dot.push_back(d);
-                    ctx->rec->push(NK_DOT, (u32) ctx->rec->dot.size() - 1, d.nblk);
-                    ctx->rec->push(NK_DOTFIN, (u32) ctx->rec->dot.size() - 1, 1);
-                }
-            }
-            InitArgs2 a{};
-            a.hg = cur.hg; a.hu = cur.hu; a.vals = ctx->d_vals; a.gc = cur.gc; a.assert_r = ctx->d_tape + ctx->as_off[i];
-            a.Vu = ctx->ln->Vu;
-            a.V = ctx->ln->tab[0][0]; a.M = ctx->ln->tab[0][1]; a.A = ctx->ln->tab[0][2];
-            a.s_layer = cur.s_layer; a.s_idx = cur.s_idx;
-            VPCHK(run_init2_rows<2>(ctx, cur.c2, a));
-            FusedSumcheck sc;
-            sc.n_tab = i; sc.rounds = mdb; sc.has_a = 1; sc.phase = 2;
-            for (int j = 0; j < i; ++j) { sc.off[j] = cur.t_off[j]; sc.len0[j] = cur.t_len[j]; sc.valid0[j] = (u32) cur.dad_size[j]; }
-            sc.V0 = ctx->ln->tab[0][0]; sc.r = ctx->d_tape + ctx->rv_off[i];
-            sc.poly_out = tr + pos_p2[i]; sc.claims_out = tr + pos_p2[i] + 3 * (u64) mdb;
-            VPCHK(run_sumcheck_seg(ctx, sc));
-        }
-    }
-    ctx->ln = main_lane;
-    if (!serial && !ctx->rec) {
-        for (int q = 0; q < 2 * (n - 1); ++q) {
-            Lane &ln = ctx->lanes[q];
-            HIPCHK(hipEventRecord(ln.done, ln.stream));
-            HIPCHK(hipStreamWaitEvent(ctx->stream, ln.done, 0));
-        }
-    }
-    return VP_OK;
-}
-
-// ---- plan: record, merge, upload ---------------------------------------------------------------------
-static void free_plan(vp_ctx *ctx) {
-    if (!ctx->plan) return;
-    for (auto &nd : ctx->plan->nodes) if (nd.ev) (void) hipEventDestroy(nd.ev);
-    if (ctx->plan->ev_root) (void) hipEventDestroy(ctx->plan->ev_root);
-    for (int q = 0; q < 4; ++q) if (ctx->plan->ev_join[q]) (void) hipEventDestroy(ctx->plan->ev_join[q]);
-    for (int q = 1; q < 4; ++q) if (ctx->plan->streams[q]) (void) hipStreamDestroy(ctx->plan->streams[q]);
-    delete ctx->plan;                       // device arrays are owned by ctx->allocs
-    ctx->plan = nullptr;
-}
-
-// Chains = the lanes of the stream path (Liu of layer i; phases 1+2 of layer i).  Step t of the plan holds the t-th launch
-// of every chain; launches of one kernel kind inside a step become ONE node.  A node depends on the nodes that hold the
-// previous launch of each of its chains, nothing else.
-static int build_plan(vp_ctx *ctx) {
-    free_plan(ctx);
-    PlanRec rec;
-    rec.chains.assign(ctx->lanes.size() + 1, {});
-    ctx->rec = &rec;
-    const vp_stats keep = ctx->st;
-    ctx->st.rounds = 0;
-    int rc = submit_gkr(ctx, false);
-    ctx->rec = nullptr;
-    {   // Vres (verifier.cpp:151) = <eq(r_0, .), output layer>: one more inner-product chain instead of a lone workgroup up front
-        LayerDev &T = ctx->L[ctx->n_layers - 1];
-        DotJob d{}; d.h = T.hg; d.val = T.val; d.part = ctx->partials; d.out = ctx->d_tr; d.size = (u32) T.size;
-        d.nblk = std::max<u32>(1, std::min<u32>(nblk(T.size), 128));
-        rec.dot.push_back(d);
-        rec.cur = (int) ctx->lanes.size();
-        rec.push(NK_DOT, (u32) rec.dot.size() - 1, d.nblk);
-        rec.push(NK_DOTFIN, (u32) rec.dot.size() - 1, 1);
-    }
-    const u64 rounds = ctx->st.rounds;
-    ctx->st = keep;
-    if (rc != VP_OK) return rc;
-    Plan *P = new Plan();
-    ctx->plan = P;
-    P->rounds = rounds;
-    static const int kind_stream[NK_COUNT] = {0, 0, 0, 0, 0, 1, 2, 3};
-    size_t T = 0;
-    for (auto &c : rec.chains) T = std::max(T, c.size());
-    P->n_steps = (int) T;
-    std::vector<LightJob> light; std::vector<ChunkJob> chunks; std::vector<CombineJob> combine; std::vector<DotJob> dot, dotfin;
-    std::vector<SfArgs> sf; std::vector<SegArgs> seg; std::vector<EmitArgs> emit;
-    std::vector<BlkMap> map;
-    // Placement of a chain's launches on the global step axis: its init and fold launches start at step 0 (the throughput
-    // work of every chain is available to the device from the beginning), its closing k_seg / k_emit launches are aligned
-    // at the END, so that those of all chains fall into the same few steps (one node each instead of a tail of small,
-    // serialised ones).  VP_PLAN_ALIGN=left|right: everything at the start / at the end.
-    static const char *al = getenv("VP_PLAN_ALIGN");
-    const bool align_left = al && !strcmp(al, "left"), align_right = al && !strcmp(al, "right");
-    std::vector<std::vector<size_t>> pos(rec.chains.size());
-    for (size_t c = 0; c < rec.chains.size(); ++c) {
-        const auto &ch = rec.chains[c];
-        size_t suf = ch.size();
-        while (suf > 0 && (ch[suf - 1].kind == NK_SEG || ch[suf - 1].kind == NK_EMIT)) --suf;
-        if (align_left) suf = ch.size();
-        if (align_right) suf = 0;
-        pos[c].resize(ch.size());
-        for (size_t k = 0; k < ch.size(); ++k) pos[c][k] = k < suf ? k : T - (ch.size() - k);
-    }
-    std::vector<size_t> cursor(rec.chains.size(), 0);
-    std::vector<int> last_node(rec.chains.size(), -1), pending(rec.chains.size(), -1);
-    for (size_t t = 0; t < T; ++t) {
-        for (size_t c = 0; c < rec.chains.size(); ++c)            // placeholder steps only consume their slot
-            if (cursor[c] < rec.chains[c].size() && pos[c][cursor[c]] == t && rec.chains[c][cursor[c]].kind < 0) ++cursor[c];
-        for (int kind = 0; kind < NK_COUNT; ++kind) {
-            PNode nd; nd.kind = kind; nd.step = (int) t; nd.stream = kind_stream[kind]; nd.map_off = (u32) map.size();
-            u32 first = 0;
-            switch (kind) {
-                case NK_LIGHT: first = (u32) light.size(); break; case NK_DOT: first = (u32) dot.size(); break; case NK_DOTFIN: first = (u32) dotfin.size(); break;
-                case NK_CHUNKS: first = (u32) chunks.size(); break; case NK_COMBINE: first = (u32) combine.size(); break;
-                case NK_SF: first = (u32) sf.size(); break; case NK_SEG: first = (u32) seg.size(); break;
-                default: first = (u32) emit.size(); break;
-            }
-            nd.first = first;
-            for (size_t c = 0; c < rec.chains.size(); ++c) {
-                const size_t k = cursor[c];
-                if (k >= rec.chains[c].size() || pos[c][k] != t || rec.chains[c][k].kind != kind) continue;
-                const PStep &st = rec.chains[c][k];
-                const u32 job = first + nd.count;
-                switch (kind) {
-                    case NK_LIGHT: light.push_back(rec.light[st.idx]); break; case NK_DOT: dot.push_back(rec.dot[st.idx]); break; case NK_DOTFIN: dotfin.push_back(rec.dot[st.idx]); break;
-                    case NK_CHUNKS: chunks.push_back(rec.chunks[st.idx]); break; case NK_COMBINE: combine.push_back(rec.combine[st.idx]); break;
-                    case NK_SF: sf.push_back(rec.sf[st.idx]); break; case NK_SEG: seg.push_back(rec.seg[st.idx]); break;
-                    default: emit.push_back(rec.emit[st.idx]); break;
-                }
-                if (kind != NK_EMIT && kind != NK_DOTFIN) for (u32 b = 0; b < st.grid; ++b) map.push_back(BlkMap{job - first, b});
-                nd.grid += st.grid; nd.lds = std::max(nd.lds, st.lds); nd.bytes += st.bytes; ++nd.count;
-                if (last_node[c] >= 0 && std::find(nd.deps.begin(), nd.deps.end(), last_node[c]) == nd.deps.end()) nd.deps.push_back(last_node[c]);
-                if (st.xchain >= 0) {
-                    const int x = last_node[st.xchain];
-                    if (x < 0) { ctx->err = "internal: plan cross dependency not placed yet"; return VP_EINVAL; }
-                    if (std::find(nd.deps.begin(), nd.deps.end(), x) == nd.deps.end()) nd.deps.push_back(x);
-                }
-                pending[c] = (int) P->nodes.size();                  // this node (pushed below); becomes last_node at the end of the step
-            }
-            if (nd.count) P->nodes.push_back(nd);
-        }
-        // advance the chains placed in this step
-        for (size_t c = 0; c < rec.chains.size(); ++c)
-            if (pending[c] >= 0) { last_node[c] = pending[c]; pending[c] = -1; ++cursor[c]; }
-    }
-    for (auto &nd : P->nodes)
-        for (int d : nd.deps) if (P->nodes[d].stream != nd.stream) P->nodes[d].record = true;
-    for (auto &nd : P->nodes) HIPCHK(hipEventCreateWithFlags(&nd.ev, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&P->ev_root, hipEventDisableTiming));
-    for (int q = 0; q < 4; ++q) HIPCHK(hipEventCreateWithFlags(&P->ev_join[q], hipEventDisableTiming));
-    VPCHK(dupload(ctx, &P->d_dot, dot)); VPCHK(dupload(ctx, &P->d_dotfin, dotfin));
-    VPCHK(dupload(ctx, &P->d_light, light)); VPCHK(dupload(ctx, &P->d_chunks, chunks));
-    VPCHK(dupload(ctx, &P->d_combine, combine)); VPCHK(dupload(ctx, &P->d_sf, sf)); VPCHK(dupload(ctx, &P->d_seg, seg));
-    VPCHK(dupload(ctx, &P->d_emit, emit)); VPCHK(dupload(ctx, &P->d_map, map));
-    // streams owned by the plan (stream priorities were measured: no effect under hipGraph replay, harmful on direct submission)
-    P->streams[0] = ctx->stream;
-    for (int q = 1; q < 4; ++q) HIPCHK(hipStreamCreateWithFlags(&P->streams[q], hipStreamNonBlocking));
-    return VP_OK;
-}
-
-static void launch_node(const Plan &P, const PNode &nd, hipStream_t st) {
-    const BlkMap *mp = P.d_map + nd.map_off;
-    switch (nd.kind) {
-        case NK_LIGHT: hipLaunchKernelGGL(k_light_multi, dim3(nd.grid), dim3(VP_BLOCK), 0, st, P.d_light + nd.first, mp); break;
-        case NK_DOT: hipLaunchKernelGGL(k_dot_multi, dim3(nd.grid), dim3(VP_BLOCK), 0, st, P.d_dot + nd.first, mp); break;
-        case NK_DOTFIN: hipLaunchKernelGGL(k_dotfin_multi, dim3(nd.count), dim3(VP_BLOCK), 0, st, P.d_dotfin + nd.first); break;
-        case NK_CHUNKS: hipLaunchKernelGGL(k_chunks_multi, dim3(nd.grid), dim3(VP_BLOCK), 0, st, P.d_chunks + nd.first, mp); break;
-        case NK_COMBINE: hipLaunchKernelGGL(k_combine_multi, dim3(nd.grid), dim3(VP_BLOCK), 0, st, P.d_combine + nd.first, mp); break;
-        case NK_SF: hipLaunchKernelGGL(k_sumfold3b_multi, dim3(nd.grid), dim3(VP_BLOCK), 0, st, P.d_sf + nd.first, mp); break;
-        case NK_SEG: hipLaunchKernelGGL(k_seg_multi, dim3(nd.grid), dim3(VP_SEG_THREADS), 0, st, P.d_seg + nd.first, mp); break;
-        default: hipLaunchKernelGGL(k_emit_multi, dim3(nd.count), dim3(VP_EMIT_THREADS), nd.lds, st, P.d_emit + nd.first); break;
-    }
-}
-
-// Replays the plan: four streams (init kernels | k_sumfold3b | k_seg | k_emit), events only where a node's predecessor
-// ran on another stream.  single = everything on the main stream in step order (profiling: the k_sumfold3b nodes are
-// bracketed with events).
-static int submit_plan(vp_ctx *ctx, bool single) {
-    Plan &P = *ctx->plan;
-    hipLaunchKernelGGL(k_beta_half_direct, dim3(ctx->n_all_jobs * ctx->beta_bpj), dim3(VP_BLOCK), 0, ctx->stream, ctx->all_jobs, ctx->beta_bpj);
-    ctx->st.launches += 1 + P.nodes.size();
-    ctx->st.rounds += P.rounds;
-    if (!single) {
-        HIPCHK(hipEventRecord(P.ev_root, ctx->stream));
-        for (int q = 1; q < 4; ++q) HIPCHK(hipStreamWaitEvent(P.streams[q], P.ev_root, 0));
-    }
-    for (auto &nd : P.nodes) {
-        hipStream_t st = single ? ctx->stream : P.streams[nd.stream];
-        if (!single) for (int d : nd.deps) if (P.nodes[d].stream != nd.stream) HIPCHK(hipStreamWaitEvent(st, P.nodes[d].ev, 0));
-        const bool prof = single && ctx->profiling && nd.kind == NK_SF && ctx->ev_used < ctx->ev_pool.size();
-        if (prof) hipEventRecord(ctx->ev_pool[ctx->ev_used].a, st);
-        launch_node(P, nd, st);
-        if (prof) { hipEventRecord(ctx->ev_pool[ctx->ev_used].b, st); ctx->ev_pool[ctx->ev_used++].bytes = nd.bytes; }
-        if (!single && nd.record) HIPCHK(hipEventRecord(nd.ev, st));
-    }
-    if (!single) {
-        for (int q = 1; q < 4; ++q) {
-            HIPCHK(hipEventRecord(P.ev_join[q], P.streams[q]));
-            HIPCHK(hipStreamWaitEvent(ctx->stream, P.ev_join[q], 0));
-        }
-    }
-    return VP_OK;
-}
-
-static int prove_gkr_fused(vp_ctx *ctx, const vp_F *tape, uint64_t n_tape, uint8_t *transcript, uint64_t *n_written) {
-    HIPCHK(hipSetDevice(ctx->device));
-    static const bool dbg_t = getenv("VP_DEBUG") != nullptr;
-    const auto t_in = std::chrono::steady_clock::now();
-    const bool use_plan = ctx->plan_path && !ctx->sumfold_path;
-    const bool serial = ctx->serial || ctx->profiling || ctx->sumfold_path;
-    F *tr = ctx->d_tr;
-    const u64 pos = ctx->n_tr;
-    ctx->ev_used = 0;
-    if (use_plan && !ctx->plan) VPCHK(build_plan(ctx));
-    // pinned staging: pageable copies would be staged synchronously by the runtime on both sides of the proof
-    if (ctx->h_io_cap < n_tape + pos) {
-        if (ctx->h_io) (void) hipHostFree(ctx->h_io);
-        ctx->h_io = nullptr; ctx->h_io_cap = 0;
-        HIPCHK(hipHostMalloc((void **) &ctx->h_io, (n_tape + pos) * sizeof(F), hipHostMallocDefault));
-        ctx->h_io_cap = n_tape + pos;
-    }
-    memcpy(ctx->h_io, tape, n_tape * sizeof(F));
-    HIPCHK(hipMemcpyAsync(ctx->d_tape, ctx->h_io, n_tape * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
-    // The launch sequence depends on the circuit only (the tape is read on the device), so the concurrent form is
-    // captured once per circuit into a hipGraph and replayed: one submission instead of ~170, every lane starts at once.
-    if (ctx->use_graph && !serial && !ctx->gkr_graph && !ctx->graph_failed) {
-        ctx->st.launches = 0; ctx->st.rounds = 0;
-        hipGraph_t g = nullptr;
-        int rc = VP_OK;
-        static const bool dbg = getenv("VP_DEBUG") != nullptr;
-        if (dbg) fprintf(stderr, "[vp] capture begin\n");
-        if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed) != hipSuccess) rc = VP_EHIP;
-        if (rc == VP_OK) {
-            rc = use_plan ? submit_plan(ctx, false) : submit_gkr(ctx, false);
-            if (dbg) fprintf(stderr, "[vp] submitted rc=%d\n", rc);
-            if (hipStreamEndCapture(ctx->stream, &g) != hipSuccess || !g) rc = rc == VP_OK ? VP_EHIP : rc;
-            if (dbg) fprintf(stderr, "[vp] capture end rc=%d g=%p\n", rc, (void *) g);
-        }
-        if (rc == VP_OK && hipGraphInstantiate(&ctx->gkr_graph, g, nullptr, nullptr, 0) != hipSuccess) { ctx->gkr_graph = nullptr; rc = VP_EHIP; }
-        if (dbg) fprintf(stderr, "[vp] instantiated rc=%d\n", rc);
-        if (g) (void) hipGraphDestroy(g);
-        if (rc == VP_ELIMIT || rc == VP_EINVAL) return rc;
-        if (rc != VP_OK) { (void) hipGetLastError(); ctx->graph_failed = true; }     // run the launches directly instead
-        ctx->graph_launches = ctx->st.launches; ctx->graph_rounds = ctx->st.rounds;
-    }
-    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
-    if (ctx->use_graph && !serial && ctx->gkr_graph) {
-        HIPCHK(hipGraphLaunch(ctx->gkr_graph, ctx->stream));
-        ctx->st.launches = ctx->graph_launches; ctx->st.rounds = ctx->graph_rounds;
-    } else {
-        ctx->st.launches = 0; ctx->st.rounds = 0;
-        if (use_plan) VPCHK(submit_plan(ctx, serial)); else VPCHK(submit_gkr(ctx, serial));
-    }
-    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->h_io + n_tape, tr, pos * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
-    const auto t_sub = std::chrono::steady_clock::now();
-    VPCHK(check_stream(ctx));
-    if (dbg_t) {
-        const auto t_done = std::chrono::steady_clock::now();
-        fprintf(stderr, "[vp] prove_gkr host: submit %.1f us, wait %.1f us\n", std::chrono::duration<double, std::micro>(t_sub - t_in).count(),
-                std::chrono::duration<double, std::micro>(t_done - t_sub).count());
-    }
-    memcpy(transcript, ctx->h_io + n_tape, pos * sizeof(F));
-    float ms = 0;
-    hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
-    ctx->st.gkr_ms = ms;
-    ctx->st.fold_ms = 0; ctx->st.fold_bytes = 0; ctx->st.fold_launches = ctx->ev_used;
-    for (size_t e = 0; e < ctx->ev_used; ++e) {
-        float t = 0;
-        hipEventElapsedTime(&t, ctx->ev_pool[e].a, ctx->ev_pool[e].b);
-        ctx->st.fold_ms += t; ctx->st.fold_bytes += ctx->ev_pool[e].bytes;
-    }
-    if (n_written) *n_written = pos * sizeof(F);
-    return VP_OK;
-}
-
-}  // extern "C"
-
-// =====================================================================================================
-// Virgo polynomial commitment — commit side
-// =====================================================================================================
-namespace {
-
-constexpr int PC_MAX_LN = 13;            // largest in-LDS transform (2^13 x 16 B = 128 KiB)
-
-F host_pow(F x, unsigned __int128 e) { F r = f_one(); while (e) { if (e & 1) r = f_mul(r, x); x = f_mul(x, x); e >>= 1; } return r; }
-F host_root_of_unity(int log_order) {    // fieldElement::getRootOfUnity (fieldElement.cpp:237-249)
-    F r = f_make(2147483648ull, 1033321771269002680ull);
-    for (int i = 0; i < 62 - log_order; ++i) r = f_mul(r, r);
-    return r;
-}
-F host_inv_real(u64 x) { return host_pow(f_make(x, 0), (unsigned __int128) P61 - 2); }   // RS_polynomial.cpp:214
-
-// RT[j] = w^j for j < M/2, M = 2^lm (doubling, one small launch per level; done once per circuit)
-int pc_root_table(vp_ctx *ctx, int lm) {
-    if (ctx->pc_lm == lm && ctx->pc_rt) return VP_OK;
-    const u32 half = 1u << (lm - 1);
-    VPCHK(dalloc(ctx, &ctx->pc_rt, (size_t) half));
-    const F one = f_one();
-    HIPCHK(hipMemcpyAsync(ctx->pc_rt, &one, sizeof(F), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    F step = host_root_of_unity(lm);                    // w^(2^s)
-    for (u32 have = 1; have < half; have <<= 1) {
-        hipLaunchKernelGGL(k_root_table_step, dim3(nblk(have)), dim3(VP_BLOCK), 0, ctx->stream, ctx->pc_rt, have, step);
-        step = f_mul(step, step);
-    }
-    ctx->pc_lm = lm;
-    return VP_OK;
-}
-
-constexpr int PC_MAX_LN_SPLIT = 17;      // with the register split in front: N1 <= 16
-
-// rows transforms of size 2^ln.  forward: `cosets` twisted copies (coset-major output [row][coset][N]); inverse: scaled
-// by 1/N.  Sizes above 2^13 go through k_ntt_split -> k_ntt_lds (N1 x 2^13) -> k_ntt_unsplit and need `scratch`
-// (rows * cosets * N elements, twice).
-int pc_launch_ntt(vp_ctx *ctx, const F *in, F *out, int ln, int lm, int inverse, u32 rows, u32 cosets, u32 in_stride) {
-    if (ln <= PC_MAX_LN) {
-        NttArgs a{};
-        a.in = in; a.out = out; a.RT = ctx->pc_rt; a.half_m = 1u << (lm - 1); a.lm = lm; a.ln = ln; a.inverse = inverse;
-        a.in_stride = in_stride; a.inv_n = inverse ? host_inv_real(1ull << ln) : f_one();
-        const u32 threads = std::max<u32>(64, std::min<u32>(1024, (1u << ln) / 2));
-        hipLaunchKernelGGL(k_ntt_lds, dim3(rows, cosets), dim3(threads), sizeof(F) << ln, ctx->stream, a);
-        return VP_OK;
-    }
-    const int l1 = ln - PC_MAX_LN;                       // 1..4
-    const u32 N = 1u << ln, N2 = 1u << PC_MAX_LN, nc = inverse ? 1 : cosets;
-    const size_t total = (size_t) rows * nc * N;
-    if (ctx->pc_scr_cap < 2 * total) {
-        VPCHK(dalloc(ctx, &ctx->pc_scr, 2 * total));
-        ctx->pc_scr_cap = 2 * total;
-    }
-    F *s1 = ctx->pc_scr, *s2 = ctx->pc_scr + total;
-    SplitArgs sa{};
-    sa.in = in; sa.out = s1; sa.RT = ctx->pc_rt; sa.half_m = 1u << (lm - 1); sa.ln = ln; sa.l1 = l1; sa.inverse = inverse;
-    sa.in_stride = in_stride; sa.ncoset = nc;
-    const dim3 g1(nblk(N2), rows, nc);
-    if (l1 == 1) hipLaunchKernelGGL(k_ntt_split<1>, g1, dim3(VP_BLOCK), 0, ctx->stream, sa);
-    else if (l1 == 2) hipLaunchKernelGGL(k_ntt_split<2>, g1, dim3(VP_BLOCK), 0, ctx->stream, sa);
-    else if (l1 == 3) hipLaunchKernelGGL(k_ntt_split<3>, g1, dim3(VP_BLOCK), 0, ctx->stream, sa);
-    else hipLaunchKernelGGL(k_ntt_split<4>, g1, dim3(VP_BLOCK), 0, ctx->stream, sa);
-    // N1 contiguous N2-point transforms per (row, coset): plain (untwisted, unscaled) forward / inverse kernels
-    NttArgs a{};
-    a.in = s1; a.out = s2; a.RT = ctx->pc_rt; a.half_m = 1u << (lm - 1); a.lm = lm; a.ln = PC_MAX_LN; a.inverse = inverse;
-    a.in_stride = N2; a.inv_n = f_one();
-    const u32 sub_rows = rows * nc << l1;
-    for (u32 r0 = 0; r0 < sub_rows; r0 += 32768) {      // gridDim.x limit safety
-        NttArgs b = a;
-        b.in = s1 + (size_t) r0 * N2; b.out = s2 + (size_t) r0 * N2;
-        hipLaunchKernelGGL(k_ntt_lds, dim3(std::min<u32>(32768, sub_rows - r0), 1), dim3(1024), sizeof(F) << PC_MAX_LN, ctx->stream, b);
-    }
-    hipLaunchKernelGGL(k_ntt_unsplit, dim3(N2 / 64, rows * nc), dim3(VP_BLOCK), 0, ctx->stream, s2, out, ln, l1,
-                       inverse ? host_inv_real(1ull << ln) : f_one(), inverse);
-    return VP_OK;
-}
-
-int pc_merkle(vp_ctx *ctx, Dig *tree, u32 n_leaves) {    // leaves already at tree[n_leaves .. 2 n_leaves)
-    u32 c = n_leaves >> 1;
-    for (; c > 512; c >>= 1)
-        hipLaunchKernelGGL(k_merkle_level, dim3(nblk(c)), dim3(VP_BLOCK), 0, ctx->stream, tree, c, c);
-    if (c >= 1) hipLaunchKernelGGL(k_merkle_top, dim3(1), dim3(VP_BLOCK), 0, ctx->stream, tree, 2 * c);
-    return VP_OK;
-}
-
-}  // namespace
-
-extern "C" {
-
-int vp_commit_private(vp_ctx *ctx, uint8_t root[32]) {
-    if (!ctx || !ctx->evaluated || !root) return VP_EINVAL;
-    HIPCHK(hipSetDevice(ctx->device));
-    const int n = ctx->L[0].bl;
-    if (n < 7) { ctx->err = "input layer too small for the commitment (bit length < 7)"; return VP_EINVAL; }
-    const int ln = n - 6, lm = n - 1;                     // slice_real_ele_cnt = 2^ln, slice_size = 2^lm (poly_commit.h:48-49)
-    if (ln > PC_MAX_LN_SPLIT) { ctx->err = "slice longer than 2^17 elements"; return VP_ELIMIT; }
-    const u32 N = 1u << ln, M = 1u << lm;
-    VPCHK(pc_root_table(ctx, lm));
-    if (!ctx->pc_coef) {
-        VPCHK(dalloc(ctx, &ctx->pc_coef, (size_t) 64 * N));
-        VPCHK(dalloc(ctx, &ctx->pc_cw, (size_t) 64 * M));
-        VPCHK(dalloc(ctx, &ctx->pc_tree, (size_t) M));    // 2 * (M/2) digests, heap layout
-    }
-    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
-    // l_coef = iFFT of each slice; l_eval = its evaluations on the 2^lm-th roots (poly_commit.h:101-107)
-    VPCHK(pc_launch_ntt(ctx, ctx->L[0].val, ctx->pc_coef, ln, lm, 1, 64, 1, N));
-    VPCHK(pc_launch_ntt(ctx, ctx->pc_coef, ctx->pc_cw, ln, lm, 0, 64, 32, N));
-    // leaf chains + tree (fri.cpp:95-127)
-    const u32 n_leaves = M >> 1;
-    hipLaunchKernelGGL(k_leaf_hash, dim3(nblk(n_leaves)), dim3(VP_BLOCK), 0, ctx->stream, ctx->pc_cw, N, 64, ctx->pc_tree + n_leaves);
-    VPCHK(pc_merkle(ctx, ctx->pc_tree, n_leaves));
-    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
-    HIPCHK(hipMemcpyAsync(root, ctx->pc_tree + 1, 32, hipMemcpyDeviceToHost, ctx->stream));
-    VPCHK(check_stream(ctx));
-    float ms = 0;
-    hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
-    ctx->commit_ms = ms;
-    ctx->pc_private_done = true;
-    return VP_OK;
-}
-
-int vp_commit_public(vp_ctx *ctx, const vp_F *pub, uint64_t n_pub, vp_F *inner, vp_F all_sum[65], uint8_t root_h[32]) {
-    if (!ctx || !ctx->evaluated || !ctx->pc_private_done || !pub || !inner || !all_sum || !root_h) return VP_EINVAL;
-    HIPCHK(hipSetDevice(ctx->device));
-    const int n = ctx->L[0].bl;
-    if (n_pub != (1ull << n)) return VP_EINVAL;
-    const int ln = n - 6, lm = n - 1;
-    const u32 N = 1u << ln, M = 1u << lm;
-    if (!ctx->pc_pub) {
-        VPCHK(dalloc(ctx, &ctx->pc_pub, (size_t) 1 << n));
-        VPCHK(dalloc(ctx, &ctx->pc_qcw, (size_t) 64 * M));
-        VPCHK(dalloc(ctx, &ctx->pc_hcw, (size_t) 64 * M));
-        VPCHK(dalloc(ctx, &ctx->pc_tmp, (size_t) 3 * 128 * N));           // products | S,T | H
-        VPCHK(dalloc(ctx, &ctx->pc_small, (size_t) 1024 + 160));
-        VPCHK(dalloc(ctx, &ctx->pc_tree_h, (size_t) M));
-    }
-    HIPCHK(hipMemcpyAsync(ctx->pc_pub, pub, sizeof(F) << n, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
-    F *P = ctx->pc_tmp, *ST = ctx->pc_tmp + (size_t) 128 * N, *H = ctx->pc_tmp + (size_t) 256 * N;
-    F *parts = ctx->pc_small, *d_inner = ctx->pc_small + 1024, *d_all = ctx->pc_small + 1025;
-    // input_0 = <circuitValue[0], pub>
-    const u32 used = (u32) ctx->L[0].size, g = std::min<u32>(1024, nblk(used));
-    hipLaunchKernelGGL(k_pc_dot, dim3(g), dim3(VP_BLOCK), 0, ctx->stream, ctx->L[0].val, ctx->pc_pub, used, parts);
-    hipLaunchKernelGGL(k_pc_sum_parts, dim3(1), dim3(VP_BLOCK), 0, ctx->stream, parts, g, d_inner);
-    // q_eval: the public vector encoded like the private one (poly_commit.h:163-176)
-    VPCHK(pc_launch_ntt(ctx, ctx->pc_pub, ctx->pc_coef, ln, lm, 1, 64, 1, N));
-    VPCHK(pc_launch_ntt(ctx, ctx->pc_coef, ctx->pc_qcw, ln, lm, 0, 64, 32, N));
-    // quotient h of l*q by x^N - 1, per slice (poly_commit.h:264-293)
-    hipLaunchKernelGGL(k_pc_products, dim3(nblk((u64) 128 * N)), dim3(VP_BLOCK), 0, ctx->stream, ctx->pc_cw, ctx->pc_qcw, N, P);
-    VPCHK(pc_launch_ntt(ctx, P, ST, ln, lm, 1, 128, 1, N));
-    hipLaunchKernelGGL(k_zero_f, dim3(1), dim3(128), 0, ctx->stream, d_all, 65u);
-    hipLaunchKernelGGL(k_pc_quotient, dim3(nblk((u64) 64 * N)), dim3(VP_BLOCK), 0, ctx->stream, ST, N, ctx->pc_rt, M >> 1,
-                       host_inv_real(2), f_make(N, 0), H, d_all);
-    VPCHK(pc_launch_ntt(ctx, H, ctx->pc_hcw, ln, lm, 0, 64, 32, N));
-    // second oracle: leaf chains + tree over h (fri.cpp:36-139 with oracle_indicator = 1)
-    const u32 n_leaves = M >> 1;
-    hipLaunchKernelGGL(k_leaf_hash, dim3(nblk(n_leaves)), dim3(VP_BLOCK), 0, ctx->stream, ctx->pc_hcw, N, 64, ctx->pc_tree_h + n_leaves);
-    VPCHK(pc_merkle(ctx, ctx->pc_tree_h, n_leaves));
-    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
-    HIPCHK(hipMemcpyAsync(root_h, ctx->pc_tree_h + 1, 32, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(inner, d_inner, sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(all_sum, d_all, 65 * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
-    VPCHK(check_stream(ctx));
-    float ms = 0;
-    hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
-    ctx->commit_ms = ms;
-    ctx->pc_public_done = true; ctx->fri_step = -1;
-    return VP_OK;
-}
-
-int vp_fri_step(vp_ctx *ctx, const vp_F *r, uint8_t root[32]) {
-    if (!ctx || !ctx->pc_public_done || !r || !root) return VP_EINVAL;
-    HIPCHK(hipSetDevice(ctx->device));
-    const int n = ctx->L[0].bl, ln = n - 6, lm = n - 1;
-    const u32 N = 1u << ln, M = 1u << lm;
-    if (!ctx->pc_fri_all) {
-        VPCHK(dalloc(ctx, &ctx->pc_fri_all, (size_t) 64 * M));            // every level's codeword is kept for the openings
-        VPCHK(dalloc(ctx, &ctx->pc_fri_tree, (size_t) M));
-    }
-    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
-    if (ctx->fri_step < 0) {
-        // virtual oracle in place over the q codeword; S_0 per slice sits behind all_sum in pc_small
-        hipLaunchKernelGGL(k_pc_virtual_oracle, dim3(nblk((u64) 64 * M)), dim3(VP_BLOCK), 0, ctx->stream, ctx->pc_cw, ctx->pc_qcw,
-                           ctx->pc_hcw, ctx->pc_small + 1025 + 80, N, ctx->pc_rt, M >> 1, f_make(N, 0));
-        ctx->fri_step = 0; ctx->fri_tree_used = 0;
-        ctx->fri_cw_off.clear(); ctx->fri_tree_off.clear();
-    }
-    const int k = ctx->fri_step;
-    if (k >= ln) { ctx->err = "FRI commit phase already finished"; return VP_EINVAL; }
-    const u32 Nk = N >> k, No = Nk >> 1;
-    size_t cw_off = 0;
-    for (int q = 0; q < k; ++q) cw_off += (size_t) 64 * 32 * (N >> (q + 1));
-    const F *in = k == 0 ? ctx->pc_qcw : ctx->pc_fri_all + ctx->fri_cw_off[k - 1];
-    F *out = ctx->pc_fri_all + cw_off;
-    ctx->fri_cw_off.push_back(cw_off);
-    ctx->fri_tree_off.push_back(ctx->fri_tree_used);
-    F rf; memcpy(&rf, r, sizeof(F));
-    hipLaunchKernelGGL(k_fri_fold, dim3(nblk((u64) 64 * 32 * No)), dim3(VP_BLOCK), 0, ctx->stream, in, out, Nk, k, ctx->pc_rt, M >> 1, rf,
-                       host_inv_real(2));
-    // leaves of the folded codeword (M_{k+1} / 2 of them) + tree
-    const u32 n_leaves = 16 * No;
-    Dig *tree = ctx->pc_fri_tree + ctx->fri_tree_used;
-    if (No >= 2) hipLaunchKernelGGL(k_leaf_hash, dim3(nblk(n_leaves)), dim3(VP_BLOCK), 0, ctx->stream, out, No, 64, tree + n_leaves);
-    else hipLaunchKernelGGL(k_leaf_hash_final, dim3(1), dim3(64), 0, ctx->stream, out, 64, tree + n_leaves);
-    VPCHK(pc_merkle(ctx, tree, n_leaves));
-    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
-    HIPCHK(hipMemcpyAsync(root, tree + 1, 32, hipMemcpyDeviceToHost, ctx->stream));
-    VPCHK(check_stream(ctx));
-    ctx->fri_tree_used += 2 * (size_t) n_leaves;
-    ctx->fri_step = k + 1;
-    float ms = 0;
-    hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
-    ctx->commit_ms = ms;
-    return VP_OK;
-}
-
-int vp_fri_commit(vp_ctx *ctx, const vp_F *r, int n_steps, uint8_t *roots) {
-    if (!ctx || !ctx->pc_public_done || !r || !roots || n_steps < 1) return VP_EINVAL;
-    HIPCHK(hipSetDevice(ctx->device));
-    const int n = ctx->L[0].bl, ln = n - 6, lm = n - 1;
-    const u32 N = 1u << ln, M = 1u << lm;
-    if (ctx->fri_step >= 0 && ctx->fri_step != 0) { ctx->err = "vp_fri_commit after vp_fri_step"; return VP_EINVAL; }
-    if (n_steps > ln || n_steps > VP_FRI_MAX) { ctx->err = "too many FRI steps"; return VP_EINVAL; }
-    if (!ctx->pc_fri_all) {
-        VPCHK(dalloc(ctx, &ctx->pc_fri_all, (size_t) 64 * M));
-        VPCHK(dalloc(ctx, &ctx->pc_fri_tree, (size_t) M));
-    }
-    Dig *d_roots = nullptr;
-    if (!ctx->pc_fri_roots) VPCHK(dalloc(ctx, &ctx->pc_fri_roots, (size_t) VP_FRI_MAX));
-    d_roots = ctx->pc_fri_roots;
-    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
-    hipLaunchKernelGGL(k_pc_virtual_oracle, dim3(nblk((u64) 64 * M)), dim3(VP_BLOCK), 0, ctx->stream, ctx->pc_cw, ctx->pc_qcw,
-                       ctx->pc_hcw, ctx->pc_small + 1025 + 80, N, ctx->pc_rt, M >> 1, f_make(N, 0));
-    ctx->fri_step = 0; ctx->fri_tree_used = 0;
-    ctx->fri_cw_off.clear(); ctx->fri_tree_off.clear();
-    // folds of every level, back to back
-    FriLeafArgs la{}; MerkleArgs ma{};
-    u32 blocks = 0; size_t cw_off = 0;
-    int last_small = -1;
-    for (int k = 0; k < n_steps; ++k) {
-        const u32 Nk = N >> k, No = Nk >> 1;
-        const F *in = k == 0 ? ctx->pc_qcw : ctx->pc_fri_all + ctx->fri_cw_off[k - 1];
-        F *out = ctx->pc_fri_all + cw_off;
-        ctx->fri_cw_off.push_back(cw_off);
-        ctx->fri_tree_off.push_back(ctx->fri_tree_used);
-        F rf; memcpy(&rf, r + k, sizeof(F));
-        hipLaunchKernelGGL(k_fri_fold, dim3(nblk((u64) 64 * 32 * No)), dim3(VP_BLOCK), 0, ctx->stream, in, out, Nk, k, ctx->pc_rt, M >> 1, rf,
-                           host_inv_real(2));
-        const u32 n_leaves = 16 * No;
-        Dig *tree = ctx->pc_fri_tree + ctx->fri_tree_used;
-        ma.tree[k] = tree; ma.count[k] = n_leaves;
-        if (No >= 2) {
-            la.cw[la.n] = out; la.leaves[la.n] = tree + n_leaves; la.N[la.n] = No; la.blk_start[la.n] = blocks;
-            blocks += nblk(n_leaves); ++la.n;
-        } else last_small = k;
-        cw_off += (size_t) 64 * 32 * No;
-        ctx->fri_tree_used += 2 * (size_t) n_leaves;
-    }
-    la.blk_start[la.n] = blocks;
-    if (la.n) hipLaunchKernelGGL(k_leaf_hash_multi, dim3(blocks), dim3(VP_BLOCK), 0, ctx->stream, la);
-    if (last_small >= 0)
-        hipLaunchKernelGGL(k_leaf_hash_final, dim3(1), dim3(64), 0, ctx->stream, ctx->pc_fri_all + ctx->fri_cw_off[last_small], 64,
-                           ma.tree[last_small] + ma.count[last_small]);
-    // Merkle trees of all levels, one launch per height while some tree still has more than 512 nodes at it
-    for (;;) {
-        MerkleArgs lv{}; u32 b = 0;
-        for (int k = 0; k < n_steps; ++k) {
-            const u32 c = ma.count[k] >> 1;
-            if (c <= 512) continue;
-            lv.tree[lv.n] = ma.tree[k]; lv.count[lv.n] = c; lv.blk_start[lv.n] = b; b += nblk(c); ++lv.n;
-            ma.count[k] = c;
-        }
-        if (!lv.n) break;
-        lv.blk_start[lv.n] = b;
-        hipLaunchKernelGGL(k_merkle_level_multi, dim3(b), dim3(VP_BLOCK), 0, ctx->stream, lv);
-    }
-    ma.n = n_steps;
-    hipLaunchKernelGGL(k_merkle_top_multi, dim3(n_steps), dim3(VP_BLOCK), 0, ctx->stream, ma, d_roots);
-    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
-    HIPCHK(hipMemcpyAsync(roots, d_roots, (size_t) 32 * n_steps, hipMemcpyDeviceToHost, ctx->stream));
-    VPCHK(check_stream(ctx));
-    ctx->fri_step = n_steps;
-    float ms = 0;
-    hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
-    ctx->commit_ms = ms;
-    return VP_OK;
-}
-
-int vp_fri_final(vp_ctx *ctx, vp_F *final_code) {
-    if (!ctx || !final_code || !ctx->pc_public_done) return VP_EINVAL;
-    const int ln = ctx->L[0].bl - 6;
-    if (ctx->fri_step != ln) { ctx->err = "FRI commit phase not finished"; return VP_EINVAL; }
-    HIPCHK(hipSetDevice(ctx->device));
-    std::vector<F> cw(64 * 32);
-    HIPCHK(hipMemcpy(cw.data(), ctx->pc_fri_all + ctx->fri_cw_off[ln - 1], cw.size() * sizeof(F), hipMemcpyDeviceToHost));
-    F *o = reinterpret_cast<F *>(final_code);
-    for (u32 i = 0; i < 16; ++i) for (u32 s = 0; s < 64; ++s) for (u32 hi = 0; hi < 2; ++hi) o[(i << 7) | (s << 1) | hi] = cw[s * 32 + i + 16 * hi];
-    return VP_OK;
-}
-
-int vp_fri_open(vp_ctx *ctx, int oracle, uint64_t leaf, vp_F values[130], uint8_t *path, int path_capacity, int *path_len) {
-    if (!ctx || !values || !path || !path_len || oracle < 0) return VP_EINVAL;
-    HIPCHK(hipSetDevice(ctx->device));
-    const int n = ctx->L[0].bl, ln = n - 6, lm = n - 1;
-    const u32 N = 1u << ln, M = 1u << lm;
-    const F *cw; const Dig *tree; u32 Nc, n_leaves;
-    if (oracle == 0) { if (!ctx->pc_private_done) return VP_EINVAL; cw = ctx->pc_cw; tree = ctx->pc_tree; Nc = N; n_leaves = M >> 1; }
-    else if (oracle == 1) { if (!ctx->pc_public_done) return VP_EINVAL; cw = ctx->pc_hcw; tree = ctx->pc_tree_h; Nc = N; n_leaves = M >> 1; }
-    else {
-        const int lvl = oracle - 2;
-        if (lvl >= ctx->fri_step || lvl >= (int) ctx->fri_cw_off.size()) { ctx->err = "FRI level not committed yet"; return VP_EINVAL; }
-        cw = ctx->pc_fri_all + ctx->fri_cw_off[lvl]; tree = ctx->pc_fri_tree + ctx->fri_tree_off[lvl];
-        Nc = N >> (lvl + 1); n_leaves = 16 * Nc;
-    }
-    if (leaf >= n_leaves) return VP_EINVAL;
-    int depth = 0; while ((1u << depth) < n_leaves) ++depth;
-    if (path_capacity < 32 * (depth + 1)) return VP_EINVAL;
-    if (!ctx->pc_open_buf) VPCHK(dalloc(ctx, &ctx->pc_open_buf, (size_t) 130 + 2 * 40));
-    Dig *dpath = reinterpret_cast<Dig *>(ctx->pc_open_buf + 130);
-    hipLaunchKernelGGL(k_pc_open, dim3(1), dim3(128), 0, ctx->stream, cw, Nc, tree, n_leaves, (u32) leaf, ctx->pc_open_buf, dpath);
-    HIPCHK(hipMemcpyAsync(values, ctx->pc_open_buf, 130 * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(path, dpath, 32 * (size_t) (depth + 1), hipMemcpyDeviceToHost, ctx->stream));
-    VPCHK(check_stream(ctx));
-    *path_len = depth + 1;
-    return VP_OK;
-}
-
-int vp_commit_stats(vp_ctx *ctx, double *commit_ms) {
-    if (!ctx || !commit_ms) return VP_EINVAL;
-    *commit_ms = ctx->commit_ms;
-    return VP_OK;
-}
-
-int vp_test_sha3(vp_ctx *ctx, const uint8_t *in, uint8_t *out, uint64_t n) {
-    if (!ctx || !in || !out) return VP_EINVAL;
-    if (!n) return VP_OK;
-    HIPCHK(hipSetDevice(ctx->device));
-    u64 *di = nullptr, *dout = nullptr;
-    HIPCHK(hipMalloc((void **) &di, n * 64));
-    HIPCHK(hipMalloc((void **) &dout, n * 32));
-    HIPCHK(hipMemcpy(di, in, n * 64, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_test_sha3, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream, di, dout, (u32) n);
-    int rc = check_stream(ctx);
-    if (rc == VP_OK && hipMemcpy(out, dout, n * 32, hipMemcpyDeviceToHost) != hipSuccess) rc = VP_EHIP;
-    (void) hipFree(di); (void) hipFree(dout);
-    return rc;
-}
-
-int vp_test_fft(vp_ctx *ctx, const vp_F *coefs, int coef_len, int order, int inverse, vp_F *out) {
-    if (!ctx || !coefs || !out || coef_len < 1 || (coef_len & (coef_len - 1))) return VP_EINVAL;
-    if (order != coef_len && order != 32 * coef_len) return VP_EINVAL;
-    if (inverse && order != coef_len) return VP_EINVAL;
-    int ln = 0; while ((1 << ln) < coef_len) ++ln;
-    if (ln > PC_MAX_LN_SPLIT) return VP_ELIMIT;
-    int lo = 0; while ((1 << lo) < order) ++lo;
-    HIPCHK(hipSetDevice(ctx->device));
-    // private root table of order max(order, 2)
-    const int lm = std::max(lo, 1);
-    F *save_rt = ctx->pc_rt; int save_lm = ctx->pc_lm;
-    ctx->pc_rt = nullptr; ctx->pc_lm = -1;
-    int rc = pc_root_table(ctx, lm);
-    F *din = nullptr, *dcw = nullptr;
-    const u32 cosets = (u32) (order / coef_len);
-    if (rc == VP_OK && hipMalloc((void **) &din, sizeof(F) * coef_len) != hipSuccess) rc = VP_EHIP;
-    if (rc == VP_OK && hipMalloc((void **) &dcw, sizeof(F) * order) != hipSuccess) rc = VP_EHIP;
-    if (rc == VP_OK && hipMemcpy(din, coefs, sizeof(F) * coef_len, hipMemcpyHostToDevice) != hipSuccess) rc = VP_EHIP;
-    std::vector<F> tmp(order);
-    if (rc == VP_OK) {
-        pc_launch_ntt(ctx, din, dcw, ln, lm, inverse, 1, inverse ? 1 : cosets, coef_len);
-        rc = check_stream(ctx);
-    }
-    if (rc == VP_OK && hipMemcpy(tmp.data(), dcw, sizeof(F) * order, hipMemcpyDeviceToHost) != hipSuccess) rc = VP_EHIP;
-    if (rc == VP_OK) {                                    // coset-major -> natural order
-        F *o = reinterpret_cast<F *>(out);
-        for (u32 b = 0; b < cosets; ++b) for (int a = 0; a < coef_len; ++a) o[(size_t) a * cosets + b] = tmp[(size_t) b * coef_len + a];
-        if (inverse) for (int a = 0; a < coef_len; ++a) o[a] = tmp[a];
-    }
-    if (din) (void) hipFree(din);
-    if (dcw) (void) hipFree(dcw);
-    ctx->pc_rt = save_rt; ctx->pc_lm = save_lm;           // the temporary table stays in ctx->allocs until the next upload
-    return rc;
-}
-
-}  // extern "C"
+#include "vpgpu_batched.inc"
+#include "vpgpu_pc.inc"
