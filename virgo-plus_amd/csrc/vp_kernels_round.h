@@ -438,7 +438,7 @@ __global__ void __launch_bounds__(VP_BLOCK) k_round_main(RoundArgs a, F *__restr
 // the round polynomial to the device transcript and, if given, to pinned host memory.
 __global__ void __launch_bounds__(VP_BLOCK)
 k_round_final(RoundArgs a, const F *__restrict__ part, u32 n_part, F *add_term, F *scalarV, F *poly_dev,
-              F *poly_host) {
+              F *poly_host, unsigned long long *seq_host, unsigned long long seq) {
     __shared__ F lds[12];
     F acc[3] = {f_zero(), f_zero(), f_zero()};
     for (u32 i = threadIdx.x; i < n_part; i += blockDim.x) {
@@ -471,7 +471,11 @@ k_round_final(RoundArgs a, const F *__restrict__ part, u32 n_part, F *add_term, 
     *add_term = at;
     const F pa = acc[0], pb = f_sub(acc[1], at), pc = f_add(acc[2], at);
     poly_dev[0] = pa; poly_dev[1] = pb; poly_dev[2] = pc;
-    if (poly_host) { poly_host[0] = pa; poly_host[1] = pb; poly_host[2] = pc; }
+    if (poly_host) {
+        poly_host[0] = pa; poly_host[1] = pb; poly_host[2] = pc;
+        // the host polls seq_host instead of waiting for the stream: the polynomial must be visible before the ticket
+        if (seq_host) { __threadfence_system(); __hip_atomic_store(seq_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+    }
 }
 
 // Finalize (src/prover.cpp:494-521): the claim of table j is its V table folded down to one value.
@@ -482,9 +486,10 @@ struct FinArgs {
     int n_tab; int rounds_done;
     u32 off[VP_MAX_TAB]; u32 valid[VP_MAX_TAB]; int bl[VP_MAX_TAB];
 };
-__global__ void k_finalize(FinArgs a, const F *__restrict__ scalarV, F *claims_dev, F *claims_host, F *Vu) {
+__global__ void k_finalize(FinArgs a, const F *__restrict__ scalarV, F *claims_dev, F *claims_host, F *Vu,
+                           unsigned long long *seq_host, unsigned long long seq) {
     int j = threadIdx.x;
-    if (j >= a.n_tab) return;
+    if (j < a.n_tab) {
     const F r = a.rp ? *a.rp : a.rv;
     F c;
     if (a.bl[j] == a.rounds_done) {
@@ -497,6 +502,12 @@ __global__ void k_finalize(FinArgs a, const F *__restrict__ scalarV, F *claims_d
     claims_dev[j] = c;
     if (claims_host) claims_host[j] = c;
     if (Vu && j == 0) *Vu = c;
+    }
+    // one wave: every lane's stores are issued before this point; the ticket goes out after they are visible to the host
+    if (claims_host && seq_host) {
+        __threadfence_system();
+        if (threadIdx.x == 0) __hip_atomic_store(seq_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -109,6 +109,8 @@ struct vp_ctx {
     F *d_tape = nullptr; u64 n_tape = 0;
     F *d_tr = nullptr; u64 n_tr = 0;      // transcript in F units
     F *h_pin = nullptr;                   // pinned: [0..2] poly, [3] vres, [4..4+64) claims
+    unsigned long long *h_seq = nullptr, seq = 0;     // pinned ticket the closing kernels of the per-round path publish
+    int poll = 1;                                     // VP_POLL=0: wait with hipStreamSynchronize instead
     F *h_io = nullptr; size_t h_io_cap = 0;   // pinned staging of the batched path: tape in, transcript out
     int *d_flag = nullptr;
     bool evaluated = false;
@@ -322,6 +324,19 @@ int do_liu_init(vp_ctx *ctx, int i) {
 }
 
 // one sumcheck round; rp (device) or rv (by value) is the previous challenge
+int check_stream(vp_ctx *ctx);
+// Per-round path: wait for the ticket the closing kernel publishes in pinned memory (a few microseconds sooner than the
+// runtime's stream wait, once per round x ~700 rounds per proof); falls back to the stream wait after 2 s or when VP_POLL=0.
+int wait_ticket(vp_ctx *ctx) {
+    if (!ctx->poll) return check_stream(ctx);
+    const unsigned long long want = ctx->seq;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (u32 spin = 0;; ++spin) {
+        if (__atomic_load_n(ctx->h_seq, __ATOMIC_ACQUIRE) == want) return VP_OK;
+        if ((spin & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) return check_stream(ctx);
+    }
+}
+
 int do_round(vp_ctx *ctx, const F *rp, const F &rv, F *poly_dev, F *poly_host) {
     SumcheckState &s = ctx->sc;
     const int k = s.round + 1;
@@ -361,7 +376,7 @@ int do_round(vp_ctx *ctx, const F *rp, const F &rv, F *poly_dev, F *poly_host) {
         count_launch(ctx);
     }
     hipLaunchKernelGGL(k_round_final, dim3(1), dim3(VP_BLOCK), 0, ctx->stream, a, ctx->partials, grid, ctx->add_term(),
-                       ctx->scalarV(), poly_dev, poly_host);
+                       ctx->scalarV(), poly_dev, poly_host, (poly_host && ctx->poll) ? ctx->h_seq : nullptr, ++ctx->seq);
     count_launch(ctx);
     s.round = k;
     ++ctx->st.rounds;
@@ -380,7 +395,7 @@ int do_finalize(vp_ctx *ctx, const F *rp, const F &rv, F *claims_dev, F *claims_
         a.valid[j] = (u32) (((u64) s.valid0[j] + (1ull << sh) - 1) >> sh);
     }
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, ctx->stream, a, ctx->scalarV(), claims_dev, claims_host,
-                       s.phase == 1 ? ctx->Vu() : nullptr);
+                       s.phase == 1 ? ctx->Vu() : nullptr, (claims_host && ctx->poll) ? ctx->h_seq : nullptr, ++ctx->seq);
     count_launch(ctx);
     return VP_OK;
 }
@@ -434,7 +449,11 @@ int vp_create(int device, vp_ctx **out) {
     if (hipHostMalloc((void **) &ctx->h_pin, (4 + VP_MAX_TAB) * sizeof(F), hipHostMallocDefault) != hipSuccess) {
         delete ctx; return VP_EHIP;
     }
+    if (hipHostMalloc((void **) &ctx->h_seq, 64, hipHostMallocDefault) != hipSuccess) { delete ctx; return VP_EHIP; }
+    *ctx->h_seq = 0;
+    { const char *pl = getenv("VP_POLL"); ctx->poll = (pl && pl[0] == '0') ? 0 : 1; }
     hipEventCreate(&ctx->ev0); hipEventCreate(&ctx->ev1);
+    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(k_emit_multi), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
     (void) hipFuncSetAttribute(reinterpret_cast<const void *>(k_emit), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
     (void) hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
     *out = ctx;
@@ -454,6 +473,7 @@ void vp_destroy(vp_ctx *ctx) {
     if (ctx->ev0) (void) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void) hipEventDestroy(ctx->ev1);
     if (ctx->h_pin) (void) hipHostFree(ctx->h_pin);
+    if (ctx->h_seq) (void) hipHostFree(ctx->h_seq);
     if (ctx->h_io) (void) hipHostFree(ctx->h_io);
     for (auto st : ctx->lane_streams) (void) hipStreamDestroy(st);
     for (auto ev : ctx->lane_events) (void) hipEventDestroy(ev);
@@ -905,7 +925,7 @@ int vp_round(vp_ctx *ctx, const vp_F *previous_random, vp_F out_poly[3]) {
     HIPCHK(hipSetDevice(ctx->device));
     F rv; memcpy(&rv, previous_random, sizeof(F));
     VPCHK(do_round(ctx, nullptr, rv, ctx->d_tr + ctx->n_tr, ctx->h_pin));
-    VPCHK(check_stream(ctx));
+    VPCHK(wait_ticket(ctx));
     memcpy(out_poly, ctx->h_pin, 3 * sizeof(F));
     return VP_OK;
 }
@@ -915,7 +935,7 @@ int vp_finalize(vp_ctx *ctx, const vp_F *previous_random, vp_F *claims, int n_cl
     HIPCHK(hipSetDevice(ctx->device));
     F rv; memcpy(&rv, previous_random, sizeof(F));
     VPCHK(do_finalize(ctx, nullptr, rv, ctx->d_tr + ctx->n_tr + 3, ctx->h_pin + 4));
-    VPCHK(check_stream(ctx));
+    VPCHK(wait_ticket(ctx));
     memcpy(claims, ctx->h_pin + 4, (size_t) n_claims * sizeof(F));
     return VP_OK;
 }
