@@ -381,12 +381,10 @@ __device__ __forceinline__ F ld_or_zero(const F *p, u32 i, u32 valid) { return i
 // go to part[blockIdx.x*3 + {0,1,2}].  CLS only names the instantiation: CLS=1 is used for launches with at
 // least VP_BIG_PAIRS pairs so that profilers report the bandwidth-relevant launches under their own name.
 #define VP_BIG_PAIRS 32768
-template <int CLS>
-__global__ void __launch_bounds__(VP_BLOCK) k_round_main(RoundArgs a, F *__restrict__ part) {
-    __shared__ F lds[12];
+// pairs of workgroup `bid` of `nb`: folds, stores, and leaves the three block sums in thread 0's acc
+__device__ __forceinline__ void round_main_body(const RoundArgs &a, u32 bid, u32 nb, F (&acc)[3], F *lds) {
     const F r = a.rp ? *a.rp : a.rv;
-    F acc[3] = {f_zero(), f_zero(), f_zero()};
-    for (u32 q = blockIdx.x * blockDim.x + threadIdx.x; q < a.total_pairs; q += gridDim.x * blockDim.x) {
+    for (u32 q = bid * blockDim.x + threadIdx.x; q < a.total_pairs; q += nb * blockDim.x) {
         int j = 0;
         while (j + 1 < a.n_tab && q >= a.t[j + 1].pair_start) ++j;
         const TabDesc td = a.t[j];
@@ -426,6 +424,12 @@ __global__ void __launch_bounds__(VP_BLOCK) k_round_main(RoundArgs a, F *__restr
         acc[2] = f_add(acc[2], f_add(qc, a0));
     }
     block_sum<3>(acc, lds);
+}
+template <int CLS>
+__global__ void __launch_bounds__(VP_BLOCK) k_round_main(RoundArgs a, F *__restrict__ part) {
+    __shared__ F lds[12];
+    F acc[3] = {f_zero(), f_zero(), f_zero()};
+    round_main_body(a, blockIdx.x, gridDim.x, acc, lds);
     if (threadIdx.x == 0) {
         part[blockIdx.x * 3 + 0] = acc[0];
         part[blockIdx.x * 3 + 1] = acc[1];
@@ -433,21 +437,8 @@ __global__ void __launch_bounds__(VP_BLOCK) k_round_main(RoundArgs a, F *__restr
     }
 }
 
-// Closing kernel of a round (one block): sums the block partials, retires the tables that have just
-// reached length one into add_term (src/prover.cpp:445,462-467), adds add_term*(1-x) (:448) and emits
-// the round polynomial to the device transcript and, if given, to pinned host memory.
-__global__ void __launch_bounds__(VP_BLOCK)
-k_round_final(RoundArgs a, const F *__restrict__ part, u32 n_part, F *add_term, F *scalarV, F *poly_dev,
-              F *poly_host, unsigned long long *seq_host, unsigned long long seq) {
-    __shared__ F lds[12];
-    F acc[3] = {f_zero(), f_zero(), f_zero()};
-    for (u32 i = threadIdx.x; i < n_part; i += blockDim.x) {
-        acc[0] = f_add(acc[0], part[3 * i]);
-        acc[1] = f_add(acc[1], part[3 * i + 1]);
-        acc[2] = f_add(acc[2], part[3 * i + 2]);
-    }
-    block_sum<3>(acc, lds);
-    if (threadIdx.x != 0) return;
+__device__ __forceinline__ void round_final_tail(const RoundArgs &a, const F (&acc)[3], F *add_term, F *scalarV, F *poly_dev, F *poly_host,
+                                                 unsigned long long *seq_host, unsigned long long seq) {
     const F r = a.rp ? *a.rp : a.rv;
     F at = *add_term;
     if (!f_is_zero(at)) at = f_mul(at, f_sub(f_one(), r));
@@ -476,6 +467,34 @@ k_round_final(RoundArgs a, const F *__restrict__ part, u32 n_part, F *add_term, 
         // the host polls seq_host instead of waiting for the stream: the polynomial must be visible before the ticket
         if (seq_host) { __threadfence_system(); __hip_atomic_store(seq_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
     }
+}
+
+// Closing kernel of a round (one block): sums the block partials, retires the tables that have just
+// reached length one into add_term (src/prover.cpp:445,462-467), adds add_term*(1-x) (:448) and emits
+// the round polynomial to the device transcript and, if given, to pinned host memory.
+__global__ void __launch_bounds__(VP_BLOCK)
+k_round_final(RoundArgs a, const F *__restrict__ part, u32 n_part, F *add_term, F *scalarV, F *poly_dev,
+              F *poly_host, unsigned long long *seq_host, unsigned long long seq) {
+    __shared__ F lds[12];
+    F acc[3] = {f_zero(), f_zero(), f_zero()};
+    for (u32 i = threadIdx.x; i < n_part; i += blockDim.x) {
+        acc[0] = f_add(acc[0], part[3 * i]);
+        acc[1] = f_add(acc[1], part[3 * i + 1]);
+        acc[2] = f_add(acc[2], part[3 * i + 2]);
+    }
+    block_sum<3>(acc, lds);
+    if (threadIdx.x != 0) return;
+    round_final_tail(a, acc, add_term, scalarV, poly_dev, poly_host, seq_host, seq);
+}
+// A round whose pairs fit one workgroup: fold + sums + closing in ONE launch (most rounds of a proof are this small; the
+// per-round path pays launch latency, not bandwidth).
+__global__ void __launch_bounds__(VP_BLOCK)
+k_round_fused(RoundArgs a, F *add_term, F *scalarV, F *poly_dev, F *poly_host, unsigned long long *seq_host, unsigned long long seq) {
+    __shared__ F lds[12];
+    F acc[3] = {f_zero(), f_zero(), f_zero()};
+    round_main_body(a, 0, 1, acc, lds);
+    if (threadIdx.x != 0) return;
+    round_final_tail(a, acc, add_term, scalarV, poly_dev, poly_host, seq_host, seq);
 }
 
 // Finalize (src/prover.cpp:494-521): the claim of table j is its V table folded down to one value.

@@ -364,6 +364,15 @@ int do_round(vp_ctx *ctx, const F *rp, const F &rv, F *poly_dev, F *poly_host) {
         }
     }
     a.total_pairs = pairs;
+    static const u32 fused_max = getenv("VP_ROUND_FUSED_MAX") ? (u32) atoi(getenv("VP_ROUND_FUSED_MAX")) : 512;
+    if (pairs <= fused_max) {            // one workgroup: fold + sums + closing in a single launch
+        hipLaunchKernelGGL(k_round_fused, dim3(1), dim3(VP_BLOCK), 0, ctx->stream, a, ctx->add_term(), ctx->scalarV(), poly_dev, poly_host,
+                           (poly_host && ctx->poll) ? ctx->h_seq : nullptr, ++ctx->seq);
+        count_launch(ctx);
+        s.round = k;
+        ++ctx->st.rounds;
+        return VP_OK;
+    }
     u32 grid = 0;
     if (pairs) {
         grid = grid_for(pairs);
