@@ -60,6 +60,23 @@ def test_loader_matches_reference_structure(vp, ob, golden, pws_path, name, bloc
     c.close(); oc.close()
 
 
+@pytest.mark.parametrize("blocks", [2, 5, 16, 64])
+def test_replicated_builder_equals_the_dag_route(vp, golden, pws_path, blocks, monkeypatch):
+    """the block-replicated circuit built from the layered form of ONE block (linear time) must be the
+    circuit the loader's own route produces from the DAG of all blocks — same gates, operands, subset ids and witness."""
+    fast = vp.Circuit.from_pws(pws_path, blocks, seed=7)
+    monkeypatch.setenv("VPH_BUILD", "dag")
+    slow = vp.Circuit.from_pws(pws_path, blocks, seed=7)
+    monkeypatch.delenv("VPH_BUILD")
+    assert (fast.layers, fast.gates) == (slow.layers, slow.gates)
+    assert fast.hash() == slow.hash()
+    if "sha256_x%d" % blocks in golden:
+        g = vp.Circuit.from_pws(pws_path, blocks, seed=1)
+        assert g.hash() == golden["sha256_x%d" % blocks]["circuit_hash"]
+        g.close()
+    fast.close(); slow.close()
+
+
 def test_randomize_matches_reference_structure(vp, golden):
     c = vp.Circuit.randomize(8, 12, seed=1)
     assert c.hash() == golden["randomize_8_12"]["circuit_hash"]

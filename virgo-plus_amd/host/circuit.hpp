@@ -67,5 +67,8 @@ namespace vph {
 bool parse_pws(const std::string &path, int blocks, std::vector<DAG_gate> &dag, std::string *err);
 // src/main.cpp:15-137
 layeredCircuit DAG_to_layered(const std::vector<DAG_gate> &dag);
+// `blocks` independent copies of the circuit in `path`, layered and with subsets initialised, built from the layered form of one
+// block (same result as parse_pws(path, blocks) -> DAG_to_layered -> subsetInit, in linear sequential time)
+bool build_replicated(const std::string &path, int blocks, layeredCircuit &out, std::string *err);
 
 }  // namespace vph

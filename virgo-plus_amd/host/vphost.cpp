@@ -24,10 +24,15 @@ extern "C" {
 vph_circuit *vph_circuit_from_pws(const char *path, int blocks, long seed, char *err, int errlen) {
     if (!path || blocks < 1) { set_err(err, errlen, "bad arguments"); return nullptr; }
     if (seed >= 0) srandom((unsigned) seed);
-    std::vector<DAG_gate> dag;
     std::string e;
-    if (!vph::parse_pws(path, blocks, dag, &e)) { set_err(err, errlen, e); return nullptr; }
     vph_circuit *vc = new vph_circuit();
+    const char *route = getenv("VPH_BUILD");                 // "dag": the loader's own route (DAG of all blocks) for any block count
+    if (blocks > 1 && !(route && !strcmp(route, "dag"))) {
+        if (!vph::build_replicated(path, blocks, vc->c, &e)) { delete vc; set_err(err, errlen, e); return nullptr; }
+        return vc;
+    }
+    std::vector<DAG_gate> dag;
+    if (!vph::parse_pws(path, blocks, dag, &e)) { delete vc; set_err(err, errlen, e); return nullptr; }
     vc->c = vph::DAG_to_layered(dag);
     vc->c.subsetInit();
     return vc;
