@@ -92,6 +92,24 @@ def test_sha256_transcript_matches_reference(vp, golden, gold_gkr, pws_path, nam
     c.close()
 
 
+@pytest.mark.parametrize("name,blocks", [("sha256_x16", 16), ("sha256_x64", 64)])
+def test_fused_init_plan_matches_reference(vp, golden, gold_gkr, pws_path, name, blocks, monkeypatch):
+    """The plan variant that runs the phase-1 / Liu init inside the first fold launch (GenP1 / GenLiu; by default only for
+    tables of >= 2^23 entries) forced on for every table the fold kernel handles: same golden transcript."""
+    monkeypatch.setenv("VP_FUSE_MIN_LOG", "17")
+    c = vp.Circuit.from_pws(pws_path, blocks, seed=1)
+    s = vp.Session(c)
+    s.draw_tape()
+    tr, res = s.prove_gkr()
+    assert tr == gold_gkr(name)
+    monkeypatch.setenv("VP_FUSE_DOT", "1")          # V_u riding on the fused launch instead of the separate pass
+    s2 = vp.Session(c)
+    s2.draw_tape()
+    tr2, _ = s2.prove_gkr()
+    assert tr2 == tr
+    s.close(); s2.close(); c.close()
+
+
 def test_randomize_transcript_matches_reference(vp, golden, gold_gkr):
     c = vp.Circuit.randomize(8, 12, seed=1)
     _both_modes(vp, c, gold_gkr("randomize_8_12"))

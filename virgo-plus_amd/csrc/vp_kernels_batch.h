@@ -296,9 +296,38 @@ __device__ __forceinline__ void sf_pair_step(const F &v0, const F &v1, const F &
     if (HAS_A) ao = f_mad_lazy(r, f_sub_lazy(a1, a0), a0);
 }
 
-struct Sf3bLds { F s1[3][256]; F s2[3][128]; F red[4][9]; Lz acc2[3][128]; Lz acc3[3][64]; };   // acc2/acc3: per-thread sums of rounds k+1, k+2
-template <bool HAS_A>
-__device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb, Sf3bLds &sm) {
+struct Sf3bLds { F s1[3][256]; F s2[3][128]; F red[4][9]; Lz acc2[3][128]; Lz acc3[3][64]; F dred[4]; };   // acc2/acc3: per-thread sums of rounds k+1, k+2
+
+// Where round k takes its mult / add entries from.  GenLoad: the tables in HBM.  GenP1 / GenLiu: computed on the spot from
+// the target-sorted contribution lists (the phase-1 init / the Liu gather), so that these tables are never written at full
+// length nor read back: the first fold launch of a sumcheck IS its init.  Rows with more than VP_LIGHT_MAX contributions
+// were summed by the chunk kernels into the mult/add arrays beforehand and are read from there.  A GenP1 job can also carry
+// the inner product V_u = sum eq(r_u,u) V[u] of its layer (it has V[u] in registers anyway).
+struct GenLoad { static constexpr int MODE = 0; };
+struct GenP1 {
+    static constexpr int MODE = 1;
+    const InitArgs2 *a; Half dot_h; F *dot_part;
+    __device__ __forceinline__ void row(u32 row, u32 valid, F &m, F &ad) const {
+        m = f_zero(); ad = f_zero();
+        if (row >= valid || row >= a->n_rows) return;
+        const u32 b = a->rowptr[row], e = a->rowptr[row + 1];
+        if (e - b > VP_LIGHT_MAX) { m = a->M[row]; ad = a->A[row]; return; }
+        for (u32 k = b; k < e; ++k) contrib2<1>(*a, k, m, ad);
+    }
+};
+struct GenLiu {
+    static constexpr int MODE = 2;
+    const u32 *rowptr; const uint8_t *e_q; const u32 *e_g; const Half *H;
+    __device__ __forceinline__ void row(u32 u, u32 valid, F &m, F &ad) const {
+        ad = f_zero(); m = f_zero();
+        if (u >= valid) return;
+        m = half_at(H[0], u);
+        for (u32 k = rowptr[u]; k < rowptr[u + 1]; ++k) m = f_add(m, half_at(H[e_q[k]], e_g[k]));
+    }
+};
+
+template <bool HAS_A, class Gen>
+__device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb, Sf3bLds &sm, const Gen &gen) {
     F (&s1)[3][256] = sm.s1; F (&s2)[3][128] = sm.s2; F (&red)[4][9] = sm.red;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     // round k sums stay in registers; those of rounds k+1 / k+2 (first two waves / first wave only) live in LDS, one
@@ -309,6 +338,7 @@ __device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb,
     if (t < 128) { for (int i = 0; i < 3; ++i) { sm.acc2[i][t].re = 0; sm.acc2[i][t].im = 0; } }
     if (t < 64) { for (int i = 0; i < 3; ++i) { sm.acc3[i][t].re = 0; sm.acc3[i][t].im = 0; } }
     const F r0 = a.r[0], r1 = a.r[1], r2 = a.r[2];
+    F dacc = f_zero();                                   // GenP1: this thread's share of the V_u inner product
     for (u32 c = bid; c < a.total_chunks; c += nb) {
         int j = 0;
         while (j + 1 < a.n_tab && c >= a.t[j + 1].chunk_start) ++j;
@@ -317,9 +347,20 @@ __device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb,
         const u32 i0 = td.off + cl * 512 + 2 * t, vend = td.off + td.valid;
         {   // round k: one pair per thread
             const F v0 = ld_or_zero(a.inV, i0, vend), v1 = ld_or_zero(a.inV, i0 + 1, vend);
-            const F m0 = ld_or_zero(a.inM, i0, vend), m1 = ld_or_zero(a.inM, i0 + 1, vend);
-            F a0 = f_zero(), a1 = f_zero();
-            if (HAS_A) { a0 = ld_or_zero(a.inA, i0, vend); a1 = ld_or_zero(a.inA, i0 + 1, vend); }
+            F m0, m1, a0 = f_zero(), a1 = f_zero();
+            if constexpr (Gen::MODE == 0) {
+                m0 = ld_or_zero(a.inM, i0, vend); m1 = ld_or_zero(a.inM, i0 + 1, vend);
+                if (HAS_A) { a0 = ld_or_zero(a.inA, i0, vend); a1 = ld_or_zero(a.inA, i0 + 1, vend); }
+            } else {                      // generated tables: one table per job, offset 0
+                gen.row(i0, vend, m0, a0);
+                gen.row(i0 + 1, vend, m1, a1);
+                if constexpr (Gen::MODE == 1) {
+                    if (gen.dot_part) {
+                        if (i0 < vend) dacc = f_add(dacc, f_mul(half_at(gen.dot_h, i0), v0));
+                        if (i0 + 1 < vend) dacc = f_add(dacc, f_mul(half_at(gen.dot_h, i0 + 1), v1));
+                    }
+                }
+            }
             F vo, mo, ao = f_zero();
             sf_pair_step<HAS_A>(v0, v1, m0, m1, a0, a1, r0, acc[0], acc[1], acc[2], vo, mo, ao);
             s1[0][t] = vo; s1[1][t] = mo;
@@ -373,11 +414,18 @@ __device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb,
         F *o = a.part + (size_t) t * a.part_stride + bid * 3;
         o[0] = X; o[1] = f_sub(f_sub(Y, X), Z); o[2] = Z;
     }
+    if constexpr (Gen::MODE == 1) {
+        if (gen.dot_part) {                              // uniform per launch
+            F d[1] = {dacc};
+            block_sum<1>(d, sm.dred);
+            if (t == 0) gen.dot_part[bid] = d[0];
+        }
+    }
 }
 template <bool HAS_A>
 __global__ void __launch_bounds__(VP_BLOCK, 4) k_sumfold3b(SfArgs a) {
     __shared__ Sf3bLds sm;
-    sumfold3b_body<HAS_A>(a, blockIdx.x, gridDim.x, sm);
+    sumfold3b_body<HAS_A>(a, blockIdx.x, gridDim.x, sm, GenLoad());
 }
 
 // ---------------------------------------------------------------------------------------------------

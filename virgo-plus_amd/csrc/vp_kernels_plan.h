@@ -457,7 +457,21 @@ __global__ void __launch_bounds__(VP_BLOCK, 4) k_sumfold3b_multi(const SfArgs *_
     __shared__ Sf3bLds sm;
     const BlkMap m = map[blockIdx.x];
     const SfArgs &a = jobs[m.job];
-    if (a.has_a) sumfold3b_body<true>(a, m.bid, a.nblk, sm); else sumfold3b_body<false>(a, m.bid, a.nblk, sm);
+    if (a.has_a) sumfold3b_body<true>(a, m.bid, a.nblk, sm, GenLoad()); else sumfold3b_body<false>(a, m.bid, a.nblk, sm, GenLoad());
+}
+// First fold launch of a phase-1 / Liu sumcheck with its init fused in (see GenP1 / GenLiu).
+struct SfGenJob { SfArgs sf; InitArgs2 a; GatherJob g; Half dot_h; F *dot_part; int mode; int pad; };
+__global__ void __launch_bounds__(VP_BLOCK, 4) k_sumfold3b_gen_multi(const SfGenJob *__restrict__ jobs, const BlkMap *__restrict__ map) {
+    __shared__ Sf3bLds sm;
+    const BlkMap m = map[blockIdx.x];
+    const SfGenJob &j = jobs[m.job];
+    if (j.mode == 1) {
+        GenP1 g; g.a = &j.a; g.dot_h = j.dot_h; g.dot_part = j.dot_part;
+        sumfold3b_body<true>(j.sf, m.bid, j.sf.nblk, sm, g);
+    } else {
+        GenLiu g; g.rowptr = j.g.rowptr; g.e_q = j.g.e_q; g.e_g = j.g.e_g; g.H = j.g.H;
+        sumfold3b_body<false>(j.sf, m.bid, j.sf.nblk, sm, g);
+    }
 }
 __global__ void __launch_bounds__(VP_SEG_THREADS) k_seg_multi(const SegArgs *__restrict__ jobs, const BlkMap *__restrict__ map) {
     __shared__ SegLds sm;

@@ -73,11 +73,11 @@ struct Lane {
 
 // Batched launch plan of the GKR part (see vp_kernels.h "Batched launches"): recorded once per circuit by running the
 // per-sumcheck drivers in record mode (same code that launches directly on the lane path), then merged step by step.
-enum { NK_LIGHT = 0, NK_CHUNKS, NK_COMBINE, NK_DOT, NK_DOTFIN, NK_SF, NK_SEG, NK_EMIT, NK_COUNT };
+enum { NK_LIGHT = 0, NK_CHUNKS, NK_COMBINE, NK_DOT, NK_DOTFIN, NK_SFGEN, NK_SF, NK_SEG, NK_EMIT, NK_COUNT };
 struct PStep { int kind; u32 idx, grid, lds; u64 bytes; int rounds; int xchain; };   // kind -1: placeholder step; xchain: also wait for that chain's latest node
 struct PlanRec {
     std::vector<LightJob> light; std::vector<ChunkJob> chunks; std::vector<CombineJob> combine; std::vector<DotJob> dot;
-    std::vector<SfArgs> sf; std::vector<SegArgs> seg; std::vector<EmitArgs> emit;
+    std::vector<SfArgs> sf; std::vector<SfGenJob> sfgen; std::vector<SegArgs> seg; std::vector<EmitArgs> emit;
     std::vector<std::vector<PStep>> chains; int cur = -1;
     void push(int kind, u32 idx, u32 grid, u32 lds = 0, u64 bytes = 0) { chains[cur].push_back(PStep{kind, idx, grid, lds, bytes, 0, -1}); }
 };
@@ -86,7 +86,7 @@ struct PNode { int kind = 0, step = 0, stream = 0; u32 first = 0, count = 0, gri
 struct Plan {
     std::vector<PNode> nodes;
     DotJob *d_dot = nullptr, *d_dotfin = nullptr; LightJob *d_light = nullptr; ChunkJob *d_chunks = nullptr; CombineJob *d_combine = nullptr;
-    SfArgs *d_sf = nullptr; SegArgs *d_seg = nullptr; EmitArgs *d_emit = nullptr; BlkMap *d_map = nullptr;
+    SfGenJob *d_sfgen = nullptr; SfArgs *d_sf = nullptr; SegArgs *d_seg = nullptr; EmitArgs *d_emit = nullptr; BlkMap *d_map = nullptr;
     hipStream_t streams[4] = {nullptr, nullptr, nullptr, nullptr};   // [0] = ctx->stream; [1..3] owned: fold (low priority), seg, emit (high)
     hipEvent_t ev_root = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     u64 rounds = 0; int n_steps = 0;
@@ -140,6 +140,8 @@ struct vp_ctx {
     F *pred_r = nullptr, *pred_pool = nullptr, *pred_part = nullptr, *pred_out = nullptr; BetaJob *pred_jobs = nullptr; u32 pred_bpj = 1;   // vp_predicates scratch
     PlanRec *rec = nullptr;           // non-null while the drivers run in record mode
     DotJob rec_dot{};                 // record mode: the V_u inner product the next phase-1 init job carries
+    SfGenJob rec_gen{};               // record mode: init to be fused into the first fold launch of the next sumcheck (mode != 0)
+    int fuse_init = 1;                // VP_FUSE_INIT=0: separate init launches for every sumcheck
     Plan *plan = nullptr; int plan_path = 1;   // VP_GKR_PATH=lanes: one stream per sumcheck chain instead of the plan
     // hipGraph of the concurrent GKR submission (per circuit; VP_GKR_GRAPH=0 submits the launches directly)
     hipGraphExec_t gkr_graph = nullptr; int use_graph = 1; bool graph_failed = false; u64 graph_launches = 0, graph_rounds = 0;
@@ -778,6 +780,7 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
         ctx->simple_path = (pth && !strcmp(pth, "simple")) ? 1 : 0;
         ctx->sumfold_path = (pth && !strcmp(pth, "sumfold")) ? 1 : 0;
         ctx->plan_path = (pth && !strcmp(pth, "lanes")) ? 0 : 1;
+        { const char *fi = getenv("VP_FUSE_INIT"); ctx->fuse_init = (fi && fi[0] == '0') ? 0 : 1; }
     }
     // event pool for the profiled launches
     if (ctx->ev_pool.empty()) {
