@@ -224,7 +224,7 @@ def main():
             ok_h, sec_h = sess.check(tr)
             ok_d, sec_d = sess.check(tr, device_predicates=True)
             verify = {"host_predicates_sec": sec_h, "device_predicates_sec": sec_d, "accepted": bool(ok_h and ok_d),
-                      "note": "verifier.cpp:50-113 on the device via vp_predicates; Liu gr / input MLE loops stay on the host"}
+                      "note": "the verifier's O(|C|) loops on the device: wiring predicates (vp_predicates), gr of verifyLiu (vp_liu_gr), input-layer MLE (vp_layer_mle); the per-round checks stay on the host"}
 
         if rank == 0:
             sec_per_proof_job = elapsed / a.steps                      # wall time of one step (all ranks in parallel)

@@ -160,6 +160,14 @@ int vp_commit_stats(vp_ctx *, double *commit_ms);
 int vp_predicates(vp_ctx *, int layer, const vp_F *r_g, const vp_F *assert_random, const vp_F *r_u, const vp_F *r_v, int n_v,
                   vp_F *out, uint64_t n_out);
 
+/* The verifier's two other O(|C|) loops.  vp_liu_gr: the `gr` of verifier::verifyLiu (src/verifier.cpp:311-323) =
+ * sum_u mult_Liu[u] * eq(r_liu, u), with mult_Liu the table prover::sumcheckInitLiu builds from (r_u, r_v[], s) — same
+ * arguments as vp_liu_init — and r_liu the bit_length(layer-1) challenges of that Liu sumcheck.  vp_layer_mle: the
+ * multilinear extension of a layer's values at r (layer 0: the input check of verifier.cpp:363-389 when the polynomial
+ * commitment is off).  Both leave no sumcheck in progress.                                                          */
+int vp_liu_gr(vp_ctx *, int layer, const vp_F *r_u, const vp_F *const *r_v, const vp_F *s, const vp_F *r_liu, vp_F *out);
+int vp_layer_mle(vp_ctx *, int layer, const vp_F *r, int n, vp_F *out);
+
 /* ---- measurement --------------------------------------------------------------------------------- */
 typedef struct {
     double gkr_ms;            /* device time of the last vp_prove_gkr (hipEvents on the library stream)     */

@@ -137,7 +137,8 @@ struct vp_ctx {
     Lane lane0; Lane *ln = nullptr;
     std::vector<Lane> lanes;          // [2*(i-1)] = phases 1+2 of layer i, [2*(i-1)+1] = Liu of layer i
     std::vector<hipStream_t> lane_streams; std::vector<hipEvent_t> lane_events; hipEvent_t ev_fork = nullptr;
-    F *pred_r = nullptr, *pred_pool = nullptr, *pred_part = nullptr, *pred_out = nullptr; BetaJob *pred_jobs = nullptr; u32 pred_bpj = 1;   // vp_predicates scratch
+    F *pred_r = nullptr, *pred_pool = nullptr, *pred_part = nullptr, *pred_out = nullptr; BetaJob *pred_jobs = nullptr; u32 pred_bpj = 1;
+    DotJob *pred_dot = nullptr; BlkMap *pred_map = nullptr;   // vp_predicates scratch
     PlanRec *rec = nullptr;           // non-null while the drivers run in record mode
     DotJob rec_dot{};                 // record mode: the V_u inner product the next phase-1 init job carries
     SfGenJob rec_gen{};               // record mode: init to be fused into the first fold launch of the next sumcheck (mode != 0)
@@ -506,7 +507,7 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
     ctx->n_layers = n_layers;
     ctx->evaluated = false;
     ctx->chunk_cap = 0;
-    ctx->pred_r = ctx->pred_pool = ctx->pred_part = ctx->pred_out = nullptr; ctx->pred_jobs = nullptr;
+    ctx->pred_r = ctx->pred_pool = ctx->pred_part = ctx->pred_out = nullptr; ctx->pred_jobs = nullptr; ctx->pred_dot = nullptr; ctx->pred_map = nullptr;
     ctx->pc_rt = ctx->pc_coef = ctx->pc_cw = nullptr; ctx->pc_tree = nullptr; ctx->pc_lm = -1;
     ctx->pc_pub = ctx->pc_qcw = ctx->pc_hcw = ctx->pc_tmp = ctx->pc_small = nullptr; ctx->pc_tree_h = nullptr; ctx->pc_private_done = false;
     ctx->pc_scr = nullptr; ctx->pc_scr_cap = 0; ctx->pc_fri_all = nullptr; ctx->pc_open_buf = nullptr; ctx->fri_cw_off.clear(); ctx->fri_tree_off.clear();
@@ -879,6 +880,58 @@ int vp_predicates(vp_ctx *ctx, int layer, const vp_F *r_g, const vp_F *assert_ra
     hipLaunchKernelGGL(k_pred_combine, dim3((D.p_buckets + 3) / 4), dim3(VP_BLOCK), 0, ctx->stream, D.p_bptr, D.p_buckets, ctx->pred_part, ctx->pred_out);
     HIPCHK(hipMemcpyAsync(out, ctx->pred_out, (size_t) D.p_buckets * sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
     return check_stream(ctx);
+}
+
+// <eq(r, .), table> for a device table of `size` entries: the verifier-side building block of vp_liu_gr / vp_layer_mle
+static int pred_inner_product(vp_ctx *ctx, const vp_F *r, int n, const F *table, u32 size, vp_F *out) {
+    if (n > 31) { ctx->err = "layer too large"; return VP_ELIMIT; }
+    if (!ctx->pred_r) {                                  // same scratch as vp_predicates
+        u32 max_chunks = 1, max_buckets = 1;
+        for (int i = 1; i < ctx->n_layers; ++i) { max_chunks = std::max(max_chunks, ctx->L[i].p_chunks); max_buckets = std::max(max_buckets, ctx->L[i].p_buckets); }
+        VPCHK(dalloc(ctx, &ctx->pred_r, (size_t) 3 * 32 + 2));
+        VPCHK(dalloc(ctx, &ctx->pred_pool, (size_t) 3 * 2 * ((size_t) 1 << 16)));
+        VPCHK(dalloc(ctx, &ctx->pred_part, (size_t) max_chunks));
+        VPCHK(dalloc(ctx, &ctx->pred_out, (size_t) max_buckets));
+        VPCHK(dalloc(ctx, &ctx->pred_jobs, (size_t) 3));
+    }
+    if (!ctx->pred_dot) {
+        VPCHK(dalloc(ctx, &ctx->pred_dot, (size_t) 1));
+        std::vector<BlkMap> mp(128);
+        for (u32 b = 0; b < 128; ++b) mp[b] = BlkMap{0, b};
+        VPCHK(dupload(ctx, &ctx->pred_map, mp));
+    }
+    std::vector<F> h(33, f_zero());
+    if (n) memcpy(h.data(), r, (size_t) n * sizeof(F));
+    h[32] = f_one();
+    HIPCHK(hipMemcpyAsync(ctx->pred_r, h.data(), h.size() * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
+    BetaJob jb; jb.r = ctx->pred_r; jb.init = ctx->pred_r + 32; jb.n = n; jb.pad = 0; jb.bf = ctx->pred_pool; jb.bs = jb.bf + ((size_t) 1 << (n >> 1));
+    DotJob d{}; d.h.bf = jb.bf; d.h.bs = jb.bs; d.h.h1 = n >> 1; d.val = table; d.part = ctx->partials; d.out = ctx->pred_out; d.size = size;
+    d.nblk = std::max<u32>(1, std::min<u32>(nblk(size), 128));
+    HIPCHK(hipMemcpyAsync(ctx->pred_jobs, &jb, sizeof(jb), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->pred_dot, &d, sizeof(d), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));          // h, jb, d are temporaries
+    const u32 bpj = nblk(((u64) 1 << (n >> 1)) + ((u64) 1 << (n - (n >> 1))));
+    hipLaunchKernelGGL(k_beta_half_direct, dim3(bpj), dim3(VP_BLOCK), 0, ctx->stream, ctx->pred_jobs, bpj);
+    hipLaunchKernelGGL(k_dot_multi, dim3(d.nblk), dim3(VP_BLOCK), 0, ctx->stream, ctx->pred_dot, ctx->pred_map);
+    hipLaunchKernelGGL(k_dotfin_multi, dim3(1), dim3(VP_BLOCK), 0, ctx->stream, ctx->pred_dot);
+    HIPCHK(hipMemcpyAsync(out, ctx->pred_out, sizeof(F), hipMemcpyDeviceToHost, ctx->stream));
+    return check_stream(ctx);
+}
+
+int vp_layer_mle(vp_ctx *ctx, int layer, const vp_F *r, int n, vp_F *out) {
+    if (!ctx || !ctx->evaluated || layer < 0 || layer >= ctx->n_layers || !out || n != ctx->L[layer].bl || (n && !r)) return VP_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    return pred_inner_product(ctx, r, n, ctx->L[layer].val, (u32) ctx->L[layer].size, out);
+}
+
+int vp_liu_gr(vp_ctx *ctx, int layer, const vp_F *r_u, const vp_F *const *r_v, const vp_F *s, const vp_F *r_liu, vp_F *out) {
+    if (!ctx || !out) return VP_EINVAL;
+    const int rc = vp_liu_init(ctx, layer, r_u, r_v, s);            // the Liu mult table of this layer, as the prover builds it
+    if (rc != VP_OK) return rc;
+    ctx->sc.phase = 0;                                               // not a sumcheck in progress
+    LayerDev &pre = ctx->L[layer - 1];
+    if (pre.bl && !r_liu) return VP_EINVAL;
+    return pred_inner_product(ctx, r_liu, pre.bl, ctx->tab[0][1], (u32) pre.size, out);
 }
 
 int vp_vres(vp_ctx *ctx, const vp_F *r_0, int r_0_size, vp_F *out) {

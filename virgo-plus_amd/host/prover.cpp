@@ -176,6 +176,18 @@ std::vector<F> prover::predicates(int layer, const std::vector<F> &r_g, const F 
                         mF(out.data()), out.size()), "vp_predicates");
     return out;
 }
+F prover::liuGr(int layer, const std::vector<F> &ru, const std::vector<std::vector<F>> &rv_all, const std::vector<F> &sig, const std::vector<F> &rliu) {
+    std::vector<const vp_F *> rv(C.size, nullptr);
+    for (int k = layer; k < C.size; ++k) if (!rv_all[k].empty()) rv[k] = cF(rv_all[k].data());
+    F out;
+    check(vp_liu_gr(ctx, layer, cF(ru.data()), rv.data(), cF(sig.data()), cF(rliu.data()), mF(&out)), "vp_liu_gr");
+    return out;
+}
+F prover::layerMle(int layer, const std::vector<F> &r, int n) {
+    F out;
+    check(vp_layer_mle(ctx, layer, n ? cF(r.data()) : nullptr, n, mF(&out)), "vp_layer_mle");
+    return out;
+}
 prover::hhash_digest prover::friStep(const F &r) {
     hhash_digest d;
     check(vp_fri_step(ctx, cF(&r), d.b), "vp_fri_step");

@@ -57,6 +57,9 @@ public:
     // verifier-side wiring predicates of one layer on the device (vp_predicates): 5 + 7*layer sums, see include/vpgpu.h
     std::vector<F> predicates(int layer, const std::vector<F> &r_g, const F &assert_random, const std::vector<F> &r_u,
                               const std::vector<F> &r_v, int n_v);
+    // the verifier's other O(|C|) loops on the device: gr of verifyLiu (vp_liu_gr) and a layer's MLE at r (vp_layer_mle)
+    F liuGr(int layer, const std::vector<F> &r_u, const std::vector<std::vector<F>> &r_v, const std::vector<F> &sig, const std::vector<F> &r_liu);
+    F layerMle(int layer, const std::vector<F> &r, int n);
     hhash_digest friStep(const F &r);
     std::vector<hhash_digest> friCommit(const std::vector<F> &r);   // every step in one device pass (challenges are transcript-independent)
     std::vector<F> friFinal();                           // 2048 elements, reference layout [i << 7 | slice << 1 | hi]

@@ -184,6 +184,9 @@ bool verifier::verifyLiu(int layer_id, F &previousSum) {         // verifier.cpp
     putF(vr);
     verify_timer.start();
     F gr = F_ZERO;
+    if (pred_dev) {
+        gr = pred_dev->liuGr(layer_id, r_u, r_v, sig, r_liu);          // same sum on the device (vp_liu_gr)
+    } else {
     initBetaTable(beta_u, pre.bitLength, r_liu.begin(), F_ONE);
     initBetaTable(beta_g, pre.bitLength, r_u.begin(), sig[0]);
     for (u64 g = 0; g < pre.size; ++g) gr = gr + beta_g[g] * beta_u[g];
@@ -192,6 +195,7 @@ bool verifier::verifyLiu(int layer_id, F &previousSum) {         // verifier.cpp
         if (!Lj.dadSize[pre_layer_id]) continue;
         initBetaTable(beta_g, Lj.dadBitLength[pre_layer_id], r_v[j].begin(), sig[j - pre_layer_id]);
         for (u64 g = 0; g < Lj.dadSize[pre_layer_id]; ++g) gr = gr + beta_g[g] * beta_u[Lj.dadId[pre_layer_id][g]];
+    }
     }
     const bool ok = (vr * gr == previousSum);
     verify_timer.stop();
@@ -271,6 +275,10 @@ F verifier::getFinalValue(int layer_id, const F &cu, const std::vector<F> &cv) {
 // at r_liu (the role of verifyPoly, verifier.cpp:363-389).
 bool verifier::checkInput(const F &claim) {
     const layer &L0 = C.circuit[0];
+    if (pred_dev) {                                       // the input layer's MLE at r_liu on the device (vp_layer_mle)
+        if (pred_dev->layerMle(0, r_liu, L0.bitLength) != claim) { fprintf(stderr, "Verification fail, final input check fail.\n"); return false; }
+        return true;
+    }
     std::vector<F> beta;
     initBetaTable(beta, L0.bitLength, r_liu.begin(), F_ONE);
     F acc = F_ZERO;
