@@ -107,7 +107,13 @@ def test_fused_init_plan_matches_reference(vp, golden, gold_gkr, pws_path, name,
     s2.draw_tape()
     tr2, _ = s2.prove_gkr()
     assert tr2 == tr
-    s.close(); s2.close(); c.close()
+    monkeypatch.delenv("VP_FUSE_MIN_LOG"); monkeypatch.delenv("VP_FUSE_DOT")
+    monkeypatch.setenv("VP_SF_ROUNDS", "4")         # four-round fold launches (k_sumfold4b_multi)
+    s3 = vp.Session(c)
+    s3.draw_tape()
+    tr3, _ = s3.prove_gkr()
+    assert tr3 == tr
+    s.close(); s2.close(); s3.close(); c.close()
 
 
 def test_randomize_transcript_matches_reference(vp, golden, gold_gkr):

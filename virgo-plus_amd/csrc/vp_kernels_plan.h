@@ -459,6 +459,12 @@ __global__ void __launch_bounds__(VP_BLOCK, 4) k_sumfold3b_multi(const SfArgs *_
     const SfArgs &a = jobs[m.job];
     if (a.has_a) sumfold3b_body<true>(a, m.bid, a.nblk, sm, GenLoad()); else sumfold3b_body<false>(a, m.bid, a.nblk, sm, GenLoad());
 }
+__global__ void __launch_bounds__(VP_BLOCK, 3) k_sumfold4b_multi(const SfArgs *__restrict__ jobs, const BlkMap *__restrict__ map) {
+    __shared__ Sf4bLds sm;
+    const BlkMap m = map[blockIdx.x];
+    const SfArgs &a = jobs[m.job];
+    if (a.has_a) sumfold4b_body<true>(a, m.bid, a.nblk, sm); else sumfold4b_body<false>(a, m.bid, a.nblk, sm);
+}
 // First fold launch of a phase-1 / Liu sumcheck with its init fused in (see GenP1 / GenLiu).
 struct SfGenJob { SfArgs sf; InitArgs2 a; GatherJob g; Half dot_h; F *dot_part; int mode; int pad; };
 __global__ void __launch_bounds__(VP_BLOCK, 4) k_sumfold3b_gen_multi(const SfGenJob *__restrict__ jobs, const BlkMap *__restrict__ map) {

@@ -89,7 +89,7 @@ struct Plan {
     SfGenJob *d_sfgen = nullptr; SfArgs *d_sf = nullptr; SegArgs *d_seg = nullptr; EmitArgs *d_emit = nullptr; BlkMap *d_map = nullptr;
     hipStream_t streams[4] = {nullptr, nullptr, nullptr, nullptr};   // [0] = ctx->stream; [1..3] owned: fold (low priority), seg, emit (high)
     hipEvent_t ev_root = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
-    u64 rounds = 0; int n_steps = 0;
+    u64 rounds = 0; int n_steps = 0, sf_rounds = 3;
 };
 
 struct vp_ctx {
