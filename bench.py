@@ -121,6 +121,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--blocks", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--randomize", type=int, nargs=2, metavar=("LAYERS", "LOG_SIZE"), default=None,
+                    help="BASELINE configs[4] flavour: layeredCircuit::randomize(LAYERS, LOG_SIZE) instead of the SHA-256 circuit (no CPU baseline, no golden)")
     ap.add_argument("--with-pc", action="store_true", help="also time the Virgo commitment (commit_private + commit_public + FRI commit phase)")
     a = ap.parse_args()
 
@@ -135,10 +137,15 @@ def main():
     barrier(world)
     vp.lib_host()
     golden = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))
-    gname = "sha256_x%d" % a.blocks
+    gname = "sha256_x%d" % a.blocks if not a.randomize else "randomize_%d_%d" % tuple(a.randomize)
+    if a.randomize:
+        a.no_cpu_baseline = True
     with tempfile.TemporaryDirectory() as tmp:
         pws = unpack_pws(tmp)
-        circ = vp.Circuit.from_pws(pws, a.blocks, seed=1 + rank)
+        if a.randomize:
+            circ = vp.Circuit.randomize(a.randomize[0], a.randomize[1], seed=1 + rank)
+        else:
+            circ = vp.Circuit.from_pws(pws, a.blocks, seed=1 + rank)
         t_up = time.perf_counter()
         sess = vp.Session(circ, device=local)            # raises without the HIP library / GPU
         upload_sec = time.perf_counter() - t_up
@@ -237,8 +244,10 @@ def main():
                 "ms_per_step": 1e3 * sec_per_proof_job,
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "u64 (F_p^2, p=2^61-1)", "data": "synthetic",
-                "config": {"workload": "SHA-256 %d-block circuit (SHA256_64.pws x%d, %d gates, %d layers), GKR sumcheck on GPU, Virgo PC off"
-                                       % (a.blocks, a.blocks, circ.gates, circ.layers),
+                "config": {"workload": ("SHA-256 %d-block circuit (SHA256_64.pws x%d, %d gates, %d layers), GKR sumcheck on GPU, Virgo PC off"
+                                        % (a.blocks, a.blocks, circ.gates, circ.layers)) if not a.randomize else
+                                       ("layeredCircuit::randomize(%d, %d) (%d gates, %d layers), GKR sumcheck on GPU, Virgo PC off"
+                                        % (a.randomize[0], a.randomize[1], circ.gates, circ.layers)),
                            "mode": "batched (verifier tape pre-drawn; transcript identical to the interactive run)",
                            "proofs_per_step": world, "field_ops_per_proof": ref_ops},
                 "prover_sec": sec_per_proof_job,
@@ -253,7 +262,7 @@ def main():
                 traffic = None
                 try:        # PMC pass of the same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs), committed summary
                     pm = json.load(open(os.path.join(ROOT, "profiles", PMC_SUMMARY)))
-                    if a.blocks == 64:
+                    if a.blocks == 64 and not a.randomize:
                         traffic = pm["sumfold_avg_hbm_bytes_per_launch"]
                 except Exception:
                     pass
