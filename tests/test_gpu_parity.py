@@ -454,6 +454,40 @@ def test_device_predicates_sha256_x64(vp, pws_path):
     s.close(); c.close()
 
 
+def test_limits_and_call_order_are_errors_not_crashes(vp, ob, ctx):
+    """Maximum sizes and misuse (the reference has `assert`s and UB there): the deepest circuit the library supports
+    (VP_MAX_TAB = 64 layers) proves and matches the oracle; one layer more is VP_ELIMIT; ABI calls out of the reference's
+    state-machine order, or with missing arguments, return VP_EINVAL and leave the context usable."""
+    c = vp.Circuit.randomize(64, 3, seed=5)
+    oc = ob.Circuit.randomize(64, 3, seed=5)
+    gold, st = oc.prove_gkr()
+    assert st["verified"] == 1
+    s = vp.Session(c)
+    s.draw_tape()
+    tr, _ = s.prove_gkr()
+    assert tr == gold
+    tr_i, _, ok = s.prove_interactive()
+    assert ok and tr_i == gold
+    s.close(); c.close(); oc.close()
+    too_deep = vp.Circuit.randomize(65, 2, seed=5)
+    with pytest.raises(RuntimeError, match="too many layers|-5"):
+        vp.Session(too_deep)
+    too_deep.close()
+    lib = vp.lib_gpu()
+    poly = (ctypes.c_uint64 * 6)()
+    r = (ctypes.c_uint64 * 2)(1, 2)
+    assert lib.vp_round(ctx, r, poly) == -1                        # no sumcheck in progress
+    assert lib.vp_finalize(ctx, r, poly, 1) == -1
+    assert lib.vp_phase1_init(ctx, 1, None, None) == -1            # no circuit uploaded on this context
+    lib.vp_prove_gkr.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
+    assert lib.vp_prove_gkr(ctx, None, 0, None, 0, None) == -1
+    assert lib.vp_commit_private(ctx, None) == -1
+    assert lib.vp_circuit_upload(ctx, 1, None) == -1
+    out = (ctypes.c_uint64 * 2)()
+    a = (ctypes.c_uint64 * 2)(3, 4)
+    assert lib.vp_test_field(ctx, 2, a, a, out, 1) == 0            # the context still works
+
+
 def test_violated_assert_gate_is_reported(vp):
     """The reference exits the process when an assert gate is non-zero (src/prover.cpp:18-21); the library returns
     VP_EASSERT through the host constructor instead."""

@@ -1019,8 +1019,6 @@ int vp_prove_gkr(vp_ctx *ctx, const vp_F *tape, uint64_t n_tape, uint8_t *transc
     if (!ctx || !ctx->evaluated || !tape || !transcript || n_tape != ctx->n_tape) return VP_EINVAL;
     if (capacity < ctx->n_tr * sizeof(F)) return VP_EINVAL;
     if (!ctx->simple_path) return prove_gkr_fused(ctx, tape, n_tape, transcript, n_written);
-    if (!ctx || !ctx->evaluated || !tape || !transcript || n_tape != ctx->n_tape) return VP_EINVAL;
-    if (capacity < ctx->n_tr * sizeof(F)) return VP_EINVAL;
     HIPCHK(hipSetDevice(ctx->device));
     const int n = ctx->n_layers;
     ctx->st.launches = 0; ctx->st.rounds = 0; ctx->ev_used = 0;
