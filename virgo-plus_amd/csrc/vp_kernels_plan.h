@@ -60,7 +60,7 @@ __device__ __forceinline__ u32 racc_off(int s) {                     // sum of r
 
 // Wave-uniform roles, one code path: role t folds table t (0: V, 1: mult, 2: add) and computes one of the three
 // products of the pair: 0: (m1-m0)(v1-v0)   1: m0*v0   2: m1*v1.  Two multiplies per lane and pair.
-struct SegLds { F bufA[3][VP_SEG]; F bufB[3][VP_SEG / 2]; F racc[4][VP_SEG_RACC]; };   // racc: [role][slot]; [3] = role 2's second sum (a0)
+struct SegLds { F bufA[3][VP_SEG]; F bufB[3][VP_SEG / 2]; F racc[4][VP_SEG_RACC]; F rr[VP_SEG_LOG + 1]; };   // racc: [role][slot]; [3] = role 2's second sum (a0)
 template <bool HAS_A>
 __device__ __forceinline__ void seg_body(const SegArgs &a, u32 bid, u32 nb, SegLds &sm) {
     F (&bufA)[3][VP_SEG] = sm.bufA; F (&bufB)[3][VP_SEG / 2] = sm.bufB; F (&racc)[4][VP_SEG_RACC] = sm.racc;
@@ -68,6 +68,7 @@ __device__ __forceinline__ void seg_body(const SegArgs &a, u32 bid, u32 nb, SegL
     const int role = __builtin_amdgcn_readfirstlane(w % 3);
     const u32 pslot = (u32) ((w / 3) * 64 + lane);
     for (int i = tid; i < 4 * VP_SEG_RACC; i += VP_SEG_THREADS) (&racc[0][0])[i] = f_zero();
+    if (tid < a.n_rounds) sm.rr[tid] = a.r[tid];          // the challenges of this launch: one LDS read per round instead of a global load on the round's critical path
     __syncthreads();
 
     for (u32 seg = bid; seg < a.total_segs; seg += nb) {
@@ -91,7 +92,7 @@ __device__ __forceinline__ void seg_body(const SegArgs &a, u32 bid, u32 nb, SegL
             const F *src = (s & 1) ? &bufB[0][0] : &bufA[0][0];
             F *dst = (s & 1) ? &bufA[0][0] : &bufB[0][0];
             const u32 sstr = (s & 1) ? VP_SEG / 2 : VP_SEG, dstr = (s & 1) ? VP_SEG : VP_SEG / 2;
-            const F rs = a.r[s];
+            const F rs = sm.rr[s];
             const u32 n = S >> (s + 1);                                   // pairs of this round
             const u32 vs = (vseg + (1u << s) - 1) >> s;                   // valid entries of this round
             const u32 act = (vs + 1) >> 1;                                // pairs that can be non-zero
@@ -188,8 +189,8 @@ struct EmitArgs {
     EmitTab t[VP_MAX_TAB];
 };
 
-// dynamic LDS: tables [2][3][cap] | psum[32][3] | wred[32][12][3] | claim[64] | retv[64] | atv[32] | retk[64] (int)
-#define VP_EMIT_LDS_EXTRA_F (32 * 3 + 32 * VP_EMIT_WAVES * 3 + VP_MAX_TAB + VP_MAX_TAB + 32)
+// dynamic LDS: tables [2][3][cap] | psum[32][3] | wred[32][12][3] | claim[64] | retv[64] | atv[32] | r[32] | retk[64] (int)
+#define VP_EMIT_LDS_EXTRA_F (32 * 3 + 32 * VP_EMIT_WAVES * 3 + VP_MAX_TAB + VP_MAX_TAB + 32 + 32)
 __device__ __forceinline__ void emit_body(const EmitArgs &a, unsigned char *smem_raw) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nth = blockDim.x;
     const u32 E = 1u << a.emit_log, cap = (u32) a.n_tab * E;
@@ -199,12 +200,14 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, unsigned char *smem
     F *s_claim = wred + 32 * VP_EMIT_WAVES * 3;
     F *s_retv = s_claim + VP_MAX_TAB;
     F *s_at = s_retv + VP_MAX_TAB;
-    int *s_retk = reinterpret_cast<int *>(s_at + 32);
+    F *s_r = s_at + 32;                                   // the challenges r[0..rounds), read once
+    int *s_retk = reinterpret_cast<int *>(s_r + 32);
     auto L = [&](int b, int tbl) { return lbuf + ((size_t) (b * 3 + tbl)) * cap; };
     const int role = __builtin_amdgcn_readfirstlane(w % 3);
     const u32 pslot = (u32) ((w / 3) * 64 + lane);
     const u32 pstride = (u32) (VP_EMIT_WAVES / 3) * 64;
     if (tid < VP_MAX_TAB) { s_claim[tid] = f_zero(); s_retv[tid] = f_zero(); s_retk[tid] = 0; }
+    if (tid >= 64 && tid - 64 < a.rounds) s_r[tid - 64] = a.r[tid - 64];
     // ---- phase 1: block partials of the k_seg launches, one round per wave ----
     for (int k = w + 1; k <= a.rounds; k += VP_EMIT_WAVES) {
         F ca = f_zero(), cbv = f_zero(), cc = f_zero();
@@ -242,7 +245,7 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, unsigned char *smem
         }
         F ca = f_zero(), cbv = f_zero(), cc = f_zero();
         if (real_round) {
-            const F rk = a.r[k - 1];
+            const F rk = s_r[k - 1];
             // global pair index -> (table, pair): tables are scanned with wave-uniform lengths
             for (u32 gp0 = 0;; gp0 += pstride) {
                 const u32 gp = gp0 + pslot;
@@ -325,7 +328,7 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, unsigned char *smem
     if (tid == 0) {                                            // add_term recurrence
         F at = f_zero();
         for (int k = 1; k <= a.rounds; ++k) {
-            if (k >= 2 && !f_is_zero(at)) at = f_mul(at, f_sub(f_one(), a.r[k - 2]));
+            if (k >= 2 && !f_is_zero(at)) at = f_mul(at, f_sub(f_one(), s_r[k - 2]));
             at = f_add(at, s_at[k - 1]);
             s_at[k - 1] = at;
         }
