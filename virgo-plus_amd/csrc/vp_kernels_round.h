@@ -497,6 +497,13 @@ k_round_fused(RoundArgs a, F *add_term, F *scalarV, F *poly_dev, F *poly_host, u
     round_final_tail(a, acc, add_term, scalarV, poly_dev, poly_host, seq_host, seq);
 }
 
+// Publishes a ticket in pinned host memory once everything submitted to the stream before it has completed (the batched
+// entry points poll it instead of waiting on the stream: the runtime's blocking wait adds a wake-up latency with a long tail).
+__global__ void k_ticket(unsigned long long *seq_host, unsigned long long seq) {
+    __threadfence_system();
+    __hip_atomic_store(seq_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Finalize (src/prover.cpp:494-521): the claim of table j is its V table folded down to one value.
 // `cur` holds the tables after the last round; tables that ran out earlier left their value in scalarV.
 struct FinArgs {
