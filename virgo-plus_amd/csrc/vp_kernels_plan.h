@@ -207,7 +207,31 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, unsigned char *smem
     const u32 pslot = (u32) ((w / 3) * 64 + lane);
     const u32 pstride = (u32) (VP_EMIT_WAVES / 3) * 64;
     if (tid < VP_MAX_TAB) { s_claim[tid] = f_zero(); s_retv[tid] = f_zero(); s_retk[tid] = 0; }
+    // table descriptors the per-round pair scan needs, one table per lane (read back with v_readlane: the scan runs twice per
+    // round on the critical path, and a scalar load of a.t[j] per table and pass was most of a round's time)
+    const int my_enter = lane < a.n_tab ? a.t[lane].enter : 0x7fffffff;
+    const u32 my_len = lane < a.n_tab ? a.t[lane].len_enter : 0u;
     if (tid >= 64 && tid - 64 < a.rounds) s_r[tid - 64] = a.r[tid - 64];
+    // ---- phase 0: every table this kernel owns is fetched into its LDS slot NOW (buffer = parity of its first round here).
+    // The tables are complete when the kernel starts, their slots are untouched until that round, and one memory round trip
+    // overlapped with phase 1 replaces one per entering round (measured: 3-6 us per round of the closing launch). ----
+    {
+        const int nr = a.rounds > 0 ? a.rounds : 1;
+        for (int j = 0; j < a.n_tab; ++j) {
+            const EmitTab td = a.t[j];
+            if (td.enter > nr) continue;
+            const int cbj = td.enter & 1;
+            const F *gV = td.v_from_v0 ? a.V0 + td.off : a.buf[td.src][0] + td.off;
+            const F *gM = a.buf[td.src][1] + td.off, *gA = a.buf[td.src][2] + td.off;
+            const bool single = td.bl == 0;                              // always-initialised single entry
+            for (u32 i = tid; i < td.len_enter; i += nth) {
+                const bool ok = single || i < td.valid_enter;
+                L(cbj, 0)[j * E + i] = ok ? gV[i] : f_zero();
+                L(cbj, 1)[j * E + i] = ok ? gM[i] : f_zero();
+                L(cbj, 2)[j * E + i] = (ok && a.has_a) ? gA[i] : f_zero();
+            }
+        }
+    }
     // ---- phase 1: block partials of the k_seg launches, one round per wave ----
     for (int k = w + 1; k <= a.rounds; k += VP_EMIT_WAVES) {
         F ca = f_zero(), cbv = f_zero(), cc = f_zero();
@@ -227,22 +251,6 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, unsigned char *smem
         if (!((a.work_mask >> (k - 1)) & 1u)) continue;                 // uniform
         const bool real_round = k <= a.rounds;
         const int cb = k & 1;
-        if ((a.enter_mask >> (k - 1)) & 1u) {
-            for (int j = 0; j < a.n_tab; ++j) {
-                const EmitTab td = a.t[j];
-                if (td.enter != k) continue;
-                const F *gV = td.v_from_v0 ? a.V0 + td.off : a.buf[td.src][0] + td.off;
-                const F *gM = a.buf[td.src][1] + td.off, *gA = a.buf[td.src][2] + td.off;
-                const bool single = td.bl == 0;                          // always-initialised single entry
-                for (u32 i = tid; i < td.len_enter; i += nth) {
-                    const bool ok = single || i < td.valid_enter;
-                    L(cb, 0)[j * E + i] = ok ? gV[i] : f_zero();
-                    L(cb, 1)[j * E + i] = ok ? gM[i] : f_zero();
-                    L(cb, 2)[j * E + i] = (ok && a.has_a) ? gA[i] : f_zero();
-                }
-            }
-            __syncthreads();
-        }
         F ca = f_zero(), cbv = f_zero(), cc = f_zero();
         if (real_round) {
             const F rk = s_r[k - 1];
@@ -250,11 +258,12 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, unsigned char *smem
             for (u32 gp0 = 0;; gp0 += pstride) {
                 const u32 gp = gp0 + pslot;
                 u32 run = 0; int mj = -1; u32 mp = 0; u32 total = 0;
-                for (int j = 0; j < a.n_tab; ++j) {
-                    const EmitTab td = a.t[j];
-                    if (k < td.enter) continue;
-                    const int sh = k - td.enter;
-                    const u32 len = sh < 32 ? (td.len_enter >> sh) : 0;
+                for (int j = 0; j < a.n_tab; ++j) {                      // lane j of every wave holds table j's (enter, len_enter)
+                    const int enter_j = __builtin_amdgcn_readlane(my_enter, j);
+                    if (k < enter_j) continue;
+                    const u32 len_j = (u32) __builtin_amdgcn_readlane((int) my_len, j);
+                    const int sh = k - enter_j;
+                    const u32 len = sh < 32 ? (len_j >> sh) : 0;
                     const u32 np = len >= 2 ? (len >> 1) : 0;
                     if (gp >= run && gp < run + np) { mj = j; mp = gp - run; }
                     run += np;
@@ -291,10 +300,9 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, unsigned char *smem
         }
         // single-entry tables: the entry is the claim; in a real round it retires into add_term.  One lane per table.
         if (w == VP_EMIT_WAVES - 1 && lane < a.n_tab) {
-            const EmitTab td = a.t[lane];
-            if (k >= td.enter) {
-                const int sh = k - td.enter;
-                const u32 len = sh < 32 ? (td.len_enter >> sh) : 0;
+            if (k >= my_enter) {
+                const int sh = k - my_enter;
+                const u32 len = sh < 32 ? (my_len >> sh) : 0;
                 if (len == 1) {
                     const F v = L(cb, 0)[lane * E], m = L(cb, 1)[lane * E], ad = L(cb, 2)[lane * E];
                     s_claim[lane] = v;
