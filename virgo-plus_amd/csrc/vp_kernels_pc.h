@@ -151,10 +151,20 @@ __global__ void __launch_bounds__(VP_BLOCK) k_leaf_hash_multi(FriLeafArgs a) {
     while (j + 1 < a.n && blockIdx.x >= a.blk_start[j + 1]) ++j;
     const u32 t = (blockIdx.x - a.blk_start[j]) * blockDim.x + threadIdx.x;
     const u32 N = a.N[j], halfN = N >> 1;
-    if (t >= 32 * halfN) return;
-    const u32 p = t % halfN, b = t / halfN;
     const F *cw = a.cw[j];
     Dig h; h.w[0] = h.w[1] = h.w[2] = h.w[3] = 0;
+    if (N == 1) {                                     // last level: one value per coset, leaf j pairs cosets j and j + 16
+        if (t >= 16) return;
+        for (int s = 0; s < 64; ++s) {
+            const F x = cw[(size_t) s * 32 + t], y = cw[(size_t) s * 32 + t + 16];
+            h = hhash64(x.re, x.im, y.re, y.im, h);
+        }
+        h = hhash64(0, 0, 0, 0, h);
+        a.leaves[j][t] = h;
+        return;
+    }
+    if (t >= 32 * halfN) return;
+    const u32 p = t % halfN, b = t / halfN;
     for (int s = 0; s < 64; ++s) {
         const F *row = cw + ((size_t) s * 32 + b) * N;
         const F x = row[p], y = row[p + halfN];
