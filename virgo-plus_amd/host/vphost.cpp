@@ -257,6 +257,7 @@ int vph_prove_full(vph_session *s, uint8_t *transcript, uint64_t capacity, uint6
             std::vector<F> tape = v.drawTape();
             std::vector<uint8_t> tr;
             s->p->proveGKR(tape, tr);
+            v.pred_dev = s->p.get();                 // the verifier's O(|C|) loops on the device (the prover is idle during the replay)
             ok = v.check(tape, tr);
         } else {
             ok = v.verify();
