@@ -35,7 +35,7 @@ struct InitArgs2 {
 };
 
 template <int PHASE>
-__device__ __forceinline__ void contrib2(const InitArgs2 &a, u32 e, F &m, F &ad) {
+__device__ __forceinline__ void contrib2(const InitArgs2 &a, u32 e, F &m, F &ad, const F &vu) {       // vu = V_u (phase 2), loaded once per row
     const u32 g = a.e_g[e], x = a.e_x[e], tl = a.e_tl[e];
     const int ty = (tl >> 8) & 0x7f;
     F t = half_at(a.hg, g);
@@ -60,7 +60,6 @@ __device__ __forceinline__ void contrib2(const InitArgs2 &a, u32 e, F &m, F &ad)
         }
     } else {
         t = f_mul(t, half_at(a.hu, x));
-        const F vu = *a.Vu;
         const F tv = f_mul(t, vu);                         // t * V_u
         switch (ty) {                                      // SURVEY.md Appendix A, phase-2 column
             case T_ADD: m = f_add(m, t); ad = f_add(ad, tv); break;
@@ -90,7 +89,8 @@ __device__ __forceinline__ void init2_light_body(const InitArgs2 &a, u32 bid) {
     u32 b = a.rowptr[row], e = a.rowptr[row + 1];
     if (e - b > VP_LIGHT_MAX) return;
     F m = f_zero(), ad = f_zero();
-    for (u32 k = b; k < e; ++k) contrib2<PHASE>(a, k, m, ad);
+    const F vu = PHASE == 2 ? *a.Vu : f_zero();
+    for (u32 k = b; k < e; ++k) contrib2<PHASE>(a, k, m, ad, vu);
     a.M[row] = m;
     a.A[row] = ad;
 }
@@ -104,7 +104,8 @@ __device__ __forceinline__ void init2_chunks_body(const InitArgs2 &a, const u32 
     if (c >= n_chunks) return;
     const int lane = threadIdx.x & 63;
     F m = f_zero(), ad = f_zero();
-    for (u32 k = chunk_beg[c] + lane; k < chunk_end[c]; k += 64) contrib2<PHASE>(a, k, m, ad);
+    const F vu = PHASE == 2 ? *a.Vu : f_zero();
+    for (u32 k = chunk_beg[c] + lane; k < chunk_end[c]; k += 64) contrib2<PHASE>(a, k, m, ad, vu);
     m = wave_sum(m);
     ad = wave_sum(ad);
     if (lane == 0) { part[2 * c] = m; part[2 * c + 1] = ad; }
@@ -312,7 +313,7 @@ struct GenP1 {
         if (row >= valid || row >= a->n_rows) return;
         const u32 b = a->rowptr[row], e = a->rowptr[row + 1];
         if (e - b > VP_LIGHT_MAX) { m = a->M[row]; ad = a->A[row]; return; }
-        for (u32 k = b; k < e; ++k) contrib2<1>(*a, k, m, ad);
+        for (u32 k = b; k < e; ++k) contrib2<1>(*a, k, m, ad, f_zero());
     }
 };
 struct GenLiu {
