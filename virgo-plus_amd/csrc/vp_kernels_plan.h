@@ -183,6 +183,7 @@ struct EmitArgs {
     int n_tab, rounds, has_a, emit_log;
     u32 work_mask;              // bit k-1: some table of this kernel has pairs or retires in round k
     u32 enter_mask;             // bit k-1: some table is loaded from global memory in round k
+    u32 pair_mask;              // bit k-1: some table has PAIRS in round k (work_mask minus the retire-only rounds)
     F *poly_out, *claims_out, *Vu;
     int n_pd;                   // launches that left block partials
     struct { int k0, nr; u32 nblk, off; } pd[VP_MAX_PD];   // rounds k0..k0+nr-1: part[off + s*nblk*3 + b*3 + c]
@@ -251,8 +252,9 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, unsigned char *smem
         if (!((a.work_mask >> (k - 1)) & 1u)) continue;                 // uniform
         const bool real_round = k <= a.rounds;
         const int cb = k & 1;
+        const bool has_pairs = real_round && ((a.pair_mask >> (k - 1)) & 1u);                 // uniform
         F ca = f_zero(), cbv = f_zero(), cc = f_zero();
-        if (real_round) {
+        if (has_pairs) {
             const F rk = s_r[k - 1];
             // global pair index -> (table, pair): tables are scanned with wave-uniform lengths
             for (u32 gp0 = 0;; gp0 += pstride) {
@@ -310,20 +312,21 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, unsigned char *smem
                 }
             }
         }
-        if (real_round) {
-            ca = wave_sum63(ca); cbv = wave_sum63(cbv); cc = wave_sum63(cc);
-            if (lane == 63) {
-                F *o = wred + ((size_t) (k - 1) * VP_EMIT_WAVES + w) * 3;
-                o[0] = ca; o[1] = cbv; o[2] = cc;
-            }
+        // a round in which tables only retire touches nothing another wave reads before phase 3: no sums, no barrier
+        if (!has_pairs) continue;
+        ca = wave_sum63(ca); cbv = wave_sum63(cbv); cc = wave_sum63(cc);
+        if (lane == 63) {
+            F *o = wred + ((size_t) (k - 1) * VP_EMIT_WAVES + w) * 3;
+            o[0] = ca; o[1] = cbv; o[2] = cc;
         }
         __syncthreads();
     }
+    __syncthreads();
     // ---- phase 3 ----
     if (tid < a.rounds * 3) {
         const int k = tid / 3, c = tid % 3;
         F t = psum[3 * k + c];
-        if ((a.work_mask >> k) & 1u)
+        if ((a.pair_mask >> k) & 1u)
             for (int q = 0; q < VP_EMIT_WAVES; ++q) t = f_add(t, wred[((size_t) k * VP_EMIT_WAVES + q) * 3 + c]);
         psum[3 * k + c] = t;
     }
