@@ -27,12 +27,13 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
-PMC_SUMMARY = "r01_g_pmc_summary_b64.json"   # made by tools/pmc_summary.py from three rocprofv3 --pmc passes of this script
+PMC_SUMMARY = "r01_i_pmc_summary_b64.json"   # made by tools/pmc_summary.py from three rocprofv3 --pmc passes of this script
 
 
-def dist_setup(n_gpus):
-    """One process per GPU.  The data path has no collective (independent proofs per rank); the control
-    plane (barriers, max-over-ranks of the elapsed time) runs over torch.distributed/gloo."""
+def dist_setup(n_gpus, rccl=False):
+    """One process per GPU.  Default mode: the data path has no collective (independent proofs per rank); the control
+    plane (barriers, max-over-ranks of the elapsed time) runs over torch.distributed/gloo.  rccl=True (--shard-chains):
+    device tensors additionally go over RCCL (backend "nccl" = RCCL over xGMI) for the transcript all-reduce."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -40,7 +41,10 @@ def dist_setup(n_gpus):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        if rccl:
+            import torch
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend="cpu:gloo,cuda:nccl" if rccl else "gloo", rank=rank, world_size=world)
     return world, rank, local
 
 
@@ -123,6 +127,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--randomize", type=int, nargs=2, metavar=("LAYERS", "LOG_SIZE"), default=None,
                     help="BASELINE configs[4] flavour: layeredCircuit::randomize(LAYERS, LOG_SIZE) instead of the SHA-256 circuit (no CPU baseline, no golden)")
+    ap.add_argument("--shard-chains", action="store_true",
+                    help="strong scaling: ONE proof per step; its independent sumcheck chains are dealt out to the ranks (vp_set_shard) and the "
+                         "transcript is assembled by one RCCL all-reduce per proof (launch under torch.distributed.run)")
+    ap.add_argument("--shard-sim", type=int, default=0, metavar="W",
+                    help="single GPU: run the W shards of a chain-sharded proof one after the other and report each shard's device time "
+                         "(the per-rank compute of a W-GPU run; outside the timed region)")
     ap.add_argument("--with-pc", action="store_true", help="also time the Virgo commitment (commit_private + commit_public + FRI commit phase)")
     a = ap.parse_args()
 
@@ -133,7 +143,9 @@ def main():
     if int(os.environ.get("LOCAL_RANK", "0")) == 0:
         vp.build()
         vp.lib_host()
-    world, rank, local = dist_setup(a.gpus)
+    world, rank, local = dist_setup(a.gpus, rccl=a.shard_chains)
+    shard = a.shard_chains and world > 1
+    seed = 1 if shard else 1 + rank          # a sharded proof: every rank holds the same instance
     barrier(world)
     vp.lib_host()
     golden = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))
@@ -143,15 +155,19 @@ def main():
     with tempfile.TemporaryDirectory() as tmp:
         pws = unpack_pws(tmp)
         if a.randomize:
-            circ = vp.Circuit.randomize(a.randomize[0], a.randomize[1], seed=1 + rank)
+            circ = vp.Circuit.randomize(a.randomize[0], a.randomize[1], seed=seed)
         else:
-            circ = vp.Circuit.from_pws(pws, a.blocks, seed=1 + rank)
+            circ = vp.Circuit.from_pws(pws, a.blocks, seed=seed)
         t_up = time.perf_counter()
         sess = vp.Session(circ, device=local)            # raises without the HIP library / GPU
         upload_sec = time.perf_counter() - t_up
         sess.draw_tape()
+        if shard:
+            sess.set_shard(rank, world)
         for _ in range(a.warmup):
-            sess.prove_gkr()
+            tr, _ = sess.prove_gkr()
+            if shard:
+                vp.allreduce_transcript(tr, local)
         gpu_sync(local)
         barrier(world)
         t0 = time.perf_counter()
@@ -159,11 +175,26 @@ def main():
         res = None
         for k in range(a.steps):
             tr, res = sess.prove_gkr()
+            if shard:       # the one data-path collective: u64 sum of the ranks' disjoint transcript slices over RCCL
+                tr = vp.allreduce_transcript(tr, local)
             dev_ms += res["gkr_device_ms"]
         gpu_sync(local)
         barrier(world)
         elapsed = time.perf_counter() - t0
         elapsed, proofs = aggregate(world, elapsed, float(a.steps))
+        shard_info = None
+        if shard:
+            proofs = float(a.steps)                    # all ranks worked on the same proof
+            import torch, torch.distributed as dist
+            dm = torch.tensor([dev_ms / a.steps if r == rank else 0.0 for r in range(world)], dtype=torch.float64)
+            dist.all_reduce(dm)
+            owner, cost = sess.shard_chains()
+            shard_info = {"device_ms_per_rank": [float(x) for x in dm], "chains": int((cost > 0).sum()),
+                          "chains_per_rank": [int(((owner == r) & (cost > 0)).sum()) for r in range(world)],
+                          "collective": "one all-reduce (sum, int64) of the %d-byte transcript per proof, RCCL" % len(tr)}
+            sess.set_shard(0, 1)                       # the roofline / verifier legs below run the whole proof on every rank
+            tr_full, _ = sess.prove_gkr()
+            assert tr_full == tr, "assembled sharded transcript differs from the unsharded proof"
         # Roofline pass (outside the timed region, same process, same resident state): the proof is replayed on ONE
         # stream with HIP events around every launch of the dominant kernel.  In the timed steps the independent
         # sumchecks overlap on separate streams, which makes per-kernel event times meaningless there.
@@ -174,6 +205,30 @@ def main():
         for key in ("fold_ms", "fold_launches", "fold_bytes"):
             res[key] = res_p[key]
         res["serial_device_ms"] = res_p["gkr_device_ms"]
+
+        shard_sim = None
+        if a.shard_sim > 1 and world == 1:
+            # per-rank compute of a chain-sharded proof on W GPUs, measured shard by shard on this one GPU (no collective here)
+            per = []
+            parts = []
+            for r in range(a.shard_sim):
+                sess.set_shard(r, a.shard_sim)
+                for _ in range(2):
+                    sess.prove_gkr()
+                ms = []
+                for _ in range(max(3, a.steps // 2)):
+                    t_s = time.perf_counter()
+                    tr_s, res_s = sess.prove_gkr()
+                    ms.append((res_s["gkr_device_ms"], 1e3 * (time.perf_counter() - t_s)))
+                parts.append(tr_s)
+                per.append({"rank": r, "device_ms": sum(m[0] for m in ms) / len(ms), "wall_ms": sum(m[1] for m in ms) / len(ms)})
+            owner, cost = sess.shard_chains()
+            sess.set_shard(0, 1)
+            shard_sim = {"world": a.shard_sim, "per_rank": per, "max_device_ms": max(x["device_ms"] for x in per),
+                         "max_wall_ms": max(x["wall_ms"] for x in per),
+                         "cost_share_per_rank": [float(cost[owner == r].sum() / cost.sum()) for r in range(a.shard_sim)],
+                         "assembled_equals_unsharded": vp.sum_transcripts(parts) == tr,
+                         "note": "each shard run alone on this GPU; a W-GPU run adds one all-reduce of the transcript per proof"}
 
         interactive = None
         if rank == 0:
@@ -242,14 +297,14 @@ def main():
                 "unit": "field-ops/s",
                 "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                 "ms_per_step": 1e3 * sec_per_proof_job,
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None,
                 "dtype": "u64 (F_p^2, p=2^61-1)", "data": "synthetic",
                 "config": {"workload": ("SHA-256 %d-block circuit (SHA256_64.pws x%d, %d gates, %d layers), GKR sumcheck on GPU, Virgo PC off"
                                         % (a.blocks, a.blocks, circ.gates, circ.layers)) if not a.randomize else
                                        ("layeredCircuit::randomize(%d, %d) (%d gates, %d layers), GKR sumcheck on GPU, Virgo PC off"
                                         % (a.randomize[0], a.randomize[1], circ.gates, circ.layers)),
                            "mode": "batched (verifier tape pre-drawn; transcript identical to the interactive run)",
-                           "proofs_per_step": world, "field_ops_per_proof": ref_ops},
+                           "proofs_per_step": 1 if shard else world, "field_ops_per_proof": ref_ops},
                 "prover_sec": sec_per_proof_job,
                 "prover_sec_device": 1e-3 * dev_ms / a.steps,
                 "rounds": res["rounds"], "kernel_launches_per_proof": res["launches"],
@@ -277,6 +332,10 @@ def main():
                 line["roofline"] = None
             if pc is not None:
                 line["polynomial_commitment"] = pc
+            if shard_info is not None:
+                line["sharded_proof"] = shard_info
+            if shard_sim is not None:
+                line["sharded_proof_simulation"] = shard_sim
             if world == 1 and not a.no_cpu_baseline:
                 cb = cpu_baseline(pws, a.blocks, ref_ops)
                 cb["host_cpu"] = cpu_model()

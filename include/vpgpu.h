@@ -113,6 +113,20 @@ int vp_prove_gkr(vp_ctx *, const vp_F *tape, uint64_t n_tape, uint8_t *transcrip
 /* Number of tape entries / transcript bytes vp_prove_gkr needs for the uploaded circuit.               */
 int vp_gkr_sizes(vp_ctx *, uint64_t *n_tape, uint64_t *n_transcript_bytes);
 
+/* One proof sharded over the GPUs of a node ("independent sumcheck instances shard across the GPUs").  Given
+ * the tape, every sumcheck of the proof — phase 1, phase 2 and the Liu sumcheck of each layer (src/verifier.cpp:191-337) and
+ * Vres (:151) — is independent of the others and writes its own slice of the transcript.  After vp_set_shard(rank, world),
+ * vp_prove_gkr on this context runs only the sumchecks dealt to `rank` (longest-processing-time greedy on table sizes,
+ * the same assignment on every rank) and leaves all other transcript bytes ZERO: the element-wise u64 sum of the `world`
+ * transcripts (one all-reduce over RCCL; the slices are disjoint, so the sum is exact) is the transcript of the unsharded
+ * proof, byte for byte.  Every rank holds the whole circuit and witness.  world = 1 restores the unsharded proof.  Only
+ * the batched entry point shards; the interactive entry points are unaffected.                                         */
+int vp_set_shard(vp_ctx *, int rank, int world);
+/* The assignment: owner rank and cost estimate of every chain, in the order phase-1(layer 1), Liu(layer 1), phase-1(layer 2),
+ * Liu(layer 2), ... then phase-2(layer 1..n-1), then Vres; *n_chains = 3*(n_layers-1) + 1.  Chains that do not exist (layers
+ * without a phase 2) have cost 0.                                                                                      */
+int vp_shard_chains(vp_ctx *, int32_t *owner, double *cost, int capacity, int *n_chains);
+
 /* ---- Virgo polynomial commitment, commit side ------------------------------------------------------ */
 /* prover::commit_private() (src/prover.cpp:524-530 -> poly_commit_prover::commit_private_array,
  * lib/virgo/src/poly_commit.h:41-124 -> fri::request_init_commit, fri.cpp:36-139 -> create_tree,

@@ -116,6 +116,66 @@ def test_fused_init_plan_matches_reference(vp, golden, gold_gkr, pws_path, name,
     s.close(); s2.close(); s3.close(); c.close()
 
 
+def _sharded_parts(vp, s, world):
+    """The transcripts of all `world` ranks of a chain-sharded proof, produced one after the other on this GPU."""
+    import numpy as np
+    parts = []
+    for r in range(world):
+        s.set_shard(r, world)
+        tr, res = s.prove_gkr()
+        tr2, _ = s.prove_gkr()            # graph replay of the shard's plan
+        assert tr2 == tr
+        parts.append(tr)
+    s.set_shard(0, 1)
+    nz = [np.frombuffer(p, dtype=np.uint64) != 0 for p in parts]
+    for a in range(world):
+        for b in range(a + 1, world):
+            assert not (nz[a] & nz[b]).any(), "ranks %d and %d wrote the same transcript slot" % (a, b)
+    return parts
+
+
+@pytest.mark.parametrize("name,blocks,worlds", [("sha256_x1", 1, (2, 8)), ("sha256_x16", 16, (2, 3, 4, 8)), ("sha256_x64", 64, (2, 8))])
+def test_chain_sharded_proof_assembles_to_reference(vp, golden, gold_gkr, pws_path, name, blocks, worlds):
+    """One proof over `world` GPUs (independent sumcheck instances): every rank runs the sumcheck chains dealt to it,
+    the other transcript slots stay zero, and the u64 sum of the ranks' transcripts (= the one RCCL all-reduce) is the
+    reference's transcript, byte for byte.  All ranks are executed in turn on this one GPU."""
+    c = vp.Circuit.from_pws(pws_path, blocks, seed=1)
+    s = vp.Session(c)
+    s.draw_tape()
+    gold = gold_gkr(name)
+    for world in worlds:
+        s.set_shard(0, world)
+        owner, cost = s.shard_chains()
+        assert len(owner) == 3 * (c.layers - 1) + 1
+        assert set(owner[cost > 0]) == set(range(min(world, int((cost > 0).sum())))), "a rank has no work"
+        parts = _sharded_parts(vp, s, world)
+        assert vp.sum_transcripts(parts) == gold, "world %d" % world
+    tr, _ = s.prove_gkr()               # back to the unsharded proof
+    assert tr == gold
+    s.close(); c.close()
+
+
+def test_chain_sharded_proof_randomize_and_fused_init(vp, golden, gold_gkr, monkeypatch):
+    """Sharding with a phase 2 that takes V_u from its own inner-product pass (phase 1 of the layer on another rank), on the
+    synthetic circuit, with the init fused into the first fold launch forced on."""
+    monkeypatch.setenv("VP_FUSE_MIN_LOG", "10")
+    c = vp.Circuit.randomize(8, 12, seed=1)
+    s = vp.Session(c)
+    s.draw_tape()
+    for world in (2, 5, 8):
+        assert vp.sum_transcripts(_sharded_parts(vp, s, world)) == gold_gkr("randomize_8_12")
+    s.close(); c.close()
+
+
+def test_set_shard_rejects_bad_arguments(vp):
+    c = vp.Circuit.randomize(4, 8, seed=7)
+    s = vp.Session(c)
+    for rank, world in ((-1, 2), (2, 2), (0, 0)):
+        with pytest.raises(RuntimeError):
+            s.set_shard(rank, world)
+    s.close(); c.close()
+
+
 def test_randomize_transcript_matches_reference(vp, golden, gold_gkr):
     c = vp.Circuit.randomize(8, 12, seed=1)
     _both_modes(vp, c, gold_gkr("randomize_8_12"))

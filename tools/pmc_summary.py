@@ -17,11 +17,31 @@ import sys
 
 
 def load(d):
+    """Per kernel, per counter: one value per dispatch.  Reads rocprofv3's CSV output (--output-format csv) or its default
+    rocpd SQLite database (view counters_collection: one row per dispatch, counter and hardware instance -> summed)."""
     out = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             out[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for f in glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True):
+        import sqlite3
+        db = sqlite3.connect(f)
+        q = "select kernel_name, counter_name, dispatch_id, sum(value) from counters_collection group by kernel_name, counter_name, dispatch_id order by dispatch_id"
+        for name, counter, _, v in db.execute(q):
+            out[name][counter].append(float(v))
     return out
+
+
+def kernel_stats_csv(db_path, out_csv):
+    """`rocprofv3 --kernel-trace --stats` summary from the rocpd database (view top_kernels), in the layout of *_kernel_stats.csv."""
+    import sqlite3
+    db = sqlite3.connect(db_path)
+    rows = list(db.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels group by name order by sum(duration) desc"))
+    tot = sum(r[2] for r in rows) or 1
+    with open(out_csv, "w") as f:
+        f.write('"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs"\n')
+        for n, c, t, a, mn, mx in rows:
+            f.write('"%s",%d,%d,%.1f,%.2f,%d,%d\n' % (n, c, t, a, 100.0 * t / tot, mn, mx))
 
 
 def short(n):
@@ -30,6 +50,9 @@ def short(n):
 
 
 def main():
+    if sys.argv[1] == "--stats":          # pmc_summary.py --stats RESULTS.db OUT.csv
+        kernel_stats_csv(sys.argv[2], sys.argv[3])
+        return
     out_path, fetch_d, write_d = sys.argv[1:4]
     sq_d = sys.argv[4] if len(sys.argv) > 4 else None
     fe, wr = load(fetch_d), load(write_d)

@@ -144,10 +144,36 @@ def lib_host():
         L.vph_fri_commit.argtypes = [vp, vp, ctypes.c_int, vp, vp, ctypes.c_char_p, ctypes.c_int]
         L.vph_fri_commit_batched.argtypes = [vp, vp, ctypes.c_int, vp, vp, ctypes.c_char_p, ctypes.c_int]
         L.vph_commit_private.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_double), ctypes.c_char_p, ctypes.c_int]
+        L.vph_set_shard.argtypes = [vp, ctypes.c_int, ctypes.c_int]
+        L.vph_shard_chains.argtypes = [vp, vp, vp, ctypes.c_int]
         L.vph_transcript_bytes.restype = u64
         L.vph_transcript_bytes.argtypes = [vp]
         _host = L
     return _host
+
+
+def sum_transcripts(parts):
+    """Element-wise u64 sum (mod 2^64) of the transcripts of a sharded proof = what the all-reduce over RCCL computes.  The
+    ranks' slices are disjoint and everything else is zero, so the sum is the unsharded transcript."""
+    import numpy as np
+    acc = np.zeros(len(parts[0]) // 8, dtype=np.uint64)
+    for p in parts:
+        acc += np.frombuffer(p, dtype=np.uint64)
+    return acc.tobytes()
+
+
+def allreduce_transcript(tr, device=None):
+    """The one data-path collective of a sharded proof: all-reduce (sum, int64 lanes) of the transcript over the default
+    torch.distributed group — RCCL over xGMI when the group's backend is "nccl" (the transcript goes through a device tensor),
+    gloo on the CPU in the tests.  Returns the assembled transcript bytes on every rank."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    t = torch.from_numpy(np.frombuffer(tr, dtype=np.int64).copy())
+    if "nccl" in dist.get_backend():
+        t = t.cuda(device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy().tobytes()
 
 
 class Circuit:
@@ -255,6 +281,23 @@ class Session:
         """One batched device pass from the attached tape: returns (transcript bytes, stats)."""
         tr, res, _ = self._call(lib_host().vph_prove_gkr)
         return tr, res
+
+    def set_shard(self, rank, world):
+        """One proof over `world` GPUs: prove_gkr() then runs only the sumcheck chains dealt to `rank` and leaves the rest of the
+        transcript zero; sum_transcripts() of all ranks' outputs (one all-reduce) is the proof.  world=1 undoes it."""
+        if lib_host().vph_set_shard(self.h, rank, world):
+            raise RuntimeError("set_shard(%d, %d) refused" % (rank, world))
+
+    def shard_chains(self):
+        """(owner rank, cost estimate) per sumcheck chain of the proof, in plan order (include/vpgpu.h: vp_shard_chains)."""
+        import numpy as np
+        cap = 3 * self.circuit.layers + 1
+        owner = np.zeros(cap, dtype=np.int32)
+        cost = np.zeros(cap, dtype=np.float64)
+        n = lib_host().vph_shard_chains(self.h, owner.ctypes.data, cost.ctypes.data, cap)
+        if n < 0:
+            raise RuntimeError("shard_chains failed")
+        return owner[:n].copy(), cost[:n].copy()
 
     def commit_private(self):
         """prover::commit_private(): (32-byte Merkle root, device milliseconds)."""

@@ -327,10 +327,16 @@ struct GenLiu {
     }
 };
 
-template <bool HAS_A, class Gen>
+// ROT: the waves of a workgroup sit on the four SIMDs of the CU in wave order, and so do those of every other workgroup of the
+// kernel: with fixed roles (rounds k+1 on waves 0-1, k+2 on wave 0) SIMD 0 issues 3 of the 7 wave pair-steps of every chunk
+// and SIMDs 2-3 one each — the CU runs at 7/12 of its multiply rate.  The roles therefore rotate with the chunk iteration:
+// role rw = (w + it) & 3; rw 0-1 run round k+1, rw 2 runs round k+2 (a wave that did not run k+1, so k+2 overlaps the other
+// waves' next round k).  Over four iterations every wave (SIMD) issues 7 steps.
+template <bool HAS_A, class Gen, bool ROT = true>
 __device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb, Sf3bLds &sm, const Gen &gen) {
     F (&s1)[3][256] = sm.s1; F (&s2)[3][128] = sm.s2; F (&red)[4][9] = sm.red;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    u32 it = 0;
     // round k sums stay in registers; those of rounds k+1 / k+2 (first two waves / first wave only) live in LDS, one
     // private slot per thread, so that the kernel fits 128 VGPRs (4 waves per SIMD) without scratch
     Lz acc[3];
@@ -368,27 +374,30 @@ __device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb,
             if (HAS_A) s1[2][t] = ao;
         }
         __syncthreads();
-        if (w < 2) {   // round k+1: 128 pairs
+        const int rw = ROT ? (int) ((w + it) & 3) : w;       // this wave's role in this iteration (wave-uniform)
+        ++it;
+        if (rw < 2) {   // round k+1: 128 pairs
+            const int q = rw * 64 + lane;
             F vo, mo, ao = f_zero();
-            Lz x = sm.acc2[0][t], y = sm.acc2[1][t], z = sm.acc2[2][t];
-            sf_pair_step<HAS_A>(s1[0][2 * t], s1[0][2 * t + 1], s1[1][2 * t], s1[1][2 * t + 1],
-                                HAS_A ? s1[2][2 * t] : f_zero(), HAS_A ? s1[2][2 * t + 1] : f_zero(), r1,
+            Lz x = sm.acc2[0][q], y = sm.acc2[1][q], z = sm.acc2[2][q];
+            sf_pair_step<HAS_A>(s1[0][2 * q], s1[0][2 * q + 1], s1[1][2 * q], s1[1][2 * q + 1],
+                                HAS_A ? s1[2][2 * q] : f_zero(), HAS_A ? s1[2][2 * q + 1] : f_zero(), r1,
                                 x, y, z, vo, mo, ao);
             lz_fold(x); lz_fold(y); lz_fold(z);
-            sm.acc2[0][t] = x; sm.acc2[1][t] = y; sm.acc2[2][t] = z;
-            s2[0][t] = vo; s2[1][t] = mo;
-            if (HAS_A) s2[2][t] = ao;
+            sm.acc2[0][q] = x; sm.acc2[1][q] = y; sm.acc2[2][q] = z;
+            s2[0][q] = vo; s2[1][q] = mo;
+            if (HAS_A) s2[2][q] = ao;
         }
         __syncthreads();
-        if (w == 0) {  // round k+2: 64 pairs, results are the folded table
+        if (rw == (ROT ? 2 : 0)) {  // round k+2: 64 pairs, results are the folded table
             F vo, mo, ao = f_zero();
-            Lz x = sm.acc3[0][t], y = sm.acc3[1][t], z = sm.acc3[2][t];
-            sf_pair_step<HAS_A>(s2[0][2 * t], s2[0][2 * t + 1], s2[1][2 * t], s2[1][2 * t + 1],
-                                HAS_A ? s2[2][2 * t] : f_zero(), HAS_A ? s2[2][2 * t + 1] : f_zero(), r2,
+            Lz x = sm.acc3[0][lane], y = sm.acc3[1][lane], z = sm.acc3[2][lane];
+            sf_pair_step<HAS_A>(s2[0][2 * lane], s2[0][2 * lane + 1], s2[1][2 * lane], s2[1][2 * lane + 1],
+                                HAS_A ? s2[2][2 * lane] : f_zero(), HAS_A ? s2[2][2 * lane + 1] : f_zero(), r2,
                                 x, y, z, vo, mo, ao);
             lz_fold(x); lz_fold(y); lz_fold(z);
-            sm.acc3[0][t] = x; sm.acc3[1][t] = y; sm.acc3[2][t] = z;
-            const u32 oi = cl * 64 + t;
+            sm.acc3[0][lane] = x; sm.acc3[1][lane] = y; sm.acc3[2][lane] = z;
+            const u32 oi = cl * 64 + lane;
             if (oi < ((td.valid + 7) >> 3)) {
                 a.outV[td.off + oi] = vo;
                 a.outM[td.off + oi] = mo;
@@ -398,6 +407,7 @@ __device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb,
 #pragma unroll
         for (int i = 0; i < 3; ++i) lz_fold(acc[i]);
     }
+    if (ROT) __syncthreads();             // the last round k+2 ran on a rotating wave: its sums must be visible below
     // block partials: rounds k+1 and k+2 only have contributions in waves 0-1 and 0
 #pragma unroll
     for (int i = 0; i < 9; ++i) {

@@ -146,6 +146,11 @@ struct vp_ctx {
     Plan *plan = nullptr; int plan_path = 1;   // VP_GKR_PATH=lanes: one stream per sumcheck chain instead of the plan
     // hipGraph of the concurrent GKR submission (per circuit; VP_GKR_GRAPH=0 submits the launches directly)
     hipGraphExec_t gkr_graph = nullptr; int use_graph = 1; bool graph_failed = false; u64 graph_launches = 0, graph_rounds = 0;
+    // one proof sharded over GPUs by sumcheck chain (vp_set_shard): this rank records and runs only the chains it owns
+    int shard_rank = 0, shard_world = 1;
+    std::vector<int> chain_owner;     // per chain of the plan (same indices as `lanes`, + 1 for Vres); empty = everything local
+    std::vector<double> chain_cost;
+    bool owned(int chain) const { return shard_world <= 1 || chain_owner.empty() || chain_owner[chain] == shard_rank; }
 
     F *zero() const { return small; }
     F *one() const { return small + 1; }
@@ -506,6 +511,7 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
     ctx->L.assign(n_layers, LayerDev());
     ctx->n_layers = n_layers;
     ctx->evaluated = false;
+    ctx->chain_owner.clear(); ctx->chain_cost.clear();
     ctx->chunk_cap = 0;
     ctx->pred_r = ctx->pred_pool = ctx->pred_part = ctx->pred_out = nullptr; ctx->pred_jobs = nullptr; ctx->pred_dot = nullptr; ctx->pred_map = nullptr;
     ctx->pc_rt = ctx->pc_coef = ctx->pc_cw = nullptr; ctx->pc_tree = nullptr; ctx->pc_lm = -1;
@@ -1013,6 +1019,31 @@ int vp_gkr_sizes(vp_ctx *ctx, uint64_t *n_tape, uint64_t *n_bytes) {
 }
 
 static int prove_gkr_fused(vp_ctx *ctx, const vp_F *tape, uint64_t n_tape, uint8_t *transcript, uint64_t *n_written);
+static void assign_chains(vp_ctx *ctx);
+
+int vp_set_shard(vp_ctx *ctx, int rank, int world) {
+    if (!ctx || world < 1 || rank < 0 || rank >= world) return VP_EINVAL;
+    if (world > 1 && ctx->n_layers >= 2 && (!ctx->plan_path || ctx->simple_path || ctx->sumfold_path)) {
+        ctx->err = "vp_set_shard: only the launch-plan path shards (unset VP_GKR_PATH)"; return VP_EINVAL;
+    }
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ctx->gkr_graph) { (void) hipGraphExecDestroy(ctx->gkr_graph); ctx->gkr_graph = nullptr; }
+    ctx->graph_failed = false;
+    free_plan(ctx);
+    ctx->shard_rank = rank; ctx->shard_world = world;
+    ctx->chain_owner.clear(); ctx->chain_cost.clear();
+    return VP_OK;
+}
+
+int vp_shard_chains(vp_ctx *ctx, int32_t *owner, double *cost, int capacity, int *n_chains) {
+    if (!ctx || ctx->n_layers < 2) return VP_EINVAL;
+    assign_chains(ctx);
+    const int n = (int) ctx->chain_owner.size();
+    if (n_chains) *n_chains = n;
+    for (int c = 0; c < n && c < capacity; ++c) { if (owner) owner[c] = ctx->chain_owner[c]; if (cost) cost[c] = ctx->chain_cost[c]; }
+    return VP_OK;
+}
 
 int vp_prove_gkr(vp_ctx *ctx, const vp_F *tape, uint64_t n_tape, uint8_t *transcript, uint64_t capacity,
                  uint64_t *n_written) {

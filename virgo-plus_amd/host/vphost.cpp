@@ -150,6 +150,13 @@ int vph_prove_gkr(vph_session *s, uint8_t *transcript, uint64_t capacity, uint64
     }
 }
 
+int vph_set_shard(vph_session *s, int rank, int world) { return vp_set_shard(s->p->context(), rank, world) == VP_OK ? 0 : -1; }
+
+int vph_shard_chains(vph_session *s, int32_t *owner, double *cost, int capacity) {
+    int n = 0;
+    return vp_shard_chains(s->p->context(), owner, cost, capacity, &n) == VP_OK ? n : -1;
+}
+
 int vph_check(vph_session *s, const uint8_t *transcript, uint64_t n, int skip_predicates, double *verify_sec) {
     try {
         verifier v(nullptr, s->circ->c);

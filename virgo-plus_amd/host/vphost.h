@@ -85,6 +85,11 @@ int vph_prove_full(vph_session *, uint8_t *transcript, uint64_t capacity, uint64
 /* No GPU needed: F::init(), draw the tape for `circuit`, replay the host verifier over `transcript`
  * (GKR slice).  0 = accepted, 1 = rejected.                                                            */
 int vph_verify_transcript(vph_circuit *, const uint8_t *transcript, uint64_t n, int skip_predicates);
+/* One proof over `world` GPUs (vp_set_shard): vph_prove_gkr on this session then proves only the sumchecks dealt to `rank`
+ * and leaves the rest of the transcript zero; the u64 sum of all ranks' transcripts is the proof.      */
+int vph_set_shard(vph_session *, int rank, int world);
+/* vp_shard_chains: owner and cost estimate per sumcheck chain; returns the number of chains (< 0 on error). */
+int vph_shard_chains(vph_session *, int32_t *owner, double *cost, int capacity);
 
 #ifdef __cplusplus
 }
