@@ -6,9 +6,9 @@
 #include <vector>
 #include <algorithm>
 using namespace vp;
-template <bool HAS_A> __global__ void __launch_bounds__(VP_BLOCK, 4) k_sumfold3b_nr(SfArgs a) {      // fixed wave roles (the kernel before role rotation)
+template <bool HAS_A> __global__ void __launch_bounds__(VP_BLOCK, 4) k_sumfold3b_nr(SfArgs a) {      // second instance of the same body (slot for A/B variants)
     __shared__ Sf3bLds sm;
-    sumfold3b_body<HAS_A, GenLoad, false>(a, blockIdx.x, gridDim.x, sm, GenLoad());
+    sumfold3b_body<HAS_A>(a, blockIdx.x, gridDim.x, sm, GenLoad());
 }
 static u64 rng_state = 88172645463325252ull;
 static u64 rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return rng_state; }

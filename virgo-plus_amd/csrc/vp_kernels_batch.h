@@ -278,7 +278,11 @@ __global__ void __launch_bounds__(VP_BLOCK, MINW) k_sumfold(SfArgs a) {
 //   is canonical, so results are bit-identical to the strict sequence.
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ F f_sub_lazy(const F &a, const F &b) { return f_make(a.re + P61 - b.re, a.im + P61 - b.im); }
+#ifdef VP_EXP_NOMUL       // development probe (tools/micro_sumfold.hip): the multiply-add replaced by three cheap ops, results meaningless
+__device__ __forceinline__ F f_mad_lazy(const F &a, const F &b, const F &c) { return f_make(((a.re ^ b.re) + c.re) & P61, ((a.im ^ b.im) + c.im) & P61); }
+#else
 __device__ __forceinline__ F f_mad_lazy(const F &a, const F &b, const F &c) { return f_mad31(a, b, c); }
+#endif
 struct Lz { u64 re, im; };                                           // unreduced sum of canonical values
 __device__ __forceinline__ void lz_add(Lz &s, const F &x) { s.re += x.re; s.im += x.im; }
 __device__ __forceinline__ void lz_fold(Lz &s) { s.re = (s.re & P61) + (s.re >> 61); s.im = (s.im & P61) + (s.im >> 61); }
@@ -327,16 +331,16 @@ struct GenLiu {
     }
 };
 
-// ROT: the waves of a workgroup sit on the four SIMDs of the CU in wave order, and so do those of every other workgroup of the
-// kernel: with fixed roles (rounds k+1 on waves 0-1, k+2 on wave 0) SIMD 0 issues 3 of the 7 wave pair-steps of every chunk
-// and SIMDs 2-3 one each — the CU runs at 7/12 of its multiply rate.  The roles therefore rotate with the chunk iteration:
-// role rw = (w + it) & 3; rw 0-1 run round k+1, rw 2 runs round k+2 (a wave that did not run k+1, so k+2 overlaps the other
-// waves' next round k).  Over four iterations every wave (SIMD) issues 7 steps.
-template <bool HAS_A, class Gen, bool ROT = true>
+// Measured on this kernel (tools/micro_sumfold.hip and its -DVP_EXP_* probes, 2^24 entries, profiles/r01_j_micro_*.txt): 327 us
+// as is; 257 us with the global loads replaced by synthesised values (pure instruction issue: ~758 VALU instructions per wave
+// pair-step, 528 of them in the six multiply-adds); 175 us with the multiply-adds replaced by three cheap ops (memory + LDS +
+// barriers: 4.9 TB/s).  Built, measured and rejected because they did not beat it: rotating the wave roles per chunk so that
+// every wave issues 7 steps per four chunks (+-5 %, +3 spilled VGPRs); requesting the next chunk's six entries right after
+// round k (needs 140 VGPRs: 342 us at 3 waves/SIMD, 385 us spilling at 4); 3 instead of 4 workgroups per CU (same).
+template <bool HAS_A, class Gen>
 __device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb, Sf3bLds &sm, const Gen &gen) {
     F (&s1)[3][256] = sm.s1; F (&s2)[3][128] = sm.s2; F (&red)[4][9] = sm.red;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    u32 it = 0;
     // round k sums stay in registers; those of rounds k+1 / k+2 (first two waves / first wave only) live in LDS, one
     // private slot per thread, so that the kernel fits 128 VGPRs (4 waves per SIMD) without scratch
     Lz acc[3];
@@ -374,30 +378,27 @@ __device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb,
             if (HAS_A) s1[2][t] = ao;
         }
         __syncthreads();
-        const int rw = ROT ? (int) ((w + it) & 3) : w;       // this wave's role in this iteration (wave-uniform)
-        ++it;
-        if (rw < 2) {   // round k+1: 128 pairs
-            const int q = rw * 64 + lane;
+        if (w < 2) {   // round k+1: 128 pairs
             F vo, mo, ao = f_zero();
-            Lz x = sm.acc2[0][q], y = sm.acc2[1][q], z = sm.acc2[2][q];
-            sf_pair_step<HAS_A>(s1[0][2 * q], s1[0][2 * q + 1], s1[1][2 * q], s1[1][2 * q + 1],
-                                HAS_A ? s1[2][2 * q] : f_zero(), HAS_A ? s1[2][2 * q + 1] : f_zero(), r1,
+            Lz x = sm.acc2[0][t], y = sm.acc2[1][t], z = sm.acc2[2][t];
+            sf_pair_step<HAS_A>(s1[0][2 * t], s1[0][2 * t + 1], s1[1][2 * t], s1[1][2 * t + 1],
+                                HAS_A ? s1[2][2 * t] : f_zero(), HAS_A ? s1[2][2 * t + 1] : f_zero(), r1,
                                 x, y, z, vo, mo, ao);
             lz_fold(x); lz_fold(y); lz_fold(z);
-            sm.acc2[0][q] = x; sm.acc2[1][q] = y; sm.acc2[2][q] = z;
-            s2[0][q] = vo; s2[1][q] = mo;
-            if (HAS_A) s2[2][q] = ao;
+            sm.acc2[0][t] = x; sm.acc2[1][t] = y; sm.acc2[2][t] = z;
+            s2[0][t] = vo; s2[1][t] = mo;
+            if (HAS_A) s2[2][t] = ao;
         }
         __syncthreads();
-        if (rw == (ROT ? 2 : 0)) {  // round k+2: 64 pairs, results are the folded table
+        if (w == 0) {  // round k+2: 64 pairs, results are the folded table
             F vo, mo, ao = f_zero();
-            Lz x = sm.acc3[0][lane], y = sm.acc3[1][lane], z = sm.acc3[2][lane];
-            sf_pair_step<HAS_A>(s2[0][2 * lane], s2[0][2 * lane + 1], s2[1][2 * lane], s2[1][2 * lane + 1],
-                                HAS_A ? s2[2][2 * lane] : f_zero(), HAS_A ? s2[2][2 * lane + 1] : f_zero(), r2,
+            Lz x = sm.acc3[0][t], y = sm.acc3[1][t], z = sm.acc3[2][t];
+            sf_pair_step<HAS_A>(s2[0][2 * t], s2[0][2 * t + 1], s2[1][2 * t], s2[1][2 * t + 1],
+                                HAS_A ? s2[2][2 * t] : f_zero(), HAS_A ? s2[2][2 * t + 1] : f_zero(), r2,
                                 x, y, z, vo, mo, ao);
             lz_fold(x); lz_fold(y); lz_fold(z);
-            sm.acc3[0][lane] = x; sm.acc3[1][lane] = y; sm.acc3[2][lane] = z;
-            const u32 oi = cl * 64 + lane;
+            sm.acc3[0][t] = x; sm.acc3[1][t] = y; sm.acc3[2][t] = z;
+            const u32 oi = cl * 64 + t;
             if (oi < ((td.valid + 7) >> 3)) {
                 a.outV[td.off + oi] = vo;
                 a.outM[td.off + oi] = mo;
@@ -407,7 +408,6 @@ __device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb,
 #pragma unroll
         for (int i = 0; i < 3; ++i) lz_fold(acc[i]);
     }
-    if (ROT) __syncthreads();             // the last round k+2 ran on a rotating wave: its sums must be visible below
     // block partials: rounds k+1 and k+2 only have contributions in waves 0-1 and 0
 #pragma unroll
     for (int i = 0; i < 9; ++i) {

@@ -374,7 +374,11 @@ struct RoundArgs {
     TabDesc t[VP_MAX_TAB];
 };
 
+#ifdef VP_EXP_NOLOAD      // development probe (tools/micro_sumfold.hip): no global loads, results meaningless
+__device__ __forceinline__ F ld_or_zero(const F *p, u32 i, u32 valid) { return i < valid ? f_make(i * 0x9E3779B97F4A7C15ull >> 3, (u64) (size_t) p + i) : f_zero(); }
+#else
 __device__ __forceinline__ F ld_or_zero(const F *p, u32 i, u32 valid) { return i < valid ? p[i] : f_zero(); }
+#endif
 
 // Main kernel: one thread per output pair, grid-stride.  For fold=1 a thread reads 4 consecutive
 // entries per table (64 B), writes 2 (32 B) and accumulates the three coefficients; block partial sums
