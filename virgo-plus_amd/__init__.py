@@ -144,6 +144,8 @@ def lib_host():
         L.vph_fri_commit.argtypes = [vp, vp, ctypes.c_int, vp, vp, ctypes.c_char_p, ctypes.c_int]
         L.vph_fri_commit_batched.argtypes = [vp, vp, ctypes.c_int, vp, vp, ctypes.c_char_p, ctypes.c_int]
         L.vph_commit_private.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_double), ctypes.c_char_p, ctypes.c_int]
+        L.vph_commit_device_ms.restype = ctypes.c_double
+        L.vph_commit_device_ms.argtypes = [vp]
         L.vph_set_shard.argtypes = [vp, ctypes.c_int, ctypes.c_int]
         L.vph_shard_chains.argtypes = [vp, vp, vp, ctypes.c_int]
         L.vph_transcript_bytes.restype = u64
@@ -281,6 +283,10 @@ class Session:
         """One batched device pass from the attached tape: returns (transcript bytes, stats)."""
         tr, res, _ = self._call(lib_host().vph_prove_gkr)
         return tr, res
+
+    def commit_device_ms(self):
+        """Device milliseconds (HIP events) of the last commit_private / commit_public / fri_commit call."""
+        return float(lib_host().vph_commit_device_ms(self.h))
 
     def set_shard(self, rank, world):
         """One proof over `world` GPUs: prove_gkr() then runs only the sumcheck chains dealt to `rank` and leaves the rest of the

@@ -64,7 +64,9 @@ VP_HD F f_mul(const F &a, const F &b) {
 // the 128-bit form, same 16 multiplier instructions.  Operands may be lazy differences in [0, 2p].
 struct Sp31 { u32 lo, hi; };                     // x = hi * 2^31 + lo,  x < 2^62
 VP_HD Sp31 split31(u64 x) { Sp31 s; s.lo = (u32) x & 0x7fffffffu; s.hi = (u32) (x >> 31); return s; }
-// x*y + z*w + addend (mod p);  x, y, z, w < 2^62, addend < 2^61 + 8.  Canonical result.
+// x*y + z*w + addend (mod p);  x, y, z, w < 2^62, addend < 2^61 + 8.  Canonical result (WEAK: folded once only, < 2^61 + 4,
+// for values that go straight into an unreduced sum).
+template <bool WEAK = false>
 VP_HD u64 dot2_31(const Sp31 &x, const Sp31 &y, const Sp31 &z, const Sp31 &w, u64 addend) {
     const u64 L = (u64) x.lo * y.lo + (u64) z.lo * w.lo;                                            // < 2^63
     const u64 C = (u64) x.lo * y.hi + (u64) x.hi * y.lo + (u64) z.lo * w.hi + (u64) z.hi * w.lo;    // < 2^64
@@ -74,13 +76,36 @@ VP_HD u64 dot2_31(const Sp31 &x, const Sp31 &y, const Sp31 &z, const Sp31 &w, u6
     const u64 l2 = (L & P61) + (L >> 61);
     u64 s = h2 + c2 + l2 + addend;                                       // < 2^63
     s = (s & P61) + (s >> 61);
+    if (WEAK) return s;
     return s >= P61 ? s - P61 : s;
 }
-// a*b + c;  limbs of a, b in [0, 2p], limbs of c in [0, p].  Canonical result.
+// a*b + c;  limbs of a, b in [0, 2p], limbs of c in [0, p].  Canonical result unless WEAK.
+template <bool WEAK = false>
 VP_HD F f_mad31(const F &a, const F &b, const F &c) {
     const Sp31 ar = split31(a.re), ai = split31(a.im), br = split31(b.re), bi = split31(b.im);
     const Sp31 nbi = split31(2 * P61 - b.im);                // -b.im (mod p), in [0, 2p]
-    return f_make(dot2_31(ar, br, ai, nbi, c.re), dot2_31(ar, bi, ai, br, c.im));
+    return f_make(dot2_31<WEAK>(ar, br, ai, nbi, c.re), dot2_31<WEAK>(ar, bi, ai, br, c.im));
+}
+// Same with x and z CANONICAL (< 2^61, so hi < 2^30): H*2^62 = 2H (mod p) is obtained by doubling x.hi / z.hi, and then
+// L + 2H < 2^64 shares ONE accumulator (four multiply-adds in a row, no separate shift-fold of H).  y, w < 2^62 as before.
+// WEAK: the result is only folded once (< 2^61 + 4, congruent mod p, not canonical) — for values that go straight into an
+// unreduced sum.
+template <bool WEAK>
+VP_HD u64 dot2_31c(const Sp31 &x, const Sp31 &y, const Sp31 &z, const Sp31 &w, u64 addend) {
+    const u64 LH = (u64) x.lo * y.lo + (u64) z.lo * w.lo + (u64) (2 * x.hi) * y.hi + (u64) (2 * z.hi) * w.hi;    // < 2^64
+    const u64 C = (u64) x.lo * y.hi + (u64) x.hi * y.lo + (u64) z.lo * w.hi + (u64) z.hi * w.lo;              // < 2^64
+    const u64 c2 = ((C & 0x3fffffffull) << 31) + (C >> 30);              // C * 2^31
+    u64 s = (LH & P61) + (LH >> 61) + c2 + addend;                       // < 2^63
+    s = (s & P61) + (s >> 61);
+    if (WEAK) return s;
+    return s >= P61 ? s - P61 : s;
+}
+// a*b + c with the limbs of a canonical; limbs of b in [0, 2p], limbs of c in [0, p].
+template <bool WEAK>
+VP_HD F f_mad31c(const F &a, const F &b, const F &c) {
+    const Sp31 ar = split31(a.re), ai = split31(a.im), br = split31(b.re), bi = split31(b.im);
+    const Sp31 nbi = split31(2 * P61 - b.im);
+    return f_make(dot2_31c<WEAK>(ar, br, ai, nbi, c.re), dot2_31c<WEAK>(ar, bi, ai, br, c.im));
 }
 // a + r*(b - a): one fold step of a bookkeeping table (src/prover.cpp:483 eval + interpolate)
 VP_HD F f_lerp(const F &a, const F &b, const F &r) { return f_add(a, f_mul(r, f_sub(b, a))); }

@@ -278,10 +278,16 @@ __global__ void __launch_bounds__(VP_BLOCK, MINW) k_sumfold(SfArgs a) {
 //   is canonical, so results are bit-identical to the strict sequence.
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ F f_sub_lazy(const F &a, const F &b) { return f_make(a.re + P61 - b.re, a.im + P61 - b.im); }
+// f_mad_lazy: a, b lazy.  f_mad_c: a canonical (one accumulator for L + 2H).  <true>: weakly reduced result for the lazy sums.
 #ifdef VP_EXP_NOMUL       // development probe (tools/micro_sumfold.hip): the multiply-add replaced by three cheap ops, results meaningless
-__device__ __forceinline__ F f_mad_lazy(const F &a, const F &b, const F &c) { return f_make(((a.re ^ b.re) + c.re) & P61, ((a.im ^ b.im) + c.im) & P61); }
+template <bool WEAK = false> __device__ __forceinline__ F f_mad_lazy(const F &a, const F &b, const F &c) { return f_make(((a.re ^ b.re) + c.re) & P61, ((a.im ^ b.im) + c.im) & P61); }
+template <bool WEAK = false> __device__ __forceinline__ F f_mad_c(const F &a, const F &b, const F &c) { return f_mad_lazy<WEAK>(a, b, c); }
+#elif defined(VP_EXP_OLDMAD)   // development probe: the general multiply-add with canonical results everywhere (the arithmetic before f_mad31c)
+template <bool WEAK = false> __device__ __forceinline__ F f_mad_lazy(const F &a, const F &b, const F &c) { return f_mad31<false>(a, b, c); }
+template <bool WEAK = false> __device__ __forceinline__ F f_mad_c(const F &a, const F &b, const F &c) { return f_mad31<false>(a, b, c); }
 #else
-__device__ __forceinline__ F f_mad_lazy(const F &a, const F &b, const F &c) { return f_mad31(a, b, c); }
+template <bool WEAK = false> __device__ __forceinline__ F f_mad_lazy(const F &a, const F &b, const F &c) { return f_mad31<WEAK>(a, b, c); }
+template <bool WEAK = false> __device__ __forceinline__ F f_mad_c(const F &a, const F &b, const F &c) { return f_mad31c<WEAK>(a, b, c); }
 #endif
 struct Lz { u64 re, im; };                                           // unreduced sum of canonical values
 __device__ __forceinline__ void lz_add(Lz &s, const F &x) { s.re += x.re; s.im += x.im; }
@@ -293,12 +299,12 @@ template <bool HAS_A>
 __device__ __forceinline__ void sf_pair_step(const F &v0, const F &v1, const F &m0, const F &m1, const F &a0, const F &a1,
                                              const F &r, Lz &X, Lz &Y, Lz &Z, F &vo, F &mo, F &ao) {
     const F dv = f_sub_lazy(v1, v0), dm = f_sub_lazy(m1, m0);
-    lz_add(X, f_mad_lazy(dm, dv, f_zero()));
-    lz_add(Y, f_mad_lazy(m1, v1, HAS_A ? a1 : f_zero()));
-    lz_add(Z, f_mad_lazy(m0, v0, HAS_A ? a0 : f_zero()));
-    vo = f_mad_lazy(r, dv, v0);
-    mo = f_mad_lazy(r, dm, m0);
-    if (HAS_A) ao = f_mad_lazy(r, f_sub_lazy(a1, a0), a0);
+    lz_add(X, f_mad_lazy<true>(dm, dv, f_zero()));                       // sums take weakly reduced products (< 2^61 + 4)
+    lz_add(Y, f_mad_c<true>(m1, v1, HAS_A ? a1 : f_zero()));
+    lz_add(Z, f_mad_c<true>(m0, v0, HAS_A ? a0 : f_zero()));
+    vo = f_mad_c(r, dv, v0);                                             // stored values are canonical
+    mo = f_mad_c(r, dm, m0);
+    if (HAS_A) ao = f_mad_c(r, f_sub_lazy(a1, a0), a0);
 }
 
 struct Sf3bLds { F s1[3][256]; F s2[3][128]; F red[4][9]; Lz acc2[3][128]; Lz acc3[3][64]; F dred[4]; };   // acc2/acc3: per-thread sums of rounds k+1, k+2
@@ -523,8 +529,11 @@ __device__ __forceinline__ void sumfold4b_body(const SfArgs &a, u32 bid, u32 nb,
     }
 }
 
+#ifndef VP_SF_MINB
+#define VP_SF_MINB 3          // workgroups per CU the fold kernels are compiled for (register budget 512 / MINB per lane)
+#endif
 template <bool HAS_A>
-__global__ void __launch_bounds__(VP_BLOCK, 4) k_sumfold3b(SfArgs a) {
+__global__ void __launch_bounds__(VP_BLOCK, VP_SF_MINB) k_sumfold3b(SfArgs a) {
     __shared__ Sf3bLds sm;
     sumfold3b_body<HAS_A>(a, blockIdx.x, gridDim.x, sm, GenLoad());
 }

@@ -467,7 +467,7 @@ __global__ void __launch_bounds__(VP_BLOCK) k_combine_multi(const CombineJob *__
     const CombineJob &j = jobs[m.job];
     init_combine_body(j.heavy_row, j.heavy_cptr, j.n_heavy, j.part, j.M, j.A, m.bid);
 }
-__global__ void __launch_bounds__(VP_BLOCK, 4) k_sumfold3b_multi(const SfArgs *__restrict__ jobs, const BlkMap *__restrict__ map) {
+__global__ void __launch_bounds__(VP_BLOCK, VP_SF_MINB) k_sumfold3b_multi(const SfArgs *__restrict__ jobs, const BlkMap *__restrict__ map) {
     __shared__ Sf3bLds sm;
     const BlkMap m = map[blockIdx.x];
     const SfArgs &a = jobs[m.job];
@@ -481,7 +481,7 @@ __global__ void __launch_bounds__(VP_BLOCK, 3) k_sumfold4b_multi(const SfArgs *_
 }
 // First fold launch of a phase-1 / Liu sumcheck with its init fused in (see GenP1 / GenLiu).
 struct SfGenJob { SfArgs sf; InitArgs2 a; GatherJob g; Half dot_h; F *dot_part; int mode; int pad; };
-__global__ void __launch_bounds__(VP_BLOCK, 4) k_sumfold3b_gen_multi(const SfGenJob *__restrict__ jobs, const BlkMap *__restrict__ map) {
+__global__ void __launch_bounds__(VP_BLOCK, VP_SF_MINB) k_sumfold3b_gen_multi(const SfGenJob *__restrict__ jobs, const BlkMap *__restrict__ map) {
     __shared__ Sf3bLds sm;
     const BlkMap m = map[blockIdx.x];
     const SfGenJob &j = jobs[m.job];

@@ -150,6 +150,8 @@ int vph_prove_gkr(vph_session *s, uint8_t *transcript, uint64_t capacity, uint64
     }
 }
 
+double vph_commit_device_ms(vph_session *s) { double ms = -1; vp_commit_stats(s->p->context(), &ms); return ms; }
+
 int vph_set_shard(vph_session *s, int rank, int world) { return vp_set_shard(s->p->context(), rank, world) == VP_OK ? 0 : -1; }
 
 int vph_shard_chains(vph_session *s, int32_t *owner, double *cost, int capacity) {

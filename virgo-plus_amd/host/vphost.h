@@ -85,6 +85,8 @@ int vph_prove_full(vph_session *, uint8_t *transcript, uint64_t capacity, uint64
 /* No GPU needed: F::init(), draw the tape for `circuit`, replay the host verifier over `transcript`
  * (GKR slice).  0 = accepted, 1 = rejected.                                                            */
 int vph_verify_transcript(vph_circuit *, const uint8_t *transcript, uint64_t n, int skip_predicates);
+/* vp_commit_stats: device milliseconds of the last commit_private / commit_public / FRI call on this session. */
+double vph_commit_device_ms(vph_session *);
 /* One proof over `world` GPUs (vp_set_shard): vph_prove_gkr on this session then proves only the sumchecks dealt to `rank`
  * and leaves the rest of the transcript zero; the u64 sum of all ranks' transcripts is the proof.      */
 int vph_set_shard(vph_session *, int rank, int world);
