@@ -201,7 +201,7 @@ def main():
             owner, cost = sess.shard_chains()
             shard_info = {"device_ms_per_rank": [float(x) for x in dm], "chains": int((cost > 0).sum()),
                           "chains_per_rank": [int(((owner == r) & (cost > 0)).sum()) for r in range(world)],
-                          "collective": "one all-reduce (sum, int64) of the %d-byte transcript per proof, RCCL" % len(tr)}
+                          "collective": "one all-reduce (sum, int64) of the %d-byte transcript per proof, backend %s" % (len(tr), dist.get_backend())}
             sess.set_shard(0, 1)                       # the roofline / verifier legs below run the whole proof on every rank
             tr_full, _ = sess.prove_gkr()
             assert tr_full == tr, "assembled sharded transcript differs from the unsharded proof"

@@ -70,7 +70,22 @@ __global__ void __launch_bounds__(1024) k_ntt_lds(NttArgs a) {
 
 // ---- K8: SHA3-256 on 64-byte messages (my_hhash.h:27-33; FIPS 202), leaf chains and Merkle levels -------
 struct Dig { u64 w[4]; };
+// The state is kept as 2 x 25 32-bit halves: gfx950 has no 64-bit logic or rotate instructions, and a 64-bit rotation written
+// on u64 compiles to two 64-bit shifts and two ORs (4-5 instructions); on halves it is two v_alignbit_b32.  Per round:
+// 120 v_bitop3_b32 (three-input xor; chi = a ^ (~b & c) in one instruction) + 58 v_alignbit_b32 + 2 xor = 180 instructions, four
+// rounds per loop iteration (was ~313 VALU instructions per round with the u64 formulation, 25 of them register moves).
 __device__ __forceinline__ u64 rotl64(u64 x, int n) { return (x << n) | (x >> (64 - n)); }
+#ifndef VP_KECCAK_UNROLL
+#define VP_KECCAK_UNROLL 4
+#endif
+template <int N> __device__ __forceinline__ void rot(u32 lo, u32 hi, u32 &olo, u32 &ohi) {      // (ohi:olo) = rotl64(hi:lo, N)
+    if (N == 0) { olo = lo; ohi = hi; }
+    else if (N == 32) { olo = hi; ohi = lo; }
+    else if (N < 32) { ohi = __builtin_amdgcn_alignbit(hi, lo, 32 - N); olo = __builtin_amdgcn_alignbit(lo, hi, 32 - N); }
+    else { ohi = __builtin_amdgcn_alignbit(lo, hi, 64 - N); olo = __builtin_amdgcn_alignbit(hi, lo, 64 - N); }
+}
+__device__ __forceinline__ u32 chi32(u32 a, u32 b, u32 c) { return a ^ (~b & c); }            // one v_bitop3_b32
+__device__ __forceinline__ u32 xor3(u32 a, u32 b, u32 c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }   // a ^ b ^ c in one instruction
 __device__ __forceinline__ void keccak_f1600(u64 (&A)[25]) {
     const u64 RC[24] = {
         0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808aull, 0x8000000080008000ull, 0x000000000000808bull,
@@ -78,34 +93,67 @@ __device__ __forceinline__ void keccak_f1600(u64 (&A)[25]) {
         0x0000000080008009ull, 0x000000008000000aull, 0x000000008000808bull, 0x800000000000008bull, 0x8000000000008089ull,
         0x8000000000008003ull, 0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800aull, 0x800000008000000aull,
         0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
-#pragma unroll 1
-    for (int rnd = 0; rnd < 24; ++rnd) {
-        u64 C0 = A[0] ^ A[5] ^ A[10] ^ A[15] ^ A[20], C1 = A[1] ^ A[6] ^ A[11] ^ A[16] ^ A[21];
-        u64 C2 = A[2] ^ A[7] ^ A[12] ^ A[17] ^ A[22], C3 = A[3] ^ A[8] ^ A[13] ^ A[18] ^ A[23];
-        u64 C4 = A[4] ^ A[9] ^ A[14] ^ A[19] ^ A[24];
-        const u64 D0 = C4 ^ rotl64(C1, 1), D1 = C0 ^ rotl64(C2, 1), D2 = C1 ^ rotl64(C3, 1), D3 = C2 ^ rotl64(C4, 1), D4 = C3 ^ rotl64(C0, 1);
+    u32 al[25], ah[25];
 #pragma unroll
-        for (int y = 0; y < 25; y += 5) { A[y] ^= D0; A[y + 1] ^= D1; A[y + 2] ^= D2; A[y + 3] ^= D3; A[y + 4] ^= D4; }
+    for (int i = 0; i < 25; ++i) { al[i] = (u32) A[i]; ah[i] = (u32) (A[i] >> 32); }
+#pragma unroll 1
+    for (int rnd0 = 0; rnd0 < 24; rnd0 += VP_KECCAK_UNROLL)
+#pragma unroll
+    for (int rnd = rnd0; rnd < rnd0 + VP_KECCAK_UNROLL; ++rnd) {
+        // theta
+        u32 cl[5], ch[5], rl[5], rh[5];
+#pragma unroll
+        for (int x = 0; x < 5; ++x) {
+            cl[x] = xor3(xor3(al[x], al[x + 5], al[x + 10]), al[x + 15], al[x + 20]);
+            ch[x] = xor3(xor3(ah[x], ah[x + 5], ah[x + 10]), ah[x + 15], ah[x + 20]);
+        }
+#pragma unroll
+        for (int x = 0; x < 5; ++x) rot<1>(cl[x], ch[x], rl[x], rh[x]);
+#pragma unroll
+        for (int i = 0; i < 25; ++i) {                       // A ^= D, D[x] = C[x-1] ^ rotl(C[x+1], 1), without materialising D
+            al[i] = xor3(al[i], cl[(i + 4) % 5], rl[(i + 1) % 5]);
+            ah[i] = xor3(ah[i], ch[(i + 4) % 5], rh[(i + 1) % 5]);
+        }
         // rho + pi
-        u64 B[25];
-        B[0] = A[0];
-        B[10] = rotl64(A[1], 1);   B[20] = rotl64(A[2], 62);  B[5] = rotl64(A[3], 28);   B[15] = rotl64(A[4], 27);
-        B[16] = rotl64(A[5], 36);  B[1] = rotl64(A[6], 44);   B[11] = rotl64(A[7], 6);   B[21] = rotl64(A[8], 55);
-        B[6] = rotl64(A[9], 20);   B[7] = rotl64(A[10], 3);   B[17] = rotl64(A[11], 10); B[2] = rotl64(A[12], 43);
-        B[12] = rotl64(A[13], 25); B[22] = rotl64(A[14], 39); B[23] = rotl64(A[15], 41); B[8] = rotl64(A[16], 45);
-        B[18] = rotl64(A[17], 15); B[3] = rotl64(A[18], 21);  B[13] = rotl64(A[19], 8);  B[14] = rotl64(A[20], 18);
-        B[24] = rotl64(A[21], 2);  B[9] = rotl64(A[22], 61);  B[19] = rotl64(A[23], 56); B[4] = rotl64(A[24], 14);
-        // chi
+        u32 bl[25], bh[25];
+        rot<0>(al[0], ah[0], bl[0], bh[0]);
+        rot<1>(al[1], ah[1], bl[10], bh[10]);
+        rot<62>(al[2], ah[2], bl[20], bh[20]);
+        rot<28>(al[3], ah[3], bl[5], bh[5]);
+        rot<27>(al[4], ah[4], bl[15], bh[15]);
+        rot<36>(al[5], ah[5], bl[16], bh[16]);
+        rot<44>(al[6], ah[6], bl[1], bh[1]);
+        rot<6>(al[7], ah[7], bl[11], bh[11]);
+        rot<55>(al[8], ah[8], bl[21], bh[21]);
+        rot<20>(al[9], ah[9], bl[6], bh[6]);
+        rot<3>(al[10], ah[10], bl[7], bh[7]);
+        rot<10>(al[11], ah[11], bl[17], bh[17]);
+        rot<43>(al[12], ah[12], bl[2], bh[2]);
+        rot<25>(al[13], ah[13], bl[12], bh[12]);
+        rot<39>(al[14], ah[14], bl[22], bh[22]);
+        rot<41>(al[15], ah[15], bl[23], bh[23]);
+        rot<45>(al[16], ah[16], bl[8], bh[8]);
+        rot<15>(al[17], ah[17], bl[18], bh[18]);
+        rot<21>(al[18], ah[18], bl[3], bh[3]);
+        rot<8>(al[19], ah[19], bl[13], bh[13]);
+        rot<18>(al[20], ah[20], bl[14], bh[14]);
+        rot<2>(al[21], ah[21], bl[24], bh[24]);
+        rot<61>(al[22], ah[22], bl[9], bh[9]);
+        rot<56>(al[23], ah[23], bl[19], bh[19]);
+        rot<14>(al[24], ah[24], bl[4], bh[4]);
+        // chi + iota
 #pragma unroll
         for (int y = 0; y < 25; y += 5) {
-            A[y] = B[y] ^ (~B[y + 1] & B[y + 2]);
-            A[y + 1] = B[y + 1] ^ (~B[y + 2] & B[y + 3]);
-            A[y + 2] = B[y + 2] ^ (~B[y + 3] & B[y + 4]);
-            A[y + 3] = B[y + 3] ^ (~B[y + 4] & B[y]);
-            A[y + 4] = B[y + 4] ^ (~B[y] & B[y + 1]);
+#pragma unroll
+            for (int x = 0; x < 5; ++x) {
+                al[y + x] = chi32(bl[y + x], bl[y + (x + 1) % 5], bl[y + (x + 2) % 5]);
+                ah[y + x] = chi32(bh[y + x], bh[y + (x + 1) % 5], bh[y + (x + 2) % 5]);
+            }
         }
-        A[0] ^= RC[rnd];
+        al[0] ^= (u32) RC[rnd]; ah[0] ^= (u32) (RC[rnd] >> 32);
     }
+#pragma unroll
+    for (int i = 0; i < 25; ++i) A[i] = ((u64) ah[i] << 32) | al[i];
 }
 // h' = SHA3-256(m0..m3 || h)   — the 64-byte block of the leaf chains and of the Merkle nodes
 __device__ __forceinline__ Dig hhash64(u64 m0, u64 m1, u64 m2, u64 m3, const Dig &h) {
