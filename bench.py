@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
-PMC_SUMMARY = "r01_i_pmc_summary_b64.json"   # made by tools/pmc_summary.py from three rocprofv3 --pmc passes of this script
+PMC_SUMMARY = "r01_k_pmc_summary_b64.json"   # made by tools/pmc_summary.py from three rocprofv3 --pmc passes of this script
 
 
 def dist_setup(n_gpus, rccl=False):
