@@ -176,6 +176,40 @@ def test_set_shard_rejects_bad_arguments(vp):
     s.close(); c.close()
 
 
+@pytest.mark.parametrize("make", ["randomize", "sha256_x1", "sha256_x16"])
+def test_fiat_shamir_proof_round_trip(vp, gold_gkr, pws_path, make):
+    """Fiat-Shamir mode: the challenges are SHA3-derived from the circuit hash and the prover's earlier messages, the
+    prover runs through its interactive entry points, and the host verifier re-derives everything from the proof alone.  A
+    separate mode: not comparable with the reference's transcripts, so the properties are accept / reject."""
+    import os
+    if make == "randomize":
+        c = vp.Circuit.randomize(6, 8, seed=5)
+        other = vp.Circuit.randomize(6, 8, seed=6)
+    else:
+        blocks = 1 if make == "sha256_x1" else 16
+        c = vp.Circuit.from_pws(pws_path, blocks, seed=1)
+        other = vp.Circuit.from_pws(pws_path, blocks, seed=2)           # same gates, another witness
+    s = vp.Session(c)
+    proof, res, ok = s.prove_fs()
+    assert ok and res["rounds"] > 0
+    assert c.verify_fs(proof)
+    proof2, _, _ = s.prove_fs()
+    assert proof2 == proof, "deterministic"
+    tr_i, _, _ = s.prove_interactive()
+    assert len(tr_i) == len(proof) and tr_i != proof, "same layout, different challenges"
+    if make != "randomize":
+        assert proof != gold_gkr(make)
+    assert not other.verify_fs(proof), "a proof is bound to its circuit and witness"
+    n = len(proof)
+    for pos in (0, 16, 64, n // 3, n // 2, n - 17, n - 1):
+        bad = bytearray(proof); bad[pos] ^= 1
+        assert not c.verify_fs(bytes(bad)), "tampered byte %d accepted" % pos
+    assert not c.verify_fs(proof[:-16]) and not c.verify_fs(proof + bytes(16)) and not c.verify_fs(b"")
+    if make == "randomize" and os.environ.get("VP_WRITE_FS_FIXTURE"):
+        open(os.environ["VP_WRITE_FS_FIXTURE"], "wb").write(proof)
+    s.close(); c.close(); other.close()
+
+
 def test_randomize_transcript_matches_reference(vp, golden, gold_gkr):
     c = vp.Circuit.randomize(8, 12, seed=1)
     _both_modes(vp, c, gold_gkr("randomize_8_12"))
@@ -617,3 +651,16 @@ def test_cli_runs_the_reference_flow(vp, pws_path):
     assert "Verification pass" in out.stderr
     for key in ("Input size 7226", "Prove Time", "verify time", "proof size", "Polynomial commitment: prove time"):
         assert key in out.stdout
+
+
+@pytest.mark.gpu
+def test_cli_fiat_shamir_mode(vp, pws_path, tmp_path):
+    """virgo_plus_run --fs: non-interactive proof, verified from the dumped bytes alone by a second verifier object and by the library."""
+    import subprocess
+    dump = tmp_path / "proof.bin"
+    out = subprocess.run([vp.CLI, pws_path, "--fs", "--dump", str(dump)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert "Verification pass" in out.stderr and "proof size" in out.stdout
+    c = vp.Circuit.from_pws(pws_path, 1)          # the CLI's witness: default glibc seed, as the reference draws it
+    assert c.verify_fs(dump.read_bytes())
+    c.close()

@@ -135,3 +135,24 @@ def test_host_sha3_is_fips202(vp):
     vp.lib_host().vph_test_sha3(msgs.ctypes.data, out.ctypes.data, n)
     for i in range(n):
         assert out[i].tobytes() == hashlib.sha3_256(msgs[i].tobytes()).digest()
+
+
+def test_fiat_shamir_verifier_on_host(vp, golden, gold_gkr):
+    """vph_verify_fs needs no GPU: the committed proof (made on the GPU box by tests/test_gpu_parity.py with VP_WRITE_FS_FIXTURE) is
+    accepted, tampered / truncated / foreign proofs are rejected, and so is a transcript of the interactive protocol (its
+    challenges came from random(), not from the hash chain)."""
+    import os
+    from conftest import GOLDEN
+    c = vp.Circuit.randomize(6, 8, seed=5)
+    proof = open(os.path.join(GOLDEN, "fs_proof_randomize_6_8_seed5.bin"), "rb").read()
+    assert c.verify_fs(proof)
+    for pos in (0, 5, len(proof) // 2, len(proof) - 1):
+        bad = bytearray(proof); bad[pos] ^= 0x80
+        assert not c.verify_fs(bytes(bad))
+    assert not c.verify_fs(proof[:-16]) and not c.verify_fs(b"")
+    other = vp.Circuit.randomize(6, 8, seed=6)
+    assert not other.verify_fs(proof)
+    g = vp.Circuit.randomize(8, 12, seed=1)
+    assert g.verify_transcript(gold_gkr("randomize_8_12"))
+    assert not g.verify_fs(gold_gkr("randomize_8_12"))
+    c.close(); other.close(); g.close()

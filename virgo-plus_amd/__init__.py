@@ -144,6 +144,8 @@ def lib_host():
         L.vph_fri_commit.argtypes = [vp, vp, ctypes.c_int, vp, vp, ctypes.c_char_p, ctypes.c_int]
         L.vph_fri_commit_batched.argtypes = [vp, vp, ctypes.c_int, vp, vp, ctypes.c_char_p, ctypes.c_int]
         L.vph_commit_private.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_double), ctypes.c_char_p, ctypes.c_int]
+        L.vph_prove_fs.argtypes = [vp, vp, u64, ctypes.POINTER(u64), ctypes.POINTER(VphResult), ctypes.c_char_p, ctypes.c_int]
+        L.vph_verify_fs.argtypes = [vp, vp, u64]
         L.vph_commit_device_ms.restype = ctypes.c_double
         L.vph_commit_device_ms.argtypes = [vp]
         L.vph_set_shard.argtypes = [vp, ctypes.c_int, ctypes.c_int]
@@ -232,6 +234,11 @@ class Circuit:
         return lib_host().vph_verify_transcript(self.h, ctypes.cast(buf, ctypes.c_void_p), len(transcript),
                                                 1 if skip_predicates else 0) == 0
 
+    def verify_fs(self, proof):
+        """Verify a Fiat-Shamir proof (Session.prove_fs) on the host: no GPU, no tape."""
+        buf = ctypes.create_string_buffer(bytes(proof), len(proof))
+        return lib_host().vph_verify_fs(self.h, ctypes.cast(buf, ctypes.c_void_p), len(proof)) == 0
+
     def close(self):
         if self.h:
             lib_host().vph_circuit_free(self.h)
@@ -274,6 +281,11 @@ class Session:
     def prove_interactive(self):
         """F::init() + verifier::verify(): returns (transcript bytes, stats, verified)."""
         tr, res, rc = self._call(lib_host().vph_prove_interactive)
+        return tr, res, rc == 0
+
+    def prove_fs(self):
+        """Non-interactive GKR proof (Fiat-Shamir over SHA3-256): returns (proof bytes, stats, accepted by the built-in verifier)."""
+        tr, res, rc = self._call(lib_host().vph_prove_fs)
         return tr, res, rc == 0
 
     def draw_tape(self):

@@ -36,7 +36,29 @@ verifier::verifier(prover *pr, const layeredCircuit &cir) : p(pr), C(cir) {     
     sig.assign(C.size, F_ZERO);
 }
 
+// ---- Fiat-Shamir: state' = SHA3-256(block || state) over the same 64-byte block function as the commitment (sha3.hpp) ----
+// absorb a prover message:  block = {real, img, 0, 0x4d};  squeeze challenge number c:  block = {c, 0, 0, 0x43}, then the two
+// limbs are the first two digest words reduced to 61 bits (p itself maps to 0; the bias is 2^-61).
+void verifier::fsInit() {
+    fs_state = vph::hhash_digest{};
+    fs_ctr = 0;
+    u64 h[2];
+    C.structuralHash(h);
+    const uint64_t m[4] = {h[0], h[1], (uint64_t) C.size, 0x53};                 // statement: the levelised circuit
+    fs_state = vph::hhash(m, fs_state);
+}
 F verifier::draw() {
+    if (fs) {
+        const uint64_t m[4] = {fs_ctr++, 0, 0, 0x43};
+        fs_state = vph::hhash(m, fs_state);
+        const uint64_t P = 2305843009213693951ull;
+        uint64_t a = fs_state.w[0] & P, b = fs_state.w[1] & P;
+        if (a == P) a = 0;
+        if (b == P) b = 0;
+        F x; x.real = a; x.img = b;
+        tape_.push_back(x);
+        return x;
+    }
     if (replay) return (*rtape)[tape_pos++];
     F x = F::random();
     tape_.push_back(x);
@@ -46,6 +68,10 @@ void verifier::putF(const F &x) {
     unsigned long long w[2] = {x.real, x.img};
     const uint8_t *b = reinterpret_cast<const uint8_t *>(w);
     tr.insert(tr.end(), b, b + 16);
+    if (fs) {
+        const uint64_t m[4] = {x.real, x.img, 0, 0x4d};
+        fs_state = vph::hhash(m, fs_state);
+    }
 }
 F verifier::nextF() {
     F x;
@@ -82,6 +108,23 @@ bool verifier::verify() {
     if (!p) throw std::runtime_error("verify(): no prover attached");
     replay = false; tape_.clear(); tr.clear();
     return run();
+}
+bool verifier::proveFS() {
+    if (!p) throw std::runtime_error("proveFS(): no prover attached");
+    replay = false; fs = true; tape_.clear(); tr.clear();
+    fsInit();
+    const bool ok = run();
+    fs = false;
+    return ok;
+}
+bool verifier::checkFS(const std::vector<uint8_t> &proof) {
+    static const std::vector<F> no_tape;
+    replay = true; fs = true; rtape = &no_tape; rtr = &proof; tape_pos = 0; tr_pos = 0; tr.clear(); tape_.clear();
+    fsInit();
+    bool ok = false;
+    try { ok = run(); } catch (const std::exception &) { ok = false; }      // truncated proof
+    fs = false;
+    return ok && tr_pos == proof.size();
 }
 bool verifier::check(const std::vector<F> &tape, const std::vector<uint8_t> &transcript) {
     replay = true; rtape = &tape; rtr = &transcript; tape_pos = 0; tr_pos = 0; tr.clear();
@@ -120,7 +163,7 @@ bool verifier::run() {                          // verifier.cpp:134-169 (GKR par
 
 bool verifier::verifyPhase1(int layer_id, F &previousSum) {      // verifier.cpp:191-229
     const layer &pre = C.circuit[layer_id - 1];
-    for (auto &x : r_u) x = draw();
+    if (!fs) for (auto &x : r_u) x = draw();
     F previousRandom = F_ZERO;
     assert_random = draw();
     if (!replay) p->sumcheckInitPhase1(assert_random);
@@ -130,6 +173,7 @@ bool verifier::verifyPhase1(int layer_id, F &previousSum) {      // verifier.cpp
             fprintf(stderr, "Verification fail, phase1, circuit %d, current bit %d\n", layer_id, j);
             return false;
         }
+        if (fs) r_u[j] = draw();                    // Fiat-Shamir: the challenge of round j follows its polynomial
         previousRandom = r_u[j];
         previousSum = poly.eval(r_u[j]);
     }
@@ -140,7 +184,7 @@ bool verifier::verifyPhase1(int layer_id, F &previousSum) {      // verifier.cpp
 }
 
 bool verifier::verifyPhase2(int layer_id, F &previousSum) {      // verifier.cpp:231-270
-    for (auto &x : r_v[layer_id]) x = draw();
+    if (!fs) for (auto &x : r_v[layer_id]) x = draw();
     F previousRandom = F_ZERO;
     if (!replay) p->sumcheckInitPhase2();
     for (int j = 0; j < C.circuit[layer_id].maxDadBitLength; ++j) {
@@ -149,6 +193,7 @@ bool verifier::verifyPhase2(int layer_id, F &previousSum) {      // verifier.cpp
             fprintf(stderr, "Verification fail, phase2, circuit level %d, current bit %d\n", layer_id, j);
             return false;
         }
+        if (fs) r_v[layer_id][j] = draw();
         previousRandom = r_v[layer_id][j];
         previousSum = poly.eval(previousRandom);
     }
@@ -163,7 +208,7 @@ bool verifier::verifyLiu(int layer_id, F &previousSum) {         // verifier.cpp
     const int pre_layer_id = layer_id - 1;
     const layer &pre = C.circuit[pre_layer_id];
     for (auto &x : sig) x = draw();
-    for (auto &x : r_liu) x = draw();
+    if (!fs) for (auto &x : r_liu) x = draw();
     previousSum = sig[0] * final_claim_u;
     for (int j = layer_id; j < C.size; ++j)
         if (C.circuit[j].dadSize[pre_layer_id])                  // an empty subset's claim is zero
@@ -176,6 +221,7 @@ bool verifier::verifyLiu(int layer_id, F &previousSum) {         // verifier.cpp
             fprintf(stderr, "Liu fail, circuit %d, current bit %d\n", layer_id, j);
             return false;
         }
+        if (fs) r_liu[j] = draw();
         previousRandom = r_liu[j];
         previousSum = poly.eval(previousRandom);
     }

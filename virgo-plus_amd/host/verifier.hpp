@@ -29,6 +29,14 @@ public:
     const std::vector<uint8_t> &fullTranscript() const { return full_tr; }
     double polyVerifyTime() const { return poly_timer.elapse_sec(); }
     double polyProveTime() const { return poly_prove_timer.elapse_sec(); }
+    // Fiat-Shamir mode (the reference's GKRProof.hpp / transcriptCache.hpp are dead code, so this is a separate
+    // mode, not part of the bit-exact parity): every challenge is SHA3-256-derived from the circuit hash and ALL prover messages
+    // sent before it, so the transcript is a non-interactive proof.  Differences from the interactive schedule: the challenges of
+    // a sumcheck are drawn one per round (after that round's polynomial), not all up front.
+    //   proveFS()   runs the prover (interactive entry points, one vp_round per derived challenge); transcript() is the proof;
+    //   checkFS()   needs no prover and no tape: re-derives every challenge from the proof and runs the same checks.
+    bool proveFS();
+    bool checkFS(const std::vector<uint8_t> &proof);
     std::vector<F> drawTape();                                  // the verifier's draws, in its own order
     bool check(const std::vector<F> &tape, const std::vector<uint8_t> &transcript);   // replay
 
@@ -59,6 +67,10 @@ private:
     prover *p;
     const layeredCircuit &C;
     bool replay = false;
+    bool fs = false;                                   // challenges derived from the transcript
+    vph::hhash_digest fs_state{};
+    uint64_t fs_ctr = 0;
+    void fsInit();
     const std::vector<F> *rtape = nullptr;
     const std::vector<uint8_t> *rtr = nullptr;
     size_t tape_pos = 0, tr_pos = 0;

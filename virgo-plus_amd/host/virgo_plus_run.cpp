@@ -1,5 +1,6 @@
 // Command-line driver with the reference's interface (src/main.cpp:145-159):
-//     virgo_plus_run <file.pws> [--blocks B] [--batched] [--device D] [--dump transcript.bin]
+//     virgo_plus_run <file.pws> [--blocks B] [--batched | --fs] [--device D] [--dump transcript.bin]
+//     --fs: non-interactive GKR proof (Fiat-Shamir over SHA3-256), then verified from the proof bytes alone
 // Loads the circuit, runs the GKR proof on the GPU against the host verifier and prints the
 // reference's result lines (interactive mode runs the whole protocol incl. the Virgo commitment and its verification).
 #include <cstdio>
@@ -11,13 +12,14 @@
 #include "verifier.hpp"
 
 int main(int argc, char **argv) {
-    if (argc < 2) { fprintf(stderr, "usage: %s <file.pws> [--blocks B] [--batched] [--device D] [--dump out.bin]\n", argv[0]); return 2; }
-    int blocks = 1, device = 0; bool batched = false; const char *dump = nullptr;
+    if (argc < 2) { fprintf(stderr, "usage: %s <file.pws> [--blocks B] [--batched | --fs] [--device D] [--dump out.bin]\n", argv[0]); return 2; }
+    int blocks = 1, device = 0; bool batched = false, fsmode = false; const char *dump = nullptr;
     for (int i = 2; i < argc; ++i) {
         std::string a = argv[i];
         if (a == "--blocks" && i + 1 < argc) blocks = atoi(argv[++i]);
         else if (a == "--device" && i + 1 < argc) device = atoi(argv[++i]);
         else if (a == "--batched") batched = true;
+        else if (a == "--fs") fsmode = true;
         else if (a == "--dump" && i + 1 < argc) dump = argv[++i];
         else { fprintf(stderr, "bad argument %s\n", argv[i]); return 2; }
     }
@@ -32,7 +34,15 @@ int main(int argc, char **argv) {
         bool ok;
         std::vector<uint8_t> tr;
         double vt = 0, pc_pt = -1;
-        if (batched) {
+        if (fsmode) {
+            verifier v(&p, c);
+            ok = v.proveFS();
+            tr = v.transcript();
+            verifier w(nullptr, c);                  // a verifier that has only the proof
+            ok = ok && w.checkFS(tr);
+            vt = w.verifyTime();
+            batched = true;                          // report the proof's own size
+        } else if (batched) {
             verifier v(nullptr, c);
             std::vector<F> tape = v.drawTape();
             p.proveGKR(tape, tr);

@@ -125,6 +125,31 @@ int vph_prove_interactive(vph_session *s, uint8_t *transcript, uint64_t capacity
     }
 }
 
+int vph_prove_fs(vph_session *s, uint8_t *proof, uint64_t capacity, uint64_t *n_written, vph_result *res, char *err, int errlen) {
+    try {
+        verifier v(s->p.get(), s->circ->c);
+        const double t0 = s->p->proveTime();
+        const bool ok = v.proveFS();
+        const auto &tr = v.transcript();
+        if (tr.size() > capacity) { set_err(err, errlen, "proof buffer too small"); return -1; }
+        memcpy(proof, tr.data(), tr.size());
+        if (n_written) *n_written = tr.size();
+        fill(res, *s->p, s->p->proveTime() - t0, v.verifyTime(), ok);
+        return ok ? 0 : 1;
+    } catch (const std::exception &e) {
+        set_err(err, errlen, e.what());
+        return -2;
+    }
+}
+
+int vph_verify_fs(vph_circuit *c, const uint8_t *proof, uint64_t n) {
+    try {
+        verifier v(nullptr, c->c);
+        std::vector<uint8_t> tr(proof, proof + n);
+        return v.checkFS(tr) ? 0 : 1;
+    } catch (const std::exception &) { return 1; }
+}
+
 int vph_draw_tape(vph_session *s) {
     F::init();
     verifier v(nullptr, s->circ->c);

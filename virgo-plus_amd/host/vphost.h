@@ -85,6 +85,13 @@ int vph_prove_full(vph_session *, uint8_t *transcript, uint64_t capacity, uint64
 /* No GPU needed: F::init(), draw the tape for `circuit`, replay the host verifier over `transcript`
  * (GKR slice).  0 = accepted, 1 = rejected.                                                            */
 int vph_verify_transcript(vph_circuit *, const uint8_t *transcript, uint64_t n, int skip_predicates);
+/* Fiat-Shamir mode: a non-interactive GKR proof.  Every verifier challenge is derived with SHA3-256 from the
+ * circuit's structural hash and all prover messages before it (one challenge per sumcheck round, after that round's
+ * polynomial); the prover runs through its interactive entry points.  The proof has the transcript layout of vph_prove_gkr.
+ * Not comparable with the reference's transcripts (its verifier draws random()).  0 = the built-in verifier accepted.  */
+int vph_prove_fs(vph_session *, uint8_t *proof, uint64_t capacity, uint64_t *n_written, vph_result *res, char *err, int errlen);
+/* No GPU, no tape: re-derive the challenges from `proof` and run the verifier's checks.  0 = accepted, 1 = rejected.   */
+int vph_verify_fs(vph_circuit *, const uint8_t *proof, uint64_t n);
 /* vp_commit_stats: device milliseconds of the last commit_private / commit_public / FRI call on this session. */
 double vph_commit_device_ms(vph_session *);
 /* One proof over `world` GPUs (vp_set_shard): vph_prove_gkr on this session then proves only the sumchecks dealt to `rank`
