@@ -658,9 +658,9 @@ def test_cli_fiat_shamir_mode(vp, pws_path, tmp_path):
     """virgo_plus_run --fs: non-interactive proof, verified from the dumped bytes alone by a second verifier object and by the library."""
     import subprocess
     dump = tmp_path / "proof.bin"
-    out = subprocess.run([vp.CLI, pws_path, "--fs", "--dump", str(dump)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    out = subprocess.run([vp.CLI, pws_path, "--fs", "--seed", "1", "--dump", str(dump)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     assert "Verification pass" in out.stderr and "proof size" in out.stdout
-    c = vp.Circuit.from_pws(pws_path, 1)          # the CLI's witness: default glibc seed, as the reference draws it
+    c = vp.Circuit.from_pws(pws_path, 1, seed=1)  # the same witness as the CLI drew
     assert c.verify_fs(dump.read_bytes())
     c.close()

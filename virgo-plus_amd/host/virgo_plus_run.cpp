@@ -1,9 +1,10 @@
 // Command-line driver with the reference's interface (src/main.cpp:145-159):
-//     virgo_plus_run <file.pws> [--blocks B] [--batched | --fs] [--device D] [--dump transcript.bin]
+//     virgo_plus_run <file.pws> [--blocks B] [--batched | --fs] [--seed S] [--device D] [--dump transcript.bin]
 //     --fs: non-interactive GKR proof (Fiat-Shamir over SHA3-256), then verified from the proof bytes alone
 // Loads the circuit, runs the GKR proof on the GPU against the host verifier and prints the
 // reference's result lines (interactive mode runs the whole protocol incl. the Virgo commitment and its verification).
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -20,6 +21,7 @@ int main(int argc, char **argv) {
         else if (a == "--device" && i + 1 < argc) device = atoi(argv[++i]);
         else if (a == "--batched") batched = true;
         else if (a == "--fs") fsmode = true;
+        else if (a == "--seed" && i + 1 < argc) srandom((unsigned) atol(argv[++i]));      // witness draw (default: glibc's initial state, as the reference)
         else if (a == "--dump" && i + 1 < argc) dump = argv[++i];
         else { fprintf(stderr, "bad argument %s\n", argv[i]); return 2; }
     }
