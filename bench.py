@@ -329,6 +329,7 @@ def main():
                 "prover_sec_device": 1e-3 * dev_ms / a.steps,
                 "rounds": res["rounds"], "kernel_launches_per_proof": res["launches"],
                 "bit_exact_vs_reference_golden": bit_exact, "host_verifier_accepts": ok,
+                "golden_origin": (golden[gname].get("origin", "the real reference binary (oracle/_ref/ref_run)") if gname in golden else None),
                 "interactive_path": interactive, "circuit_upload_sec": upload_sec, "verifier": verify,
             }
             if res["fold_launches"]:

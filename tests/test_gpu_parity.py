@@ -464,6 +464,24 @@ def test_sha256_x128_vs_oracle(vp, ob, pws_path):
     s.close(); c.close(); oc.close()
 
 
+def test_sha256_x1024_full_size_vs_oracle_fixture(vp, golden, gold_gkr, pws_path):
+    """BASELINE.json configs[2] / [3] size: 1024 blocks, 102 M gates, tables up to 2^26, 859 rounds.  The expected transcript is
+    the ORACLE's (tools/check_full_size.py ran its CPU proof on the GPU box's host: 36 s, 22 GB — too slow for this suite), the
+    oracle being pinned to the real reference at x1/x16/x64.  Batched proof, and the same proof sharded over 8 ranks."""
+    g = golden["sha256_x1024"]
+    c = vp.Circuit.from_pws(pws_path, 1024, seed=1)
+    assert c.gates == 102347776 and c.hash() == g["circuit_hash"]
+    s = vp.Session(c)
+    s.draw_tape()
+    tr, res = s.prove_gkr()
+    assert tr == gold_gkr("sha256_x1024")
+    assert res["rounds"] == g["rounds"] == 859
+    assert vp.sum_transcripts(_sharded_parts(vp, s, 8)) == tr
+    ok, _ = s.check(tr, device_predicates=True)
+    assert ok
+    s.close(); c.close()
+
+
 def test_sha256_x256_size_independent_properties(vp, pws_path):
     """256 blocks (25.6 M gates): no oracle run at this size; the host verifier (sumcheck identities, Liu identity,
     final input-layer check) must accept the device transcript, the proof must be reproducible, and a different
