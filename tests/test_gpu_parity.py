@@ -2,9 +2,12 @@
 oracle on the same seeded inputs and against the golden transcripts of the real reference.
 Bar: bit-exact (all arithmetic is integer mod 2^61-1)."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
+
+from conftest import GOLDEN as GOLDEN_DIR
 
 pytestmark = pytest.mark.gpu
 P = (1 << 61) - 1
@@ -479,6 +482,14 @@ def test_sha256_x1024_full_size_vs_oracle_fixture(vp, golden, gold_gkr, pws_path
     assert vp.sum_transcripts(_sharded_parts(vp, s, 8)) == tr
     ok, _ = s.check(tr, device_predicates=True)
     assert ok
+    # the commitment at the same size (input layer 2^23: 65 slices of 2^22 code symbols, transforms of 2^17, 2^21 leaves): the
+    # oracle's outputs (tools/check_full_size_pc.py: 273 s of CPU, 22 GB) = merkle_root_l | merkle_root_h | input_0 | all_sum[65]
+    exp = open(os.path.join(GOLDEN_DIR, "oracle_sha256_x1024_pc.bin"), "rb").read()
+    root, _ = s.commit_private()
+    assert root == exp[:32]
+    pub = np.random.default_rng(8).integers(0, P, size=(1 << c.layer_bitlen(0), 2), dtype=np.uint64)
+    root_h, inner, all_sum, _ = s.commit_public(pub)
+    assert root_h == exp[32:64] and inner == exp[64:80] and all_sum == exp[80:]
     s.close(); c.close()
 
 

@@ -270,13 +270,17 @@ class Session:
         return out
 
     def _call(self, fn):
-        n = ctypes.c_uint64(0)
-        res = VphResult()
-        err = ctypes.create_string_buffer(512)
-        rc = fn(self.h, ctypes.cast(self._buf, ctypes.c_void_p), self._cap, ctypes.byref(n), ctypes.byref(res), err, len(err))
+        # per-session scratch objects: the batched proof is sub-millisecond, so ctypes allocations per call would show up
+        if not hasattr(self, "_n"):
+            self._n = ctypes.c_uint64(0)
+            self._res = VphResult()
+            self._err = ctypes.create_string_buffer(512)
+            self._bufp = ctypes.cast(self._buf, ctypes.c_void_p)
+        n, res, err = self._n, self._res, self._err
+        rc = fn(self.h, self._bufp, self._cap, ctypes.byref(n), ctypes.byref(res), err, 512)
         if rc < 0:
             raise RuntimeError("prover failed: " + err.value.decode())
-        return self._buf.raw[: n.value], res.as_dict(), rc
+        return ctypes.string_at(self._buf, n.value), res.as_dict(), rc
 
     def prove_interactive(self):
         """F::init() + verifier::verify(): returns (transcript bytes, stats, verified)."""
