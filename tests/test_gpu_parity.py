@@ -490,6 +490,15 @@ def test_sha256_x1024_full_size_vs_oracle_fixture(vp, golden, gold_gkr, pws_path
     pub = np.random.default_rng(8).integers(0, P, size=(1 << c.layer_bitlen(0), 2), dtype=np.uint64)
     root_h, inner, all_sum, _ = s.commit_public(pub)
     assert root_h == exp[32:64] and inner == exp[64:80] and all_sum == exp[80:]
+    # ... and the FRI commit phase (the low-degree test's prover side): 17 fold steps, every Merkle root and the final codeword
+    # (tools/check_full_size_fri.py, fold challenges from default_rng(9))
+    fexp = open(os.path.join(GOLDEN_DIR, "oracle_sha256_x1024_fri.bin"), "rb").read()
+    st = c.layer_bitlen(0) - 6
+    assert st == 17
+    r = np.random.default_rng(9).integers(0, P, size=(st, 2), dtype=np.uint64)
+    roots, fin = s.fri_commit(r)
+    assert roots == fexp[:32 * st], "FRI roots differ from the oracle's"
+    assert fin.tobytes() == fexp[32 * st:], "final FRI codeword differs"
     s.close(); c.close()
 
 
