@@ -170,12 +170,18 @@ def test_chain_sharded_proof_randomize_and_fused_init(vp, golden, gold_gkr, monk
     s.close(); c.close()
 
 
-def test_set_shard_rejects_bad_arguments(vp):
+def test_set_shard_rejects_bad_arguments_and_survives_idle_ranks(vp, ob):
     c = vp.Circuit.randomize(4, 8, seed=7)
     s = vp.Session(c)
     for rank, world in ((-1, 2), (2, 2), (0, 0)):
         with pytest.raises(RuntimeError):
             s.set_shard(rank, world)
+    # more ranks than chains (3 * 3 + 1 = 10): the surplus ranks prove nothing and contribute zeros
+    s.draw_tape()
+    gold, _ = ob.Circuit.randomize(4, 8, seed=7).prove_gkr()
+    parts = _sharded_parts(vp, s, 16)
+    assert sum(1 for p in parts if any(p)) <= 10
+    assert vp.sum_transcripts(parts) == gold
     s.close(); c.close()
 
 
