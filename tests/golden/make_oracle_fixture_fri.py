@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
-"""One-off, companion of check_full_size_pc.py: the ORACLE's FRI commit phase at x1024 (17 fold steps over 65 codewords of 2^22
+"""TEST INFRASTRUCTURE (fixture generator, like make_golden.py): runs the oracle; nothing in the product imports this.
+One-off, companion of make_oracle_fixture_pc.py: the ORACLE's FRI commit phase at x1024 (17 fold steps over 65 codewords of 2^22
 symbols) for the same witness (seed 1) and public vector (default_rng(8)), fold challenges from default_rng(9).  Output:
 17 Merkle roots (32 bytes each) then the final codeword (2048 field elements) -> tests/golden/oracle_sha256_x1024_fri.bin.
 
-    python tools/check_full_size_fri.py BLOCKS OUT.bin
+    python tests/golden/make_oracle_fixture_fri.py BLOCKS OUT.bin
 """
 import ctypes, gzip, os, resource, sys, tempfile, threading, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 P = (1 << 61) - 1
 

@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
-"""One-off parity check at BASELINE.json's full size (configs[2]: SHA-256 x1024, 102 M gates), too slow for the test suite:
+"""TEST INFRASTRUCTURE (fixture generator, like make_golden.py): runs the oracle; nothing in the product imports this.
+One-off parity check at BASELINE.json's full size (configs[2]: SHA-256 x1024, 102 M gates), too slow for the test suite:
 the oracle's CPU proof (a few minutes, tens of GB) against the GPU's batched and sharded proofs.
 
-    python tools/check_full_size.py oracle BLOCKS OUT.bin     # CPU only (run under `ulimit -v` to bound memory)
-    python tools/check_full_size.py gpu BLOCKS OUT.bin        # compares the GPU transcript with OUT.bin
+    python tests/golden/make_oracle_fixture_gkr.py oracle BLOCKS OUT.bin     # CPU only (run under `ulimit -v` to bound memory)
+    python tests/golden/make_oracle_fixture_gkr.py gpu BLOCKS OUT.bin        # compares the GPU transcript with OUT.bin
 BLOCKS may be "rLxE" for layeredCircuit::randomize(L, E) (configs[4]: r16x20 = 2^24 gates) instead of a SHA-256 block count.
 """
 import gzip, json, os, resource, sys, tempfile, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 

@@ -1,14 +1,15 @@
 #!/usr/bin/env python3
-"""One-off: the ORACLE's commitment outputs at BASELINE.json's full size (configs[2]: SHA-256 x1024, input layer 2^23, 65 slices of
+"""TEST INFRASTRUCTURE (fixture generator, like make_golden.py): runs the oracle; nothing in the product imports this.
+One-off: the ORACLE's commitment outputs at BASELINE.json's full size (configs[2]: SHA-256 x1024, input layer 2^23, 65 slices of
 2^22 code symbols) — merkle_root_l | merkle_root_h | input_0 | all_sum[65] for the witness of seed 1 and the public vector of
 numpy default_rng(8).  Minutes of single-core CPU and tens of GB; the result (1 120 bytes) is committed as
 tests/golden/oracle_sha256_x1024_pc.bin and compared with the GPU's in tests/test_gpu_parity.py.
 
-    python tools/check_full_size_pc.py BLOCKS OUT.bin
+    python tests/golden/make_oracle_fixture_pc.py BLOCKS OUT.bin
 """
 import ctypes, gzip, os, resource, sys, tempfile, threading, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 P = (1 << 61) - 1
 

@@ -475,7 +475,7 @@ def test_sha256_x128_vs_oracle(vp, ob, pws_path):
 
 def test_sha256_x1024_full_size_vs_oracle_fixture(vp, golden, gold_gkr, pws_path):
     """BASELINE.json configs[2] / [3] size: 1024 blocks, 102 M gates, tables up to 2^26, 859 rounds.  The expected transcript is
-    the ORACLE's (tools/check_full_size.py ran its CPU proof on the GPU box's host: 36 s, 22 GB — too slow for this suite), the
+    the ORACLE's (tests/golden/make_oracle_fixture_gkr.py ran its CPU proof on the GPU box's host: 36 s, 22 GB — too slow for this suite), the
     oracle being pinned to the real reference at x1/x16/x64.  Batched proof, and the same proof sharded over 8 ranks."""
     g = golden["sha256_x1024"]
     c = vp.Circuit.from_pws(pws_path, 1024, seed=1)
@@ -489,7 +489,7 @@ def test_sha256_x1024_full_size_vs_oracle_fixture(vp, golden, gold_gkr, pws_path
     ok, _ = s.check(tr, device_predicates=True)
     assert ok
     # the commitment at the same size (input layer 2^23: 65 slices of 2^22 code symbols, transforms of 2^17, 2^21 leaves): the
-    # oracle's outputs (tools/check_full_size_pc.py: 273 s of CPU, 22 GB) = merkle_root_l | merkle_root_h | input_0 | all_sum[65]
+    # oracle's outputs (tests/golden/make_oracle_fixture_pc.py: 273 s of CPU, 22 GB) = merkle_root_l | merkle_root_h | input_0 | all_sum[65]
     exp = open(os.path.join(GOLDEN_DIR, "oracle_sha256_x1024_pc.bin"), "rb").read()
     root, _ = s.commit_private()
     assert root == exp[:32]
@@ -497,7 +497,7 @@ def test_sha256_x1024_full_size_vs_oracle_fixture(vp, golden, gold_gkr, pws_path
     root_h, inner, all_sum, _ = s.commit_public(pub)
     assert root_h == exp[32:64] and inner == exp[64:80] and all_sum == exp[80:]
     # ... and the FRI commit phase (the low-degree test's prover side): 17 fold steps, every Merkle root and the final codeword
-    # (tools/check_full_size_fri.py, fold challenges from default_rng(9))
+    # (tests/golden/make_oracle_fixture_fri.py, fold challenges from default_rng(9))
     fexp = open(os.path.join(GOLDEN_DIR, "oracle_sha256_x1024_fri.bin"), "rb").read()
     st = c.layer_bitlen(0) - 6
     assert st == 17
@@ -529,7 +529,7 @@ def test_sha256_x256_size_independent_properties(vp, pws_path):
 def test_randomize_16_20_synthetic_config(vp, golden, gold_gkr):
     """BASELINE.json configs[4] / SURVEY §8d config 5: layeredCircuit::randomize(16, 20) = 16 layers of 2^20 random Mul/Add
     gates (2^24 gates).  The interactive and the batched device proofs must equal the oracle's transcript (committed fixture,
-    made by tools/check_full_size.py: 9.4 s of CPU), the 8-way chain-sharded proof must assemble to it, and the host verifier
+    made by tests/golden/make_oracle_fixture_gkr.py: 9.4 s of CPU), the 8-way chain-sharded proof must assemble to it, and the host verifier
     (all sumcheck / Liu identities + the input-layer check) must accept."""
     c = vp.Circuit.randomize(16, 20, seed=1)
     assert c.hash() == golden["randomize_16_20"]["circuit_hash"]
