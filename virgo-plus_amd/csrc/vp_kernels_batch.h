@@ -78,6 +78,40 @@ __device__ __forceinline__ void contrib2(const InitArgs2 &a, u32 e, F &m, F &ad,
     }
 }
 
+// The same phase-1 contribution in three stages, so that a caller can issue the loads of several rows level by level (entry
+// -> operands -> arithmetic) instead of walking one row's dependent chain to its end before the next row's first load.
+struct P1Entry { u32 g, x, tl; };
+struct P1Vals { F bf, bs, y; };
+__device__ __forceinline__ P1Entry p1_load(const InitArgs2 &a, u32 e) { P1Entry c; c.g = a.e_g[e]; c.x = a.e_x[e]; c.tl = a.e_tl[e]; return c; }
+__device__ __forceinline__ P1Vals p1_gather(const InitArgs2 &a, const P1Entry &c) {
+    P1Vals v;
+    v.bf = a.hg.bf[c.g & ((1u << a.hg.h1) - 1)]; v.bs = a.hg.bs[c.g >> a.hg.h1];
+    const int l = c.tl & 0xff;
+    v.y = l != 0xff ? a.vals[l][c.x] : f_zero();
+    return v;
+}
+__device__ __forceinline__ void p1_apply(const InitArgs2 &a, const P1Entry &c, const P1Vals &v, F &m, F &ad) {       // == contrib2<1>
+    const int ty = (c.tl >> 8) & 0x7f;
+    F t = f_mul(v.bf, v.bs);
+    if (c.tl & 0x8000) t = f_mul(t, *a.assert_r);
+    F ty_ = f_zero();
+    if ((c.tl & 0xff) != 0xff) ty_ = f_mul(v.y, t);
+    switch (ty) {
+        case T_ADD: ad = f_add(ad, ty_); m = f_add(m, t); break;
+        case T_SUB: ad = f_sub(ad, ty_); m = f_add(m, t); break;
+        case T_ANTISUB: ad = f_add(ad, ty_); m = f_sub(m, t); break;
+        case T_MUL: m = f_add(m, ty_); break;
+        case T_NAAB: ad = f_add(ad, ty_); m = f_sub(m, ty_); break;
+        case T_ANTINAAB: m = f_add(m, f_sub(t, ty_)); break;
+        case T_ADDC: ad = f_add(ad, f_mul(a.gc[c.g], t)); m = f_add(m, t); break;
+        case T_MULC: m = f_add(m, f_mul(a.gc[c.g], t)); break;
+        case T_COPY: m = f_add(m, t); break;
+        case T_NOT: ad = f_add(ad, t); m = f_sub(m, t); break;
+        case T_XOR: ad = f_add(ad, ty_); m = f_add(m, f_sub(t, f_dbl(ty_))); break;
+        default: break;
+    }
+}
+
 template <int PHASE>
 __device__ __forceinline__ void init2_light_body(const InitArgs2 &a, u32 bid) {
     u32 row = bid * blockDim.x + threadIdx.x;
@@ -325,6 +359,36 @@ struct GenP1 {
         if (e - b > VP_LIGHT_MAX) { m = a->M[row]; ad = a->A[row]; return; }
         for (u32 k = b; k < e; ++k) contrib2<1>(*a, k, m, ad, f_zero());
     }
+    // rows r0 and r0 + 1 together: row pointers, then the first contribution of both rows, then their operands, then the
+    // arithmetic — two dependent chains in flight per lane instead of one (the fused launch runs at 3 waves per SIMD and is
+    // bound by exactly this gather latency)
+    // row pointers of rows r0, r0 + 1 (b0 | e0 = b1 | e1); rows past the end read as empty.
+    __device__ __forceinline__ void ptrs(u32 r0, u32 valid, u32 &b0, u32 &e0, u32 &e1) const {
+        const u32 lim = min(valid, a->n_rows);
+        b0 = e0 = e1 = 0;
+        if (r0 >= lim) return;
+        b0 = a->rowptr[r0]; e0 = a->rowptr[r0 + 1];
+        e1 = r0 + 1 < lim ? a->rowptr[r0 + 2] : e0;
+    }
+    __device__ __forceinline__ void row2(u32 r0, u32 valid, u32 b0, u32 e0, u32 e1, F &m0, F &a0, F &m1, F &a1) const {
+        m0 = f_zero(); a0 = f_zero(); m1 = f_zero(); a1 = f_zero();
+        const u32 lim = min(valid, a->n_rows);
+        if (r0 >= lim) return;
+        const bool heavy0 = e0 - b0 > VP_LIGHT_MAX, heavy1 = e1 - e0 > VP_LIGHT_MAX;
+        const bool f0 = !heavy0 && e0 > b0, f1 = !heavy1 && e1 > e0;
+        P1Entry c0{}, c1{};
+        if (f0) c0 = p1_load(*a, b0);
+        if (f1) c1 = p1_load(*a, e0);
+        P1Vals v0{}, v1{};
+        if (f0) v0 = p1_gather(*a, c0);
+        if (f1) v1 = p1_gather(*a, c1);
+        if (heavy0) { m0 = a->M[r0]; a0 = a->A[r0]; }
+        if (heavy1) { m1 = a->M[r0 + 1]; a1 = a->A[r0 + 1]; }
+        if (f0) p1_apply(*a, c0, v0, m0, a0);
+        if (f1) p1_apply(*a, c1, v1, m1, a1);
+        if (!heavy0) for (u32 k = b0 + 1; k < e0; ++k) contrib2<1>(*a, k, m0, a0, f_zero());
+        if (!heavy1) for (u32 k = e0 + 1; k < e1; ++k) contrib2<1>(*a, k, m1, a1, f_zero());
+    }
 };
 struct GenLiu {
     static constexpr int MODE = 2;
@@ -334,6 +398,38 @@ struct GenLiu {
         if (u >= valid) return;
         m = half_at(H[0], u);
         for (u32 k = rowptr[u]; k < rowptr[u + 1]; ++k) m = f_add(m, half_at(H[e_q[k]], e_g[k]));
+    }
+    __device__ __forceinline__ void ptrs(u32 u0, u32 valid, u32 &b0, u32 &e0, u32 &e1) const {
+        b0 = e0 = e1 = 0;
+        if (u0 >= valid) return;
+        b0 = rowptr[u0]; e0 = rowptr[u0 + 1];
+        e1 = u0 + 1 < valid ? rowptr[u0 + 2] : e0;
+    }
+    __device__ __forceinline__ void row2(u32 u0, u32 valid, u32 b0, u32 e0, u32 e1, F &m0, F &a0, F &m1, F &a1) const {     // see GenP1::row2
+        m0 = f_zero(); a0 = f_zero(); m1 = f_zero(); a1 = f_zero();
+        if (u0 >= valid) return;
+        const bool ok1 = u0 + 1 < valid;
+        const Half h0 = H[0];
+        // base terms eq(r_u, u): independent of the lists
+        const F bf0 = h0.bf[u0 & ((1u << h0.h1) - 1)], bs0 = h0.bs[u0 >> h0.h1];
+        F bf1 = f_zero(), bs1 = f_zero();
+        if (ok1) { bf1 = h0.bf[(u0 + 1) & ((1u << h0.h1) - 1)]; bs1 = h0.bs[(u0 + 1) >> h0.h1]; }
+        const bool f0 = e0 > b0, f1 = e1 > e0;
+        u32 q0 = 0, g0 = 0, q1 = 0, g1 = 0;
+        if (f0) { q0 = e_q[b0]; g0 = e_g[b0]; }
+        if (f1) { q1 = e_q[e0]; g1 = e_g[e0]; }
+        Half hq0 = h0, hq1 = h0;
+        if (f0) hq0 = H[q0];
+        if (f1) hq1 = H[q1];
+        F xf0 = f_zero(), xs0 = f_zero(), xf1 = f_zero(), xs1 = f_zero();
+        if (f0) { xf0 = hq0.bf[g0 & ((1u << hq0.h1) - 1)]; xs0 = hq0.bs[g0 >> hq0.h1]; }
+        if (f1) { xf1 = hq1.bf[g1 & ((1u << hq1.h1) - 1)]; xs1 = hq1.bs[g1 >> hq1.h1]; }
+        m0 = f_mul(bf0, bs0);
+        if (ok1) m1 = f_mul(bf1, bs1);
+        if (f0) m0 = f_add(m0, f_mul(xf0, xs0));
+        if (f1) m1 = f_add(m1, f_mul(xf1, xs1));
+        for (u32 k = b0 + 1; k < e0; ++k) m0 = f_add(m0, half_at(H[e_q[k]], e_g[k]));
+        for (u32 k = e0 + 1; k < e1; ++k) m1 = f_add(m1, half_at(H[e_q[k]], e_g[k]));
     }
 };
 
@@ -369,8 +465,14 @@ __device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb,
                 m0 = ld_or_zero(a.inM, i0, vend); m1 = ld_or_zero(a.inM, i0 + 1, vend);
                 if (HAS_A) { a0 = ld_or_zero(a.inA, i0, vend); a1 = ld_or_zero(a.inA, i0 + 1, vend); }
             } else {                      // generated tables: one table per job, offset 0
+#ifdef VP_GEN_ROW1
                 gen.row(i0, vend, m0, a0);
                 gen.row(i0 + 1, vend, m1, a1);
+#else
+                u32 cb0, ce0, ce1;                       // (requesting them one chunk ahead was measured: no gain)
+                gen.ptrs(i0, vend, cb0, ce0, ce1);
+                gen.row2(i0, vend, cb0, ce0, ce1, m0, a0, m1, a1);
+#endif
                 if constexpr (Gen::MODE == 1) {
                     if (gen.dot_part) {
                         if (i0 < vend) dacc = f_add(dacc, f_mul(half_at(gen.dot_h, i0), v0));
