@@ -336,15 +336,15 @@ def main():
                 avg_ms = res["fold_ms"] / res["fold_launches"]
                 gbps = res["fold_bytes"] / (res["fold_ms"] * 1e-3) / 1e9
                 traffic = None
+                pmc_file = PMC_SUMMARY if a.blocks == 64 else PMC_SUMMARY.replace("_b64", "_b%d" % a.blocks)
                 try:        # PMC pass of the same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs), committed summary
-                    pm = json.load(open(os.path.join(ROOT, "profiles", PMC_SUMMARY)))
-                    if a.blocks == 64 and not a.randomize:
-                        traffic = pm["sumfold_avg_hbm_bytes_per_launch"]
+                    if not a.randomize:
+                        traffic = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))["sumfold_avg_hbm_bytes_per_launch"]
                 except Exception:
                     pass
                 line["roofline"] = {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                     "frac": gbps / HBM_PEAK_GBPS, "traffic": traffic,
-                                    "traffic_source": "profiles/%s (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)" % PMC_SUMMARY if traffic else None,
+                                    "traffic_source": "profiles/%s (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)" % pmc_file if traffic else None,
                                     "kernel": "k_sumfold3b_multi (every launch; single-stream replay of the same proof)",
                                     "single_stream_proof_ms": res.get("serial_device_ms"),
                                     "launches": res["fold_launches"], "avg_launch_us": 1e3 * avg_ms,

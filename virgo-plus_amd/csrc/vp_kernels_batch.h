@@ -438,7 +438,10 @@ struct GenLiu {
 // pair-step, 528 of them in the six multiply-adds); 175 us with the multiply-adds replaced by three cheap ops (memory + LDS +
 // barriers: 4.9 TB/s).  Built, measured and rejected because they did not beat it: rotating the wave roles per chunk so that
 // every wave issues 7 steps per four chunks (+-5 %, +3 spilled VGPRs); requesting the next chunk's six entries right after
-// round k (needs 140 VGPRs: 342 us at 3 waves/SIMD, 385 us spilling at 4); 3 instead of 4 workgroups per CU (same).
+// round k (needs 140 VGPRs: 342 us at 3 waves/SIMD, 385 us spilling at 4); 3 instead of 4 workgroups per CU (same); a
+// role-split variant in the manner of k_seg (768-thread workgroup, chunk staged in LDS, two multiply-adds per lane and pair, 64
+// VGPRs, 6 waves per SIMD; kept in tools/micro_sumfold.hip): identical outputs, 360 us against 280 us — occupancy is not what
+// holds this kernel at ~5.9 cycles per wave-instruction.
 template <bool HAS_A, class Gen>
 __device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb, Sf3bLds &sm, const Gen &gen) {
     F (&s1)[3][256] = sm.s1; F (&s2)[3][128] = sm.s2; F (&red)[4][9] = sm.red;
