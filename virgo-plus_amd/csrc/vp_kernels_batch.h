@@ -341,7 +341,16 @@ __device__ __forceinline__ void sf_pair_step(const F &v0, const F &v1, const F &
     if (HAS_A) ao = f_mad_c(r, f_sub_lazy(a1, a0), a0);
 }
 
-struct Sf3bLds { F s1[3][256]; F s2[3][128]; F red[4][9]; Lz acc2[3][128]; Lz acc3[3][64]; F dred[4]; };   // acc2/acc3: per-thread sums of rounds k+1, k+2
+#ifndef VP_SF_LDSPF
+#define VP_SF_LDSPF 0          // 1: the streaming variant stages the NEXT chunk in LDS with global_load_lds_dwordx4 (no VGPRs) while it computes.
+                               // Built and measured (tools/micro_sumfold.hip -DVP_SF_LDSPF=1): outputs identical, 318 us against 280 us at 2^24
+                               // entries, 218 vs 212 us on 3 x 2^22 — the 24 KB of staging cost a workgroup per CU and the overlap buys nothing.
+#endif
+struct Sf3bLds { F s1[3][256]; F s2[3][128]; F red[4][9]; Lz acc2[3][128]; Lz acc3[3][64]; F dred[4];   // acc2/acc3: per-thread sums of rounds k+1, k+2
+#if VP_SF_LDSPF
+                 F pre[3][512];                       // staged chunk: wave w owns entries [128 w, 128 w + 128) of each table
+#endif
+};
 
 // Where round k takes its mult / add entries from.  GenLoad: the tables in HBM.  GenP1 / GenLiu: computed on the spot from
 // the target-sorted contribution lists (the phase-1 init / the Liu gather), so that these tables are never written at full
@@ -455,6 +464,9 @@ __device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb,
     if (t < 64) { for (int i = 0; i < 3; ++i) { sm.acc3[i][t].re = 0; sm.acc3[i][t].im = 0; } }
     const F r0 = a.r[0], r1 = a.r[1], r2 = a.r[2];
     F dacc = f_zero();                                   // GenP1: this thread's share of the V_u inner product
+#if VP_SF_LDSPF
+    bool staged = false;                                 // the chunk of this iteration sits in sm.pre (uniform)
+#endif
     for (u32 c = bid; c < a.total_chunks; c += nb) {
         int j = 0;
         while (j + 1 < a.n_tab && c >= a.t[j + 1].chunk_start) ++j;
@@ -462,11 +474,49 @@ __device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb,
         const u32 cl = c - td.chunk_start;
         const u32 i0 = td.off + cl * 512 + 2 * t, vend = td.off + td.valid;
         {   // round k: one pair per thread
-            const F v0 = ld_or_zero(a.inV, i0, vend), v1 = ld_or_zero(a.inV, i0 + 1, vend);
-            F m0, m1, a0 = f_zero(), a1 = f_zero();
+            F v0, v1, m0, m1, a0 = f_zero(), a1 = f_zero();
+#if VP_SF_LDSPF
             if constexpr (Gen::MODE == 0) {
+                // LDS-direct prefetch (gfx950 global_load_lds_dwordx4): a wave stages exactly the 128 entries per table that its own
+                // lanes read (entries 2t, 2t+1), 64 lanes x 16 B per instruction, so the only synchronisation is its own vmcnt.
+                // Chunks that are not completely valid (the tail of a table) take the register path with its bounds checks.
+                const bool full = cl * 512 + 512 <= td.valid;                    // uniform
+                if (full && staged) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the staged chunk is in LDS (and the compiler may not move the reads up)
+                    v0 = sm.pre[0][2 * t]; v1 = sm.pre[0][2 * t + 1]; m0 = sm.pre[1][2 * t]; m1 = sm.pre[1][2 * t + 1];
+                    if (HAS_A) { a0 = sm.pre[2][2 * t]; a1 = sm.pre[2][2 * t + 1]; }
+                } else {
+                    v0 = ld_or_zero(a.inV, i0, vend); v1 = ld_or_zero(a.inV, i0 + 1, vend);
+                    m0 = ld_or_zero(a.inM, i0, vend); m1 = ld_or_zero(a.inM, i0 + 1, vend);
+                    if (HAS_A) { a0 = ld_or_zero(a.inA, i0, vend); a1 = ld_or_zero(a.inA, i0 + 1, vend); }
+                }
+                // stage the next chunk of this workgroup (if it is a full one) behind the reads above
+                staged = false;
+                const u32 cn = c + nb;
+                if (cn < a.total_chunks) {
+                    int jn = 0;
+                    while (jn + 1 < a.n_tab && cn >= a.t[jn + 1].chunk_start) ++jn;
+                    const u32 cln = cn - a.t[jn].chunk_start;
+                    if (cln * 512 + 512 <= a.t[jn].valid) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the LDS reads of this wave are done before its region is overwritten
+                        const u32 gb = a.t[jn].off + cln * 512 + 128 * w + lane;
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            __builtin_amdgcn_global_load_lds(a.inV + gb + 64 * h, &sm.pre[0][128 * w + 64 * h], 16, 0, 0);
+                            __builtin_amdgcn_global_load_lds(a.inM + gb + 64 * h, &sm.pre[1][128 * w + 64 * h], 16, 0, 0);
+                            if (HAS_A) __builtin_amdgcn_global_load_lds(a.inA + gb + 64 * h, &sm.pre[2][128 * w + 64 * h], 16, 0, 0);
+                        }
+                        staged = true;
+                    }
+                }
+            } else
+#endif
+            { v0 = ld_or_zero(a.inV, i0, vend); v1 = ld_or_zero(a.inV, i0 + 1, vend); }
+            if constexpr (Gen::MODE == 0) {
+#if !VP_SF_LDSPF
                 m0 = ld_or_zero(a.inM, i0, vend); m1 = ld_or_zero(a.inM, i0 + 1, vend);
                 if (HAS_A) { a0 = ld_or_zero(a.inA, i0, vend); a1 = ld_or_zero(a.inA, i0 + 1, vend); }
+#endif
             } else {                      // generated tables: one table per job, offset 0
 #ifdef VP_GEN_ROW1
                 gen.row(i0, vend, m0, a0);
