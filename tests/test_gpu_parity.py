@@ -116,7 +116,18 @@ def test_fused_init_plan_matches_reference(vp, golden, gold_gkr, pws_path, name,
     s3.draw_tape()
     tr3, _ = s3.prove_gkr()
     assert tr3 == tr
-    s.close(); s2.close(); s3.close(); c.close()
+    monkeypatch.delenv("VP_SF_ROUNDS")
+    monkeypatch.setenv("VP_DROP_Y", "0")            # every round sums m1 v1 + a1 itself instead of deriving b from the previous claim
+    s4 = vp.Session(c)
+    s4.draw_tape()
+    tr4, _ = s4.prove_gkr()
+    assert tr4 == tr
+    monkeypatch.setenv("VP_SF_ROUNDS", "4")
+    s5 = vp.Session(c)
+    s5.draw_tape()
+    tr5, _ = s5.prove_gkr()
+    assert tr5 == tr
+    s.close(); s2.close(); s3.close(); s4.close(); s5.close(); c.close()
 
 
 def _sharded_parts(vp, s, world):

@@ -128,7 +128,7 @@ int main(int argc, char **argv) {
     CK(hipMemcpy(dV, hV.data(), tot * 16, hipMemcpyHostToDevice)); CK(hipMemcpy(dM, hM.data(), tot * 16, hipMemcpyHostToDevice));
     CK(hipMemcpy(dA, hA.data(), tot * 16, hipMemcpyHostToDevice)); CK(hipMemcpy(dr, hr, 48, hipMemcpyHostToDevice));
     SfArgs a{};
-    a.inV = dV; a.inM = dM; a.inA = dA; a.r = dr; a.has_a = 1; a.n_tab = n_tab;
+    a.inV = dV; a.inM = dM; a.inA = dA; a.r = dr; a.has_a = 1; a.n_tab = n_tab; a.keep_y0 = getenv("KEEP_Y") ? atoi(getenv("KEEP_Y")) : 3;
     u32 chunks = 0;
     for (int j = 0; j < n_tab; ++j) { a.t[j].off = j * len; a.t[j].len = len; a.t[j].valid = valid; a.t[j].chunk_start = chunks; chunks += (valid + 511) / 512; }
     a.total_chunks = chunks;

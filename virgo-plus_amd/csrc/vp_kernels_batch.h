@@ -185,6 +185,8 @@ struct SfArgs {
     u32 total_chunks;
     int n_tab, has_a;
     u32 nblk;                 // batched launches: blocks given to this job
+    int keep_y0;              // k_sumfold3b / 4b, bit 0: the first round of this launch sums m1 v1 + a1 (it is round 1 of its sumcheck, whose sum cannot be
+                              // derived from a previous claim); bit 1: the later rounds do too (VP_DROP_Y=0).  Otherwise the product is left out (sf_pair_step)
     SfTab t[VP_MAX_TAB];
 };
 
@@ -328,13 +330,17 @@ __device__ __forceinline__ void lz_add(Lz &s, const F &x) { s.re += x.re; s.im +
 __device__ __forceinline__ void lz_fold(Lz &s) { s.re = (s.re & P61) + (s.re >> 61); s.im = (s.im & P61) + (s.im >> 61); }
 __device__ __forceinline__ F lz_canon(const Lz &s) { return f_make(m_fold(s.re), m_fold(s.im)); }
 
-// one pair of one table family: sums into (X, Y, Z) = (sum dm*dv, sum m1*v1 + a1, sum m0*v0 + a0), folds with r
+// one pair of one table family: sums into (X, Y, Z) = (sum dm*dv, sum m1*v1 + a1, sum m0*v0 + a0), folds with r.
+// The round polynomial is a = X, b = Y - X - Z, c = Z.  From round 2 of a sumcheck on, Y is redundant: the verifier's own check
+// S_k(0) + S_k(1) = S_{k-1}(r_{k-1}) (src/verifier.cpp:208,249,295) gives Y = S_{k-1}(r_{k-1}) - Z for the totals over all tables
+// of the phase, add_term included, and the closing kernel has both (k_emit, derive_mask).  KEEP_Y = false leaves the product
+// out: five multiply-adds per pair instead of six, the same field elements in the transcript.
 template <bool HAS_A>
 __device__ __forceinline__ void sf_pair_step(const F &v0, const F &v1, const F &m0, const F &m1, const F &a0, const F &a1,
-                                             const F &r, Lz &X, Lz &Y, Lz &Z, F &vo, F &mo, F &ao) {
+                                             const F &r, Lz &X, Lz &Y, Lz &Z, F &vo, F &mo, F &ao, bool keep_y) {
     const F dv = f_sub_lazy(v1, v0), dm = f_sub_lazy(m1, m0);
     lz_add(X, f_mad_lazy<true>(dm, dv, f_zero()));                       // sums take weakly reduced products (< 2^61 + 4)
-    lz_add(Y, f_mad_c<true>(m1, v1, HAS_A ? a1 : f_zero()));
+    if (keep_y) lz_add(Y, f_mad_c<true>(m1, v1, HAS_A ? a1 : f_zero()));
     lz_add(Z, f_mad_c<true>(m0, v0, HAS_A ? a0 : f_zero()));
     vo = f_mad_c(r, dv, v0);                                             // stored values are canonical
     mo = f_mad_c(r, dm, m0);
@@ -463,6 +469,7 @@ __device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb,
     if (t < 128) { for (int i = 0; i < 3; ++i) { sm.acc2[i][t].re = 0; sm.acc2[i][t].im = 0; } }
     if (t < 64) { for (int i = 0; i < 3; ++i) { sm.acc3[i][t].re = 0; sm.acc3[i][t].im = 0; } }
     const F r0 = a.r[0], r1 = a.r[1], r2 = a.r[2];
+    const bool keep_y0 = (a.keep_y0 & 1) != 0, keep_rest = (a.keep_y0 & 2) != 0;              // uniform
     F dacc = f_zero();                                   // GenP1: this thread's share of the V_u inner product
 #if VP_SF_LDSPF
     bool staged = false;                                 // the chunk of this iteration sits in sm.pre (uniform)
@@ -534,7 +541,7 @@ __device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb,
                 }
             }
             F vo, mo, ao = f_zero();
-            sf_pair_step<HAS_A>(v0, v1, m0, m1, a0, a1, r0, acc[0], acc[1], acc[2], vo, mo, ao);
+            sf_pair_step<HAS_A>(v0, v1, m0, m1, a0, a1, r0, acc[0], acc[1], acc[2], vo, mo, ao, keep_y0);
             s1[0][t] = vo; s1[1][t] = mo;
             if (HAS_A) s1[2][t] = ao;
         }
@@ -544,7 +551,7 @@ __device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb,
             Lz x = sm.acc2[0][t], y = sm.acc2[1][t], z = sm.acc2[2][t];
             sf_pair_step<HAS_A>(s1[0][2 * t], s1[0][2 * t + 1], s1[1][2 * t], s1[1][2 * t + 1],
                                 HAS_A ? s1[2][2 * t] : f_zero(), HAS_A ? s1[2][2 * t + 1] : f_zero(), r1,
-                                x, y, z, vo, mo, ao);
+                                x, y, z, vo, mo, ao, keep_rest);
             lz_fold(x); lz_fold(y); lz_fold(z);
             sm.acc2[0][t] = x; sm.acc2[1][t] = y; sm.acc2[2][t] = z;
             s2[0][t] = vo; s2[1][t] = mo;
@@ -556,7 +563,7 @@ __device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb,
             Lz x = sm.acc3[0][t], y = sm.acc3[1][t], z = sm.acc3[2][t];
             sf_pair_step<HAS_A>(s2[0][2 * t], s2[0][2 * t + 1], s2[1][2 * t], s2[1][2 * t + 1],
                                 HAS_A ? s2[2][2 * t] : f_zero(), HAS_A ? s2[2][2 * t + 1] : f_zero(), r2,
-                                x, y, z, vo, mo, ao);
+                                x, y, z, vo, mo, ao, keep_rest);
             lz_fold(x); lz_fold(y); lz_fold(z);
             sm.acc3[0][t] = x; sm.acc3[1][t] = y; sm.acc3[2][t] = z;
             const u32 oi = cl * 64 + t;
@@ -584,7 +591,7 @@ __device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb,
         F X = red[0][3 * t], Y = red[0][3 * t + 1], Z = red[0][3 * t + 2];
         for (int k = 1; k < nw; ++k) { X = f_add(X, red[k][3 * t]); Y = f_add(Y, red[k][3 * t + 1]); Z = f_add(Z, red[k][3 * t + 2]); }
         F *o = a.part + (size_t) t * a.part_stride + bid * 3;
-        o[0] = X; o[1] = f_sub(f_sub(Y, X), Z); o[2] = Z;
+        o[0] = X; o[1] = (t == 0 ? keep_y0 : keep_rest) ? f_sub(f_sub(Y, X), Z) : f_zero(); o[2] = Z;       // b of the other rounds: derived by k_emit
     }
     if constexpr (Gen::MODE == 1) {
         if (gen.dot_part) {                              // uniform per launch
@@ -607,6 +614,7 @@ __device__ __forceinline__ void sumfold4b_body(const SfArgs &a, u32 bid, u32 nb,
     if (t < 128) { for (int i = 0; i < 3; ++i) { sm.acc3[i][t].re = 0; sm.acc3[i][t].im = 0; } }
     if (t < 64) { for (int i = 0; i < 3; ++i) { sm.acc4[i][t].re = 0; sm.acc4[i][t].im = 0; } }
     const F r0 = a.r[0], r1 = a.r[1], r2 = a.r[2], r3 = a.r[3];
+    const bool keep_y0 = (a.keep_y0 & 1) != 0, keep_rest = (a.keep_y0 & 2) != 0;
     for (u32 c = bid; c < a.total_chunks; c += nb) {
         int j = 0;
         while (j + 1 < a.n_tab && c >= a.t[j + 1].chunk_start) ++j;
@@ -621,7 +629,7 @@ __device__ __forceinline__ void sumfold4b_body(const SfArgs &a, u32 bid, u32 nb,
             F a0 = f_zero(), a1 = f_zero();
             if (HAS_A) { a0 = ld_or_zero(a.inA, i0, vend); a1 = ld_or_zero(a.inA, i0 + 1, vend); }
             F vo, mo, ao = f_zero();
-            sf_pair_step<HAS_A>(v0, v1, m0, m1, a0, a1, r0, acc[0], acc[1], acc[2], vo, mo, ao);
+            sf_pair_step<HAS_A>(v0, v1, m0, m1, a0, a1, r0, acc[0], acc[1], acc[2], vo, mo, ao, keep_y0);
             sm.s1[0][256 * h + t] = vo; sm.s1[1][256 * h + t] = mo;
             if (HAS_A) sm.s1[2][256 * h + t] = ao;
         }
@@ -630,7 +638,7 @@ __device__ __forceinline__ void sumfold4b_body(const SfArgs &a, u32 bid, u32 nb,
             F vo, mo, ao = f_zero();
             sf_pair_step<HAS_A>(sm.s1[0][2 * t], sm.s1[0][2 * t + 1], sm.s1[1][2 * t], sm.s1[1][2 * t + 1],
                                 HAS_A ? sm.s1[2][2 * t] : f_zero(), HAS_A ? sm.s1[2][2 * t + 1] : f_zero(), r1,
-                                acc[3], acc[4], acc[5], vo, mo, ao);
+                                acc[3], acc[4], acc[5], vo, mo, ao, keep_rest);
             sm.s2[0][t] = vo; sm.s2[1][t] = mo;
             if (HAS_A) sm.s2[2][t] = ao;
         }
@@ -640,7 +648,7 @@ __device__ __forceinline__ void sumfold4b_body(const SfArgs &a, u32 bid, u32 nb,
             Lz x = sm.acc3[0][t], y = sm.acc3[1][t], z = sm.acc3[2][t];
             sf_pair_step<HAS_A>(sm.s2[0][2 * t], sm.s2[0][2 * t + 1], sm.s2[1][2 * t], sm.s2[1][2 * t + 1],
                                 HAS_A ? sm.s2[2][2 * t] : f_zero(), HAS_A ? sm.s2[2][2 * t + 1] : f_zero(), r2,
-                                x, y, z, vo, mo, ao);
+                                x, y, z, vo, mo, ao, keep_rest);
             lz_fold(x); lz_fold(y); lz_fold(z);
             sm.acc3[0][t] = x; sm.acc3[1][t] = y; sm.acc3[2][t] = z;
             sm.s3[0][t] = vo; sm.s3[1][t] = mo;
@@ -652,7 +660,7 @@ __device__ __forceinline__ void sumfold4b_body(const SfArgs &a, u32 bid, u32 nb,
             Lz x = sm.acc4[0][t], y = sm.acc4[1][t], z = sm.acc4[2][t];
             sf_pair_step<HAS_A>(sm.s3[0][2 * t], sm.s3[0][2 * t + 1], sm.s3[1][2 * t], sm.s3[1][2 * t + 1],
                                 HAS_A ? sm.s3[2][2 * t] : f_zero(), HAS_A ? sm.s3[2][2 * t + 1] : f_zero(), r3,
-                                x, y, z, vo, mo, ao);
+                                x, y, z, vo, mo, ao, keep_rest);
             lz_fold(x); lz_fold(y); lz_fold(z);
             sm.acc4[0][t] = x; sm.acc4[1][t] = y; sm.acc4[2][t] = z;
             const u32 oi = cl * 64 + t;
@@ -680,7 +688,7 @@ __device__ __forceinline__ void sumfold4b_body(const SfArgs &a, u32 bid, u32 nb,
         F X = sm.red[0][3 * t], Y = sm.red[0][3 * t + 1], Z = sm.red[0][3 * t + 2];
         for (int k = 1; k < nw; ++k) { X = f_add(X, sm.red[k][3 * t]); Y = f_add(Y, sm.red[k][3 * t + 1]); Z = f_add(Z, sm.red[k][3 * t + 2]); }
         F *o = a.part + (size_t) t * a.part_stride + bid * 3;
-        o[0] = X; o[1] = f_sub(f_sub(Y, X), Z); o[2] = Z;
+        o[0] = X; o[1] = (t == 0 ? keep_y0 : keep_rest) ? f_sub(f_sub(Y, X), Z) : f_zero(); o[2] = Z;
     }
 }
 

@@ -184,6 +184,7 @@ struct EmitArgs {
     u32 work_mask;              // bit k-1: some table of this kernel has pairs or retires in round k
     u32 enter_mask;             // bit k-1: some table is loaded from global memory in round k
     u32 pair_mask;              // bit k-1: some table has PAIRS in round k (work_mask minus the retire-only rounds)
+    u32 derive_mask;            // bit k-1 (k >= 2): a fold launch left out the sum of m1 v1 + a1 in round k; b_k = S_{k-1}(r_{k-1}) - a_k - 2 c_k
     F *poly_out, *claims_out, *Vu;
     int n_pd;                   // launches that left block partials
     struct { int k0, nr; u32 nblk, off; } pd[VP_MAX_PD];   // rounds k0..k0+nr-1: part[off + s*nblk*3 + b*3 + c]
@@ -349,8 +350,23 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, unsigned char *smem
         const int k = tid / 3, c = tid % 3;
         F t = psum[3 * k + c];
         if (c == 1) t = f_sub(t, s_at[k]); else if (c == 2) t = f_add(t, s_at[k]);
-        a.poly_out[tid] = t;
+        psum[3 * k + c] = t;                                   // the round polynomial (a, b, c) as the reference sends it
     }
+    if (a.derive_mask) {                                       // uniform
+        __syncthreads();
+        // Rounds whose fold launches skipped the product sum: b_k from the verifier's identity S_k(0) + S_k(1) = S_{k-1}(r_{k-1})
+        // (totals over every table of the phase, add_term included).  One lane, two multiplies per derived round, in order.
+        if (tid == 0) {
+            for (int k = 1; k < a.rounds; ++k) {
+                if (!((a.derive_mask >> k) & 1u)) continue;
+                const F r = s_r[k - 1];
+                const F claim = f_add(f_mul(f_add(f_mul(psum[3 * (k - 1)], r), psum[3 * (k - 1) + 1]), r), psum[3 * (k - 1) + 2]);
+                psum[3 * k + 1] = f_sub(f_sub(claim, psum[3 * k]), f_dbl(psum[3 * k + 2]));
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < a.rounds * 3) a.poly_out[tid] = psum[tid];
     if (tid < a.n_tab) {
         F c = s_claim[tid];
         if (a.rounds > 0) {
