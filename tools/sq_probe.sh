@@ -21,3 +21,4 @@ json.dump(out, open(sys.argv[1] + "/sq_summary.json", "w"), indent=1)
 for k, cs in out.items():
     print(k); print("   ", {c: round(v / 1e6, 2) for c, v in sorted(cs.items())})
 PY
+rm -rf "$O"/g[0-9]*          # the databases are large (gpurun merges at most 64 MiB back); the summary is what is kept
