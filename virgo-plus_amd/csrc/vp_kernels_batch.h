@@ -518,11 +518,20 @@ __device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb,
                 }
             } else
 #endif
-            { v0 = ld_or_zero(a.inV, i0, vend); v1 = ld_or_zero(a.inV, i0 + 1, vend); }
+            {
+                // a chunk that lies completely inside the table (all but the last one) is loaded without the per-entry bounds selects
+                if (cl * 512 + 512 <= td.valid) { v0 = a.inV[i0]; v1 = a.inV[i0 + 1]; }
+                else { v0 = ld_or_zero(a.inV, i0, vend); v1 = ld_or_zero(a.inV, i0 + 1, vend); }
+            }
             if constexpr (Gen::MODE == 0) {
 #if !VP_SF_LDSPF
-                m0 = ld_or_zero(a.inM, i0, vend); m1 = ld_or_zero(a.inM, i0 + 1, vend);
-                if (HAS_A) { a0 = ld_or_zero(a.inA, i0, vend); a1 = ld_or_zero(a.inA, i0 + 1, vend); }
+                if (cl * 512 + 512 <= td.valid) {                            // uniform
+                    m0 = a.inM[i0]; m1 = a.inM[i0 + 1];
+                    if (HAS_A) { a0 = a.inA[i0]; a1 = a.inA[i0 + 1]; }
+                } else {
+                    m0 = ld_or_zero(a.inM, i0, vend); m1 = ld_or_zero(a.inM, i0 + 1, vend);
+                    if (HAS_A) { a0 = ld_or_zero(a.inA, i0, vend); a1 = ld_or_zero(a.inA, i0 + 1, vend); }
+                }
 #endif
             } else {                      // generated tables: one table per job, offset 0
 #ifdef VP_GEN_ROW1
@@ -548,24 +557,28 @@ __device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb,
         __syncthreads();
         if (w < 2) {   // round k+1: 128 pairs
             F vo, mo, ao = f_zero();
-            Lz x = sm.acc2[0][t], y = sm.acc2[1][t], z = sm.acc2[2][t];
+            Lz x = sm.acc2[0][t], y{0, 0}, z = sm.acc2[2][t];
+            if (keep_rest) y = sm.acc2[1][t];
             sf_pair_step<HAS_A>(s1[0][2 * t], s1[0][2 * t + 1], s1[1][2 * t], s1[1][2 * t + 1],
                                 HAS_A ? s1[2][2 * t] : f_zero(), HAS_A ? s1[2][2 * t + 1] : f_zero(), r1,
                                 x, y, z, vo, mo, ao, keep_rest);
-            lz_fold(x); lz_fold(y); lz_fold(z);
-            sm.acc2[0][t] = x; sm.acc2[1][t] = y; sm.acc2[2][t] = z;
+            lz_fold(x); lz_fold(z);
+            sm.acc2[0][t] = x; sm.acc2[2][t] = z;
+            if (keep_rest) { lz_fold(y); sm.acc2[1][t] = y; }
             s2[0][t] = vo; s2[1][t] = mo;
             if (HAS_A) s2[2][t] = ao;
         }
         __syncthreads();
         if (w == 0) {  // round k+2: 64 pairs, results are the folded table
             F vo, mo, ao = f_zero();
-            Lz x = sm.acc3[0][t], y = sm.acc3[1][t], z = sm.acc3[2][t];
+            Lz x = sm.acc3[0][t], y{0, 0}, z = sm.acc3[2][t];
+            if (keep_rest) y = sm.acc3[1][t];
             sf_pair_step<HAS_A>(s2[0][2 * t], s2[0][2 * t + 1], s2[1][2 * t], s2[1][2 * t + 1],
                                 HAS_A ? s2[2][2 * t] : f_zero(), HAS_A ? s2[2][2 * t + 1] : f_zero(), r2,
                                 x, y, z, vo, mo, ao, keep_rest);
-            lz_fold(x); lz_fold(y); lz_fold(z);
-            sm.acc3[0][t] = x; sm.acc3[1][t] = y; sm.acc3[2][t] = z;
+            lz_fold(x); lz_fold(z);
+            sm.acc3[0][t] = x; sm.acc3[2][t] = z;
+            if (keep_rest) { lz_fold(y); sm.acc3[1][t] = y; }
             const u32 oi = cl * 64 + t;
             if (oi < ((td.valid + 7) >> 3)) {
                 a.outV[td.off + oi] = vo;
