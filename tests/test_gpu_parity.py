@@ -127,7 +127,13 @@ def test_fused_init_plan_matches_reference(vp, golden, gold_gkr, pws_path, name,
     s5.draw_tape()
     tr5, _ = s5.prove_gkr()
     assert tr5 == tr
-    s.close(); s2.close(); s3.close(); s4.close(); s5.close(); c.close()
+    monkeypatch.delenv("VP_SF_ROUNDS"); monkeypatch.delenv("VP_DROP_Y")
+    monkeypatch.setenv("VP_DROP_Y1", "1")           # round 1 leaves its b to the fix-up pass over the finished transcript (k_fixup)
+    s6 = vp.Session(c)
+    s6.draw_tape()
+    tr6, res6 = s6.prove_gkr()
+    assert tr6 == tr
+    s.close(); s2.close(); s3.close(); s4.close(); s5.close(); s6.close(); c.close()
 
 
 def _sharded_parts(vp, s, world):

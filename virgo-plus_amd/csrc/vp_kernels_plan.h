@@ -184,7 +184,8 @@ struct EmitArgs {
     u32 work_mask;              // bit k-1: some table of this kernel has pairs or retires in round k
     u32 enter_mask;             // bit k-1: some table is loaded from global memory in round k
     u32 pair_mask;              // bit k-1: some table has PAIRS in round k (work_mask minus the retire-only rounds)
-    u32 derive_mask;            // bit k-1 (k >= 2): a fold launch left out the sum of m1 v1 + a1 in round k; b_k = S_{k-1}(r_{k-1}) - a_k - 2 c_k
+    u32 derive_mask;            // bit k-1: a fold launch left out the sum of m1 v1 + a1 in round k; b_k = S_{k-1}(r_{k-1}) - a_k - 2 c_k
+    int derive_later;           // 1: k_fixup derives those b's after all sumchecks are closed (round 1 included: its claim comes from another sumcheck)
     F *poly_out, *claims_out, *Vu;
     int n_pd;                   // launches that left block partials
     struct { int k0, nr; u32 nblk, off; } pd[VP_MAX_PD];   // rounds k0..k0+nr-1: part[off + s*nblk*3 + b*3 + c]
@@ -352,7 +353,7 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, unsigned char *smem
         if (c == 1) t = f_sub(t, s_at[k]); else if (c == 2) t = f_add(t, s_at[k]);
         psum[3 * k + c] = t;                                   // the round polynomial (a, b, c) as the reference sends it
     }
-    if (a.derive_mask) {                                       // uniform
+    if (a.derive_mask && !a.derive_later) {                    // uniform
         __syncthreads();
         // Rounds whose fold launches skipped the product sum: b_k from the verifier's identity S_k(0) + S_k(1) = S_{k-1}(r_{k-1})
         // (totals over every table of the phase, add_term included).  One lane, two multiplies per derived round, in order.
@@ -384,6 +385,37 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, unsigned char *smem
 __global__ void __launch_bounds__(VP_EMIT_THREADS) k_emit(EmitArgs a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     emit_body(a, smem_raw);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_fixup: the b coefficients the fold launches left out, round 1 of every sumcheck included.  The claim a sumcheck starts
+// from is the verifier's running `previousSum` (src/verifier.cpp): Vres for the first phase 1 (:151), vr of the layer above for
+// the others (:336), the last phase-1 polynomial at its last challenge for phase 2 (:229), sum of sig * claims for Liu
+// (:281-286).  Those inputs are final values of OTHER sumchecks that their closing launches produce directly (a last round is
+// never a fold-launch round), so every sumcheck is fixed up independently: one lane each, two multiplies per derived round.
+// ---------------------------------------------------------------------------------------------------
+struct FixJob {
+    u32 poly_pos, rounds, derive_mask, r_off;      // transcript index of the first polynomial; tape index of r[0]
+    int kind;                                      // 0: claim = tr[ref0]   1: claim = poly at tr[ref0..ref0+3) evaluated at tape[ref1]   2: sum of tape[sig[t]] * tr[cl[t]]
+    u32 ref0, ref1, n_terms;
+    u32 sig[VP_MAX_TAB + 1], cl[VP_MAX_TAB + 1];
+};
+__global__ void __launch_bounds__(64) k_fixup(const FixJob *__restrict__ jobs, u32 n_jobs, const F *__restrict__ tape, F *__restrict__ tr) {
+    const u32 q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_jobs) return;
+    const FixJob &j = jobs[q];
+    if (!j.derive_mask) return;
+    F claim = f_zero();
+    if (j.kind == 0) claim = tr[j.ref0];
+    else if (j.kind == 1) { const F r = tape[j.ref1]; claim = f_add(f_mul(f_add(f_mul(tr[j.ref0], r), tr[j.ref0 + 1]), r), tr[j.ref0 + 2]); }
+    else for (u32 t = 0; t < j.n_terms; ++t) claim = f_add(claim, f_mul(tape[j.sig[t]], tr[j.cl[t]]));
+    for (u32 k = 0; k < j.rounds; ++k) {
+        F *pk = tr + j.poly_pos + 3 * k;
+        if ((j.derive_mask >> k) & 1u) pk[1] = f_sub(f_sub(claim, pk[0]), f_dbl(pk[2]));
+        if (!(j.derive_mask >> (k + 1))) break;                       // no derived round after this one
+        const F r = tape[j.r_off + k];
+        claim = f_add(f_mul(f_add(f_mul(pk[0], r), pk[1]), r), pk[2]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -90,6 +90,7 @@ struct Plan {
     hipStream_t streams[4] = {nullptr, nullptr, nullptr, nullptr};   // [0] = ctx->stream; [1..3] owned: fold (low priority), seg, emit (high)
     hipEvent_t ev_root = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     u64 rounds = 0; int n_steps = 0, sf_rounds = 3;
+    FixJob *d_fix = nullptr; u32 n_fix = 0;          // k_fixup jobs (when round 1 of the sumchecks leaves its b to the fix-up pass)
 };
 
 struct vp_ctx {
@@ -150,6 +151,8 @@ struct vp_ctx {
     int shard_rank = 0, shard_world = 1;
     std::vector<int> chain_owner;     // per chain of the plan (same indices as `lanes`, + 1 for Vres); empty = everything local
     std::vector<double> chain_cost;
+    bool drop_round1 = false;         // plan being recorded: round 1 of every sumcheck also leaves out the product sum (k_fixup restores b)
+    std::vector<FixJob> rec_fix;      // record mode: one job per sumcheck, in protocol order
     bool owned(int chain) const { return shard_world <= 1 || chain_owner.empty() || chain_owner[chain] == shard_rank; }
 
     F *zero() const { return small; }
