@@ -27,7 +27,72 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
-PMC_SUMMARY = "r01_l_pmc_summary_b64.json"   # made by tools/pmc_summary.py from three rocprofv3 --pmc passes of this script
+# PMC summaries of this command (tools/gpu_profile.sh -> tools/pmc_summary.py: separate rocprofv3 --pmc passes for FETCH_SIZE and
+# WRITE_SIZE, FETCH_SIZE doubled for gfx950 as the guide's HBM section prescribes), newest first
+PMC_SUMMARIES = ("r02_pmc_summary_b%d.json", "r01_l_pmc_summary_b%d.json")
+# Issue-rate ceilings of the two compute-bound kernel families of the commitment, measured with tools/micro_rates.hip on MI355X
+# (profiles/r02_micro_rates.txt; 256 CUs x 4 SIMDs at 2.4 GHz, 8 waves per SIMD):
+#   F_p^2 multiply (31-bit split form, 16 v_mad_u64_u32 + Mersenne folds): 6.1e11 per second for the whole chip;
+#   Keccak-f[1600] as 24 rounds x 180 VALU instructions (v_bitop3_b32 / v_alignbit_b32) at the measured issue cost of those two.
+FMUL_PEAK_PER_S = 6.1e11
+KECCAK_INSTR = 24 * 180
+VALU_LOGIC_CYCLES = 3.0         # measured cycles per wave-instruction per SIMD for v_bitop3_b32 / v_alignbit_b32 (same as v_add_u32)
+KECCAK_PEAK_PER_S = 1024 * 64 * 2.4e9 / (KECCAK_INSTR * VALU_LOGIC_CYCLES)
+
+
+def pmc_traffic(blocks, kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC summary of this command at this size, or (None, None)."""
+    for pat in PMC_SUMMARIES:
+        f = os.path.join(ROOT, "profiles", pat % blocks)
+        try:
+            for k in json.load(open(f))["kernels"]:
+                if k["kernel"].replace("vp::", "") == kernel and "hbm_bytes_per_launch" in k:
+                    return k["hbm_bytes_per_launch"], "profiles/" + os.path.basename(f)
+        except Exception:
+            continue
+    return None, None
+
+
+def launch_table(stats, total_us=None):
+    """Per-kernel and per-launch views of a vp_get_launch_stats table: achieved algorithmic GB/s against the 8 TB/s HBM roofline,
+    share of the summed launch time."""
+    tot = sum(e["us"] for e in stats) or 1e-9
+    kern = {}
+    for e in stats:
+        k = kern.setdefault(e["kernel"], {"kernel": e["kernel"], "launches": 0, "us": 0.0, "bytes": 0, "work": 0, "workgroups": 0})
+        k["launches"] += 1; k["us"] += e["us"]; k["bytes"] += e["bytes"]; k["work"] += e["work"]; k["workgroups"] += e["workgroups"]
+    rows = []
+    for k in sorted(kern.values(), key=lambda x: -x["us"]):
+        gbps = k["bytes"] / (k["us"] * 1e-6) / 1e9 if k["us"] > 0 else 0.0
+        rows.append({"kernel": k["kernel"], "launches": k["launches"], "total_us": round(k["us"], 2), "time_share": round(k["us"] / tot, 4),
+                     "avg_launch_us": round(k["us"] / k["launches"], 2), "algorithmic_MB_per_launch": round(k["bytes"] / k["launches"] / 1e6, 3),
+                     "GBps": round(gbps, 1), "hbm_frac": round(gbps / HBM_PEAK_GBPS, 4), "work_units": k["work"]})
+    per_launch = []
+    for e in stats:
+        gbps = e["bytes"] / (e["us"] * 1e-6) / 1e9 if e["us"] > 0 else 0.0
+        per_launch.append({"step": e["step"], "kernel": e["kernel"], "jobs": e["jobs"], "workgroups": e["workgroups"],
+                           "rounds": ([e["first_round"], e["first_round"] + e["rounds"] - 1] if e["rounds"] else None),
+                           "MB": round(e["bytes"] / 1e6, 3), "us": round(e["us"], 2), "GBps": round(gbps, 1), "hbm_frac": round(gbps / HBM_PEAK_GBPS, 4)})
+    return rows, per_launch, tot
+
+
+def roofline_of(rows, blocks, serial_ms, note=None):
+    """The `roofline` object for the kernel with the largest share of the (single-stream) proof time."""
+    if not rows:
+        return None
+    d = rows[0]
+    traffic, src = pmc_traffic(blocks, d["kernel"])
+    limiter = None
+    if "sumfold" in d["kernel"] or "light" in d["kernel"]:
+        limiter = ("VALU issue: SQ_ACTIVE_INST_VALU is 76-87 % of the launch's SIMD cycles (profiles/r01_l_sq_counters_b1024.json); the bytes moved equal the "
+                   "algorithmic bytes, the integer multiply-add of F_p^2 (16 v_mad_u64_u32 + folds) sets the time")
+    return {"bound": "hbm", "achieved": d["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": d["hbm_frac"], "traffic": traffic,
+            "traffic_source": ("%s (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, per launch)" % src) if traffic else None,
+            "kernel": d["kernel"], "kernel_time_share": d["time_share"], "launches": d["launches"], "avg_launch_us": d["avg_launch_us"],
+            "algorithmic_bytes_per_launch": d["algorithmic_MB_per_launch"] * 1e6, "single_stream_proof_ms": serial_ms,
+            "measured_limiter": limiter,
+            "how": "every launch of the plan bracketed with HIP events in a single-stream replay of the same proof (vp_set_profiling / vp_get_launch_stats)" + (("; " + note) if note else "")}
+
 
 
 def dist_setup(n_gpus, rccl=False):
@@ -127,6 +192,165 @@ def cpu_model():
     return "unknown"
 
 
+def profile_gkr(sess, tr_expected, blocks):
+    """Roofline pass (outside the timed region, same process, same resident state): the proof is replayed on ONE stream with HIP
+    events around EVERY launch (in the timed steps the independent sumchecks overlap on several streams, which makes per-kernel
+    event times meaningless there).  Returns (per-kernel rows, per-launch rows, roofline object, single-stream device ms)."""
+    sess.set_profiling(1)
+    tr_p, res_p = sess.prove_gkr()
+    stats = sess.launch_stats()
+    sess.set_profiling(0)
+    assert tr_p == tr_expected, "profiled replay produced a different transcript"
+    rows, per_launch, _ = launch_table(stats)
+    return rows, per_launch, roofline_of(rows, blocks, res_p["gkr_device_ms"]), res_p
+
+
+def pc_leg(vp, sess, circ, golden, gname, full_fixture=None):
+    """BASELINE.json configs[2] flavour: the commitment's commit side on the GPU (never part of `value`).  Times commit_private,
+    commit_public on the PROTOCOL's public vector (eq table of the last Liu point, src/verifier.cpp:368-379) and the FRI commit
+    phase, compares everything a fixture exists for, and profiles each of the three calls launch by launch."""
+    import numpy as np
+    from conftest import GOLDEN
+    pc = {}
+    t1 = time.perf_counter()
+    full, okf = sess.prove_full(batched=True)                 # commit_private + GKR + commit_public(eq(r_liu, .))
+    pc["full_proof_wall_sec"] = time.perf_counter() - t1
+    pc["full_transcript_verified"] = okf
+    pc["commit_public_device_ms"] = sess.commit_device_ms()       # last commitment call of prove_full
+    fri_ref = None
+    if gname in golden and "fri" in golden[gname]:            # recorded runs of the real reference (full transcript + FRI steps)
+        gg = golden[gname]
+        pc["full_transcript_bit_exact"] = (full == open(os.path.join(GOLDEN, gg["transcript"]), "rb").read())
+        fri = open(os.path.join(GOLDEN, gg["fri"]), "rb").read()
+        st = gg["fri_steps"]
+        rec = np.frombuffer(fri[:48 * st], dtype=np.uint64).reshape(st, 6)
+        rr = np.ascontiguousarray(rec[:, :2])
+        fri_ref = b"".join(rec[i, 2:].tobytes() for i in range(st))
+        pc["fixture"] = "real reference (tests/golden/%s, %s)" % (gg["transcript"], gg["fri"])
+    elif full_fixture is not None:                            # oracle run of the whole protocol at this size (make_oracle_fixture_full.py)
+        fx = open(full_fixture, "rb").read()
+        st = circ.layer_bitlen(0) - 6
+        n_full = len(full)
+        pc["full_transcript_bit_exact"] = (fx[:n_full] == full)
+        rr = np.frombuffer(fx[n_full + 32 * st + 2048 * 16:n_full + 32 * st + 2048 * 16 + 16 * st], dtype=np.uint64).reshape(st, 2).copy()
+        fri_ref = fx[n_full:n_full + 32 * st]
+        pc["fixture"] = "oracle, whole protocol incl. the reference's FRI challenges (tests/golden/%s)" % os.path.basename(full_fixture)
+    else:
+        st = circ.layer_bitlen(0) - 6
+        rr = np.random.default_rng(1).integers(0, (1 << 61) - 1, size=(st, 2), dtype=np.uint64)
+    sess.fri_commit(rr)                                        # first call allocates nothing new, warms the kernels
+    sess.prove_full(batched=True)
+    t2 = time.perf_counter()
+    roots, fin = sess.fri_commit(rr)
+    pc["fri_commit_wall_sec"] = time.perf_counter() - t2
+    pc["fri_commit_device_ms"] = sess.commit_device_ms()
+    pc["fri_steps"] = int(st)
+    if fri_ref is not None:
+        pc["fri_roots_bit_exact"] = (roots == fri_ref)
+    t3 = time.perf_counter(); _, ms_priv = sess.commit_private(); pc["commit_private_device_ms"] = ms_priv
+    pc["commit_private_wall_sec"] = time.perf_counter() - t3
+    pc["pc_commit_side_device_ms"] = ms_priv + pc["commit_public_device_ms"] + pc["fri_commit_device_ms"]
+    pc["reference_pc_prove_sec_build_container"] = golden.get(gname, {}).get("reference_pc_prove_sec_here")
+    # per-launch profile of the three calls (events on the library stream; the commitment runs on one stream anyway)
+    sess.set_profiling(1)
+    sess.commit_private(); st_priv = sess.launch_stats()
+    sess.prove_full(batched=True); st_pub = sess.launch_stats()      # the last profiled call inside is commit_public
+    sess.fri_commit(rr); st_fri = sess.launch_stats()
+    sess.set_profiling(0)
+    allst = st_priv + st_pub + st_fri
+    rows, _, tot = launch_table(allst)
+    pc["kernels"] = rows
+    pc["profiled_device_ms"] = tot * 1e-3
+    leaf = [e for e in allst if e["kernel"] == "k_leaf_hash"]
+    ntt = [e for e in allst if e["kernel"] in ("k_ntt_lds", "k_ntt_split")]
+    rl = {}
+    if leaf:
+        w, us = sum(e["work"] for e in leaf), sum(e["us"] for e in leaf)
+        rl["k_leaf_hash"] = {"bound": "valu", "achieved": w / (us * 1e-6), "peak": KECCAK_PEAK_PER_S, "unit": "Keccak-f[1600]/s",
+                             "frac": w / (us * 1e-6) / KECCAK_PEAK_PER_S, "time_share": us / tot,
+                             "peak_definition": "1024 SIMDs x 64 lanes x 2.4 GHz / (24 rounds x 180 instructions x %.1f cycles per wave-instruction, tools/micro_rates.hip)" % VALU_LOGIC_CYCLES}
+    if ntt:
+        w, us = sum(e["work"] for e in ntt), sum(e["us"] for e in ntt)
+        rl["k_ntt"] = {"bound": "valu", "achieved": w / (us * 1e-6), "peak": FMUL_PEAK_PER_S, "unit": "F_p^2 multiplications/s",
+                       "frac": w / (us * 1e-6) / FMUL_PEAK_PER_S, "time_share": us / tot,
+                       "hbm_GBps": sum(e["bytes"] for e in ntt) / (us * 1e-6) / 1e9,
+                       "peak_definition": "chip-wide F_p^2 multiply issue rate of the 31-bit split form (tools/micro_rates.hip, f_mul)"}
+    pc["rooflines"] = rl
+    return pc
+
+
+def gkr_leg(vp, circ, sess, steps, warmup, world, shard, local):
+    """Timed region of one configuration: `warmup` untimed proofs, then exactly `steps` proofs bracketed by barrier + device sync."""
+    for _ in range(warmup):
+        tr, _ = sess.prove_gkr()
+        if shard:
+            vp.allreduce_transcript(tr, local)
+    gpu_sync(local)
+    barrier(world)
+    t0 = time.perf_counter()
+    dev_ms = 0.0
+    res = None
+    for _ in range(steps):
+        tr, res = sess.prove_gkr()
+        if shard:       # the one data-path collective: u64 sum of the ranks' disjoint transcript slices over RCCL
+            tr = vp.allreduce_transcript(tr, local)
+        dev_ms += res["gkr_device_ms"]
+    gpu_sync(local)
+    barrier(world)
+    elapsed = time.perf_counter() - t0
+    return tr, res, elapsed, dev_ms
+
+
+def x1024_leg(vp, pws, golden, a, local):
+    """BASELINE.json configs[2]: SHA-256 1024-block circuit (102 M gates, 859 rounds, tables up to 2^26), sumcheck + Virgo commitment
+    on ONE MI355X — the largest single-GPU configuration, as a nested leg of the default run.  Same contract as the headline leg:
+    warmup, timed steps, transcript compared with the committed oracle fixture, per-launch table with the dominant kernel's roofline,
+    CPU baseline (the oracle port's GKR proof of the same circuit, one core) timed in the same run."""
+    B = 1024
+    g = golden["sha256_x%d" % B]
+    t_b = time.perf_counter()
+    circ = vp.Circuit.from_pws(pws, B, seed=1)
+    build_sec = time.perf_counter() - t_b
+    t_up = time.perf_counter()
+    sess = vp.Session(circ, device=local)
+    upload_sec = time.perf_counter() - t_up
+    sess.draw_tape()
+    steps, warmup = max(3, a.steps // 2), 2
+    tr, res, elapsed, dev_ms = gkr_leg(vp, circ, sess, steps, warmup, 1, False, local)
+    gold = open(os.path.join(ROOT, "tests", "golden", g["transcript"]), "rb").read()[g["gkr_slice"][0]:g["gkr_slice"][1]]
+    ref_ops = g["mult_counter"] + g["add_counter"]
+    rows, per_launch, roof, res_p = profile_gkr(sess, tr, B)
+    ok_d, sec_d = sess.check(tr, device_predicates=True)
+    t_i = time.perf_counter()
+    tr_i, res_i, ok_i = sess.prove_interactive()
+    inter = {"prover_sec": res_i["prove_sec"], "wall_sec_with_host_verifier": time.perf_counter() - t_i, "transcript_equals_batched": tr_i == tr, "verified": ok_i}
+    sess.draw_tape()
+    fx = os.path.join(ROOT, "tests", "golden", "oracle_sha256_x1024_full.bin")
+    pc = pc_leg(vp, sess, circ, golden, "sha256_x%d" % B, full_fixture=fx if os.path.exists(fx) else None)
+    leg = {"config": {"workload": "SHA-256 %d-block circuit (SHA256_64.pws x%d, %d gates, %d layers), GKR sumcheck + Virgo FFT/LDT commit on GPU (BASELINE configs[2])"
+                                  % (B, B, circ.gates, circ.layers), "field_ops_per_proof": ref_ops},
+           "value": ref_ops * steps / elapsed, "unit": "field-ops/s", "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
+           "prover_sec": elapsed / steps, "prover_sec_device": 1e-3 * dev_ms / steps, "rounds": res["rounds"],
+           "kernel_launches_per_proof": res["launches"], "bit_exact_vs_oracle_fixture": tr == gold, "golden_origin": g.get("origin"),
+           "verifier_accepts_full_check": bool(ok_d), "verify_sec_device_predicates": sec_d, "interactive_path": inter,
+           "circuit_build_sec": build_sec, "circuit_upload_sec": upload_sec,
+           "roofline": roof, "kernels": rows, "per_launch": per_launch, "polynomial_commitment": pc}
+    sess.close(); circ.close()
+    if not a.no_cpu_baseline:
+        import oracle_binding as ob
+        t0 = time.perf_counter()
+        oc = ob.Circuit.from_pws(pws, B, seed=1)
+        t1 = time.perf_counter()
+        otr, st = oc.prove_gkr()
+        oc.close()
+        ops = st["mult_count"] + st["add_count"]
+        leg["cpu_baseline"] = {"value": ops / st["prove_sec"], "unit": "field-ops/s", "cores": 1, "kind": "port",
+                               "sample": "one full GKR proof of the same 1024-block circuit by the oracle port (PC off), single thread",
+                               "prover_sec": st["prove_sec"], "field_ops": ops, "circuit_build_sec": t1 - t0,
+                               "transcript_equals_gpu": otr == tr, "host_cpu": cpu_model(), "host_cores_visible": os.cpu_count()}
+    return leg
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -143,6 +367,9 @@ def main():
                     help="single GPU: run the W shards of a chain-sharded proof one after the other and report each shard's device time "
                          "(the per-rank compute of a W-GPU run; outside the timed region)")
     ap.add_argument("--with-pc", action="store_true", help="also time the Virgo commitment (commit_private + commit_public + FRI commit phase)")
+    ap.add_argument("--no-x1024-leg", action="store_true",
+                    help="skip the nested x1024_with_pc leg (BASELINE configs[2]) that the default single-GPU run appends to the x64 headline line")
+    ap.add_argument("--per-launch", action="store_true", help="include the per-launch table of the headline leg in the JSON line (the per-kernel table is always there)")
     a = ap.parse_args()
 
     # The native libraries are loaded BEFORE torch so that every rank count uses the same HIP runtime load order
@@ -174,23 +401,7 @@ def main():
         sess.draw_tape()
         if shard:
             sess.set_shard(rank, world)
-        for _ in range(a.warmup):
-            tr, _ = sess.prove_gkr()
-            if shard:
-                vp.allreduce_transcript(tr, local)
-        gpu_sync(local)
-        barrier(world)
-        t0 = time.perf_counter()
-        dev_ms = 0.0
-        res = None
-        for k in range(a.steps):
-            tr, res = sess.prove_gkr()
-            if shard:       # the one data-path collective: u64 sum of the ranks' disjoint transcript slices over RCCL
-                tr = vp.allreduce_transcript(tr, local)
-            dev_ms += res["gkr_device_ms"]
-        gpu_sync(local)
-        barrier(world)
-        elapsed = time.perf_counter() - t0
+        tr, res, elapsed, dev_ms = gkr_leg(vp, circ, sess, a.steps, a.warmup, world, shard, local)
         elapsed, proofs = aggregate(world, elapsed, float(a.steps))
         shard_info = None
         if shard:
@@ -205,16 +416,7 @@ def main():
             sess.set_shard(0, 1)                       # the roofline / verifier legs below run the whole proof on every rank
             tr_full, _ = sess.prove_gkr()
             assert tr_full == tr, "assembled sharded transcript differs from the unsharded proof"
-        # Roofline pass (outside the timed region, same process, same resident state): the proof is replayed on ONE
-        # stream with HIP events around every launch of the dominant kernel.  In the timed steps the independent
-        # sumchecks overlap on separate streams, which makes per-kernel event times meaningless there.
-        sess.set_profiling(1)
-        tr_p, res_p = sess.prove_gkr()
-        sess.set_profiling(0)
-        assert tr_p == tr
-        for key in ("fold_ms", "fold_launches", "fold_bytes"):
-            res[key] = res_p[key]
-        res["serial_device_ms"] = res_p["gkr_device_ms"]
+        rows, per_launch, roof, res_p = profile_gkr(sess, tr, a.blocks if not a.randomize else 0)
 
         shard_sim = None
         if a.shard_sim > 1 and world == 1:
@@ -247,50 +449,12 @@ def main():
             tr_i, res_i, ok_i = sess.prove_interactive()
             interactive = {"prover_sec": res_i["prove_sec"], "wall_sec_with_host_verifier": time.perf_counter() - t_i,
                            "transcript_equals_batched": tr_i == tr, "verified": ok_i,
-                           "note": "reference definition of Prove Time (sum of prover-method spans), one launch + sync per round"}
+                           "note": "reference definition of Prove Time (sum of prover-method spans) over the interactive entry points (vp_round per verifier message)"}
             sess.draw_tape()
 
         pc = None
         if a.with_pc and rank == 0:
-            # BASELINE.json configs[2] flavour: the commitment's commit side on the GPU (not part of `value`)
-            import numpy as np
-            t1 = time.perf_counter()
-            full, okf = sess.prove_full(batched=True)
-            t_full = time.perf_counter() - t1
-            gname_ = gname
-            pc = {"full_proof_wall_sec": t_full, "full_transcript_verified": okf}
-            if gname_ in golden and "fri" in golden[gname_]:      # recorded runs of the real reference (full transcript + FRI steps)
-                from conftest import GOLDEN
-                gg = golden[gname_]
-                pc["full_transcript_bit_exact"] = (full == open(os.path.join(GOLDEN, gg["transcript"]), "rb").read())
-                fri = open(os.path.join(GOLDEN, gg["fri"]), "rb").read()
-                st = gg["fri_steps"]
-                rec = np.frombuffer(fri[:48 * st], dtype=np.uint64).reshape(st, 6)
-                sess.fri_commit(np.ascontiguousarray(rec[:, :2]))          # first call allocates the FRI buffers
-                sess.prove_full(batched=True)
-                t2 = time.perf_counter()
-                roots, fin = sess.fri_commit(np.ascontiguousarray(rec[:, :2]))
-                pc["fri_commit_wall_sec"] = time.perf_counter() - t2
-                pc["fri_commit_device_ms"] = sess.commit_device_ms()
-                pc["fri_roots_bit_exact"] = (roots == b"".join(rec[i, 2:].tobytes() for i in range(st)))
-            else:
-                # no recorded reference run at this size: fold with fresh challenges (any challenges exercise the same work)
-                st = circ.layer_bitlen(0) - 6
-                rr = np.random.default_rng(1).integers(0, (1 << 61) - 1, size=(st, 2), dtype=np.uint64)
-                sess.fri_commit(rr)                                         # first call allocates the FRI buffers
-                sess.prove_full(batched=True)
-                t2 = time.perf_counter()
-                sess.fri_commit(rr)
-                pc["fri_commit_wall_sec"] = time.perf_counter() - t2
-                pc["fri_commit_device_ms"] = sess.commit_device_ms()
-                pc["fri_steps"] = st
-            t3 = time.perf_counter(); _, ms_priv = sess.commit_private(); pc["commit_private_device_ms"] = ms_priv
-            pc["commit_private_wall_sec"] = time.perf_counter() - t3
-            pub = np.random.default_rng(2).integers(0, (1 << 61) - 1, size=(1 << circ.layer_bitlen(0), 2), dtype=np.uint64)
-            t4 = time.perf_counter(); ms_pub = sess.commit_public(pub)[3]; pc["commit_public_device_ms"] = ms_pub
-            pc["commit_public_wall_sec"] = time.perf_counter() - t4
-            pc["pc_commit_side_device_ms"] = ms_priv + ms_pub + pc.get("fri_commit_device_ms", 0.0)
-            pc["reference_pc_prove_sec_build_container"] = golden.get(gname_, {}).get("reference_pc_prove_sec_here")
+            pc = pc_leg(vp, sess, circ, golden, gname)
 
         bit_exact = None
         ref_ops = None
@@ -300,12 +464,13 @@ def main():
             if rank == 0:
                 gold = open(os.path.join(ROOT, "tests", "golden", g["transcript"]), "rb").read()[g["gkr_slice"][0]:g["gkr_slice"][1]]
                 bit_exact = (tr == gold)
-        ok, _ = sess.check(tr, skip_predicates=True)
+        # the reported flag is the FULL replay check (per-round identities, wiring predicates and getFinalValue on the device, Liu
+        # check, input check): the per-round identities alone hold by construction for the rounds whose b is derived
+        ok, sec_d = sess.check(tr, device_predicates=True)
         verify = None
         if rank == 0:      # the verifier's side of the same proof (outside the timed region): O(|C|) predicate loops on host vs on the GPU
             ok_h, sec_h = sess.check(tr)
-            ok_d, sec_d = sess.check(tr, device_predicates=True)
-            verify = {"host_predicates_sec": sec_h, "device_predicates_sec": sec_d, "accepted": bool(ok_h and ok_d),
+            verify = {"host_predicates_sec": sec_h, "device_predicates_sec": sec_d, "accepted": bool(ok_h and ok),
                       "note": "the verifier's O(|C|) loops on the device: wiring predicates (vp_predicates), gr of verifyLiu (vp_liu_gr), input-layer MLE (vp_layer_mle); the per-round checks stay on the host"}
 
         if rank == 0:
@@ -328,29 +493,14 @@ def main():
                 "prover_sec": sec_per_proof_job,
                 "prover_sec_device": 1e-3 * dev_ms / a.steps,
                 "rounds": res["rounds"], "kernel_launches_per_proof": res["launches"],
-                "bit_exact_vs_reference_golden": bit_exact, "host_verifier_accepts": ok,
+                "bit_exact_vs_reference_golden": bit_exact, "host_verifier_accepts": bool(ok),
+                "host_verifier_check": "full replay: per-round identities, wiring predicates + getFinalValue (device loops), Liu check, input-layer check",
                 "golden_origin": (golden[gname].get("origin", "the real reference binary (oracle/_ref/ref_run)") if gname in golden else None),
                 "interactive_path": interactive, "circuit_upload_sec": upload_sec, "verifier": verify,
+                "roofline": roof, "kernels": rows,
             }
-            if res["fold_launches"]:
-                avg_ms = res["fold_ms"] / res["fold_launches"]
-                gbps = res["fold_bytes"] / (res["fold_ms"] * 1e-3) / 1e9
-                traffic = None
-                pmc_file = PMC_SUMMARY if a.blocks == 64 else PMC_SUMMARY.replace("_b64", "_b%d" % a.blocks)
-                try:        # PMC pass of the same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs), committed summary
-                    if not a.randomize:
-                        traffic = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))["sumfold_avg_hbm_bytes_per_launch"]
-                except Exception:
-                    pass
-                line["roofline"] = {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                    "frac": gbps / HBM_PEAK_GBPS, "traffic": traffic,
-                                    "traffic_source": "profiles/%s (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)" % pmc_file if traffic else None,
-                                    "kernel": "k_sumfold3b_multi (every launch; single-stream replay of the same proof)",
-                                    "single_stream_proof_ms": res.get("serial_device_ms"),
-                                    "launches": res["fold_launches"], "avg_launch_us": 1e3 * avg_ms,
-                                    "algorithmic_bytes_per_launch": res["fold_bytes"] / res["fold_launches"]}
-            else:
-                line["roofline"] = None
+            if a.per_launch:
+                line["per_launch"] = per_launch
             if pc is not None:
                 line["polynomial_commitment"] = pc
             if shard_info is not None:
@@ -362,9 +512,12 @@ def main():
                 cb["host_cpu"] = cpu_model()
                 cb["host_cores_visible"] = os.cpu_count()
                 line["cpu_baseline"] = cb
-            print(json.dumps(line), flush=True)
         sess.close()
         circ.close()
+        if rank == 0:
+            if world == 1 and a.blocks == 64 and not a.randomize and not a.no_x1024_leg and not shard and "sha256_x1024" in golden:
+                line["x1024_with_pc"] = x1024_leg(vp, pws, golden, a, local)
+            print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

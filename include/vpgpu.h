@@ -4,7 +4,7 @@
  * (src/prover.h:12-66) whose only caller is `verifier` (src/verifier.cpp:24,137,151-152,156,203,206,
  * 220,242,247,261,289,293,308,379).  This header is the FFI that class would bind if its hot loops
  * lived on a GPU: one entry point per prover method on the sumcheck path.  The host
- * mirror of the class that calls these functions is virgo-plus_amd/host/vp_prover.{hpp,cpp}; the
+ * mirror of the class that calls these functions is virgo-plus_amd/host/prover.{hpp,cpp}; the
  * binding a reference maintainer would add is shown in INTEGRATION.md.
  *
  * Conventions
@@ -133,7 +133,8 @@ int vp_shard_chains(vp_ctx *, int32_t *owner, double *cost, int capacity, int *n
  * merkle_tree.cpp:7-51): Reed-Solomon encode (rate 1/32) the 64 slices of the input layer, hash the leaf
  * chains with SHA3-256 and build the Merkle tree; returns the root (merkle_root_l).  The codeword and the
  * tree stay in HBM for the later openings.  Needs bit_length(layer 0) >= 7 (vpd_verifier.cpp:115);
- * VP_ELIMIT if a slice is longer than the in-LDS transform handles (2^13 elements in this build).      */
+ * VP_ELIMIT if a slice is longer than 2^17 elements (input layer of more than 2^23 wires): transforms up to 2^13 run
+ * in LDS, longer ones through a register split in front of it.                                         */
 int vp_commit_private(vp_ctx *, uint8_t root[32]);
 /* prover::commit_public(pub, inner_product_sum, mask, all_sum) (src/prover.cpp:542-546 ->
  * poly_commit_prover::commit_public_array, poly_commit.h:126-349 -> fri::request_init_commit(.., 1)):
@@ -193,8 +194,35 @@ typedef struct {
     uint64_t launches;        /* kernel launches of the last proof                                          */
 } vp_stats;
 int vp_get_stats(vp_ctx *, vp_stats *out);
-/* 0: no per-kernel events (default); 1: bracket the dominant kernel's launches with hipEvents.          */
+/* 0: no per-kernel events (default); 1: the next vp_prove_gkr replays its launch plan on ONE stream and brackets EVERY
+ * launch with hipEvents (in the default run the launches of independent sumchecks overlap on several streams, so
+ * per-kernel times would be meaningless there); vp_commit_private / vp_commit_public / vp_fri_commit bracket their
+ * launches as well.  The table of the last profiled call is read with vp_get_launch_stats.                          */
 int vp_set_profiling(vp_ctx *, int level);
+
+/* One kernel launch of the last profiled call: which kernel, how much it covered, its ALGORITHMIC bytes (SURVEY.md §8d:
+ * fold launch = 48 B (32 B in the Liu phase) x (valid entries in + entries out), init = 48 B per gate contribution (16 B
+ * packed record + 16 B eq value + 16 B operand) + 4 B row pointer + the tables written, NTT = 16 B x (in + out) per pass,
+ * FRI fold = 48 B per output element, leaf hash = 32 B per chained block) and its duration.  `work` counts the kernel's
+ * own unit: F_p^2 multiplications for the transforms, Keccak-f[1600] permutations for the hash kernels, active pairs for
+ * the fold kernels, gate contributions for the init kernels.  `rounds`: sumcheck rounds the launch performs (fold: 3 per
+ * launch on every table it holds; closing kernels: the remaining ones), `first_round` the earliest of them (1-based).   */
+enum { VP_K_BETA = 0, VP_K_LIGHT, VP_K_CHUNKS, VP_K_COMBINE, VP_K_DOT, VP_K_DOTFIN, VP_K_SFGEN, VP_K_SF, VP_K_SEG, VP_K_EMIT,
+       VP_K_FIXUP, VP_K_NTT_SPLIT, VP_K_NTT_LDS, VP_K_NTT_UNSPLIT, VP_K_LEAF_HASH, VP_K_MERKLE, VP_K_PC_POINTWISE, VP_K_FRI_FOLD,
+       VP_K_ROUND, VP_K_COUNT };
+typedef struct {
+    int32_t kind;             /* VP_K_*                                                          */
+    int32_t step;             /* position in the launch order of the call                        */
+    uint32_t workgroups;      /* grid size                                                       */
+    uint32_t jobs;            /* independent sumchecks / transforms / trees the launch batches   */
+    uint32_t rounds, first_round;
+    uint64_t bytes;           /* algorithmic bytes                                               */
+    uint64_t work;            /* kind-specific unit count (see above)                            */
+    double us;                /* hipEvent duration in microseconds                               */
+} vp_launch_stat;
+/* Copies up to `capacity` entries; *n receives the number available.                                                */
+int vp_get_launch_stats(vp_ctx *, vp_launch_stat *out, int capacity, int *n);
+const char *vp_kernel_name(int kind);
 
 /* ---- primitives exported for parity tests (thin wrappers over the device functions) -------------- */
 /* out[i] = a[i] op b[i], op: 0 add, 1 sub, 2 mul (device arithmetic of fieldElement.cpp:34-104).       */
@@ -205,7 +233,7 @@ int vp_test_beta(vp_ctx *, const vp_F *r, int n, const vp_F *init, vp_F *out);
 int vp_test_sha3(vp_ctx *, const uint8_t *in, uint8_t *out, uint64_t n);
 /* fast_fourier_transform(coefs, coef_len, order) / inverse_fast_fourier_transform(evals, n, n)
  * (RS_polynomial.cpp:26-220), natural order in and out.  order/coef_len must be 1 or 32 for the forward
- * transform (the two shapes the commitment uses); sizes up to 2^13 per transform.                      */
+ * transform (the two shapes the commitment uses); sizes up to 2^17 per transform.                      */
 int vp_test_fft(vp_ctx *, const vp_F *coefs, int coef_len, int order, int inverse, vp_F *out);
 
 #ifdef __cplusplus

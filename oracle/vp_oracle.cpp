@@ -1021,6 +1021,17 @@ void orc_f_random_seq(unsigned seed, int n, orc_F *out) {
     srand(seed);
     for (int i = 0; i < n; ++i) fromF(frandom(), &out[i]);
 }
+// n further draws of F::random() from the CURRENT glibc state (no reseed): what the reference's verifier draws next.
+void orc_f_random_next(int n, orc_F *out) { for (int i = 0; i < n; ++i) fromF(frandom(), &out[i]); }
+// Number of F::random() draws fft_circuit_gkr::fft_gkr(lg) consumes (lib/virgo/src/fft_circuit_GKR.cpp), called from
+// verify_poly_commitment (vpd_verifier.cpp:92) BEFORE commit_phase draws the FRI fold challenges (:56):
+//   fft_gkr                 r[lg]                                              (:840)
+//   build_circuit           eval_points[64]                                    (:84)
+//   engage_gkr              refresh(r_0, lg+10), refresh(r_1, lg+10)           (:106 via :789-790)
+//   addition_layer          refresh(r_u), refresh(r_v), log_uv = lg + 6 each   (:275-276)
+//   mult_layer              refresh(r_u), refresh(r_v), lg each                (:394-395)
+//   ifft_gkr, per depth     refresh(r_u), refresh(r_v), lg each + alpha, beta  (:563-564, :763-764), lg depths
+int orc_fft_gkr_draws(int lg) { return lg + 64 + 2 * (lg + 10) + 2 * (lg + 6) + 2 * lg + lg * (2 * lg + 2); }
 void orc_beta_table(const orc_F *r, int n, const orc_F *init, orc_F *out) {
     vector<F> rr(n), beta;
     for (int i = 0; i < n; ++i) rr[i] = toF(&r[i]);

@@ -80,6 +80,13 @@ void orc_f_inv(const orc_F *a, orc_F *out);
 void orc_f_root_of_unity(int log_order, orc_F *out);
 /* srand(seed) then n draws of F::random() (fieldElement.cpp:119-124,362-367).                         */
 void orc_f_random_seq(unsigned seed, int n, orc_F *out);
+/* n further draws from the current glibc state (no reseed), e.g. right after orc_prove_full: the draws the
+ * reference's verifier makes next.                                                                     */
+void orc_f_random_next(int n, orc_F *out);
+/* F::random() draws consumed by fft_circuit_gkr::fft_gkr(lg) (lib/virgo/src/fft_circuit_GKR.cpp:84,106,763-764,840),
+ * which verify_poly_commitment runs (vpd_verifier.cpp:92) before commit_phase draws the FRI challenges (:56).
+ * Pinned by tests/test_oracle_golden.py against the challenges the real reference recorded.            */
+int orc_fft_gkr_draws(int lg);
 /* initBetaTable(beta, n, r, init): out has 2^n entries.                                               */
 void orc_beta_table(const orc_F *r, int n, const orc_F *init, orc_F *out);
 /* One call of prover::sumcheckUpdateEach on value tables (the .a parts implied zero / carried in

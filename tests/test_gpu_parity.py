@@ -231,9 +231,50 @@ def test_fiat_shamir_proof_round_trip(vp, gold_gkr, pws_path, make):
         bad = bytearray(proof); bad[pos] ^= 1
         assert not c.verify_fs(bytes(bad)), "tampered byte %d accepted" % pos
     assert not c.verify_fs(proof[:-16]) and not c.verify_fs(proof + bytes(16)) and not c.verify_fs(b"")
+    P = (1 << 61) - 1
+    for limb in (0, 3, n // 16, n // 8 - 1):        # same field element, non-canonical encoding (limb + p)
+        w = np.frombuffer(proof, dtype=np.uint64).copy()
+        w[limb] += np.uint64(P)
+        assert not c.verify_fs(w.tobytes()), "non-canonical limb %d accepted" % limb
     if make == "randomize" and os.environ.get("VP_WRITE_FS_FIXTURE"):
         open(os.environ["VP_WRITE_FS_FIXTURE"], "wb").write(proof)
     s.close(); c.close(); other.close()
+
+
+def test_launch_stats_table_covers_every_launch(vp, gold_gkr):
+    """vp_set_profiling + vp_get_launch_stats (include/vpgpu.h): the profiled replay produces the same transcript and a per-launch
+    table that names every kernel kind of the plan with its algorithmic bytes, rounds and an event-measured duration; the
+    commitment's calls report theirs."""
+    c = vp.Circuit.randomize(8, 12, seed=1)
+    s = vp.Session(c)
+    s.draw_tape()
+    tr, res = s.prove_gkr()
+    assert tr == gold_gkr("randomize_8_12")
+    s.set_profiling(1)
+    tr_p, res_p = s.prove_gkr()
+    st = s.launch_stats()
+    s.set_profiling(0)
+    assert tr_p == tr
+    kinds = {e["kernel"] for e in st}
+    assert {"k_beta_half_direct", "k_light_multi", "k_seg_multi", "k_emit_multi"} <= kinds
+    assert len(st) == res_p["launches"]
+    assert all(e["us"] > 0 for e in st)
+    assert all(e["bytes"] > 0 for e in st if e["kernel"] not in ("k_beta_half_direct", "k_fixup"))
+    covered = set()
+    for e in st:
+        if e["rounds"]:
+            covered |= set(range(e["first_round"], e["first_round"] + e["rounds"]))
+    assert 1 in covered and max(covered) >= c.layer_bitlen(0)       # the round-covering launches span round 1 .. the longest sumcheck
+    assert res_p["fold_launches"] == sum(1 for e in st if e["kernel"] == "k_sumfold3b_multi")
+    # the commitment's three calls
+    s.set_profiling(1)
+    s.commit_private()
+    cp = s.launch_stats()
+    assert {"k_ntt_lds", "k_leaf_hash", "k_merkle"} <= {e["kernel"] for e in cp}
+    leaf = [e for e in cp if e["kernel"] == "k_leaf_hash"][0]
+    assert leaf["work"] == 65 * (1 << (c.layer_bitlen(0) - 2))      # 65 chained Keccak-f per leaf, 2^(n-2) leaves (fri.cpp:96-124)
+    s.set_profiling(0)
+    s.close(); c.close()
 
 
 def test_randomize_transcript_matches_reference(vp, golden, gold_gkr):
@@ -683,8 +724,10 @@ def test_all_gate_types_full_protocol_vs_reference(vp, golden, name):
 @pytest.mark.parametrize("name,blocks", [("sha256_x1", 1), ("sha256_x16", 16)])
 def test_complete_protocol_with_commitment_verification(vp, golden, pws_path, name, blocks):
     """verifier::verify() end to end (src/verifier.cpp:134-189): commit_private, interactive GKR, commit_public, FRI
-    commit phase, 33 query repetitions answered by vp_fri_open and checked by the host verifier.  The transcript up to
-    all_sum is the real reference's; the FRI part uses fresh challenges (the reference's come after its fft_gkr draws)."""
+    commit phase, 33 query repetitions answered by vp_fri_open and checked by the host verifier.  ONE unbroken run, no recorded
+    challenge injected: the transcript up to all_sum, every FRI Merkle root, the fold challenges and the final codeword equal what
+    the real reference recorded (the host verifier consumes the draws of the reference's fft_gkr, vpd_verifier.cpp:92, so its FRI
+    challenges are the reference's)."""
     import os
     from conftest import GOLDEN
     c = vp.Circuit.from_pws(pws_path, blocks, seed=1)
@@ -692,6 +735,10 @@ def test_complete_protocol_with_commitment_verification(vp, golden, pws_path, na
     tr, ok, times = s.prove_and_verify_full(reps=33)
     assert ok
     assert tr == open(os.path.join(GOLDEN, golden[name]["transcript"]), "rb").read()
+    r_gold, roots_gold, fin_gold = _fri_golden(golden, name)
+    roots, fin, r = s.last_fri()
+    assert np.array_equal(r, r_gold), "FRI fold challenges differ from the reference's"
+    assert roots == roots_gold and np.array_equal(fin, fin_gold)
     s.close(); c.close()
 
 
@@ -704,6 +751,9 @@ def test_complete_protocol_custom_gates(vp, golden):
     s = vp.Session(c)
     tr, ok, _ = s.prove_and_verify_full(reps=8)
     assert ok and tr == open(os.path.join(GOLDEN, g["transcript"]), "rb").read()
+    r_gold, roots_gold, fin_gold = _fri_golden(golden, "custom_b")
+    roots, fin, r = s.last_fri()
+    assert np.array_equal(r, r_gold) and roots == roots_gold and np.array_equal(fin, fin_gold)
     s.close(); c.close()
 
 

@@ -99,6 +99,10 @@ def test_host_verifier_replay_accepts_golden(vp, gold_gkr, pws_path, name, block
     c = vp.Circuit.from_pws(pws_path, blocks, seed=1)
     tr = gold_gkr(name)
     assert c.verify_transcript(tr)
+    import numpy as np
+    w = np.frombuffer(tr, dtype=np.uint64).copy()
+    w[9] += np.uint64((1 << 61) - 1)               # non-canonical encoding of the same element: rejected, not reduced
+    assert not c.verify_transcript(w.tobytes())
     bad = bytearray(tr)
     bad[len(bad) // 2] ^= 1
     assert not c.verify_transcript(bytes(bad))
@@ -150,6 +154,13 @@ def test_fiat_shamir_verifier_on_host(vp, golden, gold_gkr):
         bad = bytearray(proof); bad[pos] ^= 0x80
         assert not c.verify_fs(bytes(bad))
     assert not c.verify_fs(proof[:-16]) and not c.verify_fs(b"")
+    # a limb shifted by p is the same field element in a non-canonical encoding: algebraically consistent, still rejected
+    import numpy as np
+    P = (1 << 61) - 1
+    for limb in (0, 1, 7, len(proof) // 8 - 1):
+        w = np.frombuffer(proof, dtype=np.uint64).copy()
+        w[limb] += np.uint64(P)
+        assert not c.verify_fs(w.tobytes()), "non-canonical limb %d accepted" % limb
     other = vp.Circuit.randomize(6, 8, seed=6)
     assert not other.verify_fs(proof)
     g = vp.Circuit.randomize(8, 12, seed=1)

@@ -212,6 +212,14 @@ def _fri_case(ob, golden, name, c):
     assert st == nb - 6
     rec = np.frombuffer(fri[:48 * st], dtype=np.uint64).reshape(st, 6)
     r = np.ascontiguousarray(rec[:, :2])
+    # The reference's FRI challenges are the verifier's NEXT draws after the ones fft_gkr consumes (vpd_verifier.cpp:92,56):
+    # continuing the glibc stream where orc_prove_full left it must reproduce the recorded challenges.
+    L.orc_f_random_next.argtypes = [ctypes.c_int, ctypes.c_void_p]
+    skip = L.orc_fft_gkr_draws(nb - 6)
+    assert skip == 2 * (nb - 6) ** 2 + 9 * (nb - 6) + 96
+    nxt = np.zeros((skip + st, 2), np.uint64)
+    L.orc_f_random_next(skip + st, nxt.ctypes.data)
+    assert np.array_equal(nxt[skip:], r), "fft_gkr draw count does not lead to the reference's FRI challenges"
     roots = ctypes.create_string_buffer(32 * st)
     fin = np.zeros((2048, 2), np.uint64)
     assert L.orc_fri_commit(inp.ctypes.data, pub.ctypes.data, nb, r.ctypes.data, roots, fin.ctypes.data) == 0

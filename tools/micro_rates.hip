@@ -27,6 +27,9 @@ template <int OP> __global__ void __launch_bounds__(256) k_rate(uint64_t *out, u
             else if (OP == 8) { uint32_t lo = (uint32_t) x[j], hi = (uint32_t) (x[j] >> 32);
                                 asm volatile("v_add_co_u32 %0, vcc, %0, %2\n v_addc_co_u32 %1, vcc, %1, %2, vcc" : "+v"(lo), "+v"(hi) : "v"(m) : "vcc"); x[j] = ((uint64_t) hi << 32) | lo; }
             else if (OP == 9) { uint32_t lo = (uint32_t) x[j]; asm volatile("v_mul_hi_u32_u24 %0, %0, %1" : "+v"(lo) : "v"(m)); x[j] = lo; }
+            else if (OP == 10) { uint32_t lo = (uint32_t) x[j]; asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(lo) : "v"(m), "v"((uint32_t) it)); x[j] = lo; }
+            else if (OP == 11) { uint32_t lo = (uint32_t) x[j]; asm volatile("v_alignbit_b32 %0, %0, %1, 7" : "+v"(lo) : "v"(m)); x[j] = lo; }
+            else if (OP == 12) { uint32_t lo = (uint32_t) x[j]; asm volatile("v_xor_b32 %0, %0, %1" : "+v"(lo) : "v"(m)); x[j] = lo; }
         }
     }
     uint64_t s = 0;
@@ -109,11 +112,11 @@ int main() {
     const int blocks = cus * 8;          // 256 threads = 4 waves = one per SIMD; 8 blocks per CU -> 8 waves per SIMD
     uint64_t *o; hipMalloc(&o, (size_t) blocks * 256 * 8);
     F *of; hipMalloc(&of, (size_t) blocks * 256 * 16);
-    const char *names[] = {"v_mad_u64_u32", "v_lshl_add_u64", "v_mul_lo_u32", "v_mul_hi_u32", "v_fma_f64", "v_add_u32", "v_mad_u32_u24", "v_lshlrev_b64", "add_co+addc (2 instr)", "v_mul_hi_u32_u24"};
+    const char *names[] = {"v_mad_u64_u32", "v_lshl_add_u64", "v_mul_lo_u32", "v_mul_hi_u32", "v_fma_f64", "v_add_u32", "v_mad_u32_u24", "v_lshlrev_b64", "add_co+addc (2 instr)", "v_mul_hi_u32_u24", "v_bitop3_b32", "v_alignbit_b32", "v_xor_b32"};
 #define RUN(OP) { double ms = time_ms([&] { hipLaunchKernelGGL(k_rate<OP>, dim3(blocks), dim3(256), 0, 0, o, 0x9E3779B97F4A7C15ull); }); \
         double winst = (double) blocks * 4 * ITER * 8; double cyc = ms * 1e-3 * ghz * 1e9 * cus * 4 / winst; \
         printf("%-24s %8.3f ms  %6.2f cycles per wave-instruction per SIMD\n", names[OP], ms, cyc); }
-    RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9)
+    RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10) RUN(11) RUN(12)
     const char *fn[] = {"f_mul", "f_lerp", "f_add", "f_mul4 (schoolbook)", "f_mul4w (weak red)", "f_mulKw (karatsuba weak)", "f_addw (weak)", "f_sub", "f_mad_lazy (a*b+c, 128-bit)", "f_mad31 (a*b+c)", "f_mad31 (a*b)"};
 #define RUNF(V) { double ms = time_ms([&] { hipLaunchKernelGGL(k_fmul<V>, dim3(blocks), dim3(256), 0, 0, of, f_make(123456789123ull, 987654321987ull)); }); \
         double ops = (double) blocks * 256 * ITER * 4; double cyc = ms * 1e-3 * ghz * 1e9 * cus * 4 / (ops / 64); \

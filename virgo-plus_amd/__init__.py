@@ -77,6 +77,12 @@ class VphResult(ctypes.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class LaunchStat(ctypes.Structure):          # vp_launch_stat (include/vpgpu.h)
+    _fields_ = [("kind", ctypes.c_int32), ("step", ctypes.c_int32), ("workgroups", ctypes.c_uint32), ("jobs", ctypes.c_uint32),
+                ("rounds", ctypes.c_uint32), ("first_round", ctypes.c_uint32), ("bytes", ctypes.c_uint64), ("work", ctypes.c_uint64),
+                ("us", ctypes.c_double)]
+
+
 _gpu = None
 _host = None
 
@@ -98,6 +104,9 @@ def lib_gpu():
         L.vp_test_beta.argtypes = [vp, vp, ctypes.c_int, vp, vp]
         L.vp_test_sha3.argtypes = [vp, vp, vp, ctypes.c_uint64]
         L.vp_test_fft.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
+        L.vp_get_launch_stats.argtypes = [vp, ctypes.POINTER(LaunchStat), ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+        L.vp_kernel_name.argtypes = [ctypes.c_int]
+        L.vp_kernel_name.restype = ctypes.c_char_p
         _gpu = L
     return _gpu
 
@@ -130,6 +139,8 @@ def lib_host():
         L.vph_session_create.argtypes = [vp, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
         L.vph_session_free.argtypes = [vp]
         L.vph_set_profiling.argtypes = [vp, ctypes.c_int]
+        L.vph_session_ctx.restype = vp
+        L.vph_session_ctx.argtypes = [vp]
         L.vph_layer_values.argtypes = [vp, ctypes.c_int, vp, u64]
         L.vph_prove_interactive.argtypes = [vp, vp, u64, ctypes.POINTER(u64), ctypes.POINTER(VphResult), ctypes.c_char_p,
                                             ctypes.c_int]
@@ -140,6 +151,7 @@ def lib_host():
         L.vph_commit_public.argtypes = [vp, vp, u64, vp, ctypes.POINTER(ctypes.c_double), ctypes.c_char_p, ctypes.c_int]
         L.vph_prove_full.argtypes = [vp, vp, u64, ctypes.POINTER(u64), ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
         L.vph_prove_and_verify_full.argtypes = [vp, ctypes.c_int, vp, u64, ctypes.POINTER(u64)] + [ctypes.POINTER(ctypes.c_double)] * 3 + [ctypes.c_char_p, ctypes.c_int]
+        L.vph_last_fri.argtypes = [vp, vp, u64, vp, vp]
         L.vph_test_sha3.argtypes = [vp, vp, u64]
         L.vph_fri_commit.argtypes = [vp, vp, ctypes.c_int, vp, vp, ctypes.c_char_p, ctypes.c_int]
         L.vph_fri_commit_batched.argtypes = [vp, vp, ctypes.c_int, vp, vp, ctypes.c_char_p, ctypes.c_int]
@@ -260,6 +272,21 @@ class Session:
     def set_profiling(self, level):
         lib_host().vph_set_profiling(self.h, level)
 
+    def launch_stats(self):
+        """Per-launch table of the last profiled call (set_profiling(1), then prove_gkr / commit_private / commit_public /
+        fri_commit): list of dicts {kernel, step, workgroups, jobs, rounds, first_round, bytes, work, us}."""
+        ctx = lib_host().vph_session_ctx(self.h)
+        n = ctypes.c_int(0)
+        lib_gpu().vp_get_launch_stats(ctx, None, 0, ctypes.byref(n))
+        arr = (LaunchStat * max(1, n.value))()
+        lib_gpu().vp_get_launch_stats(ctx, arr, n.value, ctypes.byref(n))
+        out = []
+        for i in range(n.value):
+            e = arr[i]
+            out.append({"kernel": lib_gpu().vp_kernel_name(e.kind).decode(), "step": e.step, "workgroups": e.workgroups, "jobs": e.jobs,
+                        "rounds": e.rounds, "first_round": e.first_round, "bytes": e.bytes, "work": e.work, "us": e.us})
+        return out
+
     def layer_values(self, layer):
         import numpy as np
         n = self.circuit.layer_size(layer)
@@ -367,6 +394,17 @@ class Session:
         if rc < 0:
             raise RuntimeError("prove_and_verify_full failed: " + err.value.decode())
         return buf.raw[: n.value], rc == 0, {"gkr_prove_sec": t[0].value, "pc_prove_sec": t[1].value, "verify_sec": t[2].value}
+
+    def last_fri(self):
+        """FRI commit phase of the last prove_and_verify_full(): (roots bytes, final codeword (2048, 2), challenges (steps, 2))."""
+        import numpy as np
+        roots = ctypes.create_string_buffer(32 * 32)
+        fin = np.zeros((2048, 2), dtype=np.uint64)
+        r = np.zeros((32, 2), dtype=np.uint64)
+        st = lib_host().vph_last_fri(self.h, ctypes.cast(roots, ctypes.c_void_p), len(roots), fin.ctypes.data, r.ctypes.data)
+        if st < 0:
+            raise RuntimeError("no complete-protocol run on this session yet")
+        return roots.raw[:32 * st], fin, r[:st].copy()
 
     def fri_commit(self, r, batched=True):
         """FRI commit phase with the given fold challenges ((steps, 2) uint64): (roots bytes, final codeword (2048, 2)).

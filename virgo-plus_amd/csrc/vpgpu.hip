@@ -20,7 +20,7 @@ static_assert(sizeof(vp_F) == sizeof(F), "vp_F layout");
 namespace {
 
 struct Csr {                 // contributions of one layer sorted by target row (see vp_kernels.h K2/K3)
-    u32 n_rows = 0, n_entries = 0, n_heavy = 0, n_chunks = 0;
+    u32 n_rows = 0, n_entries = 0, n_heavy = 0, n_chunks = 0, n_heavy_entries = 0;
     u32 *rowptr = nullptr, *e_g = nullptr, *e_x = nullptr;
     uint16_t *e_tl = nullptr;
     u32 *heavy_row = nullptr, *heavy_cptr = nullptr, *chunk_beg = nullptr, *chunk_end = nullptr;
@@ -43,7 +43,7 @@ struct LayerDev {
     u32 n_jobs = 0; BetaJob *jobs = nullptr; std::vector<int> job_k, job_h1;
     // batched path: per-slot V gather map, Liu gather lists, half tables of this layer's sumchecks
     uint8_t *s_layer = nullptr; u32 *s_idx = nullptr;
-    u32 *lrow = nullptr, *l_g = nullptr; uint8_t *l_q = nullptr;
+    u32 *lrow = nullptr, *l_g = nullptr; uint8_t *l_q = nullptr; u32 l_n = 0;      // l_n: entries of the Liu gather lists
     Half hg{}, hu{};
     Half *liu_H = nullptr;
     // verifier-side predicates (vp_predicates): gates listed by bucket, pieces of <= 512
@@ -58,7 +58,7 @@ struct SumcheckState {
     const F *V0 = nullptr, *M0 = nullptr, *A0 = nullptr;     // round-1 sources
 };
 
-struct EvPair { hipEvent_t a, b; u64 bytes; };
+struct EvPair { hipEvent_t a, b; u64 bytes; int kind; u32 grid, jobs, rounds, first_round; u64 work; };
 
 }  // namespace
 
@@ -74,14 +74,18 @@ struct Lane {
 // Batched launch plan of the GKR part (see vp_kernels.h "Batched launches"): recorded once per circuit by running the
 // per-sumcheck drivers in record mode (same code that launches directly on the lane path), then merged step by step.
 enum { NK_LIGHT = 0, NK_CHUNKS, NK_COMBINE, NK_DOT, NK_DOTFIN, NK_SFGEN, NK_SF, NK_SEG, NK_EMIT, NK_COUNT };
-struct PStep { int kind; u32 idx, grid, lds; u64 bytes; int rounds; int xchain; };   // kind -1: placeholder step; xchain: also wait for that chain's latest node
+struct PStep { int kind; u32 idx, grid, lds; u64 bytes; int rounds; int xchain; u64 work = 0; int first_round = 0, n_rounds = 0; };   // kind -1: placeholder step; xchain: also wait for that chain's latest node
 struct PlanRec {
     std::vector<LightJob> light; std::vector<ChunkJob> chunks; std::vector<CombineJob> combine; std::vector<DotJob> dot;
     std::vector<SfArgs> sf; std::vector<SfGenJob> sfgen; std::vector<SegArgs> seg; std::vector<EmitArgs> emit;
     std::vector<std::vector<PStep>> chains; int cur = -1;
-    void push(int kind, u32 idx, u32 grid, u32 lds = 0, u64 bytes = 0) { chains[cur].push_back(PStep{kind, idx, grid, lds, bytes, 0, -1}); }
+    void push(int kind, u32 idx, u32 grid, u32 lds = 0, u64 bytes = 0, u64 work = 0, int first_round = 0, int n_rounds = 0) {
+        PStep st{kind, idx, grid, lds, bytes, 0, -1};
+        st.work = work; st.first_round = first_round; st.n_rounds = n_rounds;
+        chains[cur].push_back(st);
+    }
 };
-struct PNode { int kind = 0, step = 0, stream = 0; u32 first = 0, count = 0, grid = 0, lds = 0, map_off = 0; u64 bytes = 0;
+struct PNode { int kind = 0, step = 0, stream = 0; u32 first = 0, count = 0, grid = 0, lds = 0, map_off = 0; u64 bytes = 0, work = 0; int first_round = 0, n_rounds = 0;
                std::vector<int> deps; hipEvent_t ev = nullptr; bool record = false; };
 struct Plan {
     std::vector<PNode> nodes;
@@ -91,6 +95,7 @@ struct Plan {
     hipEvent_t ev_root = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     u64 rounds = 0; int n_steps = 0, sf_rounds = 3;
     FixJob *d_fix = nullptr; u32 n_fix = 0;          // k_fixup jobs (when round 1 of the sumchecks leaves its b to the fix-up pass)
+    std::vector<void *> allocs;                      // device arrays owned by the plan (freed with it)
 };
 
 struct vp_ctx {
@@ -122,6 +127,8 @@ struct vp_ctx {
     int profiling = 0;
     vp_stats st{};
     std::vector<EvPair> ev_pool; size_t ev_used = 0;
+    std::vector<vp_launch_stat> lstats;   // per-launch table of the last profiled call (vp_get_launch_stats)
+    u64 rec_gen_bytes = 0, rec_gen_work = 0;      // record mode: algorithmic bytes / contributions of the init fused into the next fold launch
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<void *> allocs;
     BetaJob *all_jobs = nullptr; u32 n_all_jobs = 0, beta_bpj = 1; F *half_pool = nullptr;
@@ -220,6 +227,8 @@ int build_csr(vp_ctx *ctx, Csr &c, u32 n_rows, const std::vector<u32> &key, cons
         heavy_cptr.push_back((u32) cb.size());
     }
     c.n_rows = n_rows; c.n_entries = n; c.n_heavy = (u32) heavy_row.size(); c.n_chunks = (u32) cb.size();
+    c.n_heavy_entries = 0;
+    for (size_t q = 0; q < cb.size(); ++q) c.n_heavy_entries += ce[q] - cb[q];
     VPCHK(dupload(ctx, &c.rowptr, rowptr));
     VPCHK(dupload(ctx, &c.e_g, sg));
     VPCHK(dupload(ctx, &c.e_x, sx));
@@ -233,6 +242,30 @@ int build_csr(vp_ctx *ctx, Csr &c, u32 n_rows, const std::vector<u32> &key, cons
 }
 
 void count_launch(vp_ctx *ctx) { ++ctx->st.launches; }
+
+// Profiled calls bracket each launch with a pair of events from the pool (on the stream the launch goes to) and collect
+// the table afterwards.  prof_begin returns the pool slot or -1 (not profiling / pool exhausted).
+int prof_begin(vp_ctx *ctx, hipStream_t st, int kind, u32 grid, u32 jobs, u64 bytes, u64 work, u32 rounds = 0, u32 first_round = 0) {
+    if (!ctx->profiling || ctx->ev_used >= ctx->ev_pool.size()) return -1;
+    EvPair &e = ctx->ev_pool[ctx->ev_used];
+    e.kind = kind; e.grid = grid; e.jobs = jobs; e.bytes = bytes; e.work = work; e.rounds = rounds; e.first_round = first_round;
+    hipEventRecord(e.a, st);
+    return (int) ctx->ev_used++;
+}
+void prof_end(vp_ctx *ctx, hipStream_t st, int slot) { if (slot >= 0) hipEventRecord(ctx->ev_pool[slot].b, st); }
+// after the stream has been waited for: durations of the bracketed launches -> ctx->lstats
+void prof_collect(vp_ctx *ctx) {
+    ctx->lstats.clear();
+    for (size_t e = 0; e < ctx->ev_used; ++e) {
+        const EvPair &p = ctx->ev_pool[e];
+        float t = 0;
+        if (hipEventElapsedTime(&t, p.a, p.b) != hipSuccess) t = 0;
+        vp_launch_stat s{};
+        s.kind = p.kind; s.step = (int) e; s.workgroups = p.grid; s.jobs = p.jobs; s.rounds = p.rounds; s.first_round = p.first_round;
+        s.bytes = p.bytes; s.work = p.work; s.us = 1e3 * (double) t;
+        ctx->lstats.push_back(s);
+    }
+}
 
 // ---- internal phase drivers (all arguments already on the device tape) -----------------------------
 int run_beta_half(vp_ctx *ctx, const F *r, int n, const F *init) {
@@ -388,11 +421,10 @@ int do_round(vp_ctx *ctx, const F *rp, const F &rv, F *poly_dev, F *poly_host) {
     if (pairs) {
         grid = grid_for(pairs);
         const bool big = pairs >= VP_BIG_PAIRS;
-        const bool prof = ctx->profiling && big && ctx->ev_used < ctx->ev_pool.size();
-        if (prof) hipEventRecord(ctx->ev_pool[ctx->ev_used].a, ctx->stream);
+        const int sl = big ? prof_begin(ctx, ctx->stream, VP_K_ROUND, grid, 1, bytes, pairs, 1, (u32) k) : -1;
         if (big) hipLaunchKernelGGL(k_round_main<1>, dim3(grid), dim3(VP_BLOCK), 0, ctx->stream, a, ctx->partials);
         else hipLaunchKernelGGL(k_round_main<0>, dim3(grid), dim3(VP_BLOCK), 0, ctx->stream, a, ctx->partials);
-        if (prof) { hipEventRecord(ctx->ev_pool[ctx->ev_used].b, ctx->stream); ctx->ev_pool[ctx->ev_used++].bytes = bytes; }
+        prof_end(ctx, ctx->stream, sl);
         count_launch(ctx);
     }
     hipLaunchKernelGGL(k_round_final, dim3(1), dim3(VP_BLOCK), 0, ctx->stream, a, ctx->partials, grid, ctx->add_term(),
@@ -739,6 +771,7 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
                 ++q;
             }
             VPCHK(dupload(ctx, &D.lrow, rp)); VPCHK(dupload(ctx, &D.l_g, eg)); VPCHK(dupload(ctx, &D.l_q, eq));
+            D.l_n = rp[rows];
         }
         VPCHK(dalloc(ctx, &ctx->part2, (size_t) 32 * MAX_BLOCKS * 3));
         // lanes: per-layer scratch for the concurrent chains
@@ -795,7 +828,7 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
     // event pool for the profiled launches
     if (ctx->ev_pool.empty()) {
         ctx->ev_pool.resize(1024);
-        for (auto &e : ctx->ev_pool) { hipEventCreate(&e.a); hipEventCreate(&e.b); e.bytes = 0; }
+        for (auto &e : ctx->ev_pool) { hipEventCreate(&e.a); hipEventCreate(&e.b); e.bytes = 0; e.kind = -1; e.grid = e.jobs = e.rounds = e.first_round = 0; e.work = 0; }
     }
     return VP_OK;
 }
@@ -1102,6 +1135,7 @@ int vp_prove_gkr(vp_ctx *ctx, const vp_F *tape, uint64_t n_tape, uint8_t *transc
     hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
     ctx->st.gkr_ms = ms;
     ctx->st.fold_ms = 0; ctx->st.fold_bytes = 0; ctx->st.fold_launches = ctx->ev_used;
+    if (ctx->profiling) prof_collect(ctx);
     for (size_t e = 0; e < ctx->ev_used; ++e) {
         float t = 0;
         hipEventElapsedTime(&t, ctx->ev_pool[e].a, ctx->ev_pool[e].b);
@@ -1120,6 +1154,18 @@ int vp_set_profiling(vp_ctx *ctx, int level) {
     if (!ctx) return VP_EINVAL;
     ctx->profiling = level;
     return VP_OK;
+}
+int vp_get_launch_stats(vp_ctx *ctx, vp_launch_stat *out, int capacity, int *n) {
+    if (!ctx || !n || (capacity > 0 && !out)) return VP_EINVAL;
+    *n = (int) ctx->lstats.size();
+    for (int i = 0; i < *n && i < capacity; ++i) out[i] = ctx->lstats[i];
+    return VP_OK;
+}
+const char *vp_kernel_name(int kind) {
+    static const char *names[VP_K_COUNT] = {"k_beta_half_direct", "k_light_multi", "k_chunks_multi", "k_combine_multi", "k_dot_multi", "k_dotfin_multi",
+        "k_sumfold3b_gen_multi", "k_sumfold3b_multi", "k_seg_multi", "k_emit_multi", "k_fixup", "k_ntt_split", "k_ntt_lds", "k_ntt_unsplit",
+        "k_leaf_hash", "k_merkle", "k_pc_pointwise", "k_fri_fold", "k_round"};
+    return (kind >= 0 && kind < VP_K_COUNT) ? names[kind] : "?";
 }
 
 int vp_test_field(vp_ctx *ctx, int op, const vp_F *a, const vp_F *b, vp_F *out, uint64_t n) {

@@ -57,8 +57,16 @@ prover::prover(const layeredCircuit &cir, int device) : C(cir) {
         d.is_assert = any_as ? f.as.data() : nullptr;
         d.dad_size = f.dsz.data(); d.dad_bitlen = f.dbl.data(); d.dad_id = f.dptr.data();
     }
-    check(vp_circuit_upload(ctx, n, desc.data()), "vp_circuit_upload");
-    evaluate();
+    // the destructor of a partially constructed object never runs: release the context (streams, pinned buffers, the circuit and
+    // witness in HBM) before the exception leaves, e.g. when evaluate() reports a violated assert gate (VP_EASSERT)
+    try {
+        check(vp_circuit_upload(ctx, n, desc.data()), "vp_circuit_upload");
+        evaluate();
+    } catch (...) {
+        vp_destroy(ctx);
+        ctx = nullptr;
+        throw;
+    }
 }
 
 prover::~prover() { vp_destroy(ctx); }

@@ -55,4 +55,35 @@ inline hhash_digest hhash(const uint64_t m[4], const hhash_digest &prev) {
     return d;
 }
 
+// Streaming SHA3-256 (FIPS 202 sponge, rate 136 bytes): the statement digest of the Fiat-Shamir mode absorbs the whole
+// serialised circuit and its input values through it (verifier::fsInit).
+class sha3_256 {
+public:
+    void update(const void *data, size_t n) {
+        const uint8_t *p = static_cast<const uint8_t *>(data);
+        while (n) {
+            const size_t take = n < 136 - fill ? n : 136 - fill;
+            memcpy(buf + fill, p, take);
+            fill += take; p += take; n -= take;
+            if (fill == 136) { absorb(); fill = 0; }
+        }
+    }
+    void put64(uint64_t x) { update(&x, 8); }
+    hhash_digest final() {
+        memset(buf + fill, 0, 136 - fill);
+        buf[fill] ^= 0x06; buf[135] ^= 0x80;
+        absorb();
+        hhash_digest d; memcpy(d.w, s, 32);
+        return d;
+    }
+private:
+    void absorb() {
+        for (int i = 0; i < 17; ++i) { uint64_t w; memcpy(&w, buf + 8 * i, 8); s[i] ^= w; }
+        keccak_f1600(s);
+    }
+    uint64_t s[25] = {0};
+    uint8_t buf[136];
+    size_t fill = 0;
+};
+
 }  // namespace vph

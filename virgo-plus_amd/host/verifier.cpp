@@ -42,10 +42,14 @@ verifier::verifier(prover *pr, const layeredCircuit &cir) : p(pr), C(cir) {     
 void verifier::fsInit() {
     fs_state = vph::hhash_digest{};
     fs_ctr = 0;
-    u64 h[2];
-    C.structuralHash(h);
-    const uint64_t m[4] = {h[0], h[1], (uint64_t) C.size, 0x53};                 // statement: the levelised circuit
+    // statement: SHA3-256 over the serialised levelised circuit, subset tables and input values (layeredCircuit::statementDigest);
+    // the non-cryptographic structuralHash is a test fingerprint only and is not used here
+    u64 h[4];
+    C.statementDigest(h);
+    const uint64_t m[4] = {h[0], h[1], h[2], h[3]};
     fs_state = vph::hhash(m, fs_state);
+    const uint64_t m2[4] = {(uint64_t) C.size, 0, 0, 0x53};
+    fs_state = vph::hhash(m2, fs_state);
 }
 F verifier::draw() {
     if (fs) {
@@ -79,6 +83,9 @@ F verifier::nextF() {
     unsigned long long w[2];
     memcpy(w, rtr->data() + tr_pos, 16);
     tr_pos += 16;
+    // a proof element must be the canonical representative: the host arithmetic (single conditional subtract, 125-bit reduce)
+    // is only F_p^2 arithmetic on limbs < p, and every limb would otherwise have up to 8 accepted encodings
+    if (w[0] >= F::mod || w[1] >= F::mod) throw std::runtime_error("non-canonical field element in the proof");
     x.real = w[0]; x.img = w[1];
     return x;
 }
@@ -128,7 +135,8 @@ bool verifier::checkFS(const std::vector<uint8_t> &proof) {
 }
 bool verifier::check(const std::vector<F> &tape, const std::vector<uint8_t> &transcript) {
     replay = true; rtape = &tape; rtr = &transcript; tape_pos = 0; tr_pos = 0; tr.clear();
-    bool ok = run();
+    bool ok = false;
+    try { ok = run(); } catch (const std::runtime_error &) { ok = false; }      // truncated transcript / non-canonical element
     return ok && tr_pos == transcript.size() && tape_pos == tape.size();
 }
 
@@ -428,6 +436,11 @@ bool verifier::verifyPoly(const prover::hhash_digest &root_l_raw, const F &claim
         if (s != input_0) { fprintf(stderr, "commitment: slice sums do not match the inner product\n"); return false; }
     }
     poly_timer.stop();
+    // verify_poly_commitment runs fft_circuit_gkr::fft_gkr(ln) here (vpd_verifier.cpp:92), a self-contained GKR over the iFFT
+    // circuit whose verifier draws come from the same glibc stream.  Its messages never leave that function; what the rest of
+    // the protocol sees of it is the number of F::random() draws it consumes, so the FRI fold challenges below — and the
+    // rand() query positions after them — are the reference's own (pinned against its recorded challenges at ln = 6, 7, 11).
+    for (int k = fftGkrDraws(ln); k > 0; --k) (void) F::random();
     // FRI commit phase (vpd_verifier.cpp:44-74): the fold challenges are drawn here
     std::vector<F> fr(ln);
     std::vector<vph::hhash_digest> roots(ln);
@@ -439,6 +452,9 @@ bool verifier::verifyPoly(const prover::hhash_digest &root_l_raw, const F &claim
     } else
         for (int k = 0; k < ln; ++k) { fr[k] = F::random(); roots[k] = dig(p->friStep(fr[k])); }
     const std::vector<F> final_code = p->friFinal();
+    fri_roots_.clear();
+    for (int k = 0; k < ln; ++k) { const uint8_t *b = reinterpret_cast<const uint8_t *>(roots[k].w); fri_roots_.insert(fri_roots_.end(), b, b + 32); }
+    fri_final_ = final_code; fri_r_ = fr;
     poly_prove_timer.stop();
     poly_timer.start();
     // the last codeword must be constant on its 32-point domain, per slice (vpd_verifier.cpp:309-324)
@@ -498,6 +514,11 @@ bool verifier::verifyPoly(const prover::hhash_digest &root_l_raw, const F &claim
     poly_timer.stop();
     return true;
 }
+
+// F::random() draws of fft_circuit_gkr::fft_gkr(lg) (lib/virgo/src/fft_circuit_GKR.cpp): r[lg] (:840), eval_points[64] (:84),
+// r_0 and r_1 of lg + 10 entries (:789-790 via :106), the addition layer's r_u / r_v of lg + 6 (:275-276), the multiplication
+// layer's of lg (:394-395), and per iFFT depth (lg of them) r_u / r_v of lg plus alpha and beta (:563-564, :763-764).
+int verifier::fftGkrDraws(int lg) { return lg + 64 + 2 * (lg + 10) + 2 * (lg + 6) + 2 * lg + lg * (2 * lg + 2); }
 
 bool verifier::verifyFull(int reps) {
     if (!p) throw std::runtime_error("verifyFull(): no prover attached");

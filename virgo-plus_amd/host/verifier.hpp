@@ -27,6 +27,11 @@ public:
     prover *pred_dev = nullptr;     // when set, the O(|C|) predicate loops run on the device (prover::predicates) instead of the host
     bool fri_batched = true;        // FRI commit phase as one device pass (prover::friCommit) instead of one friStep per challenge
     const std::vector<uint8_t> &fullTranscript() const { return full_tr; }
+    // FRI commit phase of the last verifyFull(): Merkle root per fold step (32 bytes each), final codeword (2048), fold challenges
+    const std::vector<uint8_t> &friRoots() const { return fri_roots_; }
+    const std::vector<F> &friFinalCode() const { return fri_final_; }
+    const std::vector<F> &friChallenges() const { return fri_r_; }
+    static int fftGkrDraws(int lg);
     double polyVerifyTime() const { return poly_timer.elapse_sec(); }
     double polyProveTime() const { return poly_prove_timer.elapse_sec(); }
     // Fiat-Shamir mode (the reference's GKRProof.hpp / transcriptCache.hpp are dead code, so this is a separate
@@ -86,6 +91,7 @@ private:
     std::vector<std::vector<F>> final_claims_v;
     timer verify_timer, poly_timer, poly_prove_timer;
     std::vector<uint8_t> full_tr;
+    std::vector<uint8_t> fri_roots_; std::vector<F> fri_final_, fri_r_;
     bool input_check_by_commitment = false;
     F last_claim;
 };

@@ -13,6 +13,7 @@ struct vph_session {
     vph_circuit *circ;
     std::unique_ptr<prover> p;
     std::vector<F> tape;
+    std::vector<uint8_t> fri_roots; std::vector<F> fri_final, fri_r;      // FRI commit phase of the last complete-protocol run
 };
 
 static void set_err(char *err, int errlen, const std::string &m) {
@@ -87,6 +88,7 @@ vph_session *vph_session_create(vph_circuit *c, int device, char *err, int errle
 }
 void vph_session_free(vph_session *s) { delete s; }
 int vph_set_profiling(vph_session *s, int level) { return vp_set_profiling(s->p->context(), level); }
+void *vph_session_ctx(vph_session *s) { return s ? (void *) s->p->context() : nullptr; }
 
 int vph_layer_values(vph_session *s, int layer, uint64_t *out, uint64_t n) {
     try {
@@ -234,6 +236,7 @@ int vph_prove_and_verify_full(vph_session *s, int reps, uint8_t *transcript, uin
         verifier v(s->p.get(), s->circ->c);
         const double t0 = s->p->proveTime();
         const bool ok = v.verifyFull(reps);
+        s->fri_roots = v.friRoots(); s->fri_final = v.friFinalCode(); s->fri_r = v.friChallenges();
         const auto &tr = v.fullTranscript();
         if (tr.size() > capacity) { set_err(err, errlen, "transcript buffer too small"); return -1; }
         memcpy(transcript, tr.data(), tr.size());
@@ -246,6 +249,17 @@ int vph_prove_and_verify_full(vph_session *s, int reps, uint8_t *transcript, uin
         set_err(err, errlen, e.what());
         return -2;
     }
+}
+
+// FRI data of the last vph_prove_and_verify_full on this session: roots (32 bytes per step), final codeword (2048 elements),
+// challenges (16 bytes per step); returns the number of fold steps or -1.
+int vph_last_fri(vph_session *s, uint8_t *roots, uint64_t roots_cap, uint64_t *final_pairs, uint64_t *r_pairs) {
+    if (!s || s->fri_roots.empty()) return -1;
+    const int steps = (int) (s->fri_roots.size() / 32);
+    if (roots) { if (roots_cap < s->fri_roots.size()) return -1; memcpy(roots, s->fri_roots.data(), s->fri_roots.size()); }
+    if (final_pairs) memcpy(final_pairs, s->fri_final.data(), s->fri_final.size() * sizeof(F));
+    if (r_pairs) memcpy(r_pairs, s->fri_r.data(), s->fri_r.size() * sizeof(F));
+    return steps;
 }
 
 void vph_test_sha3(const uint8_t *in, uint8_t *out, uint64_t n) {

@@ -43,6 +43,8 @@ void vph_circuit_hash(const vph_circuit *, uint64_t out[2]);
 vph_session *vph_session_create(vph_circuit *, int device, char *err, int errlen);
 void vph_session_free(vph_session *);
 int vph_set_profiling(vph_session *, int level);
+/* the vp_ctx behind the session's prover (for the measurement calls of include/vpgpu.h: vp_get_launch_stats, ...) */
+void *vph_session_ctx(vph_session *);
 /* circuitValue[layer] copied back (tests).                                                             */
 int vph_layer_values(vph_session *, int layer, uint64_t *out_pairs, uint64_t n);
 
@@ -70,6 +72,9 @@ int vph_commit_public(vph_session *, const uint64_t *pub_pairs, uint64_t n_pub, 
  * layout (identical to the reference's up to all_sum); times in seconds.                                  */
 int vph_prove_and_verify_full(vph_session *, int reps, uint8_t *transcript, uint64_t capacity, uint64_t *n_written,
                               double *gkr_prove_sec, double *pc_prove_sec, double *verify_sec, char *err, int errlen);
+/* FRI commit phase of the last vph_prove_and_verify_full: Merkle root per fold step (32 bytes each), final codeword (2048
+ * elements), fold challenges (one element per step); any pointer may be NULL.  Returns the number of steps or -1. */
+int vph_last_fri(vph_session *, uint8_t *roots, uint64_t roots_cap, uint64_t *final_pairs, uint64_t *r_pairs);
 /* my_hhash on the host (verifier side): SHA3-256 of n 64-byte messages.                                   */
 void vph_test_sha3(const uint8_t *in, uint8_t *out, uint64_t n);
 /* poly_commit_prover::commit_phase (vpd_verifier.cpp:44-74) with caller-supplied fold challenges: n_steps calls of
