@@ -34,10 +34,10 @@ PMC_SUMMARIES = ("r02_pmc_summary_b%d.json", "r01_l_pmc_summary_b%d.json")
 # (profiles/r02_micro_rates.txt; 256 CUs x 4 SIMDs at 2.4 GHz, 8 waves per SIMD):
 #   F_p^2 multiply (31-bit split form, 16 v_mad_u64_u32 + Mersenne folds): 6.1e11 per second for the whole chip;
 #   Keccak-f[1600] as 24 rounds x 180 VALU instructions (v_bitop3_b32 / v_alignbit_b32) at the measured issue cost of those two.
-FMUL_PEAK_PER_S = 6.1e11
-KECCAK_INSTR = 24 * 180
-VALU_LOGIC_CYCLES = 3.0         # measured cycles per wave-instruction per SIMD for v_bitop3_b32 / v_alignbit_b32 (same as v_add_u32)
-KECCAK_PEAK_PER_S = 1024 * 64 * 2.4e9 / (KECCAK_INSTR * VALU_LOGIC_CYCLES)
+FMUL_PEAK_PER_S = 7.0e11        # f_mul: 224.8 SIMD-cycles per wave-multiply
+# one Keccak round = 120 v_bitop3_b32 (3.20 cycles per wave-instruction per SIMD) + 58 v_alignbit_b32 (4.43) + 2 v_xor_b32 (2.78)
+KECCAK_CYCLES_PER_WAVE_PERM = 24 * (120 * 3.20 + 58 * 4.43 + 2 * 2.78)
+KECCAK_PEAK_PER_S = 1024 * 64 * 2.4e9 / KECCAK_CYCLES_PER_WAVE_PERM
 
 
 def pmc_traffic(blocks, kernel):
@@ -268,7 +268,7 @@ def pc_leg(vp, sess, circ, golden, gname, full_fixture=None):
         w, us = sum(e["work"] for e in leaf), sum(e["us"] for e in leaf)
         rl["k_leaf_hash"] = {"bound": "valu", "achieved": w / (us * 1e-6), "peak": KECCAK_PEAK_PER_S, "unit": "Keccak-f[1600]/s",
                              "frac": w / (us * 1e-6) / KECCAK_PEAK_PER_S, "time_share": us / tot,
-                             "peak_definition": "1024 SIMDs x 64 lanes x 2.4 GHz / (24 rounds x 180 instructions x %.1f cycles per wave-instruction, tools/micro_rates.hip)" % VALU_LOGIC_CYCLES}
+                             "peak_definition": "issue bound of the kernel's own instruction mix: 1024 SIMDs x 64 lanes x 2.4 GHz / %.0f cycles per wave-permutation (24 rounds x (120 v_bitop3_b32 x 3.20 + 58 v_alignbit_b32 x 4.43 + 2 v_xor_b32 x 2.78 cycles), profiles/r02_micro_rates.txt)" % KECCAK_CYCLES_PER_WAVE_PERM}
     if ntt:
         w, us = sum(e["work"] for e in ntt), sum(e["us"] for e in ntt)
         rl["k_ntt"] = {"bound": "valu", "achieved": w / (us * 1e-6), "peak": FMUL_PEAK_PER_S, "unit": "F_p^2 multiplications/s",

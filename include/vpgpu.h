@@ -201,15 +201,16 @@ int vp_get_stats(vp_ctx *, vp_stats *out);
 int vp_set_profiling(vp_ctx *, int level);
 
 /* One kernel launch of the last profiled call: which kernel, how much it covered, its ALGORITHMIC bytes (SURVEY.md §8d:
- * fold launch = 48 B (32 B in the Liu phase) x (valid entries in + entries out), init = 48 B per gate contribution (16 B
- * packed record + 16 B eq value + 16 B operand) + 4 B row pointer + the tables written, NTT = 16 B x (in + out) per pass,
+ * fold launch = 48 B (32 B in the Liu phase) x (valid entries in + entries out); init = 26 B per gate contribution (10 B
+ * record + 16 B gathered operand; 5 B in the Liu gather — stricter than SURVEY's 48 B: the eq value is a product of two
+ * L2-resident half-table entries, not HBM traffic) + 4 B row pointer + the tables written; NTT = 16 B x (in + out) per pass,
  * FRI fold = 48 B per output element, leaf hash = 32 B per chained block) and its duration.  `work` counts the kernel's
  * own unit: F_p^2 multiplications for the transforms, Keccak-f[1600] permutations for the hash kernels, active pairs for
  * the fold kernels, gate contributions for the init kernels.  `rounds`: sumcheck rounds the launch performs (fold: 3 per
  * launch on every table it holds; closing kernels: the remaining ones), `first_round` the earliest of them (1-based).   */
 enum { VP_K_BETA = 0, VP_K_LIGHT, VP_K_CHUNKS, VP_K_COMBINE, VP_K_DOT, VP_K_DOTFIN, VP_K_SFGEN, VP_K_SF, VP_K_SEG, VP_K_EMIT,
        VP_K_FIXUP, VP_K_NTT_SPLIT, VP_K_NTT_LDS, VP_K_NTT_UNSPLIT, VP_K_LEAF_HASH, VP_K_MERKLE, VP_K_PC_POINTWISE, VP_K_FRI_FOLD,
-       VP_K_ROUND, VP_K_COUNT };
+       VP_K_ROUND, VP_K_INIT3, VP_K_COUNT };
 typedef struct {
     int32_t kind;             /* VP_K_*                                                          */
     int32_t step;             /* position in the launch order of the call                        */

@@ -256,7 +256,7 @@ def test_launch_stats_table_covers_every_launch(vp, gold_gkr):
     s.set_profiling(0)
     assert tr_p == tr
     kinds = {e["kernel"] for e in st}
-    assert {"k_beta_half_direct", "k_light_multi", "k_seg_multi", "k_emit_multi"} <= kinds
+    assert {"k_beta_half_direct", "k_seg_multi", "k_emit_multi"} <= kinds and ({"k_init3_multi", "k_light_multi"} & kinds)
     assert len(st) == res_p["launches"]
     assert all(e["us"] > 0 for e in st)
     assert all(e["bytes"] > 0 for e in st if e["kernel"] not in ("k_beta_half_direct", "k_fixup"))

@@ -11,11 +11,12 @@
 // assembled from pairs (T_k[2p], T_k[2p+1]).  Same field values, half the bytes.
 //
 // Files: vp_kernels_round.h (reductions, eq tables, evaluation, per-round kernels)  vp_kernels_batch.h (batched init +
-// fold kernels)  vp_kernels_plan.h (segment / closing kernels, batched launches)  vp_kernels_pc.h (polynomial commitment).
+// fold kernels)  vp_kernels_init3.h (entry-parallel inits)  vp_kernels_plan.h (segment / closing kernels, batched launches)  vp_kernels_pc.h (polynomial commitment).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "vp_field.h"
 #include "vp_kernels_round.h"
 #include "vp_kernels_batch.h"
+#include "vp_kernels_init3.h"
 #include "vp_kernels_plan.h"
 #include "vp_kernels_pc.h"

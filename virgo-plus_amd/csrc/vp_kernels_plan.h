@@ -2,6 +2,7 @@
 // Part of the single translation unit vpgpu.hip (see vp_kernels.h for the overall layout rules).
 #pragma once
 #include "vp_kernels_batch.h"
+#include "vp_kernels_init3.h"
 
 // ===================================================================================================
 // Segment kernels (default batched path).
@@ -446,6 +447,15 @@ __global__ void __launch_bounds__(VP_BLOCK) k_light_multi(const LightJob *__rest
         block_sum<1>(acc, lds);
         if (threadIdx.x == 0) j.dot_part[m.bid] = acc[0];
     }
+}
+// Entry-parallel inits (vp_kernels_init3.h): block b -> (job, 512-row chunk of its target rows)
+__global__ void __launch_bounds__(VP_BLOCK) k_init3_multi(const I3Job *__restrict__ jobs, const BlkMap *__restrict__ map) {
+    __shared__ I3Lds sm;
+    const BlkMap m = map[blockIdx.x];
+    const I3Job &j = jobs[m.job];
+    if (j.phase == 1) i3_body<1>(j, m.bid, sm);
+    else if (j.phase == 2) i3_body<2>(j, m.bid, sm);
+    else i3_body<0>(j, m.bid, sm);
 }
 // Verifier-side wiring predicates (reference: verifier::betaInitPhase1/2 + predicatePhase1/2, src/verifier.cpp:50-113): for
 // layer i,  coeff_l[t] = sum over unary gates g of type t of beta_g[g] beta_u[u_g] (x c_g for Mulc),  bias = the Addc sum

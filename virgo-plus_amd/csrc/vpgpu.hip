@@ -24,6 +24,7 @@ struct Csr {                 // contributions of one layer sorted by target row 
     u32 *rowptr = nullptr, *e_g = nullptr, *e_x = nullptr;
     uint16_t *e_tl = nullptr;
     u32 *heavy_row = nullptr, *heavy_cptr = nullptr, *chunk_beg = nullptr, *chunk_end = nullptr;
+    Csr3 c3{};               // the same light contributions cut into 512-row chunks for the entry-parallel kernels
 };
 
 struct LayerDev {
@@ -44,6 +45,7 @@ struct LayerDev {
     // batched path: per-slot V gather map, Liu gather lists, half tables of this layer's sumchecks
     uint8_t *s_layer = nullptr; u32 *s_idx = nullptr;
     u32 *lrow = nullptr, *l_g = nullptr; uint8_t *l_q = nullptr; u32 l_n = 0;      // l_n: entries of the Liu gather lists
+    Csr3L l3{};              // the Liu gather lists cut into 512-row chunks (entry-parallel kernels)
     Half hg{}, hu{};
     Half *liu_H = nullptr;
     // verifier-side predicates (vp_predicates): gates listed by bucket, pieces of <= 512
@@ -76,7 +78,7 @@ struct Lane {
 enum { NK_LIGHT = 0, NK_CHUNKS, NK_COMBINE, NK_DOT, NK_DOTFIN, NK_SFGEN, NK_SF, NK_SEG, NK_EMIT, NK_COUNT };
 struct PStep { int kind; u32 idx, grid, lds; u64 bytes; int rounds; int xchain; u64 work = 0; int first_round = 0, n_rounds = 0; };   // kind -1: placeholder step; xchain: also wait for that chain's latest node
 struct PlanRec {
-    std::vector<LightJob> light; std::vector<ChunkJob> chunks; std::vector<CombineJob> combine; std::vector<DotJob> dot;
+    std::vector<LightJob> light; std::vector<I3Job> init3; std::vector<ChunkJob> chunks; std::vector<CombineJob> combine; std::vector<DotJob> dot;
     std::vector<SfArgs> sf; std::vector<SfGenJob> sfgen; std::vector<SegArgs> seg; std::vector<EmitArgs> emit;
     std::vector<std::vector<PStep>> chains; int cur = -1;
     void push(int kind, u32 idx, u32 grid, u32 lds = 0, u64 bytes = 0, u64 work = 0, int first_round = 0, int n_rounds = 0) {
@@ -89,6 +91,7 @@ struct PNode { int kind = 0, step = 0, stream = 0; u32 first = 0, count = 0, gri
                std::vector<int> deps; hipEvent_t ev = nullptr; bool record = false; };
 struct Plan {
     std::vector<PNode> nodes;
+    I3Job *d_init3 = nullptr; bool init3 = false;
     DotJob *d_dot = nullptr, *d_dotfin = nullptr; LightJob *d_light = nullptr; ChunkJob *d_chunks = nullptr; CombineJob *d_combine = nullptr;
     SfGenJob *d_sfgen = nullptr; SfArgs *d_sf = nullptr; SegArgs *d_seg = nullptr; EmitArgs *d_emit = nullptr; BlkMap *d_map = nullptr;
     hipStream_t streams[4] = {nullptr, nullptr, nullptr, nullptr};   // [0] = ctx->stream; [1..3] owned: fold (low priority), seg, emit (high)
@@ -151,6 +154,7 @@ struct vp_ctx {
     DotJob rec_dot{};                 // record mode: the V_u inner product the next phase-1 init job carries
     SfGenJob rec_gen{};               // record mode: init to be fused into the first fold launch of the next sumcheck (mode != 0)
     int fuse_init = 1;                // VP_FUSE_INIT=0: separate init launches for every sumcheck
+    int use_init3 = 1;                // VP_INIT3=0: row-per-lane init kernels (k_light_multi) instead of the entry-parallel ones (k_init3_multi)
     Plan *plan = nullptr; int plan_path = 1;   // VP_GKR_PATH=lanes: one stream per sumcheck chain instead of the plan
     // hipGraph of the concurrent GKR submission (per circuit; VP_GKR_GRAPH=0 submits the launches directly)
     hipGraphExec_t gkr_graph = nullptr; int use_graph = 1; bool graph_failed = false; u64 graph_launches = 0, graph_rounds = 0;
@@ -238,6 +242,31 @@ int build_csr(vp_ctx *ctx, Csr &c, u32 n_rows, const std::vector<u32> &key, cons
     VPCHK(dupload(ctx, &c.chunk_beg, cb));
     VPCHK(dupload(ctx, &c.chunk_end, ce));
     ctx->chunk_cap = std::max(ctx->chunk_cap, c.n_chunks);
+    {   // entry-parallel form: light rows only, chunk pointers every 512 rows, row offset per entry
+        const u32 nch = (n_rows + VP_I3_ROWS - 1) / VP_I3_ROWS;
+        std::vector<u32> cptr(nch + 1, 0), lg, lx, hptr(nch + 1, 0);
+        std::vector<uint16_t> ltl, lr;
+        lg.reserve(n); lx.reserve(n); ltl.reserve(n); lr.reserve(n);
+        size_t hi = 0;
+        for (u32 ch = 0; ch < nch; ++ch) {
+            cptr[ch] = (u32) lg.size();
+            const u32 r1 = std::min<u32>(n_rows, (ch + 1) * VP_I3_ROWS);
+            while (hi < heavy_row.size() && heavy_row[hi] < ch * VP_I3_ROWS) ++hi;
+            hptr[ch] = (u32) hi;
+            for (u32 r = ch * VP_I3_ROWS; r < r1; ++r) {
+                const u32 b = rowptr[r], e = rowptr[r + 1];
+                if (e - b > VP_LIGHT_MAX) continue;
+                for (u32 k = b; k < e; ++k) { lg.push_back(sg[k]); lx.push_back(sx[k]); ltl.push_back(stl[k]); lr.push_back((uint16_t) (r - ch * VP_I3_ROWS)); }
+            }
+        }
+        cptr[nch] = (u32) lg.size();
+        hptr[nch] = (u32) heavy_row.size();
+        u32 *d_cptr, *d_g, *d_x, *d_hptr; uint16_t *d_tl, *d_r;
+        VPCHK(dupload(ctx, &d_cptr, cptr)); VPCHK(dupload(ctx, &d_g, lg)); VPCHK(dupload(ctx, &d_x, lx));
+        VPCHK(dupload(ctx, &d_tl, ltl)); VPCHK(dupload(ctx, &d_r, lr)); VPCHK(dupload(ctx, &d_hptr, hptr));
+        c.c3.cptr = d_cptr; c.c3.e_g = d_g; c.c3.e_x = d_x; c.c3.e_tl = d_tl; c.c3.e_r = d_r; c.c3.hptr = d_hptr; c.c3.heavy_row = c.heavy_row;
+        c.c3.n_chunks = nch;
+    }
     return VP_OK;
 }
 
@@ -772,6 +801,16 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
             }
             VPCHK(dupload(ctx, &D.lrow, rp)); VPCHK(dupload(ctx, &D.l_g, eg)); VPCHK(dupload(ctx, &D.l_q, eq));
             D.l_n = rp[rows];
+            {
+                const u32 nch = (rows + VP_I3_ROWS - 1) / VP_I3_ROWS;
+                std::vector<u32> cptr(nch + 1);
+                std::vector<uint16_t> er(rp[rows]);
+                for (u32 ch = 0; ch <= nch; ++ch) cptr[ch] = rp[std::min<u32>(rows, ch * VP_I3_ROWS)];
+                for (u32 r = 0; r < rows; ++r) for (u32 k = rp[r]; k < rp[r + 1]; ++k) er[k] = (uint16_t) (r % VP_I3_ROWS);
+                u32 *d_cptr; uint16_t *d_r;
+                VPCHK(dupload(ctx, &d_cptr, cptr)); VPCHK(dupload(ctx, &d_r, er));
+                D.l3.cptr = d_cptr; D.l3.e_g = D.l_g; D.l3.e_q = D.l_q; D.l3.e_r = d_r; D.l3.n_chunks = nch;
+            }
         }
         VPCHK(dalloc(ctx, &ctx->part2, (size_t) 32 * MAX_BLOCKS * 3));
         // lanes: per-layer scratch for the concurrent chains
@@ -824,6 +863,7 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
         ctx->sumfold_path = (pth && !strcmp(pth, "sumfold")) ? 1 : 0;
         ctx->plan_path = (pth && !strcmp(pth, "lanes")) ? 0 : 1;
         { const char *fi = getenv("VP_FUSE_INIT"); ctx->fuse_init = (fi && fi[0] == '0') ? 0 : 1; }
+        { const char *fi = getenv("VP_INIT3"); ctx->use_init3 = (fi && fi[0] == '0') ? 0 : 1; }
     }
     // event pool for the profiled launches
     if (ctx->ev_pool.empty()) {
@@ -1164,7 +1204,7 @@ int vp_get_launch_stats(vp_ctx *ctx, vp_launch_stat *out, int capacity, int *n) 
 const char *vp_kernel_name(int kind) {
     static const char *names[VP_K_COUNT] = {"k_beta_half_direct", "k_light_multi", "k_chunks_multi", "k_combine_multi", "k_dot_multi", "k_dotfin_multi",
         "k_sumfold3b_gen_multi", "k_sumfold3b_multi", "k_seg_multi", "k_emit_multi", "k_fixup", "k_ntt_split", "k_ntt_lds", "k_ntt_unsplit",
-        "k_leaf_hash", "k_merkle", "k_pc_pointwise", "k_fri_fold", "k_round"};
+        "k_leaf_hash", "k_merkle", "k_pc_pointwise", "k_fri_fold", "k_round", "k_init3_multi"};
     return (kind >= 0 && kind < VP_K_COUNT) ? names[kind] : "?";
 }
 
