@@ -110,7 +110,16 @@ def test_fused_init_plan_matches_reference(vp, golden, gold_gkr, pws_path, name,
     s2.draw_tape()
     tr2, _ = s2.prove_gkr()
     assert tr2 == tr
+    monkeypatch.setenv("VP_INIT3", "1")             # entry-parallel init kernels (k_init3_multi, GenI3P1 / GenI3Liu) instead of the row-per-lane lists
+    s2b = vp.Session(c)
+    s2b.draw_tape()
+    assert s2b.prove_gkr()[0] == tr
     monkeypatch.delenv("VP_FUSE_MIN_LOG"); monkeypatch.delenv("VP_FUSE_DOT")
+    s2c = vp.Session(c)
+    s2c.draw_tape()
+    assert s2c.prove_gkr()[0] == tr
+    s2b.close(); s2c.close()
+    monkeypatch.delenv("VP_INIT3")
     monkeypatch.setenv("VP_SF_ROUNDS", "4")         # four-round fold launches (k_sumfold4b_multi)
     s3 = vp.Session(c)
     s3.draw_tape()

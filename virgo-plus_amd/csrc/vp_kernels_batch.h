@@ -533,6 +533,14 @@ __device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb,
                     if (HAS_A) { a0 = ld_or_zero(a.inA, i0, vend); a1 = ld_or_zero(a.inA, i0 + 1, vend); }
                 }
 #endif
+            } else if constexpr (Gen::MODE >= 3) {          // entry-parallel init of this 512-row chunk into LDS (vp_kernels_init3.h), then the pair from there
+                gen.chunk(cl, i0, vend, m0, a0, m1, a1);
+                if constexpr (Gen::MODE == 3) {
+                    if (gen.dot_part) {
+                        if (i0 < vend) dacc = f_add(dacc, f_mul(half_at(gen.dot_h, i0), v0));
+                        if (i0 + 1 < vend) dacc = f_add(dacc, f_mul(half_at(gen.dot_h, i0 + 1), v1));
+                    }
+                }
             } else {                      // generated tables: one table per job, offset 0
 #ifdef VP_GEN_ROW1
                 gen.row(i0, vend, m0, a0);
@@ -606,7 +614,7 @@ __device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb,
         F *o = a.part + (size_t) t * a.part_stride + bid * 3;
         o[0] = X; o[1] = (t == 0 ? keep_y0 : keep_rest) ? f_sub(f_sub(Y, X), Z) : f_zero(); o[2] = Z;       // b of the other rounds: derived by k_emit
     }
-    if constexpr (Gen::MODE == 1) {
+    if constexpr (Gen::MODE == 1 || Gen::MODE == 3) {
         if (gen.dot_part) {                              // uniform per launch
             F d[1] = {dacc};
             block_sum<1>(d, sm.dred);

@@ -20,6 +20,13 @@
 // (Liu: eq(r_u, u); phase 2: the V gather; rows with more than 16 contributions: the sums the chunk kernels left in
 // global memory) and writes mult/add — or, inside the fused fold kernel, feeds round k directly.
 //
+// MEASURED (round 2, profiles/r02_b_ab_init3_*.json): bit-exact, but no faster.  Stand-alone the launch takes the same time as
+// k_light_multi (x64: 278 vs 277 us for both init launches; x1024: 1.54 vs 1.56 ms) — the init launches move ~500 MB per
+// launch at x64, 60 % of it the mult/add tables they WRITE for every wire (most rows hold zero or one contribution), and run at
+// 3.5 TB/s of mixed read / write / 16-byte gathers; the divergence this kernel removes was not what they waited for.  Inside
+// the fused fold launch (GenI3P1 / GenI3Liu) it is slower than the row-per-lane gather (x1024: 4.7 vs 3.5 ms for the two fused
+// launches): zeroing + two more barriers per 512-entry chunk at 3 workgroups per CU.  Kept as VP_INIT3=1 (parity-tested).
+//
 // Exactness: a term is canonical (< 2^61); three scan steps add at most 8 of them (< 2^64), one Mersenne fold brings the
 // partial below 2^61 + 8, the fourth step adds two of those.  A light row (<= 16 contributions, contiguous) touches at
 // most two DPP rows, a Liu row (<= 64 later layers) at most five; partials are folded once more (< 2^61 + 2) before the
@@ -119,11 +126,19 @@ __device__ __forceinline__ void i3_term_p2(const InitArgs2 &a, u32 g, u32 x, u32
 }
 
 // Accumulate every light contribution of chunk `ch` into sm.acc (zeroed here).  PHASE 1 / 2: InitArgs2 + Csr3; PHASE 0: Liu lists.
-template <int PHASE>
+// LOAD_HEAVY (fused fold launch): rows with more than VP_LIGHT_MAX contributions take the sums the chunk kernels left in a.M / a.A.
+template <int PHASE, bool LOAD_HEAVY = false>
 __device__ __forceinline__ void i3_accumulate(const InitArgs2 &a, const Csr3 &c, const Csr3L &cl, const Half *__restrict__ H, u32 ch, I3Lds &sm) {
     const int tid = threadIdx.x;
     for (int i = tid; i < 4 * VP_I3_ROWS; i += blockDim.x) (&sm.acc[0][0])[i] = 0;
     __syncthreads();
+    if (LOAD_HEAVY && PHASE != 0) {                            // heavy rows have no light entries: nobody else touches their slots
+        for (u32 h = c.hptr[ch] + tid; h < c.hptr[ch + 1]; h += blockDim.x) {
+            const u32 row = c.heavy_row[h], q = row - ch * VP_I3_ROWS;
+            const F m = a.M[row], ad = a.A[row];
+            sm.acc[0][q] = m.re; sm.acc[1][q] = m.im; sm.acc[2][q] = ad.re; sm.acc[3][q] = ad.im;
+        }
+    }
     const u32 eb = PHASE == 0 ? cl.cptr[ch] : c.cptr[ch], ee = PHASE == 0 ? cl.cptr[ch + 1] : c.cptr[ch + 1];
     const F vu = PHASE == 2 ? *a.Vu : f_zero();
     for (u32 e0 = eb; e0 < ee; e0 += blockDim.x) {            // uniform trip count
@@ -196,5 +211,29 @@ __device__ __forceinline__ void i3_body(const I3Job &j, u32 ch, I3Lds &sm) {
         if (threadIdx.x == 0) j.dot_part[ch] = acc[0];
     }
 }
+
+// ---- inside the fused fold launch (sumfold3b_body, Gen::MODE 3 / 4): the 512 entries of a fold chunk ARE one init chunk --------
+struct GenI3P1 {
+    static constexpr int MODE = 3;
+    const InitArgs2 *a; const Csr3 *c; Half dot_h; F *dot_part; I3Lds *sm;
+    __device__ __forceinline__ void chunk(u32 ch, u32 i0, u32 valid, F &m0, F &a0, F &m1, F &a1) const {
+        i3_accumulate<1, true>(*a, *c, Csr3L{}, nullptr, ch, *sm);
+        const u32 q = i0 - ch * VP_I3_ROWS;                    // one table per job at offset 0: i0 = 512 ch + 2t
+        m0 = i3_acc_m(*sm, q); a0 = i3_acc_a(*sm, q); m1 = i3_acc_m(*sm, q + 1); a1 = i3_acc_a(*sm, q + 1);
+        __syncthreads();                                       // the accumulators are zeroed again by the next chunk
+    }
+};
+struct GenI3Liu {
+    static constexpr int MODE = 4;
+    const Csr3L *cl; const Half *H; I3Lds *sm;
+    __device__ __forceinline__ void chunk(u32 ch, u32 i0, u32 valid, F &m0, F &a0, F &m1, F &a1) const {
+        i3_accumulate<0>(InitArgs2{}, Csr3{}, *cl, H, ch, *sm);
+        const u32 q = i0 - ch * VP_I3_ROWS;
+        a0 = f_zero(); a1 = f_zero();
+        m0 = i0 < valid ? f_add(half_at(H[0], i0), i3_acc_m(*sm, q)) : f_zero();
+        m1 = i0 + 1 < valid ? f_add(half_at(H[0], i0 + 1), i3_acc_m(*sm, q + 1)) : f_zero();
+        __syncthreads();
+    }
+};
 
 }  // namespace vp

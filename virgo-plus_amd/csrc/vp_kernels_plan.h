@@ -538,7 +538,7 @@ __global__ void __launch_bounds__(VP_BLOCK, 3) k_sumfold4b_multi(const SfArgs *_
     if (a.has_a) sumfold4b_body<true>(a, m.bid, a.nblk, sm); else sumfold4b_body<false>(a, m.bid, a.nblk, sm);
 }
 // First fold launch of a phase-1 / Liu sumcheck with its init fused in (see GenP1 / GenLiu).
-struct SfGenJob { SfArgs sf; InitArgs2 a; GatherJob g; Half dot_h; F *dot_part; int mode; int pad; };
+struct SfGenJob { SfArgs sf; InitArgs2 a; GatherJob g; Half dot_h; F *dot_part; int mode; int pad; Csr3 c3; Csr3L l3; };   // mode 1 / 2: row-per-lane lists; 3 / 4: entry-parallel (c3 / l3)
 __global__ void __launch_bounds__(VP_BLOCK, VP_SF_MINB) k_sumfold3b_gen_multi(const SfGenJob *__restrict__ jobs, const BlkMap *__restrict__ map) {
     __shared__ Sf3bLds sm;
     const BlkMap m = map[blockIdx.x];
@@ -548,6 +548,20 @@ __global__ void __launch_bounds__(VP_BLOCK, VP_SF_MINB) k_sumfold3b_gen_multi(co
         sumfold3b_body<true>(j.sf, m.bid, j.sf.nblk, sm, g);
     } else {
         GenLiu g; g.rowptr = j.g.rowptr; g.e_q = j.g.e_q; g.e_g = j.g.e_g; g.H = j.g.H;
+        sumfold3b_body<false>(j.sf, m.bid, j.sf.nblk, sm, g);
+    }
+}
+// The same with the entry-parallel init (vp_kernels_init3.h): a fold chunk of 512 entries is one init chunk of 512 target rows.
+__global__ void __launch_bounds__(VP_BLOCK, VP_SF_MINB) k_sumfold3b_gen3_multi(const SfGenJob *__restrict__ jobs, const BlkMap *__restrict__ map) {
+    __shared__ Sf3bLds sm;
+    __shared__ I3Lds sm3;
+    const BlkMap m = map[blockIdx.x];
+    const SfGenJob &j = jobs[m.job];
+    if (j.mode == 3) {
+        GenI3P1 g; g.a = &j.a; g.c = &j.c3; g.dot_h = j.dot_h; g.dot_part = j.dot_part; g.sm = &sm3;
+        sumfold3b_body<true>(j.sf, m.bid, j.sf.nblk, sm, g);
+    } else {
+        GenI3Liu g; g.cl = &j.l3; g.H = j.g.H; g.sm = &sm3;
         sumfold3b_body<false>(j.sf, m.bid, j.sf.nblk, sm, g);
     }
 }

@@ -154,7 +154,10 @@ struct vp_ctx {
     DotJob rec_dot{};                 // record mode: the V_u inner product the next phase-1 init job carries
     SfGenJob rec_gen{};               // record mode: init to be fused into the first fold launch of the next sumcheck (mode != 0)
     int fuse_init = 1;                // VP_FUSE_INIT=0: separate init launches for every sumcheck
-    int use_init3 = 1;                // VP_INIT3=0: row-per-lane init kernels (k_light_multi) instead of the entry-parallel ones (k_init3_multi)
+    int use_init3 = 0;                // VP_INIT3=1: entry-parallel init kernels (k_init3_multi, vp_kernels_init3.h) instead of the row-per-lane ones.
+                                      // Measured (profiles/r02_b_*): stand-alone equal (x64 278 vs 277 us, x1024 1.54 vs 1.56 ms: the init launches are
+                                      // bound by writing the mult/add tables and the operand gathers, not by lane divergence), fused into the fold
+                                      // launch slower (x1024 4.7 vs 3.5 ms: two more barriers per chunk at 3 workgroups per CU) -> off by default
     Plan *plan = nullptr; int plan_path = 1;   // VP_GKR_PATH=lanes: one stream per sumcheck chain instead of the plan
     // hipGraph of the concurrent GKR submission (per circuit; VP_GKR_GRAPH=0 submits the launches directly)
     hipGraphExec_t gkr_graph = nullptr; int use_graph = 1; bool graph_failed = false; u64 graph_launches = 0, graph_rounds = 0;
@@ -863,7 +866,7 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
         ctx->sumfold_path = (pth && !strcmp(pth, "sumfold")) ? 1 : 0;
         ctx->plan_path = (pth && !strcmp(pth, "lanes")) ? 0 : 1;
         { const char *fi = getenv("VP_FUSE_INIT"); ctx->fuse_init = (fi && fi[0] == '0') ? 0 : 1; }
-        { const char *fi = getenv("VP_INIT3"); ctx->use_init3 = (fi && fi[0] == '0') ? 0 : 1; }
+        { const char *fi = getenv("VP_INIT3"); ctx->use_init3 = (fi && fi[0] == '1') ? 1 : 0; }
     }
     // event pool for the profiled launches
     if (ctx->ev_pool.empty()) {
