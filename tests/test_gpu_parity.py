@@ -572,7 +572,28 @@ def test_sha256_x1024_full_size_vs_oracle_fixture(vp, golden, gold_gkr, pws_path
     roots, fin = s.fri_commit(r)
     assert roots == fexp[:32 * st], "FRI roots differ from the oracle's"
     assert fin.tobytes() == fexp[32 * st:], "final FRI codeword differs"
+    # The COMPLETE protocol in one unbroken run at this size (verifier::verify(): commit_private, interactive GKR, commit_public
+    # on the protocol's own public vector eq(r_liu, .), fft_gkr's draws, FRI commit phase, query repetitions) against the oracle's
+    # run of the same (tests/golden/make_oracle_fixture_full.py 1024 1 --fri: 22 min of CPU, 34 GB): full transcript, every FRI
+    # root, the final codeword and the fold challenges the reference's verifier would draw.
+    fx = open(os.path.join(GOLDEN_DIR, "oracle_sha256_x1024_full.bin"), "rb").read()
+    trf, okf, _ = s.prove_and_verify_full(reps=3)
+    assert okf
+    n = len(trf)
+    assert n == 32 + len(tr) + 32 + 16 + 65 * 16 and trf == fx[:n], "full transcript differs from the oracle's"
+    roots2, fin2, r2 = s.last_fri()
+    assert roots2 == fx[n:n + 32 * st] and fin2.tobytes() == fx[n + 32 * st:n + 32 * st + 2048 * 16]
+    assert r2.tobytes() == fx[n + 32 * st + 2048 * 16:], "FRI fold challenges differ from the reference's draw order"
+    trb, okb = s.prove_full(batched=True)
+    assert okb and trb == trf
     s.close(); c.close()
+    # configs[3] draws witness seeds 1..8 (one proof per GPU): seed 2 against its own oracle fixture (make_oracle_fixture_full.py 1024 2 --gkr-only)
+    c2 = vp.Circuit.from_pws(pws_path, 1024, seed=2)
+    s2 = vp.Session(c2)
+    s2.draw_tape()
+    tr2, _ = s2.prove_gkr()
+    assert tr2 != tr and tr2 == open(os.path.join(GOLDEN_DIR, "oracle_sha256_x1024_gkr_seed2.bin"), "rb").read()
+    s2.close(); c2.close()
 
 
 def test_sha256_x256_size_independent_properties(vp, pws_path):
