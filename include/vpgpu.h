@@ -33,7 +33,9 @@ enum {
     VP_EHIP = -2,        /* HIP runtime error (vp_last_error has the string)        */
     VP_ENOGPU = -3,      /* no usable gfx950 device                                  */
     VP_EASSERT = -4,     /* an assert gate evaluated to non-zero (prover.cpp:18-21)  */
-    VP_ELIMIT = -5       /* circuit exceeds a compiled-in limit                      */
+    VP_ELIMIT = -5,      /* circuit exceeds a compiled-in limit                      */
+    VP_EXCHANGE = 1      /* sharded commitment without a communicator: the call stopped at a collective; run
+                            vp_shard_exchange_local on all ranks' contexts, then call the same function again */
 };
 
 /* Gate types, same numbering as enum gateType (src/inputCircuit.hpp:13-15). */
@@ -164,6 +166,30 @@ int vp_fri_final(vp_ctx *, vp_F *final_code);
 int vp_fri_open(vp_ctx *, int oracle, uint64_t leaf, vp_F values[130], uint8_t *path, int path_capacity, int *path_len);
 /* Device time of the last vp_commit_private / vp_commit_public / vp_fri_step in milliseconds (hipEvents). */
 int vp_commit_stats(vp_ctx *, double *commit_ms);
+
+/* ---- commitment sharded over the GPUs of a node (SURVEY.md §8e "PC sharding"; north_star "FFT subtrees shard") ---------------- */
+/* After vp_pc_set_shard(rank, world) (world a power of two <= 64 with 2^(n-6) >= 2 world) the SAME entry points vp_commit_private /
+ * vp_commit_public / vp_fri_commit / vp_fri_final / vp_fri_open work on this rank's share of the commitment: rank r transforms
+ * slices [64 r / world, 64 (r+1) / world) (the 64 slices are independent transforms, lib/virgo/src/poly_commit.h:89-107), ONE
+ * all-to-all per committed oracle hands every rank the positions a = rank (mod world) of ALL slices (a leaf chains all 64 slices at a
+ * position pair, lib/virgo/src/fri.cpp:81-124), the rank hashes its leaves and five tree levels, the level-5 nodes are all-gathered and
+ * every rank builds the top of the tree (merkle_tree.cpp:7-51): all ranks return the same root, equal to the unsharded one.  FRI folds
+ * stay local (fold partners a, a + N_k/2 share their low bits) until one position per rank is left.  Every rank passes the same `pub`
+ * / `r`; vp_fri_commit must be given all n-6 challenges.  vp_fri_open is answered by the owner of the leaf, rank (leaf >> 5) mod world
+ * (VP_EINVAL elsewhere); levels of the last log2(world) folds are replicated.
+ * Collectives: over RCCL when vp_comm_init attached a communicator; otherwise a call returns VP_EXCHANGE at each collective and
+ * vp_shard_exchange_local(ctxs, world) performs the pending ones among contexts of ONE process (parity tests: W ranks on one GPU).
+ * vp_pc_load_input makes a context that holds only an input layer (no circuit): enough for the commitment calls.                  */
+int vp_pc_load_input(vp_ctx *, const vp_F *inputs, uint64_t n_inputs, int bit_length);
+int vp_pc_set_shard(vp_ctx *, int rank, int world);
+int vp_shard_exchange_local(vp_ctx **ctxs, int world);
+/* RCCL over xGMI: rank 0 makes the id (128 bytes, ncclUniqueId), every rank calls vp_comm_init with it.  With a communicator attached
+ * a chain-sharded vp_prove_gkr (vp_set_shard) all-reduces the transcript on the device (u64 sum of disjoint slices) before returning
+ * it, and the sharded commitment calls run their collectives inside the call.  librccl.so.1 is resolved at run time.             */
+int vp_comm_unique_id(uint8_t id[128]);
+int vp_comm_init(vp_ctx *, const uint8_t id[128], int rank, int world);
+int vp_comm_destroy(vp_ctx *);
+int vp_allreduce_u64(vp_ctx *, void *device_buffer, uint64_t count);
 
 /* ---- verifier side ------------------------------------------------------------------------------- */
 /* The verifier's O(|C|) wiring-predicate loops for one layer (verifier::betaInitPhase1/2, predicatePhase1/2,

@@ -586,7 +586,13 @@ def test_sha256_x1024_full_size_vs_oracle_fixture(vp, golden, gold_gkr, pws_path
     assert r2.tobytes() == fx[n + 32 * st + 2048 * 16:], "FRI fold challenges differ from the reference's draw order"
     trb, okb = s.prove_full(batched=True)
     assert okb and trb == trf
+    # ... and the commitment of this size sharded over 8 ranks (8 slices per rank, 2^18 leaves per rank): same roots
+    inputs = s.layer_values(0)
+    pub = s.eq_table(s.last_point())
     s.close(); c.close()
+    r8 = np.frombuffer(fx[n + 32 * st + 2048 * 16:], dtype=np.uint64).reshape(st, 2).copy()
+    fin8 = np.frombuffer(fx[n + 32 * st:n + 32 * st + 2048 * 16], dtype=np.uint64).reshape(2048, 2)
+    _sharded_commitment_case(vp, inputs, 23, pub, r8, 8, fx[:32], fx[n - (32 + 16 + 65 * 16):n], fx[n:n + 32 * st], fin8)
     # configs[3] draws witness seeds 1..8 (one proof per GPU): seed 2 against its own oracle fixture (make_oracle_fixture_full.py 1024 2 --gkr-only)
     c2 = vp.Circuit.from_pws(pws_path, 1024, seed=2)
     s2 = vp.Session(c2)
@@ -594,6 +600,74 @@ def test_sha256_x1024_full_size_vs_oracle_fixture(vp, golden, gold_gkr, pws_path
     tr2, _ = s2.prove_gkr()
     assert tr2 != tr and tr2 == open(os.path.join(GOLDEN_DIR, "oracle_sha256_x1024_gkr_seed2.bin"), "rb").read()
     s2.close(); c2.close()
+
+
+def _opening_ok(root, leaf, vals, path):
+    """Python restatement of the verifier's opening check (lib/virgo/src/vpd_verifier.cpp:9-40, fri.cpp:96-124): the leaf is the chain
+    of 65 SHA3-256 over (value pair || previous digest), then the path to the root."""
+    import hashlib
+    h = bytes(32)
+    for k in range(65):
+        h = hashlib.sha3_256(vals[2 * k].tobytes() + vals[2 * k + 1].tobytes() + h).digest()
+    depth = len(path) - 1
+    if h != path[depth]:
+        return False
+    pos = leaf
+    for k in range(depth):
+        h = hashlib.sha3_256((path[k] + h) if (pos & 1) else (h + path[k])).digest()
+        pos >>= 1
+    return h == root
+
+
+def _sharded_commitment_case(vp, inputs, n, pub, r, world, root_l, tail_gold, roots_gold, fin_gold):
+    sc = vp.ShardedCommitment(inputs, n, world)
+    assert sc.commit_private() == root_l, "world %d: merkle_root_l" % world
+    root_h, inner, all_sum = sc.commit_public(pub)
+    assert root_h + inner + all_sum == tail_gold, "world %d: merkle_root_h | input_0 | all_sum" % world
+    roots, fin = sc.fri_commit(r)
+    assert roots == roots_gold, "world %d: FRI roots" % world
+    assert np.array_equal(fin, fin_gold), "world %d: final codeword" % world
+    # openings: answered by the owner of the leaf only, and they verify against the assembled roots
+    st = r.shape[0]
+    lw = world.bit_length() - 1
+    for oracle, root, n_leaves in [(0, root_l, 1 << (n - 2)), (1, root_h, 1 << (n - 2)), (2, roots[:32], 1 << (n - 3)),
+                                   (2 + st - lw - 2, roots[32 * (st - lw - 2):32 * (st - lw - 1)], 16 << (lw + 1)),        # last locally hashed level
+                                   (2 + st - lw - 1, roots[32 * (st - lw - 1):32 * (st - lw)], 16 << lw),                  # first replicated level
+                                   (2 + st - 1, roots[32 * (st - 1):], 16)]:
+        if oracle < 2 or oracle - 2 < 0:
+            pass
+        for leaf in sorted({0, 33 % n_leaves, n_leaves // 2 + 5 if n_leaves > 16 else 3, n_leaves - 1}):
+            got = sc.open(oracle, leaf)
+            assert got is not None, "world %d oracle %d leaf %d" % (world, oracle, leaf)
+            assert _opening_ok(root, leaf, *got), "world %d oracle %d leaf %d: opening does not verify" % (world, oracle, leaf)
+        if oracle < 2 + st - lw - 1 and world > 1:
+            assert sc.open(oracle, 0, rank=1) is None, "a rank that does not own the leaf answered"
+    ms = sc.device_ms()
+    sc.close()
+    return ms
+
+
+@pytest.mark.parametrize("name,blocks,worlds", [("sha256_x1", 1, (2, 4, 8)), ("sha256_x16", 16, (2, 8)), ("sha256_x64", 64, (8,))])
+def test_commitment_sharded_over_ranks(vp, golden, pws_path, name, blocks, worlds):
+    """SURVEY §8e "PC sharding": the commitment over W ranks — slices dealt to the ranks, one all-to-all per oracle to position
+    ownership, local leaf hashes / five tree levels / FRI folds, level-5 nodes all-gathered, top of the tree on every rank.  W light
+    contexts on this one GPU with the collectives done by vp_shard_exchange_local; every rank must return the real reference's
+    merkle_root_l, merkle_root_h, input_0, all_sum[65], all FRI roots and the final codeword, and owners' openings must verify."""
+    import os
+    from conftest import GOLDEN
+    g = golden[name]
+    gold = open(os.path.join(GOLDEN, g["transcript"]), "rb").read()
+    c = vp.Circuit.from_pws(pws_path, blocks, seed=1)
+    s = vp.Session(c)
+    full, ok = s.prove_full(batched=True)
+    assert ok and full == gold
+    n = c.layer_bitlen(0)
+    inputs = s.layer_values(0)
+    pub = s.eq_table(s.last_point())
+    r, roots_gold, fin_gold = _fri_golden(golden, name)
+    s.close(); c.close()
+    for world in worlds:
+        _sharded_commitment_case(vp, inputs, n, pub, r, world, gold[:32], gold[-(32 + 16 + 65 * 16):], roots_gold, fin_gold)
 
 
 def test_sha256_x256_size_independent_properties(vp, pws_path):

@@ -104,6 +104,20 @@ def lib_gpu():
         L.vp_test_beta.argtypes = [vp, vp, ctypes.c_int, vp, vp]
         L.vp_test_sha3.argtypes = [vp, vp, vp, ctypes.c_uint64]
         L.vp_test_fft.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
+        L.vp_pc_load_input.argtypes = [vp, vp, ctypes.c_uint64, ctypes.c_int]
+        L.vp_pc_set_shard.argtypes = [vp, ctypes.c_int, ctypes.c_int]
+        L.vp_shard_exchange_local.argtypes = [ctypes.POINTER(vp), ctypes.c_int]
+        L.vp_commit_private.argtypes = [vp, vp]
+        L.vp_commit_public.argtypes = [vp, vp, ctypes.c_uint64, vp, vp, vp]
+        L.vp_fri_commit.argtypes = [vp, vp, ctypes.c_int, vp]
+        L.vp_fri_final.argtypes = [vp, vp]
+        L.vp_fri_open.argtypes = [vp, ctypes.c_int, ctypes.c_uint64, vp, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+        L.vp_commit_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
+        L.vp_comm_unique_id.argtypes = [vp]
+        L.vp_comm_init.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int]
+        L.vp_comm_destroy.argtypes = [vp]
+        L.vp_allreduce_u64.argtypes = [vp, vp, ctypes.c_uint64]
+        L.vp_set_profiling.argtypes = [vp, ctypes.c_int]
         L.vp_get_launch_stats.argtypes = [vp, ctypes.POINTER(LaunchStat), ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
         L.vp_kernel_name.argtypes = [ctypes.c_int]
         L.vp_kernel_name.restype = ctypes.c_char_p
@@ -152,6 +166,7 @@ def lib_host():
         L.vph_prove_full.argtypes = [vp, vp, u64, ctypes.POINTER(u64), ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
         L.vph_prove_and_verify_full.argtypes = [vp, ctypes.c_int, vp, u64, ctypes.POINTER(u64)] + [ctypes.POINTER(ctypes.c_double)] * 3 + [ctypes.c_char_p, ctypes.c_int]
         L.vph_last_fri.argtypes = [vp, vp, u64, vp, vp]
+        L.vph_last_point.argtypes = [vp, vp, ctypes.c_int]
         L.vph_test_sha3.argtypes = [vp, vp, u64]
         L.vph_fri_commit.argtypes = [vp, vp, ctypes.c_int, vp, vp, ctypes.c_char_p, ctypes.c_int]
         L.vph_fri_commit_batched.argtypes = [vp, vp, ctypes.c_int, vp, vp, ctypes.c_char_p, ctypes.c_int]
@@ -190,6 +205,105 @@ def allreduce_transcript(tr, device=None):
         t = t.cuda(device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t.cpu().numpy().tobytes()
+
+
+class ShardedCommitment:
+    """The Virgo commitment sharded over `world` ranks (include/vpgpu.h: vp_pc_set_shard), rehearsed as `world` light contexts of ONE
+    process on one GPU: every rank runs the same entry points a multi-GPU run would, the collectives between them (one all-to-all per
+    committed oracle, one all-gather of the level-5 tree nodes) are performed by vp_shard_exchange_local instead of RCCL."""
+    VP_EXCHANGE = 1
+
+    def __init__(self, inputs, bit_length, world, device=0):
+        import numpy as np
+        L = lib_gpu()
+        self.world, self.n = world, bit_length
+        inputs = np.ascontiguousarray(inputs, dtype=np.uint64)
+        self.ctx = []
+        for r in range(world):
+            c = ctypes.c_void_p()
+            if L.vp_create(device, ctypes.byref(c)):
+                raise RuntimeError("vp_create failed")
+            self.ctx.append(c)
+            self._chk(L.vp_pc_load_input(c, inputs.ctypes.data, inputs.shape[0], bit_length), c, "vp_pc_load_input")
+            self._chk(L.vp_pc_set_shard(c, r, world), c, "vp_pc_set_shard")
+        self.arr = (ctypes.c_void_p * world)(*[c.value for c in self.ctx])
+
+    @staticmethod
+    def _chk(rc, c, what):
+        if rc < 0:
+            raise RuntimeError("%s failed (%d): %s" % (what, rc, lib_gpu().vp_last_error(c).decode()))
+
+    def _run(self, call, what):
+        """call(rank) on every rank until all report VP_OK, exchanging whenever all report VP_EXCHANGE."""
+        L = lib_gpu()
+        for _ in range(8):
+            rcs = [call(r) for r in range(self.world)]
+            for r, rc in enumerate(rcs):
+                self._chk(rc, self.ctx[r], what)
+            if all(rc == 0 for rc in rcs):
+                return
+            if not all(rc == self.VP_EXCHANGE for rc in rcs):
+                raise RuntimeError("%s: ranks disagree on the protocol stage %r" % (what, rcs))
+            self._chk(L.vp_shard_exchange_local(self.arr, self.world), self.ctx[0], "vp_shard_exchange_local")
+        raise RuntimeError("%s did not finish" % what)
+
+    def device_ms(self):
+        out = []
+        for c in self.ctx:
+            ms = ctypes.c_double(0)
+            lib_gpu().vp_commit_stats(c, ctypes.byref(ms))
+            out.append(ms.value)
+        return out
+
+    def commit_private(self):
+        roots = [ctypes.create_string_buffer(32) for _ in range(self.world)]
+        self._run(lambda r: lib_gpu().vp_commit_private(self.ctx[r], ctypes.cast(roots[r], ctypes.c_void_p)), "vp_commit_private")
+        assert all(x.raw == roots[0].raw for x in roots), "ranks disagree on the root"
+        return roots[0].raw
+
+    def commit_public(self, pub):
+        import numpy as np
+        pub = np.ascontiguousarray(pub, dtype=np.uint64)
+        roots = [ctypes.create_string_buffer(32) for _ in range(self.world)]
+        inner = [np.zeros(2, np.uint64) for _ in range(self.world)]
+        alls = [np.zeros((65, 2), np.uint64) for _ in range(self.world)]
+        self._run(lambda r: lib_gpu().vp_commit_public(self.ctx[r], pub.ctypes.data, pub.shape[0], inner[r].ctypes.data, alls[r].ctypes.data,
+                                                       ctypes.cast(roots[r], ctypes.c_void_p)), "vp_commit_public")
+        for r in range(1, self.world):
+            assert roots[r].raw == roots[0].raw and inner[r].tobytes() == inner[0].tobytes() and alls[r].tobytes() == alls[0].tobytes()
+        return roots[0].raw, inner[0].tobytes(), alls[0].tobytes()
+
+    def fri_commit(self, r):
+        import numpy as np
+        r = np.ascontiguousarray(r, dtype=np.uint64)
+        st = r.shape[0]
+        roots = [ctypes.create_string_buffer(32 * st) for _ in range(self.world)]
+        self._run(lambda k: lib_gpu().vp_fri_commit(self.ctx[k], r.ctypes.data, st, ctypes.cast(roots[k], ctypes.c_void_p)), "vp_fri_commit")
+        fins = []
+        for k in range(self.world):
+            fin = np.zeros((2048, 2), dtype=np.uint64)
+            self._chk(lib_gpu().vp_fri_final(self.ctx[k], fin.ctypes.data), self.ctx[k], "vp_fri_final")
+            fins.append(fin)
+        for k in range(1, self.world):
+            assert roots[k].raw == roots[0].raw and np.array_equal(fins[k], fins[0])
+        return roots[0].raw, fins[0]
+
+    def open(self, oracle, leaf, rank=None):
+        """(values (130, 2), path digests) of one leaf, asked of its owner (or of `rank`)."""
+        import numpy as np
+        owner = ((leaf >> 5) % self.world) if rank is None else rank
+        vals = np.zeros((130, 2), dtype=np.uint64)
+        path = ctypes.create_string_buffer(32 * 40)
+        n = ctypes.c_int(0)
+        rc = lib_gpu().vp_fri_open(self.ctx[owner], oracle, leaf, vals.ctypes.data, ctypes.cast(path, ctypes.c_void_p), len(path), ctypes.byref(n))
+        if rc:
+            return None
+        return vals, [path.raw[32 * i:32 * i + 32] for i in range(n.value)]
+
+    def close(self):
+        for c in self.ctx:
+            lib_gpu().vp_destroy(c)
+        self.ctx = []
 
 
 class Circuit:
@@ -405,6 +519,27 @@ class Session:
         if st < 0:
             raise RuntimeError("no complete-protocol run on this session yet")
         return roots.raw[:32 * st], fin, r[:st].copy()
+
+    def last_point(self):
+        """r_liu after the last Liu sumcheck of the last prove_full / prove_and_verify_full, (n, 2) uint64."""
+        import numpy as np
+        out = np.zeros((64, 2), dtype=np.uint64)
+        n = lib_host().vph_last_point(self.h, out.ctypes.data, 64)
+        if n < 0:
+            raise RuntimeError("no complete-protocol run on this session yet")
+        return out[:n].copy()
+
+    def eq_table(self, point):
+        """eq(point, .) over 2^n entries on the device (vp_test_beta): the protocol's public vector for point = last_point()."""
+        import numpy as np
+        point = np.ascontiguousarray(point, dtype=np.uint64)
+        n = point.shape[0]
+        one = np.array([1, 0], dtype=np.uint64)
+        out = np.zeros((1 << n, 2), dtype=np.uint64)
+        rc = lib_gpu().vp_test_beta(lib_host().vph_session_ctx(self.h), point.ctypes.data, n, one.ctypes.data, out.ctypes.data)
+        if rc:
+            raise RuntimeError("vp_test_beta failed")
+        return out
 
     def fri_commit(self, r, batched=True):
         """FRI commit phase with the given fold challenges ((steps, 2) uint64): (roots bytes, final codeword (2048, 2)).

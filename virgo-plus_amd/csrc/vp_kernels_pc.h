@@ -275,9 +275,9 @@ namespace vp {
 // Products l*q on the two cosets the quotient needs: positions 16*j, j < 2N, are coset 0 (j even) and coset 16
 // (j odd) of the coset-major codewords.  P[(2i)*N + a] = l_i*q_i at w_M^(32a), P[(2i+1)*N + a] at w_M^(32a+16).
 __global__ void __launch_bounds__(VP_BLOCK)
-k_pc_products(const F *__restrict__ lcw, const F *__restrict__ qcw, u32 N, F *__restrict__ P) {
+k_pc_products(const F *__restrict__ lcw, const F *__restrict__ qcw, u32 N, F *__restrict__ P, u32 n_slices) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= 128 * N) return;
+    if (t >= 2 * n_slices * N) return;
     const u32 a = t % N, r = t / N, i = r >> 1, b = (r & 1) ? 16 : 0;
     const size_t src = ((size_t) i * 32 + b) * N + a;
     P[t] = f_mul(lcw[src], qcw[src]);
@@ -287,9 +287,9 @@ k_pc_products(const F *__restrict__ lcw, const F *__restrict__ qcw, u32 N, F *__
 // inverse transform; this is the same polynomial from two N-point ones), all_sum = (lq_coef[0] + h_coef[0]) * N = S_0 * N.
 __global__ void __launch_bounds__(VP_BLOCK)
 k_pc_quotient(const F *__restrict__ ST, u32 N, const F *__restrict__ RT, u32 half_m, F inv2, F n_as_f, F *__restrict__ H,
-              F *__restrict__ all_sum) {
+              F *__restrict__ all_sum, u32 n_slices) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= 64 * N) return;
+    if (t >= n_slices * N) return;
     const u32 j = t % N, i = t / N;
     const F S = ST[(size_t) (2 * i) * N + j], T = ST[(size_t) (2 * i + 1) * N + j];
     const u32 M = 2 * half_m;
@@ -323,10 +323,10 @@ namespace vp {
 // Written in place over the q codeword (same coset-major index).
 __global__ void __launch_bounds__(VP_BLOCK)
 k_pc_virtual_oracle(const F *__restrict__ lcw, F *__restrict__ qcw, const F *__restrict__ hcw, const F *__restrict__ S0, u32 N,
-                    const F *__restrict__ RT, u32 half_m, F n_as_f) {
+                    const F *__restrict__ RT, u32 half_m, F n_as_f, u32 n_slices) {
     const size_t t = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
     const size_t M = 2 * (size_t) half_m;
-    if (t >= 64 * M) return;
+    if (t >= n_slices * M) return;
     const u32 a = (u32) (t % N), b = (u32) ((t / N) % 32), i = (u32) (t / M);
     const u32 k = 32 * a + b;
     const F xn_m1 = f_sub(root_pow(RT, half_m, (u32) ((size_t) b * N) & (u32) (M - 1)), f_one());   // w_M^(N*b) - 1
@@ -337,18 +337,21 @@ k_pc_virtual_oracle(const F *__restrict__ lcw, F *__restrict__ qcw, const F *__r
 
 // One FRI fold of all 64 slices: out[s][b][a] = 1/2 ((p + q) + mu^-1 r (p - q)), p = in[s][b][a], q = in[s][b][a + Nk/2],
 // mu = w_k^(32a+b) with w_k = w_M^(2^k) the generator of the current domain (fri.cpp:312-331).
+// Position-sharded commitment (vpgpu_pc_shard.inc): a rank holds the positions a = a' * 2^lw + rank of every coset; Nk is then the
+// LOCAL per-coset length and the twiddle uses the global position.  lw = rank = 0: the whole codeword.
 __global__ void __launch_bounds__(VP_BLOCK)
-k_fri_fold(const F *__restrict__ in, F *__restrict__ out, u32 Nk, int k, const F *__restrict__ RT, u32 half_m, F r, F inv2) {
+k_fri_fold(const F *__restrict__ in, F *__restrict__ out, u32 Nk, int k, const F *__restrict__ RT, u32 half_m, F r, F inv2, int lw, u32 rank) {
     const size_t t = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
     const u32 No = Nk >> 1;                                   // per-coset length of the output (>= 1)
     if (t >= (size_t) 64 * 32 * No) return;
-    const u32 a = (u32) (t % No), sb = (u32) (t / No);        // sb = slice * 32 + coset
+    const u32 al = (u32) (t % No), sb = (u32) (t / No);       // sb = slice * 32 + coset
+    const u32 a = (al << lw) + rank;
     const u32 b = sb & 31;
     const u32 M = 2 * half_m;
     const u32 e = (u32) ((((unsigned long long) (32 * a + b)) << k) & (M - 1));
     const F inv_mu = root_pow(RT, half_m, e ? M - e : 0);
     F p, q;
-    if (Nk >= 2) { p = in[(size_t) sb * Nk + a]; q = in[(size_t) sb * Nk + a + No]; }
+    if (Nk >= 2) { p = in[(size_t) sb * Nk + al]; q = in[(size_t) sb * Nk + al + No]; }
     else { p = f_zero(); q = f_zero(); }
     out[t] = f_mul(inv2, f_add(f_add(p, q), f_mul(f_mul(inv_mu, r), f_sub(p, q))));
 }

@@ -64,6 +64,8 @@ struct EvPair { hipEvent_t a, b; u64 bytes; int kind; u32 grid, jobs, rounds, fi
 
 }  // namespace
 
+struct PcShard;            // commitment sharded over ranks (vpgpu_pc_shard.inc)
+struct VpComm;             // RCCL communicator (vpgpu_pc_shard.inc)
 // One in-order chain of the batched proof: its own stream and scratch, so that independent sumchecks
 // (all of them, given the tape, except phase 1 -> phase 2 of the same layer) overlap on the device.
 struct Lane {
@@ -143,6 +145,8 @@ struct vp_ctx {
     Dig *pc_fri_roots = nullptr;
     F *pc_fri[2] = {nullptr, nullptr}; Dig *pc_fri_tree = nullptr; int fri_step = -1; size_t fri_tree_used = 0; bool pc_public_done = false;
 
+    PcShard *pcs = nullptr;              // non-null while the commitment is sharded over ranks (vp_pc_set_shard, world > 1)
+    VpComm *cm = nullptr;                // RCCL communicator (vp_comm_init)
     F *part2 = nullptr;                  // [32][MAX_BLOCKS*3] block partials of the batched path
     int simple_path = 0, sumfold_path = 0, serial = 0;
     Lane lane0; Lane *ln = nullptr;
@@ -545,11 +549,15 @@ int vp_create(int device, vp_ctx **out) {
 }
 
 static void free_plan(vp_ctx *ctx);
+void vp_free_shard_state(vp_ctx *ctx);
+void vp_free_comm(vp_ctx *ctx);
 
 void vp_destroy(vp_ctx *ctx) {
     if (!ctx) return;
     (void) hipSetDevice(ctx->device);
     (void) hipStreamSynchronize(ctx->stream);
+    vp_free_shard_state(ctx);
+    vp_free_comm(ctx);
     if (ctx->gkr_graph) (void) hipGraphExecDestroy(ctx->gkr_graph);
     free_plan(ctx);
     free_all(ctx);
@@ -574,6 +582,7 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
     if (ctx->gkr_graph) { (void) hipGraphExecDestroy(ctx->gkr_graph); ctx->gkr_graph = nullptr; }
     ctx->graph_failed = false;
     free_plan(ctx);
+    vp_free_shard_state(ctx);
     free_all(ctx);
     ctx->L.assign(n_layers, LayerDev());
     ctx->n_layers = n_layers;
@@ -1252,3 +1261,4 @@ int vp_test_beta(vp_ctx *ctx, const vp_F *r, int n, const vp_F *init, vp_F *out)
 
 #include "vpgpu_batched.inc"
 #include "vpgpu_pc.inc"
+#include "vpgpu_pc_shard.inc"

@@ -14,6 +14,7 @@ struct vph_session {
     std::unique_ptr<prover> p;
     std::vector<F> tape;
     std::vector<uint8_t> fri_roots; std::vector<F> fri_final, fri_r;      // FRI commit phase of the last complete-protocol run
+    std::vector<F> last_point;                                           // r_liu after the last Liu sumcheck of the last complete-protocol run
 };
 
 static void set_err(char *err, int errlen, const std::string &m) {
@@ -237,6 +238,7 @@ int vph_prove_and_verify_full(vph_session *s, int reps, uint8_t *transcript, uin
         const double t0 = s->p->proveTime();
         const bool ok = v.verifyFull(reps);
         s->fri_roots = v.friRoots(); s->fri_final = v.friFinalCode(); s->fri_r = v.friChallenges();
+        s->last_point.assign(v.finalPoint().begin(), v.finalPoint().begin() + s->circ->c.circuit[0].bitLength);
         const auto &tr = v.fullTranscript();
         if (tr.size() > capacity) { set_err(err, errlen, "transcript buffer too small"); return -1; }
         memcpy(transcript, tr.data(), tr.size());
@@ -260,6 +262,14 @@ int vph_last_fri(vph_session *s, uint8_t *roots, uint64_t roots_cap, uint64_t *f
     if (final_pairs) memcpy(final_pairs, s->fri_final.data(), s->fri_final.size() * sizeof(F));
     if (r_pairs) memcpy(r_pairs, s->fri_r.data(), s->fri_r.size() * sizeof(F));
     return steps;
+}
+
+// The point the input layer is opened at (r_liu after the last Liu sumcheck) in the last vph_prove_full / vph_prove_and_verify_full:
+// the protocol's public vector is its eq table (src/verifier.cpp:368-369).  Returns the number of coordinates or -1.
+int vph_last_point(vph_session *s, uint64_t *pairs, int cap) {
+    if (!s || s->last_point.empty() || cap < (int) s->last_point.size()) return -1;
+    memcpy(pairs, s->last_point.data(), s->last_point.size() * sizeof(F));
+    return (int) s->last_point.size();
 }
 
 void vph_test_sha3(const uint8_t *in, uint8_t *out, uint64_t n) {
@@ -312,6 +322,7 @@ int vph_prove_full(vph_session *s, uint8_t *transcript, uint64_t capacity, uint6
         }
         out.insert(out.end(), v.transcript().begin(), v.transcript().end());
         // verifyPoly (verifier.cpp:363-379): the public vector is eq(r_liu, .) over the input layer
+        s->last_point.assign(v.finalPoint().begin(), v.finalPoint().begin() + s->circ->c.circuit[0].bitLength);
         std::vector<F> pub;
         initBetaTable(pub, s->circ->c.circuit[0].bitLength, v.finalPoint().begin(), F_ONE);
         pub.resize(1ull << s->circ->c.circuit[0].bitLength);

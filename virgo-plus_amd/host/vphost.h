@@ -75,6 +75,9 @@ int vph_prove_and_verify_full(vph_session *, int reps, uint8_t *transcript, uint
 /* FRI commit phase of the last vph_prove_and_verify_full: Merkle root per fold step (32 bytes each), final codeword (2048
  * elements), fold challenges (one element per step); any pointer may be NULL.  Returns the number of steps or -1. */
 int vph_last_fri(vph_session *, uint8_t *roots, uint64_t roots_cap, uint64_t *final_pairs, uint64_t *r_pairs);
+/* r_liu after the last Liu sumcheck of the last vph_prove_full / vph_prove_and_verify_full (the protocol's public vector is its eq
+ * table, src/verifier.cpp:368-369); returns the number of coordinates or -1. */
+int vph_last_point(vph_session *, uint64_t *pairs, int cap);
 /* my_hhash on the host (verifier side): SHA3-256 of n 64-byte messages.                                   */
 void vph_test_sha3(const uint8_t *in, uint8_t *out, uint64_t n);
 /* poly_commit_prover::commit_phase (vpd_verifier.cpp:44-74) with caller-supplied fold challenges: n_steps calls of
