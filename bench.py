@@ -323,7 +323,8 @@ def x1024_leg(vp, pws, golden, a, local):
     ok_d, sec_d = sess.check(tr, device_predicates=True)
     t_i = time.perf_counter()
     tr_i, res_i, ok_i = sess.prove_interactive()
-    inter = {"prover_sec": res_i["prove_sec"], "wall_sec_with_host_verifier": time.perf_counter() - t_i, "transcript_equals_batched": tr_i == tr, "verified": ok_i}
+    inter = {"prover_sec": res_i["prove_sec"], "init_calls_sec": res_i.get("init_sec"), "round_calls_sec": res_i.get("round_sec"),
+             "finalize_calls_sec": res_i.get("finalize_sec"), "wall_sec_with_host_verifier": time.perf_counter() - t_i, "transcript_equals_batched": tr_i == tr, "verified": ok_i}
     sess.draw_tape()
     fx = os.path.join(ROOT, "tests", "golden", "oracle_sha256_x1024_full.bin")
     pc = pc_leg(vp, sess, circ, golden, "sha256_x%d" % B, full_fixture=fx if os.path.exists(fx) else None)
@@ -447,7 +448,8 @@ def main():
             # the drop-in path of the reference's own call pattern (one vp_round per verifier message), outside the timed region
             t_i = time.perf_counter()
             tr_i, res_i, ok_i = sess.prove_interactive()
-            interactive = {"prover_sec": res_i["prove_sec"], "wall_sec_with_host_verifier": time.perf_counter() - t_i,
+            interactive = {"prover_sec": res_i["prove_sec"], "init_calls_sec": res_i.get("init_sec"), "round_calls_sec": res_i.get("round_sec"),
+                           "finalize_calls_sec": res_i.get("finalize_sec"), "wall_sec_with_host_verifier": time.perf_counter() - t_i,
                            "transcript_equals_batched": tr_i == tr, "verified": ok_i,
                            "note": "reference definition of Prove Time (sum of prover-method spans) over the interactive entry points (vp_round per verifier message)"}
             sess.draw_tape()

@@ -670,6 +670,62 @@ def test_commitment_sharded_over_ranks(vp, golden, pws_path, name, blocks, world
         _sharded_commitment_case(vp, inputs, n, pub, r, world, gold[:32], gold[-(32 + 16 + 65 * 16):], roots_gold, fin_gold)
 
 
+def test_rccl_transport_on_one_rank(vp, golden, pws_path):
+    """The RCCL transport of include/vpgpu.h (vp_comm_unique_id / vp_comm_init, librccl resolved at run time) on the one GPU of this
+    box: a one-rank communicator; vp_allreduce_u64 on a device buffer; and the sharded commitment code path with world = 1, whose
+    all-to-all (ncclSend / ncclRecv group) and all-gather then run through RCCL instead of the in-process exchange."""
+    import os
+    from conftest import GOLDEN
+    L = vp.lib_gpu()
+    g = golden["sha256_x1"]
+    gold = open(os.path.join(GOLDEN, g["transcript"]), "rb").read()
+    c = vp.Circuit.from_pws(pws_path, 1, seed=1)
+    s = vp.Session(c)
+    full, ok = s.prove_full(batched=True)
+    assert ok and full == gold
+    inputs = s.layer_values(0)
+    pub = s.eq_table(s.last_point())
+    n = c.layer_bitlen(0)
+    s.close(); c.close()
+    uid = ctypes.create_string_buffer(128)
+    assert L.vp_comm_unique_id(ctypes.cast(uid, ctypes.c_void_p)) == 0
+    ctx = ctypes.c_void_p()
+    assert L.vp_create(0, ctypes.byref(ctx)) == 0
+    assert L.vp_comm_init(ctx, ctypes.cast(uid, ctypes.c_void_p), 0, 1) == 0, L.vp_last_error(ctx)
+    # all-reduce of a device buffer (sum over one rank = identity), through hipMalloc'ed memory
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    buf = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(buf), 8 * 1000) == 0
+    a = np.random.default_rng(3).integers(0, 1 << 62, size=1000, dtype=np.uint64)
+    assert hip.hipMemcpy(buf, a.ctypes.data, a.nbytes, 1) == 0
+    assert L.vp_allreduce_u64(ctx, buf, 1000) == 0
+    assert hip.hipDeviceSynchronize() == 0
+    b = np.zeros_like(a)
+    assert hip.hipMemcpy(b.ctypes.data, buf, a.nbytes, 2) == 0
+    assert np.array_equal(a, b)
+    hip.hipFree(buf)
+    # the sharded commitment, one rank, collectives over RCCL: the reference's roots
+    inputs = np.ascontiguousarray(inputs, dtype=np.uint64)
+    assert L.vp_pc_load_input(ctx, inputs.ctypes.data, inputs.shape[0], n) == 0
+    assert L.vp_pc_set_shard(ctx, 0, 1) == 0
+    root = ctypes.create_string_buffer(32)
+    assert L.vp_commit_private(ctx, ctypes.cast(root, ctypes.c_void_p)) == 0, L.vp_last_error(ctx)
+    assert root.raw == gold[:32]
+    pub = np.ascontiguousarray(pub, dtype=np.uint64)
+    inner = np.zeros(2, np.uint64); alls = np.zeros((65, 2), np.uint64); rh = ctypes.create_string_buffer(32)
+    assert L.vp_commit_public(ctx, pub.ctypes.data, pub.shape[0], inner.ctypes.data, alls.ctypes.data, ctypes.cast(rh, ctypes.c_void_p)) == 0, L.vp_last_error(ctx)
+    assert rh.raw + inner.tobytes() + alls.tobytes() == gold[-(32 + 16 + 65 * 16):]
+    r, roots_gold, fin_gold = _fri_golden(golden, "sha256_x1")
+    roots = ctypes.create_string_buffer(32 * r.shape[0])
+    assert L.vp_fri_commit(ctx, r.ctypes.data, r.shape[0], ctypes.cast(roots, ctypes.c_void_p)) == 0, L.vp_last_error(ctx)
+    assert roots.raw == roots_gold
+    assert L.vp_comm_destroy(ctx) == 0
+    L.vp_destroy(ctx)
+
+
 def test_sha256_x256_size_independent_properties(vp, pws_path):
     """256 blocks (25.6 M gates): no oracle run at this size; the host verifier (sumcheck identities, Liu identity,
     final input-layer check) must accept the device transcript, the proof must be reproducible, and a different
@@ -790,6 +846,62 @@ def test_limits_and_call_order_are_errors_not_crashes(vp, ob, ctx):
     out = (ctypes.c_uint64 * 2)()
     a = (ctypes.c_uint64 * 2)(3, 4)
     assert lib.vp_test_field(ctx, 2, a, a, out, 1) == 0            # the context still works
+
+
+@pytest.mark.parametrize("mode", ["launch_per_round", "resident", "resident_distributed"])
+def test_interactive_path_variants(vp, golden, gold_gkr, pws_path, monkeypatch, mode):
+    """The drop-in entry points (vp_round per verifier message) in their three forms — one launch per round (VP_PERSIST=0), the
+    resident mailbox kernel for the rounds that fit one CU (default), and the same with the distributed rounds of the large
+    single-table phases (VP_PERSIST_MULTI=1): the real reference's transcript in every case, on SHA-256 x16 (tables up to 2^20:
+    distributed rounds with 128 workgroups, the hand-over to the solo regime, multi-table phase 2) and on a ragged small circuit."""
+    if mode == "launch_per_round":
+        monkeypatch.setenv("VP_PERSIST", "0")
+    elif mode == "resident_distributed":
+        monkeypatch.setenv("VP_PERSIST_MULTI", "1")
+    c = vp.Circuit.from_pws(pws_path, 16, seed=1)
+    s = vp.Session(c)
+    tr, res, ok = s.prove_interactive()
+    assert ok and tr == gold_gkr("sha256_x16")
+    tr2, _, ok2 = s.prove_interactive()                 # a second proof on the same context (mailbox sequence numbers keep counting)
+    assert ok2 and tr2 == tr
+    s.close(); c.close()
+    c = vp.Circuit.randomize(8, 12, seed=1)
+    s = vp.Session(c)
+    tr, _, ok = s.prove_interactive()
+    assert ok and tr == gold_gkr("randomize_8_12")
+    s.close(); c.close()
+
+
+def test_abandoned_sumcheck_releases_the_resident_kernel(vp, gold_gkr):
+    """A caller that stops in the middle of a sumcheck (the resident round kernel is waiting for the next challenge) and calls any
+    other entry point: the kernel is told to leave first, nothing hangs, and the context proves correctly afterwards."""
+    c = vp.Circuit.randomize(8, 12, seed=1)
+    s = vp.Session(c)
+    L = vp.lib_gpu()
+    ctx = vp.lib_host().vph_session_ctx(s.h)
+    L.vp_vres.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_int, ctypes.c_void_p]
+    L.vp_phase1_init.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    L.vp_round.argtypes = [ctypes.c_void_p] * 3
+    L.vp_finalize.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int]
+    rng = np.random.default_rng(4)
+    r = np.ascontiguousarray(rng.integers(0, P, size=(16, 2), dtype=np.uint64))
+    one = np.array([1, 0], dtype=np.uint64)
+    out = np.zeros((3, 2), dtype=np.uint64)
+    assert L.vp_vres(ctx, r.ctypes.data, 12, out.ctypes.data) == 0
+    assert L.vp_phase1_init(ctx, 7, r.ctypes.data, one.ctypes.data) == 0
+    zero = np.zeros(2, dtype=np.uint64)
+    assert L.vp_round(ctx, zero.ctypes.data, out.ctypes.data) == 0
+    for k in range(3):                                   # the table (2^12 entries) fits one CU from round 2 on: the kernel is resident now
+        assert L.vp_round(ctx, r[k].ctypes.data, out.ctypes.data) == 0
+    assert L.vp_phase1_init(ctx, 7, r.ctypes.data, one.ctypes.data) == 0        # abandon: start the phase again
+    assert L.vp_round(ctx, zero.ctypes.data, out.ctypes.data) == 0
+    a = out.copy()
+    assert L.vp_round(ctx, r[0].ctypes.data, out.ctypes.data) == 0
+    tr, _, ok = s.prove_interactive()                    # abandon again, through the host API this time
+    assert ok and tr == gold_gkr("randomize_8_12")
+    s.draw_tape()
+    assert s.prove_gkr()[0] == tr
+    s.close(); c.close()
 
 
 def test_violated_assert_gate_is_reported(vp):

@@ -167,6 +167,7 @@ def lib_host():
         L.vph_prove_and_verify_full.argtypes = [vp, ctypes.c_int, vp, u64, ctypes.POINTER(u64)] + [ctypes.POINTER(ctypes.c_double)] * 3 + [ctypes.c_char_p, ctypes.c_int]
         L.vph_last_fri.argtypes = [vp, vp, u64, vp, vp]
         L.vph_last_point.argtypes = [vp, vp, ctypes.c_int]
+        L.vph_interactive_breakdown.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
         L.vph_test_sha3.argtypes = [vp, vp, u64]
         L.vph_fri_commit.argtypes = [vp, vp, ctypes.c_int, vp, vp, ctypes.c_char_p, ctypes.c_int]
         L.vph_fri_commit_batched.argtypes = [vp, vp, ctypes.c_int, vp, vp, ctypes.c_char_p, ctypes.c_int]
@@ -426,6 +427,9 @@ class Session:
     def prove_interactive(self):
         """F::init() + verifier::verify(): returns (transcript bytes, stats, verified)."""
         tr, res, rc = self._call(lib_host().vph_prove_interactive)
+        b = (ctypes.c_double * 3)()
+        lib_host().vph_interactive_breakdown(self.h, b)
+        res["init_sec"], res["round_sec"], res["finalize_sec"] = b[0], b[1], b[2]
         return tr, res, rc == 0
 
     def prove_fs(self):

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include "vp_field.h"
 #include "vp_kernels_round.h"
+#include "vp_kernels_persist.h"
 #include "vp_kernels_batch.h"
 #include "vp_kernels_init3.h"
 #include "vp_kernels_plan.h"

@@ -1,0 +1,488 @@
+// Interactive path: the persistent round kernel.  Part of the single translation unit vpgpu.hip.
+#pragma once
+#include "vp_kernels_round.h"
+
+// ===================================================================================================
+// The drop-in entry point vp_round (prover::sumcheckUpdate*, src/prover.cpp:422-492) answers ONE verifier message per call,
+// and the verifier only draws the next challenge after it has seen the answer (src/verifier.cpp:206-215): a sumcheck of n
+// rounds is n dependent host <-> device round trips.  A kernel launch per round costs ~13 us before any work is done
+// (tools/mailbox_probe.hip on MI355X: launch + pinned-memory reply poll); a resident kernel that waits on a mailbox in pinned
+// host memory answers in 3.0 us plus its compute (same probe).  So a phase is served by ONE launch of k_phase:
+//
+//   request  (host -> device, pinned host memory): three words r.re | r.im | cmd   (cmd 1: round, 2: finalize, 3: quit)
+//   reply    (device -> host, pinned host memory): seven words, the six limbs of the round polynomial | status; claims go to the
+//            pinned claims array.  Every word carries the low three bits of the message's sequence number in its bits 61-63 (a
+//            limb is < 2^61): a message is complete when all its words show the expected tag, so neither side needs a separate
+//            "ready" word behind a fence or a wait for the stores to be acknowledged.
+//   Every wait is bounded: the kernel leaves after VP_PH_TIMEOUT_TICKS (100 MHz s_memrealtime) without a message (status 2,
+//   the next call reports VP_EHIP); the host gives up after 15 s.
+//
+// Two regimes inside the launch:
+//   * distributed rounds (single-table phases — phase 1 and the Liu sumcheck — while the table has more than 2 * VP_PH_PMAX
+//     entries): G workgroups, workgroup g owns a fixed power-of-two slice of the table; a fold pairs ADJACENT entries
+//     (src/prover.cpp:470-487), so the slice a workgroup folds in round k is exactly what it wrote in round k-1 — no table data
+//     crosses workgroups and no fence is needed for it.  Per round: workgroup 0 takes the challenge from the host mailbox and
+//     re-publishes it in device memory (the others poll that word, not the PCIe link), every workgroup leaves its three partial
+//     sums with write-through (sc1) stores and arrives on a counter, workgroup 0 adds them up and answers the host.
+//   * solo rounds (every live table of the phase fits one CU's LDS: <= VP_PH_PMAX pairs): workgroup 0 alone; tables in LDS at
+//     full power-of-two length, folded in place; wave-uniform roles split a pair's nine multiplications over three waves (fold V /
+//     mult / add, then one product each), waves that can never have work again exit.  Entered directly for multi-table phases
+//     (phase 2) once they are small enough, and by the distributed regime after ONE release/acquire hand-over of the table.
+// Semantics (retiring single-entry tables into add_term, src/prover.cpp:445,462-467; claims, :494-521) are those of k_round_final /
+// k_finalize, which stay the path for the rounds of multi-table phases that are too large for one CU.
+// ===================================================================================================
+namespace vp {
+
+#define VP_PH_THREADS 768                       // 12 waves = 4 groups x 3 roles
+#define VP_PH_PMAX 1024                         // pairs of the first solo round (LDS: 3 x 2048 entries = 96 KiB)
+#define VP_PH_SLOTS 256                         // pair slots per pass (4 groups x 64 lanes)
+#define VP_PH_MAXIT (VP_PH_PMAX / VP_PH_SLOTS)
+#define VP_PH_TIMEOUT_TICKS 1000000000ull       // 10 s of s_memrealtime (100 MHz)
+#define VP_MULTI_MAXG 256
+
+struct TailMail { unsigned long long w[3], pad[5]; };                     // r.re | r.im | cmd, each | (seq & 7) << 61
+struct TailReply { unsigned long long w[7]; unsigned long long dead;     // poly limbs a.re a.im b.re b.im c.re c.im | status, tagged; dead = 1: the kernel has left on its own (time-out)
+                   unsigned long long stamps[16]; };                    // stamps: -DVP_TAIL_STAMPS diagnostic build only
+#define VP_TAG(seq) (((unsigned long long) (seq) & 7ull) << 61)
+#define VP_UNTAG(x) ((x) & 0x1fffffffffffffffull)
+#ifdef VP_TAIL_STAMPS
+#define TSTAMP(i) do { if (tid == 0) __hip_atomic_store(&a.rep->stamps[i], (unsigned long long) __builtin_amdgcn_s_memtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } while (0)
+#else
+#define TSTAMP(i) do { } while (0)
+#endif
+struct MultiSync {                                // device memory, one per context
+    unsigned long long arrive;                    // monotonic arrival counter of the workgroups other than 0
+    unsigned long long pad0[7];
+    unsigned long long bseq, br_re, br_im, bcmd;  // challenge re-published by workgroup 0
+    unsigned long long pad1[4];
+    unsigned long long part[VP_MULTI_MAXG][8];    // per workgroup: 3 partial sums (6 words)
+};
+
+// per-table data of a launch: written by the host into pinned memory, read once by the kernel (kernel arguments indexed per lane
+// would be copied to scratch)
+struct TailAux {
+    TabDesc t[VP_MAX_TAB];        // first SOLO round as do_round builds it (inputs in global memory; pair_start over FULL folded lengths)
+    int bl[VP_MAX_TAB];           // log2 of the table's length at round 1 (finalize)
+    u32 len_out0[VP_MAX_TAB];     // length of table j after the first solo round's fold (0: table already retired)
+    u32 loff[VP_MAX_TAB];         // LDS offset (entries) of table j
+};
+struct PTailArgs {
+    const TailAux *aux;
+    const F *inV, *inM, *inA; F rv; int fold; u32 total_pairs;      // first solo round of a multi-table phase
+    int k0, R, n_tab, has_a;
+    u32 cap;                      // LDS entries per table family
+    F *add_term, *scalarV, *claims_dev, *Vu, *poly_dev;
+    TailMail *req; TailReply *rep; F *claims_host;
+    unsigned long long seq0;      // the reply to the first round of the launch carries seq0, message i after it seq0 + i
+    // distributed regime (G > 1): one table, rounds 1 .. kc-1 on G workgroups, solo from round kc
+    int G, kc;
+    u32 off, len0, valid0, B1;    // table offset in the buffers, length / valid entries at round 1, slice of table_1 per workgroup (power of two)
+    const F *V0, *M0, *A0;        // round-1 sources
+    F *buf[2][3];                 // ping-pong buffers (ctx->tab)
+    F *hand[3];                   // hand-over copy of the table the LAST distributed round writes (<= 4096 entries per family): addresses
+                                  // workgroup 0 has not read earlier in this launch, so its XCD's L2 cannot hold stale lines of them
+    MultiSync *sync; unsigned long long arrive0;     // counter value before the launch
+};
+
+// ---- small helpers ----------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long ld_sc1(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_sc1(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// wave totals -> red[w][3]; after the caller's barrier wave 0 adds the first `nw` rows; totals valid in lane 63 of wave 0
+__device__ __forceinline__ void tail_wave_partials(F (&acc)[3], F *red) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) acc[i] = wave_sum63(acc[i]);
+    if (lane == 63) { red[w * 3] = acc[0]; red[w * 3 + 1] = acc[1]; red[w * 3 + 2] = acc[2]; }
+}
+__device__ __forceinline__ void tail_wave0_total(const F *red, int nw, F (&tot)[3]) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tot[i] = wave_sum63(lane < nw ? red[lane * 3 + i] : f_zero());
+}
+// thread 0: wait for mailbox message `expect`; returns cmd (> 0) with r, or -1 after the timeout
+__device__ __forceinline__ int tail_poll(const PTailArgs &a, unsigned long long expect, F &r) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), tag = VP_TAG(expect);
+    for (;;) {
+        // relaxed system-scope loads read the fine-grained host memory past the caches; no acquire (it would invalidate them on every poll)
+        const unsigned long long w0 = __hip_atomic_load(&a.req->w[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((w0 & (7ull << 61)) == tag) {
+            const unsigned long long w1 = __hip_atomic_load(&a.req->w[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const unsigned long long w2 = __hip_atomic_load(&a.req->w[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((w1 & (7ull << 61)) == tag && (w2 & (7ull << 61)) == tag) { r = f_make(VP_UNTAG(w0), VP_UNTAG(w1)); return (int) VP_UNTAG(w2); }
+        }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > VP_PH_TIMEOUT_TICKS) return -1;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+__device__ __forceinline__ void tail_reply_words(const PTailArgs &a, unsigned long long seq, const F &pa, const F &pb, const F &pc, unsigned long long status) {
+    const unsigned long long tag = VP_TAG(seq);
+    unsigned long long *q = a.rep->w;
+    __hip_atomic_store(q, pa.re | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(q + 1, pa.im | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(q + 2, pb.re | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(q + 3, pb.im | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(q + 4, pc.re | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(q + 5, pc.im | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(q + 6, status | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void tail_reply(const PTailArgs &a, unsigned long long seq, const F &pa, const F &pb, const F &pc) {
+    a.poly_dev[0] = pa; a.poly_dev[1] = pb; a.poly_dev[2] = pc;
+    tail_reply_words(a, seq, pa, pb, pc, 0);
+}
+// leaving: status 0 ok (finalize done), 1 quit acknowledged, 2 timed out, 3 protocol error, 4 a workgroup did not arrive
+__device__ __forceinline__ void tail_leave(const PTailArgs &a, unsigned long long seq, int cmd, unsigned long long status) {
+    __threadfence_system();                                   // claims (finalize) and add_term are out before the reply
+    if (cmd == -1 || status == 4) __hip_atomic_store(&a.rep->dead, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    tail_reply_words(a, seq, f_zero(), f_zero(), f_zero(), status);
+}
+
+// ---- the launch ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(VP_PH_THREADS) k_phase(PTailArgs a) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    F *L = reinterpret_cast<F *>(smem_raw);                       // solo regime: [3][cap]
+    __shared__ F red[12 * 3];
+    __shared__ F s_r;
+    __shared__ int s_cmd;
+    __shared__ u32 s_len[VP_MAX_TAB];                              // solo: current length of table j in LDS
+    __shared__ u32 s_loff[VP_MAX_TAB]; __shared__ int s_bl[VP_MAX_TAB];
+    __shared__ TabDesc s_t[VP_MAX_TAB];                            // first solo round's table descriptors
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const bool boss = tid == 63;                                   // lane 63 of wave 0: holds add_term and the totals
+    F at = f_zero();
+    if (boss && blockIdx.x == 0) at = *a.add_term;
+    if (blockIdx.x == 0 && tid < a.n_tab) { s_t[tid] = a.aux->t[tid]; s_loff[tid] = a.aux->loff[tid]; s_bl[tid] = a.aux->bl[tid]; s_len[tid] = a.aux->len_out0[tid]; }
+    __syncthreads();
+    unsigned long long expect = a.seq0;                            // sequence number of the message answered last
+    int k = a.k0;                                                  // round answered last (after the first round below)
+
+    // ======================= distributed rounds: k = 1 .. kc-1 on G workgroups ==========================================
+    if (a.G > 1) {
+        const u32 g = blockIdx.x, G = (u32) a.G;
+        unsigned long long arrive = a.arrive0;
+        for (k = 1; k < a.kc; ++k) {
+            F r = f_zero();
+            if (k >= 2) {                                          // challenge r_{k-1}: host -> workgroup 0 -> everybody
+                ++expect;
+                if (tid == 0) {
+                    int cmd;
+                    if (g == 0) {
+                        cmd = tail_poll(a, expect, r);
+                        st_sc1(&a.sync->br_re, r.re); st_sc1(&a.sync->br_im, r.im); st_sc1(&a.sync->bcmd, (unsigned long long) (long long) cmd);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        st_sc1(&a.sync->bseq, expect);
+                    } else {
+                        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                        cmd = -1;
+                        for (;;) {
+                            if (ld_sc1(&a.sync->bseq) == expect) { cmd = (int) (long long) ld_sc1(&a.sync->bcmd); r = f_make(ld_sc1(&a.sync->br_re), ld_sc1(&a.sync->br_im)); break; }
+                            if (__builtin_amdgcn_s_memrealtime() - t0 > VP_PH_TIMEOUT_TICKS + 100000000ull) break;
+                            __builtin_amdgcn_s_sleep(2);
+                        }
+                    }
+                    s_r = r; s_cmd = cmd;
+                }
+                __syncthreads();
+                r = s_r;
+                if (s_cmd != 1) {                                  // quit / timeout / finalize out of order: everybody leaves
+                    if (g == 0 && boss) { *a.add_term = at; tail_leave(a, expect, s_cmd, s_cmd == 3 ? 1 : s_cmd == -1 ? 2 : 3); }
+                    return;
+                }
+            }
+            // slice of table_k owned by this workgroup: entries [g B_k, (g+1) B_k), pairs [g B_k / 2, (g+1) B_k / 2)
+            const u32 Bk = a.B1 >> (k - 1);
+            const u32 valid_k = (u32) (((u64) a.valid0 + (1ull << (k - 1)) - 1) >> (k - 1));
+            const u32 p_lo = g * (Bk >> 1), p_hi = min((g + 1) * (Bk >> 1), (valid_k + 1) >> 1);
+            F acc[3] = {f_zero(), f_zero(), f_zero()};
+            if (k == 1) {
+                const u32 vi = a.off + a.valid0;
+                for (u32 p = p_lo + tid; p < p_hi; p += blockDim.x) {
+                    const u32 i0 = a.off + 2 * p;
+                    const F v0 = ld_or_zero(a.V0, i0, vi), v1 = ld_or_zero(a.V0, i0 + 1, vi), m0 = ld_or_zero(a.M0, i0, vi), m1 = ld_or_zero(a.M0, i0 + 1, vi);
+                    F a0 = f_zero(), a1 = f_zero();
+                    if (a.has_a) { a0 = ld_or_zero(a.A0, i0, vi); a1 = ld_or_zero(a.A0, i0 + 1, vi); }
+                    const F dm = f_sub(m1, m0), dv = f_sub(v1, v0);
+                    const F qa = f_mul(dm, dv), qc = f_mul(m0, v0), qe = f_mul(m1, v1);
+                    acc[0] = f_add(acc[0], qa);
+                    acc[1] = f_add(acc[1], f_add(f_sub(f_sub(qe, qa), qc), f_sub(a1, a0)));
+                    acc[2] = f_add(acc[2], f_add(qc, a0));
+                }
+            } else {
+                const F *inV = k == 2 ? a.V0 : a.buf[k & 1][0], *inM = k == 2 ? a.M0 : a.buf[k & 1][1], *inA = k == 2 ? a.A0 : a.buf[k & 1][2];
+                const bool to_hand = k == a.kc - 1;                     // the table workgroup 0 takes over: written to the hand-over buffers (offset 0)
+                F *oV = to_hand ? a.hand[0] - a.off : a.buf[(k + 1) & 1][0], *oM = to_hand ? a.hand[1] - a.off : a.buf[(k + 1) & 1][1], *oA = to_hand ? a.hand[2] - a.off : a.buf[(k + 1) & 1][2];
+                const u32 valid_in = (u32) (((u64) a.valid0 + (1ull << (k - 2)) - 1) >> (k - 2));
+                const u32 vi = a.off + valid_in;
+                for (u32 p = p_lo + tid; p < p_hi; p += blockDim.x) {
+                    const u32 i0 = a.off + 4 * p, o0 = a.off + 2 * p;
+                    const bool w1 = 2 * p + 1 < valid_k;
+                    const F v0 = f_lerp(ld_or_zero(inV, i0, vi), ld_or_zero(inV, i0 + 1, vi), r), v1 = f_lerp(ld_or_zero(inV, i0 + 2, vi), ld_or_zero(inV, i0 + 3, vi), r);
+                    const F m0 = f_lerp(ld_or_zero(inM, i0, vi), ld_or_zero(inM, i0 + 1, vi), r), m1 = f_lerp(ld_or_zero(inM, i0 + 2, vi), ld_or_zero(inM, i0 + 3, vi), r);
+                    oV[o0] = v0; oM[o0] = m0;
+                    if (w1) { oV[o0 + 1] = v1; oM[o0 + 1] = m1; }
+                    F a0 = f_zero(), a1 = f_zero();
+                    if (a.has_a) {
+                        a0 = f_lerp(ld_or_zero(inA, i0, vi), ld_or_zero(inA, i0 + 1, vi), r); a1 = f_lerp(ld_or_zero(inA, i0 + 2, vi), ld_or_zero(inA, i0 + 3, vi), r);
+                        oA[o0] = a0; if (w1) oA[o0 + 1] = a1;
+                    }
+                    const F dm = f_sub(m1, m0), dv = f_sub(v1, v0);
+                    const F qa = f_mul(dm, dv), qc = f_mul(m0, v0), qe = f_mul(m1, v1);
+                    acc[0] = f_add(acc[0], qa);
+                    acc[1] = f_add(acc[1], f_add(f_sub(f_sub(qe, qa), qc), f_sub(a1, a0)));
+                    acc[2] = f_add(acc[2], f_add(qc, a0));
+                }
+            }
+            const bool last = k == a.kc - 1;                       // the table written now is read by workgroup 0 alone next round
+            if (g != 0) {
+                // block totals (two stages), left with write-through stores by one lane; the workgroup arrives once they are acknowledged
+                tail_wave_partials(acc, red);
+                __syncthreads();
+                F tot[3];
+                if (w == 0) tail_wave0_total(red, (int) (blockDim.x >> 6), tot);
+                if (boss) {
+                    unsigned long long *pp = a.sync->part[g];
+                    st_sc1(pp, tot[0].re); st_sc1(pp + 1, tot[0].im); st_sc1(pp + 2, tot[1].re); st_sc1(pp + 3, tot[1].im); st_sc1(pp + 4, tot[2].re); st_sc1(pp + 5, tot[2].im);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the partial (and, in the last round, every wave's table stores) are out
+                if (last) __syncthreads();
+                if (boss) {
+                    if (last) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }      // write back this XCD's L2 once: the hand-over of the table
+                    __hip_atomic_fetch_add(&a.sync->arrive, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (last) return;
+            } else {
+                arrive += G - 1;
+                if (tid == 0) {
+                    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                    int ok = 1;
+                    while (ld_sc1(&a.sync->arrive) < arrive) {
+                        if (__builtin_amdgcn_s_memrealtime() - t0 > VP_PH_TIMEOUT_TICKS) { ok = 0; break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    s_cmd = ok;
+                }
+                __syncthreads();
+                if (!s_cmd) {
+                    if (boss) { *a.add_term = at; tail_leave(a, expect, 0, 4); }
+                    return;
+                }
+                // the totals of the other workgroups join this thread's own sums: ONE two-stage reduction for everything
+                const u32 nw = blockDim.x >> 6;
+                for (u32 q = 1 + tid; q < G; q += blockDim.x) {
+                    const unsigned long long *pp = a.sync->part[q];
+                    acc[0] = f_add(acc[0], f_make(ld_sc1(pp), ld_sc1(pp + 1)));
+                    acc[1] = f_add(acc[1], f_make(ld_sc1(pp + 2), ld_sc1(pp + 3)));
+                    acc[2] = f_add(acc[2], f_make(ld_sc1(pp + 4), ld_sc1(pp + 5)));
+                }
+                tail_wave_partials(acc, red);
+                __syncthreads();
+                F tot[3];
+                if (w == 0) tail_wave0_total(red, (int) nw, tot);
+                if (boss) {
+                    if (k >= 2 && !f_is_zero(at)) at = f_mul(at, f_sub(f_one(), r));
+                    tail_reply(a, expect, tot[0], f_sub(tot[1], at), f_add(tot[2], at));
+                }
+                __syncthreads();
+            }
+        }
+        // hand-over: workgroup 0 continues alone with round kc; the table of round kc-1 was written by all workgroups
+        if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        k = a.kc - 1;
+    }
+
+    // ======================= solo regime (workgroup 0) =====================================================================
+    const u32 cap = a.cap;
+    F *LV = L, *LM = L + cap, *LA = L + 2 * (size_t) cap;
+    const int role = __builtin_amdgcn_readfirstlane(w % 3);
+    const u32 pslot = (u32) ((w / 3) * 64 + lane);
+    // ---- first solo round: sources in global memory, folded tables into LDS (plain one-thread-per-pair form) ----
+    {
+        const bool multi = a.G > 1;
+        F r;
+        int n_tab, fold;
+        u32 total_pairs;
+        const F *inV, *inM, *inA;
+        if (multi) {
+            // round kc of the single table: wait for its challenge like any later round
+            ++expect;
+            if (tid == 0) { F rr = f_zero(); s_cmd = tail_poll(a, expect, rr); s_r = rr; }
+            __syncthreads();
+            if (s_cmd != 1) {
+                if (boss) { *a.add_term = at; tail_leave(a, expect, s_cmd, s_cmd == 3 ? 1 : s_cmd == -1 ? 2 : 3); }
+                return;
+            }
+            r = s_r;
+            const int kk = a.kc;                                   // >= 2
+            if (tid == 0) {
+                TabDesc td; td.off = a.off; td.pair_start = 0;
+                td.len_in = a.len0 >> (kk - 2);
+                td.valid_in = (u32) (((u64) a.valid0 + (1ull << (kk - 2)) - 1) >> (kk - 2));
+                s_t[0] = td;
+                s_len[0] = td.len_in >> 1;
+            }
+            __syncthreads();
+            n_tab = 1; fold = 1; total_pairs = s_t[0].len_in >> 2;
+            inV = a.hand[0] - a.off; inM = a.hand[1] - a.off; inA = a.hand[2] - a.off;        // kc >= 3: written by the last distributed round
+            k = kk;
+        } else {
+            r = a.rv; n_tab = a.n_tab; fold = a.fold; total_pairs = a.total_pairs;
+            inV = a.inV; inM = a.inM; inA = a.inA;
+        }
+        // hand-over reads go past the L1 (agent-scope loads): the entries were written by other workgroups, possibly on other XCDs
+        auto ldz = [&](const F *p, u32 i, u32 valid) -> F {
+            if (i >= valid) return f_zero();
+            if (!multi) return p[i];
+            const unsigned long long *w = reinterpret_cast<const unsigned long long *>(p + i);
+            return f_make(ld_sc1(w), ld_sc1(w + 1));
+        };
+        F acc[3] = {f_zero(), f_zero(), f_zero()};
+        for (u32 q = tid; q < total_pairs; q += blockDim.x) {
+            int j = 0;
+            while (j + 1 < n_tab && q >= s_t[j + 1].pair_start) ++j;
+            const TabDesc td = s_t[j];
+            const u32 p = q - td.pair_start;
+            if (td.len_in == 0) continue;
+            F v0, v1, m0, m1, a0 = f_zero(), a1 = f_zero();
+            const u32 vi = td.off + td.valid_in;
+            if (fold) {
+                const u32 i0 = td.off + 4 * p;
+                v0 = f_lerp(ldz(inV, i0, vi), ldz(inV, i0 + 1, vi), r); v1 = f_lerp(ldz(inV, i0 + 2, vi), ldz(inV, i0 + 3, vi), r);
+                m0 = f_lerp(ldz(inM, i0, vi), ldz(inM, i0 + 1, vi), r); m1 = f_lerp(ldz(inM, i0 + 2, vi), ldz(inM, i0 + 3, vi), r);
+                if (a.has_a) { a0 = f_lerp(ldz(inA, i0, vi), ldz(inA, i0 + 1, vi), r); a1 = f_lerp(ldz(inA, i0 + 2, vi), ldz(inA, i0 + 3, vi), r); }
+            } else {
+                const u32 i0 = td.off + 2 * p;
+                v0 = ldz(inV, i0, vi); v1 = ldz(inV, i0 + 1, vi);
+                m0 = ldz(inM, i0, vi); m1 = ldz(inM, i0 + 1, vi);
+                if (a.has_a) { a0 = ldz(inA, i0, vi); a1 = ldz(inA, i0 + 1, vi); }
+            }
+            const u32 o = s_loff[j] + 2 * p;
+            LV[o] = v0; LV[o + 1] = v1; LM[o] = m0; LM[o + 1] = m1; LA[o] = a0; LA[o + 1] = a1;
+            const F dm = f_sub(m1, m0), dv = f_sub(v1, v0);
+            const F qa = f_mul(dm, dv), qc = f_mul(m0, v0), qe = f_mul(m1, v1);
+            acc[0] = f_add(acc[0], qa);
+            acc[1] = f_add(acc[1], f_add(f_sub(f_sub(qe, qa), qc), f_sub(a1, a0)));
+            acc[2] = f_add(acc[2], f_add(qc, a0));
+        }
+        tail_wave_partials(acc, red);
+        __syncthreads();
+        F tot[3];
+        if (w == 0) tail_wave0_total(red, (int) (blockDim.x >> 6), tot);
+        if (boss) {
+            if (fold && !f_is_zero(at)) at = f_mul(at, f_sub(f_one(), r));
+            if (!multi)
+                for (int j = 0; j < n_tab; ++j) {                   // tables that reach length one in this round (k_round_final's loop)
+                    const TabDesc td = s_t[j];
+                    const u32 len_out = fold ? (td.len_in >> 1) : td.len_in;
+                    if (len_out != 1) continue;
+                    F v, m, ad = f_zero();
+                    if (fold) {
+                        const u32 vi = td.off + td.valid_in;
+                        v = f_lerp(ld_or_zero(inV, td.off, vi), ld_or_zero(inV, td.off + 1, vi), r);
+                        m = f_lerp(ld_or_zero(inM, td.off, vi), ld_or_zero(inM, td.off + 1, vi), r);
+                        if (a.has_a) ad = f_lerp(ld_or_zero(inA, td.off, vi), ld_or_zero(inA, td.off + 1, vi), r);
+                    } else { v = inV[td.off]; m = inM[td.off]; if (a.has_a) ad = inA[td.off]; }
+                    a.scalarV[j] = v;
+                    at = f_add(at, f_add(f_mul(v, m), ad));
+                }
+            tail_reply(a, expect, tot[0], f_sub(tot[1], at), f_add(tot[2], at));
+        }
+    }
+    // ---- mailbox loop: the remaining rounds, then finalize --------------------------------------------------------------
+    int my_alive = 1;
+    for (;;) {
+        ++expect;
+        __syncthreads();                                           // the LDS tables of the previous round are complete
+        // waves whose pair slots can never be reached again leave (a terminated wave no longer counts at the barriers)
+        {
+            u32 pairs_next = 0;
+            for (int j = 0; j < a.n_tab; ++j) pairs_next += s_len[j] >> 2;
+            const u32 groups = max(1u, (min(pairs_next, (u32) VP_PH_SLOTS) + 63) >> 6);
+            if ((u32) (w / 3) >= groups && w >= 3) return;
+        }
+        if (tid == 0) { F rr = f_zero(); s_cmd = tail_poll(a, expect, rr); s_r = rr; }
+        TSTAMP(0);
+        __syncthreads();
+        const int cmd = s_cmd;
+        const F r = s_r;
+        if (cmd == 1 && k < a.R) {
+            ++k;
+            TSTAMP(1);
+            // pass 1: role f folds table family f for its pair slots (up to VP_PH_MAXIT pairs per lane), results in registers
+            F f0[VP_PH_MAXIT], f1[VP_PH_MAXIT]; u32 fo[VP_PH_MAXIT]; int nf = 0;
+            const F *Lf = role == 0 ? LV : role == 1 ? LM : LA;
+            u32 total = 0;
+            for (int j = 0; j < a.n_tab; ++j) total += s_len[j] >> 2;
+#pragma unroll
+            for (int it = 0; it < VP_PH_MAXIT; ++it) {
+                const u32 q = (u32) it * VP_PH_SLOTS + pslot;
+                fo[it] = 0xffffffffu;
+                if (q < total && (role != 2 || a.has_a)) {
+                    u32 base = 0; int mj = 0; u32 mp = 0;
+                    for (int j = 0; j < a.n_tab; ++j) { const u32 np = s_len[j] >> 2; if (q >= base && q < base + np) { mj = j; mp = q - base; } base += np; }
+                    const u32 i0 = s_loff[mj] + 4 * mp;
+                    f0[it] = f_lerp(Lf[i0], Lf[i0 + 1], r); f1[it] = f_lerp(Lf[i0 + 2], Lf[i0 + 3], r);
+                    fo[it] = s_loff[mj] + 2 * mp;
+                } else if (q < total) { f0[it] = f_zero(); f1[it] = f_zero(); u32 base = 0; for (int j = 0; j < a.n_tab; ++j) { const u32 np = s_len[j] >> 2; if (q >= base && q < base + np) fo[it] = s_loff[j] + 2 * (q - base); base += np; } }
+            }
+            (void) nf;
+            // tables that fold to a single entry now retire into add_term: read before anything is overwritten
+            if (boss) {
+                if (!f_is_zero(at)) at = f_mul(at, f_sub(f_one(), r));
+                for (int j = 0; j < a.n_tab; ++j) {
+                    if (s_len[j] != 2) continue;
+                    const u32 o = s_loff[j];
+                    const F v = f_lerp(LV[o], LV[o + 1], r), m = f_lerp(LM[o], LM[o + 1], r);
+                    const F ad = a.has_a ? f_lerp(LA[o], LA[o + 1], r) : f_zero();
+                    a.scalarV[j] = v;
+                    at = f_add(at, f_add(f_mul(v, m), ad));
+                }
+            }
+            TSTAMP(2);
+            __syncthreads();                                       // every source entry is in registers
+            F *Lw = role == 0 ? LV : role == 1 ? LM : LA;
+#pragma unroll
+            for (int it = 0; it < VP_PH_MAXIT; ++it) if (fo[it] != 0xffffffffu) { Lw[fo[it]] = f0[it]; Lw[fo[it] + 1] = f1[it]; }
+            __syncthreads();                                       // the folded tables are in LDS
+            TSTAMP(3);
+            // pass 2: one product per role: 0: (m1-m0)(v1-v0)   1: m0 v0 (+ a0)   2: m1 v1 (+ a1 - a0)
+            F acc[3] = {f_zero(), f_zero(), f_zero()};
+#pragma unroll
+            for (int it = 0; it < VP_PH_MAXIT; ++it) {
+                const u32 o = fo[it];
+                if (o == 0xffffffffu) continue;
+                if (role == 0) { const F qa = f_mul(f_sub(LM[o + 1], LM[o]), f_sub(LV[o + 1], LV[o])); acc[0] = f_add(acc[0], qa); acc[1] = f_sub(acc[1], qa); }
+                else if (role == 1) { const F qc = f_mul(LM[o], LV[o]); acc[1] = f_sub(acc[1], qc); acc[2] = f_add(acc[2], f_add(qc, LA[o])); }
+                else { const F qe = f_mul(LM[o + 1], LV[o + 1]); acc[1] = f_add(acc[1], f_add(qe, f_sub(LA[o + 1], LA[o]))); }
+            }
+            TSTAMP(4);
+            tail_wave_partials(acc, red);
+            TSTAMP(5);
+            __syncthreads();
+            F tot[3];
+            // rows of waves that have left hold their last (stale) partials: only the waves still here count
+            int nw_alive;
+            { u32 pn = 0; for (int j = 0; j < a.n_tab; ++j) pn += s_len[j] >> 2; const u32 groups = max(1u, (min(pn, (u32) VP_PH_SLOTS) + 63) >> 6); nw_alive = (int) (3 * groups); }
+            if (w == 0) tail_wave0_total(red, nw_alive, tot);
+            TSTAMP(6);
+            __syncthreads();
+            if (tid < a.n_tab) s_len[tid] >>= 1;
+            if (boss) tail_reply(a, expect, tot[0], f_sub(tot[1], at), f_add(tot[2], at));
+            TSTAMP(7);
+            continue;
+        }
+        // finalize (cmd 2), quit (3), timeout (-1) or a protocol error: leave
+        if (cmd == 2 && tid < a.n_tab) {
+            F c;
+            if (s_bl[tid] == a.R) { const u32 o = s_loff[tid]; c = f_lerp(LV[o], LV[o + 1], r); }       // the table as long as the sumcheck: its last two entries
+            else c = a.scalarV[tid];
+            a.claims_dev[tid] = c;
+            a.claims_host[tid] = c;
+            if (a.Vu && tid == 0) *a.Vu = c;
+        }
+        __threadfence_system();
+        __syncthreads();
+        if (boss) { *a.add_term = at; tail_leave(a, expect, cmd, cmd == 2 ? 0 : cmd == 3 ? 1 : cmd == -1 ? 2 : 3); }
+        (void) my_alive;
+        return;
+    }
+}
+
+}  // namespace vp

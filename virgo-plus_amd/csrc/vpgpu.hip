@@ -121,6 +121,11 @@ struct vp_ctx {
     F *d_tr = nullptr; u64 n_tr = 0;      // transcript in F units
     F *h_pin = nullptr;                   // pinned: [0..2] poly, [3] vres, [4..4+64) claims
     unsigned long long *h_seq = nullptr, seq = 0;     // pinned ticket the closing kernels of the per-round path publish
+    // persistent round kernel of the interactive path (vp_kernels_persist.h): mailbox in pinned host memory
+    TailMail *h_req = nullptr; TailReply *h_rep = nullptr; bool tail_active = false; unsigned long long tail_seq = 0; int tail_enabled = 1;
+    TailAux *h_aux = nullptr;            // pinned: per-table data of the resident kernel's launch
+    F *d_hand = nullptr;                 // hand-over buffers of the distributed -> solo switch (3 x 4096 entries)
+    MultiSync *d_msync = nullptr; int multi_enabled = 0;      // VP_PERSIST=0: one launch per round; VP_PERSIST_MULTI=0: no distributed rounds
     int poll = 1;                                     // VP_POLL=0: wait with hipStreamSynchronize instead
     F *h_io = nullptr; size_t h_io_cap = 0;   // pinned staging of the batched path: tape in, transcript out
     int *d_flag = nullptr;
@@ -192,6 +197,10 @@ namespace {
         }                                                                                           \
     } while (0)
 #define VPCHK(x) do { int r_ = (x); if (r_ != VP_OK) return r_; } while (0)
+// every entry point except vp_round / vp_finalize: select the device and, if the persistent round kernel of the interactive path is
+// still resident (the caller abandoned a sumcheck), tell it to leave — work submitted to the stream would otherwise queue behind it
+int tail_quit(vp_ctx *ctx);
+#define VP_ENTER(ctx) do { HIPCHK(hipSetDevice((ctx)->device)); if ((ctx)->tail_active) (void) tail_quit(ctx); } while (0)
 
 constexpr u32 MAX_BLOCKS = 2048;     // 256 CUs x 8 resident 256-thread blocks
 
@@ -494,6 +503,113 @@ int check_stream(vp_ctx *ctx) {
     return VP_OK;
 }
 
+// ---- persistent round kernel (vp_kernels_persist.h): host side of the mailbox ---------------------------------------
+int tail_wait(vp_ctx *ctx, unsigned long long want) {       // every reply word must carry the tag of message `want` (vp_kernels_persist.h)
+    const auto t0 = std::chrono::steady_clock::now();
+    const unsigned long long tag = VP_TAG(want), mask = 7ull << 61;
+    for (u32 spin = 0;; ++spin) {
+        bool all = true;
+        for (int q = 0; q < 7; ++q) all &= (__atomic_load_n(&ctx->h_rep->w[q], __ATOMIC_RELAXED) & mask) == tag;
+        if (all) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return VP_OK; }
+        if ((spin & 0xfff) == 0xfff) {
+            if (__atomic_load_n(&ctx->h_rep->dead, __ATOMIC_ACQUIRE)) { ctx->tail_active = false; ctx->err = "persistent round kernel gave up waiting (no verifier message for 10 s, or a workgroup was not scheduled)"; return VP_EHIP; }
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(15)) { ctx->tail_active = false; ctx->err = "persistent round kernel did not answer"; return VP_EHIP; }
+        }
+    }
+}
+int tail_send(vp_ctx *ctx, int cmd, const F &r) {
+    TailMail *m = ctx->h_req;
+    const unsigned long long tag = VP_TAG(++ctx->tail_seq);
+    __atomic_store_n(&m->w[1], r.im | tag, __ATOMIC_RELAXED);
+    __atomic_store_n(&m->w[2], (unsigned long long) cmd | tag, __ATOMIC_RELAXED);
+    __atomic_store_n(&m->w[0], r.re | tag, __ATOMIC_RELEASE);
+    return tail_wait(ctx, ctx->tail_seq);
+}
+static inline unsigned long long tail_status(const vp_ctx *ctx) { return VP_UNTAG(ctx->h_rep->w[6]); }
+static inline void tail_poly(const vp_ctx *ctx, vp_F out[3]) {
+    for (int q = 0; q < 3; ++q) { out[q].real = VP_UNTAG(ctx->h_rep->w[2 * q]); out[q].img = VP_UNTAG(ctx->h_rep->w[2 * q + 1]); }
+}
+// leave the persistent kernel (a call other than vp_round / vp_finalize arrived while it was resident)
+int tail_quit(vp_ctx *ctx) {
+    if (!ctx->tail_active) return VP_OK;
+    const int rc = tail_send(ctx, 3, f_zero());
+    ctx->tail_active = false;
+    (void) hipStreamSynchronize(ctx->stream);
+    return rc;
+}
+// Round k = s.round + 1 with previous challenge rv: if every live table of the phase now fits one CU, launch k_phase for this
+// and all later messages of the phase.  Returns 1 when launched (the polynomial of round k is then in h_rep), 0 when not.
+int tail_try_launch(vp_ctx *ctx, const F &rv) {
+    SumcheckState &s = ctx->sc;
+    const int k = s.round + 1;
+    if (!ctx->tail_enabled || s.total_rounds - k < 1) return 0;
+    PTailArgs a{};
+    a.G = 1;
+    // single-table phase (phase 1, Liu) with a table too large for one CU: distributed rounds on G workgroups, solo from round kc
+    if (ctx->multi_enabled && k == 1 && s.n_tab == 1 && s.len0[0] >= 8192 && s.bl[0] == s.total_rounds) {
+        const u32 len0 = s.len0[0];
+        static const int gshift = getenv("VP_MULTI_SHIFT") ? atoi(getenv("VP_MULTI_SHIFT")) : 13;      // entries of table_1 per workgroup (log2)
+        const int G = (int) std::max<u32>(2, std::min<u32>(VP_MULTI_MAXG, len0 >> gshift));
+        u32 B1 = 2; while ((u64) B1 * G < s.valid0[0]) B1 <<= 1;
+        const int kc = s.bl[0] - 10;                               // first round whose source table has <= 4096 entries
+        if (!ctx->d_msync) { if (dalloc(ctx, &ctx->d_msync, (size_t) 1) != VP_OK) return 0; }
+        if (!ctx->d_hand) { if (dalloc(ctx, &ctx->d_hand, (size_t) 3 * 4096) != VP_OK) return 0; }
+        for (int t = 0; t < 3; ++t) a.hand[t] = ctx->d_hand + (size_t) t * 4096;
+        if (hipMemsetAsync(ctx->d_msync, 0, sizeof(MultiSync), ctx->stream) != hipSuccess) return 0;
+        a.G = G; a.kc = kc; a.off = s.off[0]; a.len0 = len0; a.valid0 = s.valid0[0]; a.B1 = B1;
+        a.V0 = s.V0; a.M0 = s.M0; a.A0 = s.A0;
+        for (int b = 0; b < 2; ++b) for (int t = 0; t < 3; ++t) a.buf[b][t] = ctx->tab[b][t];
+        a.sync = ctx->d_msync; a.arrive0 = 0;
+        a.k0 = 1; a.R = s.total_rounds; a.n_tab = 1; a.has_a = s.has_a; a.cap = 2 * VP_PH_PMAX;
+        a.aux = ctx->h_aux;
+        ctx->h_aux->bl[0] = s.bl[0]; ctx->h_aux->loff[0] = 0; ctx->h_aux->len_out0[0] = 0; ctx->h_aux->t[0] = TabDesc{};
+        a.rv = rv;
+        a.add_term = ctx->add_term(); a.scalarV = ctx->scalarV(); a.claims_dev = ctx->d_tr + ctx->n_tr + 3; a.poly_dev = ctx->d_tr + ctx->n_tr;
+        a.Vu = s.phase == 1 ? ctx->Vu() : nullptr;
+        a.req = ctx->h_req; a.rep = ctx->h_rep; a.claims_host = ctx->h_pin + 4;
+        a.seq0 = ++ctx->tail_seq; ctx->h_rep->dead = 0;
+        hipLaunchKernelGGL(k_phase, dim3(G), dim3(VP_PH_THREADS), (size_t) 3 * a.cap * sizeof(F), ctx->stream, a);
+        { const hipError_t e = hipGetLastError(); if (e != hipSuccess) { if (getenv("VP_DEBUG")) fprintf(stderr, "[vp] k_phase (G=%d) launch failed: %s\n", G, hipGetErrorString(e)); --ctx->tail_seq; return 0; } }
+        count_launch(ctx);
+        ctx->tail_active = true;
+        return 1;
+    }
+    TailAux &ax = *ctx->h_aux;
+    a.aux = ctx->h_aux;
+    a.rv = rv; a.fold = (k >= 2) ? 1 : 0;
+    if (k <= 2) { a.inV = s.V0; a.inM = s.M0; a.inA = s.A0; }
+    else { F **t = ctx->tab[k & 1]; a.inV = t[0]; a.inM = t[1]; a.inA = t[2]; }
+    u32 pairs = 0, ents = 0;
+    for (int j = 0; j < s.n_tab; ++j) {
+        TabDesc &t = ax.t[j];
+        t.off = s.off[j]; t.pair_start = pairs;
+        u32 len_out;
+        if (k == 1) { t.len_in = s.len0[j]; t.valid_in = s.valid0[j]; len_out = t.len_in; }
+        else {
+            const int sh = k - 2;
+            t.len_in = sh < 32 ? (s.len0[j] >> sh) : 0;
+            if (t.len_in < 2) { t.len_in = 0; t.valid_in = 0; len_out = 0; }
+            else { t.valid_in = (u32) (((u64) s.valid0[j] + (1ull << sh) - 1) >> sh); len_out = t.len_in >> 1; }
+        }
+        ax.len_out0[j] = len_out;
+        ax.loff[j] = ents;
+        ax.bl[j] = s.bl[j];
+        if (len_out >= 2) { pairs += len_out >> 1; ents += len_out; }
+    }
+    if (pairs == 0 || pairs > VP_PH_PMAX) return 0;
+    a.total_pairs = pairs;
+    a.k0 = k; a.R = s.total_rounds; a.n_tab = s.n_tab; a.has_a = s.has_a; a.cap = ents;
+    a.add_term = ctx->add_term(); a.scalarV = ctx->scalarV(); a.claims_dev = ctx->d_tr + ctx->n_tr + 3; a.poly_dev = ctx->d_tr + ctx->n_tr;
+    a.Vu = s.phase == 1 ? ctx->Vu() : nullptr;
+    a.req = ctx->h_req; a.rep = ctx->h_rep; a.claims_host = ctx->h_pin + 4;
+    a.seq0 = ++ctx->tail_seq; ctx->h_rep->dead = 0;
+    hipLaunchKernelGGL(k_phase, dim3(1), dim3(VP_PH_THREADS), (size_t) 3 * ents * sizeof(F), ctx->stream, a);
+    { const hipError_t e = hipGetLastError(); if (e != hipSuccess) { if (getenv("VP_DEBUG")) fprintf(stderr, "[vp] k_phase launch failed: %s\n", hipGetErrorString(e)); --ctx->tail_seq; return 0; } }
+    count_launch(ctx);
+    ctx->tail_active = true;
+    return 1;
+}
+
 void compute_layout(vp_ctx *ctx) {
     const int n = ctx->n_layers;
     ctx->ru_off.assign(n, 0); ctx->as_off.assign(n, 0); ctx->rv_off.assign(n, 0);
@@ -539,7 +655,16 @@ int vp_create(int device, vp_ctx **out) {
     }
     if (hipHostMalloc((void **) &ctx->h_seq, 64, hipHostMallocDefault) != hipSuccess) { delete ctx; return VP_EHIP; }
     *ctx->h_seq = 0;
+    if (hipHostMalloc((void **) &ctx->h_req, sizeof(TailMail), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void **) &ctx->h_rep, sizeof(TailReply), hipHostMallocDefault) != hipSuccess) { delete ctx; return VP_EHIP; }
+    if (hipHostMalloc((void **) &ctx->h_aux, sizeof(TailAux), hipHostMallocDefault) != hipSuccess) { delete ctx; return VP_EHIP; }
+    memset(ctx->h_req, 0, sizeof(TailMail)); memset(ctx->h_rep, 0, sizeof(TailReply)); memset(ctx->h_aux, 0, sizeof(TailAux));
+    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(k_phase), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 2 * VP_PH_PMAX * (int) sizeof(F));
     { const char *pl = getenv("VP_POLL"); ctx->poll = (pl && pl[0] == '0') ? 0 : 1; }
+    { const char *pl = getenv("VP_PERSIST"); ctx->tail_enabled = (pl && pl[0] == '0') ? 0 : 1; }
+    // distributed rounds (G workgroups of the resident kernel): measured equal to one launch per round on MI355X (x64 interactive proof
+    // 12.6 vs 12.7 ms: profiles/r02_interactive_*), and they need G idle CUs for as long as the verifier takes — opt-in
+    { const char *pl = getenv("VP_PERSIST_MULTI"); ctx->multi_enabled = (pl && pl[0] == '1') ? 1 : 0; }
     hipEventCreate(&ctx->ev0); hipEventCreate(&ctx->ev1);
     (void) hipFuncSetAttribute(reinterpret_cast<const void *>(k_emit_multi), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
     (void) hipFuncSetAttribute(reinterpret_cast<const void *>(k_emit), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
@@ -555,6 +680,7 @@ void vp_free_comm(vp_ctx *ctx);
 void vp_destroy(vp_ctx *ctx) {
     if (!ctx) return;
     (void) hipSetDevice(ctx->device);
+    if (ctx->tail_active) (void) tail_quit(ctx);
     (void) hipStreamSynchronize(ctx->stream);
     vp_free_shard_state(ctx);
     vp_free_comm(ctx);
@@ -566,6 +692,9 @@ void vp_destroy(vp_ctx *ctx) {
     if (ctx->ev1) (void) hipEventDestroy(ctx->ev1);
     if (ctx->h_pin) (void) hipHostFree(ctx->h_pin);
     if (ctx->h_seq) (void) hipHostFree(ctx->h_seq);
+    if (ctx->h_req) (void) hipHostFree(ctx->h_req);
+    if (ctx->h_rep) (void) hipHostFree(ctx->h_rep);
+    if (ctx->h_aux) (void) hipHostFree(ctx->h_aux);
     if (ctx->h_io) (void) hipHostFree(ctx->h_io);
     for (auto st : ctx->lane_streams) (void) hipStreamDestroy(st);
     for (auto ev : ctx->lane_events) (void) hipEventDestroy(ev);
@@ -577,7 +706,7 @@ void vp_destroy(vp_ctx *ctx) {
 int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
     if (!ctx || !ld || n_layers < 2) return VP_EINVAL;
     if (n_layers > VP_MAX_TAB) { ctx->err = "too many layers"; return VP_ELIMIT; }
-    HIPCHK(hipSetDevice(ctx->device));
+    VP_ENTER(ctx);
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (ctx->gkr_graph) { (void) hipGraphExecDestroy(ctx->gkr_graph); ctx->gkr_graph = nullptr; }
     ctx->graph_failed = false;
@@ -588,7 +717,7 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
     ctx->n_layers = n_layers;
     ctx->evaluated = false;
     ctx->chain_owner.clear(); ctx->chain_cost.clear();
-    ctx->chunk_cap = 0;
+    ctx->chunk_cap = 0; ctx->d_msync = nullptr; ctx->d_hand = nullptr;
     ctx->pred_r = ctx->pred_pool = ctx->pred_part = ctx->pred_out = nullptr; ctx->pred_jobs = nullptr; ctx->pred_dot = nullptr; ctx->pred_map = nullptr;
     ctx->pc_rt = ctx->pc_coef = ctx->pc_cw = nullptr; ctx->pc_tree = nullptr; ctx->pc_lm = -1;
     ctx->pc_pub = ctx->pc_qcw = ctx->pc_hcw = ctx->pc_tmp = ctx->pc_small = nullptr; ctx->pc_tree_h = nullptr; ctx->pc_private_done = false;
@@ -887,7 +1016,7 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
 
 int vp_evaluate(vp_ctx *ctx, const vp_F *inputs, uint64_t n_inputs) {
     if (!ctx || !inputs || ctx->n_layers < 2 || n_inputs != ctx->L[0].size) return VP_EINVAL;
-    HIPCHK(hipSetDevice(ctx->device));
+    VP_ENTER(ctx);
     LayerDev &L0 = ctx->L[0];
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     HIPCHK(hipMemsetAsync(L0.val, 0, (sizeof(F) << L0.bl), ctx->stream));
@@ -916,7 +1045,7 @@ int vp_evaluate(vp_ctx *ctx, const vp_F *inputs, uint64_t n_inputs) {
 
 int vp_layer_values(vp_ctx *ctx, int layer, vp_F *out, uint64_t n) {
     if (!ctx || !out || layer < 0 || layer >= ctx->n_layers || n > ctx->L[layer].size) return VP_EINVAL;
-    HIPCHK(hipSetDevice(ctx->device));
+    VP_ENTER(ctx);
     VPCHK(check_stream(ctx));
     HIPCHK(hipMemcpy(out, ctx->L[layer].val, n * sizeof(F), hipMemcpyDeviceToHost));
     return VP_OK;
@@ -935,7 +1064,7 @@ int vp_predicates(vp_ctx *ctx, int layer, const vp_F *r_g, const vp_F *assert_ra
     LayerDev &D = ctx->L[layer], &pre = ctx->L[layer - 1];
     if ((D.bl > 0 && !r_g) || (pre.bl > 0 && !r_u)) return VP_EINVAL;       // zero-variable layers have no challenges
     if (n_v < 0 || n_v > 31 || (n_v > 0 && !r_v) || n_out != D.p_buckets) { ctx->err = "vp_predicates: bad sizes"; return VP_EINVAL; }
-    HIPCHK(hipSetDevice(ctx->device));
+    VP_ENTER(ctx);
     // scratch: challenges, three pairs of half tables, piece sums, bucket sums (sized for the largest layer, once)
     if (!ctx->pred_r) {
         u32 max_chunks = 1, max_buckets = 1;
@@ -1014,7 +1143,7 @@ static int pred_inner_product(vp_ctx *ctx, const vp_F *r, int n, const F *table,
 
 int vp_layer_mle(vp_ctx *ctx, int layer, const vp_F *r, int n, vp_F *out) {
     if (!ctx || !ctx->evaluated || layer < 0 || layer >= ctx->n_layers || !out || n != ctx->L[layer].bl || (n && !r)) return VP_EINVAL;
-    HIPCHK(hipSetDevice(ctx->device));
+    VP_ENTER(ctx);
     return pred_inner_product(ctx, r, n, ctx->L[layer].val, (u32) ctx->L[layer].size, out);
 }
 
@@ -1030,7 +1159,7 @@ int vp_liu_gr(vp_ctx *ctx, int layer, const vp_F *r_u, const vp_F *const *r_v, c
 
 int vp_vres(vp_ctx *ctx, const vp_F *r_0, int r_0_size, vp_F *out) {
     if (!ctx || !ctx->evaluated || !out || r_0_size != ctx->L[ctx->n_layers - 1].bl || (r_0_size && !r_0)) return VP_EINVAL;
-    HIPCHK(hipSetDevice(ctx->device));
+    VP_ENTER(ctx);
     VPCHK(stage(ctx, 0, r_0, r_0_size));
     LayerDev &T = ctx->L[ctx->n_layers - 1];
     VPCHK(run_beta_half(ctx, ctx->d_tape, T.bl, ctx->one()));
@@ -1044,7 +1173,7 @@ int vp_vres(vp_ctx *ctx, const vp_F *r_0, int r_0_size, vp_F *out) {
 int vp_phase1_init(vp_ctx *ctx, int layer, const vp_F *r_liu, const vp_F *assert_random) {
     if (!ctx || !ctx->evaluated || layer < 1 || layer >= ctx->n_layers || !assert_random) return VP_EINVAL;
     if (ctx->L[layer].bl && !r_liu) return VP_EINVAL;
-    HIPCHK(hipSetDevice(ctx->device));
+    VP_ENTER(ctx);
     const u64 off = layer == ctx->n_layers - 1 ? 0 : ctx->rliu_off[layer + 1];
     VPCHK(stage(ctx, off, r_liu, ctx->L[layer].bl));
     VPCHK(stage(ctx, ctx->as_off[layer], assert_random, 1));
@@ -1056,7 +1185,7 @@ int vp_phase2_init(vp_ctx *ctx, int layer, const vp_F *r_u) {
     if (!ctx || !ctx->evaluated || layer < 1 || layer >= ctx->n_layers) return VP_EINVAL;
     if (ctx->L[layer - 1].bl && !r_u) return VP_EINVAL;
     if (ctx->sc.layer != layer || ctx->L[layer].max_dad_bl == -1) { ctx->err = "phase2 out of order"; return VP_EINVAL; }
-    HIPCHK(hipSetDevice(ctx->device));
+    VP_ENTER(ctx);
     VPCHK(stage(ctx, ctx->ru_off[layer], r_u, ctx->L[layer - 1].bl));
     VPCHK(do_phase2_init(ctx, layer, ctx->d_tape + ctx->ru_off[layer]));
     return check_stream(ctx);
@@ -1065,7 +1194,7 @@ int vp_phase2_init(vp_ctx *ctx, int layer, const vp_F *r_u) {
 int vp_liu_init(vp_ctx *ctx, int layer, const vp_F *r_u, const vp_F *const *r_v, const vp_F *s) {
     if (!ctx || !ctx->evaluated || layer < 1 || layer >= ctx->n_layers || !s) return VP_EINVAL;
     if (ctx->L[layer - 1].bl && !r_u) return VP_EINVAL;
-    HIPCHK(hipSetDevice(ctx->device));
+    VP_ENTER(ctx);
     const int n = ctx->n_layers;
     VPCHK(stage(ctx, ctx->ru_off[layer], r_u, ctx->L[layer - 1].bl));
     VPCHK(stage(ctx, ctx->sig_off[layer], s, n - layer + 1));
@@ -1083,6 +1212,24 @@ int vp_round(vp_ctx *ctx, const vp_F *previous_random, vp_F out_poly[3]) {
     if (ctx->sc.round >= ctx->sc.total_rounds) { ctx->err = "too many rounds"; return VP_EINVAL; }
     HIPCHK(hipSetDevice(ctx->device));
     F rv; memcpy(&rv, previous_random, sizeof(F));
+    // small rounds: one resident kernel answers every remaining message of the phase through a mailbox (vp_kernels_persist.h)
+    if (ctx->tail_active) {
+        VPCHK(tail_send(ctx, 1, rv));
+        if (tail_status(ctx) != 0) { ctx->tail_active = false; ctx->err = "persistent round kernel: protocol error"; return VP_EHIP; }
+        tail_poly(ctx, out_poly);
+        ++ctx->sc.round; ++ctx->st.rounds;
+#ifdef VP_TAIL_STAMPS
+        { const unsigned long long *t = ctx->h_rep->stamps; fprintf(stderr, "[stamps] poll->1 %llu | pass1 %llu | bar+write %llu | pass2 %llu | partials %llu | total %llu | reply %llu  (cycles)\n",
+                  t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[6] - t[5], t[7] - t[6]); }
+#endif
+        return VP_OK;
+    }
+    if (tail_try_launch(ctx, rv)) {
+        VPCHK(tail_wait(ctx, ctx->tail_seq));
+        tail_poly(ctx, out_poly);
+        ++ctx->sc.round; ++ctx->st.rounds;
+        return VP_OK;
+    }
     VPCHK(do_round(ctx, nullptr, rv, ctx->d_tr + ctx->n_tr, ctx->h_pin));
     VPCHK(wait_ticket(ctx));
     memcpy(out_poly, ctx->h_pin, 3 * sizeof(F));
@@ -1093,6 +1240,14 @@ int vp_finalize(vp_ctx *ctx, const vp_F *previous_random, vp_F *claims, int n_cl
     if (!ctx || !previous_random || !claims || ctx->sc.phase == 0 || n_claims != ctx->sc.n_tab) return VP_EINVAL;
     HIPCHK(hipSetDevice(ctx->device));
     F rv; memcpy(&rv, previous_random, sizeof(F));
+    if (ctx->tail_active) {                                   // the resident kernel holds the tables: it computes the claims and leaves
+        const int rc = tail_send(ctx, 2, rv);
+        ctx->tail_active = false;
+        VPCHK(rc);
+        if (tail_status(ctx) != 0) { ctx->err = "persistent round kernel: protocol error at finalize"; return VP_EHIP; }
+        memcpy(claims, ctx->h_pin + 4, (size_t) n_claims * sizeof(F));
+        return VP_OK;
+    }
     VPCHK(do_finalize(ctx, nullptr, rv, ctx->d_tr + ctx->n_tr + 3, ctx->h_pin + 4));
     VPCHK(wait_ticket(ctx));
     memcpy(claims, ctx->h_pin + 4, (size_t) n_claims * sizeof(F));
@@ -1114,7 +1269,7 @@ int vp_set_shard(vp_ctx *ctx, int rank, int world) {
     if (world > 1 && ctx->n_layers >= 2 && (!ctx->plan_path || ctx->simple_path || ctx->sumfold_path)) {
         ctx->err = "vp_set_shard: only the launch-plan path shards (unset VP_GKR_PATH)"; return VP_EINVAL;
     }
-    HIPCHK(hipSetDevice(ctx->device));
+    VP_ENTER(ctx);
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (ctx->gkr_graph) { (void) hipGraphExecDestroy(ctx->gkr_graph); ctx->gkr_graph = nullptr; }
     ctx->graph_failed = false;
@@ -1138,7 +1293,7 @@ int vp_prove_gkr(vp_ctx *ctx, const vp_F *tape, uint64_t n_tape, uint8_t *transc
     if (!ctx || !ctx->evaluated || !tape || !transcript || n_tape != ctx->n_tape) return VP_EINVAL;
     if (capacity < ctx->n_tr * sizeof(F)) return VP_EINVAL;
     if (!ctx->simple_path) return prove_gkr_fused(ctx, tape, n_tape, transcript, n_written);
-    HIPCHK(hipSetDevice(ctx->device));
+    VP_ENTER(ctx);
     const int n = ctx->n_layers;
     ctx->st.launches = 0; ctx->st.rounds = 0; ctx->ev_used = 0;
     HIPCHK(hipMemcpyAsync(ctx->d_tape, tape, n_tape * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
@@ -1223,7 +1378,7 @@ const char *vp_kernel_name(int kind) {
 int vp_test_field(vp_ctx *ctx, int op, const vp_F *a, const vp_F *b, vp_F *out, uint64_t n) {
     if (!ctx || !a || !b || !out || op < 0 || op > 2) return VP_EINVAL;
     if (n == 0) return VP_OK;
-    HIPCHK(hipSetDevice(ctx->device));
+    VP_ENTER(ctx);
     F *da = nullptr, *db = nullptr, *dout = nullptr;
     HIPCHK(hipMalloc((void **) &da, n * sizeof(F)));
     HIPCHK(hipMalloc((void **) &db, n * sizeof(F)));
@@ -1239,7 +1394,7 @@ int vp_test_field(vp_ctx *ctx, int op, const vp_F *a, const vp_F *b, vp_F *out, 
 
 int vp_test_beta(vp_ctx *ctx, const vp_F *r, int n, const vp_F *init, vp_F *out) {
     if (!ctx || !init || !out || n < 0 || n > 28 || (n && !r)) return VP_EINVAL;
-    HIPCHK(hipSetDevice(ctx->device));
+    VP_ENTER(ctx);
     F *dr = nullptr, *dbf = nullptr, *dbs = nullptr, *dout = nullptr;
     const size_t half = (size_t) 1 << ((n + 1) / 2);
     HIPCHK(hipMalloc((void **) &dr, (n + 2) * sizeof(F)));

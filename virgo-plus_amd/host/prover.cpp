@@ -1,5 +1,7 @@
 #include "prover.hpp"
 
+#include <cstdio>
+#include <cstdlib>
 #include <string>
 
 static_assert(sizeof(F) == sizeof(vp_F), "F must be two u64 limbs");
@@ -108,14 +110,18 @@ void prover::sumcheckInit() { --sumcheckLayerId; }                              
 
 void prover::sumcheckInitPhase1(const F &assert_random) {                        // src/prover.cpp:189-280
     prove_timer.start();
+    init_timer.start();
     check(vp_phase1_init(ctx, sumcheckLayerId, cF(r_liu.data()), cF(&assert_random)), "vp_phase1_init");
+    init_timer.stop();
     round = 0;
     prove_timer.stop();
 }
 
 void prover::sumcheckInitPhase2() {                                              // src/prover.cpp:282-367
     prove_timer.start();
+    init_timer.start();
     check(vp_phase2_init(ctx, sumcheckLayerId, cF(r_u.data())), "vp_phase2_init");
+    init_timer.stop();
     round = 0;
     prove_timer.stop();
 }
@@ -124,7 +130,9 @@ void prover::sumcheckInitLiu(std::vector<F>::const_iterator s) {                
     prove_timer.start();
     std::vector<const vp_F *> rv(C.size, nullptr);
     for (int k = sumcheckLayerId; k < C.size; ++k) if (!r_v[k].empty()) rv[k] = cF(r_v[k].data());
+    init_timer.start();
     check(vp_liu_init(ctx, sumcheckLayerId, cF(r_u.data()), rv.data(), cF(&*s)), "vp_liu_init");
+    init_timer.stop();
     round = 0;
     prove_timer.stop();
 }
@@ -134,7 +142,12 @@ quadratic_poly prover::sumcheckUpdate(const F &previous_random, std::vector<F> &
     if (round) r_arr.at(round - 1) = previous_random;
     ++round;
     F p[3];
+    static const bool dbg_rounds = getenv("VP_DEBUG_ROUNDS") != nullptr;      // development aid: per-message latency on stderr
+    const auto t_dbg = std::chrono::steady_clock::now();
+    round_timer.start();
     check(vp_round(ctx, cF(&previous_random), mF(p)), "vp_round");
+    round_timer.stop();
+    if (dbg_rounds) fprintf(stderr, "[round] layer %d round %d: %.2f us\n", sumcheckLayerId, round, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_dbg).count());
     prove_timer.stop();
     proof_size += sizeof(F) * 3;
     return quadratic_poly(p[0], p[1], p[2]);
@@ -146,7 +159,9 @@ quadratic_poly prover::sumcheckLiuUpdate(const F &r) { return sumcheckUpdate(r, 
 void prover::sumcheckFinalize1(const F &previousRandom, F &claim) {              // src/prover.cpp:494-501
     prove_timer.start();
     if (round) r_u[round - 1] = previousRandom;
+    fin_timer.start();
     check(vp_finalize(ctx, cF(&previousRandom), mF(&claim), 1), "vp_finalize");
+    fin_timer.stop();
     prove_timer.stop();
     proof_size += sizeof(F);
 }
@@ -155,7 +170,9 @@ void prover::sumcheckFinalize2(const F &previousRandom, std::vector<F>::iterator
     prove_timer.start();
     if (round) r_v[sumcheckLayerId][round - 1] = previousRandom;
     std::vector<F> tmp(sumcheckLayerId);
+    fin_timer.start();
     check(vp_finalize(ctx, cF(&previousRandom), mF(tmp.data()), sumcheckLayerId), "vp_finalize");
+    fin_timer.stop();
     for (int i = 0; i < sumcheckLayerId; ++i) claims[i] = tmp[i];
     proof_size += sizeof(F) * sumcheckLayerId;
     prove_timer.stop();
@@ -163,7 +180,9 @@ void prover::sumcheckFinalize2(const F &previousRandom, std::vector<F>::iterator
 
 void prover::sumcheckLiuFinalize(const F &previousRandom, F &claim) {            // src/prover.cpp:518-521
     if (round) r_liu[round - 1] = previousRandom;
+    fin_timer.start();
     check(vp_finalize(ctx, cF(&previousRandom), mF(&claim), 1), "vp_finalize");
+    fin_timer.stop();
 }
 
 prover::hhash_digest prover::commit_private() {      // src/prover.cpp:524-530 (mask = one zero element)

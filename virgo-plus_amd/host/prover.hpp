@@ -68,6 +68,11 @@ public:
     double commitDeviceMs();
 
     double proveTime() const { return prove_timer.elapse_sec(); }
+    // where Prove Time goes on the interactive path: phase inits | round messages | finalize calls | Vres (all inside prove_timer's spans,
+    // except sumcheckLiuFinalize, which the reference leaves out of its timer as well)
+    double initTime() const { return init_timer.elapse_sec(); }
+    double roundTime() const { return round_timer.elapse_sec(); }
+    double finalizeTime() const { return fin_timer.elapse_sec(); }
     double proofSize() const { return (double) proof_size / 1024.0; }
 
     // ---- extensions (not in the reference) ----
@@ -89,6 +94,6 @@ private:
     std::vector<std::vector<F>> r_v;
     int round = 0;
     int sumcheckLayerId = 0;
-    timer prove_timer;
+    timer prove_timer, init_timer, round_timer, fin_timer;
     u64 proof_size = 0;
 };

@@ -14,6 +14,7 @@ struct vph_session {
     std::unique_ptr<prover> p;
     std::vector<F> tape;
     std::vector<uint8_t> fri_roots; std::vector<F> fri_final, fri_r;      // FRI commit phase of the last complete-protocol run
+    double t_init = 0, t_round = 0, t_fin = 0;
     std::vector<F> last_point;                                           // r_liu after the last Liu sumcheck of the last complete-protocol run
 };
 
@@ -109,12 +110,17 @@ static void fill(vph_result *res, prover &p, double prove_sec, double verify_sec
     res->proof_kb = p.proofSize(); res->verified = ok ? 1 : 0;
 }
 
+// seconds the interactive entry points spent in phase inits / round messages / finalize calls during the last vph_prove_interactive
+void vph_interactive_breakdown(vph_session *s, double out[3]) { out[0] = s->t_init; out[1] = s->t_round; out[2] = s->t_fin; }
+
 int vph_prove_interactive(vph_session *s, uint8_t *transcript, uint64_t capacity, uint64_t *n_written, vph_result *res,
                           char *err, int errlen) {
     try {
         F::init();
         verifier v(s->p.get(), s->circ->c);
         const double t0 = s->p->proveTime();
+        const double i0 = s->p->initTime(), r0 = s->p->roundTime(), f0 = s->p->finalizeTime();
+        struct Keep { vph_session *s; double i0, r0, f0; ~Keep() { s->t_init = s->p->initTime() - i0; s->t_round = s->p->roundTime() - r0; s->t_fin = s->p->finalizeTime() - f0; } } keep{s, i0, r0, f0};
         const bool ok = v.verify();
         const auto &tr = v.transcript();
         if (tr.size() > capacity) { set_err(err, errlen, "transcript buffer too small"); return -1; }

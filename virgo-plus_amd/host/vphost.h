@@ -78,6 +78,8 @@ int vph_last_fri(vph_session *, uint8_t *roots, uint64_t roots_cap, uint64_t *fi
 /* r_liu after the last Liu sumcheck of the last vph_prove_full / vph_prove_and_verify_full (the protocol's public vector is its eq
  * table, src/verifier.cpp:368-369); returns the number of coordinates or -1. */
 int vph_last_point(vph_session *, uint64_t *pairs, int cap);
+/* seconds spent in phase inits | round messages | finalize calls by the last vph_prove_interactive */
+void vph_interactive_breakdown(vph_session *, double out[3]);
 /* my_hhash on the host (verifier side): SHA3-256 of n 64-byte messages.                                   */
 void vph_test_sha3(const uint8_t *in, uint8_t *out, uint64_t n);
 /* poly_commit_prover::commit_phase (vpd_verifier.cpp:44-74) with caller-supplied fold challenges: n_steps calls of
