@@ -766,7 +766,7 @@ def test_randomize_16_20_synthetic_config(vp, golden, gold_gkr):
 
 
 @pytest.mark.parametrize("seed,sizes", [(1, [40, 33, 50, 17]), (2, [200, 180, 150, 300, 64, 9]), (3, [1500, 2100, 900, 4100, 700]),
-                                        (4, [5, 3, 2, 1]), (5, [70000, 50000, 30000])])
+                                        (4, [5, 3, 2, 1]), (5, [70000, 50000, 30000]), (6, [300000, 280000, 150000, 270000])])
 def test_all_gate_types_and_assert_gates_vs_oracle(vp, ob, seed, sizes):
     """Addc / Mulc / Copy / AntiNaab / AntiSub and assert gates are in the reference's API (src/prover.cpp:49-87,
     229-272,319-360,209-212) but in none of its data sets: random circuits with all types, device vs oracle."""
@@ -902,6 +902,22 @@ def test_abandoned_sumcheck_releases_the_resident_kernel(vp, gold_gkr):
     s.draw_tape()
     assert s.prove_gkr()[0] == tr
     s.close(); c.close()
+
+
+def test_real_value_products_are_a_pure_specialisation(vp, golden, gold_gkr, pws_path, monkeypatch):
+    """Round 1 of every sumcheck multiplies by circuit values; when vp_evaluate finds them all real (SHA-256: always) the fold, the
+    phase-1 init and the V_u inner product take the half-price real x complex products.  Same transcript with the general
+    products forced (VP_REAL_V=0), and a circuit with complex constants (custom_circuits: Mulc/Addc constants have imaginary
+    parts, so its values are complex and the flag must come out 0) is covered by test_all_gate_types_and_assert_gates_vs_oracle."""
+    c = vp.Circuit.from_pws(pws_path, 16, seed=1)
+    for rv in ("1", "0"):
+        monkeypatch.setenv("VP_REAL_V", rv)
+        s = vp.Session(c)
+        s.draw_tape()
+        tr, _ = s.prove_gkr()
+        assert tr == gold_gkr("sha256_x16"), "VP_REAL_V=" + rv
+        s.close()
+    c.close()
 
 
 def test_violated_assert_gate_is_reported(vp):

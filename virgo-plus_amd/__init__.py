@@ -18,11 +18,14 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 HOST = os.path.join(PKG_DIR, "host")
-LIB_GPU = os.path.join(CSRC, "libvpgpu.so")
+# VP_LIBGPU: development override (A/B builds of the kernels under tools/_build/<variant>/libvpgpu.so are measured without touching the
+# product library; build() never writes to an overridden path)
+LIB_GPU = os.environ.get("VP_LIBGPU") or os.path.join(CSRC, "libvpgpu.so")
 LIB_HOST = os.path.join(HOST, "libvphost.so")
 CLI = os.path.join(HOST, "virgo_plus_run")
 
-GPU_SRC = [os.path.join(CSRC, f) for f in ("vpgpu.hip", "vpgpu_batched.inc", "vpgpu_pc.inc", "vp_kernels.h", "vp_kernels_round.h", "vp_kernels_batch.h", "vp_kernels_plan.h", "vp_kernels_pc.h", "vp_field.h")] + [
+GPU_SRC = [os.path.join(CSRC, f) for f in ("vpgpu.hip", "vpgpu_batched.inc", "vpgpu_pc.inc", "vpgpu_pc_shard.inc", "vp_kernels.h", "vp_kernels_round.h", "vp_kernels_persist.h", "vp_kernels_batch.h",
+                                              "vp_kernels_init3.h", "vp_kernels_plan.h", "vp_kernels_pc.h", "vp_field.h")] + [
     os.path.join(ROOT, "include", "vpgpu.h")]
 HOST_SRC = [os.path.join(HOST, f) for f in ("circuit.cpp", "prover.cpp", "verifier.cpp", "vphost.cpp")]
 HOST_HDR = [os.path.join(HOST, f) for f in ("circuit.hpp", "prover.hpp", "verifier.hpp", "vphost.h", "field.hpp",
@@ -50,7 +53,9 @@ def build(force=False, verbose=False):
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
 
-    if force or _stale(LIB_GPU, GPU_SRC):
+    if os.environ.get("VP_LIBGPU"):
+        pass                                            # development override: never rebuilt from here
+    elif force or _stale(LIB_GPU, GPU_SRC):
         hipcc = _hipcc()
         if hipcc is None:
             if os.path.exists(LIB_GPU):

@@ -117,6 +117,44 @@ VP_HD F f_mad31c(const F &a, const F &b, const F &c) {
     const Sp31 nbi = split31(2 * P61 - b.im);
     return f_make(dot2_31c<WEAK>(ar, br, ai, nbi, c.re), dot2_31c<WEAK>(ar, bi, ai, br, c.im));
 }
+// The same two forms for a REAL second factor (b = (y, 0)): each limb of a*b + c is ONE product, eight multiplier instructions per
+// F-multiply instead of sixteen.  Circuit values of a circuit with real inputs and constants are real (every gate of
+// src/prover.cpp:27-91 maps reals to reals), so the first round of every sumcheck takes this path when vp_evaluate found no
+// imaginary part (vp_ctx::d_vcplx); the results are the same field elements.
+template <bool WEAK = false>
+VP_HD u64 dot1_31(const Sp31 &x, const Sp31 &y, u64 addend) {                // x, y < 2^62
+    const u64 L = (u64) x.lo * y.lo;                                       // < 2^62
+    const u64 C = (u64) x.lo * y.hi + (u64) x.hi * y.lo;                   // < 2^63
+    const u64 H = (u64) x.hi * y.hi;                                       // < 2^62
+    const u64 h2 = ((H & ((1ull << 60) - 1)) << 1) + (H >> 60);
+    const u64 c2 = ((C & 0x3fffffffull) << 31) + (C >> 30);
+    u64 s = h2 + c2 + L + addend;                                          // < 2^61 + 2^61 + 2^62 + 2^61 + 8 < 2^64
+    s = (s & P61) + (s >> 61);
+    if (WEAK) return s;
+    return s >= P61 ? s - P61 : s;
+}
+template <bool WEAK>
+VP_HD u64 dot1_31c(const Sp31 &x, const Sp31 &y, u64 addend) {               // x canonical, y < 2^62
+    const u64 LH = (u64) x.lo * y.lo + (u64) (2 * x.hi) * y.hi;            // < 2^62 + 2^62
+    const u64 C = (u64) x.lo * y.hi + (u64) x.hi * y.lo;                   // < 2^63
+    const u64 c2 = ((C & 0x3fffffffull) << 31) + (C >> 30);
+    u64 s = (LH & P61) + (LH >> 61) + c2 + addend;
+    s = (s & P61) + (s >> 61);
+    if (WEAK) return s;
+    return s >= P61 ? s - P61 : s;
+}
+// a * (y, 0) + c: limbs of a in [0, 2p], y in [0, 2p], limbs of c in [0, p]
+template <bool WEAK = false>
+VP_HD F f_mad31_rb(const F &a, u64 y, const F &c) {
+    const Sp31 ar = split31(a.re), ai = split31(a.im), b = split31(y);
+    return f_make(dot1_31<WEAK>(ar, b, c.re), dot1_31<WEAK>(ai, b, c.im));
+}
+// the same with the limbs of a canonical
+template <bool WEAK>
+VP_HD F f_mad31c_rb(const F &a, u64 y, const F &c) {
+    const Sp31 ar = split31(a.re), ai = split31(a.im), b = split31(y);
+    return f_make(dot1_31c<WEAK>(ar, b, c.re), dot1_31c<WEAK>(ai, b, c.im));
+}
 // a + r*(b - a): one fold step of a bookkeeping table (src/prover.cpp:483 eval + interpolate)
 VP_HD F f_lerp(const F &a, const F &b, const F &r) { return f_add(a, f_mul(r, f_sub(b, a))); }
 

@@ -32,7 +32,11 @@ struct InitArgs2 {
     F *V, *M, *A;
     const uint8_t *s_layer; const u32 *s_idx;    // phase 2: slot -> (source layer, index) for the V gather
     u32 n_rows;
+    int vreal;                // 1: every circuit value is real (vp_evaluate), beta * V[v] takes the half-price product
 };
+__device__ __forceinline__ F mul_val(const InitArgs2 &a, const F &y, const F &t) {       // V[v] * t
+    return a.vreal ? f_mad31c_rb<false>(t, y.re, f_zero()) : f_mul(y, t);
+}
 
 template <int PHASE>
 __device__ __forceinline__ void contrib2(const InitArgs2 &a, u32 e, F &m, F &ad, const F &vu) {       // vu = V_u (phase 2), loaded once per row
@@ -43,7 +47,7 @@ __device__ __forceinline__ void contrib2(const InitArgs2 &a, u32 e, F &m, F &ad,
     if (PHASE == 1) {
         const int l = tl & 0xff;
         F ty_ = f_zero();
-        if (l != 0xff) ty_ = f_mul(a.vals[l][x], t);
+        if (l != 0xff) ty_ = mul_val(a, a.vals[l][x], t);
         switch (ty) {
             case T_ADD: ad = f_add(ad, ty_); m = f_add(m, t); break;
             case T_SUB: ad = f_sub(ad, ty_); m = f_add(m, t); break;
@@ -95,7 +99,7 @@ __device__ __forceinline__ void p1_apply(const InitArgs2 &a, const P1Entry &c, c
     F t = f_mul(v.bf, v.bs);
     if (c.tl & 0x8000) t = f_mul(t, *a.assert_r);
     F ty_ = f_zero();
-    if ((c.tl & 0xff) != 0xff) ty_ = f_mul(v.y, t);
+    if ((c.tl & 0xff) != 0xff) ty_ = mul_val(a, v.y, t);
     switch (ty) {
         case T_ADD: ad = f_add(ad, ty_); m = f_add(m, t); break;
         case T_SUB: ad = f_sub(ad, ty_); m = f_add(m, t); break;
@@ -185,7 +189,7 @@ struct SfArgs {
     u32 total_chunks;
     int n_tab, has_a;
     u32 nblk;                 // batched launches: blocks given to this job
-    int keep_y0;              // k_sumfold3b / 4b, bit 0: the first round of this launch sums m1 v1 + a1 (it is round 1 of its sumcheck, whose sum cannot be
+    int keep_y0;              // bit 2: the V entries of the first round of this launch are circuit values and vp_evaluate found them all REAL (sf_pair_step_rv).  k_sumfold3b / 4b, bit 0: the first round of this launch sums m1 v1 + a1 (it is round 1 of its sumcheck, whose sum cannot be
                               // derived from a previous claim); bit 1: the later rounds do too (VP_DROP_Y=0).  Otherwise the product is left out (sf_pair_step)
     SfTab t[VP_MAX_TAB];
 };
@@ -347,6 +351,31 @@ __device__ __forceinline__ void sf_pair_step(const F &v0, const F &v1, const F &
     if (HAS_A) ao = f_mad_c(r, f_sub_lazy(a1, a0), a0);
 }
 
+// The same pair step when v0 and v1 are REAL (round 1 of a sumcheck over a circuit with real values, f_mad31c_rb in vp_field.h):
+// the four products that have a V factor cost half the multiplier instructions.
+template <bool HAS_A>
+__device__ __forceinline__ void sf_pair_step_rv(u64 v0, u64 v1, const F &m0, const F &m1, const F &a0, const F &a1,
+                                                const F &r, Lz &X, Lz &Y, Lz &Z, F &vo, F &mo, F &ao, bool keep_y) {
+    const u64 dv = v1 + P61 - v0;
+    const F dm = f_sub_lazy(m1, m0);
+    lz_add(X, f_mad31_rb<true>(dm, dv, f_zero()));
+    if (keep_y) lz_add(Y, f_mad31c_rb<true>(m1, v1, HAS_A ? a1 : f_zero()));
+    lz_add(Z, f_mad31c_rb<true>(m0, v0, HAS_A ? a0 : f_zero()));
+    vo = f_mad31c_rb<false>(r, dv, f_make(v0, 0));
+    mo = f_mad_c(r, dm, m0);
+    if (HAS_A) ao = f_mad_c(r, f_sub_lazy(a1, a0), a0);
+}
+
+#ifndef VP_SF_ROTATE
+#define VP_SF_ROTATE 0         // 1: the waves that carry rounds k+1 / k+2 of a chunk rotate from chunk to chunk, and round k+2 runs on a wave that sat out
+                               // round k+1.  With fixed roles wave 0 of a workgroup does three pair steps per chunk, wave 1 two, waves 2-3 one; if wave w of
+                               // every workgroup sat on SIMD w, SIMD 0 would carry 3/1.75 of the mean load.  Measured, round 2, same call, alternating builds
+                               // (tools/ab_bench.sh): one 2^24-entry table alone 278 -> 261 us, but whole proofs x64 0.7188 -> 0.7233 ms and x1024
+                               // 6.79 -> 6.76 ms device: within the noise, the dispatcher already spreads the waves.  Off.
+#endif
+// (Requesting the six entries of the workgroup's NEXT chunk into registers before the arithmetic of the current one was built and measured
+// as well, round 2: +24 VGPRs, 298 us against 279 us at 2^24 entries in the same run — like the LDS staging below, it buys nothing: the
+// kernel waits for its multiplier, not for memory.)
 #ifndef VP_SF_LDSPF
 #define VP_SF_LDSPF 0          // 1: the streaming variant stages the NEXT chunk in LDS with global_load_lds_dwordx4 (no VGPRs) while it computes.
                                // Built and measured (tools/micro_sumfold.hip -DVP_SF_LDSPF=1): outputs identical, 318 us against 280 us at 2^24
@@ -470,16 +499,22 @@ __device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb,
     if (t < 64) { for (int i = 0; i < 3; ++i) { sm.acc3[i][t].re = 0; sm.acc3[i][t].im = 0; } }
     const F r0 = a.r[0], r1 = a.r[1], r2 = a.r[2];
     const bool keep_y0 = (a.keep_y0 & 1) != 0, keep_rest = (a.keep_y0 & 2) != 0;              // uniform
+    const bool vreal = (a.keep_y0 & 4) != 0;             // the V entries of this launch's first round are real circuit values (uniform)
     F dacc = f_zero();                                   // GenP1: this thread's share of the V_u inner product
 #if VP_SF_LDSPF
     bool staged = false;                                 // the chunk of this iteration sits in sm.pre (uniform)
 #endif
+    int rot = 0;                                         // see VP_SF_ROTATE
     for (u32 c = bid; c < a.total_chunks; c += nb) {
         int j = 0;
         while (j + 1 < a.n_tab && c >= a.t[j + 1].chunk_start) ++j;
         const SfTab td = a.t[j];
         const u32 cl = c - td.chunk_start;
-        const u32 i0 = td.off + cl * 512 + 2 * t, vend = td.off + td.valid;
+        // logical wave / thread of this chunk: the waves that stay busy in rounds k+1 and k+2 change from chunk to chunk
+        const int wl = (VP_SF_ROTATE && Gen::MODE < 3 && !VP_SF_LDSPF) ? ((w + rot) & 3) : w;
+        const int tl = (wl << 6) | lane;
+        rot = (rot + 1) & 3;
+        const u32 i0 = td.off + cl * 512 + 2 * tl, vend = td.off + td.valid;
         {   // round k: one pair per thread
             F v0, v1, m0, m1, a0 = f_zero(), a1 = f_zero();
 #if VP_SF_LDSPF
@@ -537,8 +572,13 @@ __device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb,
                 gen.chunk(cl, i0, vend, m0, a0, m1, a1);
                 if constexpr (Gen::MODE == 3) {
                     if (gen.dot_part) {
-                        if (i0 < vend) dacc = f_add(dacc, f_mul(half_at(gen.dot_h, i0), v0));
-                        if (i0 + 1 < vend) dacc = f_add(dacc, f_mul(half_at(gen.dot_h, i0 + 1), v1));
+                        if (vreal) {
+                            if (i0 < vend) dacc = f_mad31c_rb<false>(half_at(gen.dot_h, i0), v0.re, dacc);
+                            if (i0 + 1 < vend) dacc = f_mad31c_rb<false>(half_at(gen.dot_h, i0 + 1), v1.re, dacc);
+                        } else {
+                            if (i0 < vend) dacc = f_add(dacc, f_mul(half_at(gen.dot_h, i0), v0));
+                            if (i0 + 1 < vend) dacc = f_add(dacc, f_mul(half_at(gen.dot_h, i0 + 1), v1));
+                        }
                     }
                 }
             } else {                      // generated tables: one table per job, offset 0
@@ -552,42 +592,48 @@ __device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb,
 #endif
                 if constexpr (Gen::MODE == 1) {
                     if (gen.dot_part) {
-                        if (i0 < vend) dacc = f_add(dacc, f_mul(half_at(gen.dot_h, i0), v0));
-                        if (i0 + 1 < vend) dacc = f_add(dacc, f_mul(half_at(gen.dot_h, i0 + 1), v1));
+                        if (vreal) {
+                            if (i0 < vend) dacc = f_mad31c_rb<false>(half_at(gen.dot_h, i0), v0.re, dacc);
+                            if (i0 + 1 < vend) dacc = f_mad31c_rb<false>(half_at(gen.dot_h, i0 + 1), v1.re, dacc);
+                        } else {
+                            if (i0 < vend) dacc = f_add(dacc, f_mul(half_at(gen.dot_h, i0), v0));
+                            if (i0 + 1 < vend) dacc = f_add(dacc, f_mul(half_at(gen.dot_h, i0 + 1), v1));
+                        }
                     }
                 }
             }
             F vo, mo, ao = f_zero();
-            sf_pair_step<HAS_A>(v0, v1, m0, m1, a0, a1, r0, acc[0], acc[1], acc[2], vo, mo, ao, keep_y0);
-            s1[0][t] = vo; s1[1][t] = mo;
-            if (HAS_A) s1[2][t] = ao;
+            if (vreal) sf_pair_step_rv<HAS_A>(v0.re, v1.re, m0, m1, a0, a1, r0, acc[0], acc[1], acc[2], vo, mo, ao, keep_y0);
+            else sf_pair_step<HAS_A>(v0, v1, m0, m1, a0, a1, r0, acc[0], acc[1], acc[2], vo, mo, ao, keep_y0);
+            s1[0][tl] = vo; s1[1][tl] = mo;
+            if (HAS_A) s1[2][tl] = ao;
         }
         __syncthreads();
-        if (w < 2) {   // round k+1: 128 pairs
+        if (wl < 2) {   // round k+1: 128 pairs
             F vo, mo, ao = f_zero();
-            Lz x = sm.acc2[0][t], y{0, 0}, z = sm.acc2[2][t];
-            if (keep_rest) y = sm.acc2[1][t];
-            sf_pair_step<HAS_A>(s1[0][2 * t], s1[0][2 * t + 1], s1[1][2 * t], s1[1][2 * t + 1],
-                                HAS_A ? s1[2][2 * t] : f_zero(), HAS_A ? s1[2][2 * t + 1] : f_zero(), r1,
+            Lz x = sm.acc2[0][tl], y{0, 0}, z = sm.acc2[2][tl];
+            if (keep_rest) y = sm.acc2[1][tl];
+            sf_pair_step<HAS_A>(s1[0][2 * tl], s1[0][2 * tl + 1], s1[1][2 * tl], s1[1][2 * tl + 1],
+                                HAS_A ? s1[2][2 * tl] : f_zero(), HAS_A ? s1[2][2 * tl + 1] : f_zero(), r1,
                                 x, y, z, vo, mo, ao, keep_rest);
             lz_fold(x); lz_fold(z);
-            sm.acc2[0][t] = x; sm.acc2[2][t] = z;
-            if (keep_rest) { lz_fold(y); sm.acc2[1][t] = y; }
-            s2[0][t] = vo; s2[1][t] = mo;
-            if (HAS_A) s2[2][t] = ao;
+            sm.acc2[0][tl] = x; sm.acc2[2][tl] = z;
+            if (keep_rest) { lz_fold(y); sm.acc2[1][tl] = y; }
+            s2[0][tl] = vo; s2[1][tl] = mo;
+            if (HAS_A) s2[2][tl] = ao;
         }
         __syncthreads();
-        if (w == 0) {  // round k+2: 64 pairs, results are the folded table
+        if (wl == (VP_SF_ROTATE ? 2 : 0)) {  // round k+2: 64 pairs, results are the folded table (on a wave that sat out round k+1)
             F vo, mo, ao = f_zero();
-            Lz x = sm.acc3[0][t], y{0, 0}, z = sm.acc3[2][t];
-            if (keep_rest) y = sm.acc3[1][t];
-            sf_pair_step<HAS_A>(s2[0][2 * t], s2[0][2 * t + 1], s2[1][2 * t], s2[1][2 * t + 1],
-                                HAS_A ? s2[2][2 * t] : f_zero(), HAS_A ? s2[2][2 * t + 1] : f_zero(), r2,
+            Lz x = sm.acc3[0][lane], y{0, 0}, z = sm.acc3[2][lane];
+            if (keep_rest) y = sm.acc3[1][lane];
+            sf_pair_step<HAS_A>(s2[0][2 * lane], s2[0][2 * lane + 1], s2[1][2 * lane], s2[1][2 * lane + 1],
+                                HAS_A ? s2[2][2 * lane] : f_zero(), HAS_A ? s2[2][2 * lane + 1] : f_zero(), r2,
                                 x, y, z, vo, mo, ao, keep_rest);
             lz_fold(x); lz_fold(z);
-            sm.acc3[0][t] = x; sm.acc3[2][t] = z;
-            if (keep_rest) { lz_fold(y); sm.acc3[1][t] = y; }
-            const u32 oi = cl * 64 + t;
+            sm.acc3[0][lane] = x; sm.acc3[2][lane] = z;
+            if (keep_rest) { lz_fold(y); sm.acc3[1][lane] = y; }
+            const u32 oi = cl * 64 + lane;
             if (oi < ((td.valid + 7) >> 3)) {
                 a.outV[td.off + oi] = vo;
                 a.outM[td.off + oi] = mo;
@@ -597,7 +643,8 @@ __device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb,
 #pragma unroll
         for (int i = 0; i < 3; ++i) lz_fold(acc[i]);
     }
-    // block partials: rounds k+1 and k+2 only have contributions in waves 0-1 and 0
+    // block partials: the sums of rounds k+1 and k+2 sit in the LDS slots of threads 0-127 and 0-63 (written by whichever wave had the role)
+    if (VP_SF_ROTATE) __syncthreads();
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
         if (i >= 3 && w >= 2) break;

@@ -496,13 +496,14 @@ __global__ void __launch_bounds__(VP_BLOCK) k_pred_combine(const u32 *__restrict
 
 // V_u = V(r_u) = sum_u eq(r_u, u) * V[u] (what phase 1's last fold leaves in the V table, src/prover.cpp:494-500) as an inner
 // product: with it phase 2 of a layer no longer waits for phase 1's sumcheck, every sumcheck of the proof is independent.
-struct DotJob { Half h; const F *val; F *part; F *out; u32 size, nblk; };
+struct DotJob { Half h; const F *val; F *part; F *out; u32 size, nblk; int vreal, pad; };     // vreal: val[] are real circuit values
 __global__ void __launch_bounds__(VP_BLOCK) k_dot_multi(const DotJob *__restrict__ jobs, const BlkMap *__restrict__ map) {
     __shared__ F lds[4];
     const BlkMap m = map[blockIdx.x];
     const DotJob &j = jobs[m.job];
     F acc[1] = {f_zero()};
-    for (u32 i = m.bid * blockDim.x + threadIdx.x; i < j.size; i += j.nblk * blockDim.x) acc[0] = f_add(acc[0], f_mul(half_at(j.h, i), j.val[i]));
+    if (j.vreal) for (u32 i = m.bid * blockDim.x + threadIdx.x; i < j.size; i += j.nblk * blockDim.x) acc[0] = f_mad31c_rb<false>(half_at(j.h, i), j.val[i].re, acc[0]);
+    else for (u32 i = m.bid * blockDim.x + threadIdx.x; i < j.size; i += j.nblk * blockDim.x) acc[0] = f_add(acc[0], f_mul(half_at(j.h, i), j.val[i]));
     block_sum<1>(acc, lds);
     if (threadIdx.x == 0) j.part[m.bid] = acc[0];
 }

@@ -79,7 +79,7 @@ __device__ __forceinline__ void block_sum(F (&x)[N], F *lds /* >= N*4 */) {
 __global__ void __launch_bounds__(VP_BLOCK)
 k_evaluate_layer(int layer, u32 size, const uint8_t *__restrict__ ty, const int16_t *__restrict__ gl,
                  const u32 *__restrict__ gu, const u32 *__restrict__ gv, const F *__restrict__ gc,
-                 F *const *__restrict__ vals) {
+                 F *const *__restrict__ vals, u32 *__restrict__ vcplx) {
     u32 g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= size) return;
     const F *pre = vals[layer - 1];
@@ -104,6 +104,12 @@ k_evaluate_layer(int layer, u32 size, const uint8_t *__restrict__ ty, const int1
         default: out = f_zero(); break;
     }
     vals[layer][g] = out;
+    if (out.im) atomicOr(vcplx, 1u);                       // never taken for a circuit with real inputs and constants (vp_field.h, f_mad31c_rb)
+}
+// the same mark for the input layer
+__global__ void __launch_bounds__(VP_BLOCK) k_mark_complex(const F *__restrict__ v, u32 n, u32 *__restrict__ vcplx) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && v[i].im) atomicOr(vcplx, 1u);
 }
 
 __global__ void k_check_asserts(const u32 *__restrict__ idx, u32 n, const F *__restrict__ val, int *flag) {

@@ -129,6 +129,8 @@ struct vp_ctx {
     int poll = 1;                                     // VP_POLL=0: wait with hipStreamSynchronize instead
     F *h_io = nullptr; size_t h_io_cap = 0;   // pinned staging of the batched path: tape in, transcript out
     int *d_flag = nullptr;
+    u32 *d_vcplx = nullptr;            // non-zero: some circuit value of the last vp_evaluate has an imaginary part
+    int vreal = 0, plan_vreal = 0;     // 1: every circuit value is real — round 1 of every sumcheck and the phase-1 inits take the half-price products (vp_field.h, f_mad31c_rb)
     bool evaluated = false;
     SumcheckState sc;
     // tape / transcript layout
@@ -847,6 +849,7 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
     VPCHK(dalloc(ctx, &ctx->chunk_part, (size_t) 2 * std::max<u32>(1, ctx->chunk_cap)));
     VPCHK(dalloc(ctx, &ctx->small, (size_t) 32 + VP_MAX_TAB));
     VPCHK(dalloc(ctx, &ctx->d_flag, (size_t) 1));
+    VPCHK(dalloc(ctx, &ctx->d_vcplx, (size_t) 1));
     {
         std::vector<F> sm(32 + VP_MAX_TAB, f_zero());
         sm[1] = f_one();
@@ -1022,18 +1025,22 @@ int vp_evaluate(vp_ctx *ctx, const vp_F *inputs, uint64_t n_inputs) {
     HIPCHK(hipMemsetAsync(L0.val, 0, (sizeof(F) << L0.bl), ctx->stream));
     HIPCHK(hipMemcpyAsync(L0.val, inputs, n_inputs * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_flag, 0, sizeof(int), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_vcplx, 0, sizeof(u32), ctx->stream));
+    hipLaunchKernelGGL(k_mark_complex, dim3(nblk(L0.size)), dim3(VP_BLOCK), 0, ctx->stream, L0.val, (u32) L0.size, ctx->d_vcplx);
     for (int i = 1; i < ctx->n_layers; ++i) {
         LayerDev &D = ctx->L[i];
         hipLaunchKernelGGL(k_evaluate_layer, dim3(nblk(D.size)), dim3(VP_BLOCK), 0, ctx->stream, i, (u32) D.size, D.ty,
-                           D.gl, D.gu, D.gv, D.gc, ctx->d_vals);
+                           D.gl, D.gu, D.gv, D.gc, ctx->d_vals, ctx->d_vcplx);
         if (D.n_assert)
             hipLaunchKernelGGL(k_check_asserts, dim3(nblk(D.n_assert)), dim3(VP_BLOCK), 0, ctx->stream, D.assert_idx,
                                D.n_assert, D.val, ctx->d_flag);
     }
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
-    int flag = 0;
+    int flag = 0; u32 vcplx = 1;
     HIPCHK(hipMemcpyAsync(&flag, ctx->d_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(&vcplx, ctx->d_vcplx, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
     VPCHK(check_stream(ctx));
+    { const char *rv = getenv("VP_REAL_V"); ctx->vreal = (vcplx == 0 && !(rv && rv[0] == '0')) ? 1 : 0; }
     float ms = 0;
     hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
     ctx->st.evaluate_ms = ms;
