@@ -22,8 +22,8 @@ k_root_table_step(F *RT, u32 have /* entries already filled, power of two */, F 
     if (i < have) RT[have + i] = f_mul(RT[i], step);
 }
 
-// Batched in-LDS radix-2 NTT of size N = 2^ln <= 8192, one workgroup per transform (blockIdx.x = row,
-// blockIdx.y = coset).  DIT: bit-reversed load, ln butterfly stages with one barrier each, natural-order store.
+// Batched in-LDS NTT of size N = 2^ln <= 8192, one workgroup per transform (blockIdx.x = row,
+// blockIdx.y = coset).  DIT: bit-reversed load, radix-4 passes in registers (below), natural-order store.
 //   forward LDE mode (inverse = 0): input row `coef + row*N`, element j is first multiplied by w_M^(j*coset)
 //       (the coset twist), and the N outputs are the evaluations at w_M^(32*a + coset): out[(row*ncoset + coset)*N + a].
 //       A rate-1/32 Reed-Solomon encoding (fast_fourier_transform(coefs, N, 32N), RS_polynomial.cpp:26) is therefore
@@ -37,6 +37,16 @@ struct NttArgs {
     u32 in_stride;                        // elements between consecutive input rows
     F inv_n;                              // inverse mode: N^-1
 };
+// Multiplication by the primitive fourth root of unity iota = w_M^(M/4) = (0, +-1) of F_p[i]: a swap and a negation.
+// plus: iota == (0, 1).  NEG: multiply by -iota = iota^-1 instead (inverse transforms).
+__device__ __forceinline__ F mul_iota(const F &x, bool plus) {
+    return plus ? f_make(x.im ? P61 - x.im : 0, x.re) : f_make(x.im, x.re ? P61 - x.re : 0);
+}
+// Radix-4 decimation in time: stage 1 of an odd ln rides on the bit-reversed load (its twiddles are all 1), then two stages per pass
+// in registers: with W = w_4q^k the group (a, b, c, d) at distance q becomes
+//     (a + B) + (C + D), (a - B) + iota (C - D), (a + B) - (C + D), (a - B) - iota (C - D),   B = W^2 b, C = W c, D = W^3 d
+// — three multiplications per four points and two stages (radix 2: four), half the LDS passes and barriers; the first pass of an
+// even ln has W = 1 and does not multiply at all.  ln = 13: 4.5 multiplications per point instead of 6.5, 7 LDS passes instead of 14.
 __global__ void __launch_bounds__(1024) k_ntt_lds(NttArgs a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     F *L = reinterpret_cast<F *>(smem_raw);
@@ -44,23 +54,46 @@ __global__ void __launch_bounds__(1024) k_ntt_lds(NttArgs a) {
     const u32 M = 2 * a.half_m;
     const u32 wstride = M >> a.ln;                          // w_N = w_M^wstride
     const F *src = a.in + (size_t) row * a.in_stride;
-    for (u32 j = tid; j < N; j += nth) {
-        F x = src[j];
-        if (!a.inverse && coset) x = f_mul(x, root_pow(a.RT, a.half_m, (j * coset) & (M - 1)));
-        L[a.ln ? (__brev(j) >> (32 - a.ln)) : 0u] = x;
+    const bool twist = !a.inverse && coset;
+    int s = 1;
+    if (a.ln & 1) {
+        // x[j] and x[j + N/2] land on the adjacent bit-reversed slots 2m, 2m+1: stage 1 (twiddle 1) on the way in
+        for (u32 j = tid; j < N / 2; j += nth) {
+            F x = src[j], y = src[j + N / 2];
+            if (twist) {
+                x = f_mul(x, root_pow(a.RT, a.half_m, (j * coset) & (M - 1)));
+                y = f_mul(y, root_pow(a.RT, a.half_m, ((j + N / 2) * coset) & (M - 1)));
+            }
+            const u32 m = __brev(j) >> (32 - a.ln);         // even
+            L[m] = f_add(x, y); L[m + 1] = f_sub(x, y);
+        }
+        s = 2;
+    } else {
+        for (u32 j = tid; j < N; j += nth) {
+            F x = src[j];
+            if (twist) x = f_mul(x, root_pow(a.RT, a.half_m, (j * coset) & (M - 1)));
+            L[a.ln ? (__brev(j) >> (32 - a.ln)) : 0u] = x;
+        }
     }
     __syncthreads();
-    for (int s = 1; s <= a.ln; ++s) {
-        const u32 half = 1u << (s - 1);
-        const u32 tw = (N >> s) * wstride;                 // exponent step of this stage in units of w_M
-        for (u32 idx = tid; idx < N / 2; idx += nth) {
-            const u32 k = idx & (half - 1), i0 = ((idx >> (s - 1)) << s) | k, i1 = i0 + half;
-            u32 e = k * tw;                                 // < M/2
-            if (a.inverse) e = e ? M - e : 0;               // w^-e
-            const F w = root_pow(a.RT, a.half_m, e);
-            const F u = L[i0], v = f_mul(L[i1], w);
-            L[i0] = f_add(u, v);
-            L[i1] = f_sub(u, v);
+    const bool iota_plus = a.RT[a.half_m >> 1].im == 1;    // w_M^(M/4) is (0, 1) or (0, p - 1)  (uniform; M >= 4 whenever a pass runs)
+    const bool ip = a.inverse ? !iota_plus : iota_plus;
+    for (; s + 1 <= a.ln; s += 2) {
+        const u32 q = 1u << (s - 1);
+        const u32 tw = (N >> (s + 1)) * wstride;           // W = w_4q^k = w_M^(k * tw)
+        for (u32 idx = tid; idx < N / 4; idx += nth) {
+            const u32 k = idx & (q - 1), i0 = ((idx >> (s - 1)) << (s + 1)) | k;
+            F x0 = L[i0], x1 = L[i0 + q], x2 = L[i0 + 2 * q], x3 = L[i0 + 3 * q];
+            if (q > 1) {                                    // uniform: the first pass of an even ln has W = 1
+                const u32 e = k * tw;                       // < M/4
+                const u32 e1 = a.inverse ? (e ? M - e : 0) : e, e2 = a.inverse ? (e ? M - 2 * e : 0) : 2 * e,
+                          e3 = a.inverse ? (e ? M - 3 * e : 0) : 3 * e;
+                x1 = f_mul(x1, root_pow(a.RT, a.half_m, e2));
+                x2 = f_mul(x2, root_pow(a.RT, a.half_m, e1));
+                x3 = f_mul(x3, root_pow(a.RT, a.half_m, e3));
+            }
+            const F s0 = f_add(x0, x1), d0 = f_sub(x0, x1), s1 = f_add(x2, x3), d1 = mul_iota(f_sub(x2, x3), ip);
+            L[i0] = f_add(s0, s1); L[i0 + q] = f_add(d0, d1); L[i0 + 2 * q] = f_sub(s0, s1); L[i0 + 3 * q] = f_sub(d0, d1);
         }
         __syncthreads();
     }
@@ -394,35 +427,48 @@ __global__ void __launch_bounds__(VP_BLOCK) k_ntt_split(SplitArgs a) {
     if (j2 >= N2) return;
     const u32 wN = M >> a.ln;                                  // w_N = w_M^wN
     const F *src = a.in + (size_t) row * a.in_stride;
+    const bool twist = !a.inverse && coset;
+    // The coset twist w_M^(j coset), j = j1 N2 + j2, splits into a factor of j1 alone (applied here, none for j1 = 0) and the factor
+    // w_M^(j2 coset) that is common to the whole column: it commutes with the N1-point transform and joins the output twiddle below.
     F x[N1];
 #pragma unroll
     for (u32 j1 = 0; j1 < N1; ++j1) {
-        const u32 j = j1 * N2 + j2;
-        F v = src[j];
-        if (!a.inverse && coset) v = f_mul(v, root_pow(a.RT, a.half_m, (u32) (((unsigned long long) j * coset) & (M - 1))));
+        F v = src[j1 * N2 + j2];
+        if (twist && j1) v = f_mul(v, root_pow(a.RT, a.half_m, (u32) (((unsigned long long) j1 * N2 * coset) & (M - 1))));
         x[j1] = v;
     }
-    // N1-point DFT, decimation in frequency in registers: natural in, bit-reversed out
+    const bool iota_plus = a.RT[a.half_m >> 1].im == 1;        // w_M^(M/4) = (0, +-1)
+    const bool ip = a.inverse ? !iota_plus : iota_plus;
+    // N1-point DFT, decimation in frequency in registers: natural in, bit-reversed out.  Twiddles 1 and iota cost nothing
+    // (10 of the 32 butterflies of a 16-point transform multiply).
 #pragma unroll
     for (int s = L1; s >= 1; --s) {
         const u32 half = 1u << (s - 1);
 #pragma unroll
         for (u32 idx = 0; idx < N1 / 2; ++idx) {
             const u32 k = idx & (half - 1), i0 = ((idx >> (s - 1)) << s) | k, i1 = i0 + half;
-            u32 e = (k * (N1 >> s)) * (M >> L1);               // w_N1^(k * N1/2^s) in units of w_M
-            if (a.inverse) e = e ? M - e : 0;
+            const u32 e1 = k * (N1 >> s);                      // w_N1^e1, e1 < N1/2 (compile-time after unrolling)
             const F u = x[i0], v = x[i1];
             x[i0] = f_add(u, v);
-            x[i1] = f_mul(f_sub(u, v), root_pow(a.RT, a.half_m, e));
+            const F d = f_sub(u, v);
+            if (e1 == 0) x[i1] = d;
+            else if (4 * e1 == N1) x[i1] = mul_iota(d, ip);
+            else {
+                u32 e = e1 * (M >> L1);
+                if (a.inverse) e = M - e;
+                x[i1] = f_mul(d, root_pow(a.RT, a.half_m, e));
+            }
         }
     }
     F *dst = a.out + ((size_t) row * a.ncoset + coset) * N;
+    const u32 ec = twist ? (u32) (((unsigned long long) j2 * coset) & (M - 1)) : 0u;      // the column's share of the twist
 #pragma unroll
     for (u32 p = 0; p < N1; ++p) {
         const u32 k1 = __brev(p) >> (32 - (L1 ? L1 : 1)) >> (L1 ? 0 : 1);     // bit reversal of p in L1 bits
         u32 e = (u32) (((unsigned long long) j2 * k1 * wN) & (M - 1));         // w_N^(j2 k1)
         if (a.inverse) e = e ? M - e : 0;
-        dst[(size_t) k1 * N2 + j2] = f_mul(x[p], root_pow(a.RT, a.half_m, e));
+        e = (e + ec) & (M - 1);
+        dst[(size_t) k1 * N2 + j2] = (p == 0 && !twist) ? x[p] : f_mul(x[p], root_pow(a.RT, a.half_m, e));
     }
 }
 
