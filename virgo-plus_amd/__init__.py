@@ -64,10 +64,10 @@ def build(force=False, verbose=False):
         run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
              "-o", LIB_GPU, os.path.join(CSRC, "vpgpu.hip")])
     if force or _stale(LIB_HOST, HOST_SRC + HOST_HDR + [LIB_GPU]):
-        run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-o", LIB_HOST] + HOST_SRC +
+        run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-pthread", "-o", LIB_HOST] + HOST_SRC +
             ["-L" + CSRC, "-lvpgpu", "-Wl,-rpath,$ORIGIN/../csrc", "-Wl,-rpath,/opt/rocm/lib"])
     if force or _stale(CLI, [os.path.join(HOST, "virgo_plus_run.cpp"), LIB_HOST]):
-        run(["g++", "-std=c++17", "-O2", "-Wall", "-o", CLI, os.path.join(HOST, "virgo_plus_run.cpp"),
+        run(["g++", "-std=c++17", "-O2", "-Wall", "-pthread", "-o", CLI, os.path.join(HOST, "virgo_plus_run.cpp"),
              "-L" + HOST, "-lvphost", "-L" + CSRC, "-lvpgpu", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/../csrc",
              "-Wl,-rpath,/opt/rocm/lib"])
 

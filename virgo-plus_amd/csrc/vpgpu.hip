@@ -230,64 +230,6 @@ inline u32 grid_for(u64 n) { return std::max<u32>(1, std::min<u32>(nblk(n), MAX_
 inline int ceil_log2(u64 x) { int b = 0; while ((1ull << b) < x) ++b; return b; }
 inline bool is_unary(int ty) { return ty == VP_ADDC || ty == VP_MULC || ty == VP_COPY || ty == VP_NOT; }
 
-// Build a target-sorted contribution list (counting sort, stable in gate order).
-int build_csr(vp_ctx *ctx, Csr &c, u32 n_rows, const std::vector<u32> &key, const std::vector<u32> &eg,
-              const std::vector<u32> &ex, const std::vector<uint16_t> &etl) {
-    const u32 n = (u32) key.size();
-    std::vector<u32> rowptr(n_rows + 1, 0);
-    for (u32 i = 0; i < n; ++i) ++rowptr[key[i] + 1];
-    for (u32 r = 0; r < n_rows; ++r) rowptr[r + 1] += rowptr[r];
-    std::vector<u32> pos(rowptr.begin(), rowptr.end() - 1), sg(n), sx(n);
-    std::vector<uint16_t> stl(n);
-    for (u32 i = 0; i < n; ++i) { u32 p = pos[key[i]]++; sg[p] = eg[i]; sx[p] = ex[i]; stl[p] = etl[i]; }
-    std::vector<u32> heavy_row, heavy_cptr(1, 0), cb, ce;
-    for (u32 r = 0; r < n_rows; ++r) {
-        u32 b = rowptr[r], e = rowptr[r + 1];
-        if (e - b <= VP_LIGHT_MAX) continue;
-        heavy_row.push_back(r);
-        for (u32 s = b; s < e; s += VP_CHUNK) { cb.push_back(s); ce.push_back(std::min(e, s + VP_CHUNK)); }
-        heavy_cptr.push_back((u32) cb.size());
-    }
-    c.n_rows = n_rows; c.n_entries = n; c.n_heavy = (u32) heavy_row.size(); c.n_chunks = (u32) cb.size();
-    c.n_heavy_entries = 0;
-    for (size_t q = 0; q < cb.size(); ++q) c.n_heavy_entries += ce[q] - cb[q];
-    VPCHK(dupload(ctx, &c.rowptr, rowptr));
-    VPCHK(dupload(ctx, &c.e_g, sg));
-    VPCHK(dupload(ctx, &c.e_x, sx));
-    VPCHK(dupload(ctx, &c.e_tl, stl));
-    VPCHK(dupload(ctx, &c.heavy_row, heavy_row));
-    VPCHK(dupload(ctx, &c.heavy_cptr, heavy_cptr));
-    VPCHK(dupload(ctx, &c.chunk_beg, cb));
-    VPCHK(dupload(ctx, &c.chunk_end, ce));
-    ctx->chunk_cap = std::max(ctx->chunk_cap, c.n_chunks);
-    {   // entry-parallel form: light rows only, chunk pointers every 512 rows, row offset per entry
-        const u32 nch = (n_rows + VP_I3_ROWS - 1) / VP_I3_ROWS;
-        std::vector<u32> cptr(nch + 1, 0), lg, lx, hptr(nch + 1, 0);
-        std::vector<uint16_t> ltl, lr;
-        lg.reserve(n); lx.reserve(n); ltl.reserve(n); lr.reserve(n);
-        size_t hi = 0;
-        for (u32 ch = 0; ch < nch; ++ch) {
-            cptr[ch] = (u32) lg.size();
-            const u32 r1 = std::min<u32>(n_rows, (ch + 1) * VP_I3_ROWS);
-            while (hi < heavy_row.size() && heavy_row[hi] < ch * VP_I3_ROWS) ++hi;
-            hptr[ch] = (u32) hi;
-            for (u32 r = ch * VP_I3_ROWS; r < r1; ++r) {
-                const u32 b = rowptr[r], e = rowptr[r + 1];
-                if (e - b > VP_LIGHT_MAX) continue;
-                for (u32 k = b; k < e; ++k) { lg.push_back(sg[k]); lx.push_back(sx[k]); ltl.push_back(stl[k]); lr.push_back((uint16_t) (r - ch * VP_I3_ROWS)); }
-            }
-        }
-        cptr[nch] = (u32) lg.size();
-        hptr[nch] = (u32) heavy_row.size();
-        u32 *d_cptr, *d_g, *d_x, *d_hptr; uint16_t *d_tl, *d_r;
-        VPCHK(dupload(ctx, &d_cptr, cptr)); VPCHK(dupload(ctx, &d_g, lg)); VPCHK(dupload(ctx, &d_x, lx));
-        VPCHK(dupload(ctx, &d_tl, ltl)); VPCHK(dupload(ctx, &d_r, lr)); VPCHK(dupload(ctx, &d_hptr, hptr));
-        c.c3.cptr = d_cptr; c.c3.e_g = d_g; c.c3.e_x = d_x; c.c3.e_tl = d_tl; c.c3.e_r = d_r; c.c3.hptr = d_hptr; c.c3.heavy_row = c.heavy_row;
-        c.c3.n_chunks = nch;
-    }
-    return VP_OK;
-}
-
 void count_launch(vp_ctx *ctx) { ++ctx->st.launches; }
 
 // Profiled calls bracket each launch with a pair of events from the pool (on the stream the launch goes to) and collect
@@ -638,6 +580,8 @@ const F *rliu_ptr(vp_ctx *ctx, int i) {
 
 }  // namespace
 
+#include "vpgpu_upload.inc"
+
 extern "C" {
 
 const char *vp_version(void) { return "vpgpu 0.1 (gfx950)"; }
@@ -732,108 +676,29 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
         max_bl = std::max(max_bl, (int) ld[i].bit_length);
     }
     ctx->max_bl = max_bl;
-    // ---- validate + per-layer uploads ----
+    // ---- per-layer uploads: the raw gate arrays go to HBM as they are, every per-gate structure is built there (vpgpu_upload.inc) ----
+    { const char *fi = getenv("VP_INIT3"); ctx->use_init3 = (fi && fi[0] == '1') ? 1 : 0; }
+    UpScratch S;
+    const bool up_dbg = getenv("VP_DEBUG_UPLOAD") != nullptr;
+    const auto up_t0 = std::chrono::steady_clock::now();
+    auto up_since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - up_t0).count(); };
+    u64 *d_sizes = nullptr;
+    {
+        std::vector<u64> sizes(n_layers);
+        for (int i = 0; i < n_layers; ++i) sizes[i] = ld[i].size;
+        VPCHK(dupload(ctx, &d_sizes, sizes));
+    }
     for (int i = 0; i < n_layers; ++i) {
         LayerDev &D = ctx->L[i];
-        const vp_layer_desc &S = ld[i];
-        D.size = S.size; D.bl = S.bit_length;
-        const u64 nval = i == 0 ? (1ull << S.bit_length) : S.size;     // circuitValue[0] is padded (prover.cpp:30)
+        const vp_layer_desc &L = ld[i];
+        D.size = L.size; D.bl = L.bit_length;
+        const u64 nval = i == 0 ? (1ull << L.bit_length) : L.size;     // circuitValue[0] is padded (prover.cpp:30)
         VPCHK(dalloc(ctx, &D.val, nval));
         if (i == 0) continue;
-        const u32 n = (u32) S.size;
-        std::vector<uint8_t> ty(n); std::vector<int16_t> gl(n); std::vector<u32> gu(n), gv(n), as;
-        bool need_c = false;
-        for (u32 g = 0; g < n; ++g) {
-            const int t = S.ty[g], l = S.l[g];
-            if (t < 0 || t > VP_COPY || t == VP_INPUT) { ctx->err = "bad gate type"; return VP_EINVAL; }
-            if (S.u[g] >= ld[i - 1].size) { ctx->err = "gate.u out of range"; return VP_EINVAL; }
-            if (is_unary(t)) {
-                if (l != -1) { ctx->err = "unary gate with l != -1"; return VP_EINVAL; }
-                if (t == VP_ADDC || t == VP_MULC) need_c = true;
-            } else {
-                if (l < 0 || l >= i || S.v[g] >= ld[l].size) { ctx->err = "gate.v out of range"; return VP_EINVAL; }
-                if (!S.dad_size || S.lv[g] >= S.dad_size[l] || S.dad_id[l][S.lv[g]] != S.v[g]) {
-                    ctx->err = "gate.lv inconsistent with dadId"; return VP_EINVAL;
-                }
-            }
-            ty[g] = (uint8_t) t; gl[g] = (int16_t) l; gu[g] = S.u[g]; gv[g] = is_unary(t) ? 0 : S.v[g];
-            if (S.is_assert && S.is_assert[g]) as.push_back(g);
-        }
-        if (need_c && !S.c) { ctx->err = "Addc/Mulc gates without constants"; return VP_EINVAL; }
-        VPCHK(dupload(ctx, &D.ty, ty)); VPCHK(dupload(ctx, &D.gl, gl));
-        VPCHK(dupload(ctx, &D.gu, gu)); VPCHK(dupload(ctx, &D.gv, gv));
-        if (need_c) {
-            VPCHK(dalloc(ctx, &D.gc, (size_t) n));
-            HIPCHK(hipMemcpy(D.gc, S.c, (size_t) n * sizeof(F), hipMemcpyHostToDevice));
-        }
-        D.n_assert = (u32) as.size();
-        VPCHK(dupload(ctx, &D.assert_idx, as));
-        {   // predicate buckets: 0 Copy, 1 Not, 2 Addc, 3 Mulc (x c), 4 bias (Addc x c), 5 + tyidx * i + l for the binary types
-            static const int tyidx[12] = {3, 0, 1, 2, 4, 5, -1, -1, -1, 6, -1, -1};     // Mul Add Sub AntiSub Naab AntiNaab . . . Xor
-            const u32 nbk = 5 + 7 * (u32) i;
-            std::vector<std::vector<u32>> bk(nbk);
-            for (u32 g = 0; g < n; ++g) {
-                const int t = ty[g];
-                if (t == VP_COPY) bk[0].push_back(g);
-                else if (t == VP_NOT) bk[1].push_back(g);
-                else if (t == VP_ADDC) { bk[2].push_back(g); bk[4].push_back(g); }
-                else if (t == VP_MULC) bk[3].push_back(g);
-                else bk[5 + (u32) tyidx[t] * i + (u32) gl[g]].push_back(g);
-            }
-            std::vector<u32> pidx, cbeg, cend, bptr(1, 0), glv(n, 0);
-            std::vector<uint8_t> pflag;
-            std::vector<uint8_t> isas(n, 0);
-            for (u32 g : as) isas[g] = 1;
-            for (u32 g = 0; g < n; ++g) if (!is_unary(ty[g])) glv[g] = S.lv[g];
-            for (u32 b = 0; b < nbk; ++b) {
-                const u32 start = (u32) pidx.size();
-                const int cls = b >= 5 ? 0 : (b == 3 || b == 4) ? 2 : 1;
-                for (u32 g : bk[b]) { pidx.push_back(g); pflag.push_back((uint8_t) ((cls << 1) | isas[g])); }
-                for (u32 q = start; q < pidx.size(); q += 512) { cbeg.push_back(q); cend.push_back(std::min<u32>((u32) pidx.size(), q + 512)); }
-                bptr.push_back((u32) cbeg.size());
-            }
-            D.p_chunks = (u32) cbeg.size(); D.p_buckets = nbk;
-            VPCHK(dupload(ctx, &D.p_idx, pidx)); VPCHK(dupload(ctx, &D.p_flag, pflag)); VPCHK(dupload(ctx, &D.p_cbeg, cbeg));
-            VPCHK(dupload(ctx, &D.p_cend, cend)); VPCHK(dupload(ctx, &D.p_bptr, bptr)); VPCHK(dupload(ctx, &D.glv, glv));
-        }
-        // dad subsets / phase-2 slot layout
-        D.dad_size.resize(i); D.dad_bl.resize(i); D.dad_id.assign(i, nullptr); D.t_off.resize(i); D.t_len.resize(i);
-        D.max_dad_bl = -1;
-        u32 off = 0;
-        std::vector<u32> g_slot, g_idx; std::vector<uint8_t> g_layer;
-        for (int j = 0; j < i; ++j) {
-            D.dad_size[j] = S.dad_size[j];
-            if (S.dad_size[j] > ld[j].size) { ctx->err = "dadSize too large"; return VP_EINVAL; }
-            D.dad_bl[j] = S.dad_size[j] ? ceil_log2(S.dad_size[j]) : 0;
-            if (S.dad_size[j]) {
-                if (S.dad_bitlen[j] != D.dad_bl[j]) { ctx->err = "dadBitLength mismatch"; return VP_EINVAL; }
-                D.max_dad_bl = std::max(D.max_dad_bl, D.dad_bl[j]);
-                std::vector<u32> ids(S.dad_id[j], S.dad_id[j] + S.dad_size[j]);
-                for (u32 x : ids) if (x >= ld[j].size) { ctx->err = "dadId out of range"; return VP_EINVAL; }
-                VPCHK(dupload(ctx, &D.dad_id[j], ids));
-                for (u32 k = 0; k < ids.size(); ++k) { g_slot.push_back(off + k); g_layer.push_back((uint8_t) j); g_idx.push_back(ids[k]); }
-            } else {
-                g_slot.push_back(off); g_layer.push_back(0xff); g_idx.push_back(0);
-            }
-            D.t_off[j] = off; D.t_len[j] = 1u << D.dad_bl[j];
-            off += D.t_len[j];
-        }
-        D.p2_total = off;
-        D.n_gather = (u32) g_slot.size();
-        VPCHK(dupload(ctx, &D.g_slot, g_slot)); VPCHK(dupload(ctx, &D.g_layer, g_layer)); VPCHK(dupload(ctx, &D.g_idx, g_idx));
-        // contribution lists
-        std::vector<u32> key1(n), key2(n), eg(n), ex1(n), ex2(n);
-        std::vector<uint16_t> etl(n);
-        for (u32 g = 0; g < n; ++g) {
-            const int t = ty[g], l = gl[g];
-            eg[g] = g; ex1[g] = gv[g]; ex2[g] = gu[g];
-            etl[g] = (uint16_t) ((t << 8) | (l < 0 ? 0xff : l) | ((S.is_assert && S.is_assert[g]) ? 0x8000 : 0));
-            key1[g] = gu[g];
-            key2[g] = is_unary(t) ? D.t_off[i - 1] : D.t_off[l] + S.lv[g];    // prover.cpp:314,342-353
-        }
-        VPCHK(build_csr(ctx, D.c1, (u32) ld[i - 1].size, key1, eg, ex1, etl));
-        VPCHK(build_csr(ctx, D.c2, D.p2_total, key2, eg, ex2, etl));
+        if (!L.ty || !L.l || !L.u || !L.v || !L.lv || !L.dad_size || !L.dad_bitlen || !L.dad_id) { ctx->err = "layer arrays missing"; return VP_EINVAL; }
+        VPCHK(upload_layer_dev(ctx, S, i, ld, d_sizes));
     }
+    if (up_dbg) fprintf(stderr, "[vp_circuit_upload] layers %.3f s", up_since());
     // ---- shared buffers ----
     u32 cap = 0;
     for (int i = 1; i < n_layers; ++i) cap = std::max<u32>(cap, std::max<u32>(1u << ctx->L[i - 1].bl, ctx->L[i].p2_total));
@@ -858,6 +723,7 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
         for (int i = 0; i < n_layers; ++i) vals[i] = ctx->L[i].val;
         VPCHK(dupload(ctx, &ctx->d_vals, vals));
     }
+    if (up_dbg) fprintf(stderr, "  shared %.3f", up_since());
     compute_layout(ctx);
     VPCHK(dalloc(ctx, &ctx->d_tape, (size_t) ctx->n_tape));
     VPCHK(dalloc(ctx, &ctx->d_tr, (size_t) ctx->n_tr + 3 + VP_MAX_TAB));
@@ -880,6 +746,7 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
         D.n_jobs = (u32) jobs.size();
         VPCHK(dupload(ctx, &D.jobs, jobs));
     }
+    if (up_dbg) fprintf(stderr, "  liujobs %.3f", up_since());
     // ---- batched path: per-slot gather map, Liu gather lists, one pool of half tables for the whole proof ----
     {
         std::vector<BetaJob> jobs;
@@ -921,41 +788,9 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
             std::vector<Half> hs;
             for (int q : liu_id[i]) hs.push_back(half_of(q));
             VPCHK(dupload(ctx, &D.liu_H, hs));
-            // slot -> source of the phase-2 V value
-            std::vector<uint8_t> sl(D.p2_total, 0xfe); std::vector<u32> si(D.p2_total, 0);
-            for (int j = 0; j < i; ++j) {
-                if (!D.dad_size[j]) { sl[D.t_off[j]] = 0xff; continue; }
-                for (u64 k = 0; k < D.dad_size[j]; ++k) { sl[D.t_off[j] + k] = (uint8_t) j; si[D.t_off[j] + k] = ld[i].dad_id[j][k]; }
-            }
-            VPCHK(dupload(ctx, &D.s_layer, sl)); VPCHK(dupload(ctx, &D.s_idx, si));
-            // Liu gather lists over the wires of layer i-1 (dadId[k][i-1] inverted), counting sort by wire
-            const u32 rows = (u32) ctx->L[i - 1].size;
-            std::vector<u32> rp(rows + 1, 0);
-            int q = 1;
-            for (int k = i; k < n_layers; ++k) {
-                if (!ctx->L[k].dad_size[i - 1]) continue;
-                for (u64 g = 0; g < ctx->L[k].dad_size[i - 1]; ++g) ++rp[ld[k].dad_id[i - 1][g] + 1];
-            }
-            for (u32 r = 0; r < rows; ++r) rp[r + 1] += rp[r];
-            std::vector<u32> pos(rp.begin(), rp.end() - 1), eg(rp[rows]); std::vector<uint8_t> eq(rp[rows]);
-            for (int k = i; k < n_layers; ++k) {
-                if (!ctx->L[k].dad_size[i - 1]) continue;
-                for (u64 g = 0; g < ctx->L[k].dad_size[i - 1]; ++g) { u32 p = pos[ld[k].dad_id[i - 1][g]]++; eg[p] = (u32) g; eq[p] = (uint8_t) q; }
-                ++q;
-            }
-            VPCHK(dupload(ctx, &D.lrow, rp)); VPCHK(dupload(ctx, &D.l_g, eg)); VPCHK(dupload(ctx, &D.l_q, eq));
-            D.l_n = rp[rows];
-            {
-                const u32 nch = (rows + VP_I3_ROWS - 1) / VP_I3_ROWS;
-                std::vector<u32> cptr(nch + 1);
-                std::vector<uint16_t> er(rp[rows]);
-                for (u32 ch = 0; ch <= nch; ++ch) cptr[ch] = rp[std::min<u32>(rows, ch * VP_I3_ROWS)];
-                for (u32 r = 0; r < rows; ++r) for (u32 k = rp[r]; k < rp[r + 1]; ++k) er[k] = (uint16_t) (r % VP_I3_ROWS);
-                u32 *d_cptr; uint16_t *d_r;
-                VPCHK(dupload(ctx, &d_cptr, cptr)); VPCHK(dupload(ctx, &d_r, er));
-                D.l3.cptr = d_cptr; D.l3.e_g = D.l_g; D.l3.e_q = D.l_q; D.l3.e_r = d_r; D.l3.n_chunks = nch;
-            }
+            VPCHK(upload_liu_dev(ctx, S, i));           // Liu gather lists over the wires of layer i-1 (dadId[k][i-1] inverted)
         }
+    if (up_dbg) fprintf(stderr, "  liulists %.3f", up_since());
         VPCHK(dalloc(ctx, &ctx->part2, (size_t) 32 * MAX_BLOCKS * 3));
         // lanes: per-layer scratch for the concurrent chains
         ctx->lane0.stream = ctx->stream;
@@ -1007,8 +842,8 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
         ctx->sumfold_path = (pth && !strcmp(pth, "sumfold")) ? 1 : 0;
         ctx->plan_path = (pth && !strcmp(pth, "lanes")) ? 0 : 1;
         { const char *fi = getenv("VP_FUSE_INIT"); ctx->fuse_init = (fi && fi[0] == '0') ? 0 : 1; }
-        { const char *fi = getenv("VP_INIT3"); ctx->use_init3 = (fi && fi[0] == '1') ? 1 : 0; }
     }
+    if (up_dbg) fprintf(stderr, "  total %.3f s\n", up_since());
     // event pool for the profiled launches
     if (ctx->ev_pool.empty()) {
         ctx->ev_pool.resize(1024);

@@ -1,4 +1,12 @@
 #include "prover.hpp"
+#include <atomic>
+#include <functional>
+#include <memory>
+#include <chrono>
+#include <thread>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 #include <cstdio>
 #include <cstdlib>
@@ -20,50 +28,105 @@ prover::prover(const layeredCircuit &cir, int device) : C(cir) {
     int rc = vp_create(device, &ctx);
     if (rc != VP_OK) throw std::runtime_error("vp_create failed (" + std::to_string(rc) + "): no usable MI355X / HIP device");
     const int n = C.size;
+    const bool dbg = getenv("VP_DEBUG_UPLOAD") != nullptr;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
     std::vector<vp_layer_desc> desc(n);
+    // uninitialised arrays (no zero fill, the pages are first touched by the threads that write them)
     struct Flat {
-        std::vector<uint8_t> ty, as; std::vector<int32_t> l; std::vector<uint32_t> u, v, lv; std::vector<vp_F> c;
+        std::unique_ptr<uint8_t[]> ty, as; std::unique_ptr<int32_t[]> l; std::unique_ptr<uint32_t[]> u, v, lv; std::unique_ptr<vp_F[]> c;
         std::vector<uint64_t> dsz; std::vector<int32_t> dbl; std::vector<std::vector<uint32_t>> did; std::vector<const uint32_t *> dptr;
     };
     std::vector<Flat> flat(n);
+    // gate (array of structs, src/circuit.h:11-22) -> the structure-of-arrays view of vp_layer_desc.  Plain copies, split over the host's
+    // cores in ranges of 2^20 gates (x1024: 1e8 gates, 0.5 s on one core): pass 1 finds the layers with constants / assert gates, pass 2 copies.
+    struct Range { int layer; u64 b, e; };
+    std::vector<Range> ranges;
+    for (int i = 0; i < n; ++i) {
+        const u64 m = C.circuit[i].size;
+        for (u64 b = 0; b < m; b += (1u << 20)) ranges.push_back({i, b, std::min<u64>(m, b + (1u << 20))});
+    }
+    std::vector<std::atomic<char>> c_seen(n), as_seen(n);
+    for (int i = 0; i < n; ++i) { c_seen[i] = 0; as_seen[i] = 0; }
+    auto run_pool = [&](const std::function<void(const Range &)> &body) {
+        std::atomic<size_t> next{0};
+        auto work = [&]() { for (;;) { const size_t q = next.fetch_add(1); if (q >= ranges.size()) return; body(ranges[q]); } };
+        const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        const unsigned nt = (unsigned) std::min<size_t>(hw, std::max<size_t>(1, ranges.size()));
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work);
+        work();
+        for (auto &t : pool) t.join();
+    };
+    run_pool([&](const Range &r) {
+        const layer &L = C.circuit[r.layer];
+        bool c = false, as = false;
+        for (u64 g = r.b; g < r.e; ++g) { const gate &G = L.gates[g]; c |= (G.ty == Addc || G.ty == Mulc); as |= G.is_assert; }
+        if (c) c_seen[r.layer] = 1;
+        if (as) as_seen[r.layer] = 1;
+    });
+    std::vector<char> any_c(n, 0), any_as(n, 0);
+    for (int i = 0; i < n; ++i) {
+        Flat &f = flat[i];
+        const u64 m = C.circuit[i].size;
+        any_c[i] = c_seen[i]; any_as[i] = as_seen[i];
+        f.ty.reset(new uint8_t[m]); f.as.reset(new uint8_t[m]); f.l.reset(new int32_t[m]);
+        f.u.reset(new uint32_t[m]); f.v.reset(new uint32_t[m]); f.lv.reset(new uint32_t[m]);
+        if (any_c[i]) f.c.reset(new vp_F[m]);
+    }
+    run_pool([&](const Range &r) {
+        const layer &L = C.circuit[r.layer];
+        Flat &f = flat[r.layer];
+        const bool has_c = any_c[r.layer];
+        for (u64 g = r.b; g < r.e; ++g) {
+            const gate &G = L.gates[g];
+            f.ty[g] = (uint8_t) G.ty; f.l[g] = G.l;
+            f.u[g] = r.layer == 0 ? 0u : (uint32_t) G.u;      // layer 0: u carries the input value, not an index
+            f.v[g] = (uint32_t) G.v; f.lv[g] = (uint32_t) G.lv;
+            f.as[g] = G.is_assert ? 1 : 0;
+            if (has_c) { f.c[g].real = G.c.real; f.c[g].img = G.c.img; }
+        }
+    });
+    {   // the subset lists (u64 in the reference's layout) -> u32, one layer per task
+        std::atomic<int> next{0};
+        auto work = [&]() {
+            for (;;) {
+                const int i = next.fetch_add(1);
+                if (i >= n) return;
+                const layer &L = C.circuit[i];
+                Flat &f = flat[i];
+                f.did.resize(L.dadId.size());
+                for (size_t j = 0; j < L.dadId.size(); ++j) f.did[j].assign(L.dadId[j].begin(), L.dadId[j].end());
+            }
+        };
+        const unsigned nt = std::max(1u, std::min<unsigned>(std::min(16u, std::thread::hardware_concurrency()), (unsigned) n));
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work);
+        work();
+        for (auto &t : pool) t.join();
+    }
     for (int i = 0; i < n; ++i) {
         const layer &L = C.circuit[i];
         Flat &f = flat[i];
-        const u64 m = L.size;
-        f.ty.resize(m); f.as.resize(m); f.l.resize(m); f.u.resize(m); f.v.resize(m); f.lv.resize(m);
-        bool any_c = false, any_as = false;
-        for (u64 g = 0; g < m; ++g) {
-            const gate &G = L.gates[g];
-            f.ty[g] = (uint8_t) G.ty; f.l[g] = G.l;
-            f.u[g] = i == 0 ? 0u : (uint32_t) G.u;      // layer 0: u carries the input value, not an index
-            f.v[g] = (uint32_t) G.v; f.lv[g] = (uint32_t) G.lv;
-            f.as[g] = G.is_assert ? 1 : 0;
-            any_as |= G.is_assert;
-            any_c |= (G.ty == Addc || G.ty == Mulc);
-        }
-        if (any_c) {
-            f.c.resize(m);
-            for (u64 g = 0; g < m; ++g) { f.c[g].real = L.gates[g].c.real; f.c[g].img = L.gates[g].c.img; }
-        }
         f.dsz.assign(L.dadSize.begin(), L.dadSize.end());
         f.dbl.assign(L.dadBitLength.begin(), L.dadBitLength.end());
-        f.did.resize(L.dadId.size()); f.dptr.resize(L.dadId.size());
-        for (size_t j = 0; j < L.dadId.size(); ++j) {
-            f.did[j].assign(L.dadId[j].begin(), L.dadId[j].end());
-            f.dptr[j] = f.did[j].data();
-        }
+        f.dptr.resize(L.dadId.size());
+        for (size_t j = 0; j < L.dadId.size(); ++j) f.dptr[j] = f.did[j].data();
         vp_layer_desc &d = desc[i];
-        d.size = m; d.bit_length = L.bitLength;
-        d.ty = f.ty.data(); d.l = f.l.data(); d.u = f.u.data(); d.v = f.v.data(); d.lv = f.lv.data();
-        d.c = any_c ? f.c.data() : nullptr;
-        d.is_assert = any_as ? f.as.data() : nullptr;
+        d.size = L.size; d.bit_length = L.bitLength;
+        d.ty = f.ty.get(); d.l = f.l.get(); d.u = f.u.get(); d.v = f.v.get(); d.lv = f.lv.get();
+        d.c = any_c[i] ? f.c.get() : nullptr;
+        d.is_assert = any_as[i] ? f.as.get() : nullptr;
         d.dad_size = f.dsz.data(); d.dad_bitlen = f.dbl.data(); d.dad_id = f.dptr.data();
     }
     // the destructor of a partially constructed object never runs: release the context (streams, pinned buffers, the circuit and
     // witness in HBM) before the exception leaves, e.g. when evaluate() reports a violated assert gate (VP_EASSERT)
     try {
+        const double t0 = since();
         check(vp_circuit_upload(ctx, n, desc.data()), "vp_circuit_upload");
+        const double t1 = since();
         evaluate();
+        if (dbg) fprintf(stderr, "[vp upload] flatten %.3f s  vp_circuit_upload %.3f s  evaluate %.3f s\n", t0, t1 - t0, since() - t1);
     } catch (...) {
         vp_destroy(ctx);
         ctx = nullptr;
