@@ -920,6 +920,36 @@ def test_real_value_products_are_a_pure_specialisation(vp, golden, gold_gkr, pws
     c.close()
 
 
+def test_options_struct_selects_the_same_alternatives_as_the_test_environment(vp, gold_gkr, pws_path):
+    """vp_options (include/vpgpu.h) is the ABI for the library's switches; the VP_* environment variables the other tests flip are a
+    test-only override on top of it.  A few alternatives selected through the struct alone: same transcript, and the launch table
+    shows that the alternative actually ran."""
+    c = vp.Circuit.from_pws(pws_path, 16, seed=1)
+    gold = gold_gkr("sha256_x16")
+    d = vp.Options()
+    assert d.struct_size == ctypes.sizeof(vp.Options) and d.sf_rounds == 3 and d.drop_y == 1 and d.persistent_rounds == 1
+    launches = {}
+    for name, kw in (("default", {}), ("four_rounds", {"sf_rounds": 4}), ("keep_y", {"drop_y": 0}), ("complex_products", {"real_values": 0}),
+                     ("lanes", {"gkr_path": vp.PATH_LANES}), ("simple", {"gkr_path": vp.PATH_SIMPLE}), ("no_graph", {"use_graph": 0, "serial": 1})):
+        s = vp.Session(c, options=vp.Options(**kw))
+        s.draw_tape()
+        tr, res = s.prove_gkr()
+        assert tr == gold, name
+        launches[name] = res["launches"]
+        if name == "default":
+            tr_i, _, ok = s.prove_interactive()
+            assert ok and tr_i == gold
+        s.close()
+    # the alternatives really ran: one launch per round on the simple path, one stream per chain (no batched nodes) on the lanes path,
+    # fewer fold launches with four rounds each
+    assert launches["simple"] > 10 * launches["default"] and launches["lanes"] > launches["default"]
+    assert launches["four_rounds"] <= launches["default"] and launches["no_graph"] == launches["default"]
+    s = vp.Session(c, options=vp.Options(persistent_rounds=0))
+    tr_i, _, ok = s.prove_interactive()
+    assert ok and tr_i == gold
+    s.close(); c.close()
+
+
 def test_violated_assert_gate_is_reported(vp):
     """The reference exits the process when an assert gate is non-zero (src/prover.cpp:18-21); the library returns
     VP_EASSERT through the host constructor instead."""

@@ -101,6 +101,9 @@ def lib_gpu():
         L = ctypes.CDLL(LIB_GPU, mode=ctypes.RTLD_GLOBAL)
         vp = ctypes.c_void_p
         L.vp_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+        L.vp_create_with_options.argtypes = [ctypes.c_int, vp, ctypes.POINTER(vp)]
+        L.vp_options_default.argtypes = [vp]
+        L.vp_options_default.restype = None
         L.vp_destroy.argtypes = [vp]
         L.vp_last_error.argtypes = [vp]
         L.vp_last_error.restype = ctypes.c_char_p
@@ -156,6 +159,8 @@ def lib_host():
         L.vph_circuit_hash.argtypes = [vp, ctypes.POINTER(u64)]
         L.vph_session_create.restype = vp
         L.vph_session_create.argtypes = [vp, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
+        L.vph_session_create_opts.restype = vp
+        L.vph_session_create_opts.argtypes = [vp, ctypes.c_int, vp, ctypes.c_char_p, ctypes.c_int]
         L.vph_session_free.argtypes = [vp]
         L.vph_set_profiling.argtypes = [vp, ctypes.c_int]
         L.vph_session_ctx.restype = vp
@@ -377,13 +382,32 @@ class Circuit:
             self.h = None
 
 
+class Options(ctypes.Structure):
+    """vp_options of include/vpgpu.h (how the library computes, never what).  Options() holds the shipped defaults."""
+    _fields_ = [("struct_size", ctypes.c_uint32)] + [(n, ctypes.c_int32) for n in (
+        "gkr_path", "use_graph", "serial", "fuse_init", "fuse_min_log", "fuse_dot", "init3", "drop_y", "drop_y_round1", "real_values",
+        "seg_tiny", "sf_rounds", "sf_big_log", "sf3b", "sf3b_grid", "sf_min_waves", "dot_blocks", "plan_align", "xcd_map",
+        "round_fused_max", "persistent_rounds", "persistent_multi", "persistent_multi_shift", "poll", "debug")]
+
+    def __init__(self, **kw):
+        super().__init__()
+        lib_gpu().vp_options_default(ctypes.byref(self))
+        for k, v in kw.items():
+            if not hasattr(self, k):
+                raise TypeError("unknown option " + k)
+            setattr(self, k, v)
+
+
+PATH_PLAN, PATH_LANES, PATH_SUMFOLD, PATH_SIMPLE = range(4)
+
+
 class Session:
     """One prover on one GPU: circuit resident in HBM, witness evaluated on the device."""
 
-    def __init__(self, circuit, device=0):
+    def __init__(self, circuit, device=0, options=None):
         err = ctypes.create_string_buffer(512)
         self.circuit = circuit
-        self.h = lib_host().vph_session_create(circuit.h, device, err, len(err))
+        self.h = lib_host().vph_session_create_opts(circuit.h, device, ctypes.byref(options) if options is not None else None, err, len(err))
         if not self.h:
             raise RuntimeError("Session: " + err.value.decode())
         self._cap = int(lib_host().vph_transcript_bytes(self.h)) + 4096

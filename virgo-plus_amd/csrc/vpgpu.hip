@@ -128,6 +128,7 @@ struct vp_ctx {
     MultiSync *d_msync = nullptr; int multi_enabled = 0;      // VP_PERSIST=0: one launch per round; VP_PERSIST_MULTI=0: no distributed rounds
     int poll = 1;                                     // VP_POLL=0: wait with hipStreamSynchronize instead
     F *h_io = nullptr; size_t h_io_cap = 0;   // pinned staging of the batched path: tape in, transcript out
+    vp_options opt{};                  // resolved at vp_create: defaults <- caller's struct <- VP_* environment (test-only override)
     int *d_flag = nullptr;
     u32 *d_vcplx = nullptr;            // non-zero: some circuit value of the last vp_evaluate has an imaginary part
     int vreal = 0, plan_vreal = 0;     // 1: every circuit value is real — round 1 of every sumcheck and the phase-1 inits take the half-price products (vp_field.h, f_mad31c_rb)
@@ -397,7 +398,7 @@ int do_round(vp_ctx *ctx, const F *rp, const F &rv, F *poly_dev, F *poly_host) {
         }
     }
     a.total_pairs = pairs;
-    static const u32 fused_max = getenv("VP_ROUND_FUSED_MAX") ? (u32) atoi(getenv("VP_ROUND_FUSED_MAX")) : 512;
+    const u32 fused_max = (u32) ctx->opt.round_fused_max;
     if (pairs <= fused_max) {            // one workgroup: fold + sums + closing in a single launch
         hipLaunchKernelGGL(k_round_fused, dim3(1), dim3(VP_BLOCK), 0, ctx->stream, a, ctx->add_term(), ctx->scalarV(), poly_dev, poly_host,
                            (poly_host && ctx->poll) ? ctx->h_seq : nullptr, ++ctx->seq);
@@ -492,7 +493,7 @@ int tail_try_launch(vp_ctx *ctx, const F &rv) {
     // single-table phase (phase 1, Liu) with a table too large for one CU: distributed rounds on G workgroups, solo from round kc
     if (ctx->multi_enabled && k == 1 && s.n_tab == 1 && s.len0[0] >= 8192 && s.bl[0] == s.total_rounds) {
         const u32 len0 = s.len0[0];
-        static const int gshift = getenv("VP_MULTI_SHIFT") ? atoi(getenv("VP_MULTI_SHIFT")) : 13;      // entries of table_1 per workgroup (log2)
+        const int gshift = ctx->opt.persistent_multi_shift;      // entries of table_1 per workgroup (log2)
         const int G = (int) std::max<u32>(2, std::min<u32>(VP_MULTI_MAXG, len0 >> gshift));
         u32 B1 = 2; while ((u64) B1 * G < s.valid0[0]) B1 <<= 1;
         const int kc = s.bl[0] - 10;                               // first round whose source table has <= 4096 entries
@@ -513,7 +514,7 @@ int tail_try_launch(vp_ctx *ctx, const F &rv) {
         a.req = ctx->h_req; a.rep = ctx->h_rep; a.claims_host = ctx->h_pin + 4;
         a.seq0 = ++ctx->tail_seq; ctx->h_rep->dead = 0;
         hipLaunchKernelGGL(k_phase, dim3(G), dim3(VP_PH_THREADS), (size_t) 3 * a.cap * sizeof(F), ctx->stream, a);
-        { const hipError_t e = hipGetLastError(); if (e != hipSuccess) { if (getenv("VP_DEBUG")) fprintf(stderr, "[vp] k_phase (G=%d) launch failed: %s\n", G, hipGetErrorString(e)); --ctx->tail_seq; return 0; } }
+        { const hipError_t e = hipGetLastError(); if (e != hipSuccess) { if ((ctx->opt.debug & 1)) fprintf(stderr, "[vp] k_phase (G=%d) launch failed: %s\n", G, hipGetErrorString(e)); --ctx->tail_seq; return 0; } }
         count_launch(ctx);
         ctx->tail_active = true;
         return 1;
@@ -548,7 +549,7 @@ int tail_try_launch(vp_ctx *ctx, const F &rv) {
     a.req = ctx->h_req; a.rep = ctx->h_rep; a.claims_host = ctx->h_pin + 4;
     a.seq0 = ++ctx->tail_seq; ctx->h_rep->dead = 0;
     hipLaunchKernelGGL(k_phase, dim3(1), dim3(VP_PH_THREADS), (size_t) 3 * ents * sizeof(F), ctx->stream, a);
-    { const hipError_t e = hipGetLastError(); if (e != hipSuccess) { if (getenv("VP_DEBUG")) fprintf(stderr, "[vp] k_phase launch failed: %s\n", hipGetErrorString(e)); --ctx->tail_seq; return 0; } }
+    { const hipError_t e = hipGetLastError(); if (e != hipSuccess) { if ((ctx->opt.debug & 1)) fprintf(stderr, "[vp] k_phase launch failed: %s\n", hipGetErrorString(e)); --ctx->tail_seq; return 0; } }
     count_launch(ctx);
     ctx->tail_active = true;
     return 1;
@@ -587,7 +588,43 @@ extern "C" {
 const char *vp_version(void) { return "vpgpu 0.1 (gfx950)"; }
 const char *vp_last_error(const vp_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
-int vp_create(int device, vp_ctx **out) {
+void vp_options_default(vp_options *o) {
+    if (!o) return;
+    memset(o, 0, sizeof *o);
+    o->struct_size = (uint32_t) sizeof *o;
+    o->gkr_path = VP_PATH_PLAN; o->use_graph = 1; o->serial = 0; o->fuse_init = 1; o->fuse_min_log = 23; o->fuse_dot = 0; o->init3 = 0;
+    o->drop_y = 1; o->drop_y_round1 = 0; o->real_values = 1; o->seg_tiny = 1; o->sf_rounds = 3; o->sf_big_log = 14; o->sf3b = 1;
+    o->sf3b_grid = 512; o->sf_min_waves = 1; o->dot_blocks = 1024; o->plan_align = 0; o->xcd_map = 0; o->round_fused_max = 512;
+    o->persistent_rounds = 1; o->persistent_multi = 0; o->persistent_multi_shift = 13; o->poll = 1; o->debug = 0;
+}
+// defaults <- the caller's struct (as many bytes as its header knew) <- VP_* environment variables (test-only override, read here and nowhere else)
+static void resolve_options(vp_options *o, const vp_options *user) {
+    vp_options_default(o);
+    if (user && user->struct_size >= sizeof(uint32_t)) {
+        memcpy(o, user, std::min<size_t>(user->struct_size, sizeof *o));
+        o->struct_size = (uint32_t) sizeof *o;
+    }
+    auto flag = [](const char *name, int32_t &v) { const char *e = getenv(name); if (e && (e[0] == '0' || e[0] == '1')) v = e[0] - '0'; };
+    auto num = [](const char *name, int32_t &v) { const char *e = getenv(name); if (e && *e) v = atoi(e); };
+    if (const char *p = getenv("VP_GKR_PATH"))
+        o->gkr_path = !strcmp(p, "lanes") ? VP_PATH_LANES : !strcmp(p, "sumfold") ? VP_PATH_SUMFOLD : !strcmp(p, "simple") ? VP_PATH_SIMPLE : VP_PATH_PLAN;
+    if (const char *p = getenv("VP_PLAN_ALIGN")) o->plan_align = !strcmp(p, "left") ? 1 : !strcmp(p, "right") ? 2 : 0;
+    flag("VP_GKR_GRAPH", o->use_graph); flag("VP_GKR_SERIAL", o->serial); flag("VP_FUSE_INIT", o->fuse_init); flag("VP_FUSE_DOT", o->fuse_dot);
+    flag("VP_INIT3", o->init3); flag("VP_DROP_Y", o->drop_y); flag("VP_DROP_Y1", o->drop_y_round1); flag("VP_REAL_V", o->real_values);
+    flag("VP_SEG_TINY", o->seg_tiny); flag("VP_XCD_MAP", o->xcd_map); flag("VP_PERSIST", o->persistent_rounds);
+    flag("VP_PERSIST_MULTI", o->persistent_multi); flag("VP_POLL", o->poll);
+    num("VP_FUSE_MIN_LOG", o->fuse_min_log); num("VP_SF_ROUNDS", o->sf_rounds); num("VP_SF_BIG_LOG", o->sf_big_log); num("VP_SF3B", o->sf3b);
+    num("VP_SF3B_GRID", o->sf3b_grid); num("VP_SF_MINW", o->sf_min_waves); num("VP_DOT_BLOCKS", o->dot_blocks);
+    num("VP_ROUND_FUSED_MAX", o->round_fused_max); num("VP_MULTI_SHIFT", o->persistent_multi_shift);
+    if (getenv("VP_DEBUG")) o->debug |= 1;
+    if (getenv("VP_DEBUG_UPLOAD")) o->debug |= 2;                       // bit 1: phase times of vp_circuit_upload
+    if (o->sf_rounds != 4) o->sf_rounds = 3;
+    o->dot_blocks = std::max(1, o->dot_blocks); o->sf3b_grid = std::max(1, o->sf3b_grid);
+}
+
+int vp_create(int device, vp_ctx **out) { return vp_create_with_options(device, nullptr, out); }
+
+int vp_create_with_options(int device, const vp_options *user, vp_ctx **out) {
     if (!out) return VP_EINVAL;
     *out = nullptr;
     int n = 0;
@@ -595,6 +632,7 @@ int vp_create(int device, vp_ctx **out) {
     if (hipSetDevice(device) != hipSuccess) return VP_ENOGPU;
     vp_ctx *ctx = new vp_ctx();
     ctx->device = device;
+    resolve_options(&ctx->opt, user);
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return VP_EHIP; }
     if (hipHostMalloc((void **) &ctx->h_pin, (4 + VP_MAX_TAB) * sizeof(F), hipHostMallocDefault) != hipSuccess) {
         delete ctx; return VP_EHIP;
@@ -606,11 +644,10 @@ int vp_create(int device, vp_ctx **out) {
     if (hipHostMalloc((void **) &ctx->h_aux, sizeof(TailAux), hipHostMallocDefault) != hipSuccess) { delete ctx; return VP_EHIP; }
     memset(ctx->h_req, 0, sizeof(TailMail)); memset(ctx->h_rep, 0, sizeof(TailReply)); memset(ctx->h_aux, 0, sizeof(TailAux));
     (void) hipFuncSetAttribute(reinterpret_cast<const void *>(k_phase), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 2 * VP_PH_PMAX * (int) sizeof(F));
-    { const char *pl = getenv("VP_POLL"); ctx->poll = (pl && pl[0] == '0') ? 0 : 1; }
-    { const char *pl = getenv("VP_PERSIST"); ctx->tail_enabled = (pl && pl[0] == '0') ? 0 : 1; }
+    ctx->poll = ctx->opt.poll; ctx->tail_enabled = ctx->opt.persistent_rounds;
     // distributed rounds (G workgroups of the resident kernel): measured equal to one launch per round on MI355X (x64 interactive proof
     // 12.6 vs 12.7 ms: profiles/r02_interactive_*), and they need G idle CUs for as long as the verifier takes — opt-in
-    { const char *pl = getenv("VP_PERSIST_MULTI"); ctx->multi_enabled = (pl && pl[0] == '1') ? 1 : 0; }
+    ctx->multi_enabled = ctx->opt.persistent_multi;
     hipEventCreate(&ctx->ev0); hipEventCreate(&ctx->ev1);
     (void) hipFuncSetAttribute(reinterpret_cast<const void *>(k_emit_multi), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
     (void) hipFuncSetAttribute(reinterpret_cast<const void *>(k_emit), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
@@ -677,9 +714,9 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
     }
     ctx->max_bl = max_bl;
     // ---- per-layer uploads: the raw gate arrays go to HBM as they are, every per-gate structure is built there (vpgpu_upload.inc) ----
-    { const char *fi = getenv("VP_INIT3"); ctx->use_init3 = (fi && fi[0] == '1') ? 1 : 0; }
+    ctx->use_init3 = ctx->opt.init3;
     UpScratch S;
-    const bool up_dbg = getenv("VP_DEBUG_UPLOAD") != nullptr;
+    const bool up_dbg = (ctx->opt.debug & 2) != 0;
     const auto up_t0 = std::chrono::steady_clock::now();
     auto up_since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - up_t0).count(); };
     u64 *d_sizes = nullptr;
@@ -833,15 +870,10 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
                 ln.Vu = vus + i;
             }
         }
-        const char *ser = getenv("VP_GKR_SERIAL");
-        ctx->serial = (ser && ser[0] == '1') ? 1 : 0;
-        const char *gr = getenv("VP_GKR_GRAPH");
-        ctx->use_graph = (gr && gr[0] == '0') ? 0 : 1;
-        const char *pth = getenv("VP_GKR_PATH");
-        ctx->simple_path = (pth && !strcmp(pth, "simple")) ? 1 : 0;
-        ctx->sumfold_path = (pth && !strcmp(pth, "sumfold")) ? 1 : 0;
-        ctx->plan_path = (pth && !strcmp(pth, "lanes")) ? 0 : 1;
-        { const char *fi = getenv("VP_FUSE_INIT"); ctx->fuse_init = (fi && fi[0] == '0') ? 0 : 1; }
+        ctx->serial = ctx->opt.serial; ctx->use_graph = ctx->opt.use_graph;
+        ctx->simple_path = ctx->opt.gkr_path == VP_PATH_SIMPLE; ctx->sumfold_path = ctx->opt.gkr_path == VP_PATH_SUMFOLD;
+        ctx->plan_path = ctx->opt.gkr_path == VP_PATH_LANES ? 0 : 1;
+        ctx->fuse_init = ctx->opt.fuse_init;
     }
     if (up_dbg) fprintf(stderr, "  total %.3f s\n", up_since());
     // event pool for the profiled launches
@@ -875,7 +907,7 @@ int vp_evaluate(vp_ctx *ctx, const vp_F *inputs, uint64_t n_inputs) {
     HIPCHK(hipMemcpyAsync(&flag, ctx->d_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(&vcplx, ctx->d_vcplx, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
     VPCHK(check_stream(ctx));
-    { const char *rv = getenv("VP_REAL_V"); ctx->vreal = (vcplx == 0 && !(rv && rv[0] == '0')) ? 1 : 0; }
+    ctx->vreal = (vcplx == 0 && ctx->opt.real_values) ? 1 : 0;
     float ms = 0;
     hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
     ctx->st.evaluate_ms = ms;

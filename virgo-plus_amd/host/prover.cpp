@@ -24,8 +24,8 @@ void prover::check(int rc, const char *what) {
 // src/prover.cpp:14-25.  The circuit tables are flattened to structure-of-arrays and copied to HBM once;
 // the constructor then evaluates the circuit on the device like the reference's constructor does on the
 // CPU.  A violated assert gate surfaces as an exception instead of the reference's exit(EXIT_FAILURE).
-prover::prover(const layeredCircuit &cir, int device) : C(cir) {
-    int rc = vp_create(device, &ctx);
+prover::prover(const layeredCircuit &cir, int device, const vp_options *options) : C(cir) {
+    int rc = vp_create_with_options(device, options, &ctx);
     if (rc != VP_OK) throw std::runtime_error("vp_create failed (" + std::to_string(rc) + "): no usable MI355X / HIP device");
     const int n = C.size;
     const bool dbg = getenv("VP_DEBUG_UPLOAD") != nullptr;

@@ -25,7 +25,7 @@ private:
 
 class prover {
 public:
-    explicit prover(const layeredCircuit &cir, int device = 0);
+    explicit prover(const layeredCircuit &cir, int device = 0, const vp_options *options = nullptr);   // options: include/vpgpu.h (NULL = shipped defaults)
     ~prover();
     prover(const prover &) = delete;
     prover &operator=(const prover &) = delete;

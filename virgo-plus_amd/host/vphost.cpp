@@ -76,12 +76,13 @@ uint64_t vph_circuit_layer_size(const vph_circuit *c, int layer) { return c->c.c
 int vph_circuit_layer_bitlen(const vph_circuit *c, int layer) { return c->c.circuit[layer].bitLength; }
 void vph_circuit_hash(const vph_circuit *c, uint64_t out[2]) { u64 h[2]; c->c.structuralHash(h); out[0] = h[0]; out[1] = h[1]; }
 
-vph_session *vph_session_create(vph_circuit *c, int device, char *err, int errlen) {
+vph_session *vph_session_create(vph_circuit *c, int device, char *err, int errlen) { return vph_session_create_opts(c, device, nullptr, err, errlen); }
+vph_session *vph_session_create_opts(vph_circuit *c, int device, const vp_options *opt, char *err, int errlen) {
     if (!c) { set_err(err, errlen, "null circuit"); return nullptr; }
     try {
         std::unique_ptr<vph_session> s(new vph_session());
         s->circ = c;
-        s->p.reset(new prover(c->c, device));
+        s->p.reset(new prover(c->c, device, opt));
         return s.release();
     } catch (const std::exception &e) {
         set_err(err, errlen, e.what());

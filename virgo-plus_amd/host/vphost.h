@@ -4,6 +4,7 @@
 #ifndef VPHOST_H
 #define VPHOST_H
 #include <stdint.h>
+#include "../../include/vpgpu.h"
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -41,6 +42,7 @@ void vph_circuit_hash(const vph_circuit *, uint64_t out[2]);
 
 /* Uploads the circuit to `device` and evaluates it there.  NULL + message on failure (no CPU fallback). */
 vph_session *vph_session_create(vph_circuit *, int device, char *err, int errlen);
+vph_session *vph_session_create_opts(vph_circuit *, int device, const vp_options *opt /* include/vpgpu.h, NULL = defaults */, char *err, int errlen);
 void vph_session_free(vph_session *);
 int vph_set_profiling(vph_session *, int level);
 /* the vp_ctx behind the session's prover (for the measurement calls of include/vpgpu.h: vp_get_launch_stats, ...) */
