@@ -11,6 +11,7 @@ from conftest import GOLDEN as GOLDEN_DIR
 
 pytestmark = pytest.mark.gpu
 P = (1 << 61) - 1
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -948,6 +949,21 @@ def test_options_struct_selects_the_same_alternatives_as_the_test_environment(vp
     tr_i, _, ok = s.prove_interactive()
     assert ok and tr_i == gold
     s.close(); c.close()
+
+
+def test_reference_binary_drives_the_device_prover(pws_path):
+    """oracle/_ref/ref_run_vpgpu = the reference's own main() + verifier + circuit code + lib/virgo, unmodified, linked with
+    INTEGRATION.md's forwarding prover and libvpgpu.so (tests/test_integration_link.py builds it where the reference tree exists).
+    On SHA256_64.pws every sumcheck message of the run comes from the device through vp_round / vp_finalize, the reference verifier
+    accepts it and goes on to its own commitment check."""
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_run_vpgpu")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_run_vpgpu not built (needs the reference tree at build time)")
+    r = subprocess.run([exe, str(pws_path)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Verification pass" in r.stderr and "Verification fail" not in r.stderr
+    assert "Prove Time" in r.stdout
 
 
 def test_violated_assert_gate_is_reported(vp):
