@@ -8,6 +8,26 @@ the circuit, the witness and the verifier tape already resident in HBM.  Each ra
 independent proofs per step with no data-path collective ("scaling": "weak").  Rank 0's transcript is
 compared byte for byte with the real reference's golden transcript on every run.
 
+The ONE JSON line (rank 0):
+  metric / value / unit / ms_per_step ...   the contract fields; value = field-ops of all ranks' proofs / max-over-ranks time
+  roofline            the kernel with the largest share of the proof's summed launch time: algorithmic bytes per launch / mean launch
+                      duration, both measured live (every launch of the plan bracketed with HIP events on its own stream in a
+                      single-stream replay, vp_set_profiling / vp_get_launch_stats), against 8 TB/s; `traffic` from the committed
+                      rocprofv3 PMC summary of this command (profiles/r02_pmc_summary_b*.json); `measured_limiter` says what the
+                      counters show (VALU issue, not bytes)
+  kernels             the same table for every kernel kind of the proof (launches, us, share, algorithmic MB, GB/s, frac)
+  interactive_path    the drop-in entry points (one vp_round per verifier message): prover seconds by the reference's definition,
+                      split into init / round / finalize calls
+  circuit_upload_sec  host flatten + vp_circuit_upload (index structures built on the device) + vp_evaluate
+  verifier            the host verifier's O(|C|) loops on the host and on the device
+  cpu_baseline        the real reference (oracle/_ref/ref_run) on one host core, one full proof of the same circuit
+  x1024_with_pc       N = 1 default run only: BASELINE configs[2], the largest single-GPU configuration, as a nested leg with the
+                      same fields (transcript against the oracle fixture, roofline of ITS dominant kernel, per-launch table,
+                      cpu_baseline = the oracle port) plus `polynomial_commitment`: the complete protocol (commit_private,
+                      commit_public, FRI commit phase and queries, unbroken verifyFull with the reference's challenge schedule),
+                      per-kernel table and rooflines of k_leaf_hash (Keccak-f/s against the VALU issue bound of its instruction
+                      mix) and the NTT family (F-multiplications/s against the chip's F-multiply issue rate)
+
     python bench.py [--gpus N] [--steps K] [--warmup W] [--blocks B] [--no-cpu-baseline]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
@@ -84,8 +104,10 @@ def roofline_of(rows, blocks, serial_ms, note=None):
     traffic, src = pmc_traffic(blocks, d["kernel"])
     limiter = None
     if "sumfold" in d["kernel"] or "light" in d["kernel"]:
-        limiter = ("VALU issue: SQ_ACTIVE_INST_VALU is 76-87 % of the launch's SIMD cycles (profiles/r01_l_sq_counters_b1024.json); the bytes moved equal the "
-                   "algorithmic bytes, the integer multiply-add of F_p^2 (16 v_mad_u64_u32 + folds) sets the time")
+        limiter = ("VALU issue: SQ_INSTS_VALU per launch / 1024 SIMDs / launch cycles = one wave-instruction per 5.9-6.5 cycles per SIMD "
+                   "(profiles/r02_pmc_summary_b64.json, r02_pmc_summary_b1024.json) where this instruction mix issues at 4.3-5 cycles when nothing "
+                   "stalls (tools/micro_rates.hip: v_mad_u64_u32 7.0, 64-bit add 5.2, 32-bit ops 2.8-3.2): 75-85 % of the issue slots; the bytes "
+                   "moved equal the algorithmic bytes, the integer multiply-add of F_p^2 (16 v_mad_u64_u32 + Mersenne folds) sets the time")
     return {"bound": "hbm", "achieved": d["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": d["hbm_frac"], "traffic": traffic,
             "traffic_source": ("%s (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, per launch)" % src) if traffic else None,
             "kernel": d["kernel"], "kernel_time_share": d["time_share"], "launches": d["launches"], "avg_launch_us": d["avg_launch_us"],

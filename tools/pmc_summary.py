@@ -36,12 +36,25 @@ def kernel_stats_csv(db_path, out_csv):
     """`rocprofv3 --kernel-trace --stats` summary from the rocpd database (view top_kernels), in the layout of *_kernel_stats.csv."""
     import sqlite3
     db = sqlite3.connect(db_path)
-    rows = list(db.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels group by name order by sum(duration) desc"))
+    raw = list(db.execute("select name, duration from kernels"))
+    agg = collections.OrderedDict()
+    for n, d in raw:                                   # library kernels (rocPRIM sorts of the circuit upload) under a short name, arguments dropped
+        k = stats_name(n)
+        a = agg.setdefault(k, [0, 0, None, 0])
+        a[0] += 1; a[1] += d; a[2] = d if a[2] is None else min(a[2], d); a[3] = max(a[3], d)
+    rows = sorted(((k, a[0], a[1], a[1] / a[0], a[2], a[3]) for k, a in agg.items()), key=lambda r: -r[2])
     tot = sum(r[2] for r in rows) or 1
     with open(out_csv, "w") as f:
         f.write('"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs"\n')
         for n, c, t, a, mn, mx in rows:
             f.write('"%s",%d,%d,%.1f,%.2f,%d,%d\n' % (n, c, t, a, 100.0 * t / tot, mn, mx))
+
+
+def stats_name(n):
+    if "rocprim" in n:
+        m = re.search(r"wrapped_(\w+?)_config", n) or re.search(r"detail::(\w+?)(_kernel|<)", n)
+        return "rocprim::" + (m.group(1) if m else "kernel")
+    return n.split("(")[0]
 
 
 def short(n):
