@@ -13,5 +13,7 @@ import json, sys
 t = sys.argv[1]
 for k in ("a1", "b1", "a2", "b2"):
     d = json.loads(open("gpurun_out/%s_%s.json" % (t, k)).read().strip().splitlines()[-1])
-    print(k, "ms_per_step %.4f device %.4f single-stream %.4f exact %s" % (d["ms_per_step"], d["prover_sec_device"] * 1e3, d["roofline"]["single_stream_proof_ms"], d.get("bit_exact_vs_reference_golden", d.get("bit_exact_vs_oracle_fixture"))))
+    pc = d.get("polynomial_commitment") or {}
+    extra = (" pc_commit_side %.2f ms roots_exact %s" % (pc["pc_commit_side_device_ms"], pc.get("fri_roots_bit_exact"))) if "pc_commit_side_device_ms" in pc else ""
+    print(k, "ms_per_step %.4f device %.4f single-stream %.4f exact %s%s" % (d["ms_per_step"], d["prover_sec_device"] * 1e3, d["roofline"]["single_stream_proof_ms"], d.get("bit_exact_vs_reference_golden", d.get("bit_exact_vs_oracle_fixture")), extra))
 PY

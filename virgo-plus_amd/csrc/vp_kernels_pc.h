@@ -475,7 +475,7 @@ __global__ void __launch_bounds__(VP_BLOCK) k_ntt_split(SplitArgs a) {
 // in: [rows][N1][N2] (k1-major), out: [rows][N] natural (k = k1 + N1*k2); tile of 64 k2 x N1 k1 through LDS
 __global__ void __launch_bounds__(VP_BLOCK)
 k_ntt_unsplit(const F *__restrict__ in, F *__restrict__ out, int ln, int l1, F scale, int do_scale) {
-    __shared__ F tile[16][65];
+    __shared__ F tile[32][65];
     const u32 N = 1u << ln, N1 = 1u << l1, N2 = N >> l1;
     const u32 row = blockIdx.y, k2_0 = blockIdx.x * 64;
     const F *src = in + (size_t) row * N;
