@@ -96,6 +96,8 @@ typedef struct {
     int32_t persistent_multi_shift; /* VP_MULTI_SHIFT: log2 entries per workgroup there                                          [13] */
     int32_t poll;                   /* VP_POLL: spin on the pinned reply instead of hipStreamSynchronize (interactive path)      [1] */
     int32_t debug;                  /* bit 0 (VP_DEBUG): diagnostics on stderr; bit 1 (VP_DEBUG_UPLOAD): phase times of vp_circuit_upload [0] */
+    int32_t prefetch_round1;        /* VP_PREFETCH_R1: an init call queues round 1 of its sumcheck (it takes no challenge) behind its own kernels
+                                       and returns without waiting; the first vp_round of the phase collects the answer          [1] */
 } vp_options;
 void vp_options_default(vp_options *opt);
 

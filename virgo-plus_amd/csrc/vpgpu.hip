@@ -128,6 +128,8 @@ struct vp_ctx {
     MultiSync *d_msync = nullptr; int multi_enabled = 0;      // VP_PERSIST=0: one launch per round; VP_PERSIST_MULTI=0: no distributed rounds
     int poll = 1;                                     // VP_POLL=0: wait with hipStreamSynchronize instead
     F *h_io = nullptr; size_t h_io_cap = 0;   // pinned staging of the batched path: tape in, transcript out
+    int r1_pending = 0;                // interactive path: round 1 of the phase was queued behind its init (1: in the resident kernel, 2: per-round launch)
+    F *h_stage = nullptr; u32 stage_at = 0;         // pinned ring the challenges are staged through (an init call no longer waits for its copies)
     vp_options opt{};                  // resolved at vp_create: defaults <- caller's struct <- VP_* environment (test-only override)
     int *d_flag = nullptr;
     u32 *d_vcplx = nullptr;            // non-zero: some circuit value of the last vp_evaluate has an imaginary part
@@ -595,7 +597,7 @@ void vp_options_default(vp_options *o) {
     o->gkr_path = VP_PATH_PLAN; o->use_graph = 1; o->serial = 0; o->fuse_init = 1; o->fuse_min_log = 23; o->fuse_dot = 0; o->init3 = 0;
     o->drop_y = 1; o->drop_y_round1 = 0; o->real_values = 1; o->seg_tiny = 1; o->sf_rounds = 3; o->sf_big_log = 14; o->sf3b = 1;
     o->sf3b_grid = 512; o->sf_min_waves = 1; o->dot_blocks = 1024; o->plan_align = 0; o->xcd_map = 0; o->round_fused_max = 512;
-    o->persistent_rounds = 1; o->persistent_multi = 0; o->persistent_multi_shift = 13; o->poll = 1; o->debug = 0;
+    o->persistent_rounds = 1; o->persistent_multi = 0; o->persistent_multi_shift = 13; o->poll = 1; o->debug = 0; o->prefetch_round1 = 1;
 }
 // defaults <- the caller's struct (as many bytes as its header knew) <- VP_* environment variables (test-only override, read here and nowhere else)
 static void resolve_options(vp_options *o, const vp_options *user) {
@@ -612,7 +614,7 @@ static void resolve_options(vp_options *o, const vp_options *user) {
     flag("VP_GKR_GRAPH", o->use_graph); flag("VP_GKR_SERIAL", o->serial); flag("VP_FUSE_INIT", o->fuse_init); flag("VP_FUSE_DOT", o->fuse_dot);
     flag("VP_INIT3", o->init3); flag("VP_DROP_Y", o->drop_y); flag("VP_DROP_Y1", o->drop_y_round1); flag("VP_REAL_V", o->real_values);
     flag("VP_SEG_TINY", o->seg_tiny); flag("VP_XCD_MAP", o->xcd_map); flag("VP_PERSIST", o->persistent_rounds);
-    flag("VP_PERSIST_MULTI", o->persistent_multi); flag("VP_POLL", o->poll);
+    flag("VP_PERSIST_MULTI", o->persistent_multi); flag("VP_POLL", o->poll); flag("VP_PREFETCH_R1", o->prefetch_round1);
     num("VP_FUSE_MIN_LOG", o->fuse_min_log); num("VP_SF_ROUNDS", o->sf_rounds); num("VP_SF_BIG_LOG", o->sf_big_log); num("VP_SF3B", o->sf3b);
     num("VP_SF3B_GRID", o->sf3b_grid); num("VP_SF_MINW", o->sf_min_waves); num("VP_DOT_BLOCKS", o->dot_blocks);
     num("VP_ROUND_FUSED_MAX", o->round_fused_max); num("VP_MULTI_SHIFT", o->persistent_multi_shift);
@@ -642,6 +644,7 @@ int vp_create_with_options(int device, const vp_options *user, vp_ctx **out) {
     if (hipHostMalloc((void **) &ctx->h_req, sizeof(TailMail), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void **) &ctx->h_rep, sizeof(TailReply), hipHostMallocDefault) != hipSuccess) { delete ctx; return VP_EHIP; }
     if (hipHostMalloc((void **) &ctx->h_aux, sizeof(TailAux), hipHostMallocDefault) != hipSuccess) { delete ctx; return VP_EHIP; }
+    if (hipHostMalloc((void **) &ctx->h_stage, 4096 * sizeof(F), hipHostMallocDefault) != hipSuccess) { delete ctx; return VP_EHIP; }
     memset(ctx->h_req, 0, sizeof(TailMail)); memset(ctx->h_rep, 0, sizeof(TailReply)); memset(ctx->h_aux, 0, sizeof(TailAux));
     (void) hipFuncSetAttribute(reinterpret_cast<const void *>(k_phase), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 2 * VP_PH_PMAX * (int) sizeof(F));
     ctx->poll = ctx->opt.poll; ctx->tail_enabled = ctx->opt.persistent_rounds;
@@ -678,6 +681,7 @@ void vp_destroy(vp_ctx *ctx) {
     if (ctx->h_req) (void) hipHostFree(ctx->h_req);
     if (ctx->h_rep) (void) hipHostFree(ctx->h_rep);
     if (ctx->h_aux) (void) hipHostFree(ctx->h_aux);
+    if (ctx->h_stage) (void) hipHostFree(ctx->h_stage);
     if (ctx->h_io) (void) hipHostFree(ctx->h_io);
     for (auto st : ctx->lane_streams) (void) hipStreamDestroy(st);
     for (auto ev : ctx->lane_events) (void) hipEventDestroy(ev);
@@ -928,7 +932,24 @@ int vp_layer_values(vp_ctx *ctx, int layer, vp_F *out, uint64_t n) {
 static int stage(vp_ctx *ctx, u64 off, const vp_F *src, u64 n) {
     if (!n) return VP_OK;
     if (!src || off + n > ctx->n_tape) return VP_EINVAL;
-    HIPCHK(hipMemcpyAsync(ctx->d_tape + off, src, n * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
+    // through a pinned ring (4096 elements; a phase stages < 150): the caller's array need not outlive the call and the copy is truly asynchronous
+    if (n > 1024) { HIPCHK(hipMemcpy(ctx->d_tape + off, src, n * sizeof(F), hipMemcpyHostToDevice)); return VP_OK; }
+    if (ctx->stage_at + n > 4096) ctx->stage_at = 0;
+    F *slot = ctx->h_stage + ctx->stage_at;
+    memcpy(slot, src, n * sizeof(F));
+    ctx->stage_at += (u32) n;
+    HIPCHK(hipMemcpyAsync(ctx->d_tape + off, slot, n * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
+    return VP_OK;
+}
+// Round 1 of a sumcheck needs no challenge: it is queued right behind the init kernels, and the init call returns without waiting.
+// vp_round's first call of the phase then only waits for the answer (one synchronisation per phase start instead of two).
+static int round1_prefetch(vp_ctx *ctx) {
+    ctx->r1_pending = 0;
+    if (!ctx->opt.prefetch_round1 || ctx->sc.total_rounds < 1 || ctx->profiling) return check_stream(ctx);
+    const F zero = f_zero();
+    if (tail_try_launch(ctx, zero)) { ctx->r1_pending = 1; return VP_OK; }
+    VPCHK(do_round(ctx, nullptr, zero, ctx->d_tr + ctx->n_tr, ctx->h_pin));
+    ctx->r1_pending = 2;
     return VP_OK;
 }
 
@@ -1023,7 +1044,10 @@ int vp_layer_mle(vp_ctx *ctx, int layer, const vp_F *r, int n, vp_F *out) {
 
 int vp_liu_gr(vp_ctx *ctx, int layer, const vp_F *r_u, const vp_F *const *r_v, const vp_F *s, const vp_F *r_liu, vp_F *out) {
     if (!ctx || !out) return VP_EINVAL;
+    const int keep = ctx->opt.prefetch_round1;
+    ctx->opt.prefetch_round1 = 0;                                    // only the table is wanted here: no round is coming
     const int rc = vp_liu_init(ctx, layer, r_u, r_v, s);            // the Liu mult table of this layer, as the prover builds it
+    ctx->opt.prefetch_round1 = keep;
     if (rc != VP_OK) return rc;
     ctx->sc.phase = 0;                                               // not a sumcheck in progress
     LayerDev &pre = ctx->L[layer - 1];
@@ -1052,7 +1076,7 @@ int vp_phase1_init(vp_ctx *ctx, int layer, const vp_F *r_liu, const vp_F *assert
     VPCHK(stage(ctx, off, r_liu, ctx->L[layer].bl));
     VPCHK(stage(ctx, ctx->as_off[layer], assert_random, 1));
     VPCHK(do_phase1_init(ctx, layer, ctx->d_tape + off, ctx->d_tape + ctx->as_off[layer]));
-    return check_stream(ctx);
+    return round1_prefetch(ctx);
 }
 
 int vp_phase2_init(vp_ctx *ctx, int layer, const vp_F *r_u) {
@@ -1062,7 +1086,7 @@ int vp_phase2_init(vp_ctx *ctx, int layer, const vp_F *r_u) {
     VP_ENTER(ctx);
     VPCHK(stage(ctx, ctx->ru_off[layer], r_u, ctx->L[layer - 1].bl));
     VPCHK(do_phase2_init(ctx, layer, ctx->d_tape + ctx->ru_off[layer]));
-    return check_stream(ctx);
+    return round1_prefetch(ctx);
 }
 
 int vp_liu_init(vp_ctx *ctx, int layer, const vp_F *r_u, const vp_F *const *r_v, const vp_F *s) {
@@ -1078,14 +1102,27 @@ int vp_liu_init(vp_ctx *ctx, int layer, const vp_F *r_u, const vp_F *const *r_v,
             VPCHK(stage(ctx, ctx->rv_off[k], r_v[k], ctx->L[k].dad_bl[layer - 1]));
         }
     VPCHK(do_liu_init(ctx, layer));
-    return check_stream(ctx);
+    return round1_prefetch(ctx);
 }
 
 int vp_round(vp_ctx *ctx, const vp_F *previous_random, vp_F out_poly[3]) {
     if (!ctx || !previous_random || !out_poly || ctx->sc.phase == 0) return VP_EINVAL;
-    if (ctx->sc.round >= ctx->sc.total_rounds) { ctx->err = "too many rounds"; return VP_EINVAL; }
     HIPCHK(hipSetDevice(ctx->device));
     F rv; memcpy(&rv, previous_random, sizeof(F));
+    if (!ctx->r1_pending && ctx->sc.round >= ctx->sc.total_rounds) { ctx->err = "too many rounds"; return VP_EINVAL; }
+    if (ctx->r1_pending) {                                    // round 1 was queued by the init call (it takes no challenge): collect it
+        const int how = ctx->r1_pending;
+        ctx->r1_pending = 0;
+        if (how == 1) {
+            VPCHK(tail_wait(ctx, ctx->tail_seq));
+            tail_poly(ctx, out_poly);
+            ++ctx->sc.round; ++ctx->st.rounds;
+        } else {
+            VPCHK(wait_ticket(ctx));
+            memcpy(out_poly, ctx->h_pin, 3 * sizeof(F));
+        }
+        return VP_OK;
+    }
     // small rounds: one resident kernel answers every remaining message of the phase through a mailbox (vp_kernels_persist.h)
     if (ctx->tail_active) {
         VPCHK(tail_send(ctx, 1, rv));
