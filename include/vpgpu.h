@@ -122,7 +122,18 @@ int vp_layer_values(vp_ctx *, int layer, vp_F *out, uint64_t n);
 /* prover::Vres(r_0, r_0_size) (src/prover.cpp:99-129): MLE of the output layer at r_0.                 */
 int vp_vres(vp_ctx *, const vp_F *r_0, int r_0_size, vp_F *out);
 
-/* prover::sumcheckInitPhase1(assert_random) for layer `layer` (src/prover.cpp:189-280).  r_liu is the
+/* ---- the drop-in (interactive) path: one call per prover method, one vp_round per verifier message -------------------
+ * How it is served (vp_kernels_persist.h), none of which changes the call sequence or the values:
+ *   * an init call returns as soon as its kernels are queued, together with round 1 of the sumcheck (which takes no challenge:
+ *     `prefetch_round1`); the arrays passed in are copied before the call returns.  A failure of that queued work is reported by the
+ *     first vp_round of the phase;
+ *   * once every live table of the phase fits one CU's LDS, ONE resident kernel answers all remaining messages of the phase
+ *     through a mailbox in pinned host memory (`persistent_rounds`): vp_round then costs a 3 us round trip plus the arithmetic
+ *     instead of a kernel launch.  vp_finalize ends it.  Any other entry point called in the middle of a sumcheck first tells
+ *     the resident kernel to leave (the sumcheck is abandoned, the context stays usable); left alone it leaves by itself 10 s
+ *     after the last message, and the next vp_round / vp_finalize then returns VP_EHIP.  While it is resident, device-wide
+ *     synchronising HIP calls of other contexts of the process (hipFree, hipMalloc) wait for it.
+ * prover::sumcheckInitPhase1(assert_random) for layer `layer` (src/prover.cpp:189-280).  r_liu is the
  * point the layer's claim is at (bit_length(layer) entries; prover::r_liu in the reference).           */
 int vp_phase1_init(vp_ctx *, int layer, const vp_F *r_liu, const vp_F *assert_random);
 /* prover::sumcheckInitPhase2() (src/prover.cpp:282-367).  r_u = the bit_length(layer-1) challenges of
