@@ -119,20 +119,17 @@ template <int N> __device__ __forceinline__ void rot(u32 lo, u32 hi, u32 &olo, u
 }
 __device__ __forceinline__ u32 chi32(u32 a, u32 b, u32 c) { return a ^ (~b & c); }            // one v_bitop3_b32
 __device__ __forceinline__ u32 xor3(u32 a, u32 b, u32 c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }   // a ^ b ^ c in one instruction
-__device__ __forceinline__ void keccak_f1600(u64 (&A)[25]) {
-    const u64 RC[24] = {
-        0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808aull, 0x8000000080008000ull, 0x000000000000808bull,
-        0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull, 0x000000000000008aull, 0x0000000000000088ull,
-        0x0000000080008009ull, 0x000000008000000aull, 0x000000008000808bull, 0x800000000000008bull, 0x8000000000008089ull,
-        0x8000000000008003ull, 0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800aull, 0x800000008000000aull,
-        0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
-    u32 al[25], ah[25];
+__device__ __constant__ const u64 KECCAK_RC[24] = {
+    0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808aull, 0x8000000080008000ull, 0x000000000000808bull,
+    0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull, 0x000000000000008aull, 0x0000000000000088ull,
+    0x0000000080008009ull, 0x000000008000000aull, 0x000000008000808bull, 0x800000000000008bull, 0x8000000000008089ull,
+    0x8000000000008003ull, 0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800aull, 0x800000008000000aull,
+    0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
+// four rounds on the 2 x 25 halves, rnd0 .. rnd0 + 3
+__device__ __forceinline__ void keccak_rounds4(u32 (&al)[25], u32 (&ah)[25], int rnd0) {
+    const u64 *RC = KECCAK_RC;
 #pragma unroll
-    for (int i = 0; i < 25; ++i) { al[i] = (u32) A[i]; ah[i] = (u32) (A[i] >> 32); }
-#pragma unroll 1
-    for (int rnd0 = 0; rnd0 < 24; rnd0 += VP_KECCAK_UNROLL)
-#pragma unroll
-    for (int rnd = rnd0; rnd < rnd0 + VP_KECCAK_UNROLL; ++rnd) {
+    for (int rnd = rnd0; rnd < rnd0 + 4; ++rnd) {
         // theta
         u32 cl[5], ch[5], rl[5], rh[5];
 #pragma unroll
@@ -185,6 +182,26 @@ __device__ __forceinline__ void keccak_f1600(u64 (&A)[25]) {
         }
         al[0] ^= (u32) RC[rnd]; ah[0] ^= (u32) (RC[rnd] >> 32);
     }
+}
+// The first and the last group of four rounds are peeled out of the loop: in the first one the compiler folds the thirteen lanes of
+// the padded 64-byte message that are constants (hhash64), in the last one it drops everything that does not reach the four output
+// lanes of SHA3-256 (most of round 24's rho / pi / chi).  VP_KECCAK_PEEL=0: all 24 rounds in the rolled loop (A/B).
+#ifndef VP_KECCAK_PEEL
+#define VP_KECCAK_PEEL 1
+#endif
+__device__ __forceinline__ void keccak_f1600(u64 (&A)[25]) {
+    u32 al[25], ah[25];
+#pragma unroll
+    for (int i = 0; i < 25; ++i) { al[i] = (u32) A[i]; ah[i] = (u32) (A[i] >> 32); }
+#if VP_KECCAK_PEEL
+    keccak_rounds4(al, ah, 0);
+#pragma unroll 1
+    for (int rnd0 = 4; rnd0 < 20; rnd0 += 4) keccak_rounds4(al, ah, rnd0);
+    keccak_rounds4(al, ah, 20);
+#else
+#pragma unroll 1
+    for (int rnd0 = 0; rnd0 < 24; rnd0 += 4) keccak_rounds4(al, ah, rnd0);
+#endif
 #pragma unroll
     for (int i = 0; i < 25; ++i) A[i] = ((u64) ah[i] << 32) | al[i];
 }
