@@ -966,6 +966,38 @@ def test_reference_binary_drives_the_device_prover(pws_path):
     assert "Prove Time" in r.stdout
 
 
+def test_many_small_circuits_interactive_and_batched_vs_oracle(vp, ob):
+    """A sweep over 150 random circuits of odd shapes (2-9 layers, 1-300 gates per layer, every gate type, assert gates, complex
+    constants; and `randomize` circuits with layer sizes 2^0..2^7): the drop-in path (resident round kernel, round 1 queued at init)
+    and the batched plan must both reproduce the oracle's transcript — single-entry tables, zero- and one-round phases, tables that
+    retire in the middle of a resident phase, empty subsets."""
+    import custom_circuits as cc
+    rng = np.random.default_rng(2024)
+    n_bad = 0
+    for it in range(150):
+        if it % 3 == 2:
+            layers, lg = int(rng.integers(2, 8)), int(rng.integers(0, 8))
+            c = vp.Circuit.randomize(layers, lg, seed=100 + it); oc = ob.Circuit.randomize(layers, lg, seed=100 + it)
+            what = "randomize(%d, %d, seed %d)" % (layers, lg, 100 + it)
+        else:
+            sizes = [int(x) for x in rng.integers(1, 300 if it % 2 else 12, size=int(rng.integers(2, 10)))]
+            args = cc.make(1000 + it, sizes)
+            c = vp.Circuit.custom(*args); oc = ob.Circuit.custom(*args)
+            what = "custom(seed %d, %s)" % (1000 + it, sizes)
+        assert c.hash() == oc.hash(), what
+        gold, st = oc.prove_gkr()
+        assert st["verified"] == 1, what
+        s = vp.Session(c)
+        tr, _, ok = s.prove_interactive()
+        s.draw_tape()
+        tr2, _ = s.prove_gkr()
+        if not (ok and tr == gold and tr2 == gold):
+            n_bad += 1
+            print("MISMATCH:", what, "interactive ok/equal", ok, tr == gold, "batched equal", tr2 == gold)
+        s.close(); c.close(); oc.close()
+    assert n_bad == 0
+
+
 def test_violated_assert_gate_is_reported(vp):
     """The reference exits the process when an assert gate is non-zero (src/prover.cpp:18-21); the library returns
     VP_EASSERT through the host constructor instead."""
