@@ -75,7 +75,7 @@ typedef struct {
     int32_t use_graph;              /* VP_GKR_GRAPH: replay the plan as a hipGraph                                               [1] */
     int32_t serial;                 /* VP_GKR_SERIAL: all chains on one stream (profiling)                                       [0] */
     int32_t fuse_init;              /* VP_FUSE_INIT: phase-1 / Liu init inside the first fold launch of large tables             [1] */
-    int32_t fuse_min_log;           /* VP_FUSE_MIN_LOG: ... from 2^this entries on                                               [23] */
+    int32_t fuse_min_log;           /* VP_FUSE_MIN_LOG: ... from 2^this entries on; 0 = clamp(largest layer's bit length - 1, 20, 22)    [0] */
     int32_t fuse_dot;               /* VP_FUSE_DOT: V_u rides on the fused launch                                                [0] */
     int32_t init3;                  /* VP_INIT3: entry-parallel init kernels (measured slower)                                   [0] */
     int32_t drop_y;                 /* VP_DROP_Y: rounds >= 2 derive b from the previous claim (five products per pair)          [1] */
