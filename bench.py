@@ -108,7 +108,19 @@ def roofline_of(rows, blocks, serial_ms, note=None):
                    "(profiles/r02_pmc_summary_b64.json, r02_pmc_summary_b1024.json) where this instruction mix issues at 4.3-5 cycles when nothing "
                    "stalls (tools/micro_rates.hip: v_mad_u64_u32 7.0, 64-bit add 5.2, 32-bit ops 2.8-3.2): 75-85 % of the issue slots; the bytes "
                    "moved equal the algorithmic bytes, the integer multiply-add of F_p^2 (16 v_mad_u64_u32 + Mersenne folds) sets the time")
+    accounting = None
+    if "sumfold" in d["kernel"] and d["work_units"]:
+        # The byte figure above is the strict one: a launch reads its tables once and writes the folded tables once, whatever the number of
+        # rounds it fuses (and the init-generating variant never writes or reads the mult/add tables at full length at all).  SURVEY.md
+        # §8d's per-unit figure is per ROUND: 48 B x (entries in + entries out) = 144 B per pair step with three table families (96 B in the
+        # Liu phase, which has no add table: counted as 144 here, so this is an upper figure).  Same launches, same time:
+        survey_bytes = 144.0 * d["work_units"]
+        survey_gbps = survey_bytes / (d["total_us"] * 1e-6) / 1e9
+        accounting = {"note": "informative only, NOT `frac`: the same kernel time priced with SURVEY.md 8d's per-round byte formula (every round reads and "
+                              "writes its tables) instead of the bytes the fused launch has to move",
+                      "pair_steps": d["work_units"], "bytes_per_pair_step": 144, "GBps": round(survey_gbps, 1), "frac_of_hbm_peak": round(survey_gbps / HBM_PEAK_GBPS, 4)}
     return {"bound": "hbm", "achieved": d["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": d["hbm_frac"], "traffic": traffic,
+            "per_round_accounting_survey_8d": accounting,
             "traffic_source": ("%s (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, per launch)" % src) if traffic else None,
             "kernel": d["kernel"], "kernel_time_share": d["time_share"], "launches": d["launches"], "avg_launch_us": d["avg_launch_us"],
             "algorithmic_bytes_per_launch": d["algorithmic_MB_per_launch"] * 1e6, "single_stream_proof_ms": serial_ms,
