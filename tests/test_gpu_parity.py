@@ -948,6 +948,14 @@ def test_options_struct_selects_the_same_alternatives_as_the_test_environment(vp
     s = vp.Session(c, options=vp.Options(persistent_rounds=0))
     tr_i, _, ok = s.prove_interactive()
     assert ok and tr_i == gold
+    s.close()
+    # a caller built against an older header passes a shorter struct: the fields it does not know keep the library's defaults
+    old = vp.Options(gkr_path=vp.PATH_SIMPLE, sf_rounds=4)
+    old.struct_size = 8                                   # struct_size + gkr_path only
+    s = vp.Session(c, options=old)
+    s.draw_tape()
+    tr, res = s.prove_gkr()
+    assert tr == gold and res["launches"] == launches["simple"]
     s.close(); c.close()
 
 
