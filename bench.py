@@ -401,6 +401,8 @@ def main():
     ap.add_argument("--shard-sim", type=int, default=0, metavar="W",
                     help="single GPU: run the W shards of a chain-sharded proof one after the other and report each shard's device time "
                          "(the per-rank compute of a W-GPU run; outside the timed region)")
+    ap.add_argument("--shard-split", type=int, default=0, metavar="MIN_LOG",
+                    help="with --shard-sim: also split tables of at least 2^(log2 W + MIN_LOG) entries by index over the ranks (vp_set_shard_split; 11 is the smallest useful value)")
     ap.add_argument("--with-pc", action="store_true", help="also time the Virgo commitment (commit_private + commit_public + FRI commit phase)")
     ap.add_argument("--no-x1024-leg", action="store_true",
                     help="skip the nested x1024_with_pc leg (BASELINE configs[2]) that the default single-GPU run appends to the x64 headline line")
@@ -465,6 +467,8 @@ def main():
             parts = []
             for r in range(a.shard_sim):
                 sess.set_shard(r, a.shard_sim)
+                if a.shard_split:
+                    sess.set_shard_split(a.shard_split)
                 for _ in range(2):
                     sess.prove_gkr()
                 ms = []
@@ -475,12 +479,18 @@ def main():
                 parts.append(tr_s)
                 per.append({"rank": r, "device_ms": sum(m[0] for m in ms) / len(ms), "wall_ms": sum(m[1] for m in ms) / len(ms)})
             owner, cost = sess.shard_chains()
+            summed = vp.sum_transcripts(parts)
+            t_f = time.perf_counter()
+            assembled = sess.shard_finish(summed) if a.shard_split else summed
+            finish_ms = 1e3 * (time.perf_counter() - t_f)
             sess.set_shard(0, 1)
             shard_sim = {"world": a.shard_sim, "per_rank": per, "max_device_ms": max(x["device_ms"] for x in per),
                          "max_wall_ms": max(x["wall_ms"] for x in per),
+                         "index_split_min_log": a.shard_split or None, "chains_split_by_index": int((owner == -1).sum()),
+                         "host_finish_ms": finish_ms if a.shard_split else None,
                          "cost_share_per_rank": [float(cost[owner == r].sum() / cost.sum()) for r in range(a.shard_sim)],
-                         "assembled_equals_unsharded": vp.sum_transcripts(parts) == tr,
-                         "note": "each shard run alone on this GPU; a W-GPU run adds one all-reduce of the transcript per proof"}
+                         "assembled_equals_unsharded": assembled == tr,
+                         "note": "each shard run alone on this GPU; a W-GPU run adds one all-reduce of the transcript (and, with the index split, of the export area) per proof"}
 
         interactive = None
         if rank == 0:

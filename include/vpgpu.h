@@ -98,6 +98,8 @@ typedef struct {
     int32_t debug;                  /* bit 0 (VP_DEBUG): diagnostics on stderr; bit 1 (VP_DEBUG_UPLOAD): phase times of vp_circuit_upload [0] */
     int32_t prefetch_round1;        /* VP_PREFETCH_R1: an init call queues round 1 of its sumcheck (it takes no challenge) behind its own kernels
                                        and returns without waiting; the first vp_round of the phase collects the answer          [1] */
+    int32_t split_cost_percent;     /* VP_SPLIT_COST_PERCENT: vp_set_shard_split cuts a chain by index only if its cost estimate exceeds this
+                                       percentage of one rank's fair share of the proof (total / world); 0 = every chain with a long table  [100] */
 } vp_options;
 void vp_options_default(vp_options *opt);
 
@@ -176,6 +178,14 @@ int vp_gkr_sizes(vp_ctx *, uint64_t *n_tape, uint64_t *n_transcript_bytes);
  * proof, byte for byte.  Every rank holds the whole circuit and witness.  world = 1 restores the unsharded proof.  Only
  * the batched entry point shards; the interactive entry points are unaffected.                                         */
 int vp_set_shard(vp_ctx *, int rank, int world);
+/* On top of vp_set_shard: tables of at least 2^(log2 W' + min_log) entries (W' = the largest power of two <= world) are cut into W' slices by
+ * index and slice s is folded by rank s through the rounds that stay inside a slice; the entries the slices end in travel in an export area
+ * behind the transcript (the same u64-sum all-reduce gathers them) and the last log2 W' rounds of those tables are finished on the host.
+ * With a communicator attached vp_prove_gkr returns the finished transcript as before.  Without one it returns the rank's partial sums AND its
+ * export area (vp_gkr_sizes gives the size): add the ranks' buffers as u64 and call vp_shard_finish.  min_log = 0 switches the split off;
+ * call after vp_set_shard.  Chains without a long enough table are dealt out whole, as before.                                               */
+int vp_set_shard_split(vp_ctx *, int min_log);
+int vp_shard_finish(vp_ctx *, uint8_t *summed, uint64_t n_bytes, uint64_t *n_transcript_bytes);
 /* The assignment: owner rank and cost estimate of every chain, in the order phase-1(layer 1), Liu(layer 1), phase-1(layer 2),
  * Liu(layer 2), ... then phase-2(layer 1..n-1), then Vres; *n_chains = 3*(n_layers-1) + 1.  Chains that do not exist (layers
  * without a phase 2) have cost 0.                                                                                      */

@@ -197,6 +197,67 @@ def test_chain_sharded_proof_randomize_and_fused_init(vp, golden, gold_gkr, monk
     s.close(); c.close()
 
 
+def _split_parts(vp, s, world, min_log=11):
+    """The outputs (partial transcript + export area) of all ranks of an index-split proof, one after the other on this GPU."""
+    parts = []
+    for r in range(world):
+        s.set_shard(r, world)
+        s.set_shard_split(min_log)
+        tr, _ = s.prove_gkr()
+        tr2, _ = s.prove_gkr()            # graph replay of the rank's plan
+        assert tr2 == tr
+        parts.append(tr)
+    out = s.shard_finish(vp.sum_transcripts(parts))
+    s.set_shard(0, 1)
+    return out
+
+
+@pytest.mark.parametrize("name,blocks,worlds", [("sha256_x16", 16, (2, 3, 8)), ("sha256_x64", 64, (8,))])
+def test_index_split_proof_assembles_to_reference(vp, golden, gold_gkr, pws_path, name, blocks, worlds, monkeypatch):
+    """One proof over W ranks with the long tables cut by index (vp_set_shard_split): slice s of every table of >= 2^(log2 W + 11)
+    entries is folded by rank s, the last log2 W rounds of those tables are finished on the host from the exported entries, short
+    tables and short chains are dealt out whole.  The u64 sum of the ranks' outputs, finished, is the real reference's transcript —
+    W = 3 covers a world size that is not a power of two (two slices, the third rank takes whole chains only).  Both policies: every
+    chain with a long table cut (split_cost_percent = 0) and only the chains above half a rank's fair share (the default)."""
+    c = vp.Circuit.from_pws(pws_path, blocks, seed=1)
+    gold = gold_gkr(name)
+    s = vp.Session(c)                      # default policy
+    s.draw_tape()
+    for w in worlds:
+        assert _split_parts(vp, s, w) == gold, "default policy, W=%d" % w
+    s.close()
+    monkeypatch.setenv("VP_SPLIT_COST_PERCENT", "0")
+    s = vp.Session(c)
+    s.draw_tape()
+    gold = gold_gkr(name)
+    for w in worlds:
+        s.set_shard(0, w); s.set_shard_split(11)
+        owner, _ = s.shard_chains()
+        assert (owner == -1).any(), "nothing was split"
+        assert _split_parts(vp, s, w) == gold, "W=%d" % w
+    tr, _ = s.prove_gkr()                  # back to the unsharded proof on the same context
+    assert tr == gold
+    s.close(); c.close()
+
+
+def test_index_split_multi_table_chains_and_complex_values(vp, ob, monkeypatch):
+    """Phase-2 chains with several long tables, short tables riding with one rank, complex circuit values, assert gates: random circuits
+    with every gate type (custom_circuits) and the reference's `randomize`, W = 2, 4, 8 against the oracle."""
+    import custom_circuits as cc
+    monkeypatch.setenv("VP_SPLIT_COST_PERCENT", "0")
+    for what, mk in (("custom", lambda m: m.Circuit.custom(*cc.make(7, [300000, 280000, 150000, 270000, 9000]))),
+                     ("randomize", lambda m: m.Circuit.randomize(6, 16, seed=3))):
+        c = mk(vp); oc = mk(ob)
+        assert c.hash() == oc.hash()
+        gold, st = oc.prove_gkr()
+        assert st["verified"] == 1
+        s = vp.Session(c)
+        s.draw_tape()
+        for w in (2, 4, 8):
+            assert _split_parts(vp, s, w) == gold, "%s W=%d" % (what, w)
+        s.close(); c.close(); oc.close()
+
+
 def test_set_shard_rejects_bad_arguments_and_survives_idle_ranks(vp, ob):
     c = vp.Circuit.randomize(4, 8, seed=7)
     s = vp.Session(c)

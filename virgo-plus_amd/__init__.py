@@ -102,6 +102,9 @@ def lib_gpu():
         vp = ctypes.c_void_p
         L.vp_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
         L.vp_create_with_options.argtypes = [ctypes.c_int, vp, ctypes.POINTER(vp)]
+        L.vp_set_shard_split.argtypes = [vp, ctypes.c_int]
+        L.vp_shard_finish.argtypes = [vp, vp, ctypes.c_uint64, vp]
+        L.vp_gkr_sizes.argtypes = [vp, vp, vp]
         L.vp_options_default.argtypes = [vp]
         L.vp_options_default.restype = None
         L.vp_destroy.argtypes = [vp]
@@ -387,7 +390,7 @@ class Options(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_uint32)] + [(n, ctypes.c_int32) for n in (
         "gkr_path", "use_graph", "serial", "fuse_init", "fuse_min_log", "fuse_dot", "init3", "drop_y", "drop_y_round1", "real_values",
         "seg_tiny", "sf_rounds", "sf_big_log", "sf3b", "sf3b_grid", "sf_min_waves", "dot_blocks", "plan_align", "xcd_map",
-        "round_fused_max", "persistent_rounds", "persistent_multi", "persistent_multi_shift", "poll", "debug", "prefetch_round1")]
+        "round_fused_max", "persistent_rounds", "persistent_multi", "persistent_multi_shift", "poll", "debug", "prefetch_round1", "split_cost_percent")]
 
     def __init__(self, **kw):
         super().__init__()
@@ -483,6 +486,31 @@ class Session:
         transcript zero; sum_transcripts() of all ranks' outputs (one all-reduce) is the proof.  world=1 undoes it."""
         if lib_host().vph_set_shard(self.h, rank, world):
             raise RuntimeError("set_shard(%d, %d) refused" % (rank, world))
+
+    def set_shard_split(self, min_log):
+        """On top of set_shard: tables of at least 2^(log2 W + min_log) entries are also split by index over the ranks (include/vpgpu.h:
+        vp_set_shard_split); prove_gkr() then returns the rank's partial transcript followed by its export area, and
+        shard_finish(sum_transcripts(parts)) is the proof.  min_log=0 switches it off."""
+        ctx = lib_host().vph_session_ctx(self.h)
+        L = lib_gpu()
+        if L.vp_set_shard_split(ctx, int(min_log)):
+            raise RuntimeError("set_shard_split(%d) refused" % min_log)
+        n = ctypes.c_uint64(0)
+        L.vp_gkr_sizes(ctx, None, ctypes.byref(n))
+        if int(n.value) + 4096 > self._cap:
+            self._cap = int(n.value) + 4096
+            self._buf = ctypes.create_string_buffer(self._cap)
+            if hasattr(self, "_n"):
+                self._bufp = ctypes.cast(self._buf, ctypes.c_void_p)
+
+    def shard_finish(self, summed):
+        """The transcript of an index-split proof from the u64 sum of the ranks' prove_gkr() outputs (vp_shard_finish)."""
+        ctx = lib_host().vph_session_ctx(self.h)
+        buf = ctypes.create_string_buffer(bytes(summed), len(summed))
+        n = ctypes.c_uint64(0)
+        if lib_gpu().vp_shard_finish(ctx, buf, len(summed), ctypes.byref(n)):
+            raise RuntimeError("shard_finish refused")
+        return buf.raw[:int(n.value)]
 
     def shard_chains(self):
         """(owner rank, cost estimate) per sumcheck chain of the proof, in plan order (include/vpgpu.h: vp_shard_chains)."""

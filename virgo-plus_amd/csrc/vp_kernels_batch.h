@@ -156,10 +156,10 @@ k_init2_chunks(InitArgs2 a, const u32 *__restrict__ chunk_beg, const u32 *__rest
 // Liu init as a gather (src/prover.cpp:396-414): for every u of layer i-1 the (later layer, subset
 // position) pairs that point at it were listed at upload; M[u] = s0*eq(r_u,u) + sum eq_q(g).
 __device__ __forceinline__ void liu_gather_body(const u32 *__restrict__ rowptr, const uint8_t *__restrict__ e_q, const u32 *__restrict__ e_g,
-                                                const Half *__restrict__ H, u32 size, F *__restrict__ M, u32 bid) {
+                                                const Half *__restrict__ H, u32 size, F *__restrict__ M, u32 bid, u32 u0 = 0) {
     u32 u = bid * blockDim.x + threadIdx.x;
     if (u >= size) return;
-    F m = half_at(H[0], u);
+    F m = half_at(H[0], u0 + u);
     for (u32 k = rowptr[u]; k < rowptr[u + 1]; ++k) m = f_add(m, half_at(H[e_q[k]], e_g[k]));
     M[u] = m;
 }

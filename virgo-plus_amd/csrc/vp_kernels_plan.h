@@ -174,7 +174,9 @@ struct EmitTab {
     int src;          // global buffer holding the table at `enter` (tab[src]); V from V0 if v_from_v0
     int v_from_v0;
     int bl;           // log2 of the table's length at round 1
-    int pad;
+    int exp;          // index-split proof (vp_set_shard_split): 1 + export slot; the table is a SLICE of a longer one, and when it is down to one entry
+                      // its (v, m, a) go to exp_out[3 * slot ..] instead of retiring into add_term — the rounds that pair it with the other
+                      // ranks' slices are finished on the host from the gathered entries (vpgpu_batched.inc, split_finish).  0: ordinary table
 };
 struct EmitArgs {
     const F *V0;
@@ -188,6 +190,7 @@ struct EmitArgs {
     u32 derive_mask;            // bit k-1: a fold launch left out the sum of m1 v1 + a1 in round k; b_k = S_{k-1}(r_{k-1}) - a_k - 2 c_k
     int derive_later;           // 1: k_fixup derives those b's after all sumchecks are closed (round 1 included: its claim comes from another sumcheck)
     F *poly_out, *claims_out, *Vu;
+    F *exp_out;                 // export area of the index-split proof (EmitTab::exp)
     int n_pd;                   // launches that left block partials
     struct { int k0, nr; u32 nblk, off; } pd[VP_MAX_PD];   // rounds k0..k0+nr-1: part[off + s*nblk*3 + b*3 + c]
     EmitTab t[VP_MAX_TAB];
@@ -215,6 +218,7 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, unsigned char *smem
     // round on the critical path, and a scalar load of a.t[j] per table and pass was most of a round's time)
     const int my_enter = lane < a.n_tab ? a.t[lane].enter : 0x7fffffff;
     const u32 my_len = lane < a.n_tab ? a.t[lane].len_enter : 0u;
+    const int my_exp = lane < a.n_tab ? a.t[lane].exp : 0;
     if (tid >= 64 && tid - 64 < a.rounds) s_r[tid - 64] = a.r[tid - 64];
     // ---- phase 0: every table this kernel owns is fetched into its LDS slot NOW (buffer = parity of its first round here).
     // The tables are complete when the kernel starts, their slots are untouched until that round, and one memory round trip
@@ -227,7 +231,7 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, unsigned char *smem
             const int cbj = td.enter & 1;
             const F *gV = td.v_from_v0 ? a.V0 + td.off : a.buf[td.src][0] + td.off;
             const F *gM = a.buf[td.src][1] + td.off, *gA = a.buf[td.src][2] + td.off;
-            const bool single = td.bl == 0;                              // always-initialised single entry
+            const bool single = td.bl == 0 && td.valid_enter > 0;        // always-initialised single entry (an EMPTY one-entry table is all zero: empty subsets, and the placeholders of an index-split proof)
             for (u32 i = tid; i < td.len_enter; i += nth) {
                 const bool ok = single || i < td.valid_enter;
                 L(cbj, 0)[j * E + i] = ok ? gV[i] : f_zero();
@@ -310,8 +314,11 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, unsigned char *smem
                 const u32 len = sh < 32 ? (my_len >> sh) : 0;
                 if (len == 1) {
                     const F v = L(cb, 0)[lane * E], m = L(cb, 1)[lane * E], ad = L(cb, 2)[lane * E];
-                    s_claim[lane] = v;
-                    if (real_round) { s_retv[lane] = f_add(f_mul(v, m), ad); s_retk[lane] = k; }
+                    if (my_exp) { F *o = a.exp_out + 3 * (size_t) (my_exp - 1); o[0] = v; o[1] = m; o[2] = ad; }       // a slice: neither claim nor add_term here
+                    else {
+                        s_claim[lane] = v;
+                        if (real_round) { s_retv[lane] = f_add(f_mul(v, m), ad); s_retk[lane] = k; }
+                    }
                 }
             }
         }
@@ -427,7 +434,7 @@ __global__ void __launch_bounds__(64) k_fixup(const FixJob *__restrict__ jobs, u
 // independent sumchecks per proof, batching them side by side is what fills the chip.
 // ---------------------------------------------------------------------------------------------------
 struct BlkMap { u32 job, bid; };
-struct GatherJob { const u32 *rowptr; const uint8_t *e_q; const u32 *e_g; const Half *H; F *M; u32 size; int pad; };
+struct GatherJob { const u32 *rowptr; const uint8_t *e_q; const u32 *e_g; const Half *H; F *M; u32 size; u32 u0; };     // u0: first wire of a row range (rowptr and M already point at it)
 // phase 0: Liu gather (g), 1 / 2: phase inits (a).  A phase-1 job can carry the inner product V_u = sum_u eq(r_u,u) V[u]
 // of its layer (same rows u): one more coalesced load and two multiplies in a kernel that waits on gathers anyway.
 struct LightJob { InitArgs2 a; GatherJob g; Half dot_h; const F *dot_val; F *dot_part; int phase; u32 dot_size; };
@@ -439,7 +446,7 @@ __global__ void __launch_bounds__(VP_BLOCK) k_light_multi(const LightJob *__rest
     const LightJob &j = jobs[m.job];
     if (j.phase == 1) init2_light_body<1>(j.a, m.bid);
     else if (j.phase == 2) init2_light_body<2>(j.a, m.bid);
-    else liu_gather_body(j.g.rowptr, j.g.e_q, j.g.e_g, j.g.H, j.g.size, j.g.M, m.bid);
+    else liu_gather_body(j.g.rowptr, j.g.e_q, j.g.e_g, j.g.H, j.g.size, j.g.M, m.bid, j.g.u0);
     if (j.phase == 1 && j.dot_part) {                           // uniform per workgroup
         __shared__ F lds[4];
         const u32 row = m.bid * blockDim.x + threadIdx.x;

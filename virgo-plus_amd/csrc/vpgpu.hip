@@ -25,6 +25,7 @@ struct Csr {                 // contributions of one layer sorted by target row 
     uint16_t *e_tl = nullptr;
     u32 *heavy_row = nullptr, *heavy_cptr = nullptr, *chunk_beg = nullptr, *chunk_end = nullptr;
     Csr3 c3{};               // the same light contributions cut into 512-row chunks for the entry-parallel kernels
+    std::vector<u32> h_heavy_row, h_heavy_cptr;      // host copies (a handful of rows): row-range init jobs of the index-split proof
 };
 
 struct LayerDev {
@@ -177,6 +178,15 @@ struct vp_ctx {
     hipGraphExec_t gkr_graph = nullptr; int use_graph = 1; bool graph_failed = false; u64 graph_launches = 0, graph_rounds = 0;
     // one proof sharded over GPUs by sumcheck chain (vp_set_shard): this rank records and runs only the chains it owns
     int shard_rank = 0, shard_world = 1;
+    // index-split proof (vp_set_shard_split): tables of at least 2^(split_lw + split_min_log) entries are cut into 2^split_lw slices, slice s
+    // folded by rank s; the entries the slices end in are gathered through the export area behind the transcript and the last split_lw
+    // rounds of those tables are finished on the host (split_finish)
+    int split_lw = 0, split_min_log = 11;
+    struct SplitTab { int j, bl; u32 slot0; };                                  // table j of the chain, log2 of its full length, first export slot (2^split_lw of them)
+    struct SplitChain { u64 poly_pos = 0, claims_pos = 0, r_off = 0; int rounds = 0, has_a = 1, n_tab = 0, small_owner = 0; std::vector<SplitTab> tabs; };
+    std::vector<SplitChain> split;     // per chain (index as chain_owner); tabs empty = not split
+    F *d_trs = nullptr; u64 n_exp = 0; // transcript + export area in one buffer (one all-reduce), export slots
+    F *tr_base() const { return (split_lw > 0 && d_trs) ? d_trs : d_tr; }
     std::vector<int> chain_owner;     // per chain of the plan (same indices as `lanes`, + 1 for Vres); empty = everything local
     std::vector<double> chain_cost;
     bool drop_round1 = false;         // plan being recorded: round 1 of every sumcheck also leaves out the product sum (k_fixup restores b)
@@ -597,7 +607,7 @@ void vp_options_default(vp_options *o) {
     o->gkr_path = VP_PATH_PLAN; o->use_graph = 1; o->serial = 0; o->fuse_init = 1; o->fuse_min_log = 0; o->fuse_dot = 0; o->init3 = 0;
     o->drop_y = 1; o->drop_y_round1 = 0; o->real_values = 1; o->seg_tiny = 1; o->sf_rounds = 3; o->sf_big_log = 14; o->sf3b = 1;
     o->sf3b_grid = 512; o->sf_min_waves = 1; o->dot_blocks = 1024; o->plan_align = 0; o->xcd_map = 0; o->round_fused_max = 512;
-    o->persistent_rounds = 1; o->persistent_multi = 0; o->persistent_multi_shift = 13; o->poll = 1; o->debug = 0; o->prefetch_round1 = 1;
+    o->persistent_rounds = 1; o->persistent_multi = 0; o->persistent_multi_shift = 13; o->poll = 1; o->debug = 0; o->prefetch_round1 = 1; o->split_cost_percent = 100;
 }
 // defaults <- the caller's struct (as many bytes as its header knew) <- VP_* environment variables (test-only override, read here and nowhere else)
 static void resolve_options(vp_options *o, const vp_options *user) {
@@ -618,6 +628,7 @@ static void resolve_options(vp_options *o, const vp_options *user) {
     num("VP_FUSE_MIN_LOG", o->fuse_min_log); num("VP_SF_ROUNDS", o->sf_rounds); num("VP_SF_BIG_LOG", o->sf_big_log); num("VP_SF3B", o->sf3b);
     num("VP_SF3B_GRID", o->sf3b_grid); num("VP_SF_MINW", o->sf_min_waves); num("VP_DOT_BLOCKS", o->dot_blocks);
     num("VP_ROUND_FUSED_MAX", o->round_fused_max); num("VP_MULTI_SHIFT", o->persistent_multi_shift);
+    num("VP_SPLIT_COST_PERCENT", o->split_cost_percent);
     if (getenv("VP_DEBUG")) o->debug |= 1;
     if (getenv("VP_DEBUG_UPLOAD")) o->debug |= 2;                       // bit 1: phase times of vp_circuit_upload
     if (o->sf_rounds != 4) o->sf_rounds = 3;
@@ -1165,15 +1176,22 @@ int vp_finalize(vp_ctx *ctx, const vp_F *previous_random, vp_F *claims, int n_cl
     return VP_OK;
 }
 
+static int prove_gkr_fused(vp_ctx *ctx, const vp_F *tape, uint64_t n_tape, uint8_t *transcript, uint64_t *n_written);
+static void assign_chains(vp_ctx *ctx);
+static void split_layout(vp_ctx *ctx);
+bool vp_comm_attached(const vp_ctx *ctx);
+
 int vp_gkr_sizes(vp_ctx *ctx, uint64_t *n_tape, uint64_t *n_bytes) {
     if (!ctx || ctx->n_layers < 2) return VP_EINVAL;
     if (n_tape) *n_tape = ctx->n_tape;
-    if (n_bytes) *n_bytes = ctx->n_tr * sizeof(F);
+    if (n_bytes) {
+        // index-split proof without a communicator: the call returns the rank's transcript AND its export area (vp_shard_finish)
+        u64 n = ctx->n_tr;
+        if (ctx->split_lw > 0 && ctx->shard_world > 1 && ctx->plan_path && !vp_comm_attached(ctx)) { split_layout(ctx); n += 3 * ctx->n_exp; }
+        *n_bytes = n * sizeof(F);
+    }
     return VP_OK;
 }
-
-static int prove_gkr_fused(vp_ctx *ctx, const vp_F *tape, uint64_t n_tape, uint8_t *transcript, uint64_t *n_written);
-static void assign_chains(vp_ctx *ctx);
 
 int vp_set_shard(vp_ctx *ctx, int rank, int world) {
     if (!ctx || world < 1 || rank < 0 || rank >= world) return VP_EINVAL;
@@ -1187,11 +1205,28 @@ int vp_set_shard(vp_ctx *ctx, int rank, int world) {
     free_plan(ctx);
     ctx->shard_rank = rank; ctx->shard_world = world;
     ctx->chain_owner.clear(); ctx->chain_cost.clear();
+    if (world <= 1) ctx->split_lw = 0;
+    return VP_OK;
+}
+
+int vp_set_shard_split(vp_ctx *ctx, int min_log) {
+    if (!ctx || min_log < 0 || min_log > 30) return VP_EINVAL;
+    VP_ENTER(ctx);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ctx->gkr_graph) { (void) hipGraphExecDestroy(ctx->gkr_graph); ctx->gkr_graph = nullptr; }
+    ctx->graph_failed = false;
+    free_plan(ctx);
+    int lw = 0;
+    while ((2 << lw) <= ctx->shard_world) ++lw;                      // largest power of two <= world
+    ctx->split_lw = (min_log > 0 && ctx->shard_world > 1) ? lw : 0;
+    if (min_log > 0) ctx->split_min_log = std::max(9, min_log);      // a slice keeps at least one fold chunk
+    ctx->chain_owner.clear(); ctx->chain_cost.clear();
     return VP_OK;
 }
 
 int vp_shard_chains(vp_ctx *ctx, int32_t *owner, double *cost, int capacity, int *n_chains) {
     if (!ctx || ctx->n_layers < 2) return VP_EINVAL;
+    split_layout(ctx);                                                // owner -1: the chain is split by index over the ranks
     assign_chains(ctx);
     const int n = (int) ctx->chain_owner.size();
     if (n_chains) *n_chains = n;
@@ -1202,7 +1237,7 @@ int vp_shard_chains(vp_ctx *ctx, int32_t *owner, double *cost, int capacity, int
 int vp_prove_gkr(vp_ctx *ctx, const vp_F *tape, uint64_t n_tape, uint8_t *transcript, uint64_t capacity,
                  uint64_t *n_written) {
     if (!ctx || !ctx->evaluated || !tape || !transcript || n_tape != ctx->n_tape) return VP_EINVAL;
-    if (capacity < ctx->n_tr * sizeof(F)) return VP_EINVAL;
+    { uint64_t need = 0; (void) vp_gkr_sizes(ctx, nullptr, &need); if (ctx->opt.debug & 1) fprintf(stderr, "[vp] vp_prove_gkr: capacity %llu need %llu\n", (unsigned long long) capacity, (unsigned long long) need); if (capacity < need) return VP_EINVAL; }
     if (!ctx->simple_path) return prove_gkr_fused(ctx, tape, n_tape, transcript, n_written);
     VP_ENTER(ctx);
     const int n = ctx->n_layers;
