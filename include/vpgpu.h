@@ -99,7 +99,7 @@ typedef struct {
     int32_t prefetch_round1;        /* VP_PREFETCH_R1: an init call queues round 1 of its sumcheck (it takes no challenge) behind its own kernels
                                        and returns without waiting; the first vp_round of the phase collects the answer          [1] */
     int32_t split_cost_percent;     /* VP_SPLIT_COST_PERCENT: vp_set_shard_split cuts a chain by index only if its cost estimate exceeds this
-                                       percentage of one rank's fair share of the proof (total / world); 0 = every chain with a long table  [100] */
+                                       percentage of one rank's fair share of the proof (total / world); 0 = every chain with a long table  [50] */
 } vp_options;
 void vp_options_default(vp_options *opt);
 
