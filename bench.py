@@ -315,9 +315,10 @@ def pc_leg(vp, sess, circ, golden, gname, full_fixture=None):
 
 def gkr_leg(vp, circ, sess, steps, warmup, world, shard, local):
     """Timed region of one configuration: `warmup` untimed proofs, then exactly `steps` proofs bracketed by barrier + device sync."""
+    in_lib = shard == "rccl"       # communicator attached inside libvpgpu (Session.attach_comm): prove_gkr returns the assembled transcript
     for _ in range(warmup):
         tr, _ = sess.prove_gkr()
-        if shard:
+        if shard and not in_lib:
             vp.allreduce_transcript(tr, local)
     gpu_sync(local)
     barrier(world)
@@ -326,7 +327,7 @@ def gkr_leg(vp, circ, sess, steps, warmup, world, shard, local):
     res = None
     for _ in range(steps):
         tr, res = sess.prove_gkr()
-        if shard:       # the one data-path collective: u64 sum of the ranks' disjoint transcript slices over RCCL
+        if shard and not in_lib:       # gloo rehearsal: the same u64 sum through torch (on the GPUs it happens inside prove_gkr, over RCCL)
             tr = vp.allreduce_transcript(tr, local)
         dev_ms += res["gkr_device_ms"]
     gpu_sync(local)
@@ -402,7 +403,7 @@ def main():
                     help="single GPU: run the W shards of a chain-sharded proof one after the other and report each shard's device time "
                          "(the per-rank compute of a W-GPU run; outside the timed region)")
     ap.add_argument("--shard-split", type=int, default=0, metavar="MIN_LOG",
-                    help="with --shard-sim: also split tables of at least 2^(log2 W + MIN_LOG) entries by index over the ranks (vp_set_shard_split; 11 is the smallest useful value)")
+                    help="with --shard-sim or --shard-chains: also split tables of at least 2^(log2 W + MIN_LOG) entries by index over the ranks (vp_set_shard_split; 11 is the smallest useful value)")
     ap.add_argument("--with-pc", action="store_true", help="also time the Virgo commitment (commit_private + commit_public + FRI commit phase)")
     ap.add_argument("--no-x1024-leg", action="store_true",
                     help="skip the nested x1024_with_pc leg (BASELINE configs[2]) that the default single-GPU run appends to the x64 headline line")
@@ -443,6 +444,14 @@ def main():
         sess.draw_tape()
         if shard:
             sess.set_shard(rank, world)
+            import torch.distributed as dist
+            if "nccl" in dist.get_backend():           # the data-path collective lives in the C ABI: RCCL on the device buffer, no torch tensor
+                sess.attach_comm(rank, world)
+                shard = "rccl"
+            if a.shard_split:
+                sess.set_shard_split(a.shard_split)
+                if shard != "rccl":
+                    raise SystemExit("--shard-split in the multi-rank mode needs the in-library communicator (RCCL); rehearse it with --shard-sim")
         tr, res, elapsed, dev_ms = gkr_leg(vp, circ, sess, a.steps, a.warmup, world, shard, local)
         elapsed, proofs = aggregate(world, elapsed, float(a.steps))
         shard_info = None
@@ -454,7 +463,10 @@ def main():
             owner, cost = sess.shard_chains()
             shard_info = {"device_ms_per_rank": [float(x) for x in dm], "chains": int((cost > 0).sum()),
                           "chains_per_rank": [int(((owner == r) & (cost > 0)).sum()) for r in range(world)],
-                          "collective": "one all-reduce (sum, int64) of the %d-byte transcript per proof, backend %s" % (len(tr), dist.get_backend())}
+                          "chains_split_by_index": int((owner == -1).sum()),
+                          "collective": ("one RCCL all-reduce (u64 sum) of the transcript%s per proof inside vp_prove_gkr (vp_comm_init: no torch tensor, no host bounce)"
+                                         % (" + export area" if a.shard_split else "")) if shard == "rccl"
+                                        else "one all-reduce (sum, int64) of the %d-byte transcript per proof through torch, backend %s" % (len(tr), dist.get_backend())}
             sess.set_shard(0, 1)                       # the roofline / verifier legs below run the whole proof on every rank
             tr_full, _ = sess.prove_gkr()
             assert tr_full == tr, "assembled sharded transcript differs from the unsharded proof"

@@ -487,6 +487,27 @@ class Session:
         if lib_host().vph_set_shard(self.h, rank, world):
             raise RuntimeError("set_shard(%d, %d) refused" % (rank, world))
 
+    def attach_comm(self, rank, world):
+        """RCCL communicator inside the library (include/vpgpu.h: vp_comm_unique_id / vp_comm_init): rank 0 makes the id, the default
+        torch.distributed group only carries those 128 bytes (control plane).  From then on a sharded prove_gkr() all-reduces the
+        transcript (and the export area of an index-split proof) on the device, inside the call, and returns the finished transcript on
+        every rank — no torch tensor and no host bounce on the data path."""
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+        L = lib_gpu()
+        uid = ctypes.create_string_buffer(128)
+        if rank == 0 and L.vp_comm_unique_id(ctypes.cast(uid, ctypes.c_void_p)):
+            raise RuntimeError("vp_comm_unique_id failed (librccl.so.1 not found?)")
+        t = torch.from_numpy(np.frombuffer(uid.raw, dtype=np.uint8).copy())
+        if "nccl" in dist.get_backend():
+            t = t.cuda()
+        dist.broadcast(t, src=0)
+        idb = ctypes.create_string_buffer(t.cpu().numpy().tobytes(), 128)
+        ctx = lib_host().vph_session_ctx(self.h)
+        if L.vp_comm_init(ctx, ctypes.cast(idb, ctypes.c_void_p), rank, world):
+            raise RuntimeError("vp_comm_init failed: " + (L.vp_last_error(ctx) or b"").decode())
+
     def set_shard_split(self, min_log):
         """On top of set_shard: tables of at least 2^(log2 W + min_log) entries are also split by index over the ranks (include/vpgpu.h:
         vp_set_shard_split); prove_gkr() then returns the rank's partial transcript followed by its export area, and
