@@ -196,6 +196,15 @@ struct EmitArgs {
     EmitTab t[VP_MAX_TAB];
 };
 
+// x_k = A_k x_{k-1} + B_k over lanes 0..31 of a wave (x_{-1} = 0): on return B holds x_k.  Five steps of two independent multiplies.
+__device__ __forceinline__ void affine_scan32(F &A, F &B, int lane) {
+#pragma unroll 1
+    for (int d = 1; d < 32; d <<= 1) {
+        F Ap, Bp;
+        Ap.re = __shfl_up(A.re, d, 64); Ap.im = __shfl_up(A.im, d, 64); Bp.re = __shfl_up(B.re, d, 64); Bp.im = __shfl_up(B.im, d, 64);
+        if (lane >= d) { B = f_add(f_mul(A, Bp), B); A = f_mul(A, Ap); }
+    }
+}
 // dynamic LDS: tables [2][3][cap] | psum[32][3] | wred[32][12][3] | claim[64] | retv[64] | atv[32] | r[32] | retk[64] (int)
 #define VP_EMIT_LDS_EXTRA_F (32 * 3 + 32 * VP_EMIT_WAVES * 3 + VP_MAX_TAB + VP_MAX_TAB + 32 + 32)
 __device__ __forceinline__ void emit_body(const EmitArgs &a, unsigned char *smem_raw) {
@@ -210,15 +219,8 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, unsigned char *smem
     F *s_r = s_at + 32;                                   // the challenges r[0..rounds), read once
     int *s_retk = reinterpret_cast<int *>(s_r + 32);
     auto L = [&](int b, int tbl) { return lbuf + ((size_t) (b * 3 + tbl)) * cap; };
-    const int role = __builtin_amdgcn_readfirstlane(w % 3);
-    const u32 pslot = (u32) ((w / 3) * 64 + lane);
-    const u32 pstride = (u32) (VP_EMIT_WAVES / 3) * 64;
     if (tid < VP_MAX_TAB) { s_claim[tid] = f_zero(); s_retv[tid] = f_zero(); s_retk[tid] = 0; }
-    // table descriptors the per-round pair scan needs, one table per lane (read back with v_readlane: the scan runs twice per
-    // round on the critical path, and a scalar load of a.t[j] per table and pass was most of a round's time)
-    const int my_enter = lane < a.n_tab ? a.t[lane].enter : 0x7fffffff;
-    const u32 my_len = lane < a.n_tab ? a.t[lane].len_enter : 0u;
-    const int my_exp = lane < a.n_tab ? a.t[lane].exp : 0;
+    for (int i = tid; i < 32 * VP_EMIT_WAVES * 3; i += nth) wred[i] = f_zero();      // per-round, per-wave sums of phase 2
     if (tid >= 64 && tid - 64 < a.rounds) s_r[tid - 64] = a.r[tid - 64];
     // ---- phase 0: every table this kernel owns is fetched into its LDS slot NOW (buffer = parity of its first round here).
     // The tables are complete when the kernel starts, their slots are untouched until that round, and one memory round trip
@@ -253,83 +255,66 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, unsigned char *smem
         if (lane == 63) { psum[3 * (k - 1)] = ca; psum[3 * (k - 1) + 1] = cbv; psum[3 * (k - 1) + 2] = cc; }
     }
     __syncthreads();
-    // ---- phase 2: rounds with table work ----
+    // ---- phase 2: the closing rounds.  A table is folded by ONE wave from the round it enters down to its last entry with no workgroup
+    // barrier in between: the challenges are on the tape, so tables meet only in the per-round sums, and those every wave keeps to
+    // itself (wred[round][wave]) until phase 3.  At most 32 pairs per table and round (emit_log <= 6): lanes 0..31 take a pair's V side,
+    // lanes 32..63 its M / A side, three multiplications each.  (The lock-step form — all tables round by round behind a barrier —
+    // cost ~2 us per round with pairs, 40 us on a 23-round sumcheck.) ----
     const int nrounds = a.rounds > 0 ? a.rounds : 1;
-    for (int k = 1; k <= nrounds; ++k) {
-        if (!((a.work_mask >> (k - 1)) & 1u)) continue;                 // uniform
-        const bool real_round = k <= a.rounds;
-        const int cb = k & 1;
-        const bool has_pairs = real_round && ((a.pair_mask >> (k - 1)) & 1u);                 // uniform
-        F ca = f_zero(), cbv = f_zero(), cc = f_zero();
-        if (has_pairs) {
-            const F rk = s_r[k - 1];
-            // global pair index -> (table, pair): tables are scanned with wave-uniform lengths
-            for (u32 gp0 = 0;; gp0 += pstride) {
-                const u32 gp = gp0 + pslot;
-                u32 run = 0; int mj = -1; u32 mp = 0; u32 total = 0;
-                for (int j = 0; j < a.n_tab; ++j) {                      // lane j of every wave holds table j's (enter, len_enter)
-                    const int enter_j = __builtin_amdgcn_readlane(my_enter, j);
-                    if (k < enter_j) continue;
-                    const u32 len_j = (u32) __builtin_amdgcn_readlane((int) my_len, j);
-                    const int sh = k - enter_j;
-                    const u32 len = sh < 32 ? (len_j >> sh) : 0;
-                    const u32 np = len >= 2 ? (len >> 1) : 0;
-                    if (gp >= run && gp < run + np) { mj = j; mp = gp - run; }
-                    run += np;
-                }
-                total = run;
-                if (gp0 >= total) break;                                 // uniform
-                if (mj >= 0) {
-                    const int j = mj; const u32 p = mp;
-                    const F *sV = L(cb, 0) + j * E, *sM = L(cb, 1) + j * E, *sA = L(cb, 2) + j * E;
-                    F *dV = L(cb ^ 1, 0) + j * E, *dM = L(cb ^ 1, 1) + j * E, *dA = L(cb ^ 1, 2) + j * E;
-                    if (role == 0) {
-                        const F m0 = sM[2 * p], m1 = sM[2 * p + 1], v0 = sV[2 * p], v1 = sV[2 * p + 1];
-                        const F dv = f_sub(v1, v0), qa = f_mul(f_sub(m1, m0), dv);
-                        ca = f_add(ca, qa); cbv = f_sub(cbv, qa);
-                        dV[p] = f_add(v0, f_mul(rk, dv));
-                    } else if (role == 1) {
-                        const F m0 = sM[2 * p], m1 = sM[2 * p + 1], v0 = sV[2 * p];
-                        const F qc = f_mul(m0, v0);
-                        cc = f_add(cc, qc); cbv = f_sub(cbv, qc);
-                        dM[p] = f_add(m0, f_mul(rk, f_sub(m1, m0)));
-                    } else {
-                        cbv = f_add(cbv, f_mul(sM[2 * p + 1], sV[2 * p + 1]));
-                        F o = f_zero();
-                        if (a.has_a) {
-                            const F a0 = sA[2 * p], a1 = sA[2 * p + 1];
-                            const F da = f_sub(a1, a0);
-                            cbv = f_add(cbv, da); cc = f_add(cc, a0);
-                            o = f_add(a0, f_mul(rk, da));
-                        }
-                        dA[p] = o;
-                    }
-                }
-            }
-        }
-        // single-entry tables: the entry is the claim; in a real round it retires into add_term.  One lane per table.
-        if (w == VP_EMIT_WAVES - 1 && lane < a.n_tab) {
-            if (k >= my_enter) {
-                const int sh = k - my_enter;
-                const u32 len = sh < 32 ? (my_len >> sh) : 0;
-                if (len == 1) {
-                    const F v = L(cb, 0)[lane * E], m = L(cb, 1)[lane * E], ad = L(cb, 2)[lane * E];
-                    if (my_exp) { F *o = a.exp_out + 3 * (size_t) (my_exp - 1); o[0] = v; o[1] = m; o[2] = ad; }       // a slice: neither claim nor add_term here
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    for (int j = wu; j < a.n_tab; j += VP_EMIT_WAVES) {
+        const EmitTab td = a.t[j];
+        if (td.enter > nrounds) continue;
+        u32 len = td.len_enter;
+        const u32 p = (u32) lane & 31u;
+        const int side = lane >> 5;
+        for (int k = td.enter; k <= nrounds; ++k, len >>= 1) {
+            const int cb = k & 1;
+            const F *sV = L(cb, 0) + j * E, *sM = L(cb, 1) + j * E, *sA = L(cb, 2) + j * E;
+            if (len <= 1) {
+                // single entry: it is the claim; in a real round it retires into add_term
+                if (len == 1 && lane == 0) {
+                    const F v = sV[0], m = sM[0], ad = sA[0];
+                    if (td.exp) { F *o = a.exp_out + 3 * (size_t) (td.exp - 1); o[0] = v; o[1] = m; o[2] = ad; }       // a slice: neither claim nor add_term here
                     else {
-                        s_claim[lane] = v;
-                        if (real_round) { s_retv[lane] = f_add(f_mul(v, m), ad); s_retk[lane] = k; }
+                        s_claim[j] = v;
+                        if (k <= a.rounds) { s_retv[j] = f_add(f_mul(v, m), ad); s_retk[j] = k; }
                     }
                 }
+                break;
             }
+            if (k > a.rounds) break;
+            F *dV = L(cb ^ 1, 0) + j * E, *dM = L(cb ^ 1, 1) + j * E, *dA = L(cb ^ 1, 2) + j * E;
+            const F rk = s_r[k - 1];
+            F ca = f_zero(), cbv = f_zero(), cc = f_zero();
+            if (p < (len >> 1)) {
+                const F m0 = sM[2 * p], m1 = sM[2 * p + 1], v0 = sV[2 * p], v1 = sV[2 * p + 1];
+                if (side == 0) {
+                    const F dv = f_sub(v1, v0), qa = f_mul(f_sub(m1, m0), dv);
+                    ca = qa; cbv = f_sub(f_mul(m1, v1), qa);
+                    dV[p] = f_add(v0, f_mul(rk, dv));
+                } else {
+                    const F qc = f_mul(m0, v0);
+                    cc = qc; cbv = f_neg(qc);
+                    dM[p] = f_add(m0, f_mul(rk, f_sub(m1, m0)));
+                    F o = f_zero();
+                    if (a.has_a) {
+                        const F a0 = sA[2 * p], a1 = sA[2 * p + 1];
+                        const F da = f_sub(a1, a0);
+                        cbv = f_add(cbv, da); cc = f_add(cc, a0);
+                        o = f_add(a0, f_mul(rk, da));
+                    }
+                    dA[p] = o;
+                }
+            }
+            ca = wave_sum63(ca); cbv = wave_sum63(cbv); cc = wave_sum63(cc);
+            if (lane == 63) {
+                F *o = wred + ((size_t) (k - 1) * VP_EMIT_WAVES + wu) * 3;
+                o[0] = f_add(o[0], ca); o[1] = f_add(o[1], cbv); o[2] = f_add(o[2], cc);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the next round reads what other lanes of this wave just stored
+            __builtin_amdgcn_wave_barrier();
         }
-        // a round in which tables only retire touches nothing another wave reads before phase 3: no sums, no barrier
-        if (!has_pairs) continue;
-        ca = wave_sum63(ca); cbv = wave_sum63(cbv); cc = wave_sum63(cc);
-        if (lane == 63) {
-            F *o = wred + ((size_t) (k - 1) * VP_EMIT_WAVES + w) * 3;
-            o[0] = ca; o[1] = cbv; o[2] = cc;
-        }
-        __syncthreads();
     }
     __syncthreads();
     // ---- phase 3 ----
@@ -346,13 +331,12 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, unsigned char *smem
         s_at[lane] = t;
     }
     __syncthreads();
-    if (tid == 0) {                                            // add_term recurrence
-        F at = f_zero();
-        for (int k = 1; k <= a.rounds; ++k) {
-            if (k >= 2 && !f_is_zero(at)) at = f_mul(at, f_sub(f_one(), s_r[k - 2]));
-            at = f_add(at, s_at[k - 1]);
-            s_at[k - 1] = at;
-        }
+    if (w == 0) {                                              // add_term recurrence  at_k = (1 - r_{k-1}) at_{k-1} + retired_k
+        const bool in = lane < a.rounds;
+        F A = (in && lane >= 1) ? f_sub(f_one(), s_r[lane - 1]) : f_zero();
+        F B = in ? s_at[lane] : f_zero();
+        affine_scan32(A, B, lane);
+        if (in) s_at[lane] = B;
     }
     __syncthreads();
     if (tid < a.rounds * 3) {
@@ -364,14 +348,19 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, unsigned char *smem
     if (a.derive_mask && !a.derive_later) {                    // uniform
         __syncthreads();
         // Rounds whose fold launches skipped the product sum: b_k from the verifier's identity S_k(0) + S_k(1) = S_{k-1}(r_{k-1})
-        // (totals over every table of the phase, add_term included).  One lane, two multiplies per derived round, in order.
-        if (tid == 0) {
-            for (int k = 1; k < a.rounds; ++k) {
-                if (!((a.derive_mask >> k) & 1u)) continue;
+        // (totals over every table of the phase, add_term included):  b_k = r b_{k-1} + (a_{k-1} r^2 + c_{k-1} - a_k - 2 c_k), r = r_{k-1}
+        // — an affine recurrence in b (a known b restarts it), closed by a scan over the rounds instead of two multiplies per round in order.
+        if (w == 0) {
+            const int k = lane;
+            const bool in = k < a.rounds, der = in && k >= 1 && ((a.derive_mask >> k) & 1u);
+            F A = f_zero(), B = in ? psum[3 * k + 1] : f_zero();
+            if (der) {
                 const F r = s_r[k - 1];
-                const F claim = f_add(f_mul(f_add(f_mul(psum[3 * (k - 1)], r), psum[3 * (k - 1) + 1]), r), psum[3 * (k - 1) + 2]);
-                psum[3 * k + 1] = f_sub(f_sub(claim, psum[3 * k]), f_dbl(psum[3 * k + 2]));
+                A = r;
+                B = f_sub(f_sub(f_add(f_mul(f_mul(psum[3 * (k - 1)], r), r), psum[3 * (k - 1) + 2]), psum[3 * k]), f_dbl(psum[3 * k + 2]));
             }
+            affine_scan32(A, B, lane);
+            if (der) psum[3 * k + 1] = B;
         }
     }
     __syncthreads();
