@@ -218,103 +218,140 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, unsigned char *smem
     F *s_at = s_retv + VP_MAX_TAB;
     F *s_r = s_at + 32;                                   // the challenges r[0..rounds), read once
     int *s_retk = reinterpret_cast<int *>(s_r + 32);
-    auto L = [&](int b, int tbl) { return lbuf + ((size_t) (b * 3 + tbl)) * cap; };
+    // table j, array t (0: V, 1: mult, 2: add): a pyramid of 2E slots — the table as it enters at offset 0, its fold after s rounds at
+    // offset 2 len - (2 len >> s), the last single entry at 2 len - 2
+    auto T = [&](int t, int j) { return lbuf + ((size_t) (t * a.n_tab + j)) * 2 * E; };
     if (tid < VP_MAX_TAB) { s_claim[tid] = f_zero(); s_retv[tid] = f_zero(); s_retk[tid] = 0; }
     for (int i = tid; i < 32 * VP_EMIT_WAVES * 3; i += nth) wred[i] = f_zero();      // per-round, per-wave sums of phase 2
     if (tid >= 64 && tid - 64 < a.rounds) s_r[tid - 64] = a.r[tid - 64];
     // ---- phase 0: every table this kernel owns is fetched into its LDS slot NOW (buffer = parity of its first round here).
-    // The tables are complete when the kernel starts, their slots are untouched until that round, and one memory round trip
-    // overlapped with phase 1 replaces one per entering round (measured: 3-6 us per round of the closing launch). ----
-    {
-        const int nr = a.rounds > 0 ? a.rounds : 1;
-        for (int j = 0; j < a.n_tab; ++j) {
-            const EmitTab td = a.t[j];
-            if (td.enter > nr) continue;
-            const int cbj = td.enter & 1;
-            const F *gV = td.v_from_v0 ? a.V0 + td.off : a.buf[td.src][0] + td.off;
-            const F *gM = a.buf[td.src][1] + td.off, *gA = a.buf[td.src][2] + td.off;
-            const bool single = td.bl == 0 && td.valid_enter > 0;        // always-initialised single entry (an EMPTY one-entry table is all zero: empty subsets, and the placeholders of an index-split proof)
-            for (u32 i = tid; i < td.len_enter; i += nth) {
-                const bool ok = single || i < td.valid_enter;
-                L(cbj, 0)[j * E + i] = ok ? gV[i] : f_zero();
-                L(cbj, 1)[j * E + i] = ok ? gM[i] : f_zero();
-                L(cbj, 2)[j * E + i] = (ok && a.has_a) ? gA[i] : f_zero();
-            }
-        }
-    }
-    // ---- phase 1: block partials of the k_seg launches, one round per wave ----
-    for (int k = w + 1; k <= a.rounds; k += VP_EMIT_WAVES) {
+    // The tables are complete when the kernel starts and their slots are untouched until that round.  One table per wave, one entry
+    // per lane (emit_log <= 6); the loads of a wave's first table stay in flight while it adds up its share of phase 1, so that the
+    // closing launch starts with ONE memory round trip instead of one per table and one per 64 block partials. ----
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    const int nrounds = a.rounds > 0 ? a.rounds : 1;
+    auto tab_fetch = [&](int j, F &v, F &m, F &ad) -> int {        // -> LDS buffer of the table's first round, -1: not folded here
+        const EmitTab td = a.t[j];
+        v = f_zero(); m = f_zero(); ad = f_zero();
+        if (td.enter > nrounds) return -1;
+        const F *gV = td.v_from_v0 ? a.V0 + td.off : a.buf[td.src][0] + td.off;
+        const F *gM = a.buf[td.src][1] + td.off, *gA = a.buf[td.src][2] + td.off;
+        const bool single = td.bl == 0 && td.valid_enter > 0;        // always-initialised single entry (an EMPTY one-entry table is all zero: empty subsets, and the placeholders of an index-split proof)
+        if ((u32) lane < td.len_enter && (single || (u32) lane < td.valid_enter)) { v = gV[lane]; m = gM[lane]; if (a.has_a) ad = gA[lane]; }
+        return td.enter & 1;
+    };
+    auto tab_store = [&](int j, int cbj, const F &v, const F &m, const F &ad) {
+        if (cbj >= 0 && (u32) lane < E) { T(0, j)[lane] = v; T(1, j)[lane] = m; T(2, j)[lane] = ad; }
+    };
+    F t0v = f_zero(), t0m = f_zero(), t0a = f_zero();
+    const int t0cb = wu < a.n_tab ? tab_fetch(wu, t0v, t0m, t0a) : -1;
+    // ---- phase 1: block partials of the fold / k_seg launches, one round per wave, 256 blocks per memory round trip ----
+    for (int k = wu + 1; k <= a.rounds; k += VP_EMIT_WAVES) {
         F ca = f_zero(), cbv = f_zero(), cc = f_zero();
         for (int d = 0; d < a.n_pd; ++d) {
             if (k < a.pd[d].k0 || k >= a.pd[d].k0 + a.pd[d].nr) continue;
             const u32 nb = a.pd[d].nblk;
             const F *pp = a.part + a.pd[d].off + (size_t) (k - a.pd[d].k0) * nb * 3;
-            for (u32 i = lane; i < nb; i += 64) { ca = f_add(ca, pp[3 * i]); cbv = f_add(cbv, pp[3 * i + 1]); cc = f_add(cc, pp[3 * i + 2]); }
+            for (u32 i0 = 0; i0 < nb; i0 += 256) {
+                F x[4][3];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const u32 i = i0 + 64 * q + lane;
+                    const bool ok = i < nb;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) x[q][c] = ok ? pp[3 * i + c] : f_zero();
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { ca = f_add(ca, x[q][0]); cbv = f_add(cbv, x[q][1]); cc = f_add(cc, x[q][2]); }
+            }
         }
         ca = wave_sum63(ca); cbv = wave_sum63(cbv); cc = wave_sum63(cc);
         if (lane == 63) { psum[3 * (k - 1)] = ca; psum[3 * (k - 1) + 1] = cbv; psum[3 * (k - 1) + 2] = cc; }
     }
+    tab_store(wu, t0cb, t0v, t0m, t0a);
+    for (int j = wu + VP_EMIT_WAVES; j < a.n_tab; j += VP_EMIT_WAVES) {
+        F v, m, ad;
+        const int cbj = tab_fetch(j, v, m, ad);
+        tab_store(j, cbj, v, m, ad);
+    }
     __syncthreads();
-    // ---- phase 2: the closing rounds.  A table is folded by ONE wave from the round it enters down to its last entry with no workgroup
-    // barrier in between: the challenges are on the tape, so tables meet only in the per-round sums, and those every wave keeps to
-    // itself (wred[round][wave]) until phase 3.  At most 32 pairs per table and round (emit_log <= 6): lanes 0..31 take a pair's V side,
-    // lanes 32..63 its M / A side, three multiplications each.  (The lock-step form — all tables round by round behind a barrier —
-    // cost ~2 us per round with pairs, 40 us on a 23-round sumcheck.) ----
-    const int nrounds = a.rounds > 0 ? a.rounds : 1;
-    const int wu = __builtin_amdgcn_readfirstlane(w);
+    // ---- phase 2: the closing rounds.  A table is folded by ONE wave from the round it enters down to its last entry, with no
+    // workgroup barrier in between: the challenges are on the tape, so tables meet only in the per-round sums, which every wave keeps
+    // to itself (wred[round][wave]) until phase 3.  Per table:
+    //   (1) the fold chain — the only serial part: level s+1 = level s folded with r_k, one multiplication per lane and round (the
+    //       V, mult and add folds of a pair go to three lanes), every level kept (the pyramid above);
+    //   (2) the products of ALL rounds at once — the len - 1 pairs of the pyramid, one per lane, three multiplications each — and a
+    //       butterfly sum inside each level's aligned lane block (lane i: level S-1-floor(log2 i), pair i - 2^floor(log2 i)).
+    // (Round by round behind a workgroup barrier this cost ~2 us per round, 40 us on a 23-round sumcheck; round by round inside one wave
+    // 1.7 us per round, 10 us for a 64-entry table: the products and their sums are most of a round and none of the chain.) ----
     for (int j = wu; j < a.n_tab; j += VP_EMIT_WAVES) {
         const EmitTab td = a.t[j];
         if (td.enter > nrounds) continue;
-        u32 len = td.len_enter;
-        const u32 p = (u32) lane & 31u;
-        const int side = lane >> 5;
-        for (int k = td.enter; k <= nrounds; ++k, len >>= 1) {
-            const int cb = k & 1;
-            const F *sV = L(cb, 0) + j * E, *sM = L(cb, 1) + j * E, *sA = L(cb, 2) + j * E;
-            if (len <= 1) {
-                // single entry: it is the claim; in a real round it retires into add_term
-                if (len == 1 && lane == 0) {
-                    const F v = sV[0], m = sM[0], ad = sA[0];
-                    if (td.exp) { F *o = a.exp_out + 3 * (size_t) (td.exp - 1); o[0] = v; o[1] = m; o[2] = ad; }       // a slice: neither claim nor add_term here
-                    else {
-                        s_claim[j] = v;
-                        if (k <= a.rounds) { s_retv[j] = f_add(f_mul(v, m), ad); s_retk[j] = k; }
-                    }
-                }
-                break;
-            }
+        const u32 len0 = td.len_enter;
+        const int S = 31 - __builtin_clz(len0 | 1u);
+        F *tv = T(0, j), *tm = T(1, j), *ta = T(2, j);
+        const u32 narr = a.has_a ? 3u : 2u;
+        int s_done = 0;
+        for (int sl = 0; sl < S; ++sl) {
+            const int k = td.enter + sl;
             if (k > a.rounds) break;
-            F *dV = L(cb ^ 1, 0) + j * E, *dM = L(cb ^ 1, 1) + j * E, *dA = L(cb ^ 1, 2) + j * E;
+            const u32 np = len0 >> (sl + 1);
+            const int lg = S - sl - 1;                          // log2 np
+            const u32 so = 2 * len0 - ((2 * len0) >> sl), dof = 2 * len0 - ((2 * len0) >> (sl + 1));
             const F rk = s_r[k - 1];
-            F ca = f_zero(), cbv = f_zero(), cc = f_zero();
-            if (p < (len >> 1)) {
-                const F m0 = sM[2 * p], m1 = sM[2 * p + 1], v0 = sV[2 * p], v1 = sV[2 * p + 1];
-                if (side == 0) {
-                    const F dv = f_sub(v1, v0), qa = f_mul(f_sub(m1, m0), dv);
-                    ca = qa; cbv = f_sub(f_mul(m1, v1), qa);
-                    dV[p] = f_add(v0, f_mul(rk, dv));
-                } else {
-                    const F qc = f_mul(m0, v0);
-                    cc = qc; cbv = f_neg(qc);
-                    dM[p] = f_add(m0, f_mul(rk, f_sub(m1, m0)));
-                    F o = f_zero();
-                    if (a.has_a) {
-                        const F a0 = sA[2 * p], a1 = sA[2 * p + 1];
-                        const F da = f_sub(a1, a0);
-                        cbv = f_add(cbv, da); cc = f_add(cc, a0);
-                        o = f_add(a0, f_mul(rk, da));
-                    }
-                    dA[p] = o;
-                }
-            }
-            ca = wave_sum63(ca); cbv = wave_sum63(cbv); cc = wave_sum63(cc);
-            if (lane == 63) {
-                F *o = wred + ((size_t) (k - 1) * VP_EMIT_WAVES + wu) * 3;
-                o[0] = f_add(o[0], ca); o[1] = f_add(o[1], cbv); o[2] = f_add(o[2], cc);
+            for (u32 t = (u32) lane; t < narr * np; t += 64) {
+                F *base = T((int) (t >> lg), j);
+                const u32 pp = t & (np - 1);
+                const F x0 = base[so + 2 * pp], x1 = base[so + 2 * pp + 1];
+                base[dof + pp] = f_add(x0, f_mul(rk, f_sub(x1, x0)));
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the next round reads what other lanes of this wave just stored
             __builtin_amdgcn_wave_barrier();
+            s_done = sl + 1;
         }
+        if (S > 0) {
+            const int e = 31 - __builtin_clz((u32) lane | 1u);
+            const int sl = S - 1 - e;
+            F ca = f_zero(), cbv = f_zero(), cc = f_zero();
+            if (lane >= 1 && (u32) lane < len0 && sl < s_done) {
+                const u32 pp = (u32) lane - (1u << e);
+                const u32 so = 2 * len0 - ((2 * len0) >> sl);
+                const F m0 = tm[so + 2 * pp], m1 = tm[so + 2 * pp + 1], v0 = tv[so + 2 * pp], v1 = tv[so + 2 * pp + 1];
+                const F qa = f_mul(f_sub(m1, m0), f_sub(v1, v0)), qc = f_mul(m0, v0), y = f_mul(m1, v1);
+                ca = qa; cc = qc; cbv = f_sub(f_sub(y, qa), qc);
+                if (a.has_a) { const F a0 = ta[so + 2 * pp], a1 = ta[so + 2 * pp + 1]; cc = f_add(cc, a0); cbv = f_add(cbv, f_sub(a1, a0)); }
+            }
+            u64 acc[6] = {ca.re, ca.im, cbv.re, cbv.im, cc.re, cc.im};
+#pragma unroll
+            for (int st = 0; st < 5; ++st) {                   // at most 8 canonical limbs are added before a fold
+                const bool take = (1 << st) < (1 << e);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) { const u64 o = __shfl_xor(acc[q], 1 << st, 64); acc[q] += take ? o : 0ull; }
+                if (st == 2) {
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) acc[q] = m_fold(acc[q]);
+                }
+            }
+            if (lane >= 1 && (u32) lane == (1u << e) && (u32) lane < len0 && sl < s_done) {
+                F *o = wred + ((size_t) (td.enter + sl - 1) * VP_EMIT_WAVES + wu) * 3;
+                o[0] = f_add(o[0], f_make(m_fold(acc[0]), m_fold(acc[1])));
+                o[1] = f_add(o[1], f_make(m_fold(acc[2]), m_fold(acc[3])));
+                o[2] = f_add(o[2], f_make(m_fold(acc[4]), m_fold(acc[5])));
+            }
+        }
+        // the single entry left: it is the claim; in a real round it retires into add_term
+        if (lane == 0 && s_done == S) {
+            const u32 lo = 2 * len0 - 2;
+            const int k = td.enter + S;
+            const F v = tv[lo], m = tm[lo], ad = ta[lo];
+            if (td.exp) { F *o = a.exp_out + 3 * (size_t) (td.exp - 1); o[0] = v; o[1] = m; o[2] = ad; }       // a slice: neither claim nor add_term here
+            else {
+                s_claim[j] = v;
+                if (k <= a.rounds) { s_retv[j] = f_add(f_mul(v, m), ad); s_retk[j] = k; }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
     // ---- phase 3 ----
@@ -335,8 +372,10 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, unsigned char *smem
         const bool in = lane < a.rounds;
         F A = (in && lane >= 1) ? f_sub(f_one(), s_r[lane - 1]) : f_zero();
         F B = in ? s_at[lane] : f_zero();
-        affine_scan32(A, B, lane);
-        if (in) s_at[lane] = B;
+        if (__any(!f_is_zero(B))) {                            // uniform; nothing retires in a sumcheck over tables of one length
+            affine_scan32(A, B, lane);
+            if (in) s_at[lane] = B;
+        }
     }
     __syncthreads();
     if (tid < a.rounds * 3) {
@@ -372,7 +411,7 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, unsigned char *smem
             if (td.bl == a.rounds) {
                 // as long as the sumcheck: folded to one entry by the last round — here, or already by k_seg
                 if (td.enter > a.rounds) c = td.valid_enter ? (a.buf[td.src][0] + td.off)[0] : f_zero();
-                else c = L((a.rounds + 1) & 1, 0)[tid * E];
+                // else: phase 2 left it in s_claim
             }
         }
         a.claims_out[tid] = c;
