@@ -245,25 +245,38 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, unsigned char *smem
     };
     F t0v = f_zero(), t0m = f_zero(), t0a = f_zero();
     const int t0cb = wu < a.n_tab ? tab_fetch(wu, t0v, t0m, t0a) : -1;
-    // ---- phase 1: block partials of the fold / k_seg launches, one round per wave, 256 blocks per memory round trip ----
+    // ---- phase 1: block partials of the fold / k_seg launches, one round per wave, 256 blocks per memory round trip.  The launch
+    // descriptors come with ONE vector load (lane d holds pd[d]): read as scalars in the loop they cost a scalar-cache miss each. ----
+    int pd_k0 = 0, pd_nr = 0; u32 pd_nb = 0, pd_off = 0;
+    if (lane < a.n_pd) { pd_k0 = a.pd[lane].k0; pd_nr = a.pd[lane].nr; pd_nb = a.pd[lane].nblk; pd_off = a.pd[lane].off; }
+    const int n_pd = a.n_pd;
+    const F *part = a.part;
     for (int k = wu + 1; k <= a.rounds; k += VP_EMIT_WAVES) {
         F ca = f_zero(), cbv = f_zero(), cc = f_zero();
-        for (int d = 0; d < a.n_pd; ++d) {
-            if (k < a.pd[d].k0 || k >= a.pd[d].k0 + a.pd[d].nr) continue;
-            const u32 nb = a.pd[d].nblk;
-            const F *pp = a.part + a.pd[d].off + (size_t) (k - a.pd[d].k0) * nb * 3;
-            for (u32 i0 = 0; i0 < nb; i0 += 256) {
+        for (int d = 0; d < n_pd; ++d) {
+            const int k0 = __builtin_amdgcn_readlane(pd_k0, d), nr = __builtin_amdgcn_readlane(pd_nr, d);
+            if (k < k0 || k >= k0 + nr) continue;
+            const u32 nb = (u32) __builtin_amdgcn_readlane((int) pd_nb, d);
+            const F *pp = part + (u32) __builtin_amdgcn_readlane((int) pd_off, d) + (size_t) (k - k0) * nb * 3;
+            // the region of a round is nb x (a, b, c) = 3 nb consecutive elements: read as such (a lane taking element 3 i + c of block
+            // i fetches every cache line three times — measured: 5-9 us for the first round of a 512-block launch).  64 = 1 mod 3, so
+            // the t-th load of a lane always sees component (lane + t) mod 3: three accumulators, rotated back at the end.
+            const u32 nF = 3 * nb;
+            F A0 = f_zero(), A1 = f_zero(), A2 = f_zero();
+            for (u32 e0 = 0; e0 < nF; e0 += 768) {
                 F x[4][3];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const u32 i = i0 + 64 * q + lane;
-                    const bool ok = i < nb;
+                for (int u = 0; u < 4; ++u) {
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) x[q][c] = ok ? pp[3 * i + c] : f_zero();
+                    for (int t = 0; t < 3; ++t) { const u32 e = e0 + 192 * u + 64 * t + lane; x[u][t] = e < nF ? pp[e] : f_zero(); }
                 }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { ca = f_add(ca, x[q][0]); cbv = f_add(cbv, x[q][1]); cc = f_add(cc, x[q][2]); }
+                for (int u = 0; u < 4; ++u) { A0 = f_add(A0, x[u][0]); A1 = f_add(A1, x[u][1]); A2 = f_add(A2, x[u][2]); }
             }
+            const int rot = lane % 3;
+            ca = f_add(ca, rot == 0 ? A0 : rot == 1 ? A2 : A1);
+            cbv = f_add(cbv, rot == 0 ? A1 : rot == 1 ? A0 : A2);
+            cc = f_add(cc, rot == 0 ? A2 : rot == 1 ? A1 : A0);
         }
         ca = wave_sum63(ca); cbv = wave_sum63(cbv); cc = wave_sum63(cc);
         if (lane == 63) { psum[3 * (k - 1)] = ca; psum[3 * (k - 1) + 1] = cbv; psum[3 * (k - 1) + 2] = cc; }
@@ -292,6 +305,7 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, unsigned char *smem
         F *tv = T(0, j), *tm = T(1, j), *ta = T(2, j);
         const u32 narr = a.has_a ? 3u : 2u;
         int s_done = 0;
+        F retire_mv = f_zero();
         for (int sl = 0; sl < S; ++sl) {
             const int k = td.enter + sl;
             if (k > a.rounds) break;
@@ -313,17 +327,21 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, unsigned char *smem
             const int e = 31 - __builtin_clz((u32) lane | 1u);
             const int sl = S - 1 - e;
             F ca = f_zero(), cbv = f_zero(), cc = f_zero();
+            F y = f_zero();
+            if (lane == 0 && s_done == S) y = f_mul(tm[2 * len0 - 2], tv[2 * len0 - 2]);        // idle in the pair pass: the retiring entry's m v
             if (lane >= 1 && (u32) lane < len0 && sl < s_done) {
                 const u32 pp = (u32) lane - (1u << e);
                 const u32 so = 2 * len0 - ((2 * len0) >> sl);
                 const F m0 = tm[so + 2 * pp], m1 = tm[so + 2 * pp + 1], v0 = tv[so + 2 * pp], v1 = tv[so + 2 * pp + 1];
-                const F qa = f_mul(f_sub(m1, m0), f_sub(v1, v0)), qc = f_mul(m0, v0), y = f_mul(m1, v1);
+                const F qa = f_mul(f_sub(m1, m0), f_sub(v1, v0)), qc = f_mul(m0, v0);
+                y = f_mul(m1, v1);
                 ca = qa; cc = qc; cbv = f_sub(f_sub(y, qa), qc);
                 if (a.has_a) { const F a0 = ta[so + 2 * pp], a1 = ta[so + 2 * pp + 1]; cc = f_add(cc, a0); cbv = f_add(cbv, f_sub(a1, a0)); }
             }
+            retire_mv = y;
             u64 acc[6] = {ca.re, ca.im, cbv.re, cbv.im, cc.re, cc.im};
-#pragma unroll
-            for (int st = 0; st < 5; ++st) {                   // at most 8 canonical limbs are added before a fold
+#pragma unroll 1
+            for (int st = 0; st < S - 1; ++st) {               // the largest level has 2^(S-1) pairs; at most 8 canonical limbs are added before a fold
                 const bool take = (1 << st) < (1 << e);
 #pragma unroll
                 for (int q = 0; q < 6; ++q) { const u64 o = __shfl_xor(acc[q], 1 << st, 64); acc[q] += take ? o : 0ull; }
@@ -347,7 +365,7 @@ __device__ __forceinline__ void emit_body(const EmitArgs &a, unsigned char *smem
             if (td.exp) { F *o = a.exp_out + 3 * (size_t) (td.exp - 1); o[0] = v; o[1] = m; o[2] = ad; }       // a slice: neither claim nor add_term here
             else {
                 s_claim[j] = v;
-                if (k <= a.rounds) { s_retv[j] = f_add(f_mul(v, m), ad); s_retk[j] = k; }
+                if (k <= a.rounds) { s_retv[j] = f_add(S > 0 ? retire_mv : f_mul(v, m), ad); s_retk[j] = k; }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
