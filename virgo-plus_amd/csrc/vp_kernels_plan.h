@@ -27,8 +27,7 @@ namespace vp {
 #define VP_SEG_LOG 10           // 1024-entry segments (120 KB of LDS, one workgroup per CU); 9 = 512 entries, two per CU, was measured: no gain
 #endif
 #define VP_SEG (1 << VP_SEG_LOG)
-#define VP_SEG_THREADS 768          // 12 waves = 4 groups x 3 roles
-#define VP_SEG_SLOTS 256            // a group covers 64 pair slots
+#define VP_SEG_THREADS 768          // 12 waves
 
 struct SegTab {
     u32 off;          // table offset (same in input and output buffers)
@@ -48,27 +47,23 @@ struct SegArgs {
     SegTab t[VP_MAX_TAB];
 };
 
-// Round s of a 1024-entry segment has min(256, 512 >> s) active pair slots; their per-lane accumulators live in
-// LDS at racc_off(s) + slot (767 slots per role in all), so the round loop stays ROLLED: the whole kernel is a
-// few KB of code and stays in the instruction cache (the unrolled version was 62 KB and ran fetch-bound).
-#define VP_SEG_RACC (VP_SEG_LOG >= 9 ? 256 * (VP_SEG_LOG - 9) + 512 : VP_SEG / 2)      /* slots per role: sum of racc_cnt over the rounds (+1) */
-__device__ __forceinline__ u32 racc_cnt(int s) { return min(256u, (u32) (VP_SEG / 2) >> s); }       // active pair slots of round s
-__device__ __forceinline__ u32 racc_off(int s) {                     // sum of racc_cnt over earlier rounds
-    u32 o = 0;
-    for (int q = 0; q < s; ++q) o += racc_cnt(q);
-    return o;                                                        // SEG 1024: 0,256,512,640,...,766   SEG 512: 0,256,384,...,510
-}
-
-// Wave-uniform roles, one code path: role t folds table t (0: V, 1: mult, 2: add) and computes one of the three
-// products of the pair: 0: (m1-m0)(v1-v0)   1: m0*v0   2: m1*v1.  Two multiplies per lane and pair.
-struct SegLds { F bufA[3][VP_SEG]; F bufB[3][VP_SEG / 2]; F racc[4][VP_SEG_RACC]; F rr[VP_SEG_LOG + 1]; };   // racc: [role][slot]; [3] = role 2's second sum (a0)
+// A segment of S = 2^R entries is closed in two passes (the challenges are on the tape):
+//   (1) the fold chain, the only serial part: level s+1 = level s folded with r_s — ONE multiplication per lane and round (the V, mult
+//       and add folds of a pair are three tasks), a workgroup barrier per round while a round has more than 64 tasks, then wave 0 alone;
+//       every level is kept: table t lives in a pyramid of 2 S slots, level s at offset 2 S - (2 S >> s);
+//   (2) the three products of ALL S - 1 pairs of the pyramid, pair i (level R-1-floor(log2 i), index i - 2^floor(log2 i)) on lane i:
+//       blocks of 64 pairs from i = 64 on lie inside one level (a wave sum), the first block holds levels of 1..32 pairs (butterfly
+//       inside each aligned lane block).  Every wave keeps its round sums (wsum[round][wave]) across all the segments it works on.
+// Round by round with wave-uniform roles and a barrier per round (the previous form) a 1024-entry segment took ~20 us, most of it the
+// latency of rounds with fewer pairs than lanes; the chain costs ~0.4 us per round.
+struct SegLds { F pyr[3][2 * VP_SEG]; F wsum[VP_SEG_LOG][VP_SEG_THREADS / 64][3]; F rr[VP_SEG_LOG + 1]; };
 template <bool HAS_A>
 __device__ __forceinline__ void seg_body(const SegArgs &a, u32 bid, u32 nb, SegLds &sm) {
-    F (&bufA)[3][VP_SEG] = sm.bufA; F (&bufB)[3][VP_SEG / 2] = sm.bufB; F (&racc)[4][VP_SEG_RACC] = sm.racc;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int role = __builtin_amdgcn_readfirstlane(w % 3);
-    const u32 pslot = (u32) ((w / 3) * 64 + lane);
-    for (int i = tid; i < 4 * VP_SEG_RACC; i += VP_SEG_THREADS) (&racc[0][0])[i] = f_zero();
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    constexpr int NW = VP_SEG_THREADS / 64;
+    constexpr u32 NARR = HAS_A ? 3u : 2u;
+    for (int i = tid; i < VP_SEG_LOG * NW * 3; i += VP_SEG_THREADS) (&sm.wsum[0][0][0])[i] = f_zero();
     if (tid < a.n_rounds) sm.rr[tid] = a.r[tid];          // the challenges of this launch: one LDS read per round instead of a global load on the round's critical path
     __syncthreads();
 
@@ -83,68 +78,86 @@ __device__ __forceinline__ void seg_body(const SegArgs &a, u32 bid, u32 nb, SegL
         const u32 vseg = td.valid > q * S ? min(td.valid - q * S, S) : 0;     // valid entries of this segment
         for (u32 i = tid; i < S; i += VP_SEG_THREADS) {
             const bool ok = i < vseg;
-            bufA[0][i] = ok ? a.inV[base + i] : f_zero();
-            bufA[1][i] = ok ? a.inM[base + i] : f_zero();
-            if (HAS_A) bufA[2][i] = ok ? a.inA[base + i] : f_zero();
+            sm.pyr[0][i] = ok ? a.inV[base + i] : f_zero();
+            sm.pyr[1][i] = ok ? a.inM[base + i] : f_zero();
+            if (HAS_A) sm.pyr[2][i] = ok ? a.inA[base + i] : f_zero();
         }
         __syncthreads();
+        // ---- (1) the chain ----
 #pragma unroll 1
         for (int s = 0; s < R; ++s) {
-            const F *src = (s & 1) ? &bufB[0][0] : &bufA[0][0];
-            F *dst = (s & 1) ? &bufA[0][0] : &bufB[0][0];
-            const u32 sstr = (s & 1) ? VP_SEG / 2 : VP_SEG, dstr = (s & 1) ? VP_SEG : VP_SEG / 2;
-            const F rs = sm.rr[s];
             const u32 n = S >> (s + 1);                                   // pairs of this round
-            const u32 vs = (vseg + (1u << s) - 1) >> s;                   // valid entries of this round
-            const u32 act = (vs + 1) >> 1;                                // pairs that can be non-zero
-            const bool folds = HAS_A || role != 2;
-            const u32 ai = racc_off(s) + pslot;
-            F acc = f_zero(), acc2 = f_zero();
-            for (u32 p = pslot; p < n; p += VP_SEG_SLOTS) {
-                if (p >= act) { if (folds) dst[role * dstr + p] = f_zero(); continue; }
-                F c0 = f_zero(), c1 = f_zero();
-                if (folds) { c0 = src[role * sstr + 2 * p]; c1 = src[role * sstr + 2 * p + 1]; }
-                const F d = f_sub(c1, c0);
-                F x, y;
-                if (role == 0) { x = f_sub(src[sstr + 2 * p + 1], src[sstr + 2 * p]); y = d; }
-                else if (role == 1) { x = c0; y = src[2 * p]; }
-                else { x = src[sstr + 2 * p + 1]; y = src[2 * p + 1]; }
-                F qv = f_mul(x, y);
-                if (role == 2 && HAS_A) { qv = f_add(qv, d); acc2 = f_add(acc2, c0); }
-                acc = f_add(acc, qv);
-                if (folds) dst[role * dstr + p] = f_add(c0, f_mul(rs, d));
+            const int lg = R - s - 1;
+            const u32 so = 2 * S - ((2 * S) >> s), dof = 2 * S - ((2 * S) >> (s + 1));
+            const bool wide = NARR * n > 64;
+            if (wide || wu == 0) {
+                const F rs = sm.rr[s];
+                for (u32 t = (u32) tid; t < NARR * n; t += VP_SEG_THREADS) {
+                    F *tb = sm.pyr[t >> lg];
+                    const u32 p = t & (n - 1);
+                    const F x0 = tb[so + 2 * p], x1 = tb[so + 2 * p + 1];
+                    tb[dof + p] = f_add(x0, f_mul(rs, f_sub(x1, x0)));
+                }
             }
-            if (pslot < n) {
-                racc[role][ai] = f_add(racc[role][ai], acc);
-                if (role == 2 && HAS_A) racc[3][ai] = f_add(racc[3][ai], acc2);
-            }
-            __syncthreads();
+            if (wide) __syncthreads();
+            else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }      // wave 0 finishes the chain alone
         }
+        __syncthreads();
         // the segment is down to one entry per table
         if (tid < 3 && q * S < td.valid) {
-            const F *fin = (R & 1) ? bufB[tid] : bufA[tid];
-            if (tid == 0) a.outV[td.off + q] = fin[0];
-            else if (tid == 1) a.outM[td.off + q] = fin[0];
-            else if (HAS_A) a.outA[td.off + q] = fin[0];
+            const u32 lo = 2 * S - 2;
+            if (tid == 0) a.outV[td.off + q] = sm.pyr[0][lo];
+            else if (tid == 1) a.outM[td.off + q] = sm.pyr[1][lo];
+            else if (HAS_A) a.outA[td.off + q] = sm.pyr[2][lo];
+        }
+        // ---- (2) the products of every level ----
+        for (u32 i0 = 64 * (u32) wu; i0 < S; i0 += VP_SEG_THREADS) {       // wave-uniform: blocks of 64 pair slots
+            const u32 i = i0 + lane;
+            const int e = 31 - __builtin_clz(i | 1u);
+            const int s = R - 1 - e;
+            F ca = f_zero(), cbv = f_zero(), cc = f_zero();
+            if (i >= 1 && i < S) {
+                const u32 p = i - (1u << e);
+                const u32 so = 2 * S - ((2 * S) >> s);
+                const F m0 = sm.pyr[1][so + 2 * p], m1 = sm.pyr[1][so + 2 * p + 1], v0 = sm.pyr[0][so + 2 * p], v1 = sm.pyr[0][so + 2 * p + 1];
+                const F qa = f_mul(f_sub(m1, m0), f_sub(v1, v0)), qc = f_mul(m0, v0), y = f_mul(m1, v1);
+                ca = qa; cc = qc; cbv = f_sub(f_sub(y, qa), qc);
+                if (HAS_A) { const F a0 = sm.pyr[2][so + 2 * p], a1 = sm.pyr[2][so + 2 * p + 1]; cc = f_add(cc, a0); cbv = f_add(cbv, f_sub(a1, a0)); }
+            }
+            if (i0 >= 64) {                                               // one level: pairs [i0, i0 + 64) of level floor(log2 i0)
+                ca = wave_sum63(ca); cbv = wave_sum63(cbv); cc = wave_sum63(cc);
+                if (lane == 63) {
+                    F *o = sm.wsum[s][wu];
+                    o[0] = f_add(o[0], ca); o[1] = f_add(o[1], cbv); o[2] = f_add(o[2], cc);
+                }
+            } else {                                                      // levels of 1, 2, .. 32 pairs: lane block [2^e, 2^(e+1))
+                u64 acc[6] = {ca.re, ca.im, cbv.re, cbv.im, cc.re, cc.im};
+                const int steps = min(R - 1, 5);
+#pragma unroll 1
+                for (int st = 0; st < steps; ++st) {                      // at most 8 canonical limbs are added before a fold
+                    const bool take = (1 << st) < (1 << e);
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) { const u64 o = __shfl_xor(acc[c], 1 << st, 64); acc[c] += take ? o : 0ull; }
+                    if (st == 2) {
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) acc[c] = m_fold(acc[c]);
+                    }
+                }
+                if (i >= 1 && i < S && i == (1u << e)) {
+                    F *o = sm.wsum[s][wu];
+                    o[0] = f_add(o[0], f_make(m_fold(acc[0]), m_fold(acc[1])));
+                    o[1] = f_add(o[1], f_make(m_fold(acc[2]), m_fold(acc[3])));
+                    o[2] = f_add(o[2], f_make(m_fold(acc[4]), m_fold(acc[5])));
+                }
+            }
         }
         __syncthreads();
     }
-    // per-round block partials: wave q sums one (round, array) list of <= 256 slots, then 3 lanes per round combine
-    F *res = &bufA[0][0];                                        // [s][4]
-    for (int t = w; t < a.n_rounds * 4; t += VP_SEG_THREADS / 64) {
-        const int s = t >> 2, arr = t & 3;
-        const u32 cnt = racc_cnt(s), o = racc_off(s);
-        F x = f_zero();
-        for (u32 i = lane; i < cnt; i += 64) x = f_add(x, racc[arr][o + i]);
-        x = wave_sum63(x);
-        if (lane == 63) res[t] = x;
-    }
-    __syncthreads();
+    // per-round block partials, as the reference orders the coefficients: a = sum dm dv, b = sum (m1 v1 + da) - a - sum m0 v0, c = sum (m0 v0 + a0)
     if (tid < 3 * a.n_rounds) {
         const int s = tid / 3, c = tid % 3;
-        const F R0 = res[s * 4], R1 = res[s * 4 + 1], R2 = res[s * 4 + 2], R3 = res[s * 4 + 3];
-        // a = sum dm*dv;  b = sum (m1*v1 + da) - a - sum m0*v0;  c = sum m0*v0 + sum a0
-        const F x = c == 0 ? R0 : c == 1 ? f_sub(R2, f_add(R0, R1)) : f_add(R1, R3);
+        F x = f_zero();
+        for (int q = 0; q < NW; ++q) x = f_add(x, sm.wsum[s][q][c]);
         a.part[(size_t) s * a.part_stride + bid * 3 + c] = x;
     }
 }
