@@ -369,7 +369,8 @@ def test_sha256_x64_full_size(vp, golden, gold_gkr, pws_path):
 
 
 @pytest.mark.parametrize("layers,log_size,seed", [(2, 0, 1), (2, 1, 2), (3, 1, 3), (3, 2, 4), (4, 3, 5), (5, 4, 6), (6, 5, 7),
-                                                   (9, 2, 8), (12, 3, 9), (3, 9, 10), (4, 13, 11)])
+                                                   (9, 2, 8), (12, 3, 9), (3, 9, 10), (4, 13, 11),
+                                                   (24, 7, 12), (40, 8, 13)])          # deep: the closing launch holds 32 / 16 entries per table
 def test_small_and_ragged_circuits_vs_oracle(vp, ob, layers, log_size, seed):
     """Edge cases: single-entry tables, empty subsets, tables that retire into add_term early,
     zero-round phases (SURVEY.md §7 'loader quirks')."""
