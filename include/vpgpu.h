@@ -100,6 +100,8 @@ typedef struct {
                                        and returns without waiting; the first vp_round of the phase collects the answer          [1] */
     int32_t split_cost_percent;     /* VP_SPLIT_COST_PERCENT: vp_set_shard_split cuts a chain by index only if its cost estimate exceeds this
                                        percentage of one rank's fair share of the proof (total / world); 0 = every chain with a long table  [50] */
+    int32_t kernel_copies;          /* VP_KERNEL_COPIES: vp_prove_gkr moves the tape in and the transcript out with two small kernels on pinned host
+                                       memory (the second one also publishes the completion ticket) instead of two copy-engine commands  [1] */
 } vp_options;
 void vp_options_default(vp_options *opt);
 

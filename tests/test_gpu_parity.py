@@ -993,7 +993,8 @@ def test_options_struct_selects_the_same_alternatives_as_the_test_environment(vp
     assert d.struct_size == ctypes.sizeof(vp.Options) and d.sf_rounds == 3 and d.drop_y == 1 and d.persistent_rounds == 1
     launches = {}
     for name, kw in (("default", {}), ("four_rounds", {"sf_rounds": 4}), ("keep_y", {"drop_y": 0}), ("complex_products", {"real_values": 0}),
-                     ("lanes", {"gkr_path": vp.PATH_LANES}), ("simple", {"gkr_path": vp.PATH_SIMPLE}), ("no_graph", {"use_graph": 0, "serial": 1})):
+                     ("lanes", {"gkr_path": vp.PATH_LANES}), ("simple", {"gkr_path": vp.PATH_SIMPLE}), ("no_graph", {"use_graph": 0, "serial": 1}),
+                     ("copy_engine", {"kernel_copies": 0}), ("blocking_wait", {"poll": 0})):
         s = vp.Session(c, options=vp.Options(**kw))
         s.draw_tape()
         tr, res = s.prove_gkr()

@@ -514,6 +514,20 @@ __global__ void k_ticket(unsigned long long *seq_host, unsigned long long seq) {
     __hip_atomic_store(seq_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// The ends of a batched proof without the copy engine: the tape is read straight out of pinned host memory into its device buffer,
+// the transcript is written straight into pinned host memory and the ticket published by the same kernel (a hipMemcpyAsync on either
+// side is a separate command with ~8 us of its own latency, and the copy back needed a ticket launch behind it).
+__global__ void __launch_bounds__(256) k_tape_in(const F *__restrict__ host_tape, F *__restrict__ dev_tape, u32 n) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dev_tape[i] = host_tape[i];
+}
+__global__ void __launch_bounds__(1024) k_ship(const F *__restrict__ dev, F *__restrict__ host, u32 n, unsigned long long *seq_host, unsigned long long seq) {
+    for (u32 i = threadIdx.x; i < n; i += blockDim.x) host[i] = dev[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(seq_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Finalize (src/prover.cpp:494-521): the claim of table j is its V table folded down to one value.
 // `cur` holds the tables after the last round; tables that ran out earlier left their value in scalarV.
 struct FinArgs {
