@@ -568,7 +568,20 @@ __global__ void __launch_bounds__(VP_BLOCK) k_dot_multi(const DotJob *__restrict
     const BlkMap m = map[blockIdx.x];
     const DotJob &j = jobs[m.job];
     F acc[1] = {f_zero()};
-    if (j.vreal) for (u32 i = m.bid * blockDim.x + threadIdx.x; i < j.size; i += j.nblk * blockDim.x) acc[0] = f_mad31c_rb<false>(half_at(j.h, i), j.val[i].re, acc[0]);
+    const u32 H = 1u << j.h.h1;
+    if (H >= blockDim.x) {
+        // eq(r, i) = bf[i mod H] * bs[i div H]: the second factor is common to a run of H consecutive entries, so a workgroup takes whole
+        // runs — every thread adds up bf[lo] * V[hi H + lo] over its share of a run and multiplies by bs[hi] once (real values: 8 + 16/k
+        // multiplier instructions per entry instead of 24; the kernel was as much multiplier- as memory-bound)
+        const u32 runs = (j.size + H - 1) >> j.h.h1;
+        for (u32 hb = m.bid; hb < runs; hb += j.nblk) {
+            const u32 base = hb << j.h.h1, lim = min(H, j.size - base);
+            F in = f_zero();
+            if (j.vreal) for (u32 lo = threadIdx.x; lo < lim; lo += blockDim.x) in = f_mad31c_rb<false>(j.h.bf[lo], j.val[base + lo].re, in);
+            else for (u32 lo = threadIdx.x; lo < lim; lo += blockDim.x) in = f_add(in, f_mul(j.h.bf[lo], j.val[base + lo]));
+            acc[0] = f_add(acc[0], f_mul(in, j.h.bs[hb]));
+        }
+    } else if (j.vreal) for (u32 i = m.bid * blockDim.x + threadIdx.x; i < j.size; i += j.nblk * blockDim.x) acc[0] = f_mad31c_rb<false>(half_at(j.h, i), j.val[i].re, acc[0]);
     else for (u32 i = m.bid * blockDim.x + threadIdx.x; i < j.size; i += j.nblk * blockDim.x) acc[0] = f_add(acc[0], f_mul(half_at(j.h, i), j.val[i]));
     block_sum<1>(acc, lds);
     if (threadIdx.x == 0) j.part[m.bid] = acc[0];
