@@ -12,14 +12,13 @@
 // — not the 288 B per pair — sets the time of every table that does not fill the chip.  Hence:
 //   * k_seg: a workgroup stages a SEGMENT of <= 1024 consecutive entries of V/mult/add in LDS (coalesced
 //     1 KiB wave loads) and runs log2(segment) rounds on it without leaving the CU; ten rounds cost
-//     48 B/entry of HBM reads and 48 B per 1024 entries of writes.  Inside a round the work is split at
-//     F-multiply granularity with WAVE-UNIFORM roles (no divergence): wave role 0: dm*dv + fold V,
-//     1: m0*v0 + fold mult, 2: m1*v1, 3: fold add + its two sums — the chain per round is two multiplies
-//     instead of nine.  Round sums stay in registers (one accumulator per round, rounds unrolled) across
-//     all segments a persistent workgroup processes and are reduced once at the end.
+//     48 B/entry of HBM reads and 48 B per 1024 entries of writes.  The challenges are on the tape, so only
+//     the fold x0 + r (x1 - x0) is serial: the chain of folds runs first, one multiplication per lane and
+//     round with every level kept in LDS, then the three products of all pairs of all levels in one pass
+//     (seg_body below).
 //   * k_emit: one workgroup finishes the sumcheck: it owns every table that is down to <= 2^e entries
-//     (LDS resident), adds the block partials of the k_seg launches, retires finished tables into
-//     add_term and writes all round polynomials and the claims.
+//     (LDS resident, one wave per table, same two passes), adds the block partials of the fold / k_seg
+//     launches, retires finished tables into add_term and writes all round polynomials and the claims.
 // ===================================================================================================
 namespace vp {
 
@@ -169,13 +168,14 @@ __global__ void __launch_bounds__(VP_SEG_THREADS) k_seg(SegArgs a) {
 
 // ---------------------------------------------------------------------------------------------------
 // k_emit: one workgroup closes a sumcheck.
-//   phase 1  all waves in parallel: reduce the block partials the k_seg launches wrote, one round per wave;
-//   phase 2  only for rounds in which a table owned by this kernel has work: pair products + folds on the
-//            LDS-resident tables (wave-uniform roles), wave sums parked in LDS, one barrier per round;
-//   phase 3  totals per (round, coefficient) in parallel, the add_term recurrence (src/prover.cpp:445,
-//            462-467) by one lane, polynomials and claims written out by parallel lanes.
+//   phase 0/1  one wave per table fetches it into LDS while the same wave adds up its share of the block partials the fold and
+//              k_seg launches wrote (one round per wave, contiguous reads);
+//   phase 2    a table per wave, no workgroup barrier: fold chain first, then the products of all its levels in one pass;
+//   phase 3    totals per (round, coefficient) in parallel; the add_term recurrence (src/prover.cpp:445, 462-467) and the
+//              recurrence that restores the b's the fold launches left out, both as affine wave scans; polynomials and claims
+//              written out by parallel lanes.
 // ---------------------------------------------------------------------------------------------------
-#define VP_EMIT_THREADS 768         // 12 waves = 4 groups x 3 roles
+#define VP_EMIT_THREADS 768         // 12 waves
 #define VP_EMIT_WAVES (VP_EMIT_THREADS / 64)
 #define VP_MAX_PD 24
 #define VP_EMIT_CAP 1280            // LDS entries per buffer per table family (2 x 3 x 1280 x 16 B = 120 KiB)
