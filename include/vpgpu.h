@@ -102,6 +102,8 @@ typedef struct {
                                        percentage of one rank's fair share of the proof (total / world); 0 = every chain with a long table  [50] */
     int32_t kernel_copies;          /* VP_KERNEL_COPIES: vp_prove_gkr moves the tape in and the transcript out with two small kernels on pinned host
                                        memory (the second one also publishes the completion ticket) instead of two copy-engine commands  [1] */
+    int32_t fold_branches;          /* VP_FOLD_BRANCHES: a fold node of the launch plan that does not depend on the fold node queued before it runs on
+                                       another stream instead of behind it                                                         [1] */
 } vp_options;
 void vp_options_default(vp_options *opt);
 
