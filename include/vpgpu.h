@@ -104,6 +104,9 @@ typedef struct {
                                        memory (the second one also publishes the completion ticket) instead of two copy-engine commands  [1] */
     int32_t fold_branches;          /* VP_FOLD_BRANCHES: a fold node of the launch plan that does not depend on the fold node queued before it runs on
                                        another stream instead of behind it                                                         [1] */
+    int32_t ntt_scatter;            /* VP_NTT_SCATTER: the second pass of a long transform (> 2^13 points) stores its results in natural order itself
+                                       (16-byte pieces at stride N1, merged into whole lines in the L2 of the XCD that runs all N1 sub-transforms of
+                                       one transform) instead of a third, transposing pass                                        [1] */
 } vp_options;
 void vp_options_default(vp_options *opt);
 

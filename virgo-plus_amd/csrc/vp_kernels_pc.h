@@ -36,6 +36,11 @@ struct NttArgs {
     int inverse;
     u32 in_stride;                        // elements between consecutive input rows
     F inv_n;                              // inverse mode: N^-1
+    // Second pass of a long transform (N = N1 x 2^ln, see k_ntt_split) writing the result in natural order itself: block b is sub-transform
+    // k1 = (b / 8) % N1 of long transform (b / 8 / N1) * 8 + b % 8 — the N1 sub-transforms of one long transform run on ONE XCD (workgroups
+    // are dealt round-robin over the 8 XCDs), so that the 16-byte pieces they store at stride N1 (element k2 goes to k1 + N1 k2) meet in that
+    // XCD's L2 and leave it as whole lines.  scat_l1 = log2 N1 (0: off), scat_rows = number of long transforms, scat_scale applied if nonzero.
+    int scat_l1; u32 scat_rows; int scat_do_scale; F scat_scale;
 };
 // Multiplication by the primitive fourth root of unity iota = w_M^(M/4) = (0, +-1) of F_p[i]: a swap and a negation.
 // plus: iota == (0, 1).  NEG: multiply by -iota = iota^-1 instead (inverse transforms).
@@ -50,7 +55,15 @@ __device__ __forceinline__ F mul_iota(const F &x, bool plus) {
 __global__ void __launch_bounds__(1024) k_ntt_lds(NttArgs a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     F *L = reinterpret_cast<F *>(smem_raw);
-    const u32 N = 1u << a.ln, row = blockIdx.x, coset = blockIdx.y, tid = threadIdx.x, nth = blockDim.x;
+    const u32 N = 1u << a.ln, coset = blockIdx.y, tid = threadIdx.x, nth = blockDim.x;
+    u32 row = blockIdx.x, long_row = 0, k1 = 0;
+    if (a.scat_l1) {
+        const u32 x = blockIdx.x & 7u, sidx = blockIdx.x >> 3;
+        k1 = sidx & ((1u << a.scat_l1) - 1);
+        long_row = (sidx >> a.scat_l1) * 8 + x;
+        if (long_row >= a.scat_rows) return;                  // uniform: padding of the last group of eight
+        row = (long_row << a.scat_l1) + k1;
+    }
     const u32 M = 2 * a.half_m;
     const u32 wstride = M >> a.ln;                          // w_N = w_M^wstride
     const F *src = a.in + (size_t) row * a.in_stride;
@@ -96,6 +109,11 @@ __global__ void __launch_bounds__(1024) k_ntt_lds(NttArgs a) {
             L[i0] = f_add(s0, s1); L[i0 + q] = f_add(d0, d1); L[i0 + 2 * q] = f_sub(s0, s1); L[i0 + 3 * q] = f_sub(d0, d1);
         }
         __syncthreads();
+    }
+    if (a.scat_l1) {
+        F *dst = a.out + ((size_t) long_row << (a.ln + a.scat_l1)) + k1;
+        for (u32 k = tid; k < N; k += nth) dst[(size_t) k << a.scat_l1] = a.scat_do_scale ? f_mul(L[k], a.scat_scale) : L[k];
+        return;
     }
     F *dst = a.inverse ? a.out + (size_t) row * N : a.out + ((size_t) row * gridDim.y + coset) * N;
     for (u32 k = tid; k < N; k += nth) dst[k] = a.inverse ? f_mul(L[k], a.inv_n) : L[k];
