@@ -562,7 +562,7 @@ __global__ void __launch_bounds__(VP_BLOCK) k_pred_combine(const u32 *__restrict
 
 // V_u = V(r_u) = sum_u eq(r_u, u) * V[u] (what phase 1's last fold leaves in the V table, src/prover.cpp:494-500) as an inner
 // product: with it phase 2 of a layer no longer waits for phase 1's sumcheck, every sumcheck of the proof is independent.
-struct DotJob { Half h; const F *val; F *part; F *out; u32 size, nblk; int vreal, pad; };     // vreal: val[] are real circuit values
+struct DotJob { Half h; const F *val; F *part; F *out; u32 size, nblk; int vreal, pad; const unsigned long long *valr; };     // vreal: val[] are real circuit values; valr: their real parts as a dense array
 __global__ void __launch_bounds__(VP_BLOCK) k_dot_multi(const DotJob *__restrict__ jobs, const BlkMap *__restrict__ map) {
     __shared__ F lds[4];
     const BlkMap m = map[blockIdx.x];
@@ -577,7 +577,8 @@ __global__ void __launch_bounds__(VP_BLOCK) k_dot_multi(const DotJob *__restrict
         for (u32 hb = m.bid; hb < runs; hb += j.nblk) {
             const u32 base = hb << j.h.h1, lim = min(H, j.size - base);
             F in = f_zero();
-            if (j.vreal) for (u32 lo = threadIdx.x; lo < lim; lo += blockDim.x) in = f_mad31c_rb<false>(j.h.bf[lo], j.val[base + lo].re, in);
+            if (j.vreal && j.valr) for (u32 lo = threadIdx.x; lo < lim; lo += blockDim.x) in = f_mad31c_rb<false>(j.h.bf[lo], j.valr[base + lo], in);
+            else if (j.vreal) for (u32 lo = threadIdx.x; lo < lim; lo += blockDim.x) in = f_mad31c_rb<false>(j.h.bf[lo], j.val[base + lo].re, in);
             else for (u32 lo = threadIdx.x; lo < lim; lo += blockDim.x) in = f_add(in, f_mul(j.h.bf[lo], j.val[base + lo]));
             acc[0] = f_add(acc[0], f_mul(in, j.h.bs[hb]));
         }

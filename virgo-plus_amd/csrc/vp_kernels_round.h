@@ -112,6 +112,12 @@ __global__ void __launch_bounds__(VP_BLOCK) k_mark_complex(const F *__restrict__
     if (i < n && v[i].im) atomicOr(vcplx, 1u);
 }
 
+// real parts of a layer's values as a dense 8-byte array (the inner products V_u / V_res of an all-real circuit read half the bytes)
+__global__ void __launch_bounds__(VP_BLOCK) k_real_parts(const F *__restrict__ v, u32 n, unsigned long long *__restrict__ out) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = v[i].re;
+}
+
 __global__ void k_check_asserts(const u32 *__restrict__ idx, u32 n, const F *__restrict__ val, int *flag) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && !f_is_zero(val[idx[i]])) atomicOr(flag, 1);

@@ -32,6 +32,7 @@ struct LayerDev {
     u64 size = 0;
     int bl = 0;
     F *val = nullptr;                       // circuitValue[i]
+    unsigned long long *valr = nullptr;     // real parts of val (all-real circuits: operand of the inner products), filled by vp_evaluate
     uint8_t *ty = nullptr; int16_t *gl = nullptr; u32 *gu = nullptr, *gv = nullptr;
     F *gc = nullptr;
     u32 n_assert = 0; u32 *assert_idx = nullptr;
@@ -926,6 +927,13 @@ int vp_evaluate(vp_ctx *ctx, const vp_F *inputs, uint64_t n_inputs) {
     HIPCHK(hipMemcpyAsync(&vcplx, ctx->d_vcplx, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
     VPCHK(check_stream(ctx));
     ctx->vreal = (vcplx == 0 && ctx->opt.real_values) ? 1 : 0;
+    if (ctx->vreal) {
+        for (int i = 0; i < ctx->n_layers; ++i) {
+            LayerDev &D = ctx->L[i];
+            if (!D.valr) VPCHK(dalloc(ctx, &D.valr, (size_t) D.size));
+            hipLaunchKernelGGL(k_real_parts, dim3(nblk(D.size)), dim3(VP_BLOCK), 0, ctx->stream, D.val, (u32) D.size, D.valr);
+        }
+    }
     float ms = 0;
     hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
     ctx->st.evaluate_ms = ms;
