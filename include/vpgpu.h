@@ -107,6 +107,11 @@ typedef struct {
     int32_t ntt_scatter;            /* VP_NTT_SCATTER: the second pass of a long transform (> 2^13 points) stores its results in natural order itself
                                        (16-byte pieces at stride N1, merged into whole lines in the L2 of the XCD that runs all N1 sub-transforms of
                                        one transform) instead of a third, transposing pass                                        [1] */
+    int32_t fuse_combine;           /* VP_FUSE_COMBINE: launch plan — the heavy rows of an init (> 16 contributions) are finished by the chunk launch itself
+                                       (single-chunk rows written directly, the last-arriving wave of a multi-chunk row adds the partials) instead of a
+                                       separate k_combine node; 2: the same, and the chain keeps the (now empty) step of that node — which launches of
+                                       different chains share a node depends on the chains' alignment, and with the step removed the replay was
+                                       slower at x64 (0.61 -> 0.64 ms) although a node had gone; 0: separate k_combine node       [2] */
 } vp_options;
 void vp_options_default(vp_options *opt);
 

@@ -135,9 +135,15 @@ __device__ __forceinline__ void init2_light_body(const InitArgs2 &a, u32 bid) {
 template <int PHASE>
 __global__ void __launch_bounds__(VP_BLOCK) k_init2_light(InitArgs2 a) { init2_light_body<PHASE>(a, blockIdx.x); }
 
+// Heavy rows finished by the chunk launch itself (ChunkFuse, plan path): a row of ONE chunk (nearly all of them) is written straight into
+// the mult / add arrays; of a row cut into several chunks the wave that arrives last adds the others' partials (written through to memory
+// with sc1 stores, counted with a relaxed agent-scope atomic per ROW — a few arrivals per counter, no fence) and resets the counter.
+struct ChunkFuse { const u32 *chunk_h; const u32 *heavy_row; const u32 *heavy_cptr; u32 *heavy_cnt; F *M; F *A; };
+__device__ __forceinline__ unsigned long long cf_ld(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void cf_st(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <int PHASE>
 __device__ __forceinline__ void init2_chunks_body(const InitArgs2 &a, const u32 *__restrict__ chunk_beg, const u32 *__restrict__ chunk_end,
-                                                  u32 n_chunks, F *__restrict__ part, u32 bid) {
+                                                  u32 n_chunks, F *__restrict__ part, u32 bid, const ChunkFuse *fuse = nullptr) {
     const u32 c = bid * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (c >= n_chunks) return;
     const int lane = threadIdx.x & 63;
@@ -146,7 +152,25 @@ __device__ __forceinline__ void init2_chunks_body(const InitArgs2 &a, const u32 
     for (u32 k = chunk_beg[c] + lane; k < chunk_end[c]; k += 64) contrib2<PHASE>(a, k, m, ad, vu);
     m = wave_sum(m);
     ad = wave_sum(ad);
-    if (lane == 0) { part[2 * c] = m; part[2 * c + 1] = ad; }
+    if (!fuse) { if (lane == 0) { part[2 * c] = m; part[2 * c + 1] = ad; } return; }
+    const u32 h = fuse->chunk_h[c], c0 = fuse->heavy_cptr[h], n = fuse->heavy_cptr[h + 1] - c0, row = fuse->heavy_row[h];
+    if (n == 1) { if (lane == 0) { fuse->M[row] = m; fuse->A[row] = ad; } return; }
+    int last = 0;
+    if (lane == 0) {
+        unsigned long long *w = reinterpret_cast<unsigned long long *>(part + 2 * c);
+        cf_st(w, m.re); cf_st(w + 1, m.im); cf_st(w + 2, ad.re); cf_st(w + 3, ad.im);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // the partial is out before it is counted
+        last = __hip_atomic_fetch_add(fuse->heavy_cnt + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n - 1;
+    }
+    last = __builtin_amdgcn_readfirstlane(last);
+    if (!last) return;
+    F tm = f_zero(), ta = f_zero();
+    for (u32 i = lane; i < n; i += 64) {
+        const unsigned long long *w = reinterpret_cast<const unsigned long long *>(part + 2 * (c0 + i));
+        tm = f_add(tm, f_make(cf_ld(w), cf_ld(w + 1))); ta = f_add(ta, f_make(cf_ld(w + 2), cf_ld(w + 3)));
+    }
+    tm = wave_sum(tm); ta = wave_sum(ta);
+    if (lane == 0) { fuse->M[row] = tm; fuse->A[row] = ta; __hip_atomic_store(fuse->heavy_cnt + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 }
 template <int PHASE>
 __global__ void __launch_bounds__(VP_BLOCK)

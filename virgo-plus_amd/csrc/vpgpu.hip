@@ -24,6 +24,7 @@ struct Csr {                 // contributions of one layer sorted by target row 
     u32 *rowptr = nullptr, *e_g = nullptr, *e_x = nullptr;
     uint16_t *e_tl = nullptr;
     u32 *heavy_row = nullptr, *heavy_cptr = nullptr, *chunk_beg = nullptr, *chunk_end = nullptr;
+    u32 *chunk_h = nullptr, *heavy_cnt = nullptr;      // heavy-row index of every chunk; arrival counters of the rows cut into several chunks (zero between proofs)
     Csr3 c3{};               // the same light contributions cut into 512-row chunks for the entry-parallel kernels
     std::vector<u32> h_heavy_row, h_heavy_cptr;      // host copies (a handful of rows): row-range init jobs of the index-split proof
 };
@@ -608,7 +609,7 @@ void vp_options_default(vp_options *o) {
     o->gkr_path = VP_PATH_PLAN; o->use_graph = 1; o->serial = 0; o->fuse_init = 1; o->fuse_min_log = 0; o->fuse_dot = 0; o->init3 = 0;
     o->drop_y = 1; o->drop_y_round1 = 0; o->real_values = 1; o->seg_tiny = 1; o->sf_rounds = 3; o->sf_big_log = 14; o->sf3b = 1;
     o->sf3b_grid = 512; o->sf_min_waves = 1; o->dot_blocks = 1024; o->plan_align = 0; o->xcd_map = 0; o->round_fused_max = 512;
-    o->persistent_rounds = 1; o->persistent_multi = 0; o->persistent_multi_shift = 13; o->poll = 1; o->debug = 0; o->prefetch_round1 = 1; o->split_cost_percent = 50; o->kernel_copies = 1; o->fold_branches = 1; o->ntt_scatter = 1;
+    o->persistent_rounds = 1; o->persistent_multi = 0; o->persistent_multi_shift = 13; o->poll = 1; o->debug = 0; o->prefetch_round1 = 1; o->split_cost_percent = 50; o->kernel_copies = 1; o->fold_branches = 1; o->ntt_scatter = 1; o->fuse_combine = 2;
 }
 // defaults <- the caller's struct (as many bytes as its header knew) <- VP_* environment variables (test-only override, read here and nowhere else)
 static void resolve_options(vp_options *o, const vp_options *user) {
@@ -633,6 +634,7 @@ static void resolve_options(vp_options *o, const vp_options *user) {
     flag("VP_KERNEL_COPIES", o->kernel_copies);
     flag("VP_FOLD_BRANCHES", o->fold_branches);
     flag("VP_NTT_SCATTER", o->ntt_scatter);
+    num("VP_FUSE_COMBINE", o->fuse_combine);
     if (getenv("VP_DEBUG")) o->debug |= 1;
     if (getenv("VP_DEBUG_UPLOAD")) o->debug |= 2;                       // bit 1: phase times of vp_circuit_upload
     if (o->sf_rounds != 4) o->sf_rounds = 3;
