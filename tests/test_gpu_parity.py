@@ -994,7 +994,8 @@ def test_options_struct_selects_the_same_alternatives_as_the_test_environment(vp
     launches = {}
     for name, kw in (("default", {}), ("four_rounds", {"sf_rounds": 4}), ("keep_y", {"drop_y": 0}), ("complex_products", {"real_values": 0}),
                      ("lanes", {"gkr_path": vp.PATH_LANES}), ("simple", {"gkr_path": vp.PATH_SIMPLE}), ("no_graph", {"use_graph": 0, "serial": 1}),
-                     ("copy_engine", {"kernel_copies": 0}), ("blocking_wait", {"poll": 0})):
+                     ("copy_engine", {"kernel_copies": 0}), ("blocking_wait", {"poll": 0}), ("fixed_layout", {"plan_autotune": 0}),
+                     ("combine_node", {"plan_autotune": 0, "fuse_combine": 0}), ("one_fold_stream", {"plan_autotune": 0, "fold_branches": 0})):
         s = vp.Session(c, options=vp.Options(**kw))
         s.draw_tape()
         tr, res = s.prove_gkr()
@@ -1007,7 +1008,9 @@ def test_options_struct_selects_the_same_alternatives_as_the_test_environment(vp
     # the alternatives really ran: one launch per round on the simple path, one stream per chain (no batched nodes) on the lanes path,
     # fewer fold launches with four rounds each
     assert launches["simple"] > 10 * launches["default"] and launches["lanes"] > launches["default"]
-    assert launches["four_rounds"] <= launches["default"] and launches["no_graph"] == launches["default"]
+    # (the default session picks its plan layout by measurement on the first proof: compare launch counts against the fixed layout)
+    assert launches["four_rounds"] <= launches["fixed_layout"] + 2 and launches["no_graph"] == launches["fixed_layout"]
+    assert launches["combine_node"] > launches["fixed_layout"]
     s = vp.Session(c, options=vp.Options(persistent_rounds=0))
     tr_i, _, ok = s.prove_interactive()
     assert ok and tr_i == gold

@@ -1,5 +1,6 @@
 #!/bin/bash
 # Development A/B of one environment switch in one call:  tools/sweep_env.sh VAR "v1 v2 ..." BLOCKS [bench args]
+# (for the plan-layout switches — VP_FUSE_COMBINE, VP_FOLD_BRANCHES, VP_PLAN_ALIGN, VP_FUSE_MIN_LOG — export VP_PLAN_AUTOTUNE=0 first)
 V=$1; VALS=$2; B=$3; shift 3
 mkdir -p gpurun_out
 for v in $VALS; do

@@ -177,6 +177,7 @@ struct vp_ctx {
                                       // launch slower (x1024 4.7 vs 3.5 ms: two more barriers per chunk at 3 workgroups per CU) -> off by default
     Plan *plan = nullptr; int plan_path = 1;   // VP_GKR_PATH=lanes: one stream per sumcheck chain instead of the plan
     // hipGraph of the concurrent GKR submission (per circuit; VP_GKR_GRAPH=0 submits the launches directly)
+    bool plan_tuned = false;         // the plan layouts have been tried on this circuit (plan_autotune)
     hipGraphExec_t gkr_graph = nullptr; int use_graph = 1; bool graph_failed = false; u64 graph_launches = 0, graph_rounds = 0;
     // one proof sharded over GPUs by sumcheck chain (vp_set_shard): this rank records and runs only the chains it owns
     int shard_rank = 0, shard_world = 1;
@@ -609,7 +610,7 @@ void vp_options_default(vp_options *o) {
     o->gkr_path = VP_PATH_PLAN; o->use_graph = 1; o->serial = 0; o->fuse_init = 1; o->fuse_min_log = 0; o->fuse_dot = 0; o->init3 = 0;
     o->drop_y = 1; o->drop_y_round1 = 0; o->real_values = 1; o->seg_tiny = 1; o->sf_rounds = 3; o->sf_big_log = 14; o->sf3b = 1;
     o->sf3b_grid = 512; o->sf_min_waves = 1; o->dot_blocks = 1024; o->plan_align = 0; o->xcd_map = 0; o->round_fused_max = 512;
-    o->persistent_rounds = 1; o->persistent_multi = 0; o->persistent_multi_shift = 13; o->poll = 1; o->debug = 0; o->prefetch_round1 = 1; o->split_cost_percent = 50; o->kernel_copies = 1; o->fold_branches = 1; o->ntt_scatter = 1; o->fuse_combine = 2;
+    o->persistent_rounds = 1; o->persistent_multi = 0; o->persistent_multi_shift = 13; o->poll = 1; o->debug = 0; o->prefetch_round1 = 1; o->split_cost_percent = 50; o->kernel_copies = 1; o->fold_branches = 1; o->ntt_scatter = 1; o->fuse_combine = 2; o->plan_autotune = 1;
 }
 // defaults <- the caller's struct (as many bytes as its header knew) <- VP_* environment variables (test-only override, read here and nowhere else)
 static void resolve_options(vp_options *o, const vp_options *user) {
@@ -635,6 +636,7 @@ static void resolve_options(vp_options *o, const vp_options *user) {
     flag("VP_FOLD_BRANCHES", o->fold_branches);
     flag("VP_NTT_SCATTER", o->ntt_scatter);
     num("VP_FUSE_COMBINE", o->fuse_combine);
+    flag("VP_PLAN_AUTOTUNE", o->plan_autotune);
     if (getenv("VP_DEBUG")) o->debug |= 1;
     if (getenv("VP_DEBUG_UPLOAD")) o->debug |= 2;                       // bit 1: phase times of vp_circuit_upload
     if (o->sf_rounds != 4) o->sf_rounds = 3;
@@ -713,7 +715,7 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
     VP_ENTER(ctx);
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (ctx->gkr_graph) { (void) hipGraphExecDestroy(ctx->gkr_graph); ctx->gkr_graph = nullptr; }
-    ctx->graph_failed = false;
+    ctx->graph_failed = false; ctx->plan_tuned = false;
     free_plan(ctx);
     vp_free_shard_state(ctx);
     free_all(ctx);
