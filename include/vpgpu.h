@@ -113,8 +113,10 @@ typedef struct {
                                        different chains share a node depends on the chains' alignment, and with the step removed the replay was
                                        slower at x64 (0.61 -> 0.64 ms) although a node had gone; 0: separate k_combine node       [2] */
     int32_t plan_autotune;          /* VP_PLAN_AUTOTUNE: the first vp_prove_gkr of a circuit replays the launch plan in the few layouts that fuse_combine,
-                                       fold_branches and plan_align offer and keeps the fastest for this circuit (one-off: a plan, a graph capture and
-                                       six replays per layout); 0: the layout the other fields name                               [1] */
+                                       fold_branches and plan_align offer, then with fuse_min_log one step either way and with sf3b_grid 384 / 320, and
+                                       keeps the fastest for this circuit (one-off: a plan, a graph capture and six replays per candidate; a candidate
+                                       that does not build is skipped; the transcript does not depend on the choice).  The fields named here are then
+                                       OVERWRITTEN by the tuner; 0: they are taken as given.  Not used for sharded proofs            [1] */
 } vp_options;
 void vp_options_default(vp_options *opt);
 
