@@ -16,6 +16,11 @@
  *   - All buffers passed in are caller-owned host memory and may be freed after the call returns.
  *   - One context = one GPU = one proof at a time (the reference prover is not re-entrant either).
  *     Call order is the reference's state machine (SURVEY.md §8b "Threading").
+ *   - The library never consumes the caller's glibc random() / rand() stream: the reference verifier draws its challenges and query
+ *     positions from it (lib/virgo/src/fieldElement.cpp:119-124, vpd_verifier.cpp:121), and the ROCm runtime takes draws of the same
+ *     process-wide generator while it initialises, so vp_create*, vp_circuit_upload and vp_comm_* run on a private generator state
+ *     (initstate / setstate) and restore the caller's.  Pinned by the reference binary of oracle/integration reproducing the CPU
+ *     reference's transcript byte for byte.
  */
 #ifndef VPGPU_H
 #define VPGPU_H
@@ -165,7 +170,8 @@ int vp_liu_init(vp_ctx *, int layer, const vp_F *r_u, const vp_F *const *r_v, co
 
 /* prover::sumcheckUpdatePhase1 / Phase2 / sumcheckLiuUpdate (src/prover.cpp:422-492): one sumcheck
  * round over all live tables of the current phase.  out_poly = {a, b, c} of a*x^2 + b*x + c.
- * Blocks until the round polynomial is on the host.                                                    */
+ * Blocks until the round polynomial is on the host.  previous_random must be canonical (both limbs < 2^61 - 1): VP_EINVAL
+ * otherwise, for vp_finalize too (the sumcheck in progress is not disturbed).                           */
 int vp_round(vp_ctx *, const vp_F *previous_random, vp_F out_poly[3]);
 
 /* prover::sumcheckFinalize1 / Finalize2 / sumcheckLiuFinalize (src/prover.cpp:494-521).  n_claims is
@@ -200,7 +206,10 @@ int vp_set_shard(vp_ctx *, int rank, int world);
  * behind the transcript (the same u64-sum all-reduce gathers them) and the last log2 W' rounds of those tables are finished on the host.
  * With a communicator attached vp_prove_gkr returns the finished transcript as before.  Without one it returns the rank's partial sums AND its
  * export area (vp_gkr_sizes gives the size): add the ranks' buffers as u64 and call vp_shard_finish.  min_log = 0 switches the split off;
- * call after vp_set_shard.  Chains without a long enough table are dealt out whole, as before.                                               */
+ * call after vp_set_shard.  Chains without a long enough table are dealt out whole, as before.
+ * LIMIT: W' <= 8 (world < 16), VP_ELIMIT otherwise — the W' ranks of a split chain add partial sums < 2^61 into the same u64 slots before
+ * anything is reduced mod p; eight addends fit in 64 bits, sixteen can wrap (and 2^64 = 8 mod p would be a silently wrong transcript).  The
+ * same bound holds for the caller-side u64 sum handed to vp_shard_finish.  vp_set_shard alone (disjoint slices) has no such bound.           */
 int vp_set_shard_split(vp_ctx *, int min_log);
 int vp_shard_finish(vp_ctx *, uint8_t *summed, uint64_t n_bytes, uint64_t *n_transcript_bytes);
 /* The assignment: owner rank and cost estimate of every chain, in the order phase-1(layer 1), Liu(layer 1), phase-1(layer 2),
@@ -264,7 +273,11 @@ int vp_pc_set_shard(vp_ctx *, int rank, int world);
 int vp_shard_exchange_local(vp_ctx **ctxs, int world);
 /* RCCL over xGMI: rank 0 makes the id (128 bytes, ncclUniqueId), every rank calls vp_comm_init with it.  With a communicator attached
  * a chain-sharded vp_prove_gkr (vp_set_shard) all-reduces the transcript on the device (u64 sum of disjoint slices) before returning
- * it, and the sharded commitment calls run their collectives inside the call.  librccl.so.1 is resolved at run time.             */
+ * it, and the sharded commitment calls run their collectives inside the call.  librccl.so.1 is resolved at run time.
+ * The communicator's (rank, world) must equal vp_set_shard's / vp_pc_set_shard's (VP_EINVAL from whichever call comes second): with a
+ * duplicate shard rank a slice would be summed twice.  Every fallible set-up step of a sharded vp_prove_gkr (plan build, graph capture,
+ * capacity check) happens BEFORE the collective; a rank that returns an error there never enters it while its peers wait in
+ * ncclAllReduce — after an error on any rank the communicator must be torn down (vp_comm_destroy) on all of them.                   */
 int vp_comm_unique_id(uint8_t id[128]);
 int vp_comm_init(vp_ctx *, const uint8_t id[128], int rank, int world);
 int vp_comm_destroy(vp_ctx *);

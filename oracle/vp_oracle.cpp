@@ -641,6 +641,33 @@ struct Prover {
 // ----------------------------------------------------------------------------------------------------
 // Verifier (GKR part).  src/verifier.cpp:12-337.  Randomness schedule and checks are literal.
 // ----------------------------------------------------------------------------------------------------
+// SHA3 pieces defined with the commitment further down (same unnamed namespace)
+struct Digest { u64 w[4]; };
+Digest hhash(const u64 in[8]);
+void keccak_f1600(u64 A[25]);
+
+// Streaming SHA3-256 (FIPS 202: Keccak[512], rate 136 bytes, domain bits 01, pad10*1) — the oracle's own sponge around its own
+// permutation, for the statement digest of the Fiat-Shamir mode.
+struct Sha3Stream {
+    u64 A[25] = {0};
+    unsigned char buf[136];
+    size_t fill = 0;
+    void block() {
+        for (int i = 0; i < 17; ++i) { u64 w = 0; for (int b = 0; b < 8; ++b) w |= (u64) buf[8 * i + b] << (8 * b); A[i] ^= w; }
+        keccak_f1600(A);
+        fill = 0;
+    }
+    void bytes(const unsigned char *p, size_t n) { for (size_t i = 0; i < n; ++i) { buf[fill++] = p[i]; if (fill == 136) block(); } }
+    void word(u64 x) { unsigned char b[8]; for (int i = 0; i < 8; ++i) b[i] = (unsigned char) (x >> (8 * i)); bytes(b, 8); }
+    Digest done() {
+        for (size_t i = fill; i < 136; ++i) buf[i] = 0;
+        buf[fill] ^= 0x06; buf[135] ^= 0x80;
+        block();
+        Digest d; for (int i = 0; i < 4; ++i) d.w[i] = A[i];
+        return d;
+    }
+};
+
 struct Verifier {
     Prover *p;
     const Circuit &C;
@@ -672,7 +699,52 @@ struct Verifier {
         sig.resize(C.size);
     }
 
-    void putF(const F &x) { u64 w[2] = {x.re, x.im}; const unsigned char *b = (const unsigned char *) w; out->insert(out->end(), b, b + 16); }
+    // ---- Fiat-Shamir mode (NOT in the reference, whose verifier draws glibc random()).  The definition restated
+    // here is the one virgo-plus_amd/host/verifier.cpp documents for verifier::proveFS(): a SHA3-256 chain state' = H(block || state)
+    // over 64-byte blocks; the statement (serialised circuit + subset tables + input values, domain tag "virg") is absorbed first as
+    // H(SHA3-256(serialisation) || 0) and then {n_layers, 0, 0, 'S'}; every prover message x is absorbed as {x.re, x.im, 0, 'M'}; the
+    // c-th challenge is squeezed by absorbing {c, 0, 0, 'C'} and taking the first two state words mod 2^61 (p -> 0).  Challenges that
+    // belong to a sumcheck round are drawn AFTER that round's polynomial; the others where the interactive verifier draws them.
+    bool fs = false;
+    Digest fs_state{};
+    u64 fs_ctr = 0;
+    void fs_absorb(u64 a, u64 b, u64 c, u64 tag) { const u64 in[8] = {a, b, c, tag, fs_state.w[0], fs_state.w[1], fs_state.w[2], fs_state.w[3]}; fs_state = hhash(in); }
+    void fs_init() {
+        Sha3Stream h;
+        h.word(0x76697267ull);
+        h.word((u64) C.size);
+        for (int i = 0; i < C.size; ++i) {
+            const Layer &L = C.circuit[i];
+            h.word(L.size); h.word((u64) (long long) L.bitLength);
+            for (u64 g = 0; g < L.size; ++g) {
+                const Gate &G = L.gates[g];
+                h.word((u64) (long long) G.ty | ((u64) (G.is_assert ? 1 : 0) << 32)); h.word((u64) (long long) G.l);
+                h.word(G.u); h.word(G.v); h.word(G.lv); h.word(G.c.re); h.word(G.c.im);
+            }
+            h.word((u64) (long long) L.maxDadBitLength); h.word(L.maxDadSize);
+            for (int j = 0; j < i; ++j) {
+                h.word(L.dadSize[j]);
+                h.word(L.dadSize[j] ? (u64) (long long) L.dadBitLength[j] : ~0ull);
+                for (u64 k = 0; k < L.dadSize[j]; ++k) h.word(L.dadId[j][k]);
+            }
+        }
+        const Digest st = h.done();
+        fs_state = Digest{}; fs_ctr = 0;
+        fs_absorb(st.w[0], st.w[1], st.w[2], st.w[3]);
+        fs_absorb((u64) C.size, 0, 0, 0x53);
+    }
+    F draw() {
+        if (!fs) return frandom();
+        fs_absorb(fs_ctr++, 0, 0, 0x43);
+        u64 a = fs_state.w[0] & P, b = fs_state.w[1] & P;
+        if (a == P) a = 0;
+        if (b == P) b = 0;
+        return F(a, b);
+    }
+    void putF(const F &x) {
+        u64 w[2] = {x.re, x.im}; const unsigned char *b = (const unsigned char *) w; out->insert(out->end(), b, b + 16);
+        if (fs) fs_absorb(x.re, x.im, 0, 0x4d);
+    }
     void putQ(const Quad &q) { putF(q.a); putF(q.b); putF(q.c); }
 
     F assert_random;
@@ -721,9 +793,9 @@ struct Verifier {
 
     bool verifyPhase1(int layer_id, F &previousSum) {                // verifier.cpp:191-229
         const Layer &pre = C.circuit[layer_id - 1];
-        for (auto &x : r_u) x = frandom();
+        if (!fs) for (auto &x : r_u) x = draw();
         F previousRandom = F_ZERO;
-        assert_random = frandom();
+        assert_random = draw();
         p->sumcheckInitPhase1(assert_random);
         for (int j = 0; j < pre.bitLength; ++j) {
             Quad poly = p->sumcheckUpdatePhase1(previousRandom);
@@ -733,6 +805,7 @@ struct Verifier {
                 fprintf(stderr, "oracle: verification fail, phase1, circuit %d, bit %d\n", layer_id, j);
                 return false;
             }
+            if (fs) { vt.stop(); r_u[j] = draw(); vt.start(); }
             previousRandom = r_u[j];
             previousSum = poly.eval(r_u[j]);
             vt.stop();
@@ -745,7 +818,7 @@ struct Verifier {
         return true;
     }
     bool verifyPhase2(int layer_id, F &previousSum) {                // verifier.cpp:231-270
-        for (auto &x : r_v[layer_id]) x = frandom();
+        if (!fs) for (auto &x : r_v[layer_id]) x = draw();
         F previousRandom = F_ZERO;
         p->sumcheckInitPhase2();
         for (int j = 0; j < C.circuit[layer_id].maxDadBitLength; ++j) {
@@ -756,6 +829,7 @@ struct Verifier {
                 fprintf(stderr, "oracle: verification fail, phase2, circuit %d, bit %d\n", layer_id, j);
                 return false;
             }
+            if (fs) r_v[layer_id][j] = draw();
             previousRandom = r_v[layer_id][j];
             previousSum = poly.eval(previousRandom);
             vt.stop();
@@ -770,8 +844,8 @@ struct Verifier {
     bool verifyLiu(int layer_id, F &previousSum) {                   // verifier.cpp:272-337
         int pre_layer_id = layer_id - 1;
         const Layer &pre = C.circuit[pre_layer_id];
-        for (auto &x : sig) x = frandom();
-        for (auto &x : r_liu) x = frandom();
+        for (auto &x : sig) x = draw();
+        if (!fs) for (auto &x : r_liu) x = draw();
         previousSum = sig[0] * final_claim_u;
         for (int j = layer_id; j < C.size; ++j)                      // `~dadBitLength` is never 0
             previousSum += sig[j - pre_layer_id] * final_claims_v[j][pre_layer_id];
@@ -785,6 +859,7 @@ struct Verifier {
                 fprintf(stderr, "oracle: Liu fail, circuit %d, bit %d\n", layer_id, j);
                 return false;
             }
+            if (fs) r_liu[j] = draw();
             previousRandom = r_liu[j];
             previousSum = poly.eval(previousRandom);
             vt.stop();
@@ -809,7 +884,7 @@ struct Verifier {
     }
 
     bool verify_gkr() {                                              // verifier.cpp:134-169 without the PC calls
-        for (int i = 0; i < C.circuit[C.size - 1].bitLength; ++i) r_liu[i] = frandom();
+        for (int i = 0; i < C.circuit[C.size - 1].bitLength; ++i) r_liu[i] = draw();
         F previousSum = p->Vres(r_liu.data(), C.circuit[C.size - 1].bitLength);
         putF(previousSum);
         p->sumcheckInitAll(r_liu.data());
@@ -1008,6 +1083,27 @@ int64_t orc_prove_gkr(orc_circuit *oc, uint8_t *transcript, int64_t capacity, or
     return (int64_t) out.size();
 }
 
+// Fiat-Shamir mode: same prover, challenges from the SHA3 chain over the statement and the messages (Verifier::fs_*).  The proof is the
+// message stream in the GKR transcript layout.
+int64_t orc_prove_fs(orc_circuit *oc, uint8_t *proof, int64_t capacity, orc_stats *st) {
+    g_cnt = Counter();
+    subset_init(oc->c);
+    Prover p(oc->c);
+    vector<unsigned char> out;
+    Verifier v(&p, oc->c, &out);
+    v.fs = true;
+    v.fs_init();
+    bool ok = v.verify_gkr();
+    if (st) {
+        st->prove_sec = p.prove_timer.total; st->evaluate_sec = p.evaluate_sec; st->verify_sec = v.vt.total;
+        st->mult_count = g_cnt.mul; st->add_count = g_cnt.add; st->rounds = p.rounds; st->pairs = p.pairs;
+        st->proof_kb = (double) p.proof_size / 1024.0; st->verified = ok ? 1 : 0;
+    }
+    if ((int64_t) out.size() > capacity) return -1;
+    memcpy(proof, out.data(), out.size());
+    return (int64_t) out.size();
+}
+
 static inline F toF(const orc_F *x) { return F(x->real, x->img); }
 static inline void fromF(const F &x, orc_F *o) { o->real = x.re; o->img = x.im; }
 
@@ -1089,7 +1185,6 @@ void keccak_f1600(u64 A[25]) {
         A[0] ^= KECCAK_RC[rnd];
     }
 }
-struct Digest { u64 w[4]; };
 Digest hhash(const u64 in[8]) {           // my_hhash: 64 bytes in, 32 bytes out
     u64 A[25] = {0};
     for (int i = 0; i < 8; ++i) A[i] = in[i];

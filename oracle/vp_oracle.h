@@ -12,7 +12,7 @@
  *   verifier schedule + checks ..... src/verifier.cpp:12-337
  * Parity status: PINNED.  tests/test_oracle_golden.py checks this restatement against transcripts
  * produced by the real reference compiled here (oracle/_ref/ref_run, see oracle/Makefile):
- * tests/golden/*.bin, whose SHA-256 digests equal the ones recorded in SURVEY.md §8c, plus the
+ * tests/golden/ (the .bin files), whose SHA-256 digests equal the ones recorded in SURVEY.md §8c, plus the
  * field / root-of-unity / F::random known answers listed there.
  */
 #ifndef VP_ORACLE_H
@@ -70,6 +70,12 @@ void orc_circuit_inputs(const orc_circuit *, orc_F *out);
  * and without the trailing PC fields) into `transcript`; returns its length in bytes, or <0 on error
  * (-1: capacity too small).                                                                           */
 int64_t orc_prove_gkr(orc_circuit *, uint8_t *transcript, int64_t capacity, orc_stats *stats);
+
+/* The same proof in Fiat-Shamir mode (not a reference mode — the reference draws glibc random()): every challenge
+ * is derived by a SHA3-256 chain from the statement (serialised circuit, subset tables, input values) and all prover messages before
+ * it, one challenge per sumcheck round AFTER that round's polynomial; definition in virgo-plus_amd/host/verifier.cpp (proveFS).  This
+ * is an independent second implementation (own sponge, own serialiser, own prover): tests compare its proof bytes with the product's. */
+int64_t orc_prove_fs(orc_circuit *, uint8_t *proof, int64_t capacity, orc_stats *stats);
 
 /* ---- primitives, for unit parity tests against the HIP kernels ------------------------------------ */
 void orc_f_add(const orc_F *a, const orc_F *b, orc_F *out);

@@ -45,6 +45,8 @@ def lib():
         L.orc_circuit_inputs.argtypes = [vp, vp]
         L.orc_prove_gkr.restype = ctypes.c_int64
         L.orc_prove_gkr.argtypes = [vp, vp, ctypes.c_int64, ctypes.POINTER(Stats)]
+        L.orc_prove_fs.restype = ctypes.c_int64
+        L.orc_prove_fs.argtypes = [vp, vp, ctypes.c_int64, ctypes.POINTER(Stats)]
         for f in ("orc_f_add", "orc_f_sub", "orc_f_mul"):
             getattr(L, f).argtypes = [vp, vp, vp]
         L.orc_f_neg.argtypes = [vp, vp]
@@ -102,6 +104,15 @@ class Circuit:
         n = lib().orc_prove_gkr(self.h, ctypes.cast(buf, ctypes.c_void_p), capacity, ctypes.byref(st))
         if n < 0:
             raise RuntimeError("oracle prove failed")
+        return buf.raw[:n], st.as_dict()
+
+    def prove_fs(self, capacity=1 << 20):
+        """The same proof in Fiat-Shamir mode (orc_prove_fs): (proof bytes, stats dict)."""
+        buf = ctypes.create_string_buffer(capacity)
+        st = Stats()
+        n = lib().orc_prove_fs(self.h, ctypes.cast(buf, ctypes.c_void_p), capacity, ctypes.byref(st))
+        if n < 0:
+            raise RuntimeError("oracle FS prove failed")
         return buf.raw[:n], st.as_dict()
 
     def close(self):

@@ -1,7 +1,8 @@
 """INTEGRATION.md's claim, compiled: the reference's UNMODIFIED main.cpp / verifier.cpp / circuit.cpp / polynomial.cpp / utils.cpp and
-lib/virgo link against oracle/integration/prover_vpgpu.cpp (the forwarding bodies for src/prover.cpp, written against the reference's
-own src/prover.h) and libvpgpu.so.  Test infrastructure only (oracle/Makefile target `integration`); the GPU run of the same binary is
-tests/test_gpu_parity.py::test_reference_binary_drives_the_device_prover."""
+lib/virgo (every file but fri.cpp) link against oracle/integration/prover_vpgpu.cpp (the forwarding bodies for src/prover.cpp, written
+against the reference's own src/prover.h), oracle/integration/fri_vpgpu.cpp (the forwarding bodies for lib/virgo/src/fri.cpp, written
+against the reference's own fri.h) and libvpgpu.so.  Test infrastructure only (oracle/Makefile target `integration`); the GPU run of the
+same binary is tests/test_gpu_parity.py::test_reference_binary_drives_the_device_prover."""
 import os
 import subprocess
 
@@ -29,8 +30,24 @@ def test_unmodified_reference_links_against_the_forwarding_prover():
     und = subprocess.run(["nm", "-C", "--undefined-only", os.path.join(ROOT, "oracle", "_ref", "plain_verifier.o")],
                          check=True, stdout=subprocess.PIPE, text=True).stdout
     assert "prover::sumcheckUpdatePhase1(" in und and "prover::Vres(" in und          # the unmodified verifier asks for exactly these
+    # the commitment seam: every fri:: function lib/virgo's UNMODIFIED verifier (vpd_verifier.cpp) calls is defined by the forwarding file ...
+    fsyms = subprocess.run(["nm", "-C", "--defined-only", os.path.join(ROOT, "oracle", "_ref", "integration_fri.o")],
+                           check=True, stdout=subprocess.PIPE, text=True).stdout
+    for m in ("virgo::fri::request_init_commit(", "virgo::fri::commit_phase_step(", "virgo::fri::commit_phase_final()",
+              "virgo::fri::request_init_value_with_merkle(", "virgo::fri::request_step_commit(", "virgo::fri::cpd",
+              "virgo::fri::log_current_witness_size_per_slice"):
+        assert m in fsyms, m
+    vund = subprocess.run(["nm", "-C", "--undefined-only", os.path.join(ROOT, "oracle", "_ref", "virgo_vpd_verifier.o")],
+                          check=True, stdout=subprocess.PIPE, text=True).stdout
+    for m in ("virgo::fri::commit_phase_step(", "virgo::fri::commit_phase_final()", "virgo::fri::request_init_value_with_merkle(",
+              "virgo::fri::request_step_commit(", "virgo::fri::cpd"):
+        assert m in vund, m                                                            # ... which is exactly what that verifier asks for
+    # ... and the reference's own fri.cpp is not in the binary (its file-static helper has no other definition)
+    allsyms = subprocess.run(["nm", "-C", BIN], check=True, stdout=subprocess.PIPE, text=True).stdout
+    assert "merkle_tree_consistency_check" not in allsyms
     dyn = subprocess.run(["nm", "-D", "--undefined-only", BIN], check=True, stdout=subprocess.PIPE, text=True).stdout
-    for f in ("vp_create", "vp_circuit_upload", "vp_evaluate", "vp_vres", "vp_phase1_init", "vp_phase2_init", "vp_liu_init", "vp_round", "vp_finalize"):
+    for f in ("vp_create", "vp_circuit_upload", "vp_evaluate", "vp_vres", "vp_phase1_init", "vp_phase2_init", "vp_liu_init", "vp_round", "vp_finalize",
+              "vp_commit_private", "vp_commit_public", "vp_fri_step", "vp_fri_final", "vp_fri_open"):
         assert f in dyn, f                                                             # ... and they reach the C ABI of libvpgpu.so
 
 

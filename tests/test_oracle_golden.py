@@ -261,3 +261,22 @@ def test_oracle_on_all_gate_types_and_asserts_vs_reference(ob, golden, name):
     n = L.orc_prove_full(c.h, buf, len(buf), None)
     assert buf.raw[:n] == gold and hashlib.sha256(gold).hexdigest() == g["sha256"]
     c.close()
+
+
+def test_oracle_fiat_shamir_proof_equals_the_committed_device_proof(ob):
+    """Second opinion for the Fiat-Shamir mode: tests/golden/fs_proof_randomize_6_8_seed5.bin was produced on the GPU box by
+    the product (host/verifier.cpp::proveFS driving vp_round).  The oracle derives the same challenges with its OWN SHA3 sponge, its own
+    statement serialiser and its own CPU prover (orc_prove_fs) and must arrive at the same 5 936 proof bytes — challenges and messages
+    are interlocked, so one differing challenge or one differing field element anywhere changes everything after it."""
+    from conftest import GOLDEN
+    c = ob.Circuit.randomize(6, 8, seed=5)
+    proof, st = c.prove_fs()
+    assert st["verified"] == 1
+    assert proof == open(os.path.join(GOLDEN, "fs_proof_randomize_6_8_seed5.bin"), "rb").read()
+    tr, _ = c.prove_gkr()
+    assert len(tr) == len(proof) and tr != proof            # same layout, other challenges (random() instead of the hash chain)
+    c.close()
+    other = ob.Circuit.randomize(6, 8, seed=6)              # another witness: another statement digest, other challenges from the start
+    p2, _ = other.prove_fs()
+    assert p2 != proof and p2[:16] != proof[:16]
+    other.close()

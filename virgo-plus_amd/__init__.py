@@ -416,6 +416,10 @@ class Session:
         self._cap = int(lib_host().vph_transcript_bytes(self.h)) + 4096
         self._buf = ctypes.create_string_buffer(self._cap)
 
+    def gpu_ctx(self):
+        """The vp_ctx* of this session (for direct C-ABI calls in tests)."""
+        return ctypes.c_void_p(lib_host().vph_session_ctx(self.h))
+
     def set_profiling(self, level):
         lib_host().vph_set_profiling(self.h, level)
 

@@ -645,9 +645,21 @@ static void resolve_options(vp_options *o, const vp_options *user) {
 
 int vp_create(int device, vp_ctx **out) { return vp_create_with_options(device, nullptr, out); }
 
+// The caller's glibc random() / rand() stream is not ours to consume: the reference verifier draws every challenge and every query position
+// from it (lib/virgo/src/fieldElement.cpp:119-124,362-367, vpd_verifier.cpp:121), and the ROCm runtime takes draws from the same process-wide
+// generator while it initialises (measured through the reference binary, oracle/integration: vp_create shifted the stream, the proof still
+// verified but was no longer the CPU reference's).  The set-up entry points therefore run on a private generator state and hand the caller's
+// back untouched.
+struct RandKeep {
+    char priv[128]; char *caller;
+    RandKeep() { memset(priv, 0, sizeof priv); caller = initstate(1u, priv, sizeof priv); }
+    ~RandKeep() { if (caller) setstate(caller); }
+};
+
 int vp_create_with_options(int device, const vp_options *user, vp_ctx **out) {
     if (!out) return VP_EINVAL;
     *out = nullptr;
+    RandKeep keep_callers_random_stream;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return VP_ENOGPU;
     if (hipSetDevice(device) != hipSuccess) return VP_ENOGPU;
@@ -712,6 +724,7 @@ void vp_destroy(vp_ctx *ctx) {
 int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
     if (!ctx || !ld || n_layers < 2) return VP_EINVAL;
     if (n_layers > VP_MAX_TAB) { ctx->err = "too many layers"; return VP_ELIMIT; }
+    RandKeep keep_callers_random_stream;                               // rocPRIM / first-use module loads: see vp_create_with_options
     VP_ENTER(ctx);
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (ctx->gkr_graph) { (void) hipGraphExecDestroy(ctx->gkr_graph); ctx->gkr_graph = nullptr; }
@@ -1135,6 +1148,8 @@ int vp_round(vp_ctx *ctx, const vp_F *previous_random, vp_F out_poly[3]) {
     if (!ctx || !previous_random || !out_poly || ctx->sc.phase == 0) return VP_EINVAL;
     HIPCHK(hipSetDevice(ctx->device));
     F rv; memcpy(&rv, previous_random, sizeof(F));
+    // canonical limbs only (header convention); the mailbox of the resident kernel also keeps its sequence tag in bits 61-63 of every word
+    if (rv.re >= P61 || rv.im >= P61) { ctx->err = "vp_round: previous_random is not canonical (limb >= 2^61 - 1)"; return VP_EINVAL; }
     if (!ctx->r1_pending && ctx->sc.round >= ctx->sc.total_rounds) { ctx->err = "too many rounds"; return VP_EINVAL; }
     if (ctx->r1_pending) {                                    // round 1 was queued by the init call (it takes no challenge): collect it
         const int how = ctx->r1_pending;
@@ -1177,6 +1192,7 @@ int vp_finalize(vp_ctx *ctx, const vp_F *previous_random, vp_F *claims, int n_cl
     if (!ctx || !previous_random || !claims || ctx->sc.phase == 0 || n_claims != ctx->sc.n_tab) return VP_EINVAL;
     HIPCHK(hipSetDevice(ctx->device));
     F rv; memcpy(&rv, previous_random, sizeof(F));
+    if (rv.re >= P61 || rv.im >= P61) { ctx->err = "vp_finalize: previous_random is not canonical (limb >= 2^61 - 1)"; return VP_EINVAL; }
     if (ctx->tail_active) {                                   // the resident kernel holds the tables: it computes the claims and leaves
         const int rc = tail_send(ctx, 2, rv);
         ctx->tail_active = false;
@@ -1195,6 +1211,7 @@ static int prove_gkr_fused(vp_ctx *ctx, const vp_F *tape, uint64_t n_tape, uint8
 static void assign_chains(vp_ctx *ctx);
 static void split_layout(vp_ctx *ctx);
 bool vp_comm_attached(const vp_ctx *ctx);
+bool vp_comm_matches(const vp_ctx *ctx, int rank, int world);
 
 int vp_gkr_sizes(vp_ctx *ctx, uint64_t *n_tape, uint64_t *n_bytes) {
     if (!ctx || ctx->n_layers < 2) return VP_EINVAL;
@@ -1213,6 +1230,7 @@ int vp_set_shard(vp_ctx *ctx, int rank, int world) {
     if (world > 1 && ctx->n_layers >= 2 && (!ctx->plan_path || ctx->simple_path || ctx->sumfold_path)) {
         ctx->err = "vp_set_shard: only the launch-plan path shards (unset VP_GKR_PATH)"; return VP_EINVAL;
     }
+    if (world > 1 && vp_comm_attached(ctx) && !vp_comm_matches(ctx, rank, world)) { ctx->err = "vp_set_shard: rank/world differ from the attached communicator's"; return VP_EINVAL; }
     VP_ENTER(ctx);
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (ctx->gkr_graph) { (void) hipGraphExecDestroy(ctx->gkr_graph); ctx->gkr_graph = nullptr; }
@@ -1233,6 +1251,11 @@ int vp_set_shard_split(vp_ctx *ctx, int min_log) {
     free_plan(ctx);
     int lw = 0;
     while ((2 << lw) <= ctx->shard_world) ++lw;                      // largest power of two <= world
+    // the 2^lw ranks of a split chain ADD partial sums (each < 2^61) into the same transcript / export slots with a plain u64 all-reduce
+    // before anything is reduced mod p: eight addends fit in 64 bits (8 (2^61 - 1) < 2^64), sixteen can wrap — and 2^64 = 8 (mod p) would
+    // silently give a wrong transcript.  One node has 8 GPUs; more ranks than that are refused here (chain sharding alone — disjoint
+    // slices — has no such bound).
+    if (min_log > 0 && lw > 3) { ctx->err = "vp_set_shard_split: at most 8 slices (u64 partial sums of 2^lw ranks must not wrap)"; return VP_ELIMIT; }
     ctx->split_lw = (min_log > 0 && ctx->shard_world > 1) ? lw : 0;
     if (min_log > 0) ctx->split_min_log = std::max(9, min_log);      // a slice keeps at least one fold chunk
     ctx->chain_owner.clear(); ctx->chain_cost.clear();

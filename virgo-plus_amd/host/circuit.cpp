@@ -93,30 +93,28 @@ void layeredCircuit::structuralHash(u64 out[2]) const {
 }
 
 void layeredCircuit::statementDigest(u64 out[4]) const {
-    if (!digest_valid_) {
-        vph::sha3_256 h;
-        h.put64(0x76697267ull);                       // domain tag
-        h.put64((u64) size);
-        for (int i = 0; i < size; ++i) {
-            const layer &L = circuit[i];
-            h.put64(L.size); h.put64((u64) (i64) L.bitLength);
-            for (u64 g = 0; g < L.size; ++g) {
-                const gate &G = L.gates[g];
-                const u64 rec[7] = {(u64) (i64) G.ty | ((u64) (G.is_assert ? 1 : 0) << 32), (u64) (i64) G.l, G.u, G.v, G.lv, G.c.real, G.c.img};
-                h.update(rec, sizeof rec);
-            }
-            h.put64((u64) (i64) L.maxDadBitLength); h.put64(L.maxDadSize);
-            for (int j = 0; j < i; ++j) {
-                h.put64(L.dadSize[j]);
-                h.put64(L.dadSize[j] ? (u64) (i64) L.dadBitLength[j] : ~0ull);
-                if (L.dadSize[j]) h.update(L.dadId[j].data(), L.dadSize[j] * sizeof(u64));
-            }
+    // recomputed on every call (O(|C|), the order of the verifier's own work): `circuit` is a public member, a cached digest would keep
+    // binding the Fiat-Shamir challenges to a statement that was edited after the first proof
+    vph::sha3_256 h;
+    h.put64(0x76697267ull);                       // domain tag
+    h.put64((u64) size);
+    for (int i = 0; i < size; ++i) {
+        const layer &L = circuit[i];
+        h.put64(L.size); h.put64((u64) (i64) L.bitLength);
+        for (u64 g = 0; g < L.size; ++g) {
+            const gate &G = L.gates[g];
+            const u64 rec[7] = {(u64) (i64) G.ty | ((u64) (G.is_assert ? 1 : 0) << 32), (u64) (i64) G.l, G.u, G.v, G.lv, G.c.real, G.c.img};
+            h.update(rec, sizeof rec);
         }
-        const vph::hhash_digest d = h.final();
-        for (int k = 0; k < 4; ++k) digest_[k] = d.w[k];
-        digest_valid_ = true;
+        h.put64((u64) (i64) L.maxDadBitLength); h.put64(L.maxDadSize);
+        for (int j = 0; j < i; ++j) {
+            h.put64(L.dadSize[j]);
+            h.put64(L.dadSize[j] ? (u64) (i64) L.dadBitLength[j] : ~0ull);
+            if (L.dadSize[j]) h.update(L.dadId[j].data(), L.dadSize[j] * sizeof(u64));
+        }
     }
-    for (int k = 0; k < 4; ++k) out[k] = digest_[k];
+    const vph::hhash_digest d = h.final();
+    for (int k = 0; k < 4; ++k) out[k] = d.w[k];
 }
 
 namespace vph {

@@ -59,11 +59,9 @@ public:
     void structuralHash(u64 out[2]) const;
     // SHA3-256 of the same serialisation (every gate tuple, the subset tables, the layer sizes and — through gate::u of
     // layer 0 — the input values): the statement digest the Fiat-Shamir mode binds its challenges to.  structuralHash is
-    // only a loader-parity fingerprint (FNV + xor-multiply, invertible); this one is collision resistant.  Cached.
+    // only a loader-parity fingerprint (FNV + xor-multiply, invertible); this one is collision resistant.  Not cached (the gate
+    // tables are public and may be edited between proofs).
     void statementDigest(u64 out[4]) const;
-private:
-    mutable bool digest_valid_ = false;
-    mutable u64 digest_[4] = {0, 0, 0, 0};
 };
 
 namespace vph {
