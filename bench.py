@@ -367,7 +367,8 @@ def x1024_leg(vp, pws, golden, a, local):
                                   % (B, B, circ.gates, circ.layers), "field_ops_per_proof": ref_ops},
            "value": ref_ops * steps / elapsed, "unit": "field-ops/s", "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
            "prover_sec": elapsed / steps, "prover_sec_device": 1e-3 * dev_ms / steps, "rounds": res["rounds"],
-           "kernel_launches_per_proof": res["launches"], "bit_exact_vs_oracle_fixture": tr == gold, "golden_origin": g.get("origin"),
+           "kernel_launches_per_proof": res["launches"], "bit_exact_vs_reference": tr == gold, "golden_origin": g.get("origin"),
+           "reference_prove_sec_build_container": g.get("reference_prove_sec_here"), "reference_pc_prove_sec_build_container": g.get("reference_pc_prove_sec_here"),
            "verifier_accepts_full_check": bool(ok_d), "verify_sec_device_predicates": sec_d, "interactive_path": inter,
            "circuit_build_sec": build_sec, "circuit_upload_sec": upload_sec,
            "roofline": roof, "kernels": rows, "per_launch": per_launch, "polynomial_commitment": pc}

@@ -11,6 +11,9 @@ and a gzip copy of the reference's own circuit data file data/SHA256_64.pws.
 
     python tests/golden/make_golden.py            # x1, randomize(8,12), x16
     python tests/golden/make_golden.py --with-x64 # also the 64-block case (~1 min)
+    python tests/golden/make_golden.py --with-big # also BASELINE configs[2] / [4]: SHA-256 x1024 with the commitment (round 3: 131 s circuit
+                                                  # build + 809 s verify(), peak RSS 63 GB — needs the whole 62 GiB container, run nothing
+                                                  # beside it) and randomize(16, 20) with the commitment (~2 min, 4 GB)
 """
 import argparse
 import gzip
@@ -57,7 +60,7 @@ def run_case(name, args):
     if name in SURVEY_SHA256 and SURVEY_SHA256[name] != digest:
         raise SystemExit(f"{name}: transcript digest {digest} != SURVEY.md {SURVEY_SHA256[name]}")
     m = re.search(r"circuit layers (\d+) gates (\d+) hash ([0-9a-f]{32})", txt)
-    c = re.search(r"mult counter (-?\d+), add counter (-?\d+)", txt)
+    c = re.search(r"mult counter (-?\d+), add counter (-?\d+)", txt)      # `int` counters: they wrap at x1024
     r = re.search(r"rounds (\d+)", txt)
     pt = re.search(r"Prove Time ([0-9.]+)", txt)
     pc = re.search(r"Polynomial commitment: prove time ([0-9.]+)", txt)
@@ -88,6 +91,7 @@ def run_case(name, args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--with-x64", action="store_true")
+    ap.add_argument("--with-big", action="store_true")
     a = ap.parse_args()
     subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "ref"], check=True, stdout=subprocess.DEVNULL)
     pws_gz = os.path.join(HERE, "SHA256_64.pws.gz")
@@ -122,6 +126,18 @@ def main():
             os.remove(path)
         if a.with_x64:
             meta["sha256_x64"] = run_case("sha256_x64", ["--pws", tmp_pws, "--blocks", "64"])
+        if a.with_big:
+            # the reference's int counters wrap at these sizes: keep what it printed beside the 64-bit counts of the oracle fixture
+            # (congruent mod 2^32, checked by tests/test_oracle_golden.py)
+            for name, args in (("randomize_16_20", ["--randomize", "16", "20"]), ("sha256_x1024", ["--pws", tmp_pws, "--blocks", "1024"])):
+                old = meta.get(name, {})
+                new = run_case(name, args)
+                new["mult_counter_printed_int32"], new["add_counter_printed_int32"] = new["mult_counter"], new["add_counter"]
+                for k in ("mult_counter", "add_counter", "pairs", "oracle_fixture"):
+                    if k in old:
+                        new[k] = old[k]
+                new["origin"] = "real reference (oracle/_ref/ref_run %s --pc 1 --dump --dump-fri; tests/golden/make_golden.py --with-big)" % " ".join(args[:1] + args[-2:])
+                meta[name] = new
     finally:
         os.remove(tmp_pws)
     for k in meta:
