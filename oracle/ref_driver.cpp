@@ -13,11 +13,21 @@
 // Everything downstream of circuit construction is the reference's own code:
 // DAG_to_layered, F::init, subsetInit, prover, verifier::verify.
 //
+//   * the messages of lib/virgo's self-contained fft_gkr (lib/virgo/src/fft_circuit_GKR.cpp:833-849, run by verify_poly_commitment,
+//     vpd_verifier.cpp:92) can be recorded: that function sends nothing to its caller, so the record is taken at LINK time —
+//     `ld --wrap` (oracle/Makefile) routes fft_circuit_GKR.o's calls to virgo::quadratic_poly::eval / virgo::linear_poly::eval (out-of-line
+//     in lib/virgo/src/polynomial.cpp) and vpd_verifier.o's call to fft_gkr through the wrappers below, which forward to the real
+//     functions unchanged.  Every round polynomial is evaluated three times in a row (at 0, at 1, at the challenge: :261,263,265 and
+//     their copies), every phase ends with one linear_poly::eval (v_u / v_v, :268): the third evaluation of each triple and every linear
+//     evaluation, in call order, preceded by the circuit's 64 outputs, is the record (--dump-fft).  No reference line is edited.
 // Usage:
-//   ref_run --pws FILE [--blocks B] [--ref-parser] [--pc 0|1] [--dump OUT] [--seed S]
+//   ref_run --pws FILE [--blocks B] [--ref-parser] [--pc 0|1] [--dump OUT] [--dump-fri OUT] [--dump-fft OUT] [--seed S]
 //   ref_run --randomize LAYERS LOG_SIZE      [--pc 0|1] [--dump OUT] [--seed S]
+//   ref_run --fft-gkr LG [--dump-fft OUT]    F::init(), then fft_gkr(LG) alone (its own prover + verifier)
 #include "verifier.h"
 #include "inputCircuit.hpp"
+#include "virgo/src/polynomial.h"          // lib/virgo's own polynomial classes (namespace virgo), the ones fft_circuit_GKR.cpp uses
+#include "virgo/src/fft_circuit_GKR.h"
 #include <fstream>
 #include <string>
 #include <chrono>
@@ -39,6 +49,46 @@ __hhash_digest commit_phase_step(fieldElement r) {
     return d;
 }
 } }
+
+// ---- fft_gkr record (see the header comment).  The reference's globals of that translation unit are namespace-scope with external
+// linkage; `C` holds the layer values (fft_circuit_GKR.cpp:9-13) and is declared here with the same definition to read the outputs.
+namespace virgo { namespace fft_circuit_gkr {
+class circuit { public: std::vector<fieldElement *> circuit_val; std::vector<int> size; };
+extern circuit C;
+} }
+static FILE *g_fft_dump = nullptr;
+static bool g_fft_rec = false;
+static unsigned long g_fft_qcalls = 0;
+static std::vector<unsigned long long> g_fft_msgs;
+static inline void fft_put(const virgo::fieldElement &x) { g_fft_msgs.push_back(x.real); g_fft_msgs.push_back(x.img); }
+extern "C" {
+virgo::fieldElement __real__ZNK5virgo14quadratic_poly4evalERKNS_12fieldElementE(const virgo::quadratic_poly *, const virgo::fieldElement &);
+virgo::fieldElement __real__ZNK5virgo11linear_poly4evalERKNS_12fieldElementE(const virgo::linear_poly *, const virgo::fieldElement &);
+int __real__ZN5virgo15fft_circuit_gkr7fft_gkrEiRdRiS1_(int, double &, int &, double &);
+virgo::fieldElement __wrap__ZNK5virgo14quadratic_poly4evalERKNS_12fieldElementE(const virgo::quadratic_poly *self, const virgo::fieldElement &x) {
+    if (g_fft_rec && (g_fft_qcalls++ % 3) == 2) { fft_put(self->a); fft_put(self->b); fft_put(self->c); }
+    return __real__ZNK5virgo14quadratic_poly4evalERKNS_12fieldElementE(self, x);
+}
+virgo::fieldElement __wrap__ZNK5virgo11linear_poly4evalERKNS_12fieldElementE(const virgo::linear_poly *self, const virgo::fieldElement &x) {
+    virgo::fieldElement v = __real__ZNK5virgo11linear_poly4evalERKNS_12fieldElementE(self, x);
+    if (g_fft_rec) fft_put(v);
+    return v;
+}
+int __wrap__ZN5virgo15fft_circuit_gkr7fft_gkrEiRdRiS1_(int lg, double &vt, int &ps, double &pt) {
+    g_fft_rec = true; g_fft_qcalls = 0; g_fft_msgs.clear();
+    const int rc = __real__ZN5virgo15fft_circuit_gkr7fft_gkrEiRdRiS1_(lg, vt, ps, pt);
+    g_fft_rec = false;
+    if (g_fft_dump) {
+        using namespace virgo::fft_circuit_gkr;
+        const virgo::fieldElement *out = C.circuit_val.back();                 // the 64 evaluations (fft_circuit_GKR.cpp:91-100)
+        for (int i = 0; i < 64; ++i) { unsigned long long w[2] = {out[i].real, out[i].img}; fwrite(w, 8, 2, g_fft_dump); }
+        fwrite(g_fft_msgs.data(), 8, g_fft_msgs.size(), g_fft_dump);
+        fflush(g_fft_dump);
+    }
+    fprintf(stdout, "fft_gkr lg %d p_time %lf v_time %lf proof_bytes %d recorded_F %lu\n", lg, pt, vt, ps, (unsigned long) (g_fft_msgs.size() / 2));
+    return rc;
+}
+}
 
 // symbols defined in the reference's src/main.cpp
 extern layeredCircuit c;
@@ -129,7 +179,7 @@ static void circuit_hash(const layeredCircuit &C, unsigned long long out[2]) {
 
 int main(int argc, char **argv) {
     const char *pws = nullptr, *dump = nullptr, *custom = nullptr;
-    int blocks = 1, ref_parser = 0, rnd_layers = 0, rnd_log = 0;
+    int blocks = 1, ref_parser = 0, rnd_layers = 0, rnd_log = 0, fft_lg = 0;
     long seed = -1;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -140,11 +190,20 @@ int main(int argc, char **argv) {
         else if (a == "--dump" && i + 1 < argc) dump = argv[++i];
         else if (a == "--seed" && i + 1 < argc) seed = atol(argv[++i]);
         else if (a == "--dump-fri" && i + 1 < argc) { g_fri_dump = fopen(argv[++i], "wb"); if (!g_fri_dump) { perror("dump-fri"); return 2; } }
+        else if (a == "--dump-fft" && i + 1 < argc) { g_fft_dump = fopen(argv[++i], "wb"); if (!g_fft_dump) { perror("dump-fft"); return 2; } }
+        else if (a == "--fft-gkr" && i + 1 < argc) fft_lg = atoi(argv[++i]);
         else if (a == "--randomize" && i + 2 < argc) { rnd_layers = atoi(argv[++i]); rnd_log = atoi(argv[++i]); }
         else if (a == "--custom" && i + 1 < argc) custom = argv[++i];
         else { fprintf(stderr, "bad arg %s\n", argv[i]); return 2; }
     }
-    if (!pws && !rnd_layers && !custom) { fprintf(stderr, "need --pws, --randomize or --custom\n"); return 2; }
+    if (fft_lg > 0) {                          // fft_gkr alone, from the generator state F::init() leaves (srand(3396))
+        F::init();
+        double vt = 0, pt = 0; int ps = 0;
+        virgo::fft_circuit_gkr::fft_gkr(fft_lg, vt, ps, pt);
+        if (g_fft_dump) fclose(g_fft_dump);
+        return 0;
+    }
+    if (!pws && !rnd_layers && !custom) { fprintf(stderr, "need --pws, --randomize, --custom or --fft-gkr\n"); return 2; }
     if (seed >= 0) srandom((unsigned) seed);   // per-proof witness seed
 
     auto t0 = std::chrono::high_resolution_clock::now();
@@ -209,6 +268,7 @@ int main(int argc, char **argv) {
     }
     auto t3 = std::chrono::high_resolution_clock::now();
     if (g_vp_ref.dump) fclose(g_vp_ref.dump);
+    if (g_fft_dump) fclose(g_fft_dump);
     if (g_fri_dump) {
         // final codeword of the commit phase (fri::commit_phase_final, fri.cpp:426-431): 32 values per slice,
         // interleaved [i << 7 | slice << 1 | hi] for i < 16, followed by the mask codeword (32 values)

@@ -1459,3 +1459,244 @@ extern "C" int orc_last_point(const orc_circuit *oc, orc_F *out, int n) {
     for (int i = 0; i < n; ++i) { out[i].real = oc->last_point[i].re; out[i].img = oc->last_point[i].im; }
     return 0;
 }
+
+// ====================================================================================================
+// fft_gkr — lib/virgo/src/fft_circuit_GKR.cpp:22-849.  verify_poly_commitment runs it between the commitment and
+// the FRI commit phase (vpd_verifier.cpp:92): a self-contained GKR (prover AND verifier in one function, verifier randomness from
+// the same glibc stream) over the circuit  r -> eq-expansion E(r) -> inverse FFT (lg butterfly layers) -> scaling by 1/n ->
+// 64 polynomial evaluations at random points (a multiplication layer of 64 * 2^lg products and an addition layer of 64 sums).
+// Restated here on VALUE tables (fold, then sum the pair products — the same field elements as the reference's linear_poly tables,
+// :156-188); pinned against the real reference's record (oracle/ref_driver.cpp --dump-fft: the 64 outputs, every round polynomial,
+// every v_u / v_v) by tests/test_oracle_golden.py.  Draw order = the reference's: r[lg] (:840), eval_points[64] (:84), r_0, r_1 of
+// lg + 10 (:789-790), per sumcheck r_u then r_v (:275-276, :394-395, :563-564), alpha, beta after every inverse-FFT depth (:763-764).
+// ====================================================================================================
+namespace {
+
+struct FftGkr {
+    int lg;
+    vector<F> msgs;                                  // outputs[64] | per sumcheck: round polynomials, then the claimed table value(s)
+    vector<vector<F>> B;                             // B[0] = E(r), B[t] = after the butterflies of depth lg - t (t = 1..lg)
+    vector<F> S, Pm, O, xs;                          // scaled coefficients, the 64 * 2^lg products, the 64 sums, the evaluation points
+    F alpha, beta;
+    vector<F> r0, r1, ru, rv;
+    bool ok = true;
+    double p_sec = 0, v_sec = 0;
+    u64 rounds = 0, pairs = 0;
+
+    static void draws(vector<F> &v, int n) { for (int i = 0; i < n; ++i) v[i] = frandom(); }
+    // alpha * eq(r0[0..n), g) + beta * eq(r1[0..n), g), bit b of g set <-> r[b] (the beta_g half tables, :193-216)
+    vector<F> g_table(int n) const {
+        vector<F> t0, t1;
+        init_beta_table(t0, n, r0.data(), alpha);
+        init_beta_table(t1, n, r1.data(), beta);
+        vector<F> g(1ull << n);
+        for (u64 i = 0; i < g.size(); ++i) g[i] = t0[i] + t1[i];
+        return g;
+    }
+    // one sumcheck over (V, M, A): `n` rounds with challenges ch[0..n); appends the polynomials; returns V's last value
+    F sumcheck(vector<F> V, vector<F> M, vector<F> A, int n, const F *ch, F &claim) {
+        Timer t; t.start();
+        for (int k = 0; k < n; ++k) {
+            const u64 half = V.size() >> 1;
+            Quad q(F_ZERO, F_ZERO, F_ZERO);
+            for (u64 i = 0; i < half; ++i) {
+                const F v0 = V[2 * i], dv = V[2 * i + 1] - v0, m0 = M[2 * i], dm = M[2 * i + 1] - m0, a0 = A[2 * i], da = A[2 * i + 1] - a0;
+                q.a = q.a + dm * dv;
+                q.b = q.b + dm * v0 + m0 * dv + da;
+                q.c = q.c + m0 * v0 + a0;
+            }
+            pairs += half; ++rounds;
+            msgs.push_back(q.a); msgs.push_back(q.b); msgs.push_back(q.c);
+            t.stop();
+            Timer tv; tv.start();
+            if (q.eval(F_ZERO) + q.eval(F_ONE) != claim) ok = false;              // :264-266
+            claim = q.eval(ch[k]);
+            tv.stop(); v_sec += tv.total;
+            t.start();
+            for (u64 i = 0; i < half; ++i) {
+                V[i] = V[2 * i] + ch[k] * (V[2 * i + 1] - V[2 * i]);
+                M[i] = M[2 * i] + ch[k] * (M[2 * i + 1] - M[2 * i]);
+                A[i] = A[2 * i] + ch[k] * (A[2 * i + 1] - A[2 * i]);
+            }
+            V.resize(half); M.resize(half); A.resize(half);
+        }
+        t.stop(); p_sec += t.total;
+        msgs.push_back(V[0]);
+        return V[0];
+    }
+
+    void build(const vector<F> &r) {                                              // build_circuit, :22-101
+        const u64 N = 1ull << lg;
+        B.assign(lg + 1, vector<F>());
+        vector<F> e(1, F_ONE);
+        for (int i = 0; i < lg; ++i) {
+            vector<F> nx(e.size() * 2);
+            for (u64 j = 0; j < e.size(); ++j) { nx[2 * j] = e[j] * r[i]; nx[2 * j + 1] = e[j] * (F_ONE - r[i]); }
+            e.swap(nx);
+        }
+        B[0] = e;
+        const F inv_rou = finv(root_of_unity(lg));
+        for (int dep = lg - 1; dep >= 0; --dep) {
+            const int t = lg - dep;
+            const u64 half = 1ull << (lg - dep - 1), J = 1ull << dep;
+            F w = inv_rou;
+            for (int q = 0; q < dep; ++q) w = w * w;                                // rot_mul[dep] = inv_rou^(2^dep)
+            B[t].assign(N, F_ZERO);
+            F x = F_ONE;
+            for (u64 k = 0; k < half; ++k) {
+                for (u64 j = 0; j < J; ++j) {
+                    const F l = B[t - 1][k << (dep + 1) | j], rr = x * B[t - 1][k << (dep + 1) | J | j];
+                    B[t][k << dep | j] = l + rr;
+                    B[t][(k + half) << dep | j] = l - rr;
+                }
+                x = x * w;
+            }
+        }
+        const F inv_n = fpow(F((long long) N), (u128) P - 2);
+        S.resize(N);
+        for (u64 i = 0; i < N; ++i) S[i] = B[lg][i] * inv_n;
+        xs.resize(64); Pm.resize(64 * N); O.assign(64, F_ZERO);
+        for (int i = 0; i < 64; ++i) {
+            xs[i] = frandom();
+            F x = F_ONE;
+            for (u64 j = 0; j < N; ++j) { Pm[j + ((u64) i << lg)] = S[j] * x; x = x * xs[i]; }
+        }
+        for (int i = 0; i < 64; ++i) for (u64 j = 0; j < N; ++j) O[i] = O[i] + Pm[j + (u64) i * N];
+    }
+
+    void run() {
+        const u64 N = 1ull << lg;
+        vector<F> r(lg);
+        draws(r, lg);
+        build(r);
+        for (int i = 0; i < 64; ++i) msgs.push_back(O[i]);
+        alpha = F_ONE; beta = F_ZERO;                                              // engage_gkr, :774-831
+        r0.assign(lg + 10, F_ZERO); r1 = r0; ru = r0; rv = r0;
+        draws(r0, lg + 10); draws(r1, lg + 10);
+        vector<F> o = O;                                                           // V_output, :121-136
+        for (int i = 0; i < 6; ++i) { for (u64 j = 0; j < o.size() / 2; ++j) o[j] = o[2 * j] * (F_ONE - r0[i]) + o[2 * j + 1] * r0[i]; o.resize(o.size() / 2); }
+        F claim = o[0];
+        {   // addition layer (:190-309): the 64 sums; g ranges over the 64 outputs, u over the 64 * 2^lg products
+            const int n = lg + 6;
+            const vector<F> g = g_table(6);
+            vector<F> M(64 * N), A(64 * N, F_ZERO);
+            for (u64 j = 0; j < 64 * N; ++j) M[j] = g[j >> lg];
+            draws(ru, n); draws(rv, n);
+            const F vu = sumcheck(Pm, M, A, n, ru.data(), claim);
+            Timer tv; tv.start();
+            vector<F> eu;
+            init_beta_table(eu, 6, ru.data() + lg, F_ONE);
+            F s = F_ZERO;
+            for (int i = 0; i < 64; ++i) s = s + g[i] * eu[i];
+            if (claim != s * vu) ok = false;
+            tv.stop(); v_sec += tv.total;
+            for (int i = 0; i < n; ++i) { r0[i] = ru[i]; r1[i] = rv[i]; }
+            claim = alpha * vu;
+        }
+        {   // multiplication layer (:311-447): product j * 2^lg + i = S[i] * x_j^i
+            const vector<F> g = g_table(lg + 6);
+            vector<F> M(N, F_ZERO), A(N, F_ZERO), xp(64, F_ONE);
+            for (u64 i = 0; i < N; ++i)
+                for (int j = 0; j < 64; ++j) { M[i] = M[i] + g[(u64) j * N + i] * xp[j]; xp[j] = xp[j] * xs[j]; }
+            draws(ru, lg); draws(rv, lg);
+            const F vu = sumcheck(S, M, A, lg, ru.data(), claim);
+            Timer tv; tv.start();
+            F s = F_ZERO;
+            for (int i = 0; i < 64; ++i) {
+                F g0 = alpha, g1 = beta;
+                for (int j = 0; j < 6; ++j) {
+                    if ((i >> j) & 1) { g0 = g0 * r0[lg + j]; g1 = g1 * r1[lg + j]; }
+                    else { g0 = g0 * (F_ONE - r0[lg + j]); g1 = g1 * (F_ONE - r1[lg + j]); }
+                }
+                F u0 = F_ONE, u1 = F_ONE, x = xs[i];
+                for (int j = 0; j < lg; ++j) {
+                    u0 = u0 * (r0[j] * ru[j] * x + (F_ONE - r0[j]) * (F_ONE - ru[j]));
+                    u1 = u1 * (r1[j] * ru[j] * x + (F_ONE - r1[j]) * (F_ONE - ru[j]));
+                    x = x * x;
+                }
+                s = s + g0 * u0 + g1 * u1;
+            }
+            if (claim != s * vu) ok = false;
+            tv.stop(); v_sec += tv.total;
+            for (int i = 0; i < lg; ++i) { r0[i] = ru[i]; r1[i] = rv[i]; }
+            claim = alpha * vu;
+        }
+        claim = claim * F((long long) N);                                          // intermediate_layer, :449-456
+        const F inv_rou = finv(root_of_unity(lg));
+        for (int dep = 0; dep < lg; ++dep) {                                       // ifft_gkr, :458-768
+            const vector<F> &pre = B[lg - dep - 1];
+            const vector<F> g = g_table(lg);
+            const u64 half = 1ull << (lg - dep - 1), J = 1ull << dep;
+            F w = inv_rou;
+            for (int q = 0; q < dep; ++q) w = w * w;
+            vector<F> M(N, F_ZERO), A(N, F_ZERO);
+            F x = F_ONE;
+            for (u64 k = 0; k < half; ++k) {
+                for (u64 j = 0; j < J; ++j) {
+                    const u64 u = k << (dep + 1) | j, v = u | J;
+                    const F t1 = g[k << dep | j], t2 = g[(k + half) << dep | j];
+                    M[u] = t1 + t2;
+                    A[u] = t1 * x * pre[v] - t2 * x * pre[v];
+                }
+                x = x * w;
+            }
+            draws(ru, lg); draws(rv, lg);
+            const F vu = sumcheck(pre, M, A, lg, ru.data(), claim);
+            vector<F> eu;
+            init_beta_table(eu, lg, ru.data(), F_ONE);
+            M.assign(N, F_ZERO); A.assign(N, F_ZERO);
+            x = F_ONE;
+            for (u64 k = 0; k < half; ++k) {
+                for (u64 j = 0; j < J; ++j) {
+                    const u64 u = k << (dep + 1) | j, v = u | J;
+                    const F a1 = g[k << dep | j] * eu[u], a2 = g[(k + half) << dep | j] * eu[u];
+                    M[v] = a1 * x - a2 * x;
+                    A[v] = a1 * vu + a2 * vu;
+                }
+                x = x * w;
+            }
+            const F vv = sumcheck(pre, M, A, lg, rv.data(), claim);
+            Timer tv; tv.start();
+            {   // the verifier's closed form of the wiring predicate at (r_0 | r_1, r_u, r_v), :639-752
+                const int lj = dep, lk = lg - dep - 1;
+                const F hu = (F_ONE - ru[lj]) * rv[lj];
+                F uA0 = (F_ONE - r0[lg - 1]) * hu * alpha, uA1 = (F_ONE - r1[lg - 1]) * hu * beta, vA0 = uA0, vA1 = uA1;
+                F uB0 = r0[lg - 1] * hu * alpha, uB1 = r1[lg - 1] * hu * beta, vB0 = uB0, vB1 = uB1;
+                F xx = w;
+                for (int i = 0; i < lk; ++i) {
+                    const F p0 = r0[lj + i] * ru[lj + 1 + i] * rv[lj + 1 + i], q0 = (F_ONE - r0[lj + i]) * (F_ONE - ru[lj + 1 + i]) * (F_ONE - rv[lj + 1 + i]);
+                    const F p1 = r1[lj + i] * ru[lj + 1 + i] * rv[lj + 1 + i], q1 = (F_ONE - r1[lj + i]) * (F_ONE - ru[lj + 1 + i]) * (F_ONE - rv[lj + 1 + i]);
+                    uA0 = uA0 * (p0 + q0); uA1 = uA1 * (p1 + q1); uB0 = uB0 * (p0 + q0); uB1 = uB1 * (p1 + q1);
+                    vA0 = vA0 * (p0 * xx + q0); vA1 = vA1 * (p1 * xx + q1); vB0 = vB0 * (q0 + p0 * xx); vB1 = vB1 * (q1 + p1 * xx);
+                    xx = xx * xx;
+                }
+                for (int i = 0; i < lj; ++i) {
+                    const F e0 = r0[i] * ru[i] * rv[i] + (F_ONE - r0[i]) * (F_ONE - ru[i]) * (F_ONE - rv[i]);
+                    const F e1 = r1[i] * ru[i] * rv[i] + (F_ONE - r1[i]) * (F_ONE - ru[i]) * (F_ONE - rv[i]);
+                    uA0 = uA0 * e0; vA0 = vA0 * e0; uB0 = uB0 * e0; vB0 = vB0 * e0;
+                    uA1 = uA1 * e1; vA1 = vA1 * e1; uB1 = uB1 * e1; vB1 = vB1 * e1;
+                }
+                if (claim != (uA0 + uA1 + uB0 + uB1) * vu + (vA0 + vA1 - vB0 - vB1) * vv) ok = false;
+            }
+            tv.stop(); v_sec += tv.total;
+            for (int i = 0; i < lg; ++i) { r0[i] = ru[i]; r1[i] = rv[i]; }
+            alpha = frandom(); beta = frandom();
+            claim = alpha * vu + beta * vv;
+        }
+    }
+};
+
+}  // namespace
+
+extern "C" int64_t orc_fft_gkr(int lg, long seed, uint8_t *msgs, int64_t capacity, double *prove_sec, int *verified) {
+    if (lg < 1 || lg > 24) return -2;
+    if (seed >= 0) srand((unsigned) seed);
+    FftGkr f; f.lg = lg;
+    f.run();
+    if (prove_sec) *prove_sec = f.p_sec;
+    if (verified) *verified = f.ok ? 1 : 0;
+    const int64_t n = (int64_t) f.msgs.size() * 16;
+    if (n > capacity) return -1;
+    for (size_t i = 0; i < f.msgs.size(); ++i) { u64 w[2] = {f.msgs[i].re, f.msgs[i].im}; memcpy(msgs + 16 * i, w, 16); }
+    return n;
+}

@@ -93,6 +93,13 @@ void orc_f_random_next(int n, orc_F *out);
  * which verify_poly_commitment runs (vpd_verifier.cpp:92) before commit_phase draws the FRI challenges (:56).
  * Pinned by tests/test_oracle_golden.py against the challenges the real reference recorded.            */
 int orc_fft_gkr_draws(int lg);
+/* fft_circuit_gkr::fft_gkr(lg) (lib/virgo/src/fft_circuit_GKR.cpp:833-849), prover and verifier: seed >= 0 -> srand(seed) first, else the
+ * current glibc state.  msgs receives the record the real reference is hooked for (oracle/ref_driver.cpp --dump-fft): the circuit's 64
+ * outputs, then per sumcheck its round polynomials (3 F each) and the table value(s) claimed at its end — addition layer (lg + 6 rounds,
+ * v_u), multiplication layer (lg rounds, v_u), per inverse-FFT depth: phase 1 (lg rounds, v_u), phase 2 (lg rounds, v_v).  Returns the
+ * byte count (16 * (64 + 3 * (2 lg^2 + 2 lg + 6) + 2 + 2 lg)), -1 if capacity is too small.  *verified = every check of the
+ * reference's embedded verifier held.                                                                 */
+int64_t orc_fft_gkr(int lg, long seed, uint8_t *msgs, int64_t capacity, double *prove_sec, int *verified);
 /* initBetaTable(beta, n, r, init): out has 2^n entries.                                               */
 void orc_beta_table(const orc_F *r, int n, const orc_F *init, orc_F *out);
 /* One call of prover::sumcheckUpdateEach on value tables (the .a parts implied zero / carried in

@@ -312,3 +312,52 @@ def test_full_size_oracle_fixtures_equal_the_real_reference(golden, name):
         assert fri[48 * st:48 * st + 2048 * 16] == fin
         pc = open(os.path.join(GOLDEN, "oracle_sha256_x1024_pc.bin"), "rb").read()
         assert pc[:32] == ref[:32]                                                       # merkle_root_l (the rest used another public vector)
+
+
+def _orc_fft_gkr(ob, lg, seed):
+    L = ob.lib()
+    L.orc_fft_gkr.restype = ctypes.c_int64
+    L.orc_fft_gkr.argtypes = [ctypes.c_int, ctypes.c_long, ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
+    buf = ctypes.create_string_buffer(1 << 20)
+    ok = ctypes.c_int(0)
+    n = L.orc_fft_gkr(lg, seed, buf, len(buf), None, ctypes.byref(ok))
+    assert n > 0
+    return buf.raw[:n], ok.value
+
+
+@pytest.mark.parametrize("lg", [7, 13, 17])
+def test_oracle_fft_gkr_vs_reference_record(ob, lg):
+    """lib/virgo's fft_gkr (fft_circuit_GKR.cpp:22-849) restated in the oracle (orc_fft_gkr) against the REAL reference's
+    record of the same call — `ref_run --fft-gkr LG --dump-fft` after F::init(): the circuit's 64 outputs, every round polynomial of the
+    2 + 2 lg sumchecks and every claimed table value, taken at link time (ld --wrap on quadratic_poly::eval / linear_poly::eval, no
+    reference line edited).  lg = 7 / 13 / 17 are the sizes of the x1 / x64 / x1024 SHA-256 commitments."""
+    from conftest import GOLDEN
+    rec, ok = _orc_fft_gkr(ob, lg, 3396)
+    assert ok == 1
+    assert len(rec) == 16 * (64 + 3 * (2 * lg * lg + 2 * lg + 6) + 2 + 2 * lg)
+    assert rec == open(os.path.join(GOLDEN, "fftgkr_lg%d.bin" % lg), "rb").read()
+
+
+@pytest.mark.parametrize("name,lg", [("sha256_x1", 7), ("randomize_8_12", 6)])
+def test_oracle_fft_gkr_inside_the_protocol(ob, golden, pws_path, name, lg):
+    """The same record taken INSIDE the reference's complete run (verify_poly_commitment, vpd_verifier.cpp:92): the oracle proves up to
+    commit_public and then runs fft_gkr from wherever the glibc stream stands — equality pins the stream position too (the draw-count
+    replay of round 2, 2 lg^2 + 9 lg + 96 draws, is now a consequence)."""
+    from conftest import GOLDEN
+    c = ob.Circuit.from_pws(pws_path, 1, seed=1) if name == "sha256_x1" else ob.Circuit.randomize(8, 12, seed=1)
+    L = ob.lib()
+    L.orc_prove_full.restype = ctypes.c_int64
+    L.orc_prove_full.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+    buf = ctypes.create_string_buffer(1 << 20)
+    n = L.orc_prove_full(c.h, buf, len(buf), None)
+    assert buf.raw[:n] == open(os.path.join(GOLDEN, golden[name]["transcript"]), "rb").read()
+    rec, ok = _orc_fft_gkr(ob, lg, -1)
+    assert ok == 1 and rec == open(os.path.join(GOLDEN, "fftgkr_%s.bin" % name), "rb").read()
+    # ... and the FRI challenges the reference drew next are the next draws of the stream
+    L.orc_f_random_next.argtypes = [ctypes.c_int, ctypes.c_void_p]
+    st = golden[name]["fri_steps"]
+    nxt = np.zeros((st, 2), dtype=np.uint64)
+    L.orc_f_random_next(st, nxt.ctypes.data)
+    fri = open(os.path.join(GOLDEN, golden[name]["fri"]), "rb").read()
+    assert nxt.tobytes() == b"".join(fri[48 * k:48 * k + 16] for k in range(st))
+    c.close()
