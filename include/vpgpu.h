@@ -252,7 +252,19 @@ int vp_fri_final(vp_ctx *, vp_F *final_code);
  * mask pair) = the two codeword entries of the leaf per slice; path: depth+1 digests, path[k] = sibling at height k,
  * path[depth] = the leaf digest (the reference's com_hhash layout).  *path_len receives depth + 1.           */
 int vp_fri_open(vp_ctx *, int oracle, uint64_t leaf, vp_F values[130], uint8_t *path, int path_capacity, int *path_len);
-/* Device time of the last vp_commit_private / vp_commit_public / vp_fri_step in milliseconds (hipEvents). */
+/* fft_circuit_gkr::fft_gkr(lg) (lib/virgo/src/fft_circuit_GKR.cpp:833-849), prover side: the self-contained GKR over the inverse-FFT +
+ * polynomial-evaluation circuit that verify_poly_commitment runs between commit_public and the FRI commit phase (vpd_verifier.cpp:92,
+ * lg = bit_length(layer 0) - 6) and whose prover time the reference adds to "Polynomial commitment: prove time" (:94, src/verifier.cpp:183).
+ * Like vp_prove_gkr it takes the verifier's whole tape up front (its draws are glibc random(), transcript-independent) — in the
+ * reference's draw order:  r[lg] (:840) | eval_points[64] (:84) | r_0[lg+10] | r_1[lg+10] (:789-790) | addition layer r_u[lg+6], r_v[lg+6]
+ * (:275-276) | multiplication layer r_u[lg], r_v[lg] (:394-395) | per inverse-FFT depth (lg of them): r_u[lg], r_v[lg] (:563-564), alpha, beta
+ * (:763-764) — and returns every prover message:  the circuit's 64 outputs | addition layer: lg+6 round polynomials (a, b, c), v_u |
+ * multiplication layer: lg polynomials, v_u | per depth: lg polynomials, v_u, lg polynomials, v_v.  The checks of the reference's embedded
+ * verifier (:261-266, :285-308, :405-446, :639-752) stay on the host (virgo-plus_amd/host/fft_gkr_verify.hpp).  No circuit needs to be
+ * uploaded.  vp_fft_gkr_sizes gives the two element counts (2 lg^2 + 9 lg + 96 and 64 + 3 (2 lg^2 + 2 lg + 6) + 2 + 2 lg); lg in 1..20.        */
+int vp_fft_gkr_sizes(int lg, uint64_t *n_tape, uint64_t *n_msgs);
+int vp_fft_gkr(vp_ctx *, int lg, const vp_F *tape, uint64_t n_tape, vp_F *msgs, uint64_t capacity, uint64_t *n_written);
+/* Device time of the last vp_commit_private / vp_commit_public / vp_fri_step / vp_fft_gkr in milliseconds (hipEvents). */
 int vp_commit_stats(vp_ctx *, double *commit_ms);
 
 /* ---- commitment sharded over the GPUs of a node (SURVEY.md §8e "PC sharding"; north_star "FFT subtrees shard") ---------------- */

@@ -341,6 +341,52 @@ def test_fiat_shamir_proof_bytes_equal_the_oracles(vp, ob, pws_path, make):
     s.close(); c.close(); oc.close()
 
 
+@pytest.mark.parametrize("lg", [1, 2, 3, 4, 5, 7, 10, 11, 12, 13, 17])
+def test_fft_gkr_vs_reference_record_and_oracle(vp, ob, ctx, lg):
+    """lib/virgo's fft_gkr (fft_circuit_GKR.cpp:833-849) on the device, vp_fft_gkr: the circuit's 64 outputs, every round
+    polynomial of its 2 + 2 lg sumchecks and every claimed table value, bit-exact against the REAL reference's record of the same call
+    (tests/golden/fftgkr_lg{7,13,17}.bin: `ref_run --fft-gkr LG --dump-fft`, taken at link time, lg = 7 / 13 / 17 are the x1 / x64 / x1024
+    commitments) and against the oracle's restatement at every size, including the degenerate ones (one-round sumchecks).  The tape is the
+    reference's own draw sequence after F::init()."""
+    lib = vp.lib_gpu()
+    lib.vp_fft_gkr_sizes.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    lib.vp_fft_gkr.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
+    nt, nm = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    assert lib.vp_fft_gkr_sizes(lg, ctypes.byref(nt), ctypes.byref(nm)) == 0
+    assert nt.value == 2 * lg * lg + 9 * lg + 96 and nm.value == 64 + 3 * (2 * lg * lg + 2 * lg + 6) + 2 + 2 * lg
+    tape = np.zeros((nt.value, 2), dtype=np.uint64)
+    ob.lib().orc_f_random_seq(3396, int(nt.value), tape.ctypes.data)
+    msgs = np.zeros((nm.value, 2), dtype=np.uint64)
+    nw = ctypes.c_uint64(0)
+    rc = lib.vp_fft_gkr(ctx, lg, tape.ctypes.data, nt.value, msgs.ctypes.data, nm.value, ctypes.byref(nw))
+    assert rc == 0, lib.vp_last_error(ctx)
+    assert nw.value == nm.value
+    L = ob.lib()
+    L.orc_fft_gkr.restype = ctypes.c_int64
+    L.orc_fft_gkr.argtypes = [ctypes.c_int, ctypes.c_long, ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
+    buf = ctypes.create_string_buffer(16 * int(nm.value))
+    ok = ctypes.c_int(0)
+    n = L.orc_fft_gkr(lg, 3396, buf, len(buf), None, ctypes.byref(ok))
+    assert n == 16 * nm.value and ok.value == 1
+    got = msgs.tobytes()
+    if got != buf.raw:
+        first = next(i for i in range(int(nm.value)) if got[16 * i:16 * i + 16] != buf.raw[16 * i:16 * i + 16])
+        raise AssertionError("fft_gkr(lg=%d): first differing message element %d of %d" % (lg, first, nm.value))
+    if lg in (7, 13, 17):
+        assert got == open(os.path.join(GOLDEN_DIR, "fftgkr_lg%d.bin" % lg), "rb").read()
+    # a second call on the same context (buffers reused), another tape: still the oracle's answer
+    ob.lib().orc_f_random_seq(77, int(nt.value), tape.ctypes.data)
+    assert lib.vp_fft_gkr(ctx, lg, tape.ctypes.data, nt.value, msgs.ctypes.data, nm.value, None) == 0
+    assert L.orc_fft_gkr(lg, 77, buf, len(buf), None, ctypes.byref(ok)) == n and ok.value == 1
+    assert msgs.tobytes() == buf.raw
+    # misuse: wrong sizes, non-canonical tape element
+    assert lib.vp_fft_gkr(ctx, lg, tape.ctypes.data, nt.value - 1, msgs.ctypes.data, nm.value, None) == -1
+    assert lib.vp_fft_gkr(ctx, lg, tape.ctypes.data, nt.value, msgs.ctypes.data, nm.value - 1, None) == -1
+    tape[3, 1] = np.uint64(P)
+    assert lib.vp_fft_gkr(ctx, lg, tape.ctypes.data, nt.value, msgs.ctypes.data, nm.value, None) == -1
+    assert lib.vp_fft_gkr(ctx, 21, tape.ctypes.data, nt.value, msgs.ctypes.data, nm.value, None) == -5
+
+
 def test_launch_stats_table_covers_every_launch(vp, gold_gkr):
     """vp_set_profiling + vp_get_launch_stats (include/vpgpu.h): the profiled replay produces the same transcript and a per-launch
     table that names every kernel kind of the plan with its algorithmic bytes, rounds and an event-measured duration; the

@@ -24,7 +24,7 @@ LIB_GPU = os.environ.get("VP_LIBGPU") or os.path.join(CSRC, "libvpgpu.so")
 LIB_HOST = os.path.join(HOST, "libvphost.so")
 CLI = os.path.join(HOST, "virgo_plus_run")
 
-GPU_SRC = [os.path.join(CSRC, f) for f in ("vpgpu.hip", "vpgpu_batched.inc", "vpgpu_pc.inc", "vpgpu_pc_shard.inc", "vp_kernels.h", "vp_kernels_round.h", "vp_kernels_persist.h", "vp_kernels_batch.h",
+GPU_SRC = [os.path.join(CSRC, f) for f in ("vpgpu.hip", "vpgpu_batched.inc", "vpgpu_pc.inc", "vpgpu_pc_shard.inc", "vpgpu_fftgkr.inc", "vpgpu_upload.inc", "vp_kernels_fftgkr.h", "vp_kernels.h", "vp_kernels_round.h", "vp_kernels_persist.h", "vp_kernels_batch.h",
                                               "vp_kernels_init3.h", "vp_kernels_plan.h", "vp_kernels_pc.h", "vp_field.h")] + [
     os.path.join(ROOT, "include", "vpgpu.h")]
 HOST_SRC = [os.path.join(HOST, f) for f in ("circuit.cpp", "prover.cpp", "verifier.cpp", "vphost.cpp")]

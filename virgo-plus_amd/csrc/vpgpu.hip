@@ -68,6 +68,7 @@ struct EvPair { hipEvent_t a, b; u64 bytes; int kind; u32 grid, jobs, rounds, fi
 }  // namespace
 
 struct PcShard;            // commitment sharded over ranks (vpgpu_pc_shard.inc)
+struct FgkState;           // buffers of vp_fft_gkr (vpgpu_fftgkr.inc)
 struct VpComm;             // RCCL communicator (vpgpu_pc_shard.inc)
 // One in-order chain of the batched proof: its own stream and scratch, so that independent sumchecks
 // (all of them, given the tape, except phase 1 -> phase 2 of the same layer) overlap on the device.
@@ -159,6 +160,7 @@ struct vp_ctx {
     F *pc_fri[2] = {nullptr, nullptr}; Dig *pc_fri_tree = nullptr; int fri_step = -1; size_t fri_tree_used = 0; bool pc_public_done = false;
 
     PcShard *pcs = nullptr;              // non-null while the commitment is sharded over ranks (vp_pc_set_shard, world > 1)
+    FgkState *fgk = nullptr;             // vp_fft_gkr: circuit layers and sumcheck tables of the last size used
     VpComm *cm = nullptr;                // RCCL communicator (vp_comm_init)
     F *part2 = nullptr;                  // [32][MAX_BLOCKS*3] block partials of the batched path
     int simple_path = 0, sumfold_path = 0, serial = 0;
@@ -693,6 +695,7 @@ int vp_create_with_options(int device, const vp_options *user, vp_ctx **out) {
 static void free_plan(vp_ctx *ctx);
 void vp_free_shard_state(vp_ctx *ctx);
 void vp_free_comm(vp_ctx *ctx);
+void vp_free_fgk(vp_ctx *ctx);
 
 void vp_destroy(vp_ctx *ctx) {
     if (!ctx) return;
@@ -701,6 +704,7 @@ void vp_destroy(vp_ctx *ctx) {
     (void) hipStreamSynchronize(ctx->stream);
     vp_free_shard_state(ctx);
     vp_free_comm(ctx);
+    vp_free_fgk(ctx);
     if (ctx->gkr_graph) (void) hipGraphExecDestroy(ctx->gkr_graph);
     free_plan(ctx);
     free_all(ctx);
@@ -1401,3 +1405,4 @@ int vp_test_beta(vp_ctx *ctx, const vp_F *r, int n, const vp_F *init, vp_F *out)
 #include "vpgpu_batched.inc"
 #include "vpgpu_pc.inc"
 #include "vpgpu_pc_shard.inc"
+#include "vpgpu_fftgkr.inc"
