@@ -62,14 +62,15 @@ static FILE *env_file(const char *name) {
 }
 FILE *vpi_dump_file() { static FILE *f = env_file("VPI_DUMP"); return f; }
 FILE *vpi_dump_fri_file() { static FILE *f = env_file("VPI_DUMP_FRI"); return f; }
+FILE *vpi_dump_fft_file() { static FILE *f = env_file("VPI_DUMP_FFT"); return f; }
 static void dumpF(const F &x) { if (FILE *f = vpi_dump_file()) { unsigned long long w[2] = {x.real, x.img}; fwrite(w, 8, 2, f); fflush(f); } }
 static void dumpH(const void *d) { if (FILE *f = vpi_dump_file()) { fwrite(d, 32, 1, f); fflush(f); } }
 static void trace_at_exit() {
     const char *t = getenv("VPI_TRACE");
     if (!t || !*t || *t == '0') return;
-    fprintf(stderr, "vpgpu calls: commit_private %lu commit_public %lu fri_step %lu fri_final %lu open_init %lu open_step %lu round %lu finalize %lu rand_consumers %lu\n",
+    fprintf(stderr, "vpgpu calls: commit_private %lu commit_public %lu fri_step %lu fri_final %lu open_init %lu open_step %lu round %lu finalize %lu rand_consumers %lu fft_gkr %lu\n",
             g_vpi_count.commit_private, g_vpi_count.commit_public, g_vpi_count.fri_step, g_vpi_count.fri_final, g_vpi_count.open_init,
-            g_vpi_count.open_step, g_vpi_count.round, g_vpi_count.finalize, g_vpi_count.rand_consumers);
+            g_vpi_count.open_step, g_vpi_count.round, g_vpi_count.finalize, g_vpi_count.rand_consumers, g_vpi_count.fft_gkr);
 }
 static_assert(sizeof(F) == sizeof(vp_F), "virgo::fieldElement is two u64 limbs (fieldElement.hpp:96-97)");
 

@@ -1,8 +1,9 @@
 // TEST INFRASTRUCTURE ONLY — never linked into the product.
 //
-// Shared between the two forwarding files a reference maintainer would add:
-//   prover_vpgpu.cpp  — bodies of src/prover.cpp        (class prover, src/prover.h:12-66)
-//   fri_vpgpu.cpp     — bodies of lib/virgo/src/fri.cpp (namespace virgo::fri, lib/virgo/src/fri.h:56-104)
+// Shared between the three forwarding files a reference maintainer would add:
+//   prover_vpgpu.cpp   — bodies of src/prover.cpp        (class prover, src/prover.h:12-66)
+//   fri_vpgpu.cpp      — bodies of lib/virgo/src/fri.cpp (namespace virgo::fri, lib/virgo/src/fri.h:56-104)
+//   fft_gkr_vpgpu.cpp  — body of lib/virgo/src/fft_circuit_GKR.cpp's fft_gkr (lib/virgo/src/fft_circuit_GKR.h:4)
 // The reference has one prover per process (not re-entrant), so the device context is one
 // process-wide object owned by prover_vpgpu.cpp.
 #pragma once
@@ -19,6 +20,7 @@ void vpi_oracle_committed(int oracle_indicator, int bit_len, const unsigned char
 //   VPI_DUMP=<file>      every prover message in the golden transcript layout of SURVEY.md §8c
 //   VPI_DUMP_FRI=<file>  per FRI step challenge[16] | root[32], then the final codeword (2048 F) and the mask codeword (32 F)
 //                        — the layout of tests/golden/fri_*.bin (oracle/ref_driver.cpp)
+//   VPI_DUMP_FFT=<file>  the messages of fft_gkr (vp_fft_gkr's layout = the layout of tests/golden/fftgkr_*.bin)
 //   VPI_TRACE=1          at exit: how many vp_* calls of each kind served the reference's verifier (stderr)
 
 // The reference's verifier draws every challenge from glibc random() (lib/virgo/src/fieldElement.cpp:119-124,362-367) and its query positions
@@ -35,5 +37,6 @@ struct vpi_rand_guard {
 };
 FILE *vpi_dump_file();
 FILE *vpi_dump_fri_file();
-struct vpi_counters { unsigned long commit_private, commit_public, fri_step, fri_final, open_init, open_step, round, finalize, rand_consumers; };
+FILE *vpi_dump_fft_file();
+struct vpi_counters { unsigned long commit_private, commit_public, fri_step, fri_final, open_init, open_step, round, finalize, rand_consumers, fft_gkr; };
 extern vpi_counters g_vpi_count;

@@ -1157,7 +1157,8 @@ def test_options_struct_selects_the_same_alternatives_as_the_test_environment(vp
 
 def test_reference_binary_drives_the_device_prover(pws_path, tmp_path, golden):
     """oracle/_ref/ref_run_vpgpu = the reference's own main() + verifier + circuit code + lib/virgo (minus fri.cpp), unmodified, linked
-    with INTEGRATION.md's two forwarding files (prover_vpgpu.cpp for src/prover.cpp, fri_vpgpu.cpp for lib/virgo/src/fri.cpp) and
+    with INTEGRATION.md's three forwarding files (prover_vpgpu.cpp for src/prover.cpp, fri_vpgpu.cpp for lib/virgo/src/fri.cpp,
+    fft_gkr_vpgpu.cpp for fft_circuit_GKR.cpp's fft_gkr) and
     libvpgpu.so (tests/test_integration_link.py builds it where the reference tree exists).  On SHA256_64.pws every sumcheck message,
     both Merkle roots, input_0 / all_sum, every FRI root, the final codeword and all 33 x (2 + 7) openings with their Merkle paths come
     from the device; the reference's verifier (src/verifier.cpp) and lib/virgo's verify_poly_commitment (vpd_verifier.cpp:76-328) check
@@ -1168,22 +1169,25 @@ def test_reference_binary_drives_the_device_prover(pws_path, tmp_path, golden):
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_run_vpgpu")
     if not os.path.exists(exe):
         pytest.skip("oracle/_ref/ref_run_vpgpu not built (needs the reference tree at build time)")
-    dump, dump_fri = tmp_path / "messages.bin", tmp_path / "fri.bin"
-    env = dict(os.environ, VPI_DUMP=str(dump), VPI_DUMP_FRI=str(dump_fri), VPI_TRACE="1")
+    dump, dump_fri, dump_fft = tmp_path / "messages.bin", tmp_path / "fri.bin", tmp_path / "fft.bin"
+    env = dict(os.environ, VPI_DUMP=str(dump), VPI_DUMP_FRI=str(dump_fri), VPI_DUMP_FFT=str(dump_fft), VPI_TRACE="1")
     r = subprocess.run([exe, str(pws_path)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "Verification pass" in r.stderr and "Verification fail" not in r.stderr
     assert "Prove Time" in r.stdout and "Polynomial commitment: prove time" in r.stdout
     # who served the reference's verifier: 439 rounds, 1 + 1 commitments, n - 6 = 7 FRI steps, 33 query repetitions x (l, h) and x 7 levels
     m = re.search(r"vpgpu calls: commit_private (\d+) commit_public (\d+) fri_step (\d+) fri_final (\d+) open_init (\d+) open_step (\d+) round (\d+) "
-                  r"finalize (\d+) rand_consumers (\d+)", r.stderr)
+                  r"finalize (\d+) rand_consumers (\d+) fft_gkr (\d+)", r.stderr)
     assert m, r.stderr[-2000:]
     # rand_consumers = 0: no vp_* call took draws from the process's random() generator (the library keeps the ROCm runtime's own draws
     # away from it; the verifier's challenges come from that stream, fieldElement.cpp:119-124)
-    assert [int(x) for x in m.groups()] == [1, 1, 7, 1, 66, 231, 439, 42, 0]
+    assert [int(x) for x in m.groups()] == [1, 1, 7, 1, 66, 231, 439, 42, 0, 1]
     g = golden["sha256_x1"]
     assert dump.read_bytes() == open(os.path.join(GOLDEN_DIR, g["transcript"]), "rb").read()
     assert dump_fri.read_bytes() == open(os.path.join(GOLDEN_DIR, g["fri"]), "rb").read()
+    # fft_gkr (fft_gkr_vpgpu.cpp in place of lib/virgo's fft_circuit_GKR.cpp): the device's messages = the CPU reference's record of that call
+    assert dump_fft.read_bytes() == open(os.path.join(GOLDEN_DIR, "fftgkr_sha256_x1.bin"), "rb").read()
+    assert "fft gkr failed" not in r.stderr
 
 
 def test_many_small_circuits_interactive_and_batched_vs_oracle(vp, ob):
@@ -1269,6 +1273,11 @@ def test_complete_protocol_with_commitment_verification(vp, golden, pws_path, na
     roots, fin, r = s.last_fri()
     assert np.array_equal(r, r_gold), "FRI fold challenges differ from the reference's"
     assert roots == roots_gold and np.array_equal(fin, fin_gold)
+    if name == "sha256_x1":
+        # fft_gkr INSIDE the protocol (vpd_verifier.cpp:92), at the stream position the reference runs it: the device's messages equal the
+        # real reference's record of that very call (tests/golden/fftgkr_sha256_x1.bin), and its time is part of the commitment's prove time
+        assert s.last_fft_gkr() == open(os.path.join(GOLDEN, "fftgkr_sha256_x1.bin"), "rb").read()
+        assert 0 < times["pc_fft_gkr_sec"] < times["pc_prove_sec"]
     s.close(); c.close()
 
 

@@ -42,12 +42,16 @@ def test_unmodified_reference_links_against_the_forwarding_prover():
     for m in ("virgo::fri::commit_phase_step(", "virgo::fri::commit_phase_final()", "virgo::fri::request_init_value_with_merkle(",
               "virgo::fri::request_step_commit(", "virgo::fri::cpd"):
         assert m in vund, m                                                            # ... which is exactly what that verifier asks for
+    gsyms = subprocess.run(["nm", "-C", "--defined-only", os.path.join(ROOT, "oracle", "_ref", "integration_fftgkr.o")],
+                           check=True, stdout=subprocess.PIPE, text=True).stdout
+    assert "virgo::fft_circuit_gkr::fft_gkr(int, double&, int&, double&)" in gsyms and "virgo::fft_circuit_gkr::fft_gkr(" in vund
     # ... and the reference's own fri.cpp is not in the binary (its file-static helper has no other definition)
     allsyms = subprocess.run(["nm", "-C", BIN], check=True, stdout=subprocess.PIPE, text=True).stdout
     assert "merkle_tree_consistency_check" not in allsyms
+    assert "virgo::fft_circuit_gkr::engage_gkr" not in allsyms and "virgo::fft_circuit_gkr::build_circuit" not in allsyms   # nor its fft_circuit_GKR.cpp
     dyn = subprocess.run(["nm", "-D", "--undefined-only", BIN], check=True, stdout=subprocess.PIPE, text=True).stdout
     for f in ("vp_create", "vp_circuit_upload", "vp_evaluate", "vp_vres", "vp_phase1_init", "vp_phase2_init", "vp_liu_init", "vp_round", "vp_finalize",
-              "vp_commit_private", "vp_commit_public", "vp_fri_step", "vp_fri_final", "vp_fri_open"):
+              "vp_commit_private", "vp_commit_public", "vp_fri_step", "vp_fri_final", "vp_fri_open", "vp_fft_gkr"):
         assert f in dyn, f                                                             # ... and they reach the C ABI of libvpgpu.so
 
 

@@ -180,6 +180,10 @@ def lib_host():
         L.vph_prove_and_verify_full.argtypes = [vp, ctypes.c_int, vp, u64, ctypes.POINTER(u64)] + [ctypes.POINTER(ctypes.c_double)] * 3 + [ctypes.c_char_p, ctypes.c_int]
         L.vph_last_fri.argtypes = [vp, vp, u64, vp, vp]
         L.vph_last_point.argtypes = [vp, vp, ctypes.c_int]
+        L.vph_last_fft_gkr.restype = ctypes.c_int64
+        L.vph_last_fft_gkr.argtypes = [vp, vp, u64]
+        L.vph_last_pc_times.restype = None
+        L.vph_last_pc_times.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
         L.vph_interactive_breakdown.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
         L.vph_test_sha3.argtypes = [vp, vp, u64]
         L.vph_fri_commit.argtypes = [vp, vp, ctypes.c_int, vp, vp, ctypes.c_char_p, ctypes.c_int]
@@ -593,7 +597,19 @@ class Session:
                                                   ctypes.byref(t[0]), ctypes.byref(t[1]), ctypes.byref(t[2]), err, len(err))
         if rc < 0:
             raise RuntimeError("prove_and_verify_full failed: " + err.value.decode())
-        return buf.raw[: n.value], rc == 0, {"gkr_prove_sec": t[0].value, "pc_prove_sec": t[1].value, "verify_sec": t[2].value}
+        pt = (ctypes.c_double * 3)()
+        lib_host().vph_last_pc_times(self.h, pt)
+        return buf.raw[: n.value], rc == 0, {"gkr_prove_sec": t[0].value, "pc_prove_sec": t[1].value, "verify_sec": t[2].value,
+                                            "pc_fft_gkr_sec": pt[1], "pc_query_answer_sec": pt[2]}
+
+    def last_fft_gkr(self):
+        """Messages of fft_gkr (vp_fft_gkr layout) of the last prove_and_verify_full(), as bytes."""
+        import numpy as np
+        out = np.zeros((4096, 2), dtype=np.uint64)
+        n = lib_host().vph_last_fft_gkr(self.h, out.ctypes.data, out.shape[0])
+        if n < 0:
+            raise RuntimeError("no complete-protocol run on this session yet")
+        return out[:n].tobytes()
 
     def last_fri(self):
         """FRI commit phase of the last prove_and_verify_full(): (roots bytes, final codeword (2048, 2), challenges (steps, 2))."""

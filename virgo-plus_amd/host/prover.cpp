@@ -300,6 +300,16 @@ void prover::friOpen(int oracle, u64 leaf, std::vector<F> &values, std::vector<h
     check(vp_fri_open(ctx, oracle, leaf, mF(values.data()), path[0].b, 40 * 32, &len), "vp_fri_open");
     path.resize(len);
 }
+std::vector<F> prover::fftGkr(int lg, const std::vector<F> &tape) {
+    uint64_t nt = 0, nm = 0;
+    check(vp_fft_gkr_sizes(lg, &nt, &nm), "vp_fft_gkr_sizes");
+    if (tape.size() != nt) throw std::runtime_error("fftGkr: tape has the wrong length");
+    std::vector<F> msgs(nm);
+    uint64_t written = 0;
+    check(vp_fft_gkr(ctx, lg, cF(tape.data()), nt, mF(msgs.data()), nm, &written), "vp_fft_gkr");
+    msgs.resize(written);
+    return msgs;
+}
 double prover::commitDeviceMs() { double ms = 0; check(vp_commit_stats(ctx, &ms), "vp_commit_stats"); return ms; }
 
 void prover::gkrSizes(u64 &n_tape, u64 &n_bytes) {

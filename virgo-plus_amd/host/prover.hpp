@@ -65,6 +65,9 @@ public:
     std::vector<F> friFinal();                           // 2048 elements, reference layout [i << 7 | slice << 1 | hi]
     // fri::request_init_value_with_merkle (oracle 0 = l, 1 = h) / fri::request_step_commit (oracle 2 + level)
     void friOpen(int oracle, u64 leaf, std::vector<F> &values /* 130 */, std::vector<hhash_digest> &path);
+    // fft_circuit_gkr::fft_gkr (lib/virgo/src/fft_circuit_GKR.cpp:833-849), prover side on the device (vp_fft_gkr): tape = the verifier's
+    // draws in the reference's order; returns every prover message (layouts: include/vpgpu.h)
+    std::vector<F> fftGkr(int lg, const std::vector<F> &tape);
     double commitDeviceMs();
 
     double proveTime() const { return prove_timer.elapse_sec(); }

@@ -33,7 +33,14 @@ public:
     const std::vector<F> &friChallenges() const { return fri_r_; }
     static int fftGkrDraws(int lg);
     double polyVerifyTime() const { return poly_timer.elapse_sec(); }
+    // "Polynomial commitment: prove time" by the REFERENCE's definition (src/verifier.cpp:183): poly_prover.total_time = commit_private +
+    // commit_public + commit_phase (lib/virgo/src/poly_commit.h:43,121,336,345, vpd_verifier.cpp:70) + fft_gkr's prover time (:92-94).
+    // Answering the verifier's queries (fri::request_*) is outside that number in the reference and is reported separately here.
     double polyProveTime() const { return poly_prove_timer.elapse_sec(); }
+    double polyOpenTime() const { return open_timer.elapse_sec(); }
+    // fft_gkr of the last verifyFull(): its share of polyProveTime() (the reference's p_time_fft, vpd_verifier.cpp:92-94) and its messages
+    double fftGkrProveTime() const { return fft_gkr_timer.elapse_sec(); }
+    const std::vector<F> &fftGkrMessages() const { return fft_gkr_msgs_; }
     // Fiat-Shamir mode (the reference's GKRProof.hpp / transcriptCache.hpp are dead code, so this is a separate
     // mode, not part of the bit-exact parity): every challenge is SHA3-256-derived from the circuit hash and ALL prover messages
     // sent before it, so the transcript is a non-interactive proof.  Differences from the interactive schedule: the challenges of
@@ -89,7 +96,8 @@ private:
     std::vector<F> coeff_r[(int) gateType::SIZE];
     F bias, final_claim_u, assert_random;
     std::vector<std::vector<F>> final_claims_v;
-    timer verify_timer, poly_timer, poly_prove_timer;
+    timer verify_timer, poly_timer, poly_prove_timer, fft_gkr_timer, open_timer;
+    std::vector<F> fft_gkr_msgs_;
     std::vector<uint8_t> full_tr;
     std::vector<uint8_t> fri_roots_; std::vector<F> fri_final_, fri_r_;
     bool input_check_by_commitment = false;

@@ -14,6 +14,7 @@ struct vph_session {
     std::unique_ptr<prover> p;
     std::vector<F> tape;
     std::vector<uint8_t> fri_roots; std::vector<F> fri_final, fri_r;      // FRI commit phase of the last complete-protocol run
+    std::vector<F> fft_gkr_msgs; double pc_times[3] = {0, 0, 0};          // fft_gkr messages; {PC prove (reference definition), of which fft_gkr, query answering}
     double t_init = 0, t_round = 0, t_fin = 0;
     std::vector<F> last_point;                                           // r_liu after the last Liu sumcheck of the last complete-protocol run
 };
@@ -245,6 +246,8 @@ int vph_prove_and_verify_full(vph_session *s, int reps, uint8_t *transcript, uin
         const double t0 = s->p->proveTime();
         const bool ok = v.verifyFull(reps);
         s->fri_roots = v.friRoots(); s->fri_final = v.friFinalCode(); s->fri_r = v.friChallenges();
+        s->fft_gkr_msgs = v.fftGkrMessages();
+        s->pc_times[0] = v.polyProveTime(); s->pc_times[1] = v.fftGkrProveTime(); s->pc_times[2] = v.polyOpenTime();
         s->last_point.assign(v.finalPoint().begin(), v.finalPoint().begin() + s->circ->c.circuit[0].bitLength);
         const auto &tr = v.fullTranscript();
         if (tr.size() > capacity) { set_err(err, errlen, "transcript buffer too small"); return -1; }
@@ -259,6 +262,16 @@ int vph_prove_and_verify_full(vph_session *s, int reps, uint8_t *transcript, uin
         return -2;
     }
 }
+
+// fft_gkr of the last vph_prove_and_verify_full: its messages ({real,img} pairs, layout of vp_fft_gkr); returns their number or -1
+int64_t vph_last_fft_gkr(vph_session *s, uint64_t *pairs, uint64_t cap_elems) {
+    if (!s || s->fft_gkr_msgs.empty() || cap_elems < s->fft_gkr_msgs.size()) return -1;
+    memcpy(pairs, s->fft_gkr_msgs.data(), s->fft_gkr_msgs.size() * sizeof(F));
+    return (int64_t) s->fft_gkr_msgs.size();
+}
+// seconds of the last vph_prove_and_verify_full: [0] "Polynomial commitment: prove time" by the reference's definition (commit_private +
+// commit_public + fft_gkr + FRI commit phase), [1] its fft_gkr share, [2] answering the verifier's queries (outside [0], as in the reference)
+void vph_last_pc_times(vph_session *s, double out[3]) { for (int i = 0; i < 3; ++i) out[i] = s ? s->pc_times[i] : 0; }
 
 // FRI data of the last vph_prove_and_verify_full on this session: roots (32 bytes per step), final codeword (2048 elements),
 // challenges (16 bytes per step); returns the number of fold steps or -1.

@@ -77,6 +77,11 @@ int vph_prove_and_verify_full(vph_session *, int reps, uint8_t *transcript, uint
 /* FRI commit phase of the last vph_prove_and_verify_full: Merkle root per fold step (32 bytes each), final codeword (2048
  * elements), fold challenges (one element per step); any pointer may be NULL.  Returns the number of steps or -1. */
 int vph_last_fri(vph_session *, uint8_t *roots, uint64_t roots_cap, uint64_t *final_pairs, uint64_t *r_pairs);
+/* fft_gkr of the last vph_prove_and_verify_full (vp_fft_gkr's message layout); returns the element count or -1.  vph_last_pc_times:
+ * [0] "Polynomial commitment: prove time" by the reference's definition (src/verifier.cpp:183: commit_private + commit_public +
+ * commit_phase + fft_gkr's prover time), [1] the fft_gkr share of it, [2] answering the queries (not part of [0], as in the reference). */
+int64_t vph_last_fft_gkr(vph_session *, uint64_t *pairs, uint64_t cap_elems);
+void vph_last_pc_times(vph_session *, double out[3]);
 /* r_liu after the last Liu sumcheck of the last vph_prove_full / vph_prove_and_verify_full (the protocol's public vector is its eq
  * table, src/verifier.cpp:368-369); returns the number of coordinates or -1. */
 int vph_last_point(vph_session *, uint64_t *pairs, int cap);
