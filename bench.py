@@ -55,9 +55,15 @@ PMC_SUMMARIES = ("r02_pmc_summary_b%d.json", "r01_l_pmc_summary_b%d.json")
 #   F_p^2 multiply (31-bit split form, 16 v_mad_u64_u32 + Mersenne folds): 6.1e11 per second for the whole chip;
 #   Keccak-f[1600] as 24 rounds x 180 VALU instructions (v_bitop3_b32 / v_alignbit_b32) at the measured issue cost of those two.
 FMUL_PEAK_PER_S = 7.0e11        # f_mul: 224.8 SIMD-cycles per wave-multiply
-# one Keccak round = 120 v_bitop3_b32 (3.20 cycles per wave-instruction per SIMD) + 58 v_alignbit_b32 (4.43) + 2 v_xor_b32 (2.78)
-KECCAK_CYCLES_PER_WAVE_PERM = 24 * (120 * 3.20 + 58 * 4.43 + 2 * 2.78)
-KECCAK_PEAK_PER_S = 1024 * 64 * 2.4e9 / KECCAK_CYCLES_PER_WAVE_PERM
+# Keccak-f[1600] on 32-bit lanes: 180 VALU instructions per round is the instruction-count FLOOR (theta parity 20 three-input xors, 10 rotations by 1,
+# 50 theta-apply, rho 48 64-bit rotations = 2 v_alignbit each... counted as 48 here + the 10 above = 58 v_alignbit_b32, chi 50 v_bitop3_b32, iota 2) —
+# 120 v_bitop3_b32 + 58 v_alignbit_b32 + 2 v_xor_b32.  The peak prices EVERY one of those at the fastest issue cost measured for any of them
+# (v_xor_b32: 2.78 SIMD-cycles per wave-instruction, tools/micro_rates.hip) — not at the cost of the kernel's own mix, against which any
+# kernel would score ~1.
+KECCAK_INSTR_PER_ROUND = 180
+KECCAK_BEST_ISSUE_CYCLES = 2.78
+KECCAK_PEAK_PER_S = 1024 * 64 * 2.4e9 / (24 * KECCAK_INSTR_PER_ROUND * KECCAK_BEST_ISSUE_CYCLES)
+KECCAK_MIX_CYCLES_PER_WAVE_PERM = 24 * (120 * 3.20 + 58 * 4.43 + 2 * 2.78)      # the kernel's own mix at its measured per-instruction costs
 
 
 def pmc_traffic(blocks, kernel):
@@ -96,37 +102,78 @@ def launch_table(stats, total_us=None):
     return rows, per_launch, tot
 
 
+# F_p^2 multiplications per pair step of the fold kernels (one pair of entries of one table family in one round): the three folds
+# x0 + r (x1 - x0) of V, mult and add, and the products of the round polynomial — dm dv and m0 v0; the third product (m1 v1) only in round 1
+# of a sumcheck, afterwards b comes from the previous claim (DESIGN.md §4 "five products per pair").  4 without an add table (Liu phase).
+FMUL_PER_PAIR_STEP = 5
+
+
 def roofline_of(rows, blocks, serial_ms, note=None):
-    """The `roofline` object for the kernel with the largest share of the (single-stream) proof time."""
+    """The `roofline` object for the kernel with the largest share of the (single-stream) proof time.  The fold family is bound by VALU issue,
+    not by HBM (PMC: traffic = algorithmic bytes, VALU busy ~80 %): its `achieved` is F_p^2-multiply-equivalents per second against the
+    chip's measured F-multiply issue rate; the HBM figure of the same launches is kept beside it (hbm_frac)."""
     if not rows:
         return None
     d = rows[0]
     traffic, src = pmc_traffic(blocks, d["kernel"])
+    fold = "sumfold" in d["kernel"]
     limiter = None
-    if "sumfold" in d["kernel"] or "light" in d["kernel"]:
+    if fold or "light" in d["kernel"]:
         limiter = ("VALU issue: SQ_INSTS_VALU per launch / 1024 SIMDs / launch cycles = one wave-instruction per 5.9-6.5 cycles per SIMD "
                    "(profiles/r02_pmc_summary_b64.json, r02_pmc_summary_b1024.json) where this instruction mix issues at 4.3-5 cycles when nothing "
                    "stalls (tools/micro_rates.hip: v_mad_u64_u32 7.0, 64-bit add 5.2, 32-bit ops 2.8-3.2): 75-85 % of the issue slots; the bytes "
                    "moved equal the algorithmic bytes, the integer multiply-add of F_p^2 (16 v_mad_u64_u32 + Mersenne folds) sets the time")
     accounting = None
-    if "sumfold" in d["kernel"] and d["work_units"]:
-        # The byte figure above is the strict one: a launch reads its tables once and writes the folded tables once, whatever the number of
-        # rounds it fuses (and the init-generating variant never writes or reads the mult/add tables at full length at all).  SURVEY.md
-        # §8d's per-unit figure is per ROUND: 48 B x (entries in + entries out) = 144 B per pair step with three table families (96 B in the
-        # Liu phase, which has no add table: counted as 144 here, so this is an upper figure).  Same launches, same time:
-        survey_bytes = 144.0 * d["work_units"]
-        survey_gbps = survey_bytes / (d["total_us"] * 1e-6) / 1e9
-        accounting = {"note": "informative only, NOT `frac`: the same kernel time priced with SURVEY.md 8d's per-round byte formula (every round reads and "
-                              "writes its tables) instead of the bytes the fused launch has to move",
+    out = {"kernel": d["kernel"], "kernel_time_share": d["time_share"], "launches": d["launches"], "avg_launch_us": d["avg_launch_us"],
+           "algorithmic_bytes_per_launch": d["algorithmic_MB_per_launch"] * 1e6, "single_stream_proof_ms": serial_ms,
+           "traffic": traffic, "traffic_source": ("%s (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, per launch)" % src) if traffic else None,
+           "hbm_GBps": d["GBps"], "hbm_peak_GBps": HBM_PEAK_GBPS, "hbm_frac": d["hbm_frac"], "measured_limiter": limiter,
+           "how": "every launch of the plan bracketed with HIP events in a single-stream replay of the same proof (vp_set_profiling / vp_get_launch_stats)" + (("; " + note) if note else "")}
+    if fold and d["work_units"]:
+        fmul = FMUL_PER_PAIR_STEP * d["work_units"] / (d["total_us"] * 1e-6)
+        out.update({"bound": "valu", "achieved": fmul, "peak": FMUL_PEAK_PER_S, "unit": "F_p^2 multiply-equivalents/s", "frac": fmul / FMUL_PEAK_PER_S,
+                    "achieved_definition": "%d F_p^2 multiplications per pair step (3 folds + 2 products; the additions, subtractions and lazy reductions around "
+                                           "them are NOT converted into multiply-equivalents, and the contribution products of the init-generating variant are "
+                                           "not counted: a lower figure) x pair steps of the launches / their summed HIP-event time" % FMUL_PER_PAIR_STEP,
+                    "peak_definition": "chip-wide F_p^2 multiply issue rate of the 31-bit split form, measured (tools/micro_rates.hip, profiles/r02_micro_rates.txt: "
+                                       "224.8 SIMD-cycles per wave-multiply, 1024 SIMDs, 2.4 GHz)"})
+        # SURVEY.md 8d's per-ROUND byte formula on the same launches (every round reads and writes its tables): 144 B per pair step with three
+        # table families — informative, above what the fused launch has to move
+        survey_gbps = 144.0 * d["work_units"] / (d["total_us"] * 1e-6) / 1e9
+        accounting = {"note": "informative only: the same kernel time priced with SURVEY.md 8d's per-round byte formula instead of the bytes the fused launch moves",
                       "pair_steps": d["work_units"], "bytes_per_pair_step": 144, "GBps": round(survey_gbps, 1), "frac_of_hbm_peak": round(survey_gbps / HBM_PEAK_GBPS, 4)}
-    return {"bound": "hbm", "achieved": d["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": d["hbm_frac"], "traffic": traffic,
-            "per_round_accounting_survey_8d": accounting,
-            "traffic_source": ("%s (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, per launch)" % src) if traffic else None,
-            "kernel": d["kernel"], "kernel_time_share": d["time_share"], "launches": d["launches"], "avg_launch_us": d["avg_launch_us"],
-            "algorithmic_bytes_per_launch": d["algorithmic_MB_per_launch"] * 1e6, "single_stream_proof_ms": serial_ms,
-            "measured_limiter": limiter,
-            "how": "every launch of the plan bracketed with HIP events in a single-stream replay of the same proof (vp_set_profiling / vp_get_launch_stats)" + (("; " + note) if note else "")}
+    else:
+        out.update({"bound": "hbm", "achieved": d["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": d["hbm_frac"]})
+    out["per_round_accounting_survey_8d"] = accounting
+    return out
 
+
+def per_round_summary(stats, full=False):
+    """north_star: "achieved HBM-bandwidth fraction reported per sumcheck round" — the interactive path, where a round IS a call: algorithmic
+    bytes of the round / wall time of vp_round as the verifier sees it (vp_get_round_stats)."""
+    if not stats:
+        return None
+    names = {0: "one launch per round", 1: "resident kernel (pinned mailbox)", 2: "round 1, computed behind the init call"}
+    by = {}
+    for e in stats:
+        k = by.setdefault(e["how"], {"rounds": 0, "us": 0.0, "bytes": 0})
+        k["rounds"] += 1; k["us"] += e["us"]; k["bytes"] += e["bytes"]
+    classes = [{"served_by": names.get(h, str(h)), "rounds": v["rounds"], "total_us": round(v["us"], 1), "avg_us": round(v["us"] / v["rounds"], 2),
+                "algorithmic_MB": round(v["bytes"] / 1e6, 3), "GBps": round(v["bytes"] / (v["us"] * 1e-6) / 1e9, 2) if v["us"] > 0 else None}
+               for h, v in sorted(by.items())]
+    def row(e):
+        g = e["bytes"] / (e["us"] * 1e-6) / 1e9 if e["us"] > 0 else 0.0
+        return {"layer": e["layer"], "phase": e["phase"], "round": e["round"], "tables": e["tables"], "served_by": e["how"], "MB": round(e["bytes"] / 1e6, 3),
+                "us": round(e["us"], 2), "GBps": round(g, 1), "hbm_frac": round(g / HBM_PEAK_GBPS, 4)}
+    big = sorted((e for e in stats if e["how"] == 0), key=lambda e: -e["bytes"])[:12]
+    tot_b, tot_us = sum(e["bytes"] for e in stats), sum(e["us"] for e in stats)
+    out = {"rounds": len(stats), "algorithmic_MB": round(tot_b / 1e6, 2), "total_us": round(tot_us, 1), "GBps_overall": round(tot_b / (tot_us * 1e-6) / 1e9, 1),
+           "hbm_frac_overall": round(tot_b / (tot_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4), "by_path": classes, "largest_rounds": [row(e) for e in big],
+           "bytes_definition": "SURVEY.md 8d: 48 B x (L_in + L_out) per table family (32 B in the Liu phase); round 1 only reads",
+           "time_definition": "wall time of the vp_round call (launch or mailbox round trip + arithmetic + reply)"}
+    if full:
+        out["all_rounds"] = [row(e) for e in stats]
+    return out
 
 
 def dist_setup(n_gpus, rccl=False):
@@ -140,13 +187,30 @@ def dist_setup(n_gpus, rccl=False):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        if rccl and os.environ.get("VP_BENCH_BACKEND", "") != "gloo":
-            import torch
+        import torch
+        if rccl and os.environ.get("VP_BENCH_BACKEND", "") != "gloo" and torch.cuda.device_count() >= world:
             torch.cuda.set_device(local)
             dist.init_process_group(backend="cpu:gloo,cuda:nccl", rank=rank, world_size=world)
         else:       # VP_BENCH_BACKEND=gloo: rehearsal of the sharded mode on a box with fewer GPUs than ranks (RCCL needs one GPU per rank)
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     return world, rank, local
+
+
+class stdout_to_stderr:
+    """Gloo announces its connections on the C-level stdout ("[Gloo] Rank 0 is connected to 1 peer ranks ...") when the process group forms:
+    stdout carries ONE JSON line and nothing else, so file descriptor 1 points at stderr while the group is set up."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
 
 
 def device_of(local):
@@ -285,6 +349,20 @@ def pc_leg(vp, sess, circ, golden, gname, full_fixture=None):
     pc["commit_private_wall_sec"] = time.perf_counter() - t3
     pc["pc_commit_side_device_ms"] = ms_priv + pc["commit_public_device_ms"] + pc["fri_commit_device_ms"]
     pc["reference_pc_prove_sec_build_container"] = golden.get(gname, {}).get("reference_pc_prove_sec_here")
+    # "Polynomial commitment: prove time" exactly as the reference defines it (src/verifier.cpp:183): poly_prover.total_time = commit_private
+    # + commit_public + commit_phase (lib/virgo/src/poly_commit.h:43,121,336,345, vpd_verifier.cpp:70) + fft_gkr's prover time (:92-94), host
+    # wall clock around the prover calls of ONE unbroken run of the complete protocol (33 query repetitions; answering the queries is not part
+    # of the number in the reference either)
+    trf, okf2, times = sess.prove_and_verify_full(reps=33)
+    pc["prove_sec"] = times["pc_prove_sec"]
+    pc["prove_sec_definition"] = "commit_private + commit_public + fft_gkr prover + FRI commit phase, host wall clock (reference: src/verifier.cpp:183, vpd_verifier.cpp:70,92-95)"
+    pc["fft_gkr_sec"] = times["pc_fft_gkr_sec"]
+    pc["query_answer_sec"] = times["pc_query_answer_sec"]
+    pc["complete_protocol"] = {"accepted": bool(okf2), "transcript_equals_batched_run": trf == full, "gkr_prove_sec_interactive": times["gkr_prove_sec"],
+                               "verify_sec": times["verify_sec"], "query_repetitions": 33}
+    if gname in golden and os.path.exists(os.path.join(GOLDEN, "fftgkr_%s.bin" % gname)):
+        pc["fft_gkr_bit_exact_vs_reference_record"] = sess.last_fft_gkr() == open(os.path.join(GOLDEN, "fftgkr_%s.bin" % gname), "rb").read()
+    sess.draw_tape()
     # per-launch profile of the three calls (events on the library stream; the commitment runs on one stream anyway)
     sess.set_profiling(1)
     sess.commit_private(); st_priv = sess.launch_stats()
@@ -302,7 +380,10 @@ def pc_leg(vp, sess, circ, golden, gname, full_fixture=None):
         w, us = sum(e["work"] for e in leaf), sum(e["us"] for e in leaf)
         rl["k_leaf_hash"] = {"bound": "valu", "achieved": w / (us * 1e-6), "peak": KECCAK_PEAK_PER_S, "unit": "Keccak-f[1600]/s",
                              "frac": w / (us * 1e-6) / KECCAK_PEAK_PER_S, "time_share": us / tot,
-                             "peak_definition": "issue bound of the kernel's own instruction mix: 1024 SIMDs x 64 lanes x 2.4 GHz / %.0f cycles per wave-permutation (24 rounds x (120 v_bitop3_b32 x 3.20 + 58 v_alignbit_b32 x 4.43 + 2 v_xor_b32 x 2.78 cycles), profiles/r02_micro_rates.txt)" % KECCAK_CYCLES_PER_WAVE_PERM}
+                             "frac_of_own_instruction_mix": w / (us * 1e-6) / (1024 * 64 * 2.4e9 / KECCAK_MIX_CYCLES_PER_WAVE_PERM),
+                             "peak_definition": "instruction-count floor x best issue rate: 24 rounds x %d VALU instructions (the 32-bit minimum: 120 v_bitop3_b32 + 58 v_alignbit_b32 + 2 v_xor_b32) "
+                                                "x %.2f SIMD-cycles per wave-instruction (the cheapest measured, tools/micro_rates.hip) on 1024 SIMDs x 64 lanes at 2.4 GHz; "
+                                                "frac_of_own_instruction_mix prices the same instructions at their own measured costs (3.20 / 4.43 / 2.78)" % (KECCAK_INSTR_PER_ROUND, KECCAK_BEST_ISSUE_CYCLES)}
     if ntt:
         w, us = sum(e["work"] for e in ntt), sum(e["us"] for e in ntt)
         rl["k_ntt"] = {"bound": "valu", "achieved": w / (us * 1e-6), "peak": FMUL_PEAK_PER_S, "unit": "F_p^2 multiplications/s",
@@ -359,7 +440,8 @@ def x1024_leg(vp, pws, golden, a, local):
     t_i = time.perf_counter()
     tr_i, res_i, ok_i = sess.prove_interactive()
     inter = {"prover_sec": res_i["prove_sec"], "init_calls_sec": res_i.get("init_sec"), "round_calls_sec": res_i.get("round_sec"),
-             "finalize_calls_sec": res_i.get("finalize_sec"), "wall_sec_with_host_verifier": time.perf_counter() - t_i, "transcript_equals_batched": tr_i == tr, "verified": ok_i}
+             "finalize_calls_sec": res_i.get("finalize_sec"), "wall_sec_with_host_verifier": time.perf_counter() - t_i, "transcript_equals_batched": tr_i == tr, "verified": ok_i,
+             "per_round": per_round_summary(sess.round_stats())}
     sess.draw_tape()
     fx = os.path.join(ROOT, "tests", "golden", "oracle_sha256_x1024_full.bin")
     pc = pc_leg(vp, sess, circ, golden, "sha256_x%d" % B, full_fixture=fx if os.path.exists(fx) else None)
@@ -388,6 +470,168 @@ def x1024_leg(vp, pws, golden, a, local):
     return leg
 
 
+def spawn_ranks(n):
+    """`bench.py --gpus N` (N > 1) started WITHOUT a launcher: start the N ranks here, one process per GPU, exactly as the driver's command
+    would (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>), and exit with its code.  This runs
+    at the very top of main(), before any HIP / torch.cuda call of this process (a process that has touched the GPU must not start or
+    become another GPU program on this pool).  Never falls back to one rank: too few GPUs is an error, not an `n_gpus: 1` line."""
+    import socket
+    import torch
+    have = torch.cuda.device_count()             # counting devices does not initialise the GPU
+    if have < n and os.environ.get("VP_BENCH_BACKEND", "") != "gloo":
+        sys.stderr.write("bench.py: --gpus %d but %d GPU(s) visible (set VP_BENCH_BACKEND=gloo to REHEARSE more ranks than GPUs; that line says so)\n" % (n, have))
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
+class Watchdog:
+    """The multi-rank sub-legs run collectives that no builder box could ever execute (RCCL over more than one GPU).  If one of them does not
+    come back, the rank still prints the line it has — with the sub-leg marked as timed out — and the process ends, instead of the job
+    hanging without a line."""
+
+    def __init__(self, seconds, on_timeout):
+        import threading
+        self.t = threading.Timer(seconds, on_timeout)
+        self.t.daemon = True
+        self.t.start()
+
+    def cancel(self):
+        self.t.cancel()
+
+
+def allreduce_min_flag(world, ok):
+    if world == 1:
+        return bool(ok)
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item() > 0.5)
+
+
+def gather_floats(world, rank, x):
+    if world == 1:
+        return [float(x)]
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([float(x) if r == rank else 0.0 for r in range(world)], dtype=torch.float64)
+    dist.all_reduce(t)
+    return [float(v) for v in t]
+
+
+def replicas_x1024_leg(vp, pws, golden, a, world, rank, local):
+    """BASELINE.json configs[3]: SHA-256 1024-block circuit, one independent proof per GPU (witness seed 1 + rank), no data-path collective.
+    Rank 0's transcript against the real reference's golden (seed 1), rank 1's against the oracle's seed-2 fixture; every rank's proof through
+    the full verifier replay (device predicates)."""
+    B = 1024
+    g = golden["sha256_x%d" % B]
+    t_b = time.perf_counter()
+    circ = vp.Circuit.from_pws(pws, B, seed=1 + rank)
+    build_sec = time.perf_counter() - t_b
+    sess = vp.Session(circ, device=local)
+    sess.draw_tape()
+    steps, warmup = max(3, a.steps // 4), 2
+    tr, res, elapsed, dev_ms = gkr_leg(vp, circ, sess, steps, warmup, world, False, local)
+    elapsed_max, proofs = aggregate(world, elapsed, float(steps))
+    ok, _ = sess.check(tr, device_predicates=True)
+    exact = None
+    if rank == 0:
+        exact = tr == open(os.path.join(ROOT, "tests", "golden", g["transcript"]), "rb").read()[g["gkr_slice"][0]:g["gkr_slice"][1]]
+    elif rank == 1:
+        fx = os.path.join(ROOT, "tests", "golden", "oracle_sha256_x1024_gkr_seed2.bin")
+        exact = (tr == open(fx, "rb").read()) if os.path.exists(fx) else None
+    all_ok = allreduce_min_flag(world, ok and exact is not False)
+    dev = gather_floats(world, rank, dev_ms / steps)
+    sess.close(); circ.close()
+    ref_ops = g["mult_counter"] + g["add_counter"]
+    return {"config": {"workload": "SHA-256 1024-block circuit x %d independent proofs, one per GPU, witness seeds 1..%d (BASELINE configs[3]); GKR sumcheck on GPU"
+                                   % (world, world), "field_ops_per_proof": ref_ops, "proofs_per_step": world},
+            "value": ref_ops * proofs / elapsed_max, "unit": "field-ops/s", "scaling": "weak", "steps": steps, "warmup": warmup,
+            "ms_per_step": 1e3 * elapsed_max / steps, "prover_sec_device_per_rank": [1e-3 * x for x in dev], "rounds": res["rounds"],
+            "rank0_bit_exact_vs_reference": exact if rank == 0 else None, "every_rank_verified_and_matching_its_fixture": all_ok,
+            "circuit_build_sec_rank0": build_sec}
+
+
+def sharded_leg(vp, pws, golden, a, world, rank, local, blocks):
+    """One proof over the GPUs of the node (north_star: "independent sumcheck instances / FFT subtrees shard across the GPUs with a single RCCL
+    reduce"): the chains of ONE proof dealt to the ranks (vp_set_shard; long chains also cut by index when the in-library communicator is
+    there), ONE all-reduce of the transcript per proof; then the commitment of the same instance sharded over the ranks (vp_pc_set_shard:
+    slices -> one all-to-all per oracle -> positions, one all-gather of tree nodes).  Every rank holds the same instance (seed 1).  With one
+    GPU per rank the collectives are RCCL calls inside the C ABI; in a rehearsal with more ranks than GPUs (VP_BENCH_BACKEND=gloo) the
+    transcript goes through torch/gloo and the commitment's collectives through the host transport (vp_shard_exchange_get / _put)."""
+    import numpy as np
+    import torch.distributed as dist
+    name = "sha256_x%d" % blocks
+    g = golden[name]
+    rccl = "nccl" in dist.get_backend()
+    circ = vp.Circuit.from_pws(pws, blocks, seed=1)
+    sess = vp.Session(circ, device=local)
+    sess.draw_tape()
+    full, okf = sess.prove_full(batched=True)                     # unsharded, on every rank: the answer the shards must assemble to
+    gold_full = open(os.path.join(ROOT, "tests", "golden", g["transcript"]), "rb").read()
+    gold = gold_full[g["gkr_slice"][0]:g["gkr_slice"][1]]
+    point = sess.last_point()
+    inputs = sess.layer_values(0)
+    pub = sess.eq_table(point)
+    n_bits = circ.layer_bitlen(0)
+    sess.set_shard(rank, world)
+    mode = "gloo"
+    rccl_ranks = None
+    if rccl:
+        sess.attach_comm(rank, world)
+        rccl_ranks = sess.comm_count()
+        mode = "rccl"
+        if world < 16:                                              # vp_set_shard_split: at most 8 slices
+            sess.set_shard_split(11)
+    steps, warmup = max(3, a.steps // 2), 2
+    tr, res, elapsed, dev_ms = gkr_leg(vp, circ, sess, steps, warmup, world, mode, local)
+    elapsed_max, _ = aggregate(world, elapsed, 0.0)
+    owner, cost = sess.shard_chains()
+    dev = gather_floats(world, rank, dev_ms / steps)
+    ref_ops = g["mult_counter"] + g["add_counter"]
+    out = {"config": {"workload": "ONE SHA-256 %d-block proof over %d ranks: sumcheck chains dealt to the ranks%s, one all-reduce of the transcript per proof"
+                                  % (blocks, world, " (long chains cut by table index)" if rccl else ""), "field_ops_per_proof": ref_ops},
+           "scaling": "strong", "transport": ("RCCL inside the C ABI (vp_comm_init), ncclCommCount = %s" % rccl_ranks) if rccl else "torch.distributed/gloo on host buffers (REHEARSAL: more ranks than GPUs)",
+           "rccl_ranks": rccl_ranks, "steps": steps, "value": ref_ops * steps / elapsed_max, "unit": "field-ops/s", "ms_per_step": 1e3 * elapsed_max / steps,
+           "device_ms_per_rank": dev, "chains": int((cost > 0).sum()), "chains_split_by_index": int((owner == -1).sum()),
+           "assembled_transcript_bit_exact_vs_reference": tr == gold, "assembled_equals_unsharded": tr == full[32:32 + len(gold)]}
+    sess.close(); circ.close()
+    # ---- the commitment of the same instance, sharded
+    if (world & (world - 1)) == 0 and (1 << (n_bits - 6)) >= 2 * world:
+        st = n_bits - 6
+        fri = open(os.path.join(ROOT, "tests", "golden", g["fri"]), "rb").read()
+        rr = np.frombuffer(b"".join(fri[48 * k:48 * k + 16] for k in range(st)), dtype=np.uint64).reshape(st, 2).copy()
+        roots_gold = b"".join(fri[48 * k + 16:48 * k + 48] for k in range(st))
+        sc = vp.ShardedCommitmentRank(inputs, n_bits, rank, world, device=local, transport="rccl" if rccl else "host")
+        barrier(world)
+        t0 = time.perf_counter()
+        root_l = sc.commit_private(); ms_priv = sc.device_ms()
+        root_h, inner, all_sum = sc.commit_public(pub); ms_pub = sc.device_ms()
+        roots, fin = sc.fri_commit(rr); ms_fri = sc.device_ms()
+        gpu_sync(local)
+        barrier(world)
+        wall = time.perf_counter() - t0
+        tail = gold_full[len(gold_full) - (32 + 16 + 65 * 16):]
+        ok_pc = (root_l == gold_full[:32] and root_h + inner + all_sum == tail and roots == roots_gold
+                 and fin.tobytes() == fri[48 * st:48 * st + 2048 * 16])
+        out["commitment"] = {"workload": "commit_private + commit_public + FRI commit phase of the same input layer (2^%d wires), 64 / %d slices per rank" % (n_bits, world),
+                             "transport": "RCCL (all-to-all as grouped send/recv, all-gather) inside the entry points" if rccl else "host transport over gloo (rehearsal)",
+                             "rccl_ranks": sc.comm_count() if rccl else None, "wall_sec": wall,
+                             "device_ms_per_rank": {"commit_private": gather_floats(world, rank, ms_priv), "commit_public": gather_floats(world, rank, ms_pub),
+                                                    "fri_commit": gather_floats(world, rank, ms_fri)},
+                             "roots_input0_allsum_fri_bit_exact_vs_reference_on_every_rank": allreduce_min_flag(world, ok_pc)}
+        sc.close()
+    else:
+        out["commitment"] = {"skipped": "vp_pc_set_shard needs a power-of-two world with at least two positions per rank"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -408,8 +652,20 @@ def main():
     ap.add_argument("--with-pc", action="store_true", help="also time the Virgo commitment (commit_private + commit_public + FRI commit phase)")
     ap.add_argument("--no-x1024-leg", action="store_true",
                     help="skip the nested x1024_with_pc leg (BASELINE configs[2]) that the default single-GPU run appends to the x64 headline line")
-    ap.add_argument("--per-launch", action="store_true", help="include the per-launch table of the headline leg in the JSON line (the per-kernel table is always there)")
+    ap.add_argument("--per-launch", action="store_true", help="include the per-launch table of the headline leg (and every interactive round) in the JSON line (the per-kernel table is always there)")
+    ap.add_argument("--no-sharded-leg", action="store_true", help="N > 1: skip the `sharded` sub-leg (one proof + its commitment over all ranks, RCCL)")
+    ap.add_argument("--subleg-timeout", type=float, default=900.0, help="N > 1: seconds the multi-rank sub-legs may take before the line is printed without them")
     a = ap.parse_args()
+
+    # ---- one process per GPU, always.  N > 1 without a launcher: start the ranks (before anything of this process touches the GPU).
+    env_world = int(os.environ.get("WORLD_SIZE", "0") or 0)
+    if a.gpus < 1:
+        sys.stderr.write("bench.py: --gpus must be >= 1\n"); sys.exit(2)
+    if env_world == 0 and a.gpus > 1:
+        sys.exit(spawn_ranks(a.gpus))
+    if env_world not in (0, a.gpus):
+        sys.stderr.write("bench.py: launched with WORLD_SIZE=%d but --gpus %d: refusing to report a rank count that is not the one running\n" % (env_world, a.gpus))
+        sys.exit(2)
 
     # The native libraries are loaded BEFORE torch so that every rank count uses the same HIP runtime load order
     # (libvpgpu.so first; torch then reuses the already loaded libamdhip64).  Only local rank 0 may (re)build.
@@ -418,11 +674,12 @@ def main():
     if int(os.environ.get("LOCAL_RANK", "0")) == 0:
         vp.build()
         vp.lib_host()
-    world, rank, local = dist_setup(a.gpus, rccl=a.shard_chains)
+    with stdout_to_stderr():
+        world, rank, local = dist_setup(a.gpus, rccl=True)
+        barrier(world)
     local = device_of(local)
     shard = a.shard_chains and world > 1
     seed = 1 if shard else 1 + rank          # a sharded proof: every rank holds the same instance
-    barrier(world)
     vp.lib_host()
     golden = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))
     gname = "sha256_x%d" % a.blocks if not a.randomize else "randomize_%d_%d" % tuple(a.randomize)
@@ -513,6 +770,7 @@ def main():
             interactive = {"prover_sec": res_i["prove_sec"], "init_calls_sec": res_i.get("init_sec"), "round_calls_sec": res_i.get("round_sec"),
                            "finalize_calls_sec": res_i.get("finalize_sec"), "wall_sec_with_host_verifier": time.perf_counter() - t_i,
                            "transcript_equals_batched": tr_i == tr, "verified": ok_i,
+                           "per_round": per_round_summary(sess.round_stats(), full=a.per_launch),
                            "note": "reference definition of Prove Time (sum of prover-method spans) over the interactive entry points (vp_round per verifier message)"}
             sess.draw_tape()
 
@@ -581,6 +839,43 @@ def main():
         if rank == 0:
             if world == 1 and a.blocks == 64 and not a.randomize and not a.no_x1024_leg and not shard and "sha256_x1024" in golden:
                 line["x1024_with_pc"] = x1024_leg(vp, pws, golden, a, local)
+            line["rccl_ranks"] = None
+        # ---- N > 1: BASELINE configs[3] (x1024, one proof per GPU) and one proof + commitment sharded over all ranks, in the SAME line.
+        # Every rank takes part; a watchdog prints the line without them if a collective does not come back.
+        if world > 1 and not shard and a.blocks == 64 and not a.randomize:
+            state = {"leg": None}
+
+            def on_timeout():
+                if rank == 0:
+                    line["multi_gpu_sublegs_error"] = "timed out after %.0f s in %s" % (a.subleg_timeout, state["leg"])
+                    print(json.dumps(line), flush=True)
+                os._exit(0)
+
+            wd = Watchdog(a.subleg_timeout, on_timeout)
+            sub = {}
+            for name, enabled, fn in (("x1024_replicas", not a.no_x1024_leg and "sha256_x1024" in golden,
+                                       lambda: replicas_x1024_leg(vp, pws, golden, a, world, rank, local)),
+                                      ("sharded", not a.no_sharded_leg,
+                                       lambda: sharded_leg(vp, pws, golden, a, world, rank, local, 64 if a.no_x1024_leg else 1024))):
+                if not enabled:
+                    continue
+                state["leg"] = name
+                failed = None
+                try:
+                    sub[name] = fn()
+                except Exception as e:          # a rank that fails outside a collective: the others find out at the next flag exchange
+                    failed = "%s: %s" % (type(e).__name__, e)
+                    sub[name] = {"error": failed}
+                if not allreduce_min_flag(world, failed is None):
+                    sub.setdefault(name, {})
+                    if "error" not in sub[name]:
+                        sub[name] = {"error": "another rank failed in this leg", "partial": sub[name]}
+            wd.cancel()
+            if rank == 0:
+                line.update(sub)
+                if isinstance(sub.get("sharded"), dict):
+                    line["rccl_ranks"] = sub["sharded"].get("rccl_ranks")
+        if rank == 0:
             print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -283,6 +283,15 @@ int vp_commit_stats(vp_ctx *, double *commit_ms);
 int vp_pc_load_input(vp_ctx *, const vp_F *inputs, uint64_t n_inputs, int bit_length);
 int vp_pc_set_shard(vp_ctx *, int rank, int world);
 int vp_shard_exchange_local(vp_ctx **ctxs, int world);
+/* The same pending collectives through a CALLER-SUPPLIED transport — ranks in different processes without RCCL (more ranks than GPUs in a
+ * rehearsal, CPU tests over gloo): after VP_EXCHANGE, for i < *n: vp_shard_exchange_info gives kind (1 all-to-all, 2 all-gather) and bytes (per
+ * peer / per rank); vp_shard_exchange_get copies the send side to the host (kind 1: world x bytes, peer-major; kind 2: bytes), the caller moves
+ * the data, vp_shard_exchange_put copies the world x bytes received back; vp_shard_exchange_done, then call the interrupted function again.   */
+int vp_shard_pending(vp_ctx *, int *n);
+int vp_shard_exchange_info(vp_ctx *, int i, int *kind, uint64_t *bytes);
+int vp_shard_exchange_get(vp_ctx *, int i, void *host_send);
+int vp_shard_exchange_put(vp_ctx *, int i, const void *host_recv);
+int vp_shard_exchange_done(vp_ctx *);
 /* RCCL over xGMI: rank 0 makes the id (128 bytes, ncclUniqueId), every rank calls vp_comm_init with it.  With a communicator attached
  * a chain-sharded vp_prove_gkr (vp_set_shard) all-reduces the transcript on the device (u64 sum of disjoint slices) before returning
  * it, and the sharded commitment calls run their collectives inside the call.  librccl.so.1 is resolved at run time.
@@ -293,6 +302,8 @@ int vp_shard_exchange_local(vp_ctx **ctxs, int world);
 int vp_comm_unique_id(uint8_t id[128]);
 int vp_comm_init(vp_ctx *, const uint8_t id[128], int rank, int world);
 int vp_comm_destroy(vp_ctx *);
+/* ncclCommCount of the attached communicator: the number of ranks RCCL itself reports (a benchmark prints it beside its own world size). */
+int vp_comm_count(vp_ctx *, int *n_ranks);
 int vp_allreduce_u64(vp_ctx *, void *device_buffer, uint64_t count);
 
 /* ---- verifier side ------------------------------------------------------------------------------- */
@@ -324,6 +335,18 @@ typedef struct {
     uint64_t launches;        /* kernel launches of the last proof                                          */
 } vp_stats;
 int vp_get_stats(vp_ctx *, vp_stats *out);
+/* The interactive path, per sumcheck round (north_star: "achieved HBM-bandwidth fraction reported per sumcheck round"): one entry per
+ * vp_round since the last vp_vres.  bytes = the round's ALGORITHMIC bytes by SURVEY.md §8d: 48 B x (L_in + L_out) summed over the live
+ * table families of the phase (32 B in the Liu phase, which has no add table); round 1 reads L_in = valid entries and writes nothing, round
+ * k >= 2 reads ceil(valid / 2^(k-2)) and writes ceil(valid / 2^(k-1)) (fold by r_(k-1) fused with the sums of round k).  us = wall time of
+ * the vp_round call as the caller sees it (launch or mailbox round trip + arithmetic + reply).  how: 0 one launch for the round, 1 answered
+ * by the resident kernel through the pinned mailbox, 2 round 1 computed behind the init call (the call only collects it).            */
+typedef struct {
+    int32_t phase, layer, round, how, tables;
+    uint64_t bytes;
+    double us;
+} vp_round_stat;
+int vp_get_round_stats(vp_ctx *, vp_round_stat *out, int capacity, int *n);
 /* 0: no per-kernel events (default); 1: the next vp_prove_gkr replays its launch plan on ONE stream and brackets EVERY
  * launch with hipEvents (in the default run the launches of independent sumchecks overlap on several streams, so
  * per-kernel times would be meaningless there); vp_commit_private / vp_commit_public / vp_fri_commit bracket their

@@ -82,6 +82,11 @@ class VphResult(ctypes.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class RoundStat(ctypes.Structure):           # vp_round_stat (include/vpgpu.h)
+    _fields_ = [("phase", ctypes.c_int32), ("layer", ctypes.c_int32), ("round", ctypes.c_int32), ("how", ctypes.c_int32), ("tables", ctypes.c_int32),
+                ("bytes", ctypes.c_uint64), ("us", ctypes.c_double)]
+
+
 class LaunchStat(ctypes.Structure):          # vp_launch_stat (include/vpgpu.h)
     _fields_ = [("kind", ctypes.c_int32), ("step", ctypes.c_int32), ("workgroups", ctypes.c_uint32), ("jobs", ctypes.c_uint32),
                 ("rounds", ctypes.c_uint32), ("first_round", ctypes.c_uint32), ("bytes", ctypes.c_uint64), ("work", ctypes.c_uint64),
@@ -127,6 +132,8 @@ def lib_gpu():
         L.vp_comm_unique_id.argtypes = [vp]
         L.vp_comm_init.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int]
         L.vp_comm_destroy.argtypes = [vp]
+        L.vp_comm_count.argtypes = [vp, ctypes.POINTER(ctypes.c_int)]
+        L.vp_get_round_stats.argtypes = [vp, ctypes.POINTER(RoundStat), ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
         L.vp_allreduce_u64.argtypes = [vp, vp, ctypes.c_uint64]
         L.vp_set_profiling.argtypes = [vp, ctypes.c_int]
         L.vp_get_launch_stats.argtypes = [vp, ctypes.POINTER(LaunchStat), ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
@@ -324,6 +331,120 @@ class ShardedCommitment:
         self.ctx = []
 
 
+class ShardedCommitmentRank:
+    """ONE rank of the Virgo commitment sharded over the ranks of a torch.distributed job (include/vpgpu.h: vp_pc_set_shard): a light
+    context holding the input layer.  transport="rccl": the collectives (one all-to-all per committed oracle, one all-gather of tree nodes)
+    run inside the entry points over an RCCL communicator attached to the context (needs one GPU per rank).  transport="host": no
+    communicator — every call that returns VP_EXCHANGE has its pending collectives moved by torch.distributed on host buffers (gloo; the
+    all-to-all as an all-gather of every rank's send side), which is how more ranks than GPUs are rehearsed and how the CPU suite's
+    world-size-2 test drives it."""
+    VP_EXCHANGE = 1
+
+    def __init__(self, inputs, bit_length, rank, world, device=0, transport="rccl"):
+        import numpy as np
+        L = lib_gpu()
+        for f in ("vp_shard_pending", "vp_shard_exchange_done"):
+            getattr(L, f).argtypes = [ctypes.c_void_p] + ([ctypes.POINTER(ctypes.c_int)] if f == "vp_shard_pending" else [])
+        L.vp_shard_exchange_info.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint64)]
+        L.vp_shard_exchange_get.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.vp_shard_exchange_put.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        self.rank, self.world, self.n, self.transport = rank, world, bit_length, transport
+        inputs = np.ascontiguousarray(inputs, dtype=np.uint64)
+        self.ctx = ctypes.c_void_p()
+        if L.vp_create(device, ctypes.byref(self.ctx)):
+            raise RuntimeError("vp_create failed")
+        self._chk(L.vp_pc_load_input(self.ctx, inputs.ctypes.data, inputs.shape[0], bit_length), "vp_pc_load_input")
+        if transport == "rccl":
+            import torch
+            import torch.distributed as dist
+            uid = ctypes.create_string_buffer(128)
+            if rank == 0 and L.vp_comm_unique_id(ctypes.cast(uid, ctypes.c_void_p)):
+                raise RuntimeError("vp_comm_unique_id failed (librccl.so.1 not found?)")
+            t = torch.from_numpy(np.frombuffer(uid.raw, dtype=np.uint8).copy())
+            if "nccl" in dist.get_backend():
+                t = t.cuda()
+            dist.broadcast(t, src=0)
+            idb = ctypes.create_string_buffer(t.cpu().numpy().tobytes(), 128)
+            self._chk(L.vp_comm_init(self.ctx, ctypes.cast(idb, ctypes.c_void_p), rank, world), "vp_comm_init")
+        self._chk(L.vp_pc_set_shard(self.ctx, rank, world), "vp_pc_set_shard")
+
+    def _chk(self, rc, what):
+        if rc < 0:
+            raise RuntimeError("%s failed (%d): %s" % (what, rc, lib_gpu().vp_last_error(self.ctx).decode()))
+
+    def comm_count(self):
+        n = ctypes.c_int(0)
+        self._chk(lib_gpu().vp_comm_count(self.ctx, ctypes.byref(n)), "vp_comm_count")
+        return n.value
+
+    def _exchange_host(self):
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+        L = lib_gpu()
+        n = ctypes.c_int(0)
+        L.vp_shard_pending(self.ctx, ctypes.byref(n))
+        for i in range(n.value):
+            kind, nb = ctypes.c_int(0), ctypes.c_uint64(0)
+            self._chk(L.vp_shard_exchange_info(self.ctx, i, ctypes.byref(kind), ctypes.byref(nb)), "vp_shard_exchange_info")
+            b = int(nb.value)
+            send = np.zeros(self.world * b if kind.value == 1 else b, dtype=np.uint8)
+            self._chk(L.vp_shard_exchange_get(self.ctx, i, send.ctypes.data), "vp_shard_exchange_get")
+            parts = [torch.zeros(send.shape[0], dtype=torch.uint8) for _ in range(self.world)]
+            dist.all_gather(parts, torch.from_numpy(send))
+            if kind.value == 1:        # all-to-all: from every peer p, the block it addressed to this rank
+                recv = np.concatenate([parts[p].numpy()[self.rank * b:(self.rank + 1) * b] for p in range(self.world)])
+            else:
+                recv = np.concatenate([parts[p].numpy() for p in range(self.world)])
+            recv = np.ascontiguousarray(recv)
+            self._chk(L.vp_shard_exchange_put(self.ctx, i, recv.ctypes.data), "vp_shard_exchange_put")
+        L.vp_shard_exchange_done(self.ctx)
+
+    def _run(self, call, what):
+        for _ in range(8):
+            rc = call()
+            self._chk(rc, what)
+            if rc == 0:
+                return
+            if rc != self.VP_EXCHANGE or self.transport != "host":
+                raise RuntimeError("%s: unexpected return %d" % (what, rc))
+            self._exchange_host()
+        raise RuntimeError("%s did not finish" % what)
+
+    def device_ms(self):
+        ms = ctypes.c_double(0)
+        lib_gpu().vp_commit_stats(self.ctx, ctypes.byref(ms))
+        return ms.value
+
+    def commit_private(self):
+        root = ctypes.create_string_buffer(32)
+        self._run(lambda: lib_gpu().vp_commit_private(self.ctx, ctypes.cast(root, ctypes.c_void_p)), "vp_commit_private")
+        return root.raw
+
+    def commit_public(self, pub):
+        import numpy as np
+        pub = np.ascontiguousarray(pub, dtype=np.uint64)
+        root = ctypes.create_string_buffer(32)
+        inner, alls = np.zeros(2, np.uint64), np.zeros((65, 2), np.uint64)
+        self._run(lambda: lib_gpu().vp_commit_public(self.ctx, pub.ctypes.data, pub.shape[0], inner.ctypes.data, alls.ctypes.data,
+                                                     ctypes.cast(root, ctypes.c_void_p)), "vp_commit_public")
+        return root.raw, inner.tobytes(), alls.tobytes()
+
+    def fri_commit(self, r):
+        import numpy as np
+        r = np.ascontiguousarray(r, dtype=np.uint64)
+        roots = ctypes.create_string_buffer(32 * r.shape[0])
+        self._run(lambda: lib_gpu().vp_fri_commit(self.ctx, r.ctypes.data, r.shape[0], ctypes.cast(roots, ctypes.c_void_p)), "vp_fri_commit")
+        fin = np.zeros((2048, 2), dtype=np.uint64)
+        self._chk(lib_gpu().vp_fri_final(self.ctx, fin.ctypes.data), "vp_fri_final")
+        return roots.raw, fin
+
+    def close(self):
+        if self.ctx:
+            lib_gpu().vp_destroy(self.ctx)
+            self.ctx = None
+
+
 class Circuit:
     """layeredCircuit after subsetInit (host/circuit.hpp)."""
 
@@ -441,6 +562,24 @@ class Session:
             out.append({"kernel": lib_gpu().vp_kernel_name(e.kind).decode(), "step": e.step, "workgroups": e.workgroups, "jobs": e.jobs,
                         "rounds": e.rounds, "first_round": e.first_round, "bytes": e.bytes, "work": e.work, "us": e.us})
         return out
+
+    def round_stats(self):
+        """Interactive path, one dict per vp_round since the last prove_interactive() started: {phase, layer, round, how, tables, bytes, us}
+        (include/vpgpu.h: vp_round_stat — algorithmic bytes of the round by SURVEY §8d and the wall time of the call)."""
+        ctx = lib_host().vph_session_ctx(self.h)
+        n = ctypes.c_int(0)
+        lib_gpu().vp_get_round_stats(ctx, None, 0, ctypes.byref(n))
+        arr = (RoundStat * max(1, n.value))()
+        lib_gpu().vp_get_round_stats(ctx, arr, n.value, ctypes.byref(n))
+        return [{"phase": e.phase, "layer": e.layer, "round": e.round, "how": e.how, "tables": e.tables, "bytes": e.bytes, "us": e.us}
+                for e in (arr[i] for i in range(n.value))]
+
+    def comm_count(self):
+        """ncclCommCount of the communicator attached with attach_comm()."""
+        n = ctypes.c_int(0)
+        if lib_gpu().vp_comm_count(lib_host().vph_session_ctx(self.h), ctypes.byref(n)):
+            raise RuntimeError("vp_comm_count failed")
+        return n.value
 
     def layer_values(self, layer):
         import numpy as np

@@ -147,6 +147,8 @@ struct vp_ctx {
     vp_stats st{};
     std::vector<EvPair> ev_pool; size_t ev_used = 0;
     std::vector<vp_launch_stat> lstats;   // per-launch table of the last profiled call (vp_get_launch_stats)
+    std::vector<vp_round_stat> rlog;      // interactive path: one entry per vp_round since the last vp_vres (vp_get_round_stats)
+    int rlog_round = 0;                   // vp_round calls since the last phase init
     u64 rec_gen_bytes = 0, rec_gen_work = 0;      // record mode: algorithmic bytes / contributions of the init fused into the next fold launch
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<void *> allocs;
@@ -1101,6 +1103,7 @@ int vp_liu_gr(vp_ctx *ctx, int layer, const vp_F *r_u, const vp_F *const *r_v, c
 int vp_vres(vp_ctx *ctx, const vp_F *r_0, int r_0_size, vp_F *out) {
     if (!ctx || !ctx->evaluated || !out || r_0_size != ctx->L[ctx->n_layers - 1].bl || (r_0_size && !r_0)) return VP_EINVAL;
     VP_ENTER(ctx);
+    ctx->rlog.clear();
     VPCHK(stage(ctx, 0, r_0, r_0_size));
     LayerDev &T = ctx->L[ctx->n_layers - 1];
     VPCHK(run_beta_half(ctx, ctx->d_tape, T.bl, ctx->one()));
@@ -1119,6 +1122,7 @@ int vp_phase1_init(vp_ctx *ctx, int layer, const vp_F *r_liu, const vp_F *assert
     VPCHK(stage(ctx, off, r_liu, ctx->L[layer].bl));
     VPCHK(stage(ctx, ctx->as_off[layer], assert_random, 1));
     VPCHK(do_phase1_init(ctx, layer, ctx->d_tape + off, ctx->d_tape + ctx->as_off[layer]));
+    ctx->rlog_round = 0;
     return round1_prefetch(ctx);
 }
 
@@ -1129,6 +1133,7 @@ int vp_phase2_init(vp_ctx *ctx, int layer, const vp_F *r_u) {
     VP_ENTER(ctx);
     VPCHK(stage(ctx, ctx->ru_off[layer], r_u, ctx->L[layer - 1].bl));
     VPCHK(do_phase2_init(ctx, layer, ctx->d_tape + ctx->ru_off[layer]));
+    ctx->rlog_round = 0;
     return round1_prefetch(ctx);
 }
 
@@ -1145,20 +1150,46 @@ int vp_liu_init(vp_ctx *ctx, int layer, const vp_F *r_u, const vp_F *const *r_v,
             VPCHK(stage(ctx, ctx->rv_off[k], r_v[k], ctx->L[k].dad_bl[layer - 1]));
         }
     VPCHK(do_liu_init(ctx, layer));
+    ctx->rlog_round = 0;
     return round1_prefetch(ctx);
 }
 
+static int vp_round_impl(vp_ctx *ctx, const vp_F *previous_random, vp_F out_poly[3], int *how);
+// The round as the caller sees it: wall time of the call and the ALGORITHMIC bytes of the round (48 B x (L_in + L_out) per table
+// family with an add table, 32 B without; round 1 only reads) -> achieved GB/s per sumcheck round (vp_get_round_stats).
 int vp_round(vp_ctx *ctx, const vp_F *previous_random, vp_F out_poly[3]) {
     if (!ctx || !previous_random || !out_poly || ctx->sc.phase == 0) return VP_EINVAL;
+    const auto t0 = std::chrono::steady_clock::now();
+    int how = 0;
+    const int rc = vp_round_impl(ctx, previous_random, out_poly, &how);
+    if (rc == VP_OK && ctx->rlog.size() < (size_t) 1 << 16) {
+        const int k = ++ctx->rlog_round;
+        const SumcheckState &sc = ctx->sc;
+        u64 ent = 0;
+        for (int j = 0; j < sc.n_tab; ++j) {
+            const u64 v = sc.valid0[j];
+            if (k == 1) ent += v;
+            else ent += ((v + (1ull << (k - 2)) - 1) >> (k - 2)) + ((v + (1ull << (k - 1)) - 1) >> (k - 1));
+        }
+        vp_round_stat e;
+        e.phase = sc.phase; e.layer = sc.layer; e.round = k; e.how = how; e.tables = sc.n_tab;
+        e.bytes = ent * (sc.has_a ? 48 : 32);
+        e.us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        ctx->rlog.push_back(e);
+    }
+    return rc;
+}
+static int vp_round_impl(vp_ctx *ctx, const vp_F *previous_random, vp_F out_poly[3], int *how) {
     HIPCHK(hipSetDevice(ctx->device));
     F rv; memcpy(&rv, previous_random, sizeof(F));
     // canonical limbs only (header convention); the mailbox of the resident kernel also keeps its sequence tag in bits 61-63 of every word
     if (rv.re >= P61 || rv.im >= P61) { ctx->err = "vp_round: previous_random is not canonical (limb >= 2^61 - 1)"; return VP_EINVAL; }
     if (!ctx->r1_pending && ctx->sc.round >= ctx->sc.total_rounds) { ctx->err = "too many rounds"; return VP_EINVAL; }
     if (ctx->r1_pending) {                                    // round 1 was queued by the init call (it takes no challenge): collect it
-        const int how = ctx->r1_pending;
+        const int how1 = ctx->r1_pending;
         ctx->r1_pending = 0;
-        if (how == 1) {
+        *how = 2;                                             // round 1 was computed behind the init call
+        if (how1 == 1) {
             VPCHK(tail_wait(ctx, ctx->tail_seq));
             tail_poly(ctx, out_poly);
             ++ctx->sc.round; ++ctx->st.rounds;
@@ -1170,6 +1201,7 @@ int vp_round(vp_ctx *ctx, const vp_F *previous_random, vp_F out_poly[3]) {
     }
     // small rounds: one resident kernel answers every remaining message of the phase through a mailbox (vp_kernels_persist.h)
     if (ctx->tail_active) {
+        *how = 1;                                             // answered by the resident kernel through the mailbox
         VPCHK(tail_send(ctx, 1, rv));
         if (tail_status(ctx) != 0) { ctx->tail_active = false; ctx->err = "persistent round kernel: protocol error"; return VP_EHIP; }
         tail_poly(ctx, out_poly);
@@ -1181,6 +1213,7 @@ int vp_round(vp_ctx *ctx, const vp_F *previous_random, vp_F out_poly[3]) {
         return VP_OK;
     }
     if (tail_try_launch(ctx, rv)) {
+        *how = 1;
         VPCHK(tail_wait(ctx, ctx->tail_seq));
         tail_poly(ctx, out_poly);
         ++ctx->sc.round; ++ctx->st.rounds;
@@ -1343,6 +1376,12 @@ int vp_prove_gkr(vp_ctx *ctx, const vp_F *tape, uint64_t n_tape, uint8_t *transc
 int vp_get_stats(vp_ctx *ctx, vp_stats *out) {
     if (!ctx || !out) return VP_EINVAL;
     *out = ctx->st;
+    return VP_OK;
+}
+int vp_get_round_stats(vp_ctx *ctx, vp_round_stat *out, int capacity, int *n) {
+    if (!ctx || !n || (capacity > 0 && !out)) return VP_EINVAL;
+    *n = (int) ctx->rlog.size();
+    for (int i = 0; i < *n && i < capacity; ++i) out[i] = ctx->rlog[i];
     return VP_OK;
 }
 int vp_set_profiling(vp_ctx *ctx, int level) {
