@@ -122,6 +122,10 @@ typedef struct {
                                        keeps the fastest for this circuit (one-off: a plan, a graph capture and six replays per candidate; a candidate
                                        that does not build is skipped; the transcript does not depend on the choice).  The fields named here are then
                                        OVERWRITTEN by the tuner; 0: they are taken as given.  Not used for sharded proofs            [1] */
+    int32_t pc_tensor_pub;          /* VP_PC_TENSOR: vp_commit_public checks (exactly, on the device) whether the public vector is a tensor — every
+                                       slice a scalar multiple of slice 0, which the protocol's own vector eq(r, .) always is — and then encodes ONE
+                                       slice instead of 64 (q_i = c_i q_0 formed where it is consumed): same field elements, a third fewer
+                                       transforms per commitment.  0: always encode all 64 slices                                    [1] */
 } vp_options;
 void vp_options_default(vp_options *opt);
 

@@ -1190,6 +1190,42 @@ def test_reference_binary_drives_the_device_prover(pws_path, tmp_path, golden):
     assert "fft gkr failed" not in r.stderr
 
 
+def test_tensor_public_vector_shortcut_is_exact(vp, ob, monkeypatch):
+    """vp_commit_public encodes ONE slice when the public vector is a tensor (every slice a multiple of slice 0 — the protocol's eq table
+    always is) and forms q_i = c_i q_0 where it is consumed.  Same roots, input_0 and all_sum as the general path (VP_PC_TENSOR=0) on: an eq
+    table; a tensor with generic factors; a tensor whose corner is zero and a near-tensor with one entry changed (both must take the
+    general path: the device check is exact); FRI roots after either path."""
+    rng = np.random.default_rng(31)
+    c = vp.Circuit.randomize(3, 11, seed=4)
+    n = c.layer_bitlen(0)
+    N = 1 << (n - 6)
+
+    def run(pub, tensor):
+        monkeypatch.setenv("VP_PC_TENSOR", "1" if tensor else "0")
+        s = vp.Session(c)
+        root_l, _ = s.commit_private()
+        root_h, inner, all_sum, _ = s.commit_public(pub)
+        rr = np.random.default_rng(5).integers(0, P, size=(n - 6, 2), dtype=np.uint64)
+        roots, fin = s.fri_commit(rr)
+        s.close()
+        return root_l, root_h, inner, all_sum, roots, fin.tobytes()
+
+    s0 = vp.Session(c)
+    eq = s0.eq_table(rng.integers(0, P, size=(n, 2), dtype=np.uint64))
+    s0.close()
+    lo, hi = rng.integers(0, P, size=(N, 2), dtype=np.uint64), rng.integers(0, P, size=(64, 2), dtype=np.uint64)
+    L = ob.lib()
+    generic = np.zeros((64 * N, 2), dtype=np.uint64)
+    for i in range(64):
+        for k in range(N):
+            L.orc_f_mul(hi[i].ctypes.data, lo[k].ctypes.data, generic[i * N + k].ctypes.data)
+    zero_corner = generic.copy(); zero_corner[0] = 0
+    near = generic.copy(); near[17 * N + 5, 0] ^= np.uint64(1)
+    for name, pub in (("eq table", eq), ("generic tensor", generic), ("zero corner", zero_corner), ("near-tensor", near)):
+        assert run(pub, True) == run(pub, False), name
+    c.close()
+
+
 def _run_ranks(world, transport, blocks, timeout=600):
     import socket
     import subprocess

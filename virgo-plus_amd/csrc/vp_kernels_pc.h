@@ -21,6 +21,11 @@ k_root_table_step(F *RT, u32 have /* entries already filled, power of two */, F 
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < have) RT[have + i] = f_mul(RT[i], step);
 }
+// out[k] = RT[k * stride], k < n: the roots of a smaller order, contiguous
+__global__ void __launch_bounds__(VP_BLOCK) k_root_compact(const F *__restrict__ RT, u32 stride, u32 n, F *__restrict__ out) {
+    const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) out[k] = RT[(size_t) k * stride];
+}
 
 // Batched in-LDS NTT of size N = 2^ln <= 8192, one workgroup per transform (blockIdx.x = row,
 // blockIdx.y = coset).  DIT: bit-reversed load, radix-4 passes in registers (below), natural-order store.
@@ -31,7 +36,11 @@ k_root_table_step(F *RT, u32 have /* entries already filled, power of two */, F 
 //   inverse mode: out[row*N + k] = N^-1 * sum_j in[row*N + j] * w_N^(-jk)   (inverse_fast_fourier_transform, :159-220).
 struct NttArgs {
     const F *in; F *out;
-    const F *RT; u32 half_m; int lm;      // root table of order M = 2^lm
+    const F *RT; u32 half_m; int lm;      // root table of order M = 2^lm (the coset twist indexes it with j * coset)
+    // The butterflies' roots w_N^k come from a COMPACT table of order N (RTp[k] = w_N^k, k < half_p = N/2; pc_compact_roots): through the
+    // order-M table they are M/N entries apart — one cache line each, a 2^12-point sub-transform of a x1024 commitment touched 256 KB of L2
+    // for 32 KB of roots (and the 2^16 twiddles of k_ntt_split were spread over all 32 MB of it: the 1.28x HBM traffic of round 2's PMC).
+    const F *RTp; u32 half_p;
     int ln;                               // transform size N = 2^ln
     int inverse;
     u32 in_stride;                        // elements between consecutive input rows
@@ -52,6 +61,24 @@ __device__ __forceinline__ F mul_iota(const F &x, bool plus) {
 //     (a + B) + (C + D), (a - B) + iota (C - D), (a + B) - (C + D), (a - B) - iota (C - D),   B = W^2 b, C = W c, D = W^3 d
 // — three multiplications per four points and two stages (radix 2: four), half the LDS passes and barriers; the first pass of an
 // even ln has W = 1 and does not multiply at all.  ln = 13: 4.5 multiplications per point instead of 6.5, 7 LDS passes instead of 14.
+// LDS slot of element i.  An element is 16 bytes, a row of the 32 LDS banks holds 8 of them: lanes that are 4, 16, ... or N/2 elements apart
+// (the radix-4 passes with q = 1 and 4, the bit-reversed load) all fall into the same one or two slots of the row and serialise — 8-way in
+// the first pass, 64-way on the load.  XOR-ing the three low index bits with the three-bit groups above them spreads every power-of-two
+// stride over all 8 slots (consecutive indices stay a permutation of their aligned group of 8, so unit-stride accesses stay conflict-free).
+// MEASURED (round 3, same-call A/B at x1024, tools/pc_ab.py): k_ntt_lds 10.6 ms without, 10.8 ms with — the bank conflicts are not what the
+// kernel waits for (neither are the root-table gathers: compact tables changed nothing): ~500 VALU instructions per radix-4 butterfly (three
+// multiplications at ~85, eight canonical add/sub at ~20) at the ~5 cycles per wave-instruction every kernel of this library issues at ARE
+// its 41 us per 2^12-point workgroup.  Off by default; kept as the switch that measured it.
+#ifndef VP_NTT_SWZ
+#define VP_NTT_SWZ 0
+#endif
+__device__ __forceinline__ u32 ntt_slot(u32 i) {
+#if VP_NTT_SWZ
+    return i ^ (((i >> 3) ^ (i >> 6) ^ (i >> 9) ^ (i >> 12)) & 7u);
+#else
+    return i;
+#endif
+}
 __global__ void __launch_bounds__(1024) k_ntt_lds(NttArgs a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     F *L = reinterpret_cast<F *>(smem_raw);
@@ -65,7 +92,7 @@ __global__ void __launch_bounds__(1024) k_ntt_lds(NttArgs a) {
         row = (long_row << a.scat_l1) + k1;
     }
     const u32 M = 2 * a.half_m;
-    const u32 wstride = M >> a.ln;                          // w_N = w_M^wstride
+    const u32 Mp = 2 * a.half_p, wstride = Mp >> a.ln;      // w_N = w_Mp^wstride in the pass table (wstride = 1 for the compact one)
     const F *src = a.in + (size_t) row * a.in_stride;
     const bool twist = !a.inverse && coset;
     int s = 1;
@@ -78,14 +105,14 @@ __global__ void __launch_bounds__(1024) k_ntt_lds(NttArgs a) {
                 y = f_mul(y, root_pow(a.RT, a.half_m, ((j + N / 2) * coset) & (M - 1)));
             }
             const u32 m = __brev(j) >> (32 - a.ln);         // even
-            L[m] = f_add(x, y); L[m + 1] = f_sub(x, y);
+            L[ntt_slot(m)] = f_add(x, y); L[ntt_slot(m + 1)] = f_sub(x, y);
         }
         s = 2;
     } else {
         for (u32 j = tid; j < N; j += nth) {
             F x = src[j];
             if (twist) x = f_mul(x, root_pow(a.RT, a.half_m, (j * coset) & (M - 1)));
-            L[a.ln ? (__brev(j) >> (32 - a.ln)) : 0u] = x;
+            L[ntt_slot(a.ln ? (__brev(j) >> (32 - a.ln)) : 0u)] = x;
         }
     }
     __syncthreads();
@@ -96,27 +123,28 @@ __global__ void __launch_bounds__(1024) k_ntt_lds(NttArgs a) {
         const u32 tw = (N >> (s + 1)) * wstride;           // W = w_4q^k = w_M^(k * tw)
         for (u32 idx = tid; idx < N / 4; idx += nth) {
             const u32 k = idx & (q - 1), i0 = ((idx >> (s - 1)) << (s + 1)) | k;
-            F x0 = L[i0], x1 = L[i0 + q], x2 = L[i0 + 2 * q], x3 = L[i0 + 3 * q];
+            const u32 p0 = ntt_slot(i0), p1 = ntt_slot(i0 + q), p2 = ntt_slot(i0 + 2 * q), p3 = ntt_slot(i0 + 3 * q);
+            F x0 = L[p0], x1 = L[p1], x2 = L[p2], x3 = L[p3];
             if (q > 1) {                                    // uniform: the first pass of an even ln has W = 1
-                const u32 e = k * tw;                       // < M/4
-                const u32 e1 = a.inverse ? (e ? M - e : 0) : e, e2 = a.inverse ? (e ? M - 2 * e : 0) : 2 * e,
-                          e3 = a.inverse ? (e ? M - 3 * e : 0) : 3 * e;
-                x1 = f_mul(x1, root_pow(a.RT, a.half_m, e2));
-                x2 = f_mul(x2, root_pow(a.RT, a.half_m, e1));
-                x3 = f_mul(x3, root_pow(a.RT, a.half_m, e3));
+                const u32 e = k * tw;                       // < Mp/4
+                const u32 e1 = a.inverse ? (e ? Mp - e : 0) : e, e2 = a.inverse ? (e ? Mp - 2 * e : 0) : 2 * e,
+                          e3 = a.inverse ? (e ? Mp - 3 * e : 0) : 3 * e;
+                x1 = f_mul(x1, root_pow(a.RTp, a.half_p, e2));
+                x2 = f_mul(x2, root_pow(a.RTp, a.half_p, e1));
+                x3 = f_mul(x3, root_pow(a.RTp, a.half_p, e3));
             }
             const F s0 = f_add(x0, x1), d0 = f_sub(x0, x1), s1 = f_add(x2, x3), d1 = mul_iota(f_sub(x2, x3), ip);
-            L[i0] = f_add(s0, s1); L[i0 + q] = f_add(d0, d1); L[i0 + 2 * q] = f_sub(s0, s1); L[i0 + 3 * q] = f_sub(d0, d1);
+            L[p0] = f_add(s0, s1); L[p1] = f_add(d0, d1); L[p2] = f_sub(s0, s1); L[p3] = f_sub(d0, d1);
         }
         __syncthreads();
     }
     if (a.scat_l1) {
         F *dst = a.out + ((size_t) long_row << (a.ln + a.scat_l1)) + k1;
-        for (u32 k = tid; k < N; k += nth) dst[(size_t) k << a.scat_l1] = a.scat_do_scale ? f_mul(L[k], a.scat_scale) : L[k];
+        for (u32 k = tid; k < N; k += nth) dst[(size_t) k << a.scat_l1] = a.scat_do_scale ? f_mul(L[ntt_slot(k)], a.scat_scale) : L[ntt_slot(k)];
         return;
     }
     F *dst = a.inverse ? a.out + (size_t) row * N : a.out + ((size_t) row * gridDim.y + coset) * N;
-    for (u32 k = tid; k < N; k += nth) dst[k] = a.inverse ? f_mul(L[k], a.inv_n) : L[k];
+    for (u32 k = tid; k < N; k += nth) dst[k] = a.inverse ? f_mul(L[ntt_slot(k)], a.inv_n) : L[ntt_slot(k)];
 }
 
 // ---- K8: SHA3-256 on 64-byte messages (my_hhash.h:27-33; FIPS 202), leaf chains and Merkle levels -------
@@ -342,13 +370,27 @@ namespace vp {
 
 // Products l*q on the two cosets the quotient needs: positions 16*j, j < 2N, are coset 0 (j even) and coset 16
 // (j odd) of the coset-major codewords.  P[(2i)*N + a] = l_i*q_i at w_M^(32a), P[(2i+1)*N + a] at w_M^(32a+16).
+// q0 / qscal != NULL: the public vector is a TENSOR (every slice a scalar multiple of slice 0: pub[i N + k] = qscal[i] pub[k] — the protocol's
+// own public vector, the eq table of the opening point, src/verifier.cpp:368-369, always is), so only slice 0 was encoded (q0, one
+// coset-major codeword) and q_i = qscal[i] * q0: 32 instead of 2048 transforms, 1/64 of the q traffic, one more multiplication here.
 __global__ void __launch_bounds__(VP_BLOCK)
-k_pc_products(const F *__restrict__ lcw, const F *__restrict__ qcw, u32 N, F *__restrict__ P, u32 n_slices) {
+k_pc_products(const F *__restrict__ lcw, const F *__restrict__ qcw, u32 N, F *__restrict__ P, u32 n_slices, const F *__restrict__ q0,
+              const F *__restrict__ qscal) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= 2 * n_slices * N) return;
     const u32 a = t % N, r = t / N, i = r >> 1, b = (r & 1) ? 16 : 0;
     const size_t src = ((size_t) i * 32 + b) * N + a;
-    P[t] = f_mul(lcw[src], qcw[src]);
+    const F q = q0 ? f_mul(qscal[i], q0[(size_t) b * N + a]) : qcw[src];
+    P[t] = f_mul(lcw[src], q);
+}
+// Is the public vector a tensor with a non-zero corner?  pub[i N + k] * pub[0] == pub[i N] * pub[k] for every i >= 1, k (exact in a field:
+// with pub[0] != 0 this IS proportionality of slice i to slice 0 with factor pub[i N] / pub[0]).  flag |= 1 on any violation.
+__global__ void __launch_bounds__(VP_BLOCK) k_pc_rank1_check(const F *__restrict__ pub, u32 N, u32 n_slices, int *__restrict__ flag) {
+    const size_t t = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t) n_slices * N) return;
+    const u32 k = (u32) (t % N), i = (u32) (t / N);
+    if (i == 0) return;
+    if (!f_eq(f_mul(pub[t], pub[0]), f_mul(pub[(size_t) i * N], pub[k]))) atomicOr(flag, 1);
 }
 // With l*q = L + x^N H (deg L, H < N):  S = iNTT_N(products on coset 0) = L + H,  T_j * w_2N^-j = L_j - H_j for
 // T = iNTT_N(products on coset 16).  h_coef = H = (S - D)/2  (poly_commit.h:283-287 takes the upper half of a 2N-point
@@ -391,14 +433,15 @@ namespace vp {
 // Written in place over the q codeword (same coset-major index).
 __global__ void __launch_bounds__(VP_BLOCK)
 k_pc_virtual_oracle(const F *__restrict__ lcw, F *__restrict__ qcw, const F *__restrict__ hcw, const F *__restrict__ S0, u32 N,
-                    const F *__restrict__ RT, u32 half_m, F n_as_f, u32 n_slices) {
+                    const F *__restrict__ RT, u32 half_m, F n_as_f, u32 n_slices, const F *__restrict__ q0, const F *__restrict__ qscal) {
     const size_t t = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
     const size_t M = 2 * (size_t) half_m;
     if (t >= n_slices * M) return;
     const u32 a = (u32) (t % N), b = (u32) ((t / N) % 32), i = (u32) (t / M);
     const u32 k = 32 * a + b;
     const F xn_m1 = f_sub(root_pow(RT, half_m, (u32) ((size_t) b * N) & (u32) (M - 1)), f_one());   // w_M^(N*b) - 1
-    const F g = f_sub(f_mul(lcw[t], qcw[t]), f_mul(xn_m1, hcw[t]));
+    const F q = q0 ? f_mul(qscal[i], q0[t - (size_t) i * M]) : qcw[t];           // tensor public vector: q_i = qscal[i] * q0 (k_pc_products)
+    const F g = f_sub(f_mul(lcw[t], q), f_mul(xn_m1, hcw[t]));
     const F inv_x = f_mul(n_as_f, root_pow(RT, half_m, k ? (u32) M - k : 0));
     qcw[t] = f_mul(f_sub(g, S0[i]), inv_x);
 }
@@ -465,6 +508,9 @@ __global__ void __launch_bounds__(VP_BLOCK) k_ntt_split(SplitArgs a) {
     const bool twist = !a.inverse && coset;
     // The coset twist w_M^(j coset), j = j1 N2 + j2, splits into a factor of j1 alone (applied here, none for j1 = 0) and the factor
     // w_M^(j2 coset) that is common to the whole column: it commutes with the N1-point transform and joins the output twiddle below.
+    // (Round 3 tried the other arrangement — the whole twist on the inputs, the output twiddles w_N^(j2 k1) from a compact order-N table
+    // that stays in L2 instead of a merged index striding through the 32 MB order-M table: 14 % SLOWER per byte, 2213 -> 1908 GB/s at x1024;
+    // the kernel is bound by its VALU instructions, one more multiplication per column costs more than the gathers do.)
     F x[N1];
 #pragma unroll
     for (u32 j1 = 0; j1 < N1; ++j1) {

@@ -103,13 +103,13 @@ __device__ __forceinline__ void tail_wave0_total(const F *red, int nw, F (&tot)[
 __device__ __forceinline__ int tail_poll(const PTailArgs &a, unsigned long long expect, F &r) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), tag = VP_TAG(expect);
     for (;;) {
-        // relaxed system-scope loads read the fine-grained host memory past the caches; no acquire (it would invalidate them on every poll)
+        // relaxed system-scope loads read the fine-grained host memory past the caches; no acquire (it would invalidate them on every poll).
+        // All three words are requested in ONE go (independent loads, one wait): every such load is a read over PCIe (~2 us); taken one
+        // after the other — w0, and w1 / w2 only once w0 showed the tag, as rounds 2 did — a message cost three of them.
         const unsigned long long w0 = __hip_atomic_load(&a.req->w[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if ((w0 & (7ull << 61)) == tag) {
-            const unsigned long long w1 = __hip_atomic_load(&a.req->w[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            const unsigned long long w2 = __hip_atomic_load(&a.req->w[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if ((w1 & (7ull << 61)) == tag && (w2 & (7ull << 61)) == tag) { r = f_make(VP_UNTAG(w0), VP_UNTAG(w1)); return (int) VP_UNTAG(w2); }
-        }
+        const unsigned long long w1 = __hip_atomic_load(&a.req->w[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long w2 = __hip_atomic_load(&a.req->w[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((w0 & (7ull << 61)) == tag && (w1 & (7ull << 61)) == tag && (w2 & (7ull << 61)) == tag) { r = f_make(VP_UNTAG(w0), VP_UNTAG(w1)); return (int) VP_UNTAG(w2); }
         if (__builtin_amdgcn_s_memrealtime() - t0 > VP_PH_TIMEOUT_TICKS) return -1;
         __builtin_amdgcn_s_sleep(1);
     }
@@ -386,17 +386,60 @@ __global__ void __launch_bounds__(VP_PH_THREADS) k_phase(PTailArgs a) {
         }
     }
     // ---- mailbox loop: the remaining rounds, then finalize --------------------------------------------------------------
-    int my_alive = 1;
+    // Round 3: THE ANSWER FIRST.  A round's polynomial depends on the challenge only through the fold of the tables, and that dependence is
+    // quadratic: with the pair (x0, x1) of the next level made of the quad (e0, e1, e2, e3) of this one, x0(r) = e0 + r (e1 - e0) and
+    // x1(r) = e2 + r (e3 - e2), so   sum dm(r) dv(r) = P0 + P1 r + P2 r^2   and   sum m0(r) v0(r) + a0(r) = C0 + C1 r + C2 r^2.
+    // The six sums are formed WHILE the verifier is still looking at the previous answer (three multiplications per quad each, Karatsuba on
+    // the two linear factors); when the challenge arrives the reply is two Horner evaluations on one lane plus the identity
+    // b = S_prev(r) - a - 2c (src/verifier.cpp:208: the check the verifier makes is the equation b is solved from), and the fold of the
+    // tables — and the next round's six sums — happen behind it, in the shadow of the host's round trip.  Critical path per round: the
+    // mailbox latency plus ~8 dependent multiplications, instead of fold -> barrier -> products -> reduction -> reply.
+    // MEASURED (in-kernel timestamps, -DVP_TAIL_STAMPS, MI355X): six sums 9 200 shader clocks, then the kernel still WAITS 3 500 for the
+    // challenge, reply chain 3 400, fold 2 100 — the device's work between two challenges (11 300 clocks) is shorter than the host's round
+    // trip (reply over PCIe, the verifier's round, request back over PCIe: ~14 800 clocks = 7 us), so a resident round now costs that round
+    // trip plus the reply chain: 10.2 -> 9.2 us per vp_round at x64 (with the three mailbox words polled in one go).
+    F pp0 = f_zero(), pp1 = f_zero(), pp2 = f_zero();              // boss: the polynomial answered last
+    if (boss) { pp0 = a.poly_dev[0]; pp1 = a.poly_dev[1]; pp2 = a.poly_dev[2]; }        // written by tail_reply a few lines up (same lane)
+    const int role2 = __builtin_amdgcn_readfirstlane(w & 1);
+    const u32 qslot = (u32) ((w >> 1) * 64 + lane);
     for (;;) {
         ++expect;
-        __syncthreads();                                           // the LDS tables of the previous round are complete
-        // waves whose pair slots can never be reached again leave (a terminated wave no longer counts at the barriers)
+        __syncthreads();                                           // the LDS tables of this level and s_len are complete
+        // (A) the coming round as a function of its challenge
+        TSTAMP(4);
+        F PA[3] = {f_zero(), f_zero(), f_zero()}, PC[3] = {f_zero(), f_zero(), f_zero()};
         {
-            u32 pairs_next = 0;
-            for (int j = 0; j < a.n_tab; ++j) pairs_next += s_len[j] >> 2;
-            const u32 groups = max(1u, (min(pairs_next, (u32) VP_PH_SLOTS) + 63) >> 6);
-            if ((u32) (w / 3) >= groups && w >= 3) return;
+            F acc[3] = {f_zero(), f_zero(), f_zero()};
+            u32 nq = 0;
+            for (int j = 0; j < a.n_tab; ++j) nq += s_len[j] >> 2;
+            if (k < a.R)
+                for (u32 q = qslot; q < nq; q += (VP_PH_THREADS / 128) * 64) {
+                    u32 base = 0, i0 = 0;
+                    for (int j = 0; j < a.n_tab; ++j) { const u32 np = s_len[j] >> 2; if (q >= base && q < base + np) i0 = s_loff[j] + 4 * (q - base); base += np; }
+                    if (role2 == 0) {
+                        const F m0 = LM[i0], m1 = LM[i0 + 1], m2 = LM[i0 + 2], m3 = LM[i0 + 3], v0 = LV[i0], v1 = LV[i0 + 1], v2 = LV[i0 + 2], v3 = LV[i0 + 3];
+                        const F dm0 = f_sub(m2, m0), dv0 = f_sub(v2, v0), sm = f_sub(m3, m1), sv = f_sub(v3, v1);
+                        const F p0 = f_mul(dm0, dv0), p2 = f_mul(f_sub(sm, dm0), f_sub(sv, dv0)), p1 = f_sub(f_sub(f_mul(sm, sv), p0), p2);
+                        acc[0] = f_add(acc[0], p0); acc[1] = f_add(acc[1], p1); acc[2] = f_add(acc[2], p2);
+                    } else {
+                        const F m0 = LM[i0], m1 = LM[i0 + 1], v0 = LV[i0], v1 = LV[i0 + 1];
+                        const F c0 = f_mul(m0, v0), c2 = f_mul(f_sub(m1, m0), f_sub(v1, v0)), c1 = f_sub(f_sub(f_mul(m1, v1), c0), c2);
+                        acc[0] = f_add(acc[0], c0); acc[1] = f_add(acc[1], c1); acc[2] = f_add(acc[2], c2);
+                        if (a.has_a) { const F a0 = LA[i0], a1 = LA[i0 + 1]; acc[0] = f_add(acc[0], a0); acc[1] = f_add(acc[1], f_sub(a1, a0)); }
+                    }
+                }
+            tail_wave_partials(acc, red);
+            __syncthreads();
+            if (w == 0) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    PA[i] = wave_sum63((lane < VP_PH_THREADS / 64 && !(lane & 1)) ? red[lane * 3 + i] : f_zero());
+                    PC[i] = wave_sum63((lane < VP_PH_THREADS / 64 && (lane & 1)) ? red[lane * 3 + i] : f_zero());
+                }
+            }
         }
+        // (B) the challenge
+        TSTAMP(5);
         if (tid == 0) { F rr = f_zero(); s_cmd = tail_poll(a, expect, rr); s_r = rr; }
         TSTAMP(0);
         __syncthreads();
@@ -404,29 +447,10 @@ __global__ void __launch_bounds__(VP_PH_THREADS) k_phase(PTailArgs a) {
         const F r = s_r;
         if (cmd == 1 && k < a.R) {
             ++k;
-            TSTAMP(1);
-            // pass 1: role f folds table family f for its pair slots (up to VP_PH_MAXIT pairs per lane), results in registers
-            F f0[VP_PH_MAXIT], f1[VP_PH_MAXIT]; u32 fo[VP_PH_MAXIT]; int nf = 0;
-            const F *Lf = role == 0 ? LV : role == 1 ? LM : LA;
-            u32 total = 0;
-            for (int j = 0; j < a.n_tab; ++j) total += s_len[j] >> 2;
-#pragma unroll
-            for (int it = 0; it < VP_PH_MAXIT; ++it) {
-                const u32 q = (u32) it * VP_PH_SLOTS + pslot;
-                fo[it] = 0xffffffffu;
-                if (q < total && (role != 2 || a.has_a)) {
-                    u32 base = 0; int mj = 0; u32 mp = 0;
-                    for (int j = 0; j < a.n_tab; ++j) { const u32 np = s_len[j] >> 2; if (q >= base && q < base + np) { mj = j; mp = q - base; } base += np; }
-                    const u32 i0 = s_loff[mj] + 4 * mp;
-                    f0[it] = f_lerp(Lf[i0], Lf[i0 + 1], r); f1[it] = f_lerp(Lf[i0 + 2], Lf[i0 + 3], r);
-                    fo[it] = s_loff[mj] + 2 * mp;
-                } else if (q < total) { f0[it] = f_zero(); f1[it] = f_zero(); u32 base = 0; for (int j = 0; j < a.n_tab; ++j) { const u32 np = s_len[j] >> 2; if (q >= base && q < base + np) fo[it] = s_loff[j] + 2 * (q - base); base += np; } }
-            }
-            (void) nf;
-            // tables that fold to a single entry now retire into add_term: read before anything is overwritten
+            // (C) the answer: one lane, from the sums formed before the challenge came
             if (boss) {
                 if (!f_is_zero(at)) at = f_mul(at, f_sub(f_one(), r));
-                for (int j = 0; j < a.n_tab; ++j) {
+                for (int j = 0; j < a.n_tab; ++j) {                 // tables that fold to a single entry now retire into add_term
                     if (s_len[j] != 2) continue;
                     const u32 o = s_loff[j];
                     const F v = f_lerp(LV[o], LV[o + 1], r), m = f_lerp(LM[o], LM[o + 1], r);
@@ -434,38 +458,43 @@ __global__ void __launch_bounds__(VP_PH_THREADS) k_phase(PTailArgs a) {
                     a.scalarV[j] = v;
                     at = f_add(at, f_add(f_mul(v, m), ad));
                 }
+                const F qa = f_add(PA[0], f_mul(r, f_add(PA[1], f_mul(r, PA[2]))));
+                const F qc = f_add(f_add(PC[0], f_mul(r, f_add(PC[1], f_mul(r, PC[2])))), at);
+                const F sp = f_add(f_mul(f_add(f_mul(pp0, r), pp1), r), pp2);            // S_prev(r) = the claim this round must add up to
+                const F qb = f_sub(f_sub(sp, qa), f_dbl(qc));
+                tail_reply(a, expect, qa, qb, qc);
+                pp0 = qa; pp1 = qb; pp2 = qc;
+            }
+            TSTAMP(1);
+            // (D) behind the answer: fold every table by r (registers, barrier, write back)
+            u32 tot_out = 0;
+            for (int j = 0; j < a.n_tab; ++j) tot_out += s_len[j] >> 1;
+            constexpr int FIT = (2 * VP_PH_PMAX + VP_PH_THREADS - 1) / VP_PH_THREADS;     // entries of one family per thread
+            F fv[3][FIT]; u32 fo[FIT];
+#pragma unroll
+            for (int it = 0; it < FIT; ++it) {
+                const u32 idx = (u32) it * VP_PH_THREADS + (u32) tid;
+                fo[it] = 0xffffffffu;
+                if (idx >= tot_out) continue;
+                // entry (idx - base) of table j's next level = lerp of entries 2 (idx - base), + 1 of this level
+                u32 base = 0, o = 0, src = 0;
+                for (int j = 0; j < a.n_tab; ++j) {
+                    const u32 no = s_len[j] >> 1;
+                    if (idx >= base && idx < base + no) { o = s_loff[j] + (idx - base); src = s_loff[j] + 2 * (idx - base); }
+                    base += no;
+                }
+                fo[it] = o;
+                fv[0][it] = f_lerp(LV[src], LV[src + 1], r);
+                fv[1][it] = f_lerp(LM[src], LM[src + 1], r);
+                fv[2][it] = a.has_a ? f_lerp(LA[src], LA[src + 1], r) : f_zero();
             }
             TSTAMP(2);
             __syncthreads();                                       // every source entry is in registers
-            F *Lw = role == 0 ? LV : role == 1 ? LM : LA;
 #pragma unroll
-            for (int it = 0; it < VP_PH_MAXIT; ++it) if (fo[it] != 0xffffffffu) { Lw[fo[it]] = f0[it]; Lw[fo[it] + 1] = f1[it]; }
-            __syncthreads();                                       // the folded tables are in LDS
-            TSTAMP(3);
-            // pass 2: one product per role: 0: (m1-m0)(v1-v0)   1: m0 v0 (+ a0)   2: m1 v1 (+ a1 - a0)
-            F acc[3] = {f_zero(), f_zero(), f_zero()};
-#pragma unroll
-            for (int it = 0; it < VP_PH_MAXIT; ++it) {
-                const u32 o = fo[it];
-                if (o == 0xffffffffu) continue;
-                if (role == 0) { const F qa = f_mul(f_sub(LM[o + 1], LM[o]), f_sub(LV[o + 1], LV[o])); acc[0] = f_add(acc[0], qa); acc[1] = f_sub(acc[1], qa); }
-                else if (role == 1) { const F qc = f_mul(LM[o], LV[o]); acc[1] = f_sub(acc[1], qc); acc[2] = f_add(acc[2], f_add(qc, LA[o])); }
-                else { const F qe = f_mul(LM[o + 1], LV[o + 1]); acc[1] = f_add(acc[1], f_add(qe, f_sub(LA[o + 1], LA[o]))); }
-            }
-            TSTAMP(4);
-            tail_wave_partials(acc, red);
-            TSTAMP(5);
-            __syncthreads();
-            F tot[3];
-            // rows of waves that have left hold their last (stale) partials: only the waves still here count
-            int nw_alive;
-            { u32 pn = 0; for (int j = 0; j < a.n_tab; ++j) pn += s_len[j] >> 2; const u32 groups = max(1u, (min(pn, (u32) VP_PH_SLOTS) + 63) >> 6); nw_alive = (int) (3 * groups); }
-            if (w == 0) tail_wave0_total(red, nw_alive, tot);
-            TSTAMP(6);
-            __syncthreads();
+            for (int it = 0; it < FIT; ++it) if (fo[it] != 0xffffffffu) { LV[fo[it]] = fv[0][it]; LM[fo[it]] = fv[1][it]; LA[fo[it]] = fv[2][it]; }
+            __syncthreads();                                       // nobody still reads s_len of this level
             if (tid < a.n_tab) s_len[tid] >>= 1;
-            if (boss) tail_reply(a, expect, tot[0], f_sub(tot[1], at), f_add(tot[2], at));
-            TSTAMP(7);
+            TSTAMP(3);
             continue;
         }
         // finalize (cmd 2), quit (3), timeout (-1) or a protocol error: leave
@@ -480,7 +509,6 @@ __global__ void __launch_bounds__(VP_PH_THREADS) k_phase(PTailArgs a) {
         __threadfence_system();
         __syncthreads();
         if (boss) { *a.add_term = at; tail_leave(a, expect, cmd, cmd == 2 ? 0 : cmd == 3 ? 1 : cmd == -1 ? 2 : 3); }
-        (void) my_alive;
         return;
     }
 }

@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -155,6 +156,8 @@ struct vp_ctx {
     BetaJob *all_jobs = nullptr; u32 n_all_jobs = 0, beta_bpj = 1; F *half_pool = nullptr;
     // polynomial commitment
     F *pc_rt = nullptr, *pc_coef = nullptr, *pc_cw = nullptr; Dig *pc_tree = nullptr; int pc_lm = -1; double commit_ms = 0;
+    std::map<std::pair<const void *, int>, F *> pc_rtc;   // compact root tables of smaller orders, keyed by (source table, log2 order)
+    F *pc_q0 = nullptr; int *pc_flag = nullptr; bool pc_q_tensor = false;   // tensor public vector: its one encoded slice (commit_public)
     F *pc_pub = nullptr, *pc_qcw = nullptr, *pc_hcw = nullptr, *pc_tmp = nullptr, *pc_small = nullptr; Dig *pc_tree_h = nullptr; bool pc_private_done = false;
     F *pc_scr = nullptr; size_t pc_scr_cap = 0;
     F *pc_fri_all = nullptr; std::vector<size_t> fri_cw_off, fri_tree_off; F *pc_open_buf = nullptr;
@@ -615,6 +618,7 @@ void vp_options_default(vp_options *o) {
     o->drop_y = 1; o->drop_y_round1 = 0; o->real_values = 1; o->seg_tiny = 1; o->sf_rounds = 3; o->sf_big_log = 14; o->sf3b = 1;
     o->sf3b_grid = 512; o->sf_min_waves = 1; o->dot_blocks = 1024; o->plan_align = 0; o->xcd_map = 0; o->round_fused_max = 512;
     o->persistent_rounds = 1; o->persistent_multi = 0; o->persistent_multi_shift = 13; o->poll = 1; o->debug = 0; o->prefetch_round1 = 1; o->split_cost_percent = 50; o->kernel_copies = 1; o->fold_branches = 1; o->ntt_scatter = 1; o->fuse_combine = 2; o->plan_autotune = 1;
+    o->pc_tensor_pub = 1;
 }
 // defaults <- the caller's struct (as many bytes as its header knew) <- VP_* environment variables (test-only override, read here and nowhere else)
 static void resolve_options(vp_options *o, const vp_options *user) {
@@ -639,6 +643,7 @@ static void resolve_options(vp_options *o, const vp_options *user) {
     flag("VP_KERNEL_COPIES", o->kernel_copies);
     flag("VP_FOLD_BRANCHES", o->fold_branches);
     flag("VP_NTT_SCATTER", o->ntt_scatter);
+    flag("VP_PC_TENSOR", o->pc_tensor_pub);
     num("VP_FUSE_COMBINE", o->fuse_combine);
     flag("VP_PLAN_AUTOTUNE", o->plan_autotune);
     if (getenv("VP_DEBUG")) o->debug |= 1;
@@ -651,7 +656,7 @@ int vp_create(int device, vp_ctx **out) { return vp_create_with_options(device, 
 
 // The caller's glibc random() / rand() stream is not ours to consume: the reference verifier draws every challenge and every query position
 // from it (lib/virgo/src/fieldElement.cpp:119-124,362-367, vpd_verifier.cpp:121), and the ROCm runtime takes draws from the same process-wide
-// generator while it initialises (measured through the reference binary, oracle/integration: vp_create shifted the stream, the proof still
+// generator while it initialises (measured through the reference binary of INTEGRATION.md: vp_create shifted the stream, the proof still
 // verified but was no longer the CPU reference's).  The set-up entry points therefore run on a private generator state and hand the caller's
 // back untouched.
 struct RandKeep {
@@ -744,8 +749,9 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
     ctx->chain_owner.clear(); ctx->chain_cost.clear();
     ctx->chunk_cap = 0; ctx->d_msync = nullptr; ctx->d_hand = nullptr;
     ctx->pred_r = ctx->pred_pool = ctx->pred_part = ctx->pred_out = nullptr; ctx->pred_jobs = nullptr; ctx->pred_dot = nullptr; ctx->pred_map = nullptr;
-    ctx->pc_rt = ctx->pc_coef = ctx->pc_cw = nullptr; ctx->pc_tree = nullptr; ctx->pc_lm = -1;
+    ctx->pc_rt = ctx->pc_coef = ctx->pc_cw = nullptr; ctx->pc_tree = nullptr; ctx->pc_lm = -1; ctx->pc_rtc.clear();
     ctx->pc_pub = ctx->pc_qcw = ctx->pc_hcw = ctx->pc_tmp = ctx->pc_small = nullptr; ctx->pc_tree_h = nullptr; ctx->pc_private_done = false;
+    ctx->pc_q0 = nullptr; ctx->pc_flag = nullptr; ctx->pc_q_tensor = false;
     ctx->pc_scr = nullptr; ctx->pc_scr_cap = 0; ctx->pc_fri_all = nullptr; ctx->pc_open_buf = nullptr; ctx->fri_cw_off.clear(); ctx->fri_tree_off.clear();
     ctx->pc_fri[0] = ctx->pc_fri[1] = nullptr; ctx->pc_fri_tree = nullptr; ctx->pc_fri_roots = nullptr; ctx->fri_step = -1; ctx->pc_public_done = false;
     int max_bl = 0;
@@ -1207,8 +1213,8 @@ static int vp_round_impl(vp_ctx *ctx, const vp_F *previous_random, vp_F out_poly
         tail_poly(ctx, out_poly);
         ++ctx->sc.round; ++ctx->st.rounds;
 #ifdef VP_TAIL_STAMPS
-        { const unsigned long long *t = ctx->h_rep->stamps; fprintf(stderr, "[stamps] poll->1 %llu | pass1 %llu | bar+write %llu | pass2 %llu | partials %llu | total %llu | reply %llu  (cycles)\n",
-                  t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[6] - t[5], t[7] - t[6]); }
+        { const unsigned long long *t = ctx->h_rep->stamps; fprintf(stderr, "[stamps] sums(before challenge) %llu | wait for challenge %llu | reply chain %llu | fold to regs %llu | write back %llu  (shader clocks)\n",
+                  t[5] - t[4], t[0] - t[5], t[1] - t[0], t[2] - t[1], t[3] - t[2]); }
 #endif
         return VP_OK;
     }

@@ -3,8 +3,8 @@
 // function makes on the prover's messages — the per-round identity p(0) + p(1) = claim (:261-266), the closed forms of the wiring
 // predicates at the end of the addition layer (:285-308), the multiplication layer (:405-446) and each inverse-FFT depth (:639-752), and
 // the claim hand-over between layers (:307, :445, :449-456, :763-765).  Field-type generic (Fe needs Fe(long long), + - *, == / !=):
-// virgo-plus_amd/host/verifier.cpp instantiates it with vph::fieldElement, oracle/integration/fft_gkr_vpgpu.cpp with the reference's own
-// virgo::fieldElement.  `tape` is the draw sequence in the reference's order, `msgs` what vp_fft_gkr returned (layouts: include/vpgpu.h).
+// virgo-plus_amd/host/verifier.cpp instantiates it with vph::fieldElement, the forwarding file for the reference's fft_circuit_GKR.cpp
+//  with the reference's own virgo::fieldElement.  `tape` is the draw sequence in the reference's order, `msgs` what vp_fft_gkr returned (layouts: include/vpgpu.h).
 #pragma once
 #include <cstddef>
 #include <vector>
