@@ -120,18 +120,24 @@ typedef struct {
     int32_t plan_autotune;          /* VP_PLAN_AUTOTUNE: the first vp_prove_gkr of a circuit replays the launch plan in the few layouts that fuse_combine,
                                        fold_branches and plan_align offer, then with fuse_min_log one step either way and with sf3b_grid 384 / 320, and
                                        keeps the fastest for this circuit (one-off: a plan, a graph capture and six replays per candidate; a candidate
-                                       that does not build is skipped; the transcript does not depend on the choice).  The fields named here are then
-                                       OVERWRITTEN by the tuner; 0: they are taken as given.  Not used for sharded proofs            [1] */
+                                       that does not build is skipped; the transcript does not depend on the choice).  A field named here that the
+                                       caller (struct or environment) moved off its default is taken as given, the tuner only chooses among the
+                                       others; 0: all of them are taken as given.  Not used for sharded proofs                       [1] */
     int32_t pc_tensor_pub;          /* VP_PC_TENSOR: vp_commit_public checks (exactly, on the device) whether the public vector is a tensor — every
                                        slice a scalar multiple of slice 0, which the protocol's own vector eq(r, .) always is — and then encodes ONE
                                        slice instead of 64 (q_i = c_i q_0 formed where it is consumed): same field elements, a third fewer
                                        transforms per commitment.  0: always encode all 64 slices                                    [1] */
+    int32_t persistent_timeout_ms;  /* VP_PERSIST_TIMEOUT_MS: how long the resident round kernel waits for the verifier's next message before it saves
+                                       its phase and leaves the CU; the next vp_round / vp_finalize relaunches it on the saved phase              [10000] */
 } vp_options;
 void vp_options_default(vp_options *opt);
 
 /* ---- life cycle ---------------------------------------------------------------------------------- */
 int vp_create(int device, vp_ctx **out);                                 /* = vp_create_with_options(device, NULL, out) */
 int vp_create_with_options(int device, const vp_options *opt, vp_ctx **out);
+int vp_get_options(const vp_ctx *, vp_options *out);                   /* the configuration in effect: defaults <- struct <- environment, and after the
+                                                                           first vp_prove_gkr of a circuit what plan_autotune kept; out->struct_size (set by
+                                                                           the caller) bounds the bytes written */
 void vp_destroy(vp_ctx *);
 const char *vp_last_error(const vp_ctx *);     /* static/ctx-owned string, never NULL */
 const char *vp_version(void);
@@ -157,10 +163,13 @@ int vp_vres(vp_ctx *, const vp_F *r_0, int r_0_size, vp_F *out);
  *     first vp_round of the phase;
  *   * once every live table of the phase fits one CU's LDS, ONE resident kernel answers all remaining messages of the phase
  *     through a mailbox in pinned host memory (`persistent_rounds`): vp_round then costs a 3 us round trip plus the arithmetic
- *     instead of a kernel launch.  vp_finalize ends it.  Any other entry point called in the middle of a sumcheck first tells
- *     the resident kernel to leave (the sumcheck is abandoned, the context stays usable); left alone it leaves by itself 10 s
- *     after the last message, and the next vp_round / vp_finalize then returns VP_EHIP.  While it is resident, device-wide
- *     synchronising HIP calls of other contexts of the process (hipFree, hipMalloc) wait for it.
+ *     instead of a kernel launch.  vp_finalize ends it.  Any other entry point called ON THE SAME CONTEXT in the middle of a sumcheck
+ *     first tells the resident kernel to leave (the sumcheck is abandoned, the context stays usable).  It never stands in anybody's way
+ *     for long (round 3): an entry point called on ANOTHER context of the process suspends it — the phase (LDS tables, lengths, round
+ *     counter, add_term) is saved to device memory, the CU is released, device-wide synchronising HIP calls of that other context
+ *     (hipMalloc / hipFree of an upload or a destroy) proceed at once — and left alone for persistent_timeout_ms it suspends itself the
+ *     same way; this context's next vp_round / vp_finalize relaunches it on the saved phase and the sumcheck continues (bit-identical
+ *     transcript).  Contexts of one process are driven from one thread, or the caller serialises its calls.
  * prover::sumcheckInitPhase1(assert_random) for layer `layer` (src/prover.cpp:189-280).  r_liu is the
  * point the layer's claim is at (bit_length(layer) entries; prover::r_liu in the reference).           */
 int vp_phase1_init(vp_ctx *, int layer, const vp_F *r_liu, const vp_F *assert_random);

@@ -44,6 +44,22 @@ def pws_path(tmp_path_factory):
     return str(p)
 
 
+_GPU_COUNT = None
+
+
+def gpu_count():
+    """GPUs of this box, counted in a CHILD process: importing torch into a process that already holds libvpgpu.so (and with it /opt/rocm's HIP
+    runtime) would load PyTorch's own bundled ROCm libraries beside them — two HIP runtimes, two rocm_smi copies whose same-named globals are
+    destroyed twice at exit."""
+    global _GPU_COUNT
+    if _GPU_COUNT is None:
+        import subprocess
+        r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], stdout=subprocess.PIPE,
+                           stderr=subprocess.DEVNULL, text=True, timeout=600)
+        _GPU_COUNT = int(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else 0
+    return _GPU_COUNT
+
+
 def gkr_slice(golden, name):
     g = golden[name]
     data = open(os.path.join(GOLDEN, g["transcript"]), "rb").read()

@@ -1065,6 +1065,88 @@ def test_interactive_path_variants(vp, golden, gold_gkr, pws_path, monkeypatch, 
     s.close(); c.close()
 
 
+def _drive_phase1(vp, h, c, disturb_at=None, disturb=None):
+    """Phase 1 of the top layer of `c`, message by message through the C ABI, with fixed challenges: Vres, every round polynomial, the claim."""
+    lib = vp.lib_gpu()
+    lib.vp_vres.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    lib.vp_phase1_init.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    lib.vp_round.argtypes = [ctypes.c_void_p] * 3
+    lib.vp_finalize.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int]
+    top = c.layers - 1
+    bl_top, bl_pre = c.layer_bitlen(top), c.layer_bitlen(top - 1)
+    rng = np.random.default_rng(12)
+    r0 = rng.integers(0, P, size=(max(bl_top, 1), 2), dtype=np.uint64)
+    ar = rng.integers(0, P, size=(1, 2), dtype=np.uint64)
+    ru = rng.integers(0, P, size=(bl_pre, 2), dtype=np.uint64)
+    out = np.zeros((1, 2), dtype=np.uint64)
+    assert lib.vp_vres(h, r0.ctypes.data, bl_top, out.ctypes.data) == 0
+    msgs = [out.tobytes()]
+    assert lib.vp_phase1_init(h, top, r0.ctypes.data, ar.ctypes.data) == 0
+    prev = np.zeros((1, 2), dtype=np.uint64)
+    poly = np.zeros((3, 2), dtype=np.uint64)
+    for j in range(bl_pre):
+        if disturb_at == j:
+            disturb()
+        rc = lib.vp_round(h, prev.ctypes.data, poly.ctypes.data)
+        assert rc == 0, (j, lib.vp_last_error(h))
+        msgs.append(poly.tobytes())
+        prev = ru[j:j + 1].copy()
+    if disturb_at == bl_pre:
+        disturb()
+    claim = np.zeros((1, 2), dtype=np.uint64)
+    assert lib.vp_finalize(h, prev.ctypes.data, claim.ctypes.data, 1) == 0, lib.vp_last_error(h)
+    msgs.append(claim.tobytes())
+    return b"".join(msgs)
+
+
+@pytest.mark.parametrize("where", [0, 1, 4, 9, 10])
+def test_resident_kernel_yields_to_another_context_and_resumes(vp, where):
+    """One process, two contexts (the shape the sharded tests and any multi-prover host have): context A is in the middle of a sumcheck, its
+    resident round kernel waiting for the next challenge, when context B is created, uploads a circuit, proves and is destroyed — hipMalloc /
+    hipFree, device-wide synchronising calls that used to wait behind A's kernel until its 10 s time-out, after which A's phase was lost.
+    Now B's entry points suspend A's kernel (phase saved to device memory), B proceeds at once, and A's next vp_round / vp_finalize
+    relaunches the kernel on the saved phase: A's messages are bit-identical to an undisturbed run, wherever the interruption falls —
+    before the first vp_round (round 1 already answered behind the init call), mid-phase, before the last round, before finalize."""
+    import time
+    c = vp.Circuit.randomize(3, 10, seed=21)
+    s = vp.Session(c)
+    h = s.gpu_ctx()
+    undisturbed = _drive_phase1(vp, h, c)
+    took = []
+
+    def other_context():
+        t0 = time.perf_counter()
+        c2 = vp.Circuit.randomize(4, 9, seed=5)
+        s2 = vp.Session(c2)                      # vp_create + vp_circuit_upload (hipMalloc) + vp_evaluate on a SECOND context
+        s2.draw_tape()
+        tr, _ = s2.prove_gkr()
+        tr_i, _, ok = s2.prove_interactive()     # B runs its own resident kernels meanwhile
+        assert ok and tr_i == tr
+        s2.close(); c2.close()                   # vp_destroy: hipFree
+        took.append(time.perf_counter() - t0)
+
+    disturbed = _drive_phase1(vp, h, c, disturb_at=where, disturb=other_context)
+    assert disturbed == undisturbed
+    assert took and took[0] < 5.0, "the other context waited %.1f s behind the resident kernel" % took[0]
+    again = _drive_phase1(vp, h, c)              # and the context is as good as new
+    assert again == undisturbed
+    s.close(); c.close()
+
+
+def test_resident_kernel_times_out_saves_its_phase_and_resumes(vp):
+    """A verifier that falls silent (debugger, SIGSTOP, a loaded host) for longer than persistent_timeout_ms: the resident kernel saves its
+    phase and releases the CU by itself; when the verifier comes back the phase continues — it used to be lost (VP_EHIP)."""
+    import time
+    c = vp.Circuit.randomize(3, 10, seed=22)
+    s_ref = vp.Session(c)
+    undisturbed = _drive_phase1(vp, s_ref.gpu_ctx(), c)
+    s_ref.close()
+    s = vp.Session(c, options=vp.Options(persistent_timeout_ms=150))
+    for where in (2, 10):
+        assert _drive_phase1(vp, s.gpu_ctx(), c, disturb_at=where, disturb=lambda: time.sleep(0.6)) == undisturbed
+    s.close(); c.close()
+
+
 def test_abandoned_sumcheck_releases_the_resident_kernel(vp, gold_gkr):
     """A caller that stops in the middle of a sumcheck (the resident round kernel is waiting for the next challenge) and calls any
     other entry point: the kernel is told to leave first, nothing hangs, and the context proves correctly afterwards."""
@@ -1144,6 +1226,14 @@ def test_options_struct_selects_the_same_alternatives_as_the_test_environment(vp
     s = vp.Session(c, options=vp.Options(persistent_rounds=0))
     tr_i, _, ok = s.prove_interactive()
     assert ok and tr_i == gold
+    s.close()
+    # the plan tuner (on by default) chooses only among the fields the caller left at their defaults: what was set explicitly is still in
+    # effect after the first proof (vp_get_options), whatever else the tuner picked
+    s = vp.Session(c, options=vp.Options(fuse_combine=1, sf3b_grid=448, fuse_min_log=21))
+    s.draw_tape()
+    tr, _ = s.prove_gkr()
+    eff = s.options_in_effect()
+    assert tr == gold and eff.plan_autotune == 1 and (eff.fuse_combine, eff.sf3b_grid, eff.fuse_min_log) == (1, 448, 21)
     s.close()
     # a caller built against an older header passes a shorter struct: the fields it does not know keep the library's defaults
     old = vp.Options(gkr_path=vp.PATH_SIMPLE, sf_rounds=4)
@@ -1249,13 +1339,49 @@ def test_two_processes_share_a_sharded_proof_and_commitment_host_transport(vp):
     assert "RANK 0 OK" in r.stdout and "RANK 1 OK" in r.stdout
 
 
+_EXIT_WORKER = r"""
+import ctypes, os, sys
+sys.path.insert(0, %r)
+order = sys.argv[1]
+if order == "torch_first":
+    import torch
+    torch.cuda.device_count()
+import vp_loader
+vp = vp_loader.load()
+L = vp.lib_gpu()
+ctx = ctypes.c_void_p()
+assert L.vp_create(0, ctypes.byref(ctx)) == 0
+uid = ctypes.create_string_buffer(128)
+assert L.vp_comm_unique_id(ctypes.cast(uid, ctypes.c_void_p)) == 0
+assert L.vp_comm_init(ctx, ctypes.cast(uid, ctypes.c_void_p), 0, 1) == 0, L.vp_last_error(ctx)
+n = ctypes.c_int(0)
+assert L.vp_comm_count(ctx, ctypes.byref(n)) == 0 and n.value == 1
+if order == "library_first":
+    import torch
+    torch.cuda.device_count()
+L.vp_destroy(ctx)
+print("DONE", order, flush=True)
+"""
+
+
+@pytest.mark.parametrize("order", ["torch_first", "library_first"])
+def test_process_with_pytorch_and_the_librarys_rccl_exits_cleanly(vp, order):
+    """bench.py's ranks import torch and then attach the library's RCCL communicator; a test process may do it the other way round.  Either
+    way the process has to END with status 0 (a rank that aborts in a library destructor after printing its line still fails the job):
+    torch first = one ROCm stack shared under the same sonames; library first = two stacks, ours outside the global symbol scope."""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, "-c", _EXIT_WORKER % ROOT, order], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert "DONE " + order in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+    assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
+
+
 def test_two_gpus_rccl_sharded_proof_and_commitment(vp):
     """The same over RCCL / xGMI with one GPU per rank: the transcript all-reduce (also of an index-split proof's export area) and the
     commitment's collectives are RCCL calls on device buffers inside the C ABI (vp_comm_init).  Needs two GPUs: skipped on the builder's
     one-GPU box, run wherever the suite finds them."""
-    import torch
-    if torch.cuda.device_count() < 2:
-        pytest.skip("needs 2 GPUs (this box has %d)" % torch.cuda.device_count())
+    from conftest import gpu_count
+    if gpu_count() < 2:
+        pytest.skip("needs 2 GPUs (this box has %d)" % gpu_count())
     r = _run_ranks(2, "rccl", 64)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     assert "RANK 0 OK" in r.stdout and "RANK 1 OK" in r.stdout

@@ -107,6 +107,7 @@ def lib_gpu():
         vp = ctypes.c_void_p
         L.vp_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
         L.vp_create_with_options.argtypes = [ctypes.c_int, vp, ctypes.POINTER(vp)]
+        L.vp_get_options.argtypes = [vp, vp]
         L.vp_set_shard_split.argtypes = [vp, ctypes.c_int]
         L.vp_shard_finish.argtypes = [vp, vp, ctypes.c_uint64, vp]
         L.vp_gkr_sizes.argtypes = [vp, vp, vp]
@@ -515,7 +516,7 @@ class Options(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_uint32)] + [(n, ctypes.c_int32) for n in (
         "gkr_path", "use_graph", "serial", "fuse_init", "fuse_min_log", "fuse_dot", "init3", "drop_y", "drop_y_round1", "real_values",
         "seg_tiny", "sf_rounds", "sf_big_log", "sf3b", "sf3b_grid", "sf_min_waves", "dot_blocks", "plan_align", "xcd_map",
-        "round_fused_max", "persistent_rounds", "persistent_multi", "persistent_multi_shift", "poll", "debug", "prefetch_round1", "split_cost_percent", "kernel_copies", "fold_branches", "ntt_scatter", "fuse_combine", "plan_autotune", "pc_tensor_pub")]
+        "round_fused_max", "persistent_rounds", "persistent_multi", "persistent_multi_shift", "poll", "debug", "prefetch_round1", "split_cost_percent", "kernel_copies", "fold_branches", "ntt_scatter", "fuse_combine", "plan_autotune", "pc_tensor_pub", "persistent_timeout_ms")]
 
     def __init__(self, **kw):
         super().__init__()
@@ -627,6 +628,14 @@ class Session:
     def commit_device_ms(self):
         """Device milliseconds (HIP events) of the last commit_private / commit_public / fri_commit call."""
         return float(lib_host().vph_commit_device_ms(self.h))
+
+    def options_in_effect(self):
+        """vp_get_options: the configuration this session runs with (after the plan tuner, once a proof has run)."""
+        o = Options()
+        ctx = lib_host().vph_session_ctx(self.h)
+        if lib_gpu().vp_get_options(ctx, ctypes.byref(o)):
+            raise RuntimeError("vp_get_options failed")
+        return o
 
     def set_shard(self, rank, world):
         """One proof over `world` GPUs: prove_gkr() then runs only the sumcheck chains dealt to `rank` and leaves the rest of the

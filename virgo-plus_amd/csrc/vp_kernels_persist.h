@@ -82,6 +82,13 @@ struct PTailArgs {
     F *hand[3];                   // hand-over copy of the table the LAST distributed round writes (<= 4096 entries per family): addresses
                                   // workgroup 0 has not read earlier in this launch, so its XCD's L2 cannot hold stale lines of them
     MultiSync *sync; unsigned long long arrive0;     // counter value before the launch
+    // Suspend / resume (round 3).  A resident kernel that is told to leave in the middle of a phase (another context of the process needs
+    // the device for a synchronising call) or that waited longer than `timeout_ticks` for the verifier saves the phase — the LDS tables of
+    // the current level, their lengths, the round counter, add_term and the polynomial answered last — into `save` ([3][cap] entries, then
+    // a header) and leaves with status 5; the next vp_round / vp_finalize relaunches it with resume = 1 and the sumcheck continues where it
+    // was.  Solo regime only (the distributed regime, off by default, still gives up with status 2).
+    F *save; int resume;
+    unsigned long long timeout_ticks;                // s_memrealtime ticks (100 MHz) without a message before the kernel leaves
 };
 
 // ---- small helpers ----------------------------------------------------------------------------------------------------
@@ -110,7 +117,7 @@ __device__ __forceinline__ int tail_poll(const PTailArgs &a, unsigned long long 
         const unsigned long long w1 = __hip_atomic_load(&a.req->w[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         const unsigned long long w2 = __hip_atomic_load(&a.req->w[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if ((w0 & (7ull << 61)) == tag && (w1 & (7ull << 61)) == tag && (w2 & (7ull << 61)) == tag) { r = f_make(VP_UNTAG(w0), VP_UNTAG(w1)); return (int) VP_UNTAG(w2); }
-        if (__builtin_amdgcn_s_memrealtime() - t0 > VP_PH_TIMEOUT_TICKS) return -1;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) return -1;
         __builtin_amdgcn_s_sleep(1);
     }
 }
@@ -129,7 +136,8 @@ __device__ __forceinline__ void tail_reply(const PTailArgs &a, unsigned long lon
 // leaving: status 0 ok (finalize done), 1 quit acknowledged, 2 timed out, 3 protocol error, 4 a workgroup did not arrive
 __device__ __forceinline__ void tail_leave(const PTailArgs &a, unsigned long long seq, int cmd, unsigned long long status) {
     __threadfence_system();                                   // claims (finalize) and add_term are out before the reply
-    if (cmd == -1 || status == 4) __hip_atomic_store(&a.rep->dead, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // dead: the kernel has left on its own.  1 = gave up (not resumable), 2 = timed out with the phase saved (the host relaunches it)
+    if (cmd == -1 || status == 4) __hip_atomic_store(&a.rep->dead, (cmd == -1 && status == 5) ? 2ull : 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     tail_reply_words(a, seq, f_zero(), f_zero(), f_zero(), status);
 }
 
@@ -153,7 +161,7 @@ __global__ void __launch_bounds__(VP_PH_THREADS) k_phase(PTailArgs a) {
     int k = a.k0;                                                  // round answered last (after the first round below)
 
     // ======================= distributed rounds: k = 1 .. kc-1 on G workgroups ==========================================
-    if (a.G > 1) {
+    if (a.G > 1 && !a.resume) {
         const u32 g = blockIdx.x, G = (u32) a.G;
         unsigned long long arrive = a.arrive0;
         for (k = 1; k < a.kc; ++k) {
@@ -293,8 +301,16 @@ __global__ void __launch_bounds__(VP_PH_THREADS) k_phase(PTailArgs a) {
     F *LV = L, *LM = L + cap, *LA = L + 2 * (size_t) cap;
     const int role = __builtin_amdgcn_readfirstlane(w % 3);
     const u32 pslot = (u32) ((w / 3) * 64 + lane);
+    F *const hdr = a.save + 3 * (size_t) cap;                        // saved phase: hdr[0].re = k, hdr[1] = add_term, hdr[2..4] = last polynomial, hdr[5 + j].re = s_len[j]
+    if (a.resume) {
+        for (u32 i = tid; i < 3 * cap; i += blockDim.x) L[i] = a.save[i];
+        if (tid < a.n_tab) s_len[tid] = (u32) hdr[5 + tid].re;
+        if (boss) at = hdr[1];
+        k = (int) hdr[0].re;
+        expect = a.seq0 - 1;                                        // the loop below waits for message seq0
+    }
     // ---- first solo round: sources in global memory, folded tables into LDS (plain one-thread-per-pair form) ----
-    {
+    if (!a.resume) {
         const bool multi = a.G > 1;
         F r;
         int n_tab, fold;
@@ -399,7 +415,10 @@ __global__ void __launch_bounds__(VP_PH_THREADS) k_phase(PTailArgs a) {
     // trip (reply over PCIe, the verifier's round, request back over PCIe: ~14 800 clocks = 7 us), so a resident round now costs that round
     // trip plus the reply chain: 10.2 -> 9.2 us per vp_round at x64 (with the three mailbox words polled in one go).
     F pp0 = f_zero(), pp1 = f_zero(), pp2 = f_zero();              // boss: the polynomial answered last
-    if (boss) { pp0 = a.poly_dev[0]; pp1 = a.poly_dev[1]; pp2 = a.poly_dev[2]; }        // written by tail_reply a few lines up (same lane)
+    if (boss) {
+        if (a.resume) { pp0 = hdr[2]; pp1 = hdr[3]; pp2 = hdr[4]; }
+        else { pp0 = a.poly_dev[0]; pp1 = a.poly_dev[1]; pp2 = a.poly_dev[2]; }          // written by tail_reply a few lines up (same lane)
+    }
     const int role2 = __builtin_amdgcn_readfirstlane(w & 1);
     const u32 qslot = (u32) ((w >> 1) * 64 + lane);
     for (;;) {
@@ -506,9 +525,17 @@ __global__ void __launch_bounds__(VP_PH_THREADS) k_phase(PTailArgs a) {
             a.claims_host[tid] = c;
             if (a.Vu && tid == 0) *a.Vu = c;
         }
+        // quit (another entry point needs the device) or time-out in the middle of the phase: save it, so that the next vp_round /
+        // vp_finalize can continue (status 5).  The tables in LDS are those of the current level, k rounds are answered.
+        const bool suspend = (cmd == 3 || cmd == -1) && a.save != nullptr;
+        if (suspend) {
+            for (u32 i = tid; i < 3 * cap; i += blockDim.x) a.save[i] = L[i];
+            if (tid < a.n_tab) hdr[5 + tid] = f_make(s_len[tid], 0);
+            if (boss) { hdr[0] = f_make((u64) k, 0); hdr[1] = at; hdr[2] = pp0; hdr[3] = pp1; hdr[4] = pp2; }
+        }
         __threadfence_system();
         __syncthreads();
-        if (boss) { *a.add_term = at; tail_leave(a, expect, cmd, cmd == 2 ? 0 : cmd == 3 ? 1 : cmd == -1 ? 2 : 3); }
+        if (boss) { *a.add_term = at; tail_leave(a, expect, cmd, cmd == 2 ? 0 : suspend ? 5 : cmd == 3 ? 1 : cmd == -1 ? 2 : 3); }
         return;
     }
 }

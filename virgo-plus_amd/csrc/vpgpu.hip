@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -128,12 +129,17 @@ struct vp_ctx {
     unsigned long long *h_seq = nullptr, seq = 0;     // pinned ticket the closing kernels of the per-round path publish
     // persistent round kernel of the interactive path (vp_kernels_persist.h): mailbox in pinned host memory
     TailMail *h_req = nullptr; TailReply *h_rep = nullptr; bool tail_active = false; unsigned long long tail_seq = 0; int tail_enabled = 1;
+    // suspend / resume of the resident round kernel (vp_kernels_persist.h): its last launch arguments, the device buffer it saves a phase
+    // into, and whether such a saved phase is waiting for the next vp_round / vp_finalize
+    PTailArgs tail_args{}; F *tail_save = nullptr; bool tail_suspended = false, tail_lost = false; u64 tail_resumes = 0;
     TailAux *h_aux = nullptr;            // pinned: per-table data of the resident kernel's launch
     F *d_hand = nullptr;                 // hand-over buffers of the distributed -> solo switch (3 x 4096 entries)
     MultiSync *d_msync = nullptr; int multi_enabled = 0;      // VP_PERSIST=0: one launch per round; VP_PERSIST_MULTI=0: no distributed rounds
     int poll = 1;                                     // VP_POLL=0: wait with hipStreamSynchronize instead
     F *h_io = nullptr; size_t h_io_cap = 0;   // pinned staging of the batched path: tape in, transcript out
-    int r1_pending = 0;                // interactive path: round 1 of the phase was queued behind its init (1: in the resident kernel, 2: per-round launch)
+    int r1_pending = 0;                // interactive path: round 1 of the phase was queued behind its init (1: in the resident kernel, 2: per-round launch,
+                                       // 3: collected into r1_stash when the resident kernel was suspended before the first vp_round)
+    vp_F r1_stash[3];
     F *h_stage = nullptr; u32 stage_at = 0;         // pinned ring the challenges are staged through (an init call no longer waits for its copies)
     vp_options opt{};                  // resolved at vp_create: defaults <- caller's struct <- VP_* environment (test-only override)
     int *d_flag = nullptr;
@@ -185,6 +191,8 @@ struct vp_ctx {
     Plan *plan = nullptr; int plan_path = 1;   // VP_GKR_PATH=lanes: one stream per sumcheck chain instead of the plan
     // hipGraph of the concurrent GKR submission (per circuit; VP_GKR_GRAPH=0 submits the launches directly)
     bool plan_tuned = false;         // the plan layouts have been tried on this circuit (plan_autotune)
+    uint32_t opt_pinned = 0;         // tuner fields the caller (struct or environment) moved off their defaults: bit 0 fuse_combine, 1 fold_branches,
+                                     // 2 plan_align, 3 fuse_min_log, 4 sf3b_grid — plan_autotune leaves those alone
     hipGraphExec_t gkr_graph = nullptr; int use_graph = 1; bool graph_failed = false; u64 graph_launches = 0, graph_rounds = 0;
     // one proof sharded over GPUs by sumcheck chain (vp_set_shard): this rank records and runs only the chains it owns
     int shard_rank = 0, shard_world = 1;
@@ -225,7 +233,10 @@ namespace {
 // every entry point except vp_round / vp_finalize: select the device and, if the persistent round kernel of the interactive path is
 // still resident (the caller abandoned a sumcheck), tell it to leave — work submitted to the stream would otherwise queue behind it
 int tail_quit(vp_ctx *ctx);
-#define VP_ENTER(ctx) do { HIPCHK(hipSetDevice((ctx)->device)); if ((ctx)->tail_active) (void) tail_quit(ctx); } while (0)
+// ... and the resident kernels of the OTHER contexts of this process are suspended (phase saved, resumed by their next vp_round): device-wide
+// synchronising HIP calls — hipMalloc / hipFree of an upload, a destroy — would otherwise wait behind them for up to their time-out.
+void vp_suspend_others(vp_ctx *ctx);
+#define VP_ENTER(ctx) do { HIPCHK(hipSetDevice((ctx)->device)); if ((ctx)->tail_active) (void) tail_quit(ctx); (ctx)->tail_suspended = false; (ctx)->tail_lost = false; vp_suspend_others(ctx); } while (0)
 
 constexpr u32 MAX_BLOCKS = 2048;     // 256 CUs x 8 resident 256-thread blocks
 
@@ -471,6 +482,7 @@ int check_stream(vp_ctx *ctx) {
 }
 
 // ---- persistent round kernel (vp_kernels_persist.h): host side of the mailbox ---------------------------------------
+constexpr int VP_TAIL_SAVED = 1000;                           // internal: the kernel left with its phase saved (status 5)
 int tail_wait(vp_ctx *ctx, unsigned long long want) {       // every reply word must carry the tag of message `want` (vp_kernels_persist.h)
     const auto t0 = std::chrono::steady_clock::now();
     const unsigned long long tag = VP_TAG(want), mask = 7ull << 61;
@@ -479,7 +491,10 @@ int tail_wait(vp_ctx *ctx, unsigned long long want) {       // every reply word 
         for (int q = 0; q < 7; ++q) all &= (__atomic_load_n(&ctx->h_rep->w[q], __ATOMIC_RELAXED) & mask) == tag;
         if (all) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return VP_OK; }
         if ((spin & 0xfff) == 0xfff) {
-            if (__atomic_load_n(&ctx->h_rep->dead, __ATOMIC_ACQUIRE)) { ctx->tail_active = false; ctx->err = "persistent round kernel gave up waiting (no verifier message for 10 s, or a workgroup was not scheduled)"; return VP_EHIP; }
+            if (__atomic_load_n(&ctx->h_rep->dead, __ATOMIC_ACQUIRE)) {
+                if (__atomic_load_n(&ctx->h_rep->dead, __ATOMIC_ACQUIRE) == 2) return VP_TAIL_SAVED;     // timed out with the phase saved: the caller relaunches it
+                ctx->tail_active = false; ctx->err = "persistent round kernel gave up waiting (a workgroup was not scheduled, or the distributed regime timed out)"; return VP_EHIP;
+            }
             if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(15)) { ctx->tail_active = false; ctx->err = "persistent round kernel did not answer"; return VP_EHIP; }
         }
     }
@@ -499,11 +514,53 @@ static inline void tail_poly(const vp_ctx *ctx, vp_F out[3]) {
 // leave the persistent kernel (a call other than vp_round / vp_finalize arrived while it was resident)
 int tail_quit(vp_ctx *ctx) {
     if (!ctx->tail_active) return VP_OK;
-    const int rc = tail_send(ctx, 3, f_zero());
+    int rc = tail_send(ctx, 3, f_zero());
+    if (rc == VP_TAIL_SAVED) rc = VP_OK;                      // it had already left by itself
     ctx->tail_active = false;
     (void) hipStreamSynchronize(ctx->stream);
     return rc;
 }
+// Another context needs the device: the resident kernel saves its phase and leaves; this context's next vp_round / vp_finalize resumes it.
+int tail_suspend(vp_ctx *ctx) {
+    if (!ctx->tail_active) return VP_OK;
+    if (ctx->r1_pending == 1) {                               // round 1 was answered behind the init call and not collected yet: the quit's reply would overwrite it
+        if (tail_wait(ctx, ctx->tail_seq) == VP_OK) { tail_poly(ctx, ctx->r1_stash); ctx->r1_pending = 3; ++ctx->sc.round; ++ctx->st.rounds; }
+    }
+    int rc = tail_send(ctx, 3, f_zero());
+    if (rc == VP_TAIL_SAVED) rc = VP_OK;
+    ctx->tail_active = false;
+    ctx->tail_suspended = rc == VP_OK && tail_status(ctx) == 5;
+    ctx->tail_lost = !ctx->tail_suspended;                    // left without saving (distributed regime): the phase cannot be continued
+    (void) hipStreamSynchronize(ctx->stream);
+    return rc;
+}
+// Relaunch the resident kernel on the phase it saved.  already_sent: the message the kernel is to answer next is already in the mailbox
+// (the host sent it while the kernel was timing out) and carries ctx->tail_seq; otherwise the next tail_send will carry tail_seq + 1.
+int tail_resume(vp_ctx *ctx, bool already_sent) {
+    PTailArgs a = ctx->tail_args;
+    a.resume = 1; a.G = 1;
+    a.seq0 = already_sent ? ctx->tail_seq : ctx->tail_seq + 1;
+    // the reply words still carry the leaving kernel's message with the tag the relaunched kernel will answer under: give them another one
+    if (already_sent) for (int q = 0; q < 7; ++q) __atomic_store_n(&ctx->h_rep->w[q], VP_TAG(ctx->tail_seq + 1), __ATOMIC_RELAXED);
+    __atomic_store_n(&ctx->h_rep->dead, 0ull, __ATOMIC_RELEASE);
+    hipLaunchKernelGGL(k_phase, dim3(1), dim3(VP_PH_THREADS), (size_t) 3 * a.cap * sizeof(F), ctx->stream, a);
+    { const hipError_t e = hipGetLastError(); if (e != hipSuccess) { ctx->err = std::string("k_phase relaunch failed: ") + hipGetErrorString(e); return VP_EHIP; } }
+    count_launch(ctx);
+    ctx->tail_active = true; ctx->tail_suspended = false; ++ctx->tail_resumes;
+    return VP_OK;
+}
+// every live context of the process (vp_create .. vp_destroy).  Contexts are driven from one thread (the reference is single-threaded), or the
+// caller serialises its calls: the registry is locked, the mailboxes are not.
+static std::mutex g_ctx_mu;
+static std::vector<vp_ctx *> g_ctxs;
+void vp_suspend_others(vp_ctx *ctx) {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    bool any = false;
+    for (vp_ctx *o : g_ctxs)
+        if (o != ctx && o->tail_active) { (void) hipSetDevice(o->device); (void) tail_suspend(o); any = true; }
+    if (any) (void) hipSetDevice(ctx->device);
+}
+
 // Round k = s.round + 1 with previous challenge rv: if every live table of the phase now fits one CU, launch k_phase for this
 // and all later messages of the phase.  Returns 1 when launched (the polynomial of round k is then in h_rep), 0 when not.
 int tail_try_launch(vp_ctx *ctx, const F &rv) {
@@ -535,6 +592,8 @@ int tail_try_launch(vp_ctx *ctx, const F &rv) {
         a.Vu = s.phase == 1 ? ctx->Vu() : nullptr;
         a.req = ctx->h_req; a.rep = ctx->h_rep; a.claims_host = ctx->h_pin + 4;
         a.seq0 = ++ctx->tail_seq; ctx->h_rep->dead = 0;
+        a.save = ctx->tail_save; a.resume = 0; a.timeout_ticks = (unsigned long long) std::max(1, ctx->opt.persistent_timeout_ms) * 100000ull;
+        ctx->tail_args = a;
         hipLaunchKernelGGL(k_phase, dim3(G), dim3(VP_PH_THREADS), (size_t) 3 * a.cap * sizeof(F), ctx->stream, a);
         { const hipError_t e = hipGetLastError(); if (e != hipSuccess) { if ((ctx->opt.debug & 1)) fprintf(stderr, "[vp] k_phase (G=%d) launch failed: %s\n", G, hipGetErrorString(e)); --ctx->tail_seq; return 0; } }
         count_launch(ctx);
@@ -570,6 +629,8 @@ int tail_try_launch(vp_ctx *ctx, const F &rv) {
     a.Vu = s.phase == 1 ? ctx->Vu() : nullptr;
     a.req = ctx->h_req; a.rep = ctx->h_rep; a.claims_host = ctx->h_pin + 4;
     a.seq0 = ++ctx->tail_seq; ctx->h_rep->dead = 0;
+    a.save = ctx->tail_save; a.resume = 0; a.timeout_ticks = (unsigned long long) std::max(1, ctx->opt.persistent_timeout_ms) * 100000ull;
+    ctx->tail_args = a;
     hipLaunchKernelGGL(k_phase, dim3(1), dim3(VP_PH_THREADS), (size_t) 3 * ents * sizeof(F), ctx->stream, a);
     { const hipError_t e = hipGetLastError(); if (e != hipSuccess) { if ((ctx->opt.debug & 1)) fprintf(stderr, "[vp] k_phase launch failed: %s\n", hipGetErrorString(e)); --ctx->tail_seq; return 0; } }
     count_launch(ctx);
@@ -619,9 +680,10 @@ void vp_options_default(vp_options *o) {
     o->sf3b_grid = 512; o->sf_min_waves = 1; o->dot_blocks = 1024; o->plan_align = 0; o->xcd_map = 0; o->round_fused_max = 512;
     o->persistent_rounds = 1; o->persistent_multi = 0; o->persistent_multi_shift = 13; o->poll = 1; o->debug = 0; o->prefetch_round1 = 1; o->split_cost_percent = 50; o->kernel_copies = 1; o->fold_branches = 1; o->ntt_scatter = 1; o->fuse_combine = 2; o->plan_autotune = 1;
     o->pc_tensor_pub = 1;
+    o->persistent_timeout_ms = 10000;
 }
 // defaults <- the caller's struct (as many bytes as its header knew) <- VP_* environment variables (test-only override, read here and nowhere else)
-static void resolve_options(vp_options *o, const vp_options *user) {
+static void resolve_options(vp_options *o, const vp_options *user, uint32_t *pinned) {
     vp_options_default(o);
     if (user && user->struct_size >= sizeof(uint32_t)) {
         memcpy(o, user, std::min<size_t>(user->struct_size, sizeof *o));
@@ -644,15 +706,26 @@ static void resolve_options(vp_options *o, const vp_options *user) {
     flag("VP_FOLD_BRANCHES", o->fold_branches);
     flag("VP_NTT_SCATTER", o->ntt_scatter);
     flag("VP_PC_TENSOR", o->pc_tensor_pub);
+    num("VP_PERSIST_TIMEOUT_MS", o->persistent_timeout_ms);
     num("VP_FUSE_COMBINE", o->fuse_combine);
     flag("VP_PLAN_AUTOTUNE", o->plan_autotune);
     if (getenv("VP_DEBUG")) o->debug |= 1;
     if (getenv("VP_DEBUG_UPLOAD")) o->debug |= 2;                       // bit 1: phase times of vp_circuit_upload
     if (o->sf_rounds != 4) o->sf_rounds = 3;
     o->dot_blocks = std::max(1, o->dot_blocks); o->sf3b_grid = std::max(1, o->sf3b_grid);
+    vp_options d; vp_options_default(&d);
+    *pinned = (o->fuse_combine != d.fuse_combine ? 1u : 0u) | (o->fold_branches != d.fold_branches ? 2u : 0u) | (o->plan_align != d.plan_align ? 4u : 0u) |
+              (o->fuse_min_log != d.fuse_min_log ? 8u : 0u) | (o->sf3b_grid != d.sf3b_grid ? 16u : 0u);
 }
 
 int vp_create(int device, vp_ctx **out) { return vp_create_with_options(device, nullptr, out); }
+int vp_get_options(const vp_ctx *ctx, vp_options *out) {
+    if (!ctx || !out || out->struct_size < sizeof(uint32_t)) return VP_EINVAL;
+    const uint32_t n = std::min<uint32_t>(out->struct_size, (uint32_t) sizeof ctx->opt);
+    memcpy(out, &ctx->opt, n);
+    out->struct_size = n;
+    return VP_OK;
+}
 
 // The caller's glibc random() / rand() stream is not ours to consume: the reference verifier draws every challenge and every query position
 // from it (lib/virgo/src/fieldElement.cpp:119-124,362-367, vpd_verifier.cpp:121), and the ROCm runtime takes draws from the same process-wide
@@ -674,7 +747,7 @@ int vp_create_with_options(int device, const vp_options *user, vp_ctx **out) {
     if (hipSetDevice(device) != hipSuccess) return VP_ENOGPU;
     vp_ctx *ctx = new vp_ctx();
     ctx->device = device;
-    resolve_options(&ctx->opt, user);
+    resolve_options(&ctx->opt, user, &ctx->opt_pinned);
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return VP_EHIP; }
     if (hipHostMalloc((void **) &ctx->h_pin, (4 + VP_MAX_TAB) * sizeof(F), hipHostMallocDefault) != hipSuccess) {
         delete ctx; return VP_EHIP;
@@ -695,6 +768,7 @@ int vp_create_with_options(int device, const vp_options *user, vp_ctx **out) {
     (void) hipFuncSetAttribute(reinterpret_cast<const void *>(k_emit_multi), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
     (void) hipFuncSetAttribute(reinterpret_cast<const void *>(k_emit), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
     (void) hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    { std::lock_guard<std::mutex> lk(g_ctx_mu); g_ctxs.push_back(ctx); }
     *out = ctx;
     return VP_OK;
 }
@@ -708,6 +782,8 @@ void vp_destroy(vp_ctx *ctx) {
     if (!ctx) return;
     (void) hipSetDevice(ctx->device);
     if (ctx->tail_active) (void) tail_quit(ctx);
+    vp_suspend_others(ctx);                                   // the hipFree calls below synchronise the device
+    { std::lock_guard<std::mutex> lk(g_ctx_mu); g_ctxs.erase(std::remove(g_ctxs.begin(), g_ctxs.end(), ctx), g_ctxs.end()); }
     (void) hipStreamSynchronize(ctx->stream);
     vp_free_shard_state(ctx);
     vp_free_comm(ctx);
@@ -877,6 +953,7 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
         }
     if (up_dbg) fprintf(stderr, "  liulists %.3f", up_since());
         VPCHK(dalloc(ctx, &ctx->part2, (size_t) 32 * MAX_BLOCKS * 3));
+        VPCHK(dalloc(ctx, &ctx->tail_save, (size_t) 3 * 2 * VP_PH_PMAX + 8 + VP_MAX_TAB));     // a suspended phase of the resident round kernel
         // lanes: per-layer scratch for the concurrent chains
         ctx->lane0.stream = ctx->stream;
         for (int b = 0; b < 2; ++b) for (int t = 0; t < 3; ++t) ctx->lane0.tab[b][t] = ctx->tab[b][t];
@@ -1195,6 +1272,7 @@ static int vp_round_impl(vp_ctx *ctx, const vp_F *previous_random, vp_F out_poly
         const int how1 = ctx->r1_pending;
         ctx->r1_pending = 0;
         *how = 2;                                             // round 1 was computed behind the init call
+        if (how1 == 3) { memcpy(out_poly, ctx->r1_stash, 3 * sizeof(F)); return VP_OK; }      // collected when the kernel was suspended
         if (how1 == 1) {
             VPCHK(tail_wait(ctx, ctx->tail_seq));
             tail_poly(ctx, out_poly);
@@ -1206,9 +1284,16 @@ static int vp_round_impl(vp_ctx *ctx, const vp_F *previous_random, vp_F out_poly
         return VP_OK;
     }
     // small rounds: one resident kernel answers every remaining message of the phase through a mailbox (vp_kernels_persist.h)
+    if (ctx->tail_lost) { ctx->err = "the resident round kernel was told to leave by another context before it could save its phase"; return VP_EHIP; }
+    if (ctx->tail_suspended) VPCHK(tail_resume(ctx, false));  // another context's call (or nothing at all, for longer than the time-out) suspended the phase
     if (ctx->tail_active) {
         *how = 1;                                             // answered by the resident kernel through the mailbox
-        VPCHK(tail_send(ctx, 1, rv));
+        int rc = tail_send(ctx, 1, rv);
+        if (rc == VP_TAIL_SAVED || (rc == VP_OK && tail_status(ctx) == 5)) {   // the kernel timed out (phase saved) before this message reached it
+            VPCHK(tail_resume(ctx, true));
+            rc = tail_wait(ctx, ctx->tail_seq);
+        }
+        VPCHK(rc);
         if (tail_status(ctx) != 0) { ctx->tail_active = false; ctx->err = "persistent round kernel: protocol error"; return VP_EHIP; }
         tail_poly(ctx, out_poly);
         ++ctx->sc.round; ++ctx->st.rounds;
@@ -1236,8 +1321,13 @@ int vp_finalize(vp_ctx *ctx, const vp_F *previous_random, vp_F *claims, int n_cl
     HIPCHK(hipSetDevice(ctx->device));
     F rv; memcpy(&rv, previous_random, sizeof(F));
     if (rv.re >= P61 || rv.im >= P61) { ctx->err = "vp_finalize: previous_random is not canonical (limb >= 2^61 - 1)"; return VP_EINVAL; }
+    if (ctx->tail_suspended) VPCHK(tail_resume(ctx, false));
     if (ctx->tail_active) {                                   // the resident kernel holds the tables: it computes the claims and leaves
-        const int rc = tail_send(ctx, 2, rv);
+        int rc = tail_send(ctx, 2, rv);
+        if (rc == VP_TAIL_SAVED || (rc == VP_OK && tail_status(ctx) == 5)) {
+            rc = tail_resume(ctx, true);
+            if (rc == VP_OK) rc = tail_wait(ctx, ctx->tail_seq);
+        }
         ctx->tail_active = false;
         VPCHK(rc);
         if (tail_status(ctx) != 0) { ctx->err = "persistent round kernel: protocol error at finalize"; return VP_EHIP; }

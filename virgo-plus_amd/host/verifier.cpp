@@ -371,7 +371,6 @@ void host_fft(std::vector<F> &a, const F &root) {          // in place, natural 
         }
     }
 }
-int log2u(u64 x) { int b = 0; while ((1ull << b) < x) ++b; return b; }
 vph::hhash_digest dig(const prover::hhash_digest &d) { vph::hhash_digest r; memcpy(r.w, d.b, 32); return r; }
 
 }  // namespace
