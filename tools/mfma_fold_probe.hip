@@ -64,11 +64,21 @@ __device__ __forceinline__ void swap32(u64 &x, u64 &y) {        // x[32..63] <->
     const v2u hi = __builtin_amdgcn_permlane32_swap((unsigned) (x >> 32), (unsigned) (y >> 32), false, false);
     x = ((u64) hi[0] << 32) | lo[0]; y = ((u64) hi[1] << 32) | lo[1];
 }
+// NO_MFMA (round 3): the same VALU work around the two matrix instructions, which are replaced by one cheap dependent operation each (results
+// meaningless) — what the form would cost if the matrix pipe overlapped PERFECTLY with other waves' VALU work.
+template <bool NO_MFMA = false>
 __device__ __forceinline__ F fold_mfma(const RoundConst &c, const F &d, const F &x0) {
     u64 b1 = d.re, b2 = d.im;
     swap32(b1, b2);                                              // b1: elements 0-31 (re | im), b2: elements 32-63
-    const v16i d1 = __builtin_amdgcn_mfma_i32_32x32x16_i8(c.a, (long) (b1 ^ 0x8080808080808080ull), c.cin, 0, 0, 0);
-    const v16i d2 = __builtin_amdgcn_mfma_i32_32x32x16_i8(c.a, (long) (b2 ^ 0x8080808080808080ull), c.cin, 0, 0, 0);
+    v16i d1, d2;
+    if (NO_MFMA) {
+        d1 = c.cin; d2 = c.cin;
+        const u64 y1 = b1 ^ 0x8080808080808080ull, y2 = b2 ^ 0x8080808080808080ull;
+        d1[0] += (int) y1; d1[3] ^= (int) (y1 >> 32); d1[8] += (int) y1; d2[0] += (int) y2; d2[5] ^= (int) (y2 >> 32); d2[8] += (int) y2;
+    } else {
+        d1 = __builtin_amdgcn_mfma_i32_32x32x16_i8(c.a, (long) (b1 ^ 0x8080808080808080ull), c.cin, 0, 0, 0);
+        d2 = __builtin_amdgcn_mfma_i32_32x32x16_i8(c.a, (long) (b2 ^ 0x8080808080808080ull), c.cin, 0, 0, 0);
+    }
     u64 w1 = recombine(d1), w2 = recombine(d2);
     swap32(w1, w2);                                              // w1: real parts of all 64 elements, w2: imaginary parts
     u64 sr = w1 + x0.re, si = w2 + x0.im;                        // < 2^63 + 2^61
@@ -80,10 +90,16 @@ template <int MODE> __global__ void __launch_bounds__(256) k_fold(const F *__res
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     F d = d_in[i], acc = x_in[i];
     RoundConst c{};
-    if (MODE == 1) c = make_const(r);
+    if (MODE >= 1) c = make_const(r);
+    // MODE 3: waves 0, 2 of a workgroup (SIMDs are shared by the 8 workgroups of a CU) run the VALU form, waves 1, 3 the matrix form: does a SIMD
+    // overlap one wave's matrix instructions with another wave's VALU work?  MODE 4: the same split with the matrix instructions taken out.
+    const bool odd = (threadIdx.x >> 6) & 1;
     for (int k = 0; k < reps; ++k) {
         if (MODE == 0) acc = f_mad31c<false>(r, d, acc);
-        else acc = fold_mfma(c, d, acc);
+        else if (MODE == 1) acc = fold_mfma(c, d, acc);
+        else if (MODE == 2) acc = fold_mfma<true>(c, d, acc);
+        else if (MODE == 3) { if (odd) acc = fold_mfma(c, d, acc); else acc = f_mad31c<false>(r, d, acc); }
+        else { if (odd) acc = fold_mfma<true>(c, d, acc); else acc = f_mad31c<false>(r, d, acc); }
         d.re = (d.re + 0x1234567ull * (k + 1)) & P61; d.im = (d.im ^ acc.re) & P61;       // the next "entry" (same sequence in both modes)
     }
     out[i] = acc;
@@ -116,18 +132,22 @@ int main() {
     else printf("mfma form == f_mad31c on %zu elements x 4 challenges x {1,3} chained steps\n", n);
     const int reps = 512;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int mode = 0; mode < 2; ++mode) {
+    for (int mode = 0; mode < 5; ++mode) {
         float best = 1e9;
         for (int it = 0; it < 4; ++it) {
             hipEventRecord(e0);
             if (mode == 0) hipLaunchKernelGGL(k_fold<0>, dim3(blocks), dim3(256), 0, 0, dd, dx, rs[0], o0, reps);
-            else hipLaunchKernelGGL(k_fold<1>, dim3(blocks), dim3(256), 0, 0, dd, dx, rs[0], o1, reps);
+            else if (mode == 1) hipLaunchKernelGGL(k_fold<1>, dim3(blocks), dim3(256), 0, 0, dd, dx, rs[0], o1, reps);
+            else if (mode == 2) hipLaunchKernelGGL(k_fold<2>, dim3(blocks), dim3(256), 0, 0, dd, dx, rs[0], o1, reps);
+            else if (mode == 3) hipLaunchKernelGGL(k_fold<3>, dim3(blocks), dim3(256), 0, 0, dd, dx, rs[0], o1, reps);
+            else hipLaunchKernelGGL(k_fold<4>, dim3(blocks), dim3(256), 0, 0, dd, dx, rs[0], o1, reps);
             hipEventRecord(e1); CK(hipEventSynchronize(e1));
             float ms; hipEventElapsedTime(&ms, e0, e1); if (it) best = std::min(best, ms);
         }
         const double waveops = (double) n / 64 * reps;
         printf("%-28s %8.3f ms  %7.1f SIMD-cycles per wave-op (64 x  x0 + r*d, incl. ~12 cycles of the probe's own entry update)\n",
-               mode == 0 ? "valu  f_mad31c" : "mfma  32x32x16 i8 + recombine", best, best * 1e-3 * ghz * 1e9 * cus * 4 / waveops);
+               mode == 0 ? "valu  f_mad31c" : mode == 1 ? "mfma  32x32x16 i8 + recombine" : mode == 2 ? "mfma form WITHOUT its mfma" :
+               mode == 3 ? "half the waves each form" : "half valu, half no-mfma form", best, best * 1e-3 * ghz * 1e9 * cus * 4 / waveops);
     }
     return bad != 0;
 }

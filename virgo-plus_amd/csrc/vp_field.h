@@ -57,12 +57,22 @@ VP_HD F f_mul128(const F &a, const F &b) {      // Karatsuba on 128-bit products
     u128 cr = (u128) (a.re + a.im) * (b.re + b.im);
     return f_make(m_red128(ac + C - bd), m_red128(cr + C + C - ac - bd));
 }
-template <bool WEAK> VP_HD F f_mad31c(const F &a, const F &b, const F &c);
+template <bool WEAK, bool MS> VP_HD F f_mad31c(const F &a, const F &b, const F &c);
 // a*b for canonical a, b.  On the device the 31-bit split form (f_mad31c below) is ~12 % cheaper than the 128-bit Karatsuba
 // form (fewer shift/mask/select instructions around the same sixteen v_mad_u64_u32); both give the canonical product.
+#ifndef VP_MADSHIFT
+#define VP_MADSHIFT 1         // device multiplies take C * 2^31 through the multiplier (c31_add below); f_mul_plain is the form without it
+#endif
 VP_HD F f_mul(const F &a, const F &b) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(VP_MUL128)
-    return f_mad31c<false>(a, b, f_make(0, 0));
+    return f_mad31c<false, VP_MADSHIFT != 0>(a, b, f_make(0, 0));
+#else
+    return f_mul128(a, b);
+#endif
+}
+VP_HD F f_mul_plain(const F &a, const F &b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(VP_MUL128)
+    return f_mad31c<false, false>(a, b, f_make(0, 0));
 #else
     return f_mul128(a, b);
 #endif
@@ -74,86 +84,108 @@ VP_HD F f_mul(const F &a, const F &b) {
 // the 128-bit form, same 16 multiplier instructions.  Operands may be lazy differences in [0, 2p].
 struct Sp31 { u32 lo, hi; };                     // x = hi * 2^31 + lo,  x < 2^62
 VP_HD Sp31 split31(u64 x) { Sp31 s; s.lo = (u32) x & 0x7fffffffu; s.hi = (u32) (x >> 31); return s; }
+// C * 2^31 + base (mod p) for the middle word C < 2^64 of a split product:  (C mod 2^30) * 2^31 + (C >> 30) + base.
+// MS (device only): the shift by 31 rides on the multiplier — v_mad_u64_u32(C mod 2^30, 2^31, base) instead of v_lshlrev_b64 + two v_and +
+// v_lshl_add_u64; the constant is kept opaque in an SGPR or the compiler turns the product back into the shift.  A template switch, because it
+// pays in the GKR kernels (x64 proof -2.5 %, x1024 -3 %: the gain sits in the plain products of the init / light / closing kernels, the fold
+// pair step alone is indifferent) and costs in the transforms of the commitment (commit side +25 %, same call): vp_kernels_pc.h multiplies
+// with f_mul_plain.
+template <bool MS>
+VP_HD u64 c31_add(u64 C, u64 base) {             // base + c2 < 2^64 is the caller's business
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (MS) {
+        u32 k31;
+        asm("s_mov_b32 %0, 0x80000000" : "=s"(k31));
+        return (u64) ((u32) C & 0x3fffffffu) * k31 + base + (C >> 30);
+    }
+#endif
+    return ((C & 0x3fffffffull) << 31) + (C >> 30) + base;
+}
 // x*y + z*w + addend (mod p);  x, y, z, w < 2^62, addend < 2^61 + 8.  Canonical result (WEAK: folded once only, < 2^61 + 4,
 // for values that go straight into an unreduced sum).
-template <bool WEAK = false>
+template <bool WEAK = false, bool MS = false>
 VP_HD u64 dot2_31(const Sp31 &x, const Sp31 &y, const Sp31 &z, const Sp31 &w, u64 addend) {
     const u64 L = (u64) x.lo * y.lo + (u64) z.lo * w.lo;                                            // < 2^63
     const u64 C = (u64) x.lo * y.hi + (u64) x.hi * y.lo + (u64) z.lo * w.hi + (u64) z.hi * w.lo;    // < 2^64
     const u64 H = (u64) x.hi * y.hi + (u64) z.hi * w.hi;                                            // < 2^63
     const u64 h2 = ((H & ((1ull << 60) - 1)) << 1) + (H >> 60);          // H * 2^62
-    const u64 c2 = ((C & 0x3fffffffull) << 31) + (C >> 30);              // C * 2^31
     const u64 l2 = (L & P61) + (L >> 61);
-    u64 s = h2 + c2 + l2 + addend;                                       // < 2^63
+    u64 s = c31_add<MS>(C, l2) + h2 + addend;                                // C * 2^31 + ...  < 2^63
     s = (s & P61) + (s >> 61);
     if (WEAK) return s;
     return s >= P61 ? s - P61 : s;
 }
 // a*b + c;  limbs of a, b in [0, 2p], limbs of c in [0, p].  Canonical result unless WEAK.
-template <bool WEAK = false>
+template <bool WEAK = false, bool MS = false>
 VP_HD F f_mad31(const F &a, const F &b, const F &c) {
     const Sp31 ar = split31(a.re), ai = split31(a.im), br = split31(b.re), bi = split31(b.im);
     const Sp31 nbi = split31(2 * P61 - b.im);                // -b.im (mod p), in [0, 2p]
-    return f_make(dot2_31<WEAK>(ar, br, ai, nbi, c.re), dot2_31<WEAK>(ar, bi, ai, br, c.im));
+    return f_make(dot2_31<WEAK, MS>(ar, br, ai, nbi, c.re), dot2_31<WEAK, MS>(ar, bi, ai, br, c.im));
 }
 // Same with x and z CANONICAL (< 2^61, so hi < 2^30): H*2^62 = 2H (mod p) is obtained by doubling x.hi / z.hi, and then
 // L + 2H < 2^64 shares ONE accumulator (four multiply-adds in a row, no separate shift-fold of H).  y, w < 2^62 as before.
 // WEAK: the result is only folded once (< 2^61 + 4, congruent mod p, not canonical) — for values that go straight into an
 // unreduced sum.
-template <bool WEAK>
+template <bool WEAK, bool MS = false>
 VP_HD u64 dot2_31c(const Sp31 &x, const Sp31 &y, const Sp31 &z, const Sp31 &w, u64 addend) {
     const u64 LH = (u64) x.lo * y.lo + (u64) z.lo * w.lo + (u64) (2 * x.hi) * y.hi + (u64) (2 * z.hi) * w.hi;    // < 2^64
     const u64 C = (u64) x.lo * y.hi + (u64) x.hi * y.lo + (u64) z.lo * w.hi + (u64) z.hi * w.lo;              // < 2^64
-    const u64 c2 = ((C & 0x3fffffffull) << 31) + (C >> 30);              // C * 2^31
-    u64 s = (LH & P61) + (LH >> 61) + c2 + addend;                       // < 2^63
+    u64 s = c31_add<MS>(C, LH & P61) + (LH >> 61) + addend;              // C * 2^31 + ...  < 2^63
     s = (s & P61) + (s >> 61);
     if (WEAK) return s;
     return s >= P61 ? s - P61 : s;
 }
 // a*b + c with the limbs of a canonical; limbs of b in [0, 2p], limbs of c in [0, p].
-template <bool WEAK>
+template <bool WEAK, bool MS = false>
 VP_HD F f_mad31c(const F &a, const F &b, const F &c) {
     const Sp31 ar = split31(a.re), ai = split31(a.im), br = split31(b.re), bi = split31(b.im);
     const Sp31 nbi = split31(2 * P61 - b.im);
-    return f_make(dot2_31c<WEAK>(ar, br, ai, nbi, c.re), dot2_31c<WEAK>(ar, bi, ai, br, c.im));
+    return f_make(dot2_31c<WEAK, MS>(ar, br, ai, nbi, c.re), dot2_31c<WEAK, MS>(ar, bi, ai, br, c.im));
+}
+// x0 + r*d for a challenge r that the whole launch shares (the fold of a bookkeeping table): the two partial products that carry -r.im take
+// the negated SCALAR p - r.im (wave-uniform, computed once on the scalar unit) instead of a per-element negation of d.im — a 64-bit subtract
+// and one split less per fold than f_mad31c(r, d, x0), and d.im may exceed 2p.  r canonical; limbs of d < 2^62 + 8, of x0 < 2^61 + 8.
+template <bool WEAK, bool MS = false>
+VP_HD F f_fold31(const F &r, const F &d, const F &x0) {
+    const Sp31 rr = split31(r.re), ri = split31(r.im), nri = split31(P61 - r.im);       // p - r.im in [1, p]: hi < 2^30, as dot2_31c wants
+    const Sp31 dr = split31(d.re), di = split31(d.im);
+    return f_make(dot2_31c<WEAK, MS>(rr, dr, nri, di, x0.re), dot2_31c<WEAK, MS>(rr, di, ri, dr, x0.im));
 }
 // The same two forms for a REAL second factor (b = (y, 0)): each limb of a*b + c is ONE product, eight multiplier instructions per
 // F-multiply instead of sixteen.  Circuit values of a circuit with real inputs and constants are real (every gate of
 // src/prover.cpp:27-91 maps reals to reals), so the first round of every sumcheck takes this path when vp_evaluate found no
 // imaginary part (vp_ctx::d_vcplx); the results are the same field elements.
-template <bool WEAK = false>
+template <bool WEAK = false, bool MS = false>
 VP_HD u64 dot1_31(const Sp31 &x, const Sp31 &y, u64 addend) {                // x, y < 2^62
     const u64 L = (u64) x.lo * y.lo;                                       // < 2^62
     const u64 C = (u64) x.lo * y.hi + (u64) x.hi * y.lo;                   // < 2^63
     const u64 H = (u64) x.hi * y.hi;                                       // < 2^62
     const u64 h2 = ((H & ((1ull << 60) - 1)) << 1) + (H >> 60);
-    const u64 c2 = ((C & 0x3fffffffull) << 31) + (C >> 30);
-    u64 s = h2 + c2 + L + addend;                                          // < 2^61 + 2^61 + 2^62 + 2^61 + 8 < 2^64
+    u64 s = c31_add<MS>(C, L) + h2 + addend;                                   // < 2^61 + 2^61 + 2^62 + 2^61 + 8 < 2^64
     s = (s & P61) + (s >> 61);
     if (WEAK) return s;
     return s >= P61 ? s - P61 : s;
 }
-template <bool WEAK>
+template <bool WEAK, bool MS = false>
 VP_HD u64 dot1_31c(const Sp31 &x, const Sp31 &y, u64 addend) {               // x canonical, y < 2^62
     const u64 LH = (u64) x.lo * y.lo + (u64) (2 * x.hi) * y.hi;            // < 2^62 + 2^62
     const u64 C = (u64) x.lo * y.hi + (u64) x.hi * y.lo;                   // < 2^63
-    const u64 c2 = ((C & 0x3fffffffull) << 31) + (C >> 30);
-    u64 s = (LH & P61) + (LH >> 61) + c2 + addend;
+    u64 s = c31_add<MS>(C, LH & P61) + (LH >> 61) + addend;
     s = (s & P61) + (s >> 61);
     if (WEAK) return s;
     return s >= P61 ? s - P61 : s;
 }
 // a * (y, 0) + c: limbs of a in [0, 2p], y in [0, 2p], limbs of c in [0, p]
-template <bool WEAK = false>
+template <bool WEAK = false, bool MS = false>
 VP_HD F f_mad31_rb(const F &a, u64 y, const F &c) {
     const Sp31 ar = split31(a.re), ai = split31(a.im), b = split31(y);
-    return f_make(dot1_31<WEAK>(ar, b, c.re), dot1_31<WEAK>(ai, b, c.im));
+    return f_make(dot1_31<WEAK, MS>(ar, b, c.re), dot1_31<WEAK, MS>(ai, b, c.im));
 }
 // the same with the limbs of a canonical
-template <bool WEAK>
+template <bool WEAK, bool MS = false>
 VP_HD F f_mad31c_rb(const F &a, u64 y, const F &c) {
     const Sp31 ar = split31(a.re), ai = split31(a.im), b = split31(y);
-    return f_make(dot1_31c<WEAK>(ar, b, c.re), dot1_31c<WEAK>(ai, b, c.im));
+    return f_make(dot1_31c<WEAK, MS>(ar, b, c.re), dot1_31c<WEAK, MS>(ai, b, c.im));
 }
 // a + r*(b - a): one fold step of a bookkeeping table (src/prover.cpp:483 eval + interpolate)
 VP_HD F f_lerp(const F &a, const F &b, const F &r) { return f_add(a, f_mul(r, f_sub(b, a))); }

@@ -350,8 +350,8 @@ template <bool WEAK = false> __device__ __forceinline__ F f_mad_c(const F &a, co
 template <bool WEAK = false> __device__ __forceinline__ F f_mad_lazy(const F &a, const F &b, const F &c) { return f_mad31<false>(a, b, c); }
 template <bool WEAK = false> __device__ __forceinline__ F f_mad_c(const F &a, const F &b, const F &c) { return f_mad31<false>(a, b, c); }
 #else
-template <bool WEAK = false> __device__ __forceinline__ F f_mad_lazy(const F &a, const F &b, const F &c) { return f_mad31<WEAK>(a, b, c); }
-template <bool WEAK = false> __device__ __forceinline__ F f_mad_c(const F &a, const F &b, const F &c) { return f_mad31c<WEAK>(a, b, c); }
+template <bool WEAK = false> __device__ __forceinline__ F f_mad_lazy(const F &a, const F &b, const F &c) { return f_mad31<WEAK, VP_MADSHIFT>(a, b, c); }
+template <bool WEAK = false> __device__ __forceinline__ F f_mad_c(const F &a, const F &b, const F &c) { return f_mad31c<WEAK, VP_MADSHIFT>(a, b, c); }
 #endif
 struct Lz { u64 re, im; };                                           // unreduced sum of canonical values
 __device__ __forceinline__ void lz_add(Lz &s, const F &x) { s.re += x.re; s.im += x.im; }
@@ -363,6 +363,20 @@ __device__ __forceinline__ F lz_canon(const Lz &s) { return f_make(m_fold(s.re),
 // S_k(0) + S_k(1) = S_{k-1}(r_{k-1}) (src/verifier.cpp:208,249,295) gives Y = S_{k-1}(r_{k-1}) - Z for the totals over all tables
 // of the phase, add_term included, and the closing kernel has both (k_emit, derive_mask).  KEEP_Y = false leaves the product
 // out: five multiply-adds per pair instead of six, the same field elements in the transcript.
+#ifndef VP_SF_FOLD31
+#define VP_SF_FOLD31 0         // 1: the three folds use f_fold31 (the negated challenge limb instead of a negated difference per element)
+#endif
+// (Round 3, built and measured: M and A entries travelling through LDS weakly reduced (<= p + 3) between the rounds of a launch, so that the
+// conditional subtraction disappears from two of the three folds.  The lazy difference of two such values needs an offset that is a multiple
+// of p AND at least p + 3, i.e. 2p, and then exceeds the 2^62 the split multiply takes; with the extra fold that brings it back the net gain
+// is ~3 % of the fold arithmetic.  Not kept.)
+template <bool WEAK> __device__ __forceinline__ F sf_fold(const F &r, const F &d, const F &x0) {
+#if VP_SF_FOLD31
+    return f_fold31<WEAK, VP_MADSHIFT>(r, d, x0);
+#else
+    return f_mad_c<WEAK>(r, d, x0);
+#endif
+}
 template <bool HAS_A>
 __device__ __forceinline__ void sf_pair_step(const F &v0, const F &v1, const F &m0, const F &m1, const F &a0, const F &a1,
                                              const F &r, Lz &X, Lz &Y, Lz &Z, F &vo, F &mo, F &ao, bool keep_y) {
@@ -370,9 +384,9 @@ __device__ __forceinline__ void sf_pair_step(const F &v0, const F &v1, const F &
     lz_add(X, f_mad_lazy<true>(dm, dv, f_zero()));                       // sums take weakly reduced products (< 2^61 + 4)
     if (keep_y) lz_add(Y, f_mad_c<true>(m1, v1, HAS_A ? a1 : f_zero()));
     lz_add(Z, f_mad_c<true>(m0, v0, HAS_A ? a0 : f_zero()));
-    vo = f_mad_c(r, dv, v0);                                             // stored values are canonical
-    mo = f_mad_c(r, dm, m0);
-    if (HAS_A) ao = f_mad_c(r, f_sub_lazy(a1, a0), a0);
+    vo = sf_fold<false>(r, dv, v0);                                      // stored values are canonical
+    mo = sf_fold<false>(r, dm, m0);
+    if (HAS_A) ao = sf_fold<false>(r, f_sub_lazy(a1, a0), a0);
 }
 
 // The same pair step when v0 and v1 are REAL (round 1 of a sumcheck over a circuit with real values, f_mad31c_rb in vp_field.h):
@@ -382,12 +396,12 @@ __device__ __forceinline__ void sf_pair_step_rv(u64 v0, u64 v1, const F &m0, con
                                                 const F &r, Lz &X, Lz &Y, Lz &Z, F &vo, F &mo, F &ao, bool keep_y) {
     const u64 dv = v1 + P61 - v0;
     const F dm = f_sub_lazy(m1, m0);
-    lz_add(X, f_mad31_rb<true>(dm, dv, f_zero()));
-    if (keep_y) lz_add(Y, f_mad31c_rb<true>(m1, v1, HAS_A ? a1 : f_zero()));
-    lz_add(Z, f_mad31c_rb<true>(m0, v0, HAS_A ? a0 : f_zero()));
-    vo = f_mad31c_rb<false>(r, dv, f_make(v0, 0));
-    mo = f_mad_c(r, dm, m0);
-    if (HAS_A) ao = f_mad_c(r, f_sub_lazy(a1, a0), a0);
+    lz_add(X, f_mad31_rb<true, VP_MADSHIFT>(dm, dv, f_zero()));
+    if (keep_y) lz_add(Y, f_mad31c_rb<true, VP_MADSHIFT>(m1, v1, HAS_A ? a1 : f_zero()));
+    lz_add(Z, f_mad31c_rb<true, VP_MADSHIFT>(m0, v0, HAS_A ? a0 : f_zero()));
+    vo = f_mad31c_rb<false, VP_MADSHIFT>(r, dv, f_make(v0, 0));
+    mo = sf_fold<false>(r, dm, m0);
+    if (HAS_A) ao = sf_fold<false>(r, f_sub_lazy(a1, a0), a0);
 }
 
 #ifndef VP_SF_ROTATE

@@ -2,6 +2,9 @@
 // Part of the single translation unit vpgpu.hip (see vp_kernels.h for the overall layout rules).
 #pragma once
 #include "vp_kernels_round.h"
+// Every product in this file is the plain split form: with the multiplier-shift form of the GKR kernels (vp_field.h, c31_add) the transforms
+// lose more than the pointwise kernels gain (commit side 70.8 -> 88.9 ms at x1024, same call).  Undone at the end of the file.
+#define f_mul f_mul_plain
 
 // ===================================================================================================
 // Virgo polynomial commitment, commit side (reference: lib/virgo/src/RS_polynomial.cpp, poly_commit.h,
@@ -601,3 +604,4 @@ __global__ void k_pc_open(const F *__restrict__ cw, u32 Nc, const Dig *__restric
     }
 }
 }  // namespace vp
+#undef f_mul
