@@ -16,9 +16,18 @@ namespace vp {
 // One table of roots for the whole commitment: RT[j] = w^j, j < M/2, w = root of unity of order M = 2^lm
 // (fieldElement::getRootOfUnity, fieldElement.cpp:237-249).  w^(M/2) = -1, so any power and any inverse
 // power is one load and possibly one negation; smaller orders use strided indices.
-__device__ __forceinline__ F root_pow(const F *__restrict__ RT, u32 half_m, u32 e /* < 2*half_m */) {
-    return e < half_m ? RT[e] : f_neg(RT[e - half_m]);
+// Branch-free on purpose: written as `e < half_m ? RT[e] : f_neg(RT[e - half_m])` the compiler makes two divergent arms, each with its own
+// load and a wait for it — the three roots of a radix-4 butterfly (and the 32 output twiddles of a k_ntt_split column) were fetched one
+// memory latency after the other.  One load from the masked index and a select-form negation let it issue all of them before the first use.
+__device__ __forceinline__ F root_raw(const F *__restrict__ RT, u32 half_m /* power of two */, u32 e /* < 2*half_m */) { return RT[e & (half_m - 1)]; }
+__device__ __forceinline__ F root_fin(const F &r, u32 half_m, u32 e) {                       // the raw entry -> w^e
+    const bool neg = e >= half_m;
+    const u64 nre = r.re ? P61 - r.re : 0, nim = r.im ? P61 - r.im : 0;
+    return f_make(neg ? nre : r.re, neg ? nim : r.im);
 }
+__device__ __forceinline__ F root_pow(const F *__restrict__ RT, u32 half_m, u32 e) { return root_fin(root_raw(RT, half_m, e), half_m, e); }
+// nothing moves across this point: the loads requested above it are all in flight before the first instruction that waits for one of them
+__device__ __forceinline__ void loads_first() { __builtin_amdgcn_sched_barrier(0); }
 __global__ void __launch_bounds__(VP_BLOCK)
 k_root_table_step(F *RT, u32 have /* entries already filled, power of two */, F step /* w^have */) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -132,9 +141,11 @@ __global__ void __launch_bounds__(1024) k_ntt_lds(NttArgs a) {
                 const u32 e = k * tw;                       // < Mp/4
                 const u32 e1 = a.inverse ? (e ? Mp - e : 0) : e, e2 = a.inverse ? (e ? Mp - 2 * e : 0) : 2 * e,
                           e3 = a.inverse ? (e ? Mp - 3 * e : 0) : 3 * e;
-                x1 = f_mul(x1, root_pow(a.RTp, a.half_p, e2));
-                x2 = f_mul(x2, root_pow(a.RTp, a.half_p, e1));
-                x3 = f_mul(x3, root_pow(a.RTp, a.half_p, e3));
+                const F w1 = root_raw(a.RTp, a.half_p, e1), w2 = root_raw(a.RTp, a.half_p, e2), w3 = root_raw(a.RTp, a.half_p, e3);
+                loads_first();                              // three root gathers and four LDS reads in flight together
+                x1 = f_mul(x1, root_fin(w2, a.half_p, e2));
+                x2 = f_mul(x2, root_fin(w1, a.half_p, e1));
+                x3 = f_mul(x3, root_fin(w3, a.half_p, e3));
             }
             const F s0 = f_add(x0, x1), d0 = f_sub(x0, x1), s1 = f_add(x2, x3), d1 = mul_iota(f_sub(x2, x3), ip);
             L[p0] = f_add(s0, s1); L[p1] = f_add(d0, d1); L[p2] = f_sub(s0, s1); L[p3] = f_sub(d0, d1);
@@ -546,13 +557,26 @@ __global__ void __launch_bounds__(VP_BLOCK) k_ntt_split(SplitArgs a) {
     }
     F *dst = a.out + ((size_t) row * a.ncoset + coset) * N;
     const u32 ec = twist ? (u32) (((unsigned long long) j2 * coset) & (M - 1)) : 0u;      // the column's share of the twist
+    // output twiddles w_N^(j2 k1) (x the column's twist): per-lane gathers from the order-M table, requested four at a time ahead of their products
+    constexpr u32 G = N1 < 4 ? N1 : 4;
 #pragma unroll
-    for (u32 p = 0; p < N1; ++p) {
-        const u32 k1 = __brev(p) >> (32 - (L1 ? L1 : 1)) >> (L1 ? 0 : 1);     // bit reversal of p in L1 bits
-        u32 e = (u32) (((unsigned long long) j2 * k1 * wN) & (M - 1));         // w_N^(j2 k1)
-        if (a.inverse) e = e ? M - e : 0;
-        e = (e + ec) & (M - 1);
-        dst[(size_t) k1 * N2 + j2] = (p == 0 && !twist) ? x[p] : f_mul(x[p], root_pow(a.RT, a.half_m, e));
+    for (u32 p0 = 0; p0 < N1; p0 += G) {
+        u32 e[G], k1[G]; F w[G];
+#pragma unroll
+        for (u32 i = 0; i < G; ++i) {
+            const u32 p = p0 + i;
+            k1[i] = __brev(p) >> (32 - (L1 ? L1 : 1)) >> (L1 ? 0 : 1);         // bit reversal of p in L1 bits
+            u32 ee = (u32) (((unsigned long long) j2 * k1[i] * wN) & (M - 1));  // w_N^(j2 k1)
+            if (a.inverse) ee = ee ? M - ee : 0;
+            e[i] = (ee + ec) & (M - 1);
+            w[i] = root_raw(a.RT, a.half_m, e[i]);
+        }
+        loads_first();
+#pragma unroll
+        for (u32 i = 0; i < G; ++i) {
+            const u32 p = p0 + i;
+            dst[(size_t) k1[i] * N2 + j2] = (p == 0 && !twist) ? x[p] : f_mul(x[p], root_fin(w[i], a.half_m, e[i]));
+        }
     }
 }
 
