@@ -1280,6 +1280,33 @@ def test_reference_binary_drives_the_device_prover(pws_path, tmp_path, golden):
     assert "fft gkr failed" not in r.stderr
 
 
+@pytest.mark.parametrize("blocks", [16, 64])
+def test_reference_verifier_accepts_device_commitment_at_block_counts(pws_path, tmp_path, golden, blocks):
+    """The same seam at x16 and x64 (the reference's main() fixes repeat = 1; oracle/integration/blocks_main.cpp replaces main() only and
+    feeds the B-fold DAG to the reference's own DAG_to_layered / subsetInit): the unmodified reference verifier — GKR and
+    verify_poly_commitment with its 33 query repetitions — accepts a proof whose every message, root, opening and Merkle path comes from the
+    device, and the messages handed over equal the CPU reference's transcript and FRI record of the same circuit and seed, byte for byte."""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_run_vpgpu_blocks")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_run_vpgpu_blocks not built (needs the reference tree at build time)")
+    dump, dump_fri = tmp_path / "messages.bin", tmp_path / "fri.bin"
+    env = dict(os.environ, VPI_DUMP=str(dump), VPI_DUMP_FRI=str(dump_fri), VPI_TRACE="1")
+    r = subprocess.run([exe, str(pws_path), str(blocks)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200, env=env)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2000:])
+    assert "Verification pass" in r.stderr and "Verification fail" not in r.stderr and "ok 1" in r.stdout
+    m = re.search(r"vpgpu calls: commit_private (\d+) commit_public (\d+) fri_step (\d+) fri_final (\d+) open_init (\d+) open_step (\d+) round (\d+) "
+                  r"finalize (\d+) rand_consumers (\d+) fft_gkr (\d+)", r.stderr)
+    assert m, r.stderr[-2000:]
+    calls = [int(x) for x in m.groups()]
+    g = golden["sha256_x%d" % blocks]
+    assert calls[0] == 1 and calls[1] == 1 and calls[3] == 1 and calls[4] == 66 and calls[8] == 0 and calls[9] == 1
+    assert calls[5] == 33 * calls[2]                                  # one opening per query repetition and FRI level
+    assert dump.read_bytes() == open(os.path.join(GOLDEN_DIR, g["transcript"]), "rb").read()
+    assert dump_fri.read_bytes() == open(os.path.join(GOLDEN_DIR, g["fri"]), "rb").read()
+
+
 def test_tensor_public_vector_shortcut_is_exact(vp, ob, monkeypatch):
     """vp_commit_public encodes ONE slice when the public vector is a tensor (every slice a multiple of slice 0 — the protocol's eq table
     always is) and forms q_i = c_i q_0 where it is consumed.  Same roots, input_0 and all_sum as the general path (VP_PC_TENSOR=0) on: an eq

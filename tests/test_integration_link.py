@@ -53,6 +53,11 @@ def test_unmodified_reference_links_against_the_forwarding_prover():
     for f in ("vp_create", "vp_circuit_upload", "vp_evaluate", "vp_vres", "vp_phase1_init", "vp_phase2_init", "vp_liu_init", "vp_round", "vp_finalize",
               "vp_commit_private", "vp_commit_public", "vp_fri_step", "vp_fri_final", "vp_fri_open", "vp_fft_gkr"):
         assert f in dyn, f                                                             # ... and they reach the C ABI of libvpgpu.so
+    # the block-count variant (oracle/integration/blocks_main.cpp replaces main() only): same seam, same absence of the reference's prover side
+    blk = os.path.join(ROOT, "oracle", "_ref", "ref_run_vpgpu_blocks")
+    assert os.path.exists(blk)
+    bsyms = subprocess.run(["nm", "-C", blk], check=True, stdout=subprocess.PIPE, text=True).stdout
+    assert "merkle_tree_consistency_check" not in bsyms and "virgo::fft_circuit_gkr::engage_gkr" not in bsyms and "DAG_to_layered()" in bsyms
 
 
 @pytest.mark.skipif(not os.path.exists(BIN), reason="oracle/_ref/ref_run_vpgpu not built")
