@@ -139,8 +139,6 @@ __global__ void __launch_bounds__(VP_BLOCK) k_init2_light(InitArgs2 a) { init2_l
 // the mult / add arrays; of a row cut into several chunks the wave that arrives last adds the others' partials (written through to memory
 // with sc1 stores, counted with a relaxed agent-scope atomic per ROW — a few arrivals per counter, no fence) and resets the counter.
 struct ChunkFuse { const u32 *chunk_h; const u32 *heavy_row; const u32 *heavy_cptr; u32 *heavy_cnt; F *M; F *A; };
-__device__ __forceinline__ unsigned long long cf_ld(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void cf_st(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <int PHASE>
 __device__ __forceinline__ void init2_chunks_body(const InitArgs2 &a, const u32 *__restrict__ chunk_beg, const u32 *__restrict__ chunk_end,
                                                   u32 n_chunks, F *__restrict__ part, u32 bid, const ChunkFuse *fuse = nullptr) {
@@ -341,22 +339,7 @@ __global__ void __launch_bounds__(VP_BLOCK, MINW) k_sumfold(SfArgs a) {
 //   a*b + c  with a, b in [0, 2p], c in [0, p]:  f_mad31 (vp_field.h), canonical result; every stored value
 //   is canonical, so results are bit-identical to the strict sequence.
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ F f_sub_lazy(const F &a, const F &b) { return f_make(a.re + P61 - b.re, a.im + P61 - b.im); }
-// f_mad_lazy: a, b lazy.  f_mad_c: a canonical (one accumulator for L + 2H).  <true>: weakly reduced result for the lazy sums.
-#ifdef VP_EXP_NOMUL       // development probe (tools/micro_sumfold.hip): the multiply-add replaced by three cheap ops, results meaningless
-template <bool WEAK = false> __device__ __forceinline__ F f_mad_lazy(const F &a, const F &b, const F &c) { return f_make(((a.re ^ b.re) + c.re) & P61, ((a.im ^ b.im) + c.im) & P61); }
-template <bool WEAK = false> __device__ __forceinline__ F f_mad_c(const F &a, const F &b, const F &c) { return f_mad_lazy<WEAK>(a, b, c); }
-#elif defined(VP_EXP_OLDMAD)   // development probe: the general multiply-add with canonical results everywhere (the arithmetic before f_mad31c)
-template <bool WEAK = false> __device__ __forceinline__ F f_mad_lazy(const F &a, const F &b, const F &c) { return f_mad31<false>(a, b, c); }
-template <bool WEAK = false> __device__ __forceinline__ F f_mad_c(const F &a, const F &b, const F &c) { return f_mad31<false>(a, b, c); }
-#else
-template <bool WEAK = false> __device__ __forceinline__ F f_mad_lazy(const F &a, const F &b, const F &c) { return f_mad31<WEAK, VP_MADSHIFT>(a, b, c); }
-template <bool WEAK = false> __device__ __forceinline__ F f_mad_c(const F &a, const F &b, const F &c) { return f_mad31c<WEAK, VP_MADSHIFT>(a, b, c); }
-#endif
-struct Lz { u64 re, im; };                                           // unreduced sum of canonical values
-__device__ __forceinline__ void lz_add(Lz &s, const F &x) { s.re += x.re; s.im += x.im; }
-__device__ __forceinline__ void lz_fold(Lz &s) { s.re = (s.re & P61) + (s.re >> 61); s.im = (s.im & P61) + (s.im >> 61); }
-__device__ __forceinline__ F lz_canon(const Lz &s) { return f_make(m_fold(s.re), m_fold(s.im)); }
+// (f_sub_lazy, f_mad_lazy / f_mad_c and the unreduced sums Lz live in vp_kernels_round.h: the per-round kernels use them too)
 
 // one pair of one table family: sums into (X, Y, Z) = (sum dm*dv, sum m1*v1 + a1, sum m0*v0 + a0), folds with r.
 // The round polynomial is a = X, b = Y - X - Z, c = Z.  From round 2 of a sumcheck on, Y is redundant: the verifier's own check

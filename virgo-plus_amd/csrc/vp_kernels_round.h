@@ -386,6 +386,28 @@ struct RoundArgs {
     TabDesc t[VP_MAX_TAB];
 };
 
+// Lazy arithmetic of the throughput kernels (values are limbs of F):
+//   d = x1 + p - x0            in [0, 2p]           (x0, x1 canonical)
+//   a*b + c  with a, b in [0, 2p], c in [0, p]:  f_mad31 (vp_field.h), canonical result unless <true> (then < 2^61 + 4, for unreduced sums)
+__device__ __forceinline__ F f_sub_lazy(const F &a, const F &b) { return f_make(a.re + P61 - b.re, a.im + P61 - b.im); }
+// f_mad_lazy: a, b lazy.  f_mad_c: a canonical (one accumulator for L + 2H).  <true>: weakly reduced result for the lazy sums.
+#ifdef VP_EXP_NOMUL       // development probe (tools/micro_sumfold.hip): the multiply-add replaced by three cheap ops, results meaningless
+template <bool WEAK = false> __device__ __forceinline__ F f_mad_lazy(const F &a, const F &b, const F &c) { return f_make(((a.re ^ b.re) + c.re) & P61, ((a.im ^ b.im) + c.im) & P61); }
+template <bool WEAK = false> __device__ __forceinline__ F f_mad_c(const F &a, const F &b, const F &c) { return f_mad_lazy<WEAK>(a, b, c); }
+#elif defined(VP_EXP_OLDMAD)   // development probe: the general multiply-add with canonical results everywhere (the arithmetic before f_mad31c)
+template <bool WEAK = false> __device__ __forceinline__ F f_mad_lazy(const F &a, const F &b, const F &c) { return f_mad31<false>(a, b, c); }
+template <bool WEAK = false> __device__ __forceinline__ F f_mad_c(const F &a, const F &b, const F &c) { return f_mad31<false>(a, b, c); }
+#else
+template <bool WEAK = false> __device__ __forceinline__ F f_mad_lazy(const F &a, const F &b, const F &c) { return f_mad31<WEAK, VP_MADSHIFT>(a, b, c); }
+template <bool WEAK = false> __device__ __forceinline__ F f_mad_c(const F &a, const F &b, const F &c) { return f_mad31c<WEAK, VP_MADSHIFT>(a, b, c); }
+#endif
+struct Lz { u64 re, im; };                                           // unreduced sum of canonical values
+__device__ __forceinline__ void lz_add(Lz &s, const F &x) { s.re += x.re; s.im += x.im; }
+__device__ __forceinline__ void lz_fold(Lz &s) { s.re = (s.re & P61) + (s.re >> 61); s.im = (s.im & P61) + (s.im >> 61); }
+__device__ __forceinline__ F lz_canon(const Lz &s) { return f_make(m_fold(s.re), m_fold(s.im)); }
+// agent-scope word accesses: partial results that another workgroup (possibly on another XCD, behind another L2) picks up inside the same launch
+__device__ __forceinline__ unsigned long long cf_ld(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void cf_st(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #ifdef VP_EXP_NOLOAD      // development probe (tools/micro_sumfold.hip): no global loads, results meaningless
 __device__ __forceinline__ F ld_or_zero(const F *p, u32 i, u32 valid) { return i < valid ? f_make(i * 0x9E3779B97F4A7C15ull >> 3, (u64) (size_t) p + i) : f_zero(); }
 #else
@@ -393,13 +415,17 @@ __device__ __forceinline__ F ld_or_zero(const F *p, u32 i, u32 valid) { return i
 #endif
 
 // Main kernel: one thread per output pair, grid-stride.  For fold=1 a thread reads 4 consecutive
-// entries per table (64 B), writes 2 (32 B) and accumulates the three coefficients; block partial sums
-// go to part[blockIdx.x*3 + {0,1,2}].  CLS only names the instantiation: CLS=1 is used for launches with at
-// least VP_BIG_PAIRS pairs so that profilers report the bandwidth-relevant launches under their own name.
+// entries per table (64 B), writes 2 (32 B) and accumulates the three sums X = sum dm*dv, Y = sum m1*v1 + a1, Z = sum m0*v0 + a0
+// (the round polynomial is a = X, b = Y - X - Z, c = Z before add_term).  CLS only names the instantiation: CLS=1 is used for launches
+// with at least VP_BIG_PAIRS pairs so that profilers report the bandwidth-relevant launches under their own name.
+// Round 3: the arithmetic of the batched fold kernels (lazy differences, weakly reduced products into unreduced sums, the fold as one
+// multiply-add) instead of f_lerp + canonical products and sums — the large rounds of the interactive path are VALU-bound too.
 #define VP_BIG_PAIRS 32768
-// pairs of workgroup `bid` of `nb`: folds, stores, and leaves the three block sums in thread 0's acc
+__device__ __forceinline__ F fold_entry(const F &e0, const F &e1, const F &r) { return f_mad_c(r, f_sub_lazy(e1, e0), e0); }     // e0 + r (e1 - e0), canonical
+// pairs of workgroup `bid` of `nb`: folds, stores, and leaves the block sums (X, Y, Z) in thread 0's acc
 __device__ __forceinline__ void round_main_body(const RoundArgs &a, u32 bid, u32 nb, F (&acc)[3], F *lds) {
     const F r = a.rp ? *a.rp : a.rv;
+    Lz X{0, 0}, Y{0, 0}, Z{0, 0};
     for (u32 q = bid * blockDim.x + threadIdx.x; q < a.total_pairs; q += nb * blockDim.x) {
         int j = 0;
         while (j + 1 < a.n_tab && q >= a.t[j + 1].pair_start) ++j;
@@ -411,10 +437,10 @@ __device__ __forceinline__ void round_main_body(const RoundArgs &a, u32 bid, u32
             const u32 vo = (td.valid_in + 1) >> 1;            // valid length of the folded table
             F e0 = ld_or_zero(a.inV, i0, vi), e1 = ld_or_zero(a.inV, i0 + 1, vi);
             F e2 = ld_or_zero(a.inV, i0 + 2, vi), e3 = ld_or_zero(a.inV, i0 + 3, vi);
-            v0 = f_lerp(e0, e1, r); v1 = f_lerp(e2, e3, r);
+            v0 = fold_entry(e0, e1, r); v1 = fold_entry(e2, e3, r);
             e0 = ld_or_zero(a.inM, i0, vi); e1 = ld_or_zero(a.inM, i0 + 1, vi);
             e2 = ld_or_zero(a.inM, i0 + 2, vi); e3 = ld_or_zero(a.inM, i0 + 3, vi);
-            m0 = f_lerp(e0, e1, r); m1 = f_lerp(e2, e3, r);
+            m0 = fold_entry(e0, e1, r); m1 = fold_entry(e2, e3, r);
             const u32 o0 = td.off + 2 * p;
             const bool w1 = 2 * p + 1 < vo;
             a.outV[o0] = v0; a.outM[o0] = m0;
@@ -422,7 +448,7 @@ __device__ __forceinline__ void round_main_body(const RoundArgs &a, u32 bid, u32
             if (a.has_a) {
                 e0 = ld_or_zero(a.inA, i0, vi); e1 = ld_or_zero(a.inA, i0 + 1, vi);
                 e2 = ld_or_zero(a.inA, i0 + 2, vi); e3 = ld_or_zero(a.inA, i0 + 3, vi);
-                a0 = f_lerp(e0, e1, r); a1 = f_lerp(e2, e3, r);
+                a0 = fold_entry(e0, e1, r); a1 = fold_entry(e2, e3, r);
                 a.outA[o0] = a0;
                 if (w1) a.outA[o0 + 1] = a1;
             }
@@ -433,26 +459,17 @@ __device__ __forceinline__ void round_main_body(const RoundArgs &a, u32 bid, u32
             if (a.has_a) { a0 = ld_or_zero(a.inA, i0, vi); a1 = ld_or_zero(a.inA, i0 + 1, vi); }
         }
         // mult(x)*V(x) + add(x) with X(x) = X0 + x*(X1-X0): Karatsuba on the two evaluation points
-        const F dm = f_sub(m1, m0), dv = f_sub(v1, v0);
-        const F qa = f_mul(dm, dv), qc = f_mul(m0, v0), qe = f_mul(m1, v1);
-        acc[0] = f_add(acc[0], qa);
-        acc[1] = f_add(acc[1], f_add(f_sub(f_sub(qe, qa), qc), f_sub(a1, a0)));
-        acc[2] = f_add(acc[2], f_add(qc, a0));
+        lz_add(X, f_mad_lazy<true>(f_sub_lazy(m1, m0), f_sub_lazy(v1, v0), f_zero()));
+        lz_add(Y, f_mad_c<true>(m1, v1, a1));
+        lz_add(Z, f_mad_c<true>(m0, v0, a0));
+        lz_fold(X); lz_fold(Y); lz_fold(Z);
     }
+    acc[0] = lz_canon(X); acc[1] = lz_canon(Y); acc[2] = lz_canon(Z);
     block_sum<3>(acc, lds);
 }
-template <int CLS>
-__global__ void __launch_bounds__(VP_BLOCK) k_round_main(RoundArgs a, F *__restrict__ part) {
-    __shared__ F lds[12];
-    F acc[3] = {f_zero(), f_zero(), f_zero()};
-    round_main_body(a, blockIdx.x, gridDim.x, acc, lds);
-    if (threadIdx.x == 0) {
-        part[blockIdx.x * 3 + 0] = acc[0];
-        part[blockIdx.x * 3 + 1] = acc[1];
-        part[blockIdx.x * 3 + 2] = acc[2];
-    }
-}
 
+// (X, Y, Z) of the whole round -> the round polynomial: retires the tables that have just reached length one into add_term
+// (src/prover.cpp:445,462-467), adds add_term*(1-x) (:448) and emits the polynomial to the device transcript and, if given, to pinned host memory.
 __device__ __forceinline__ void round_final_tail(const RoundArgs &a, const F (&acc)[3], F *add_term, F *scalarV, F *poly_dev, F *poly_host,
                                                  unsigned long long *seq_host, unsigned long long seq) {
     const F r = a.rp ? *a.rp : a.rv;
@@ -476,7 +493,7 @@ __device__ __forceinline__ void round_final_tail(const RoundArgs &a, const F (&a
         at = f_add(at, f_add(f_mul(v, m), ad));
     }
     *add_term = at;
-    const F pa = acc[0], pb = f_sub(acc[1], at), pc = f_add(acc[2], at);
+    const F pa = acc[0], pb = f_sub(f_sub(f_sub(acc[1], acc[0]), acc[2]), at), pc = f_add(acc[2], at);
     poly_dev[0] = pa; poly_dev[1] = pb; poly_dev[2] = pc;
     if (poly_host) {
         poly_host[0] = pa; poly_host[1] = pb; poly_host[2] = pc;
@@ -485,22 +502,46 @@ __device__ __forceinline__ void round_final_tail(const RoundArgs &a, const F (&a
     }
 }
 
-// Closing kernel of a round (one block): sums the block partials, retires the tables that have just
-// reached length one into add_term (src/prover.cpp:445,462-467), adds add_term*(1-x) (:448) and emits
-// the round polynomial to the device transcript and, if given, to pinned host memory.
-__global__ void __launch_bounds__(VP_BLOCK)
-k_round_final(RoundArgs a, const F *__restrict__ part, u32 n_part, F *add_term, F *scalarV, F *poly_dev,
-              F *poly_host, unsigned long long *seq_host, unsigned long long seq) {
+// What the closing launch of a round needs besides the sums
+struct RoundOut { F *add_term, *scalarV, *poly_dev, *poly_host; unsigned long long *seq_host; unsigned long long seq; };
+
+// Round 3: the workgroup that finishes LAST closes the round itself (no second launch: a round of the interactive path with more pairs than one
+// workgroup takes cost two dependent launches, ~5 us of every such vp_round).  Every workgroup leaves its three sums with agent-scope stores
+// (workgroups sit on different XCDs behind different L2s), makes sure they are out, and counts itself in; the one that reads n - 1 adds up all
+// n triples (agent-scope loads), resets the counter for the next round and runs round_final_tail.
+template <int CLS>
+__global__ void __launch_bounds__(VP_BLOCK) k_round_main(RoundArgs a, F *__restrict__ part, unsigned int *__restrict__ arrivals, RoundOut o) {
     __shared__ F lds[12];
+    __shared__ int s_last;
     F acc[3] = {f_zero(), f_zero(), f_zero()};
-    for (u32 i = threadIdx.x; i < n_part; i += blockDim.x) {
-        acc[0] = f_add(acc[0], part[3 * i]);
-        acc[1] = f_add(acc[1], part[3 * i + 1]);
-        acc[2] = f_add(acc[2], part[3 * i + 2]);
+    round_main_body(a, blockIdx.x, gridDim.x, acc, lds);
+    if (threadIdx.x == 0) {
+        unsigned long long *w = reinterpret_cast<unsigned long long *>(part + (size_t) blockIdx.x * 3);
+        cf_st(w, acc[0].re); cf_st(w + 1, acc[0].im); cf_st(w + 2, acc[1].re); cf_st(w + 3, acc[1].im); cf_st(w + 4, acc[2].re); cf_st(w + 5, acc[2].im);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // the sums are out before they are counted
+        s_last = __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
     }
-    block_sum<3>(acc, lds);
+    __syncthreads();
+    if (!s_last) return;                                                       // uniform per workgroup
+    F t[3] = {f_zero(), f_zero(), f_zero()};
+    for (u32 i = threadIdx.x; i < gridDim.x; i += blockDim.x) {
+        const unsigned long long *w = reinterpret_cast<const unsigned long long *>(part + (size_t) i * 3);
+        t[0] = f_add(t[0], f_make(cf_ld(w), cf_ld(w + 1)));
+        t[1] = f_add(t[1], f_make(cf_ld(w + 2), cf_ld(w + 3)));
+        t[2] = f_add(t[2], f_make(cf_ld(w + 4), cf_ld(w + 5)));
+    }
+    __syncthreads();                                                           // lds is free again
+    block_sum<3>(t, lds);
     if (threadIdx.x != 0) return;
-    round_final_tail(a, acc, add_term, scalarV, poly_dev, poly_host, seq_host, seq);
+    __hip_atomic_store(arrivals, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    round_final_tail(a, t, o.add_term, o.scalarV, o.poly_dev, o.poly_host, o.seq_host, o.seq);
+}
+
+// Closing kernel of a round without pairs (every live table has a single entry left): one block, nothing to sum.
+__global__ void __launch_bounds__(VP_BLOCK) k_round_final(RoundArgs a, RoundOut o) {
+    if (threadIdx.x != 0) return;
+    const F z[3] = {f_zero(), f_zero(), f_zero()};
+    round_final_tail(a, z, o.add_term, o.scalarV, o.poly_dev, o.poly_host, o.seq_host, o.seq);
 }
 // A round whose pairs fit one workgroup: fold + sums + closing in ONE launch (most rounds of a proof are this small; the
 // per-round path pays launch latency, not bandwidth).

@@ -121,6 +121,7 @@ struct vp_ctx {
     F *tab[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
     u32 cap = 0;
     F *partials = nullptr;
+    unsigned int *round_arrivals = nullptr;       // k_round_main: workgroups that have left their sums (zero between rounds)
     F *small = nullptr;          // [0]=0 [1]=1 [2]=add_term [3]=V_u [4..27]=coef [32..95]=scalarV [96..]=chunk partials ptr elsewhere
     F *chunk_part = nullptr; u32 chunk_cap = 0;
     F *d_tape = nullptr; u64 n_tape = 0;
@@ -440,18 +441,17 @@ int do_round(vp_ctx *ctx, const F *rp, const F &rv, F *poly_dev, F *poly_host) {
         ++ctx->st.rounds;
         return VP_OK;
     }
-    u32 grid = 0;
-    if (pairs) {
-        grid = grid_for(pairs);
+    const RoundOut ro{ctx->add_term(), ctx->scalarV(), poly_dev, poly_host, (poly_host && ctx->poll) ? ctx->h_seq : nullptr, ++ctx->seq};
+    if (pairs) {                         // the workgroup that finishes last closes the round (k_round_main)
+        const u32 grid = grid_for(pairs);
         const bool big = pairs >= VP_BIG_PAIRS;
         const int sl = big ? prof_begin(ctx, ctx->stream, VP_K_ROUND, grid, 1, bytes, pairs, 1, (u32) k) : -1;
-        if (big) hipLaunchKernelGGL(k_round_main<1>, dim3(grid), dim3(VP_BLOCK), 0, ctx->stream, a, ctx->partials);
-        else hipLaunchKernelGGL(k_round_main<0>, dim3(grid), dim3(VP_BLOCK), 0, ctx->stream, a, ctx->partials);
+        if (big) hipLaunchKernelGGL(k_round_main<1>, dim3(grid), dim3(VP_BLOCK), 0, ctx->stream, a, ctx->partials, ctx->round_arrivals, ro);
+        else hipLaunchKernelGGL(k_round_main<0>, dim3(grid), dim3(VP_BLOCK), 0, ctx->stream, a, ctx->partials, ctx->round_arrivals, ro);
         prof_end(ctx, ctx->stream, sl);
-        count_launch(ctx);
+    } else {
+        hipLaunchKernelGGL(k_round_final, dim3(1), dim3(VP_BLOCK), 0, ctx->stream, a, ro);
     }
-    hipLaunchKernelGGL(k_round_final, dim3(1), dim3(VP_BLOCK), 0, ctx->stream, a, ctx->partials, grid, ctx->add_term(),
-                       ctx->scalarV(), poly_dev, poly_host, (poly_host && ctx->poll) ? ctx->h_seq : nullptr, ++ctx->seq);
     count_launch(ctx);
     s.round = k;
     ++ctx->st.rounds;
@@ -872,6 +872,7 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
     VPCHK(dalloc(ctx, &ctx->bs, (size_t) ctx->half_cap));
     VPCHK(dalloc(ctx, &ctx->liu_half, (size_t) 2 * (n_layers + 1) * ctx->half_cap));
     VPCHK(dalloc(ctx, &ctx->partials, (size_t) 3 * MAX_BLOCKS));
+    VPCHK(dalloc(ctx, &ctx->round_arrivals, (size_t) 16)); HIPCHK(hipMemsetAsync(ctx->round_arrivals, 0, 64, ctx->stream));
     VPCHK(dalloc(ctx, &ctx->chunk_part, (size_t) 2 * std::max<u32>(1, ctx->chunk_cap)));
     VPCHK(dalloc(ctx, &ctx->small, (size_t) 32 + VP_MAX_TAB));
     VPCHK(dalloc(ctx, &ctx->d_flag, (size_t) 1));
