@@ -417,6 +417,48 @@ def gkr_leg(vp, circ, sess, steps, warmup, world, shard, local):
     return tr, res, elapsed, dev_ms
 
 
+def two_in_flight_leg(vp, circ, sess, tr_expected, steps, warmup, local, ref_ops):
+    """Throughput of a prover that serves a QUEUE of proofs of one circuit: two sessions (two contexts, each with its own tables, tape and launch
+    plan) driven by two host threads, so that one proof's latency tail (the single-workgroup closing launches, the ramp of its first launches)
+    is filled by the other proof's kernels.  Not the headline: `value` stays one proof at a time; this is the same work, 2 x steps proofs,
+    timed as a whole.  Both sessions' transcripts are compared with the headline's."""
+    import threading
+    other = vp.Session(circ, device=local)
+    other.draw_tape()
+    pair = (sess, other)
+    for s_ in pair:
+        for _ in range(max(1, warmup)):
+            s_.prove_gkr()
+    out = [None, None]
+    err = []
+
+    def run(i):
+        try:
+            tr = None
+            for _ in range(steps):
+                tr, _ = pair[i].prove_gkr()
+            out[i] = tr
+        except Exception as e:                                  # a failed thread must not look like a fast one
+            err.append(repr(e))
+
+    gpu_sync(local)
+    th = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    gpu_sync(local)
+    wall = time.perf_counter() - t0
+    other.close()
+    ok = not err and out[0] == tr_expected and out[1] == tr_expected
+    return {"proofs_in_flight": 2, "proofs": 2 * steps, "wall_sec": wall, "ms_per_proof": 1e3 * wall / (2 * steps),
+            "value": (ref_ops * 2 * steps / wall) if (ref_ops and ok) else None, "unit": "field-ops/s",
+            "transcripts_equal_headline": bool(ok), "errors": err or None,
+            "note": "two sessions of the same circuit on one GPU, one host thread each (the C ABI is one context per thread); a proof's latency is "
+                    "unchanged (prover_sec), the GPU's idle tails are filled"}
+
+
 def x1024_leg(vp, pws, golden, a, local):
     """BASELINE.json configs[2]: SHA-256 1024-block circuit (102 M gates, 859 rounds, tables up to 2^26), sumcheck + Virgo commitment
     on ONE MI355X — the largest single-GPU configuration, as a nested leg of the default run.  Same contract as the headline leg:
@@ -653,6 +695,7 @@ def main():
     ap.add_argument("--no-x1024-leg", action="store_true",
                     help="skip the nested x1024_with_pc leg (BASELINE configs[2]) that the default single-GPU run appends to the x64 headline line")
     ap.add_argument("--per-launch", action="store_true", help="include the per-launch table of the headline leg (and every interactive round) in the JSON line (the per-kernel table is always there)")
+    ap.add_argument("--no-two-in-flight", action="store_true", help="N = 1: skip the `two_in_flight` sub-leg (two sessions of the circuit, two host threads)")
     ap.add_argument("--no-sharded-leg", action="store_true", help="N > 1: skip the `sharded` sub-leg (one proof + its commitment over all ranks, RCCL)")
     ap.add_argument("--subleg-timeout", type=float, default=900.0, help="N > 1: seconds the multi-rank sub-legs may take before the line is printed without them")
     a = ap.parse_args()
@@ -762,6 +805,11 @@ def main():
                          "assembled_equals_unsharded": assembled == tr,
                          "note": "each shard run alone on this GPU; a W-GPU run adds one all-reduce of the transcript (and, with the index split, of the export area) per proof"}
 
+        pipelined = None
+        if rank == 0 and world == 1 and not shard and not a.no_two_in_flight:
+            g_ = golden.get(gname)
+            pipelined = two_in_flight_leg(vp, circ, sess, tr, a.steps, a.warmup, local, (g_["mult_counter"] + g_["add_counter"]) if g_ else None)
+
         interactive = None
         if rank == 0:
             # the drop-in path of the reference's own call pattern (one vp_round per verifier message), outside the timed region
@@ -818,6 +866,7 @@ def main():
                 "bit_exact_vs_reference_golden": bit_exact, "host_verifier_accepts": bool(ok),
                 "host_verifier_check": "full replay: per-round identities, wiring predicates + getFinalValue (device loops), Liu check, input-layer check",
                 "golden_origin": (golden[gname].get("origin", "the real reference binary (oracle/_ref/ref_run)") if gname in golden else None),
+                "two_in_flight": pipelined,
                 "interactive_path": interactive, "circuit_upload_sec": upload_sec, "process_first_use_sec": first_use_sec, "verifier": verify,
                 "roofline": roof, "kernels": rows,
             }
