@@ -455,7 +455,7 @@ def two_in_flight_leg(vp, circ, sess, tr_expected, steps, warmup, local, ref_ops
     return {"proofs_in_flight": 2, "proofs": 2 * steps, "wall_sec": wall, "ms_per_proof": 1e3 * wall / (2 * steps),
             "value": (ref_ops * 2 * steps / wall) if (ref_ops and ok) else None, "unit": "field-ops/s",
             "transcripts_equal_headline": bool(ok), "errors": err or None,
-            "note": "two sessions of the same circuit on one GPU, one host thread each (the C ABI is one context per thread); a proof's latency is "
+            "note": "two sessions of the same circuit on one GPU, one host thread each (include/vpgpu.h, Threads: different contexts run concurrently); a proof's latency is "
                     "unchanged (prover_sec), the GPU's idle tails are filled"}
 
 

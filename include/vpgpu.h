@@ -169,7 +169,12 @@ int vp_vres(vp_ctx *, const vp_F *r_0, int r_0_size, vp_F *out);
  *     counter, add_term) is saved to device memory, the CU is released, device-wide synchronising HIP calls of that other context
  *     (hipMalloc / hipFree of an upload or a destroy) proceed at once — and left alone for persistent_timeout_ms it suspends itself the
  *     same way; this context's next vp_round / vp_finalize relaunches it on the saved phase and the sumcheck continues (bit-identical
- *     transcript).  Contexts of one process are driven from one thread, or the caller serialises its calls.
+ *     transcript).
+ *     Threads: every entry point holds its context's lock for the duration of the call — calls on one context are serialised, calls on
+ *     different contexts run concurrently (two proofs in flight from two threads).  An entry point that suspends another context's resident
+ *     kernel waits for that context's current call to return first; the set-up entry points (vp_create*, vp_circuit_upload, vp_comm_*) take
+ *     turns among themselves (they park the process-wide random() state).  vp_destroy of a context another thread is still calling into is
+ *     the caller's bug, as is vp_shard_exchange_local on contexts other threads are using.
  * prover::sumcheckInitPhase1(assert_random) for layer `layer` (src/prover.cpp:189-280).  r_liu is the
  * point the layer's claim is at (bit_length(layer) entries; prover::r_liu in the reference).           */
 int vp_phase1_init(vp_ctx *, int layer, const vp_F *r_liu, const vp_F *assert_random);
@@ -360,6 +365,9 @@ typedef struct {
     double us;
 } vp_round_stat;
 int vp_get_round_stats(vp_ctx *, vp_round_stat *out, int capacity, int *n);
+/* How many times this context's resident round kernel has been relaunched on a saved phase (suspended by another context's call, or by its
+ * own time-out) since vp_create. */
+int vp_get_resident_resumes(const vp_ctx *, uint64_t *n);
 /* 0: no per-kernel events (default); 1: the next vp_prove_gkr replays its launch plan on ONE stream and brackets EVERY
  * launch with hipEvents (in the default run the launches of independent sumchecks overlap on several streams, so
  * per-kernel times would be meaningless there); vp_commit_private / vp_commit_public / vp_fri_commit bracket their

@@ -1133,6 +1133,72 @@ def test_resident_kernel_yields_to_another_context_and_resumes(vp, where):
     s.close(); c.close()
 
 
+def test_contexts_on_different_threads(vp, gold_gkr, pws_path):
+    """include/vpgpu.h, "Threads": calls on one context are serialised by the context's lock, different contexts run concurrently.  Three
+    threads at once on the x16 circuit: two INTERACTIVE proofs (each phase's resident round kernel is suspended whenever the other thread's
+    init call — or the third thread's session set-up — needs the device, and resumes), and a thread that creates a session, proves in
+    batched mode and destroys it, over and over.  The verifier's challenges come from the process-wide random() stream, as in the reference,
+    so with three threads drawing from it the transcripts are not the golden ones: every proof has to pass the full verification instead
+    (per-round identities, wiring predicates, Liu and input checks), and the sessions used afterwards, alone, reproduce the golden transcript."""
+    import threading
+    c = vp.Circuit.from_pws(pws_path, 16, seed=1)
+    gold = gold_gkr("sha256_x16")
+    out, err = {}, []
+    stop = threading.Event()
+    ready = threading.Barrier(3)
+
+    def interactive(name):
+        try:
+            s = vp.Session(c)
+            ready.wait(timeout=120)                        # set-up calls take turns; the proofs below are what has to overlap
+            n = 0
+            while n < 3 or not stop.is_set():
+                tr, _, ok = s.prove_interactive()
+                assert ok and len(tr) == len(gold), name
+                n += 1
+                if n >= 400:
+                    break
+            out[name] = (s, s.tail_resumes())
+        except BaseException as e:                         # noqa: B036 - the main thread reports it
+            err.append((name, repr(e)))
+
+    def churn():
+        try:
+            n = 0
+            ready.wait(timeout=120)
+            while n < 6:
+                s = vp.Session(c)
+                s.draw_tape()
+                tr, _ = s.prove_gkr()
+                ok, _ = s.check(tr, device_predicates=True)
+                assert ok and len(tr) == len(gold)
+                s.close()
+                n += 1
+            out["churn"] = n
+        except BaseException as e:                         # noqa: B036
+            err.append(("churn", repr(e)))
+        finally:
+            stop.set()
+
+    th = [threading.Thread(target=interactive, args=("a",)), threading.Thread(target=interactive, args=("b",)), threading.Thread(target=churn)]
+    for t in th:
+        t.start()
+    th[2].join(timeout=300)
+    stop.set()
+    for t in th[:2]:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in th), "a thread is stuck (lock cycle?)"
+    assert not err, err
+    assert out["churn"] >= 1 and out["a"][1] + out["b"][1] > 0, out    # the resident kernels really were suspended and resumed
+    for name in ("a", "b"):                                            # alone again: the reference's stream, the reference's transcript
+        s = out[name][0]
+        s2 = vp.Session(c)
+        tr, _, ok = s2.prove_interactive()
+        assert ok and tr == gold
+        s2.close(); s.close()
+    c.close()
+
+
 def test_resident_kernel_times_out_saves_its_phase_and_resumes(vp):
     """A verifier that falls silent (debugger, SIGSTOP, a loaded host) for longer than persistent_timeout_ms: the resident kernel saves its
     phase and releases the CU by itself; when the verifier comes back the phase continues — it used to be lost (VP_EHIP)."""

@@ -108,6 +108,7 @@ def lib_gpu():
         L.vp_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
         L.vp_create_with_options.argtypes = [ctypes.c_int, vp, ctypes.POINTER(vp)]
         L.vp_get_options.argtypes = [vp, vp]
+        L.vp_get_resident_resumes.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
         L.vp_set_shard_split.argtypes = [vp, ctypes.c_int]
         L.vp_shard_finish.argtypes = [vp, vp, ctypes.c_uint64, vp]
         L.vp_gkr_sizes.argtypes = [vp, vp, vp]
@@ -628,6 +629,13 @@ class Session:
     def commit_device_ms(self):
         """Device milliseconds (HIP events) of the last commit_private / commit_public / fri_commit call."""
         return float(lib_host().vph_commit_device_ms(self.h))
+
+    def tail_resumes(self):
+        """vp_get_resident_resumes: relaunches of this session's resident round kernel on a saved phase."""
+        n = ctypes.c_uint64(0)
+        if lib_gpu().vp_get_resident_resumes(lib_host().vph_session_ctx(self.h), ctypes.byref(n)):
+            raise RuntimeError("vp_get_resident_resumes failed")
+        return int(n.value)
 
     def options_in_effect(self):
         """vp_get_options: the configuration this session runs with (after the plan tuner, once a proof has run)."""

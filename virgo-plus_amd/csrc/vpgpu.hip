@@ -191,6 +191,7 @@ struct vp_ctx {
                                       // launch slower (x1024 4.7 vs 3.5 ms: two more barriers per chunk at 3 workgroups per CU) -> off by default
     Plan *plan = nullptr; int plan_path = 1;   // VP_GKR_PATH=lanes: one stream per sumcheck chain instead of the plan
     // hipGraph of the concurrent GKR submission (per circuit; VP_GKR_GRAPH=0 submits the launches directly)
+    std::recursive_mutex mu;         // held by every entry point for the duration of its call (CtxLock)
     bool plan_tuned = false;         // the plan layouts have been tried on this circuit (plan_autotune)
     uint32_t opt_pinned = 0;         // tuner fields the caller (struct or environment) moved off their defaults: bit 0 fuse_combine, 1 fold_branches,
                                      // 2 plan_align, 3 fuse_min_log, 4 sf3b_grid — plan_autotune leaves those alone
@@ -237,7 +238,23 @@ int tail_quit(vp_ctx *ctx);
 // ... and the resident kernels of the OTHER contexts of this process are suspended (phase saved, resumed by their next vp_round): device-wide
 // synchronising HIP calls — hipMalloc / hipFree of an upload, a destroy — would otherwise wait behind them for up to their time-out.
 void vp_suspend_others(vp_ctx *ctx);
-#define VP_ENTER(ctx) do { HIPCHK(hipSetDevice((ctx)->device)); if ((ctx)->tail_active) (void) tail_quit(ctx); (ctx)->tail_suspended = false; (ctx)->tail_lost = false; vp_suspend_others(ctx); } while (0)
+// Threads.  Every entry point holds its context's lock for the duration of the call: calls on ONE context are serialised, calls on DIFFERENT
+// contexts run concurrently (two proofs in flight from two threads).  The outermost entry point of a thread that may synchronise the device first
+// suspends the other contexts' resident kernels — BEFORE it takes its own lock, and taking each other context's lock only while it suspends it
+// (so it waits for that context's current call to return): no thread ever holds one context's lock while it waits for another's or for the
+// registry's, which is what rules out a cycle.
+static thread_local int tl_entry_depth = 0;
+struct CtxLock {
+    vp_ctx *c;
+    CtxLock(vp_ctx *ctx, bool suspend_others) : c(ctx) {
+        if (suspend_others && tl_entry_depth == 0) vp_suspend_others(ctx);
+        c->mu.lock(); ++tl_entry_depth;
+    }
+    ~CtxLock() { --tl_entry_depth; c->mu.unlock(); }
+    CtxLock(const CtxLock &) = delete; CtxLock &operator=(const CtxLock &) = delete;
+};
+#define VP_LOCK(ctx) CtxLock vp_ctx_lock_(ctx, false)
+#define VP_ENTER(ctx) CtxLock vp_ctx_lock_(ctx, true); do { HIPCHK(hipSetDevice((ctx)->device)); if ((ctx)->tail_active) (void) tail_quit(ctx); (ctx)->tail_suspended = false; (ctx)->tail_lost = false; } while (0)
 
 constexpr u32 MAX_BLOCKS = 2048;     // 256 CUs x 8 resident 256-thread blocks
 
@@ -549,15 +566,18 @@ int tail_resume(vp_ctx *ctx, bool already_sent) {
     ctx->tail_active = true; ctx->tail_suspended = false; ++ctx->tail_resumes;
     return VP_OK;
 }
-// every live context of the process (vp_create .. vp_destroy).  Contexts are driven from one thread (the reference is single-threaded), or the
-// caller serialises its calls: the registry is locked, the mailboxes are not.
+// every live context of the process (vp_create .. vp_destroy).  Called without any context lock held (CtxLock): the registry lock, then one
+// other context's lock at a time — the wait is for that context's current call to return.
 static std::mutex g_ctx_mu;
 static std::vector<vp_ctx *> g_ctxs;
 void vp_suspend_others(vp_ctx *ctx) {
     std::lock_guard<std::mutex> lk(g_ctx_mu);
     bool any = false;
-    for (vp_ctx *o : g_ctxs)
-        if (o != ctx && o->tail_active) { (void) hipSetDevice(o->device); (void) tail_suspend(o); any = true; }
+    for (vp_ctx *o : g_ctxs) {
+        if (o == ctx) continue;
+        std::lock_guard<std::recursive_mutex> lo(o->mu);
+        if (o->tail_active) { (void) hipSetDevice(o->device); (void) tail_suspend(o); any = true; }
+    }
     if (any) (void) hipSetDevice(ctx->device);
 }
 
@@ -732,10 +752,13 @@ int vp_get_options(const vp_ctx *ctx, vp_options *out) {
 // generator while it initialises (measured through the reference binary of INTEGRATION.md: vp_create shifted the stream, the proof still
 // verified but was no longer the CPU reference's).  The set-up entry points therefore run on a private generator state and hand the caller's
 // back untouched.
+// (The generator state is process-wide: two threads inside set-up entry points at once would hand each other's private state back.  They take
+// turns: one lock around every RandKeep.)
+static std::recursive_mutex g_rand_mu;
 struct RandKeep {
     char priv[128]; char *caller;
-    RandKeep() { memset(priv, 0, sizeof priv); caller = initstate(1u, priv, sizeof priv); }
-    ~RandKeep() { if (caller) setstate(caller); }
+    RandKeep() { g_rand_mu.lock(); memset(priv, 0, sizeof priv); caller = initstate(1u, priv, sizeof priv); }
+    ~RandKeep() { if (caller) setstate(caller); g_rand_mu.unlock(); }
 };
 
 int vp_create_with_options(int device, const vp_options *user, vp_ctx **out) {
@@ -780,10 +803,12 @@ void vp_free_fgk(vp_ctx *ctx);
 
 void vp_destroy(vp_ctx *ctx) {
     if (!ctx) return;
+    if (tl_entry_depth == 0) vp_suspend_others(ctx);          // the hipFree calls below synchronise the device
+    // out of the registry first (no other thread can reach the context any more), then through its lock once (a suspender that had it is gone)
+    { std::lock_guard<std::mutex> lk(g_ctx_mu); g_ctxs.erase(std::remove(g_ctxs.begin(), g_ctxs.end(), ctx), g_ctxs.end()); }
+    { std::lock_guard<std::recursive_mutex> lo(ctx->mu); }
     (void) hipSetDevice(ctx->device);
     if (ctx->tail_active) (void) tail_quit(ctx);
-    vp_suspend_others(ctx);                                   // the hipFree calls below synchronise the device
-    { std::lock_guard<std::mutex> lk(g_ctx_mu); g_ctxs.erase(std::remove(g_ctxs.begin(), g_ctxs.end(), ctx), g_ctxs.end()); }
     (void) hipStreamSynchronize(ctx->stream);
     vp_free_shard_state(ctx);
     vp_free_comm(ctx);
@@ -1242,7 +1267,9 @@ static int vp_round_impl(vp_ctx *ctx, const vp_F *previous_random, vp_F out_poly
 // The round as the caller sees it: wall time of the call and the ALGORITHMIC bytes of the round (48 B x (L_in + L_out) per table
 // family with an add table, 32 B without; round 1 only reads) -> achieved GB/s per sumcheck round (vp_get_round_stats).
 int vp_round(vp_ctx *ctx, const vp_F *previous_random, vp_F out_poly[3]) {
-    if (!ctx || !previous_random || !out_poly || ctx->sc.phase == 0) return VP_EINVAL;
+    if (!ctx || !previous_random || !out_poly) return VP_EINVAL;
+    VP_LOCK(ctx);                                             // no device-wide call in here: other contexts' resident kernels stay where they are
+    if (ctx->sc.phase == 0) return VP_EINVAL;
     const auto t0 = std::chrono::steady_clock::now();
     int how = 0;
     const int rc = vp_round_impl(ctx, previous_random, out_poly, &how);
@@ -1318,7 +1345,9 @@ static int vp_round_impl(vp_ctx *ctx, const vp_F *previous_random, vp_F out_poly
 }
 
 int vp_finalize(vp_ctx *ctx, const vp_F *previous_random, vp_F *claims, int n_claims) {
-    if (!ctx || !previous_random || !claims || ctx->sc.phase == 0 || n_claims != ctx->sc.n_tab) return VP_EINVAL;
+    if (!ctx || !previous_random || !claims) return VP_EINVAL;
+    VP_LOCK(ctx);
+    if (ctx->sc.phase == 0 || n_claims != ctx->sc.n_tab) return VP_EINVAL;
     HIPCHK(hipSetDevice(ctx->device));
     F rv; memcpy(&rv, previous_random, sizeof(F));
     if (rv.re >= P61 || rv.im >= P61) { ctx->err = "vp_finalize: previous_random is not canonical (limb >= 2^61 - 1)"; return VP_EINVAL; }
@@ -1473,6 +1502,11 @@ int vp_prove_gkr(vp_ctx *ctx, const vp_F *tape, uint64_t n_tape, uint8_t *transc
 int vp_get_stats(vp_ctx *ctx, vp_stats *out) {
     if (!ctx || !out) return VP_EINVAL;
     *out = ctx->st;
+    return VP_OK;
+}
+int vp_get_resident_resumes(const vp_ctx *ctx, uint64_t *n) {
+    if (!ctx || !n) return VP_EINVAL;
+    *n = ctx->tail_resumes;
     return VP_OK;
 }
 int vp_get_round_stats(vp_ctx *ctx, vp_round_stat *out, int capacity, int *n) {
