@@ -9,6 +9,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -129,7 +130,7 @@ struct vp_ctx {
     F *h_pin = nullptr;                   // pinned: [0..2] poly, [3] vres, [4..4+64) claims
     unsigned long long *h_seq = nullptr, seq = 0;     // pinned ticket the closing kernels of the per-round path publish
     // persistent round kernel of the interactive path (vp_kernels_persist.h): mailbox in pinned host memory
-    TailMail *h_req = nullptr; TailReply *h_rep = nullptr; bool tail_active = false; unsigned long long tail_seq = 0; int tail_enabled = 1;
+    TailMail *h_req = nullptr; TailReply *h_rep = nullptr; std::atomic<bool> tail_active{false}; unsigned long long tail_seq = 0; int tail_enabled = 1;
     // suspend / resume of the resident round kernel (vp_kernels_persist.h): its last launch arguments, the device buffer it saves a phase
     // into, and whether such a saved phase is waiting for the next vp_round / vp_finalize
     PTailArgs tail_args{}; F *tail_save = nullptr; bool tail_suspended = false, tail_lost = false; u64 tail_resumes = 0;
@@ -574,7 +575,10 @@ void vp_suspend_others(vp_ctx *ctx) {
     std::lock_guard<std::mutex> lk(g_ctx_mu);
     bool any = false;
     for (vp_ctx *o : g_ctxs) {
-        if (o == ctx) continue;
+        // a context without a resident kernel is nobody's obstacle: passed without its lock (two batched proofs on two threads must not take
+        // turns).  Should its owner launch one a moment later, the device-wide call of this thread waits for that phase as it would have
+        // before round 3 — at most until the kernel's own time-out suspends it.
+        if (o == ctx || !o->tail_active.load(std::memory_order_acquire)) continue;
         std::lock_guard<std::recursive_mutex> lo(o->mu);
         if (o->tail_active) { (void) hipSetDevice(o->device); (void) tail_suspend(o); any = true; }
     }
