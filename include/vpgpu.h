@@ -118,7 +118,7 @@ typedef struct {
                                        different chains share a node depends on the chains' alignment, and with the step removed the replay was
                                        slower at x64 (0.61 -> 0.64 ms) although a node had gone; 0: separate k_combine node       [2] */
     int32_t plan_autotune;          /* VP_PLAN_AUTOTUNE: the first vp_prove_gkr of a circuit replays the launch plan in the few layouts that fuse_combine,
-                                       fold_branches and plan_align offer, then with fuse_min_log one step either way and with sf3b_grid 384 / 320, and
+                                       fold_branches and plan_align offer, then with fuse_min_log one step either way, with sf3b_grid 384 / 320 and with graph_explicit, and
                                        keeps the fastest for this circuit (one-off: a plan, a graph capture and six replays per candidate; a candidate
                                        that does not build is skipped; the transcript does not depend on the choice).  A field named here that the
                                        caller (struct or environment) moved off its default is taken as given, the tuner only chooses among the
@@ -129,6 +129,10 @@ typedef struct {
                                        transforms per commitment.  0: always encode all 64 slices                                    [1] */
     int32_t persistent_timeout_ms;  /* VP_PERSIST_TIMEOUT_MS: how long the resident round kernel waits for the verifier's next message before it saves
                                        its phase and leaves the CU; the next vp_round / vp_finalize relaunches it on the saved phase              [10000] */
+    int32_t graph_explicit;         /* VP_GRAPH_EXPLICIT: the launch plan's hipGraph is built node by node with exactly the plan's dependencies
+                                       (hipGraphAddKernelNode) instead of captured from four streams, where the order of unrelated launches on a stream
+                                       becomes a dependency too.  Faster or slower depending on the circuit (the runtime places the branches of such a
+                                       graph itself): plan_autotune tries it last and keeps what replays faster                               [0] */
 } vp_options;
 void vp_options_default(vp_options *opt);
 

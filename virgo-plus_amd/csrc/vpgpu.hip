@@ -195,7 +195,7 @@ struct vp_ctx {
     std::recursive_mutex mu;         // held by every entry point for the duration of its call (CtxLock)
     bool plan_tuned = false;         // the plan layouts have been tried on this circuit (plan_autotune)
     uint32_t opt_pinned = 0;         // tuner fields the caller (struct or environment) moved off their defaults: bit 0 fuse_combine, 1 fold_branches,
-                                     // 2 plan_align, 3 fuse_min_log, 4 sf3b_grid — plan_autotune leaves those alone
+                                     // 2 plan_align, 3 fuse_min_log, 4 sf3b_grid, 5 graph_explicit — plan_autotune leaves those alone
     hipGraphExec_t gkr_graph = nullptr; int use_graph = 1; bool graph_failed = false; u64 graph_launches = 0, graph_rounds = 0;
     // one proof sharded over GPUs by sumcheck chain (vp_set_shard): this rank records and runs only the chains it owns
     int shard_rank = 0, shard_world = 1;
@@ -705,6 +705,7 @@ void vp_options_default(vp_options *o) {
     o->persistent_rounds = 1; o->persistent_multi = 0; o->persistent_multi_shift = 13; o->poll = 1; o->debug = 0; o->prefetch_round1 = 1; o->split_cost_percent = 50; o->kernel_copies = 1; o->fold_branches = 1; o->ntt_scatter = 1; o->fuse_combine = 2; o->plan_autotune = 1;
     o->pc_tensor_pub = 1;
     o->persistent_timeout_ms = 10000;
+    o->graph_explicit = 0;
 }
 // defaults <- the caller's struct (as many bytes as its header knew) <- VP_* environment variables (test-only override, read here and nowhere else)
 static void resolve_options(vp_options *o, const vp_options *user, uint32_t *pinned) {
@@ -731,6 +732,7 @@ static void resolve_options(vp_options *o, const vp_options *user, uint32_t *pin
     flag("VP_NTT_SCATTER", o->ntt_scatter);
     flag("VP_PC_TENSOR", o->pc_tensor_pub);
     num("VP_PERSIST_TIMEOUT_MS", o->persistent_timeout_ms);
+    flag("VP_GRAPH_EXPLICIT", o->graph_explicit);
     num("VP_FUSE_COMBINE", o->fuse_combine);
     flag("VP_PLAN_AUTOTUNE", o->plan_autotune);
     if (getenv("VP_DEBUG")) o->debug |= 1;
@@ -739,7 +741,7 @@ static void resolve_options(vp_options *o, const vp_options *user, uint32_t *pin
     o->dot_blocks = std::max(1, o->dot_blocks); o->sf3b_grid = std::max(1, o->sf3b_grid);
     vp_options d; vp_options_default(&d);
     *pinned = (o->fuse_combine != d.fuse_combine ? 1u : 0u) | (o->fold_branches != d.fold_branches ? 2u : 0u) | (o->plan_align != d.plan_align ? 4u : 0u) |
-              (o->fuse_min_log != d.fuse_min_log ? 8u : 0u) | (o->sf3b_grid != d.sf3b_grid ? 16u : 0u);
+              (o->fuse_min_log != d.fuse_min_log ? 8u : 0u) | (o->sf3b_grid != d.sf3b_grid ? 16u : 0u) | (o->graph_explicit != d.graph_explicit ? 32u : 0u);
 }
 
 int vp_create(int device, vp_ctx **out) { return vp_create_with_options(device, nullptr, out); }
