@@ -732,7 +732,7 @@ static void resolve_options(vp_options *o, const vp_options *user, uint32_t *pin
     flag("VP_NTT_SCATTER", o->ntt_scatter);
     flag("VP_PC_TENSOR", o->pc_tensor_pub);
     num("VP_PERSIST_TIMEOUT_MS", o->persistent_timeout_ms);
-    flag("VP_GRAPH_EXPLICIT", o->graph_explicit);
+    num("VP_GRAPH_EXPLICIT", o->graph_explicit);
     num("VP_FUSE_COMBINE", o->fuse_combine);
     flag("VP_PLAN_AUTOTUNE", o->plan_autotune);
     if (getenv("VP_DEBUG")) o->debug |= 1;
