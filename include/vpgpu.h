@@ -132,7 +132,7 @@ typedef struct {
     int32_t graph_explicit;         /* VP_GRAPH_EXPLICIT: the launch plan's hipGraph is built node by node with exactly the plan's dependencies
                                        (hipGraphAddKernelNode) instead of captured from four streams, where the order of unrelated launches on a stream
                                        becomes a dependency too.  2: built node by node in the captured shape (stream order kept as edges) except that
-                                       the inner products V_u get a stream of their own.  Faster or slower depending on the circuit (the runtime places
+                                       the inner products V_u get a stream of their own; 3: and the phase-2 init launches another.  Faster or slower depending on the circuit (the runtime places
                                        the branches of such a graph itself): plan_autotune tries the forms last and keeps what replays fastest    [0] */
 } vp_options;
 void vp_options_default(vp_options *opt);

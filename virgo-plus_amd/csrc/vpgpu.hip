@@ -97,7 +97,7 @@ struct PlanRec {
     }
 };
 struct PNode { int kind = 0, step = 0, stream = 0; u32 first = 0, count = 0, grid = 0, lds = 0, map_off = 0; u64 bytes = 0, work = 0; int first_round = 0, n_rounds = 0;
-               std::vector<int> deps; hipEvent_t ev = nullptr; bool record = false; };
+               std::vector<int> deps; hipEvent_t ev = nullptr; bool record = false; bool p2 = false; };     // p2: every job belongs to a phase-2 chain
 struct Plan {
     std::vector<PNode> nodes;
     I3Job *d_init3 = nullptr; bool init3 = false;
