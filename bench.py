@@ -1,34 +1,22 @@
 #!/usr/bin/env python3
-"""bench.py — headline benchmark: GKR prover seconds and field-ops/s on the SHA-256 64-block circuit
-(BASELINE.json configs[1]: "SHA-256 64-block circuit, 1xMI355X, sumcheck rounds on GPU, Virgo PC off").
+"""bench.py — headline benchmark: prover seconds and field-ops/s of the SHA-256 1024-block circuit with the Virgo commitment on ONE MI355X
+(BASELINE.json configs[2], the largest single-GPU configuration; N > 1: configs[3], one independent instance per GPU).
 
-A step = one complete GKR proof (Vres + three sumchecks per layer, 691 rounds) by the device prover, with
-the circuit, the witness and the verifier tape already resident in HBM.  Each rank proves its own instance
-(rank r draws its witness after srandom(1 + r); rank 0's instance is the golden one), so N GPUs produce N
-independent proofs per step with no data-path collective ("scaling": "weak").  Rank 0's transcript is
-compared byte for byte with the real reference's golden transcript on every run.
+A step = the prover side of the COMPLETE protocol in one pass (vph_prove_protocol): commit_private -> GKR proof (batched: Vres + three sumchecks
+per layer, 859 rounds, from the pre-drawn verifier tape) -> commit_public on eq(r_liu, .) built on the device -> fft_gkr -> FRI commit phase and
+final codeword — every prover call of the reference's verifier::verify() except answering the queries, and nothing of the verifier.  The
+circuit, the witness and every verifier draw are resident / known before the timed region; no field data crosses PCIe inside it except the
+transcript (45 KB) coming back.  Rank r proves its own instance (witness drawn after srandom(1 + r)), no data-path collective: "scaling": "weak".
+Rank 0's transcript, FRI roots and final codeword are compared byte for byte with the REAL reference's recorded run on every run.
 
-The ONE JSON line (rank 0):
-  metric / value / unit / ms_per_step ...   the contract fields; value = field-ops of all ranks' proofs / max-over-ranks time
-  roofline            the kernel with the largest share of the proof's summed launch time: algorithmic bytes per launch / mean launch
-                      duration, both measured live (every launch of the plan bracketed with HIP events on its own stream in a
-                      single-stream replay, vp_set_profiling / vp_get_launch_stats), against 8 TB/s; `traffic` from the committed
-                      rocprofv3 PMC summary of this command (profiles/r02_pmc_summary_b*.json); `measured_limiter` says what the
-                      counters show (VALU issue, not bytes)
-  kernels             the same table for every kernel kind of the proof (launches, us, share, algorithmic MB, GB/s, frac)
-  interactive_path    the drop-in entry points (one vp_round per verifier message): prover seconds by the reference's definition,
-                      split into init / round / finalize calls
-  circuit_upload_sec  host flatten + vp_circuit_upload (index structures built on the device) + vp_evaluate
-  verifier            the host verifier's O(|C|) loops on the host and on the device
-  cpu_baseline        the real reference (oracle/_ref/ref_run) on one host core, one full proof of the same circuit
-  x1024_with_pc       N = 1 default run only: BASELINE configs[2], the largest single-GPU configuration, as a nested leg with the
-                      same fields (transcript against the oracle fixture, roofline of ITS dominant kernel, per-launch table,
-                      cpu_baseline = the oracle port) plus `polynomial_commitment`: the complete protocol (commit_private,
-                      commit_public, FRI commit phase and queries, unbroken verifyFull with the reference's challenge schedule),
-                      per-kernel table and rooflines of k_leaf_hash (Keccak-f/s against the VALU issue bound of its instruction
-                      mix) and the NTT family (F-multiplications/s against the chip's F-multiply issue rate)
+stdout carries ONE compact JSON line (<= 4 KB, strict JSON: compact_line): the contract fields, `roofline` (the kernel with the largest share of
+the step: k_leaf_hash, Keccak-f/s against its instruction-count floor, HIP events around every launch on the library stream), `cpu_baseline`
+(the real reference binary on a bounded sample: the same protocol at x64 on one host core), one-number summaries of the other legs; the tables —
+per kernel, per launch, per interactive round, the nested x64 GKR-only leg (BASELINE configs[1]), the oracle port's full-size GKR proof on one
+core, the multi-rank `sharded` sub-leg — go to the detail file named in the line (gpurun_out/bench_detail_n<N>.json).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--blocks B] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--blocks B] [--no-pc] [--no-cpu-baseline]
+    python bench.py --blocks 64 --no-pc              the round-1..3 headline (BASELINE configs[1]: GKR only, commitment off)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 """
@@ -49,7 +37,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 # PMC summaries of this command (tools/gpu_profile.sh -> tools/pmc_summary.py: separate rocprofv3 --pmc passes for FETCH_SIZE and
 # WRITE_SIZE, FETCH_SIZE doubled for gfx950 as the guide's HBM section prescribes), newest first
-PMC_SUMMARIES = ("r03_pmc_summary_b%d.json", "r02_pmc_summary_b%d.json", "r01_l_pmc_summary_b%d.json")
+PMC_SUMMARIES = ("r04_pmc_summary_b%d.json", "r03_pmc_summary_b%d.json", "r02_pmc_summary_b%d.json", "r01_l_pmc_summary_b%d.json")
 # Issue-rate ceilings of the two compute-bound kernel families of the commitment, measured with tools/micro_rates.hip on MI355X
 # (profiles/r02_micro_rates.txt; 256 CUs x 4 SIMDs at 2.4 GHz, 8 waves per SIMD):
 #   F_p^2 multiply (31-bit split form, 16 v_mad_u64_u32 + Mersenne folds): 6.1e11 per second for the whole chip;
@@ -459,59 +447,6 @@ def two_in_flight_leg(vp, circ, sess, tr_expected, steps, warmup, local, ref_ops
                     "unchanged (prover_sec), the GPU's idle tails are filled"}
 
 
-def x1024_leg(vp, pws, golden, a, local):
-    """BASELINE.json configs[2]: SHA-256 1024-block circuit (102 M gates, 859 rounds, tables up to 2^26), sumcheck + Virgo commitment
-    on ONE MI355X — the largest single-GPU configuration, as a nested leg of the default run.  Same contract as the headline leg:
-    warmup, timed steps, transcript compared with the committed oracle fixture, per-launch table with the dominant kernel's roofline,
-    CPU baseline (the oracle port's GKR proof of the same circuit, one core) timed in the same run."""
-    B = 1024
-    g = golden["sha256_x%d" % B]
-    t_b = time.perf_counter()
-    circ = vp.Circuit.from_pws(pws, B, seed=1)
-    build_sec = time.perf_counter() - t_b
-    t_up = time.perf_counter()
-    sess = vp.Session(circ, device=local)
-    upload_sec = time.perf_counter() - t_up
-    sess.draw_tape()
-    steps, warmup = max(3, a.steps // 2), 2
-    tr, res, elapsed, dev_ms = gkr_leg(vp, circ, sess, steps, warmup, 1, False, local)
-    gold = open(os.path.join(ROOT, "tests", "golden", g["transcript"]), "rb").read()[g["gkr_slice"][0]:g["gkr_slice"][1]]
-    ref_ops = g["mult_counter"] + g["add_counter"]
-    rows, per_launch, roof, res_p = profile_gkr(sess, tr, B)
-    ok_d, sec_d = sess.check(tr, device_predicates=True)
-    t_i = time.perf_counter()
-    tr_i, res_i, ok_i = sess.prove_interactive()
-    inter = {"prover_sec": res_i["prove_sec"], "init_calls_sec": res_i.get("init_sec"), "round_calls_sec": res_i.get("round_sec"),
-             "finalize_calls_sec": res_i.get("finalize_sec"), "wall_sec_with_host_verifier": time.perf_counter() - t_i, "transcript_equals_batched": tr_i == tr, "verified": ok_i,
-             "per_round": per_round_summary(sess.round_stats())}
-    sess.draw_tape()
-    fx = os.path.join(ROOT, "tests", "golden", "oracle_sha256_x1024_full.bin")
-    pc = pc_leg(vp, sess, circ, golden, "sha256_x%d" % B, full_fixture=fx if os.path.exists(fx) else None)
-    leg = {"config": {"workload": "SHA-256 %d-block circuit (SHA256_64.pws x%d, %d gates, %d layers), GKR sumcheck + Virgo FFT/LDT commit on GPU (BASELINE configs[2])"
-                                  % (B, B, circ.gates, circ.layers), "field_ops_per_proof": ref_ops},
-           "value": ref_ops * steps / elapsed, "unit": "field-ops/s", "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
-           "prover_sec": elapsed / steps, "prover_sec_device": 1e-3 * dev_ms / steps, "rounds": res["rounds"],
-           "kernel_launches_per_proof": res["launches"], "bit_exact_vs_reference": tr == gold, "golden_origin": g.get("origin"),
-           "reference_prove_sec_build_container": g.get("reference_prove_sec_here"), "reference_pc_prove_sec_build_container": g.get("reference_pc_prove_sec_here"),
-           "verifier_accepts_full_check": bool(ok_d), "verify_sec_device_predicates": sec_d, "interactive_path": inter,
-           "circuit_build_sec": build_sec, "circuit_upload_sec": upload_sec,
-           "roofline": roof, "kernels": rows, "per_launch": per_launch, "polynomial_commitment": pc}
-    sess.close(); circ.close()
-    if not a.no_cpu_baseline:
-        import oracle_binding as ob
-        t0 = time.perf_counter()
-        oc = ob.Circuit.from_pws(pws, B, seed=1)
-        t1 = time.perf_counter()
-        otr, st = oc.prove_gkr()
-        oc.close()
-        ops = st["mult_count"] + st["add_count"]
-        leg["cpu_baseline"] = {"value": ops / st["prove_sec"], "unit": "field-ops/s", "cores": 1, "kind": "port",
-                               "sample": "one full GKR proof of the same 1024-block circuit by the oracle port (PC off), single thread",
-                               "prover_sec": st["prove_sec"], "field_ops": ops, "circuit_build_sec": t1 - t0,
-                               "transcript_equals_gpu": otr == tr, "host_cpu": cpu_model(), "host_cores_visible": os.cpu_count()}
-    return leg
-
-
 def spawn_ranks(n):
     """`bench.py --gpus N` (N > 1) started WITHOUT a launcher: start the N ranks here, one process per GPU, exactly as the driver's command
     would (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>), and exit with its code.  This runs
@@ -565,39 +500,6 @@ def gather_floats(world, rank, x):
     t = torch.tensor([float(x) if r == rank else 0.0 for r in range(world)], dtype=torch.float64)
     dist.all_reduce(t)
     return [float(v) for v in t]
-
-
-def replicas_x1024_leg(vp, pws, golden, a, world, rank, local):
-    """BASELINE.json configs[3]: SHA-256 1024-block circuit, one independent proof per GPU (witness seed 1 + rank), no data-path collective.
-    Rank 0's transcript against the real reference's golden (seed 1), rank 1's against the oracle's seed-2 fixture; every rank's proof through
-    the full verifier replay (device predicates)."""
-    B = 1024
-    g = golden["sha256_x%d" % B]
-    t_b = time.perf_counter()
-    circ = vp.Circuit.from_pws(pws, B, seed=1 + rank)
-    build_sec = time.perf_counter() - t_b
-    sess = vp.Session(circ, device=local)
-    sess.draw_tape()
-    steps, warmup = max(3, a.steps // 4), 2
-    tr, res, elapsed, dev_ms = gkr_leg(vp, circ, sess, steps, warmup, world, False, local)
-    elapsed_max, proofs = aggregate(world, elapsed, float(steps))
-    ok, _ = sess.check(tr, device_predicates=True)
-    exact = None
-    if rank == 0:
-        exact = tr == open(os.path.join(ROOT, "tests", "golden", g["transcript"]), "rb").read()[g["gkr_slice"][0]:g["gkr_slice"][1]]
-    elif rank == 1:
-        fx = os.path.join(ROOT, "tests", "golden", "oracle_sha256_x1024_gkr_seed2.bin")
-        exact = (tr == open(fx, "rb").read()) if os.path.exists(fx) else None
-    all_ok = allreduce_min_flag(world, ok and exact is not False)
-    dev = gather_floats(world, rank, dev_ms / steps)
-    sess.close(); circ.close()
-    ref_ops = g["mult_counter"] + g["add_counter"]
-    return {"config": {"workload": "SHA-256 1024-block circuit x %d independent proofs, one per GPU, witness seeds 1..%d (BASELINE configs[3]); GKR sumcheck on GPU"
-                                   % (world, world), "field_ops_per_proof": ref_ops, "proofs_per_step": world},
-            "value": ref_ops * proofs / elapsed_max, "unit": "field-ops/s", "scaling": "weak", "steps": steps, "warmup": warmup,
-            "ms_per_step": 1e3 * elapsed_max / steps, "prover_sec_device_per_rank": [1e-3 * x for x in dev], "rounds": res["rounds"],
-            "rank0_bit_exact_vs_reference": exact if rank == 0 else None, "every_rank_verified_and_matching_its_fixture": all_ok,
-            "circuit_build_sec_rank0": build_sec}
 
 
 def sharded_leg(vp, pws, golden, a, world, rank, local, blocks):
@@ -674,30 +576,571 @@ def sharded_leg(vp, pws, golden, a, world, rank, local, blocks):
     return out
 
 
+def gkr_workload(vp, a, pws, golden, world, rank, local, blocks, shard_req, cpu_base=True, nested=False):
+    """GKR-only workload (BASELINE configs[1] at blocks = 64, configs[4] with --randomize): a step = one batched GKR proof, commitment off.
+    Returns the DETAIL dict of the leg on rank 0 (None elsewhere); every rank takes part in the timed region."""
+    shard = shard_req and world > 1
+    seed = 1 if shard else 1 + rank          # a sharded proof: every rank holds the same instance
+    gname = "sha256_x%d" % blocks if not a.randomize else "randomize_%d_%d" % tuple(a.randomize)
+    if a.randomize:
+        circ = vp.Circuit.randomize(a.randomize[0], a.randomize[1], seed=seed)
+    else:
+        circ = vp.Circuit.from_pws(pws, blocks, seed=seed)
+    t_up = time.perf_counter()
+    sess = vp.Session(circ, device=local)            # raises without the HIP library / GPU
+    upload_sec = time.perf_counter() - t_up
+    sess.draw_tape()
+    if shard:
+        sess.set_shard(rank, world)
+        import torch.distributed as dist
+        if "nccl" in dist.get_backend():           # the data-path collective lives in the C ABI: RCCL on the device buffer, no torch tensor
+            sess.attach_comm(rank, world)
+            shard = "rccl"
+        if a.shard_split:
+            sess.set_shard_split(a.shard_split)
+            if shard != "rccl":
+                raise SystemExit("--shard-split in the multi-rank mode needs the in-library communicator (RCCL); rehearse it with --shard-sim")
+    t_f = time.perf_counter()
+    sess.prove_gkr()                               # the first proof of a circuit: launch plan recorded, tuner, graph capture
+    first_proof_sec = time.perf_counter() - t_f
+    steps, warmup = (a.steps, a.warmup) if not nested else (max(5, a.steps), max(2, a.warmup))
+    tr, res, elapsed, dev_ms = gkr_leg(vp, circ, sess, steps, warmup, world, shard, local)
+    elapsed, proofs = aggregate(world, elapsed, float(steps))
+    shard_info = None
+    if shard:
+        proofs = float(steps)                      # all ranks worked on the same proof
+        import torch, torch.distributed as dist
+        dm = torch.tensor([dev_ms / steps if r == rank else 0.0 for r in range(world)], dtype=torch.float64)
+        dist.all_reduce(dm)
+        owner, cost = sess.shard_chains()
+        shard_info = {"device_ms_per_rank": [float(x) for x in dm], "chains": int((cost > 0).sum()),
+                      "chains_per_rank": [int(((owner == r) & (cost > 0)).sum()) for r in range(world)],
+                      "chains_split_by_index": int((owner == -1).sum()),
+                      "collective": ("one RCCL all-reduce (u64 sum) of the transcript%s per proof inside vp_prove_gkr (vp_comm_init: no torch tensor, no host bounce)"
+                                     % (" + export area" if a.shard_split else "")) if shard == "rccl"
+                                    else "one all-reduce (sum, int64) of the %d-byte transcript per proof through torch, backend %s" % (len(tr), dist.get_backend())}
+        sess.set_shard(0, 1)                       # the roofline / verifier legs below run the whole proof on every rank
+        tr_full, _ = sess.prove_gkr()
+        assert tr_full == tr, "assembled sharded transcript differs from the unsharded proof"
+    rows, per_launch, roof, res_p = profile_gkr(sess, tr, blocks if not a.randomize else 0)
+
+    shard_sim = None
+    if a.shard_sim > 1 and world == 1 and not nested:
+        # per-rank compute of a chain-sharded proof on W GPUs, measured shard by shard on this one GPU (no collective here)
+        per = []
+        parts = []
+        for r in range(a.shard_sim):
+            sess.set_shard(r, a.shard_sim)
+            if a.shard_split:
+                sess.set_shard_split(a.shard_split)
+            for _ in range(2):
+                sess.prove_gkr()
+            ms = []
+            for _ in range(max(3, a.steps // 2)):
+                t_s = time.perf_counter()
+                tr_s, res_s = sess.prove_gkr()
+                ms.append((res_s["gkr_device_ms"], 1e3 * (time.perf_counter() - t_s)))
+            parts.append(tr_s)
+            per.append({"rank": r, "device_ms": sum(m[0] for m in ms) / len(ms), "wall_ms": sum(m[1] for m in ms) / len(ms)})
+        owner, cost = sess.shard_chains()
+        summed = vp.sum_transcripts(parts)
+        t_f = time.perf_counter()
+        assembled = sess.shard_finish(summed) if a.shard_split else summed
+        finish_ms = 1e3 * (time.perf_counter() - t_f)
+        sess.set_shard(0, 1)
+        shard_sim = {"world": a.shard_sim, "per_rank": per, "max_device_ms": max(x["device_ms"] for x in per),
+                     "max_wall_ms": max(x["wall_ms"] for x in per),
+                     "index_split_min_log": a.shard_split or None, "chains_split_by_index": int((owner == -1).sum()),
+                     "host_finish_ms": finish_ms if a.shard_split else None,
+                     "cost_share_per_rank": [float(cost[owner == r].sum() / cost.sum()) for r in range(a.shard_sim)],
+                     "assembled_equals_unsharded": assembled == tr,
+                     "note": "each shard run alone on this GPU; a W-GPU run adds one all-reduce of the transcript (and, with the index split, of the export area) per proof"}
+
+    pipelined = None
+    if rank == 0 and world == 1 and not shard and not a.no_two_in_flight and not nested:
+        g_ = golden.get(gname)
+        pipelined = two_in_flight_leg(vp, circ, sess, tr, a.steps, a.warmup, local, (g_["mult_counter"] + g_["add_counter"]) if g_ else None)
+
+    interactive = None
+    if rank == 0:
+        # the drop-in path of the reference's own call pattern (one vp_round per verifier message), outside the timed region
+        t_i = time.perf_counter()
+        tr_i, res_i, ok_i = sess.prove_interactive()
+        interactive = {"prover_sec": res_i["prove_sec"], "init_calls_sec": res_i.get("init_sec"), "round_calls_sec": res_i.get("round_sec"),
+                       "finalize_calls_sec": res_i.get("finalize_sec"), "wall_sec_with_host_verifier": time.perf_counter() - t_i,
+                       "transcript_equals_batched": tr_i == tr, "verified": ok_i,
+                       "per_round": per_round_summary(sess.round_stats(), full=a.per_launch),
+                       "note": "reference definition of Prove Time (sum of prover-method spans) over the interactive entry points (vp_round per verifier message)"}
+        sess.draw_tape()
+
+    pc = None
+    if a.with_pc and rank == 0 and not nested:
+        pc = pc_leg(vp, sess, circ, golden, gname)
+
+    bit_exact = None
+    ref_ops = None
+    if gname in golden:
+        g = golden[gname]
+        ref_ops = g["mult_counter"] + g["add_counter"]
+        if rank == 0:
+            gold = open(os.path.join(ROOT, "tests", "golden", g["transcript"]), "rb").read()[g["gkr_slice"][0]:g["gkr_slice"][1]]
+            bit_exact = (tr == gold)
+    # the reported flag is the FULL replay check (per-round identities, wiring predicates and getFinalValue on the device, Liu
+    # check, input check): the per-round identities alone hold by construction for the rounds whose b is derived
+    ok, sec_d = sess.check(tr, device_predicates=True)
+    verify = None
+    if rank == 0:      # the verifier's side of the same proof (outside the timed region): O(|C|) predicate loops on host vs on the GPU
+        ok_h, sec_h = sess.check(tr)
+        verify = {"host_predicates_sec": sec_h, "device_predicates_sec": sec_d, "accepted": bool(ok_h and ok),
+                  "note": "the verifier's O(|C|) loops on the device: wiring predicates (vp_predicates), gr of verifyLiu (vp_liu_gr), input-layer MLE (vp_layer_mle); the per-round checks stay on the host"}
+
+    line = None
+    if rank == 0:
+        sec_per_proof_job = elapsed / steps                      # wall time of one step (all ranks in parallel)
+        ops_total = (ref_ops or 0) * proofs
+        line = {
+            "metric": METRIC,
+            "value": ops_total / elapsed if ref_ops else None,
+            "unit": "field-ops/s",
+            "n_gpus": distinct_gpus(world), "ranks": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": 1e3 * sec_per_proof_job,
+            "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None,
+            "dtype": DTYPE, "data": "synthetic",
+            "config": {"workload": ("SHA-256 %d-block circuit (SHA256_64.pws x%d, %d gates, %d layers), GKR sumcheck on GPU, Virgo PC off%s"
+                                    % (blocks, blocks, circ.gates, circ.layers, " (BASELINE configs[1])" if blocks == 64 else "")) if not a.randomize else
+                                   ("layeredCircuit::randomize(%d, %d) (%d gates, %d layers), GKR sumcheck on GPU, Virgo PC off"
+                                    % (a.randomize[0], a.randomize[1], circ.gates, circ.layers)),
+                       "mode": "batched (verifier tape pre-drawn; transcript identical to the interactive run)",
+                       "proofs_per_step": 1 if shard else world, "field_ops_per_proof": ref_ops},
+            "prover_sec": sec_per_proof_job,
+            "prover_sec_device": 1e-3 * dev_ms / steps,
+            "first_proof_sec": first_proof_sec,
+            "rounds": res["rounds"], "kernel_launches_per_proof": res["launches"],
+            "bit_exact_vs_reference_golden": bit_exact, "host_verifier_accepts": bool(ok),
+            "host_verifier_check": "full replay: per-round identities, wiring predicates + getFinalValue (device loops), Liu check, input-layer check",
+            "golden_origin": (golden[gname].get("origin", "the real reference binary (oracle/_ref/ref_run)") if gname in golden else None),
+            "two_in_flight": pipelined,
+            "interactive_path": interactive, "circuit_upload_sec": upload_sec, "verifier": verify,
+            "roofline": roof, "kernels": rows,
+        }
+        if a.per_launch:
+            line["per_launch"] = per_launch
+        if pc is not None:
+            line["polynomial_commitment"] = pc
+        if shard_info is not None:
+            line["sharded_proof"] = shard_info
+        if shard_sim is not None:
+            line["sharded_proof_simulation"] = shard_sim
+        if world == 1 and cpu_base and not a.no_cpu_baseline and not a.randomize:
+            cb = cpu_baseline(pws, blocks, ref_ops)
+            cb["host_cpu"] = cpu_model()
+            cb["host_cores_visible"] = os.cpu_count()
+            line["cpu_baseline"] = cb
+    sess.close()
+    circ.close()
+    return line
+
+
+METRIC = "prover sec + field-ops/sec, SHA-256 circuit, 1/2/4/8 MI355X (bit-exact)"
+DTYPE = "u64 (F_p^2, p=2^61-1)"
+
+
+def distinct_gpus(world):
+    """Headline n_gpus = DISTINCT devices the ranks run on (a rehearsal of N ranks on one card is n_gpus 1, ranks N)."""
+    import torch
+    n = torch.cuda.device_count()
+    return min(world, n) if n else world
+
+
+def keccak_roofline(stats, blocks):
+    """roofline object of the leaf-hash launches (k_leaf_hash): integer-ALU-bound — Keccak-f[1600]/s against the instruction-count floor; the
+    HBM side of the same launches (bytes read / time against 8 TB/s) beside it."""
+    leaf = [e for e in stats if e["kernel"] == "k_leaf_hash"]
+    if not leaf:
+        return None
+    tot = sum(e["us"] for e in stats) or 1e-9
+    w, us, by = sum(e["work"] for e in leaf), sum(e["us"] for e in leaf), sum(e["bytes"] for e in leaf)
+    traffic, src = pmc_traffic(blocks, "k_leaf_hash")
+    return {"kernel": "k_leaf_hash", "bound": "valu", "achieved": w / (us * 1e-6), "peak": KECCAK_PEAK_PER_S, "unit": "Keccak-f[1600]/s",
+            "frac": w / (us * 1e-6) / KECCAK_PEAK_PER_S,
+            "frac_of_own_instruction_mix": w / (us * 1e-6) / (1024 * 64 * 2.4e9 / KECCAK_MIX_CYCLES_PER_WAVE_PERM),
+            "launches": len(leaf), "avg_launch_us": us / len(leaf), "algorithmic_bytes_per_launch": by / len(leaf),
+            "hbm_GBps": by / (us * 1e-6) / 1e9, "hbm_frac": by / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "hbm_peak_GBps": HBM_PEAK_GBPS,
+            "traffic": traffic, "traffic_source": src, "kernel_time_share": us / tot,
+            "peak_definition": "instruction-count floor x best issue rate: 24 rounds x %d VALU instructions (32-bit minimum: 120 v_bitop3_b32 + 58 v_alignbit_b32 + 2 v_xor_b32) x %.2f "
+                               "SIMD-cycles per wave-instruction (cheapest measured, tools/micro_rates.hip), 1024 SIMDs x 64 lanes, 2.4 GHz; 65 chained permutations per leaf: "
+                               "integer-ALU-bound (SURVEY 8d: report hashes/s, not GB/s)" % (KECCAK_INSTR_PER_ROUND, KECCAK_BEST_ISSUE_CYCLES),
+            "how": "HIP events around every launch on the library stream (vp_set_profiling), commit_private + commit_public + FRI commit phase of the same session"}
+
+
+def protocol_workload(vp, a, pws, golden, world, rank, local, blocks):
+    """BASELINE configs[2] (N = 1) / configs[3] (N > 1, one independent instance per GPU, witness seed 1 + rank): SHA-256 x`blocks`, GKR sumcheck
+    AND the Virgo commitment on the GPU.  A step = the prover side of the complete protocol, one pass (vph_prove_protocol): commit_private ->
+    GKR (batched) -> commit_public on eq(r_liu, .) -> fft_gkr -> FRI commit phase; nothing of the verifier inside.  Circuit, witness and every
+    verifier draw are resident / known before the timed region; the public vector is built on the device.  Returns the DETAIL dict on rank 0."""
+    import numpy as np
+    from conftest import GOLDEN
+    gname = "sha256_x%d" % blocks
+    g = golden.get(gname)
+    t_b = time.perf_counter()
+    circ = vp.Circuit.from_pws(pws, blocks, seed=1 + rank)
+    build_sec = time.perf_counter() - t_b
+    t_up = time.perf_counter()
+    sess = vp.Session(circ, device=local)
+    upload_sec = time.perf_counter() - t_up
+    sess.draw_protocol_tape()
+    t_f = time.perf_counter()
+    sess.prove_gkr()                               # first GKR proof of the circuit: plan recorded, tuner, graph capture
+    first_gkr = time.perf_counter() - t_f
+    t_f = time.perf_counter()
+    sess.prove_protocol()                          # first complete pass: the commitment's buffers and root tables
+    first_pass = time.perf_counter() - t_f
+    for _ in range(a.warmup):
+        sess.prove_protocol()
+    gpu_sync(local)
+    barrier(world)
+    acc = {}
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        tr, roots, fin, sec = sess.prove_protocol()
+        for k, v in sec.items():
+            acc[k] = acc.get(k, 0.0) + v
+    gpu_sync(local)
+    barrier(world)
+    elapsed = time.perf_counter() - t0
+    elapsed_max, proofs = aggregate(world, elapsed, float(a.steps))
+    # ---- parity: rank 0 against the REAL reference's files; every rank through the complete protocol's host verifier
+    exact = {}
+    if g and rank == 0:
+        gold = open(os.path.join(GOLDEN, g["transcript"]), "rb").read()
+        exact["transcript"] = tr == gold
+        st = g["fri_steps"]
+        fri = open(os.path.join(GOLDEN, g["fri"]), "rb").read()
+        exact["fri_roots"] = roots == b"".join(fri[48 * k + 16:48 * k + 48] for k in range(st))
+        exact["fri_final_codeword"] = fin.tobytes() == fri[48 * st:48 * st + 2048 * 16]
+    elif rank == 1 and blocks == 1024:
+        fx = os.path.join(GOLDEN, "oracle_sha256_x1024_gkr_seed2.bin")
+        if os.path.exists(fx):
+            exact["gkr_slice_vs_oracle_seed2"] = tr[32:32 + os.path.getsize(fx)] == open(fx, "rb").read()
+    trf, ok_full, times = sess.prove_and_verify_full(reps=33)      # interactive GKR + commitment verification, 33 query repetitions
+    exact["complete_protocol_accepted"] = bool(ok_full)
+    exact["interactive_run_equals_batched"] = trf == tr
+    all_ok = allreduce_min_flag(world, all(v is not False for v in exact.values()))
+    steps_sec = gather_floats(world, rank, elapsed / a.steps)
+    if rank != 0:
+        sess.close(); circ.close()
+        return None
+    ref_ops = (g["mult_counter"] + g["add_counter"]) if g else None
+    per = {k: v / a.steps for k, v in acc.items()}
+    # ---- roofline pass (outside the timed region): HIP events around every launch of each call
+    point = sess.last_point()
+    _, _, rr = sess.last_fri()
+    sess.draw_protocol_tape()
+    sess.set_profiling(1)
+    tr_g, res_g = sess.prove_gkr(); st_gkr = sess.launch_stats()
+    sess.commit_private(); st_priv = sess.launch_stats()
+    sess.commit_public_eq(point); st_pub = sess.launch_stats()
+    sess.fri_commit(rr); st_fri = sess.launch_stats()
+    sess.set_profiling(0)
+    allst = st_gkr + st_priv + st_pub + st_fri
+    rows, per_launch, tot_us = launch_table(allst)
+    gkr_rows, gkr_per_launch, _ = launch_table(st_gkr)
+    pc_rows, _, pc_us = launch_table(st_priv + st_pub + st_fri)
+    roof = keccak_roofline(allst, blocks)
+    roof_gkr = roofline_of(gkr_rows, blocks, res_g["gkr_device_ms"])
+    ntt = [e for e in allst if e["kernel"] in ("k_ntt_lds", "k_ntt_split", "k_ntt_r8")]
+    roof_ntt = None
+    if ntt:
+        w, us = sum(e["work"] for e in ntt), sum(e["us"] for e in ntt)
+        roof_ntt = {"bound": "valu", "achieved": w / (us * 1e-6), "peak": FMUL_PEAK_PER_S, "unit": "F_p^2 multiplications/s", "frac": w / (us * 1e-6) / FMUL_PEAK_PER_S,
+                    "total_us": us, "time_share": us / tot_us, "hbm_GBps": sum(e["bytes"] for e in ntt) / (us * 1e-6) / 1e9,
+                    "hbm_frac": sum(e["bytes"] for e in ntt) / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                    "peak_definition": "chip-wide F_p^2 multiply issue rate of the 31-bit split form (tools/micro_rates.hip, f_mul)"}
+    # ---- the drop-in (interactive) path of the GKR part, and the verifier's side
+    t_i = time.perf_counter()
+    tr_i, res_i, ok_i = sess.prove_interactive()
+    inter = {"prover_sec": res_i["prove_sec"], "init_calls_sec": res_i.get("init_sec"), "round_calls_sec": res_i.get("round_sec"),
+             "finalize_calls_sec": res_i.get("finalize_sec"), "wall_sec_with_host_verifier": time.perf_counter() - t_i,
+             "transcript_equals_batched": tr_i == tr_g, "verified": ok_i, "per_round": per_round_summary(sess.round_stats(), full=a.per_launch)}
+    sess.draw_protocol_tape()
+    ok_d, sec_d = sess.check(tr_g, device_predicates=True)
+    detail = {
+        "metric": METRIC,
+        "value": (ref_ops * proofs / elapsed_max) if ref_ops else None, "unit": "field-ops/s",
+        "value_definition": "the reference's field-op count of the circuit (mult + add counters of its own prover, SURVEY 8d) x proofs / wall time of the timed steps; a step is the "
+                            "WHOLE prover pass of the protocol (GKR + commitment), so the commitment's time is inside the denominator although the reference's counters tick in the GKR part only; "
+                            "gkr_field_ops_per_sec is the same count over the GKR part alone (the round-1..3 headline's definition)",
+        "n_gpus": distinct_gpus(world), "ranks": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed_max / a.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
+        "config": {"workload": "SHA-256 %d-block circuit (SHA256_64.pws x%d, %d gates, %d layers, 2^%d input wires), GKR sumcheck + Virgo FFT/LDT commit on GPU (BASELINE configs[%d]%s)"
+                               % (blocks, blocks, circ.gates, circ.layers, circ.layer_bitlen(0), 2 if world == 1 else 3,
+                                  "" if world == 1 else ": %d independent proofs, one per GPU, witness seeds 1..%d" % (world, world)),
+                   "mode": "one prover pass per step: commit_private -> GKR (batched, tape pre-drawn) -> commit_public(eq(r_liu,.) built on device) -> fft_gkr -> FRI commit phase",
+                   "proofs_per_step": world, "field_ops_per_proof": ref_ops},
+        "prover_sec": {"step_wall": elapsed_max / a.steps, "gkr": per.get("gkr"), "commit_private": per.get("commit_private"), "commit_public": per.get("commit_public"),
+                       "fft_gkr": per.get("fft_gkr"), "fri_commit": per.get("fri_commit"),
+                       "pc_prove_reference_definition": per.get("commit_private", 0) + per.get("commit_public", 0) + per.get("fft_gkr", 0) + per.get("fri_commit", 0),
+                       "note": "host wall clock per call, mean over the timed steps (rank 0); the reference prints `Prove Time` (GKR) and `Polynomial commitment: prove time` (the other four)",
+                       "step_wall_per_rank": steps_sec},
+        "gkr_field_ops_per_sec": (ref_ops / per["gkr"]) if ref_ops and per.get("gkr") else None,
+        "first_proof_sec": {"gkr_first_call_incl_plan_tuner_and_graph_capture": first_gkr, "first_complete_pass_incl_commitment_buffers": first_pass},
+        "bit_exact": exact, "bit_exact_all_ranks": all_ok,
+        "golden_origin": g.get("origin") if g else None,
+        "reference_prove_sec_build_container": g.get("reference_prove_sec_here") if g else None,
+        "reference_pc_prove_sec_build_container": g.get("reference_pc_prove_sec_here") if g else None,
+        "rounds": res_g["rounds"], "kernel_launches_per_gkr_proof": res_g["launches"],
+        "verifier": {"gkr_replay_device_predicates_sec": sec_d, "gkr_replay_accepted": bool(ok_d),
+                     "complete_protocol": {"accepted": bool(ok_full), "gkr_prove_sec_interactive": times["gkr_prove_sec"], "pc_prove_sec": times["pc_prove_sec"],
+                                           "fft_gkr_sec": times["pc_fft_gkr_sec"], "query_answer_sec": times["pc_query_answer_sec"], "verify_sec": times["verify_sec"],
+                                           "query_repetitions": 33}},
+        "interactive_path": inter,
+        "circuit_build_sec": build_sec, "circuit_upload_sec": upload_sec,
+        "roofline": roof, "roofline_gkr_dominant": roof_gkr, "roofline_ntt": roof_ntt,
+        "profiled_device_ms": {"all": tot_us * 1e-3, "gkr_single_stream": res_g["gkr_device_ms"], "commitment": pc_us * 1e-3},
+        "kernels": rows, "per_launch": per_launch if a.per_launch else gkr_per_launch,
+    }
+    sess.close(); circ.close()
+    return detail
+
+
+def cpu_protocol_baseline(pws, ref_ops_headline, blocks_sample=64):
+    """cpu_baseline of the configs[2] headline: the REAL reference (oracle/_ref/ref_run: /root/reference compiled in place) running the
+    same protocol — GKR + Virgo commitment — on a BOUNDED sample: the x64 circuit (1/16 of the headline's blocks), one thread (the reference
+    has no threading).  value = the reference's own field-op count / (its Prove Time + its commitment prove time), the headline's unit."""
+    ref_run = os.path.join(ROOT, "oracle", "_ref", "ref_run")
+    if not os.path.exists(ref_run):
+        return None
+    t0 = time.perf_counter()
+    try:
+        out = subprocess.run([ref_run, "--pws", pws, "--blocks", str(blocks_sample), "--pc", "1"], stdout=subprocess.PIPE,
+                             stderr=subprocess.DEVNULL, text=True, timeout=900)
+    except Exception:
+        return None
+    wall = time.perf_counter() - t0
+    m = re.search(r"Prove Time ([0-9.]+)", out.stdout)
+    pm = re.search(r"Polynomial commitment: prove time ([0-9.]+)", out.stdout)
+    c = re.search(r"mult counter (-?\d+), add counter (-?\d+)", out.stdout)
+    if out.returncode != 0 or not (m and pm and c):
+        return None
+    gkr, pcs = float(m.group(1)), float(pm.group(1))
+    ops = int(c.group(1)) + int(c.group(2))
+    return {"value": ops / (gkr + pcs), "unit": "field-ops/s", "cores": 1, "kind": "reference",
+            "sample": "the real reference binary, SHA-256 x%d (1/%d of the headline's blocks), complete protocol (GKR + commitment, verifier::verify), single thread"
+                      % (blocks_sample, max(1, 1024 // blocks_sample)),
+            "prover_sec": gkr + pcs, "gkr_prove_sec": gkr, "pc_prove_sec": pcs, "field_ops": ops, "gkr_field_ops_per_sec": ops / gkr,
+            "process_wall_sec": wall, "host_cpu": cpu_model(), "host_cores_visible": os.cpu_count()}
+
+
+def cpu_port_x1024(pws, tr_gpu):
+    """The oracle port's GKR proof of the FULL headline circuit on one host core (the real reference needs 63 GB and 13 minutes for it:
+    tests/golden/golden.json holds that run); compared byte for byte with the GPU's GKR slice."""
+    import oracle_binding as ob
+    t0 = time.perf_counter()
+    oc = ob.Circuit.from_pws(pws, 1024, seed=1)
+    t1 = time.perf_counter()
+    otr, st = oc.prove_gkr()
+    oc.close()
+    ops = st["mult_count"] + st["add_count"]
+    return {"kind": "port", "cores": 1, "gkr_prove_sec": st["prove_sec"], "field_ops": ops, "gkr_field_ops_per_sec": ops / st["prove_sec"],
+            "circuit_build_sec": t1 - t0, "transcript_equals_gpu": (otr == tr_gpu) if tr_gpu is not None else None,
+            "sample": "one full GKR proof of the 1024-block circuit by the oracle port (commitment off), single thread"}
+
+
+def _finite(x):
+    """strict JSON: NaN / inf become null, numpy scalars become Python numbers."""
+    import math
+    if isinstance(x, dict):
+        return {str(k): _finite(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_finite(v) for v in x]
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        return x if math.isfinite(x) else None
+    try:
+        f = float(x)
+        return f if math.isfinite(f) else None
+    except Exception:
+        return str(x)
+
+
+def _r(x, nd=4):
+    """round to `nd` significant digits (numbers in the headline line are for reading; the detail file keeps everything)."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        if x == 0 or x != x or x in (float("inf"), float("-inf")):
+            return x
+        from math import floor, log10
+        return round(x, max(0, nd - 1 - int(floor(log10(abs(x))))))
+    if isinstance(x, dict):
+        return {k: _r(v, nd) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, nd) for v in x]
+    return x
+
+
+LINE_TARGET_BYTES = 4096
+LINE_HARD_CAP_BYTES = 8192
+
+
+def compact_line(d, detail_file=None):
+    """The ONE stdout line from a leg's detail dict: the contract fields whole, `roofline` and `cpu_baseline` as compact objects, one-number summaries
+    of everything else; the tables (per kernel, per launch, per round, sub-legs) stay in the detail file.  Strict JSON, <= LINE_TARGET_BYTES when
+    it can be (optional keys are dropped from the end of `optional` until it fits), never above LINE_HARD_CAP_BYTES."""
+    def pick(obj, keys):
+        return {k: obj[k] for k in keys if isinstance(obj, dict) and k in obj and obj[k] is not None} if isinstance(obj, dict) else None
+    line = {k: d.get(k) for k in ("metric", "value", "unit", "n_gpus", "ranks", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                                  "dtype", "data")}
+    cfg = d.get("config") or {}
+    line["config"] = {k: cfg[k] for k in ("workload", "mode", "proofs_per_step", "field_ops_per_proof") if k in cfg}
+    roof = d.get("roofline")
+    if isinstance(roof, dict):
+        line["roofline"] = pick(roof, ("kernel", "bound", "achieved", "peak", "unit", "frac", "hbm_frac", "hbm_GBps", "traffic", "algorithmic_bytes_per_launch",
+                                       "avg_launch_us", "launches", "kernel_time_share", "frac_of_own_instruction_mix"))
+        line["roofline"].setdefault("traffic", None)
+    else:
+        line["roofline"] = None
+    cb = d.get("cpu_baseline")
+    line["cpu_baseline"] = pick(cb, ("value", "unit", "cores", "kind", "sample", "prover_sec", "gkr_prove_sec", "pc_prove_sec", "host_cpu",
+                                     "reference_over_port_ratio_x64_same_box")) if isinstance(cb, dict) else None
+    line["rccl_ranks"] = d.get("rccl_ranks")
+    be = d.get("bit_exact")
+    if isinstance(be, dict):
+        line["bit_exact"] = all(v is not False for v in be.values()) and bool(d.get("bit_exact_all_ranks", True))
+        line["bit_exact_checks"] = be
+    else:
+        line["bit_exact"] = d.get("bit_exact_vs_reference_golden")
+    optional = []
+    ps = d.get("prover_sec")
+    if isinstance(ps, dict):
+        optional.append(("prover_sec", pick(ps, ("step_wall", "gkr", "commit_private", "commit_public", "fft_gkr", "fri_commit", "pc_prove_reference_definition"))))
+        optional.append(("gkr_field_ops_per_sec", d.get("gkr_field_ops_per_sec")))
+    else:
+        optional.append(("prover_sec", ps))
+        optional.append(("prover_sec_device", d.get("prover_sec_device")))
+    optional.append(("host_verifier_accepts", d.get("host_verifier_accepts", ((d.get("verifier") or {}).get("complete_protocol") or {}).get("accepted"))))
+    fp = d.get("first_proof_sec")
+    optional.append(("first_proof_sec", fp))
+    ip = d.get("interactive_path")
+    if isinstance(ip, dict):
+        pr = ip.get("per_round") or {}
+        optional.append(("interactive_path", {"prover_sec": ip.get("prover_sec"), "init_calls_sec": ip.get("init_calls_sec"), "round_calls_sec": ip.get("round_calls_sec"),
+                                              "transcript_equals_batched": ip.get("transcript_equals_batched"), "rounds": pr.get("rounds"),
+                                              "hbm_frac_overall_per_round": pr.get("hbm_frac_overall")}))
+    for name in ("roofline_gkr_dominant", "roofline_ntt"):
+        r = d.get(name)
+        if isinstance(r, dict):
+            optional.append((name, pick(r, ("kernel", "bound", "frac", "hbm_frac", "avg_launch_us", "kernel_time_share", "time_share", "total_us"))))
+    ks = d.get("kernels")
+    if isinstance(ks, list):
+        optional.append(("kernel_time_share", {k["kernel"]: k["time_share"] for k in ks[:8]}))
+    x64 = d.get("x64_gkr")
+    if isinstance(x64, dict):
+        r64 = x64.get("roofline") or {}
+        i64 = x64.get("interactive_path") or {}
+        optional.append(("x64_gkr", {"workload": "BASELINE configs[1]: SHA-256 x64, GKR on GPU, PC off", "value": x64.get("value"), "ms_per_step": x64.get("ms_per_step"),
+                                     "prover_sec_device": x64.get("prover_sec_device"), "steps": x64.get("steps"), "bit_exact": x64.get("bit_exact_vs_reference_golden"),
+                                     "roofline_kernel": r64.get("kernel"), "roofline_frac": r64.get("frac"), "roofline_hbm_frac": r64.get("hbm_frac"),
+                                     "interactive_prover_sec": i64.get("prover_sec"), "first_proof_sec": x64.get("first_proof_sec"),
+                                     "cpu_reference_prover_sec": (x64.get("cpu_baseline") or {}).get("prover_sec"),
+                                     "two_in_flight_ms_per_proof": (x64.get("two_in_flight") or {}).get("ms_per_proof")}))
+    cp = d.get("cpu_port_x1024_gkr")
+    if isinstance(cp, dict):
+        optional.append(("cpu_port_x1024_gkr", pick(cp, ("kind", "gkr_prove_sec", "gkr_field_ops_per_sec", "transcript_equals_gpu"))))
+    sh = d.get("sharded")
+    if isinstance(sh, dict):
+        cm = sh.get("commitment") or {}
+        optional.append(("sharded", {"workload": (sh.get("config") or {}).get("workload"), "ms_per_step": sh.get("ms_per_step"), "value": sh.get("value"), "scaling": sh.get("scaling"),
+                                     "rccl_ranks": sh.get("rccl_ranks"), "transport": sh.get("transport"), "bit_exact": sh.get("assembled_transcript_bit_exact_vs_reference"),
+                                     "commitment_wall_sec": cm.get("wall_sec"),
+                                     "commitment_bit_exact": cm.get("roots_input0_allsum_fri_bit_exact_vs_reference_on_every_rank"), "error": sh.get("error")}))
+    for k in ("sharded_proof", "sharded_proof_simulation"):
+        if isinstance(d.get(k), dict):
+            v = d[k]
+            optional.append((k, pick(v, ("world", "max_device_ms", "device_ms_per_rank", "chains", "chains_split_by_index", "assembled_equals_unsharded"))))
+    if d.get("multi_gpu_sublegs_error"):
+        line["multi_gpu_sublegs_error"] = d["multi_gpu_sublegs_error"]
+    if d.get("value_definition"):
+        optional.append(("value_definition", d["value_definition"][:400]))
+    line["detail_file"] = detail_file
+    line = _r(_finite(line))
+    opt = [(k, _r(_finite(v))) for k, v in optional if v is not None]
+    def render(n):
+        o = dict(line)
+        for k, v in opt[:n]:
+            o[k] = v
+        return json.dumps(o, allow_nan=False, separators=(",", ":"))
+    n = len(opt)
+    s = render(n)
+    while n > 0 and len(s.encode()) > LINE_TARGET_BYTES:
+        n -= 1
+        s = render(n)
+    if len(s.encode()) > LINE_HARD_CAP_BYTES:           # cannot happen with the fields above; keep the contract fields whatever happens
+        keep = {k: line[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+        keep["config"] = {"workload": str(line["config"].get("workload"))[:300]}
+        keep["detail_file"] = detail_file
+        s = json.dumps(keep, allow_nan=False, separators=(",", ":"))
+    return s
+
+
+def write_detail(d, n_gpus, path=None):
+    """Everything the line leaves out.  Default: gpurun_out/bench_detail_n<N>.json under the repo (merged back by gpurun), else the temp dir."""
+    cands = [path] if path else [os.path.join(ROOT, "gpurun_out", "bench_detail_n%d.json" % n_gpus), os.path.join(tempfile.gettempdir(), "bench_detail_n%d.json" % n_gpus)]
+    for p in cands:
+        try:
+            os.makedirs(os.path.dirname(p), exist_ok=True)
+            with open(p, "w") as f:
+                json.dump(_finite(d), f, allow_nan=False)
+            return os.path.relpath(p, ROOT) if p.startswith(ROOT) else p
+        except OSError:
+            continue
+    return None
+
+
+class OneLine:
+    """Exactly one JSON line on stdout, whoever gets there first (the normal end of main() or the watchdog)."""
+
+    def __init__(self):
+        import threading
+        self.lock = threading.Lock()
+        self.done = False
+
+    def emit(self, detail, n_gpus, path=None):
+        with self.lock:
+            if self.done:
+                return False
+            self.done = True
+            f = write_detail(detail, n_gpus, path)
+            print(compact_line(detail, f), flush=True)
+            return True
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--blocks", type=int, default=64)
+    ap.add_argument("--blocks", type=int, default=1024, help="SHA-256 blocks of the headline circuit (default 1024: BASELINE configs[2] / configs[3])")
+    ap.add_argument("--no-pc", action="store_true", help="headline = GKR only, commitment off (--blocks 64 --no-pc is BASELINE configs[1], the round-1..3 headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-port-x1024", action="store_true", help="skip the oracle port's full-size GKR proof on one host core (~55 s) beside cpu_baseline")
     ap.add_argument("--randomize", type=int, nargs=2, metavar=("LAYERS", "LOG_SIZE"), default=None,
-                    help="BASELINE configs[4] flavour: layeredCircuit::randomize(LAYERS, LOG_SIZE) instead of the SHA-256 circuit (no CPU baseline, no golden)")
+                    help="BASELINE configs[4] flavour: layeredCircuit::randomize(LAYERS, LOG_SIZE) instead of the SHA-256 circuit, GKR only (no CPU baseline)")
     ap.add_argument("--shard-chains", action="store_true",
-                    help="strong scaling: ONE proof per step; its independent sumcheck chains are dealt out to the ranks (vp_set_shard) and the "
+                    help="strong scaling, GKR only: ONE proof per step; its independent sumcheck chains are dealt out to the ranks (vp_set_shard) and the "
                          "transcript is assembled by one RCCL all-reduce per proof (launch under torch.distributed.run)")
     ap.add_argument("--shard-sim", type=int, default=0, metavar="W",
-                    help="single GPU: run the W shards of a chain-sharded proof one after the other and report each shard's device time "
-                         "(the per-rank compute of a W-GPU run; outside the timed region)")
+                    help="single GPU, GKR only: run the W shards of a chain-sharded proof one after the other and report each shard's device time")
     ap.add_argument("--shard-split", type=int, default=0, metavar="MIN_LOG",
                     help="with --shard-sim or --shard-chains: also split tables of at least 2^(log2 W + MIN_LOG) entries by index over the ranks (vp_set_shard_split; 11 is the smallest useful value)")
-    ap.add_argument("--with-pc", action="store_true", help="also time the Virgo commitment (commit_private + commit_public + FRI commit phase)")
-    ap.add_argument("--no-x1024-leg", action="store_true",
-                    help="skip the nested x1024_with_pc leg (BASELINE configs[2]) that the default single-GPU run appends to the x64 headline line")
-    ap.add_argument("--per-launch", action="store_true", help="include the per-launch table of the headline leg (and every interactive round) in the JSON line (the per-kernel table is always there)")
-    ap.add_argument("--no-two-in-flight", action="store_true", help="N = 1: skip the `two_in_flight` sub-leg (two sessions of the circuit, two host threads)")
+    ap.add_argument("--with-pc", action="store_true", help="GKR-only headline: also time the Virgo commitment calls one by one (detail file)")
+    ap.add_argument("--no-x64-leg", action="store_true", help="N = 1 default run: skip the nested x64 GKR-only leg (BASELINE configs[1])")
+    ap.add_argument("--per-launch", action="store_true", help="detail file: per-launch table of every call and every interactive round")
+    ap.add_argument("--no-two-in-flight", action="store_true", help="GKR-only legs: skip the `two_in_flight` sub-leg (two sessions of the circuit, two host threads)")
     ap.add_argument("--no-sharded-leg", action="store_true", help="N > 1: skip the `sharded` sub-leg (one proof + its commitment over all ranks, RCCL)")
-    ap.add_argument("--subleg-timeout", type=float, default=900.0, help="N > 1: seconds the multi-rank sub-legs may take before the line is printed without them")
+    ap.add_argument("--subleg-timeout", type=float, default=900.0, help="N > 1: seconds the multi-rank sub-leg may take before the line is printed without it and the ranks exit 3")
+    ap.add_argument("--detail-file", default=None, help="where everything the line leaves out goes (default gpurun_out/bench_detail_n<N>.json)")
     a = ap.parse_args()
 
     # ---- one process per GPU, always.  N > 1 without a launcher: start the ranks (before anything of this process touches the GPU).
@@ -721,211 +1164,79 @@ def main():
         world, rank, local = dist_setup(a.gpus, rccl=True)
         barrier(world)
     local = device_of(local)
-    shard = a.shard_chains and world > 1
-    seed = 1 if shard else 1 + rank          # a sharded proof: every rank holds the same instance
     vp.lib_host()
     golden = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))
-    gname = "sha256_x%d" % a.blocks if not a.randomize else "randomize_%d_%d" % tuple(a.randomize)
+    gkr_only = a.no_pc or a.randomize or a.shard_chains or a.shard_sim
     if a.randomize:
         a.no_cpu_baseline = True
+    out = OneLine()
     with tempfile.TemporaryDirectory() as tmp:
         pws = unpack_pws(tmp)
-        if a.randomize:
-            circ = vp.Circuit.randomize(a.randomize[0], a.randomize[1], seed=seed)
-        else:
-            circ = vp.Circuit.from_pws(pws, a.blocks, seed=seed)
         # one-time cost of the process (HIP context, code objects: ~0.25 s) paid by a 3-gate circuit first, so that circuit_upload_sec is
         # what a caller sees per circuit (host flatten + vp_circuit_upload with its device-side list building + vp_evaluate)
         t_up = time.perf_counter()
         c0 = vp.Circuit.randomize(2, 1, seed=1); s0 = vp.Session(c0, device=local); s0.close(); c0.close()
         first_use_sec = time.perf_counter() - t_up
-        t_up = time.perf_counter()
-        sess = vp.Session(circ, device=local)            # raises without the HIP library / GPU
-        upload_sec = time.perf_counter() - t_up
-        sess.draw_tape()
-        if shard:
-            sess.set_shard(rank, world)
-            import torch.distributed as dist
-            if "nccl" in dist.get_backend():           # the data-path collective lives in the C ABI: RCCL on the device buffer, no torch tensor
-                sess.attach_comm(rank, world)
-                shard = "rccl"
-            if a.shard_split:
-                sess.set_shard_split(a.shard_split)
-                if shard != "rccl":
-                    raise SystemExit("--shard-split in the multi-rank mode needs the in-library communicator (RCCL); rehearse it with --shard-sim")
-        tr, res, elapsed, dev_ms = gkr_leg(vp, circ, sess, a.steps, a.warmup, world, shard, local)
-        elapsed, proofs = aggregate(world, elapsed, float(a.steps))
-        shard_info = None
-        if shard:
-            proofs = float(a.steps)                    # all ranks worked on the same proof
-            import torch, torch.distributed as dist
-            dm = torch.tensor([dev_ms / a.steps if r == rank else 0.0 for r in range(world)], dtype=torch.float64)
-            dist.all_reduce(dm)
-            owner, cost = sess.shard_chains()
-            shard_info = {"device_ms_per_rank": [float(x) for x in dm], "chains": int((cost > 0).sum()),
-                          "chains_per_rank": [int(((owner == r) & (cost > 0)).sum()) for r in range(world)],
-                          "chains_split_by_index": int((owner == -1).sum()),
-                          "collective": ("one RCCL all-reduce (u64 sum) of the transcript%s per proof inside vp_prove_gkr (vp_comm_init: no torch tensor, no host bounce)"
-                                         % (" + export area" if a.shard_split else "")) if shard == "rccl"
-                                        else "one all-reduce (sum, int64) of the %d-byte transcript per proof through torch, backend %s" % (len(tr), dist.get_backend())}
-            sess.set_shard(0, 1)                       # the roofline / verifier legs below run the whole proof on every rank
-            tr_full, _ = sess.prove_gkr()
-            assert tr_full == tr, "assembled sharded transcript differs from the unsharded proof"
-        rows, per_launch, roof, res_p = profile_gkr(sess, tr, a.blocks if not a.randomize else 0)
-
-        shard_sim = None
-        if a.shard_sim > 1 and world == 1:
-            # per-rank compute of a chain-sharded proof on W GPUs, measured shard by shard on this one GPU (no collective here)
-            per = []
-            parts = []
-            for r in range(a.shard_sim):
-                sess.set_shard(r, a.shard_sim)
-                if a.shard_split:
-                    sess.set_shard_split(a.shard_split)
-                for _ in range(2):
-                    sess.prove_gkr()
-                ms = []
-                for _ in range(max(3, a.steps // 2)):
-                    t_s = time.perf_counter()
-                    tr_s, res_s = sess.prove_gkr()
-                    ms.append((res_s["gkr_device_ms"], 1e3 * (time.perf_counter() - t_s)))
-                parts.append(tr_s)
-                per.append({"rank": r, "device_ms": sum(m[0] for m in ms) / len(ms), "wall_ms": sum(m[1] for m in ms) / len(ms)})
-            owner, cost = sess.shard_chains()
-            summed = vp.sum_transcripts(parts)
-            t_f = time.perf_counter()
-            assembled = sess.shard_finish(summed) if a.shard_split else summed
-            finish_ms = 1e3 * (time.perf_counter() - t_f)
-            sess.set_shard(0, 1)
-            shard_sim = {"world": a.shard_sim, "per_rank": per, "max_device_ms": max(x["device_ms"] for x in per),
-                         "max_wall_ms": max(x["wall_ms"] for x in per),
-                         "index_split_min_log": a.shard_split or None, "chains_split_by_index": int((owner == -1).sum()),
-                         "host_finish_ms": finish_ms if a.shard_split else None,
-                         "cost_share_per_rank": [float(cost[owner == r].sum() / cost.sum()) for r in range(a.shard_sim)],
-                         "assembled_equals_unsharded": assembled == tr,
-                         "note": "each shard run alone on this GPU; a W-GPU run adds one all-reduce of the transcript (and, with the index split, of the export area) per proof"}
-
-        pipelined = None
-        if rank == 0 and world == 1 and not shard and not a.no_two_in_flight:
-            g_ = golden.get(gname)
-            pipelined = two_in_flight_leg(vp, circ, sess, tr, a.steps, a.warmup, local, (g_["mult_counter"] + g_["add_counter"]) if g_ else None)
-
-        interactive = None
+        if gkr_only:
+            detail = gkr_workload(vp, a, pws, golden, world, rank, local, a.blocks, a.shard_chains)
+        else:
+            detail = protocol_workload(vp, a, pws, golden, world, rank, local, a.blocks)
         if rank == 0:
-            # the drop-in path of the reference's own call pattern (one vp_round per verifier message), outside the timed region
-            t_i = time.perf_counter()
-            tr_i, res_i, ok_i = sess.prove_interactive()
-            interactive = {"prover_sec": res_i["prove_sec"], "init_calls_sec": res_i.get("init_sec"), "round_calls_sec": res_i.get("round_sec"),
-                           "finalize_calls_sec": res_i.get("finalize_sec"), "wall_sec_with_host_verifier": time.perf_counter() - t_i,
-                           "transcript_equals_batched": tr_i == tr, "verified": ok_i,
-                           "per_round": per_round_summary(sess.round_stats(), full=a.per_launch),
-                           "note": "reference definition of Prove Time (sum of prover-method spans) over the interactive entry points (vp_round per verifier message)"}
-            sess.draw_tape()
-
-        pc = None
-        if a.with_pc and rank == 0:
-            pc = pc_leg(vp, sess, circ, golden, gname)
-
-        bit_exact = None
-        ref_ops = None
-        if gname in golden:
-            g = golden[gname]
-            ref_ops = g["mult_counter"] + g["add_counter"]
-            if rank == 0:
-                gold = open(os.path.join(ROOT, "tests", "golden", g["transcript"]), "rb").read()[g["gkr_slice"][0]:g["gkr_slice"][1]]
-                bit_exact = (tr == gold)
-        # the reported flag is the FULL replay check (per-round identities, wiring predicates and getFinalValue on the device, Liu
-        # check, input check): the per-round identities alone hold by construction for the rounds whose b is derived
-        ok, sec_d = sess.check(tr, device_predicates=True)
-        verify = None
-        if rank == 0:      # the verifier's side of the same proof (outside the timed region): O(|C|) predicate loops on host vs on the GPU
-            ok_h, sec_h = sess.check(tr)
-            verify = {"host_predicates_sec": sec_h, "device_predicates_sec": sec_d, "accepted": bool(ok_h and ok),
-                      "note": "the verifier's O(|C|) loops on the device: wiring predicates (vp_predicates), gr of verifyLiu (vp_liu_gr), input-layer MLE (vp_layer_mle); the per-round checks stay on the host"}
-
-        if rank == 0:
-            sec_per_proof_job = elapsed / a.steps                      # wall time of one step (all ranks in parallel)
-            ops_total = (ref_ops or 0) * proofs
-            line = {
-                "metric": "prover sec + field-ops/sec, SHA-256 circuit, 1/2/4/8 MI355X (bit-exact)",
-                "value": ops_total / elapsed if ref_ops else None,
-                "unit": "field-ops/s",
-                "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-                "ms_per_step": 1e3 * sec_per_proof_job,
-                "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None,
-                "dtype": "u64 (F_p^2, p=2^61-1)", "data": "synthetic",
-                "config": {"workload": ("SHA-256 %d-block circuit (SHA256_64.pws x%d, %d gates, %d layers), GKR sumcheck on GPU, Virgo PC off"
-                                        % (a.blocks, a.blocks, circ.gates, circ.layers)) if not a.randomize else
-                                       ("layeredCircuit::randomize(%d, %d) (%d gates, %d layers), GKR sumcheck on GPU, Virgo PC off"
-                                        % (a.randomize[0], a.randomize[1], circ.gates, circ.layers)),
-                           "mode": "batched (verifier tape pre-drawn; transcript identical to the interactive run)",
-                           "proofs_per_step": 1 if shard else world, "field_ops_per_proof": ref_ops},
-                "prover_sec": sec_per_proof_job,
-                "prover_sec_device": 1e-3 * dev_ms / a.steps,
-                "rounds": res["rounds"], "kernel_launches_per_proof": res["launches"],
-                "bit_exact_vs_reference_golden": bit_exact, "host_verifier_accepts": bool(ok),
-                "host_verifier_check": "full replay: per-round identities, wiring predicates + getFinalValue (device loops), Liu check, input-layer check",
-                "golden_origin": (golden[gname].get("origin", "the real reference binary (oracle/_ref/ref_run)") if gname in golden else None),
-                "two_in_flight": pipelined,
-                "interactive_path": interactive, "circuit_upload_sec": upload_sec, "process_first_use_sec": first_use_sec, "verifier": verify,
-                "roofline": roof, "kernels": rows,
-            }
-            if a.per_launch:
-                line["per_launch"] = per_launch
-            if pc is not None:
-                line["polynomial_commitment"] = pc
-            if shard_info is not None:
-                line["sharded_proof"] = shard_info
-            if shard_sim is not None:
-                line["sharded_proof_simulation"] = shard_sim
-            if world == 1 and not a.no_cpu_baseline:
-                cb = cpu_baseline(pws, a.blocks, ref_ops)
-                cb["host_cpu"] = cpu_model()
-                cb["host_cores_visible"] = os.cpu_count()
-                line["cpu_baseline"] = cb
-        sess.close()
-        circ.close()
-        if rank == 0:
-            if world == 1 and a.blocks == 64 and not a.randomize and not a.no_x1024_leg and not shard and "sha256_x1024" in golden:
-                line["x1024_with_pc"] = x1024_leg(vp, pws, golden, a, local)
-            line["rccl_ranks"] = None
-        # ---- N > 1: BASELINE configs[3] (x1024, one proof per GPU) and one proof + commitment sharded over all ranks, in the SAME line.
-        # Every rank takes part; a watchdog prints the line without them if a collective does not come back.
-        if world > 1 and not shard and a.blocks == 64 and not a.randomize:
-            state = {"leg": None}
+            detail["process_first_use_sec"] = first_use_sec
+            detail["rccl_ranks"] = None
+            if world == 1 and not gkr_only and not a.no_cpu_baseline:
+                detail["cpu_baseline"] = cpu_protocol_baseline(pws, detail["config"].get("field_ops_per_proof"))
+        # ---- N = 1 default run: BASELINE configs[1] (x64, GKR only) as a nested leg, with the real reference's GKR proof of it on one host core
+        if world == 1 and not gkr_only and a.blocks == 1024 and not a.no_x64_leg:
+            x64 = gkr_workload(vp, a, pws, golden, 1, 0, local, 64, False, cpu_base=False, nested=True)
+            detail["x64_gkr"] = x64
+            cb = detail.get("cpu_baseline")
+            if isinstance(cb, dict):      # the reference's x64 GKR proof was timed inside the cpu_baseline run (same circuit, same box)
+                x64["cpu_baseline"] = {"kind": "reference", "cores": 1, "prover_sec": cb["gkr_prove_sec"], "value": cb["gkr_field_ops_per_sec"], "unit": "field-ops/s"}
+            if not a.no_cpu_baseline and not a.no_cpu_port_x1024:
+                import oracle_binding as ob
+                gold = open(os.path.join(ROOT, "tests", "golden", golden["sha256_x1024"]["transcript"]), "rb").read()
+                gs = golden["sha256_x1024"]["gkr_slice"]
+                port = cpu_port_x1024(pws, gold[gs[0]:gs[1]] if detail["bit_exact"].get("transcript") else None)
+                oc = ob.Circuit.from_pws(pws, 64, seed=1)
+                _, st64 = oc.prove_gkr()
+                oc.close()
+                port["port_x64_gkr_prove_sec_same_box"] = st64["prove_sec"]
+                if isinstance(cb, dict):
+                    port["reference_over_port_ratio_x64_same_box"] = cb["gkr_prove_sec"] / st64["prove_sec"]
+                    cb["reference_over_port_ratio_x64_same_box"] = port["reference_over_port_ratio_x64_same_box"]
+                detail["cpu_port_x1024_gkr"] = port
+        # ---- N > 1: ONE proof + its commitment sharded over all ranks (RCCL inside the C ABI), in the SAME line.  Every rank takes part; a
+        # watchdog prints the line without it and ends the ranks with a non-zero code if a collective does not come back.
+        if world > 1 and not gkr_only and not a.no_sharded_leg:
+            state = {"leg": "sharded"}
 
             def on_timeout():
+                # never restart anything from here: print what there is (rank 0) and leave with an error code, so that the launcher reports the hang
                 if rank == 0:
-                    line["multi_gpu_sublegs_error"] = "timed out after %.0f s in %s" % (a.subleg_timeout, state["leg"])
-                    print(json.dumps(line), flush=True)
-                os._exit(0)
+                    detail["multi_gpu_sublegs_error"] = "timed out after %.0f s in %s" % (a.subleg_timeout, state["leg"])
+                    out.emit(detail, world, a.detail_file)
+                    sys.stdout.flush()
+                os._exit(3)
 
             wd = Watchdog(a.subleg_timeout, on_timeout)
-            sub = {}
-            for name, enabled, fn in (("x1024_replicas", not a.no_x1024_leg and "sha256_x1024" in golden,
-                                       lambda: replicas_x1024_leg(vp, pws, golden, a, world, rank, local)),
-                                      ("sharded", not a.no_sharded_leg,
-                                       lambda: sharded_leg(vp, pws, golden, a, world, rank, local, 64 if a.no_x1024_leg else 1024))):
-                if not enabled:
-                    continue
-                state["leg"] = name
-                failed = None
-                try:
-                    sub[name] = fn()
-                except Exception as e:          # a rank that fails outside a collective: the others find out at the next flag exchange
-                    failed = "%s: %s" % (type(e).__name__, e)
-                    sub[name] = {"error": failed}
-                if not allreduce_min_flag(world, failed is None):
-                    sub.setdefault(name, {})
-                    if "error" not in sub[name]:
-                        sub[name] = {"error": "another rank failed in this leg", "partial": sub[name]}
+            failed = None
+            sub = None
+            try:
+                sub = sharded_leg(vp, pws, golden, a, world, rank, local, a.blocks)
+            except Exception as e:          # a rank that fails outside a collective: the others find out at the flag exchange
+                failed = "%s: %s" % (type(e).__name__, e)
+                sub = {"error": failed}
+            if not allreduce_min_flag(world, failed is None) and "error" not in sub:
+                sub = {"error": "another rank failed in this leg", "partial": sub}
             wd.cancel()
             if rank == 0:
-                line.update(sub)
-                if isinstance(sub.get("sharded"), dict):
-                    line["rccl_ranks"] = sub["sharded"].get("rccl_ranks")
+                detail["sharded"] = sub
+                detail["rccl_ranks"] = sub.get("rccl_ranks") if isinstance(sub, dict) else None
+                if isinstance(sub, dict) and "error" in sub:
+                    detail["multi_gpu_sublegs_error"] = sub["error"]
         if rank == 0:
-            print(json.dumps(line), flush=True)
+            out.emit(detail, world, a.detail_file)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

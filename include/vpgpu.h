@@ -256,6 +256,12 @@ int vp_commit_private(vp_ctx *, uint8_t root[32]);
  * codewords h (merkle_root_h).  vp_commit_private must have run.                                       */
 int vp_commit_public(vp_ctx *, const vp_F *pub, uint64_t n_pub, vp_F *inner_product_sum, vp_F all_sum[65],
                      uint8_t root_h[32]);
+/* The same call for the public vector the PROTOCOL passes (src/verifier.cpp:368-369: `initBetaTable(pub, bit_length, r_liu, 1)` right before
+ * `p->commit_public(pub, ...)`): the caller hands over the opening point (bit_length(layer 0) canonical coordinates) instead of its 2^n-entry
+ * eq table, and the device builds eq(point, .) in HBM itself (src/utils.cpp:29-45) — nothing of the public vector crosses PCIe (134 MB at
+ * n = 23).  Same outputs, same field elements as vp_commit_public(eq table of the point); an eq table is a tensor by construction, so the one-
+ * slice encoding (pc_tensor_pub) applies without its check.  VP_EINVAL on a sharded commitment.                                       */
+int vp_commit_public_eq(vp_ctx *, const vp_F *point, int n_point, vp_F *inner_product_sum, vp_F all_sum[65], uint8_t root_h[32]);
 /* fri::commit_phase_step(r) (lib/virgo/src/fri.cpp:289-424), called n-6 times by poly_commit_prover::commit_phase
  * (vpd_verifier.cpp:44-74): fold the current codewords of all slices by r, hash the new leaves, build the Merkle
  * tree, return its root.  The first call builds the virtual oracle (poly_commit.h:294-318) from the data

@@ -608,6 +608,54 @@ def _fri_golden(golden, name):
     return r, roots, fin
 
 
+@pytest.mark.parametrize("name,blocks", [("sha256_x1", 1), ("sha256_x16", 16), ("sha256_x64", 64)])
+def test_protocol_pass_matches_reference(vp, golden, pws_path, name, blocks):
+    """vph_prove_protocol — the prover side of the complete protocol in one pass from a tape drawn up front (commit_private, batched GKR,
+    vp_commit_public_eq on the opening point, fft_gkr, FRI commit phase; bench.py's configs[2] step): the real reference's whole transcript,
+    its FRI roots and its final codeword, byte for byte; twice in a row (the second pass runs on the buffers of the first)."""
+    import os
+    from conftest import GOLDEN
+    c = vp.Circuit.from_pws(pws_path, blocks, seed=1)
+    s = vp.Session(c)
+    s.draw_protocol_tape()
+    gold = open(os.path.join(GOLDEN, golden[name]["transcript"]), "rb").read()
+    _, roots_gold, fin_gold = _fri_golden(golden, name)
+    for _ in range(2):
+        tr, roots, fin, sec = s.prove_protocol()
+        assert tr == gold
+        assert roots == roots_gold and np.array_equal(fin, fin_gold)
+        assert sec["total"] >= sec["gkr"] + sec["commit_private"] + sec["commit_public"] + sec["fft_gkr"] + sec["fri_commit"] - 1e-6
+    if name == "sha256_x1":                            # fft_gkr's messages inside the protocol run: the reference's record
+        assert s.last_fft_gkr() == open(os.path.join(GOLDEN, "fftgkr_sha256_x1.bin"), "rb").read()
+    s.close(); c.close()
+
+
+def test_commit_public_eq_equals_commit_public_on_the_table(vp, pws_path):
+    """vp_commit_public_eq(point) == vp_commit_public(eq(point, .)): root, inner product, all_sum — for a random point, a point with a zero
+    coordinate and a point with a coordinate 1 (pub[0] = 0: the tensor shortcut must step aside)."""
+    c = vp.Circuit.from_pws(pws_path, 2, seed=3)
+    s = vp.Session(c)
+    s.commit_private()
+    n = c.layer_bitlen(0)
+    rng = np.random.default_rng(11)
+    for case in range(3):
+        point = rng.integers(0, P, size=(n, 2), dtype=np.uint64)
+        if case == 1:
+            point[3] = 0
+        if case == 2:
+            point[n - 2] = (1, 0)
+        want = s.commit_public(s.eq_table(point))[:3]
+        got = s.commit_public_eq(point)[:3]
+        assert got == want
+    bad = rng.integers(0, P, size=(n, 2), dtype=np.uint64)
+    bad[0, 0] = P                                       # non-canonical coordinate: refused at the door
+    with pytest.raises(RuntimeError):
+        s.commit_public_eq(bad)
+    with pytest.raises(RuntimeError):
+        s.commit_public_eq(bad[:-1])
+    s.close(); c.close()
+
+
 @pytest.mark.parametrize("batched", [True, False])
 @pytest.mark.parametrize("name,blocks", [("sha256_x1", 1), ("sha256_x16", 16), ("sha256_x64", 64)])
 def test_fri_commit_phase_matches_reference(vp, golden, pws_path, name, blocks, batched):

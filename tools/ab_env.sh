@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}; B=$1; shift
 for S in "$@"; do
   if [ "$S" = "-" ]; then E=""; else E="$S"; fi
-  env $E python3 $R/bench.py --blocks $B --steps 8 --warmup 2 --no-cpu-baseline 2> /dev/null | python3 -c "
+  env $E python3 $R/bench.py --blocks $B --no-pc --steps 8 --warmup 2 --no-cpu-baseline 2> /dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read()); r=d['roofline']
 print('%-40s device ms %.4f wall %.4f | fold launches %d avg us %.1f GB/s %.0f | ok %s' % ('$S', d['prover_sec_device']*1e3, d['ms_per_step'], r['launches'], r['avg_launch_us'], r['achieved'], d['host_verifier_accepts']))"

@@ -1,13 +1,13 @@
 #!/bin/bash
 # Profiles of the headline bench on the GPU box (run through gpurun from the repo root):
-#   tools/gpu_profile.sh TAG [bench args, e.g. --blocks 1024]   -> gpurun_out/prof_TAG/{stats,stats_serial,fetch,write,sq}/..., pmc_summary.json
+#   tools/gpu_profile.sh TAG [bench args; default = the headline (x1024 + commitment); e.g. --blocks 64 --no-pc]   -> gpurun_out/prof_TAG/{stats,stats_serial,fetch,write,sq}/..., pmc_summary.json
 # Kernel-trace stats and each PMC counter set are separate rocprofv3 runs (MI355X_MICROARCH.md, HBM / rocprofv3 section).
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof_$1
 shift
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline $*"
+B="python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-x64-leg $*"
 rocprofv3 --kernel-trace --stats -d "$O/stats" -o stats -- $B > "$O/bench_stats.json" 2> "$O/stats.err" || exit 1
 VP_GKR_SERIAL=1 rocprofv3 --kernel-trace --stats -d "$O/stats_serial" -o stats -- $B > "$O/bench_stats_serial.json" 2> "$O/stats_serial.err" || exit 1
 rocprofv3 --pmc FETCH_SIZE -d "$O/fetch" -o pmc -- $B > /dev/null 2> "$O/fetch.err" || exit 1

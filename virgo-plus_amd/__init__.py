@@ -127,6 +127,7 @@ def lib_gpu():
         L.vp_shard_exchange_local.argtypes = [ctypes.POINTER(vp), ctypes.c_int]
         L.vp_commit_private.argtypes = [vp, vp]
         L.vp_commit_public.argtypes = [vp, vp, ctypes.c_uint64, vp, vp, vp]
+        L.vp_commit_public_eq.argtypes = [vp, vp, ctypes.c_int, vp, vp, vp]
         L.vp_fri_commit.argtypes = [vp, vp, ctypes.c_int, vp]
         L.vp_fri_final.argtypes = [vp, vp]
         L.vp_fri_open.argtypes = [vp, ctypes.c_int, ctypes.c_uint64, vp, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
@@ -188,6 +189,8 @@ def lib_host():
         L.vph_prove_full.argtypes = [vp, vp, u64, ctypes.POINTER(u64), ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
         L.vph_prove_and_verify_full.argtypes = [vp, ctypes.c_int, vp, u64, ctypes.POINTER(u64)] + [ctypes.POINTER(ctypes.c_double)] * 3 + [ctypes.c_char_p, ctypes.c_int]
         L.vph_last_fri.argtypes = [vp, vp, u64, vp, vp]
+        L.vph_draw_protocol_tape.argtypes = [vp]
+        L.vph_prove_protocol.argtypes = [vp, vp, u64, ctypes.POINTER(u64), vp, u64, vp, ctypes.POINTER(ctypes.c_double), ctypes.c_char_p, ctypes.c_int]
         L.vph_last_point.argtypes = [vp, vp, ctypes.c_int]
         L.vph_last_fft_gkr.restype = ctypes.c_int64
         L.vph_last_fft_gkr.argtypes = [vp, vp, u64]
@@ -741,6 +744,41 @@ class Session:
         if rc < 0:
             raise RuntimeError("prove_full failed: " + err.value.decode())
         return buf.raw[: n.value], rc == 0
+
+    def commit_public_eq(self, point):
+        """prover::commit_public on pub = eq(point, .) built on the device (vp_commit_public_eq): (root_h, input_0 bytes, all_sum bytes, device ms)."""
+        import numpy as np
+        point = np.ascontiguousarray(point, dtype=np.uint64)
+        out = ctypes.create_string_buffer(32 + 16 + 65 * 16)
+        ctx = lib_host().vph_session_ctx(self.h)
+        base = ctypes.addressof(out)
+        rc = lib_gpu().vp_commit_public_eq(ctx, point.ctypes.data, point.shape[0], base + 32, base + 48, base)
+        if rc:
+            raise RuntimeError("vp_commit_public_eq failed: %d %s" % (rc, (lib_gpu().vp_last_error(ctx) or b"").decode()))
+        return out.raw[:32], out.raw[32:48], out.raw[48:], self.commit_device_ms()
+
+    def draw_protocol_tape(self):
+        """F::init() + every draw of verifier::verify() up front, in its order: GKR, fft_gkr, FRI fold challenges."""
+        if lib_host().vph_draw_protocol_tape(self.h):
+            raise RuntimeError("draw_protocol_tape: the commitment needs an input layer of at least 2^7 wires")
+
+    def prove_protocol(self):
+        """The prover side of the complete protocol in one pass (no verifier work): commit_private -> batched GKR -> commit_public on
+        eq(r_liu, .) -> fft_gkr -> FRI commit phase.  Returns (transcript in the golden layout, FRI roots bytes, final codeword (2048, 2),
+        seconds dict {total, commit_private, gkr, commit_public, fft_gkr, fri_commit})."""
+        import numpy as np
+        if not hasattr(self, "_pp"):
+            cap = self._cap + 32 + 32 + 16 + 65 * 16
+            self._pp = (ctypes.create_string_buffer(cap), cap, ctypes.create_string_buffer(32 * 32), np.zeros((2048, 2), dtype=np.uint64),
+                        (ctypes.c_double * 6)(), ctypes.c_uint64(0), ctypes.create_string_buffer(512))
+        buf, cap, roots, fin, sec, n, err = self._pp
+        rc = lib_host().vph_prove_protocol(self.h, ctypes.cast(buf, ctypes.c_void_p), cap, ctypes.byref(n), ctypes.cast(roots, ctypes.c_void_p), len(roots),
+                                           fin.ctypes.data, sec, err, len(err))
+        if rc:
+            raise RuntimeError("prove_protocol failed: " + err.value.decode())
+        st = self.circuit.layer_bitlen(0) - 6
+        return (buf.raw[: n.value], roots.raw[:32 * st], fin.copy(),
+                {"total": sec[0], "commit_private": sec[1], "gkr": sec[2], "commit_public": sec[3], "fft_gkr": sec[4], "fri_commit": sec[5]})
 
     def prove_and_verify_full(self, reps=33):
         """The complete protocol incl. commitment verification: (transcript bytes, accepted, times dict)."""

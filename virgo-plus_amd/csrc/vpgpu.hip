@@ -165,7 +165,7 @@ struct vp_ctx {
     // polynomial commitment
     F *pc_rt = nullptr, *pc_coef = nullptr, *pc_cw = nullptr; Dig *pc_tree = nullptr; int pc_lm = -1; double commit_ms = 0;
     std::map<std::pair<const void *, int>, F *> pc_rtc;   // compact root tables of smaller orders, keyed by (source table, log2 order)
-    F *pc_q0 = nullptr; int *pc_flag = nullptr; bool pc_q_tensor = false;   // tensor public vector: its one encoded slice (commit_public)
+    F *pc_q0 = nullptr, *pc_eq = nullptr; int *pc_flag = nullptr; bool pc_q_tensor = false;   // tensor public vector: its one encoded slice (commit_public)
     F *pc_pub = nullptr, *pc_qcw = nullptr, *pc_hcw = nullptr, *pc_tmp = nullptr, *pc_small = nullptr; Dig *pc_tree_h = nullptr; bool pc_private_done = false;
     F *pc_scr = nullptr; size_t pc_scr_cap = 0;
     F *pc_fri_all = nullptr; std::vector<size_t> fri_cw_off, fri_tree_off; F *pc_open_buf = nullptr;
@@ -858,7 +858,7 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
     ctx->pred_r = ctx->pred_pool = ctx->pred_part = ctx->pred_out = nullptr; ctx->pred_jobs = nullptr; ctx->pred_dot = nullptr; ctx->pred_map = nullptr;
     ctx->pc_rt = ctx->pc_coef = ctx->pc_cw = nullptr; ctx->pc_tree = nullptr; ctx->pc_lm = -1; ctx->pc_rtc.clear();
     ctx->pc_pub = ctx->pc_qcw = ctx->pc_hcw = ctx->pc_tmp = ctx->pc_small = nullptr; ctx->pc_tree_h = nullptr; ctx->pc_private_done = false;
-    ctx->pc_q0 = nullptr; ctx->pc_flag = nullptr; ctx->pc_q_tensor = false;
+    ctx->pc_q0 = nullptr; ctx->pc_eq = nullptr; ctx->pc_flag = nullptr; ctx->pc_q_tensor = false;
     ctx->pc_scr = nullptr; ctx->pc_scr_cap = 0; ctx->pc_fri_all = nullptr; ctx->pc_open_buf = nullptr; ctx->fri_cw_off.clear(); ctx->fri_tree_off.clear();
     ctx->pc_fri[0] = ctx->pc_fri[1] = nullptr; ctx->pc_fri_tree = nullptr; ctx->pc_fri_roots = nullptr; ctx->fri_step = -1; ctx->pc_public_done = false;
     int max_bl = 0;

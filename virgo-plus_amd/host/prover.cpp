@@ -259,6 +259,12 @@ prover::hhash_digest prover::commit_public(std::vector<F> &pub, F &inner_product
     check(vp_commit_public(ctx, cF(pub.data()), pub.size(), mF(&inner_product_sum), mF(all_sum.data()), d.b), "vp_commit_public");
     return d;
 }
+prover::hhash_digest prover::commit_public_eq(const std::vector<F> &point, F &inner_product_sum, std::vector<F> &all_sum) {
+    hhash_digest d;
+    all_sum.resize(65);
+    check(vp_commit_public_eq(ctx, cF(point.data()), (int) point.size(), mF(&inner_product_sum), mF(all_sum.data()), d.b), "vp_commit_public_eq");
+    return d;
+}
 std::vector<F> prover::predicates(int layer, const std::vector<F> &r_g, const F &assert_random, const std::vector<F> &r_u,
                                   const std::vector<F> &r_v, int n_v) {
     std::vector<F> out(5 + 7 * (size_t) layer);

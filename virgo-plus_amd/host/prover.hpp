@@ -53,6 +53,9 @@ public:
     hhash_digest commit_private();                       // src/prover.cpp:524-530
     // src/prover.cpp:542-546 (the mask argument of the reference is the one-element zero vector and is implied)
     hhash_digest commit_public(std::vector<F> &pub, F &inner_product_sum, std::vector<F> &all_sum);
+    // extension: the protocol's own public vector, pub = eq(point, .) (src/verifier.cpp:368-369), built on the device from the point
+    // (vp_commit_public_eq) — same outputs as commit_public on that table, nothing of it crosses PCIe
+    hhash_digest commit_public_eq(const std::vector<F> &point, F &inner_product_sum, std::vector<F> &all_sum);
     // poly_commit_prover::commit_phase pieces (vpd_verifier.cpp:44-74 -> fri::commit_phase_step / commit_phase_final)
     // verifier-side wiring predicates of one layer on the device (vp_predicates): 5 + 7*layer sums, see include/vpgpu.h
     std::vector<F> predicates(int layer, const std::vector<F> &r_g, const F &assert_random, const std::vector<F> &r_u,

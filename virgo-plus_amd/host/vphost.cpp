@@ -1,5 +1,6 @@
 #include "vphost.h"
 
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -17,6 +18,7 @@ struct vph_session {
     std::vector<F> fft_gkr_msgs; double pc_times[3] = {0, 0, 0};          // fft_gkr messages; {PC prove (reference definition), of which fft_gkr, query answering}
     double t_init = 0, t_round = 0, t_fin = 0;
     std::vector<F> last_point;                                           // r_liu after the last Liu sumcheck of the last complete-protocol run
+    std::vector<F> ptape_fft, ptape_fri;                                 // vph_draw_protocol_tape: the draws after the GKR tape (fft_gkr, FRI folds)
 };
 
 static void set_err(char *err, int errlen, const std::string &m) {
@@ -357,6 +359,83 @@ int vph_prove_full(vph_session *s, uint8_t *transcript, uint64_t capacity, uint6
         memcpy(transcript, out.data(), out.size());
         if (n_written) *n_written = out.size();
         return ok ? 0 : 1;
+    } catch (const std::exception &e) {
+        set_err(err, errlen, e.what());
+        return -2;
+    }
+}
+
+// ---- the prover side of the COMPLETE protocol as one pass (the bench's configs[2] step) -----------------------------------------------
+// The reference verifier's draws do not depend on the prover's messages (glibc random(), lib/virgo/src/fieldElement.cpp:119-124), so the
+// whole tape of verifier::verify() can be drawn first, in its order: F::init(), the GKR draws (src/verifier.cpp:144-279), fft_gkr's
+// (lib/virgo/src/fft_circuit_GKR.cpp, count verifier::fftGkrDraws), the FRI fold challenges (vpd_verifier.cpp:57).
+int vph_draw_protocol_tape(vph_session *s) {
+    const int n = s->circ->c.circuit[0].bitLength;
+    if (n < 7) return -1;
+    F::init();
+    verifier v(nullptr, s->circ->c);
+    s->tape = v.drawTape();
+    const int ln = n - 6;
+    s->ptape_fft.resize((size_t) verifier::fftGkrDraws(ln));
+    for (auto &x : s->ptape_fft) x = F::random();
+    s->ptape_fri.resize(ln);
+    for (auto &x : s->ptape_fri) x = F::random();
+    return 0;
+}
+// commit_private -> GKR (one batched device pass) -> commit_public on eq(r_liu, .) built on the device -> fft_gkr -> FRI commit phase +
+// final codeword: every prover call of verifier::verify() except answering the queries, nothing of the verifier.  transcript = the golden
+// layout (merkle_root_l | GKR | merkle_root_h | input_0 | all_sum[65]); fri_roots: 32 bytes per fold step; final_pairs: 2048 elements;
+// sec[6] = whole pass | commit_private | GKR | commit_public | fft_gkr | FRI commit phase + final (host wall clock).  The fft_gkr
+// messages stay with the session (vph_last_fft_gkr), the FRI data too (vph_last_fri).  0 = done, < 0 = error.
+int vph_prove_protocol(vph_session *s, uint8_t *transcript, uint64_t capacity, uint64_t *n_written, uint8_t *fri_roots, uint64_t roots_cap,
+                       uint64_t *final_pairs, double sec[6], char *err, int errlen) {
+    try {
+        const layeredCircuit &C = s->circ->c;
+        const int n = C.circuit[0].bitLength, ln = n - 6;
+        if (s->tape.empty() || (int) s->ptape_fri.size() != ln) { set_err(err, errlen, "vph_draw_protocol_tape first"); return -1; }
+        int max_bl = 0;
+        for (auto &l : C.circuit) max_bl = std::max(max_bl, l.bitLength);
+        using clk = std::chrono::high_resolution_clock;
+        auto since = [](clk::time_point t) { return std::chrono::duration<double>(clk::now() - t).count(); };
+        const auto t0 = clk::now();
+        std::vector<uint8_t> out;
+        out.reserve(capacity);
+        auto t = clk::now();
+        const prover::hhash_digest rl = s->p->commit_private();                       // src/verifier.cpp:137
+        out.insert(out.end(), rl.b, rl.b + 32);
+        const double s_priv = since(t);
+        t = clk::now();
+        s->p->proveGKR(s->tape, out);                                                 // :144-169
+        const double s_gkr = since(t);
+        // r_liu after the last Liu sumcheck = the last max_bl draws of the GKR tape (verifier::drawTape), its first n coordinates
+        s->last_point.assign(s->tape.end() - max_bl, s->tape.end() - max_bl + n);
+        t = clk::now();
+        F inner; std::vector<F> all_sum;
+        const prover::hhash_digest rh = s->p->commit_public_eq(s->last_point, inner, all_sum);   // :368-379
+        const double s_pub = since(t);
+        out.insert(out.end(), rh.b, rh.b + 32);
+        const uint8_t *ib = reinterpret_cast<const uint8_t *>(&inner);
+        out.insert(out.end(), ib, ib + 16);
+        const uint8_t *ab = reinterpret_cast<const uint8_t *>(all_sum.data());
+        out.insert(out.end(), ab, ab + 65 * 16);
+        t = clk::now();
+        s->fft_gkr_msgs = s->p->fftGkr(ln, s->ptape_fft);                             // vpd_verifier.cpp:92
+        const double s_fft = since(t);
+        t = clk::now();
+        const std::vector<prover::hhash_digest> ds = s->p->friCommit(s->ptape_fri);   // vpd_verifier.cpp:44-74
+        s->fri_final = s->p->friFinal();
+        const double s_fri = since(t);
+        s->fri_roots.clear();
+        for (auto &d : ds) s->fri_roots.insert(s->fri_roots.end(), d.b, d.b + 32);
+        s->fri_r = s->ptape_fri;
+        const double s_all = since(t0);
+        if (out.size() > capacity || (fri_roots && roots_cap < s->fri_roots.size())) { set_err(err, errlen, "output buffer too small"); return -1; }
+        memcpy(transcript, out.data(), out.size());
+        if (n_written) *n_written = out.size();
+        if (fri_roots) memcpy(fri_roots, s->fri_roots.data(), s->fri_roots.size());
+        if (final_pairs) memcpy(final_pairs, s->fri_final.data(), s->fri_final.size() * sizeof(F));
+        if (sec) { sec[0] = s_all; sec[1] = s_priv; sec[2] = s_gkr; sec[3] = s_pub; sec[4] = s_fft; sec[5] = s_fri; }
+        return 0;
     } catch (const std::exception &e) {
         set_err(err, errlen, e.what());
         return -2;

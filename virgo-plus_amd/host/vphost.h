@@ -99,6 +99,15 @@ int vph_fri_commit_batched(vph_session *, const uint64_t *r_pairs, int n_steps, 
  * GKR: writes merkle_root_l | GKR slice | merkle_root_h | input_0 | all_sum[65] — the golden layout.   */
 int vph_prove_full(vph_session *, uint8_t *transcript, uint64_t capacity, uint64_t *n_written, int batched, char *err,
                    int errlen);
+/* The prover side of the COMPLETE protocol in one pass (bench step of BASELINE configs[2]).  vph_draw_protocol_tape: F::init() and every
+ * draw of verifier::verify() in its order — GKR (src/verifier.cpp:144-279), fft_gkr (fft_circuit_GKR.cpp), FRI fold challenges
+ * (vpd_verifier.cpp:57) — valid up front because the reference's challenges are glibc random() (fieldElement.cpp:119-124).
+ * vph_prove_protocol: commit_private -> batched GKR -> commit_public on eq(r_liu, .) built on the device (vp_commit_public_eq) -> fft_gkr
+ * -> FRI commit phase + final codeword; no verifier work inside.  transcript: the golden layout; fri_roots: 32 bytes per step;
+ * final_pairs: 2048 elements; sec[6] = whole pass | commit_private | GKR | commit_public | fft_gkr | FRI commit (host wall clock).   */
+int vph_draw_protocol_tape(vph_session *);
+int vph_prove_protocol(vph_session *, uint8_t *transcript, uint64_t capacity, uint64_t *n_written, uint8_t *fri_roots, uint64_t roots_cap,
+                       uint64_t *final_pairs, double sec[6], char *err, int errlen);
 /* No GPU needed: F::init(), draw the tape for `circuit`, replay the host verifier over `transcript`
  * (GKR slice).  0 = accepted, 1 = rejected.                                                            */
 int vph_verify_transcript(vph_circuit *, const uint8_t *transcript, uint64_t n, int skip_predicates);
