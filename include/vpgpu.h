@@ -134,6 +134,12 @@ typedef struct {
                                        becomes a dependency too.  2: built node by node in the captured shape (stream order kept as edges) except that
                                        the inner products V_u get a stream of their own; 3: and the phase-2 init launches another.  Faster or slower depending on the circuit (the runtime places
                                        the branches of such a graph itself): plan_autotune tries the forms last and keeps what replays fastest    [0] */
+    int32_t ntt_r8;                 /* VP_NTT_R8: transforms of 2^13 .. 2^17 points as two LDS passes of radix-8 Stockham butterflies with lazy arithmetic
+                                       (k_ntt8_cols / k_ntt8_rows: the eighth root of unity is 2^30 (1 -+ i) in F_p[i], p = 2^61 - 1, so three stages cost
+                                       seven multiplications per eight points; sums stay unreduced between folds).  0: the radix-4 pair k_ntt_split /
+                                       k_ntt_lds of rounds 2-3 (kept as the cross-check)                                             [1] */
+    int32_t fri_vo_fused;           /* VP_FRI_VO_FUSED: vp_fri_commit folds the first FRI level straight from the committed codewords l, q, h (k_fri_fold0_vo); the
+                                       virtual oracle of poly_commit.h:294-318 is never written to HBM and read back.  0: separate k_pc_virtual_oracle pass [1] */
 } vp_options;
 void vp_options_default(vp_options *opt);
 
@@ -178,8 +184,11 @@ int vp_vres(vp_ctx *, const vp_F *r_0, int r_0_size, vp_F *out);
  *     Threads: every entry point holds its context's lock for the duration of the call — calls on one context are serialised, calls on
  *     different contexts run concurrently (two proofs in flight from two threads).  An entry point that suspends another context's resident
  *     kernel waits for that context's current call to return first; the set-up entry points (vp_create*, vp_circuit_upload, vp_comm_*) take
- *     turns among themselves (they park the process-wide random() state).  vp_destroy of a context another thread is still calling into is
- *     the caller's bug, as is vp_shard_exchange_local on contexts other threads are using.
+ *     turns among themselves (they park the process-wide random() state).  While a thread is inside one of those set-up entry points NO other
+ *     thread of the process may call random() / rand() / srandom(): glibc's generator state is process-wide, a draw made meanwhile comes from the
+ *     library's private seed-1 state and is missing from the caller's stream afterwards (the reference's verifier is single-threaded and draws
+ *     between prover calls, never during one).  vp_destroy of a context another thread is still calling into is the caller's bug, as is
+ *     vp_shard_exchange_local on contexts other threads are using.
  * prover::sumcheckInitPhase1(assert_random) for layer `layer` (src/prover.cpp:189-280).  r_liu is the
  * point the layer's claim is at (bit_length(layer) entries; prover::r_liu in the reference).           */
 int vp_phase1_init(vp_ctx *, int layer, const vp_F *r_liu, const vp_F *assert_random);
@@ -293,6 +302,13 @@ int vp_fri_open(vp_ctx *, int oracle, uint64_t leaf, vp_F values[130], uint8_t *
  * uploaded.  vp_fft_gkr_sizes gives the two element counts (2 lg^2 + 9 lg + 96 and 64 + 3 (2 lg^2 + 2 lg + 6) + 2 + 2 lg); lg in 1..20.        */
 int vp_fft_gkr_sizes(int lg, uint64_t *n_tape, uint64_t *n_msgs);
 int vp_fft_gkr(vp_ctx *, int lg, const vp_F *tape, uint64_t n_tape, vp_F *msgs, uint64_t capacity, uint64_t *n_written);
+/* The same call in two halves: vp_fft_gkr_begin copies the tape and queues the whole pass on a stream of its own, vp_fft_gkr_end waits for it and
+ * hands out the messages.  fft_gkr reads nothing of the circuit or the commitment (its circuit is fixed by lg, its inputs are the verifier's
+ * draws), so a prover that has the tape up front starts it first and lets its ~250 small launches fill the gaps of the commitment's and the
+ * proof's kernels (vph_prove_protocol does).  Between the two calls every other entry point of the context may be used; a second begin, or the
+ * one-call form, before the end is VP_EINVAL.                                                                                             */
+int vp_fft_gkr_begin(vp_ctx *, int lg, const vp_F *tape, uint64_t n_tape);
+int vp_fft_gkr_end(vp_ctx *, vp_F *msgs, uint64_t capacity, uint64_t *n_written);
 /* Device time of the last vp_commit_private / vp_commit_public / vp_fri_step / vp_fft_gkr in milliseconds (hipEvents). */
 int vp_commit_stats(vp_ctx *, double *commit_ms);
 
@@ -395,7 +411,7 @@ int vp_set_profiling(vp_ctx *, int level);
  * launch on every table it holds; closing kernels: the remaining ones), `first_round` the earliest of them (1-based).   */
 enum { VP_K_BETA = 0, VP_K_LIGHT, VP_K_CHUNKS, VP_K_COMBINE, VP_K_DOT, VP_K_DOTFIN, VP_K_SFGEN, VP_K_SF, VP_K_SEG, VP_K_EMIT,
        VP_K_FIXUP, VP_K_NTT_SPLIT, VP_K_NTT_LDS, VP_K_NTT_UNSPLIT, VP_K_LEAF_HASH, VP_K_MERKLE, VP_K_PC_POINTWISE, VP_K_FRI_FOLD,
-       VP_K_ROUND, VP_K_INIT3, VP_K_COUNT };
+       VP_K_ROUND, VP_K_INIT3, VP_K_NTT8_COLS, VP_K_NTT8_ROWS, VP_K_COUNT };
 typedef struct {
     int32_t kind;             /* VP_K_*                                                          */
     int32_t step;             /* position in the launch order of the call                        */

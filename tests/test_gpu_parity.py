@@ -490,7 +490,7 @@ def test_sha3_matches_hashlib(vp, ctx):
     assert out[0].tobytes().hex() == "070fa1ab6fcc557ed14d42941f1967693048551eb9042a8d0a057afbd75e81e0"
 
 
-@pytest.mark.parametrize("ln,ratio", [(0, 1), (1, 1), (3, 32), (3, 1), (7, 32), (10, 1), (13, 32), (14, 1), (14, 32), (15, 32), (16, 1), (17, 1)])
+@pytest.mark.parametrize("ln,ratio", [(0, 1), (1, 1), (3, 32), (3, 1), (7, 32), (10, 1), (12, 32), (13, 1), (13, 32), (14, 1), (14, 32), (15, 1), (15, 32), (16, 1), (16, 32), (17, 1), (17, 32)])
 def test_fft_vs_oracle(vp, ob, ctx, ln, ratio):
     rng = np.random.default_rng(ln * 7 + ratio)
     n = 1 << ln

@@ -1,0 +1,288 @@
+// Round 4: the long transforms of the commitment (N = 2^13 .. 2^17 points: RS_polynomial.cpp:26-220 at the sizes of poly_commit.h:41-349) as two
+// LDS passes of radix-8 Stockham butterflies with LAZY arithmetic.  Part of the single translation unit vpgpu.hip (included by vp_kernels_pc.h).
+//
+//   N = N1 x N2, N2 = 512.   j = j1 N2 + j2,  k = k1 + N1 k2:   w_N^(jk) = w_N1^(j1 k1) . w_N^(j2 k1) . w_N2^(j2 k2)
+//   k_ntt8_cols (pass A): a workgroup holds 4096 / N1 neighbouring COLUMNS j2 of one (row, coset) in LDS ([j1][column], columns fastest: every
+//       global and LDS access of a wave is a run of >= 256 contiguous bytes) and runs the N1-point transform down each of them; the first pass
+//       reads its eight inputs straight from global memory (the coset twist w_M^(j1 N2 b) of the encoder rides on that load), the last pass
+//       multiplies by w_N^(j2 k1) (times the column's share w_M^(j2 b) of the twist: ONE root w_M^(j2 (32 k1 + b))) and stores [k1][j2].
+//   k_ntt8_rows (pass B): a workgroup holds 8 neighbouring ROWS k1 (512 contiguous elements each), one wave per row: 64 lanes x 8 points, three
+//       radix-8 passes, then the 8 x 512 tile goes out in natural order k1 + N1 k2 — eight consecutive k1 per k2: whole 128-byte lines.
+//
+// What is different from k_ntt_lds / k_ntt_split (kept for N <= 2^12 and as the cross-check, vp_options.ntt_r8 = 0):
+//   * radix 8 with the eighth root for free.  p = 2^61 - 1 has sqrt(2) = 2^31, so w_8 = 2^30 (1 -+ i): a multiplication by it is two additions and
+//     two 61-bit rotations, by w_4 = -+i a swap and a negation.  Seven twiddle multiplications per eight points and THREE stages (radix 4: three
+//     per four points and two stages), none in the first pass of a transform; three LDS round trips for 512 points instead of five.
+//   * lazy butterflies.  Limbs travel weakly reduced (< 2^61 + 8, congruent mod p): sums and differences of the three butterfly levels are plain
+//     64-bit additions (a difference adds a multiple of p first), folded (x & p) + (x >> 61) once after the second level and once at the end —
+//     no compare / subtract / select anywhere; the products are the weak form of f_mad31c (one fold, no conditional subtraction).  Only the last
+//     store of a transform canonicalises.  (k_ntt_lds: eight canonical add/sub of ~20 instructions per radix-4 butterfly.)
+//   * Stockham ordering: natural order in, natural order out, no bit reversal anywhere; an in-place pass is "all reads, barrier, all writes".
+//   * the second pass stores whole lines by itself: no dependence on which XCD the neighbouring sub-transform ran on.
+#pragma once
+
+namespace vp {
+
+constexpr u64 LZ_P2 = 2 * P61;              // 2^62 - 2
+constexpr u64 LZ_P4 = 4 * P61;              // 2^63 - 4
+__device__ __forceinline__ u64 lz_fold(u64 x) { return (x & P61) + (x >> 61); }
+__device__ __forceinline__ F lz_fold(const F &x) { return f_make(lz_fold(x.re), lz_fold(x.im)); }
+__device__ __forceinline__ F lz_add(const F &a, const F &b) { return f_make(a.re + b.re, a.im + b.im); }
+// a - b (mod p) as a + (K - b), K a multiple of p with K >= every limb of b
+template <u64 K> __device__ __forceinline__ F lz_sub(const F &a, const F &b) { return f_make(a.re + (K - b.re), a.im + (K - b.im)); }
+// x * w_4, w_4 = -i (forward) / +i (inverse); K as above for the limbs of x
+template <bool INV, u64 K> __device__ __forceinline__ F lz_mul_w4(const F &x) { return INV ? f_make(K - x.im, x.re) : f_make(x.im, K - x.re); }
+// v * 2^30 (mod p) for any v < 2^64: v = h 2^31 + l  ->  h + l 2^30  (< 2^61 + 2^33)
+__device__ __forceinline__ u64 lz_rot30(u64 v) { return (v >> 31) + ((v & 0x7fffffffull) << 30); }
+// x * w_8, w_8 = 2^30 (1 - i) (forward: the reference's w_M^(M/8), fieldElement.cpp:237-249) / 2^30 (1 + i) (inverse); limbs of x < 2^61 + 8
+template <bool INV> __device__ __forceinline__ F lz_mul_w8(const F &x) {
+    const u64 s = x.re + x.im;
+    return INV ? f_make(lz_rot30(x.re + (LZ_P2 - x.im)), lz_rot30(s)) : f_make(lz_rot30(s), lz_rot30(x.im + (LZ_P2 - x.re)));
+}
+__device__ __forceinline__ F lz_canon(const F &x) {                      // weakly reduced (< 2^62) -> canonical
+    u64 a = lz_fold(x.re), b = lz_fold(x.im);
+    return f_make(a >= P61 ? a - P61 : a, b >= P61 ? b - P61 : b);
+}
+// root (canonical) x data (limbs < 2^62): weak product, limbs < 2^61 + 4
+__device__ __forceinline__ F lz_mul(const F &root, const F &x) { return f_mad31c<true, false>(root, x, f_make(0, 0)); }
+
+// Eight-point DFT in place: u[m'] <- sum_m u[m] w_8^(m m').  Inputs: limbs < 2^61 + 8.  Outputs: limbs < 2^61 + 8 (folded), congruent mod p.
+template <bool INV> __device__ __forceinline__ void lz_dft8(F (&u)[8]) {
+    // level 1 (pairs m, m + 4):                         sums < 2^62 + 16, differences < 3 * 2^61
+    const F a0 = lz_add(u[0], u[4]), a1 = lz_sub<LZ_P2>(u[0], u[4]), a2 = lz_add(u[2], u[6]), a3 = lz_sub<LZ_P2>(u[2], u[6]);
+    const F a4 = lz_add(u[1], u[5]), a5 = lz_sub<LZ_P2>(u[1], u[5]), a6 = lz_add(u[3], u[7]), a7 = lz_sub<LZ_P2>(u[3], u[7]);
+    // level 2 (4-point transforms of the even and of the odd inputs):   every limb < 7 * 2^61 < 2^64, then folded to < 2^61 + 8
+    const F t3 = lz_mul_w4<INV, LZ_P4>(a3), t7 = lz_mul_w4<INV, LZ_P4>(a7);          // limbs <= 2^63 - 4
+    const F e0 = lz_fold(lz_add(a0, a2)), e2 = lz_fold(lz_sub<LZ_P4>(a0, a2)), e1 = lz_fold(lz_add(a1, t3)), e3 = lz_fold(lz_sub<LZ_P4>(a1, t3));
+    const F o0 = lz_fold(lz_add(a4, a6)), o2 = lz_fold(lz_sub<LZ_P4>(a4, a6)), o1 = lz_fold(lz_add(a5, t7)), o3 = lz_fold(lz_sub<LZ_P4>(a5, t7));
+    // level 3: X[k] = E[k] + w_8^k O[k], X[k + 4] = E[k] - w_8^k O[k];  w_8^k O[k] has limbs <= 2^62 - 2
+    const F q1 = lz_mul_w8<INV>(o1), q2 = lz_mul_w4<INV, LZ_P2>(o2), q3 = lz_mul_w4<INV, LZ_P2>(lz_mul_w8<INV>(o3));
+    u[0] = lz_fold(lz_add(e0, o0)); u[4] = lz_fold(lz_sub<LZ_P2>(e0, o0));
+    u[1] = lz_fold(lz_add(e1, q1)); u[5] = lz_fold(lz_sub<LZ_P2>(e1, q1));
+    u[2] = lz_fold(lz_add(e2, q2)); u[6] = lz_fold(lz_sub<LZ_P2>(e2, q2));
+    u[3] = lz_fold(lz_add(e3, q3)); u[7] = lz_fold(lz_sub<LZ_P2>(e3, q3));
+}
+// Four-point DFT in place (same bounds in and out)
+template <bool INV> __device__ __forceinline__ void lz_dft4(F (&u)[4]) {
+    const F a0 = lz_add(u[0], u[2]), a1 = lz_sub<LZ_P2>(u[0], u[2]), a2 = lz_add(u[1], u[3]), a3 = lz_sub<LZ_P2>(u[1], u[3]);
+    const F t3 = lz_mul_w4<INV, LZ_P4>(a3);
+    u[0] = lz_fold(lz_add(a0, a2)); u[2] = lz_fold(lz_sub<LZ_P4>(a0, a2)); u[1] = lz_fold(lz_add(a1, t3)); u[3] = lz_fold(lz_sub<LZ_P4>(a1, t3));
+}
+__device__ __forceinline__ void lz_dft2(F (&u)[2]) {
+    const F s = lz_fold(lz_add(u[0], u[1])), d = lz_fold(lz_sub<LZ_P2>(u[0], u[1]));
+    u[0] = s; u[1] = d;
+}
+
+struct Ntt8Args {
+    const F *in; F *out;            // cols: source rows -> scratch [row x coset][k1][j2];   rows: scratch -> destination (natural order)
+    const F *RT; u32 half_m;        // w_M^e, e < M/2 (pc_root_table): the coset twist and the w_N^(j2 k1) twiddles between the passes
+    const F *RTn;                   // FULL circle of the pass's own order (N1 entries for cols, 512 for rows): w^k, k < order
+    int ln, l1;                     // N = 2^ln, N1 = 2^l1 (4 <= l1 <= 8), N2 = 2^(ln - l1) = 512
+    u32 in_stride;                  // cols: elements between input rows
+    u32 ncoset;                     // forward encoder: cosets per row (blockIdx.z); otherwise 1
+    int twist;                      // cols: multiply input j by w_M^(j coset)
+    int do_scale; F scale;          // rows: multiply by N^-1 on the way out (inverse transforms)
+};
+
+constexpr u32 NTT8_TILE = 4096;     // elements of a workgroup's tile (64 KiB of LDS; two workgroups per CU)
+constexpr u32 NTT8_THREADS = 512;
+
+// ---- pass A: N1-point transforms down 4096 / N1 neighbouring columns --------------------------------------------------------------------
+// Stockham pass of radix R at sub-length s over a transform of length n: butterfly q < n / R takes the inputs at q + m n / R, multiplies input m by
+// w_(R s)^(k m), k = q mod s, and leaves output m' at (q - k) R + k + m' s.
+template <bool INV>
+__global__ void __launch_bounds__(NTT8_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) k_ntt8_cols(Ntt8Args a) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    F *L = reinterpret_cast<F *>(smem_raw);
+    const u32 l1 = (u32) a.l1, N1 = 1u << l1, lc = 12 - l1, cols = 1u << lc, N2 = 1u << (a.ln - a.l1), M = 2 * a.half_m;
+    const u32 tid = threadIdx.x, row = blockIdx.y, coset = blockIdx.z;
+    const u32 c = tid & (cols - 1), j2 = blockIdx.x * cols + c;
+    const F *src = a.in + (size_t) row * a.in_stride + j2;
+    F *dst = a.out + (((size_t) row * a.ncoset + coset) << a.ln) + j2;
+    const u32 wN = M >> a.ln;                                   // w_N = w_M^wN
+    const u32 nr8 = l1 / 3, rem = l1 - 3 * nr8;                 // passes: nr8 of radix 8, then one of radix 4 (rem 2) or 2 (rem 1)
+    // ---- first pass (radix 8, s = 1, no twiddles): inputs from global memory, twisted
+    {
+        const u32 q = tid >> lc;                                // < N1 / 8
+        F u[8];
+#pragma unroll
+        for (u32 m = 0; m < 8; ++m) u[m] = src[(size_t) (q + m * (N1 >> 3)) * N2];
+        if (a.twist && coset) {
+#pragma unroll
+            for (u32 g = 0; g < 8; g += 4) {                    // four root gathers in flight at a time (register budget: 128 VGPRs, 4 waves per SIMD)
+                F w[4]; u32 e[4];
+#pragma unroll
+                for (u32 m = 0; m < 4; ++m) {
+                    e[m] = (u32) (((unsigned long long) (q + (g + m) * (N1 >> 3)) * N2 * coset) & (M - 1));      // the j1 share of w_M^(j coset); j2's joins the output twiddle
+                    w[m] = root_raw(a.RT, a.half_m, e[m]);
+                }
+                loads_first();
+#pragma unroll
+                for (u32 m = 0; m < 4; ++m) u[g + m] = lz_mul(root_fin(w[m], a.half_m, e[m]), u[g + m]);
+            }
+        }
+        lz_dft8<INV>(u);
+#pragma unroll
+        for (u32 m = 0; m < 8; ++m) L[((q * 8 + m) << lc) + c] = u[m];
+    }
+    __syncthreads();
+    u32 s = 8;
+    // ---- middle passes of radix 8 (all but the last pass of the transform)
+    const u32 total_passes = nr8 + (rem ? 1 : 0);
+    for (u32 p = 1; p + 1 < total_passes; ++p) {
+        const u32 q = tid >> lc, k = q & (s - 1);
+        F u[8];
+#pragma unroll
+        for (u32 m = 0; m < 8; ++m) u[m] = L[((q + m * (N1 >> 3)) << lc) + c];
+        {
+            const u32 st = N1 / (8 * s);                        // w_(8 s) = w_N1^st
+            F w[8];
+#pragma unroll
+            for (u32 m = 1; m < 8; ++m) { const u32 e = (k * m * st) & (N1 - 1); w[m] = a.RTn[INV ? ((N1 - e) & (N1 - 1)) : e]; }
+#pragma unroll
+            for (u32 m = 1; m < 8; ++m) u[m] = lz_mul(w[m], u[m]);
+        }
+        lz_dft8<INV>(u);
+        __syncthreads();
+#pragma unroll
+        for (u32 m = 0; m < 8; ++m) L[(((q - k) * 8 + k + m * s) << lc) + c] = u[m];
+        __syncthreads();
+        s *= 8;
+    }
+    // ---- last pass: radix 8, 4 or 2; outputs multiplied by w_N^(j2 k1) (and the column's share of the twist) and stored [k1][j2]
+    const u32 ec = (a.twist && coset) ? coset : 0u;
+    auto out_twiddle = [&](u32 k1) -> u32 {                     // exponent of w_M
+        unsigned long long e = (unsigned long long) j2 * ((unsigned long long) k1 * wN);
+        if (INV) e = (M - (e & (M - 1))) & (M - 1);
+        return (u32) ((e + (unsigned long long) j2 * ec) & (M - 1));
+    };
+    if (rem == 0) {
+        const u32 q = tid >> lc, k = q & (s - 1);               // s = N1 / 8: k = q
+        F u[8];
+#pragma unroll
+        for (u32 m = 0; m < 8; ++m) u[m] = L[((q + m * (N1 >> 3)) << lc) + c];
+        {
+            const u32 st = N1 / (8 * s);
+            F w[8];
+#pragma unroll
+            for (u32 m = 1; m < 8; ++m) { const u32 e = (k * m * st) & (N1 - 1); w[m] = a.RTn[INV ? ((N1 - e) & (N1 - 1)) : e]; }
+#pragma unroll
+            for (u32 m = 1; m < 8; ++m) u[m] = lz_mul(w[m], u[m]);
+        }
+        lz_dft8<INV>(u);
+#pragma unroll
+        for (u32 g = 0; g < 8; g += 4) {
+            F w[4]; u32 e[4];
+#pragma unroll
+            for (u32 m = 0; m < 4; ++m) { e[m] = out_twiddle((q - k) * 8 + k + (g + m) * s); w[m] = root_raw(a.RT, a.half_m, e[m]); }
+            loads_first();
+#pragma unroll
+            for (u32 m = 0; m < 4; ++m) dst[(size_t) ((q - k) * 8 + k + (g + m) * s) * N2] = lz_mul(root_fin(w[m], a.half_m, e[m]), u[g + m]);     // weakly reduced: pass B folds
+        }
+    } else if (rem == 2) {
+        // radix 4 at s = N1 / 4: two butterflies per thread
+#pragma unroll
+        for (u32 h = 0; h < 2; ++h) {
+            const u32 t = tid + h * NTT8_THREADS, q = t >> lc, k = q & (s - 1);
+            F u[4];
+#pragma unroll
+            for (u32 m = 0; m < 4; ++m) u[m] = L[((q + m * (N1 >> 2)) << lc) + c];
+            const u32 st = N1 / (4 * s);
+            F w[4];
+#pragma unroll
+            for (u32 m = 1; m < 4; ++m) { const u32 e = (k * m * st) & (N1 - 1); w[m] = a.RTn[INV ? ((N1 - e) & (N1 - 1)) : e]; }
+#pragma unroll
+            for (u32 m = 1; m < 4; ++m) u[m] = lz_mul(w[m], u[m]);
+            lz_dft4<INV>(u);
+            F ww[4]; u32 e[4];
+#pragma unroll
+            for (u32 m = 0; m < 4; ++m) { e[m] = out_twiddle((q - k) * 4 + k + m * s); ww[m] = root_raw(a.RT, a.half_m, e[m]); }
+            loads_first();
+#pragma unroll
+            for (u32 m = 0; m < 4; ++m) dst[(size_t) ((q - k) * 4 + k + m * s) * N2] = lz_mul(root_fin(ww[m], a.half_m, e[m]), u[m]);
+        }
+    } else {
+        // radix 2 at s = N1 / 2: four butterflies per thread
+#pragma unroll
+        for (u32 h = 0; h < 4; ++h) {
+            const u32 t = tid + h * NTT8_THREADS, q = t >> lc, k = q & (s - 1);
+            F u[2];
+            u[0] = L[(q << lc) + c]; u[1] = L[((q + (N1 >> 1)) << lc) + c];
+            { const u32 e = k & (N1 - 1); u[1] = lz_mul(a.RTn[INV ? ((N1 - e) & (N1 - 1)) : e], u[1]); }      // w_(2 s)^k = w_N1^k
+            lz_dft2(u);
+            F ww[2]; u32 e[2];
+#pragma unroll
+            for (u32 m = 0; m < 2; ++m) { e[m] = out_twiddle((q - k) * 2 + k + m * s); ww[m] = root_raw(a.RT, a.half_m, e[m]); }
+            loads_first();
+#pragma unroll
+            for (u32 m = 0; m < 2; ++m) dst[(size_t) ((q - k) * 2 + k + m * s) * N2] = lz_mul(root_fin(ww[m], a.half_m, e[m]), u[m]);
+        }
+    }
+}
+
+// ---- pass B: 512-point transforms along 8 neighbouring rows k1, one wave per row; natural-order store -----------------------------------------
+constexpr u32 NTT8_PITCH = 578;     // elements per row in LDS: 512 * 9 / 8 padded positions, + 2 so that the transposed read-out spreads over the banks
+__device__ __forceinline__ u32 ntt8_pad(u32 i) { return i + (i >> 3); }
+template <bool INV>
+__global__ void __launch_bounds__(NTT8_THREADS, 2) k_ntt8_rows(Ntt8Args a) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    F *L = reinterpret_cast<F *>(smem_raw);                       // 8 x NTT8_PITCH elements
+    const u32 N1 = 1u << a.l1, tid = threadIdx.x, w = tid >> 6, j = tid & 63;
+    const u32 k1_0 = blockIdx.x * 8, rt = blockIdx.y;             // rt = row * ncoset + coset
+    const F *src = a.in + ((size_t) rt << a.ln) + (size_t) (k1_0 + w) * 512;
+    F *Lw = L + w * NTT8_PITCH;
+    F u[8];
+    // pass 1 (s = 1): straight from global memory, no twiddles; outputs at 8 j + m
+#pragma unroll
+    for (u32 m = 0; m < 8; ++m) u[m] = src[j + 64 * m];
+    lz_dft8<INV>(u);
+#pragma unroll
+    for (u32 m = 0; m < 8; ++m) Lw[9 * j + m] = u[m];
+    __syncthreads();
+    // pass 2 (s = 8): twiddles w_64^(k m) = w_512^(8 k m); outputs at (j - k) 8 + k + 8 m
+    {
+        const u32 k = j & 7;
+#pragma unroll
+        for (u32 m = 0; m < 8; ++m) u[m] = Lw[ntt8_pad(j) + 72 * m];
+        F tw[8];
+#pragma unroll
+        for (u32 m = 1; m < 8; ++m) { const u32 e = 8 * k * m; tw[m] = a.RTn[INV ? ((512 - e) & 511) : e]; }
+#pragma unroll
+        for (u32 m = 1; m < 8; ++m) u[m] = lz_mul(tw[m], u[m]);
+        lz_dft8<INV>(u);
+        __syncthreads();
+#pragma unroll
+        for (u32 m = 0; m < 8; ++m) Lw[9 * (j - k) + k + 9 * m] = u[m];
+        __syncthreads();
+    }
+    // pass 3 (s = 64): twiddles w_512^(j m); outputs at j + 64 m
+    {
+#pragma unroll
+        for (u32 m = 0; m < 8; ++m) u[m] = Lw[ntt8_pad(j) + 72 * m];
+        F tw[8];
+#pragma unroll
+        for (u32 m = 1; m < 8; ++m) { const u32 e = (j * m) & 511; tw[m] = a.RTn[INV ? ((512 - e) & 511) : e]; }
+#pragma unroll
+        for (u32 m = 1; m < 8; ++m) u[m] = lz_mul(tw[m], u[m]);
+        lz_dft8<INV>(u);
+        __syncthreads();
+#pragma unroll
+        for (u32 m = 0; m < 8; ++m) Lw[ntt8_pad(j) + 72 * m] = a.do_scale ? lz_mul(a.scale, u[m]) : u[m];
+        __syncthreads();
+    }
+    // natural order: element k2 of row k1 goes to k1 + N1 k2 — the tile's eight k1 are consecutive: 128 contiguous bytes per k2
+    F *dst = a.out + ((size_t) rt << a.ln) + k1_0;
+#pragma unroll
+    for (u32 it = 0; it < 8; ++it) {
+        const u32 e = it * NTT8_THREADS + tid, cc = e & 7, k2 = e >> 3;
+        dst[(size_t) k2 * N1 + cc] = lz_canon(L[cc * NTT8_PITCH + ntt8_pad(k2)]);
+    }
+}
+
+// out[k] = w^k for k < n = 2^lo, w of order n, from the half table of order M (full circle: the inverse transforms index it with n - e)
+__global__ void __launch_bounds__(VP_BLOCK) k_root_circle(const F *__restrict__ RT, u32 half_m, u32 stride, u32 n, F *__restrict__ out) {
+    const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) out[k] = root_pow(RT, half_m, (u32) (((unsigned long long) k * stride) & (2ull * half_m - 1)));
+}
+
+}  // namespace vp

@@ -480,6 +480,36 @@ k_fri_fold(const F *__restrict__ in, F *__restrict__ out, u32 Nk, int k, const F
     else { p = f_zero(); q = f_zero(); }
     out[t] = f_mul(inv2, f_add(f_add(p, q), f_mul(f_mul(inv_mu, r), f_sub(p, q))));
 }
+// Round 4: the FIRST fold straight from the three committed codewords — the virtual oracle (k_pc_virtual_oracle) is never written.  With
+// G(a) = l q - (x^N - 1) h - S0 at position (b, a) and X = N x^-1, the oracle is G X; its partner at a + N/2 sits at -x (w_M^(16 N) = -1), so
+//   p = G(a) X,  q' = -G(a') X   and   1/2 ((p + q') + mu^-1 r (p - q')) = (X / 2) ((G(a) - G(a')) + x^-1 r (G(a) + G(a'))),  mu = x at level 0
+// — the same field element as k_fri_fold(k = 0) on the materialised oracle (every operation is exact), ten multiplications per output instead
+// of thirteen, and 64 M x 16 B less written and read back (x1024: 8.6 GB).  Openings never read the oracle itself (fri.cpp:148-287 open l, h
+// and the folded levels), so nothing else needs it.  Unsharded commitment only (lw = 0).
+__global__ void __launch_bounds__(VP_BLOCK)
+k_fri_fold0_vo(const F *__restrict__ lcw, const F *__restrict__ qcw, const F *__restrict__ hcw, const F *__restrict__ S0, F *__restrict__ out, u32 N,
+               const F *__restrict__ RT, u32 half_m, F r, F half_n /* N / 2 */, const F *__restrict__ q0, const F *__restrict__ qscal) {
+    const size_t t = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 No = N >> 1;
+    if (t >= (size_t) 64 * 32 * No) return;
+    const u32 al = (u32) (t % No), sb = (u32) (t / No), b = sb & 31, i = sb >> 5;
+    const u32 M = 2 * half_m;
+    const size_t p0 = (size_t) sb * N + al, p1 = p0 + No;
+    const u32 e = 32 * al + b;                                               // x = w_M^e
+    const u32 ex = e ? M - e : 0, exn = (u32) (((size_t) b * N) & (M - 1));
+    const F wx = root_raw(RT, half_m, ex), wn = root_raw(RT, half_m, exn);
+    F qa, qb;
+    if (q0) { const F sc = qscal[i]; const size_t o = (size_t) b * N + al; qa = f_mul(sc, q0[o]); qb = f_mul(sc, q0[o + No]); }
+    else { qa = qcw[p0]; qb = qcw[p1]; }
+    const F la = lcw[p0], lb = lcw[p1], ha = hcw[p0], hb = hcw[p1];
+    loads_first();
+    const F inv_x = root_fin(wx, half_m, ex);
+    const F xn_m1 = f_sub(root_fin(wn, half_m, exn), f_one());              // x^N - 1 = w_M^(N b) - 1: the same for both positions
+    const F s0 = S0[i];
+    const F Ga = f_sub(f_sub(f_mul(la, qa), f_mul(xn_m1, ha)), s0), Gb = f_sub(f_sub(f_mul(lb, qb), f_mul(xn_m1, hb)), s0);
+    const F D = f_sub(Ga, Gb), S = f_add(Ga, Gb);
+    out[t] = f_mul(f_mul(half_n, inv_x), f_add(D, f_mul(f_mul(inv_x, r), S)));
+}
 // The last fold leaves ONE value per coset (32 per slice); its 16 leaves pair coset b with coset b + 16.
 __global__ void k_leaf_hash_final(const F *__restrict__ cw, int n_slices, Dig *__restrict__ leaves) {
     const u32 j = threadIdx.x;
@@ -602,6 +632,8 @@ k_ntt_unsplit(const F *__restrict__ in, F *__restrict__ out, int ln, int l1, F s
 }
 
 }  // namespace vp
+
+#include "vp_kernels_ntt8.h"
 
 // ---- openings (fri::request_init_value_with_merkle, fri.cpp:148-205; fri::request_step_commit, :229-287) ----
 namespace vp {

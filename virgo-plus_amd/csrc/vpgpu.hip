@@ -494,8 +494,14 @@ int do_finalize(vp_ctx *ctx, const F *rp, const F &rv, F *claims_dev, F *claims_
 }
 
 int check_stream(vp_ctx *ctx) {
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    HIPCHK(hipGetLastError());
+    const hipError_t e1 = hipStreamSynchronize(ctx->stream), e2 = e1 == hipSuccess ? hipGetLastError() : e1;
+    if (e2 != hipSuccess) {
+        // a launch that did not finish may have left workgroups counted in k_round_main's arrival counter: a later round on this context must
+        // not close early or never (best effort — after a device fault the memset fails too and every later call reports the fault)
+        if (ctx->round_arrivals) (void) hipMemsetAsync(ctx->round_arrivals, 0, 64, ctx->stream);
+        ctx->err = std::string("stream: ") + hipGetErrorString(e2);
+        return VP_EHIP;
+    }
     return VP_OK;
 }
 
@@ -554,6 +560,18 @@ int tail_suspend(vp_ctx *ctx) {
 }
 // Relaunch the resident kernel on the phase it saved.  already_sent: the message the kernel is to answer next is already in the mailbox
 // (the host sent it while the kernel was timing out) and carries ctx->tail_seq; otherwise the next tail_send will carry tail_seq + 1.
+int tail_resume(vp_ctx *ctx, bool already_sent);
+// tail_wait for callers that collect a reply: a kernel that timed out with its phase saved (VP_TAIL_SAVED, internal) is relaunched on the saved
+// phase and waited for once more; the internal code never reaches the C ABI's caller.
+int tail_wait_resumed(vp_ctx *ctx, unsigned long long want) {
+    int rc = tail_wait(ctx, want);
+    if (rc == VP_TAIL_SAVED) {
+        rc = tail_resume(ctx, true);
+        if (rc == VP_OK) rc = tail_wait(ctx, want);
+        if (rc == VP_TAIL_SAVED) { ctx->err = "resident round kernel: timed out twice on one message"; rc = VP_EHIP; }
+    }
+    return rc;
+}
 int tail_resume(vp_ctx *ctx, bool already_sent) {
     PTailArgs a = ctx->tail_args;
     a.resume = 1; a.G = 1;
@@ -706,6 +724,8 @@ void vp_options_default(vp_options *o) {
     o->pc_tensor_pub = 1;
     o->persistent_timeout_ms = 10000;
     o->graph_explicit = 0;
+    o->ntt_r8 = 1;
+    o->fri_vo_fused = 1;
 }
 // defaults <- the caller's struct (as many bytes as its header knew) <- VP_* environment variables (test-only override, read here and nowhere else)
 static void resolve_options(vp_options *o, const vp_options *user, uint32_t *pinned) {
@@ -730,6 +750,8 @@ static void resolve_options(vp_options *o, const vp_options *user, uint32_t *pin
     flag("VP_KERNEL_COPIES", o->kernel_copies);
     flag("VP_FOLD_BRANCHES", o->fold_branches);
     flag("VP_NTT_SCATTER", o->ntt_scatter);
+    flag("VP_NTT_R8", o->ntt_r8);
+    flag("VP_FRI_VO_FUSED", o->fri_vo_fused);
     flag("VP_PC_TENSOR", o->pc_tensor_pub);
     num("VP_PERSIST_TIMEOUT_MS", o->persistent_timeout_ms);
     num("VP_GRAPH_EXPLICIT", o->graph_explicit);
@@ -797,6 +819,10 @@ int vp_create_with_options(int device, const vp_options *user, vp_ctx **out) {
     (void) hipFuncSetAttribute(reinterpret_cast<const void *>(k_emit_multi), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
     (void) hipFuncSetAttribute(reinterpret_cast<const void *>(k_emit), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
     (void) hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt8_cols<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt8_cols<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt8_rows<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt8_rows<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     { std::lock_guard<std::mutex> lk(g_ctx_mu); g_ctxs.push_back(ctx); }
     *out = ctx;
     return VP_OK;
@@ -1308,7 +1334,7 @@ static int vp_round_impl(vp_ctx *ctx, const vp_F *previous_random, vp_F out_poly
         *how = 2;                                             // round 1 was computed behind the init call
         if (how1 == 3) { memcpy(out_poly, ctx->r1_stash, 3 * sizeof(F)); return VP_OK; }      // collected when the kernel was suspended
         if (how1 == 1) {
-            VPCHK(tail_wait(ctx, ctx->tail_seq));
+            VPCHK(tail_wait_resumed(ctx, ctx->tail_seq));
             tail_poly(ctx, out_poly);
             ++ctx->sc.round; ++ctx->st.rounds;
         } else {
@@ -1327,6 +1353,7 @@ static int vp_round_impl(vp_ctx *ctx, const vp_F *previous_random, vp_F out_poly
             VPCHK(tail_resume(ctx, true));
             rc = tail_wait(ctx, ctx->tail_seq);
         }
+        if (rc == VP_TAIL_SAVED) { ctx->err = "resident round kernel: timed out twice on one message"; rc = VP_EHIP; }
         VPCHK(rc);
         if (tail_status(ctx) != 0) { ctx->tail_active = false; ctx->err = "persistent round kernel: protocol error"; return VP_EHIP; }
         tail_poly(ctx, out_poly);
@@ -1339,7 +1366,7 @@ static int vp_round_impl(vp_ctx *ctx, const vp_F *previous_random, vp_F out_poly
     }
     if (tail_try_launch(ctx, rv)) {
         *how = 1;
-        VPCHK(tail_wait(ctx, ctx->tail_seq));
+        VPCHK(tail_wait_resumed(ctx, ctx->tail_seq));
         tail_poly(ctx, out_poly);
         ++ctx->sc.round; ++ctx->st.rounds;
         return VP_OK;
@@ -1357,6 +1384,8 @@ int vp_finalize(vp_ctx *ctx, const vp_F *previous_random, vp_F *claims, int n_cl
     HIPCHK(hipSetDevice(ctx->device));
     F rv; memcpy(&rv, previous_random, sizeof(F));
     if (rv.re >= P61 || rv.im >= P61) { ctx->err = "vp_finalize: previous_random is not canonical (limb >= 2^61 - 1)"; return VP_EINVAL; }
+    // the live level of a lost phase was in LDS only: the tables in HBM are stale, claims from them would be wrong (vp_round refuses the same way)
+    if (ctx->tail_lost) { ctx->err = "the resident round kernel was told to leave by another context before it could save its phase"; return VP_EHIP; }
     if (ctx->tail_suspended) VPCHK(tail_resume(ctx, false));
     if (ctx->tail_active) {                                   // the resident kernel holds the tables: it computes the claims and leaves
         int rc = tail_send(ctx, 2, rv);
@@ -1365,6 +1394,7 @@ int vp_finalize(vp_ctx *ctx, const vp_F *previous_random, vp_F *claims, int n_cl
             if (rc == VP_OK) rc = tail_wait(ctx, ctx->tail_seq);
         }
         ctx->tail_active = false;
+        if (rc == VP_TAIL_SAVED) { ctx->err = "resident round kernel: timed out twice on one message"; rc = VP_EHIP; }
         VPCHK(rc);
         if (tail_status(ctx) != 0) { ctx->err = "persistent round kernel: protocol error at finalize"; return VP_EHIP; }
         memcpy(claims, ctx->h_pin + 4, (size_t) n_claims * sizeof(F));
@@ -1507,16 +1537,20 @@ int vp_prove_gkr(vp_ctx *ctx, const vp_F *tape, uint64_t n_tape, uint8_t *transc
 
 int vp_get_stats(vp_ctx *ctx, vp_stats *out) {
     if (!ctx || !out) return VP_EINVAL;
+    VP_LOCK(ctx);
     *out = ctx->st;
     return VP_OK;
 }
-int vp_get_resident_resumes(const vp_ctx *ctx, uint64_t *n) {
-    if (!ctx || !n) return VP_EINVAL;
+int vp_get_resident_resumes(const vp_ctx *cctx, uint64_t *n) {
+    if (!cctx || !n) return VP_EINVAL;
+    vp_ctx *ctx = const_cast<vp_ctx *>(cctx);
+    VP_LOCK(ctx);
     *n = ctx->tail_resumes;
     return VP_OK;
 }
 int vp_get_round_stats(vp_ctx *ctx, vp_round_stat *out, int capacity, int *n) {
     if (!ctx || !n || (capacity > 0 && !out)) return VP_EINVAL;
+    VP_LOCK(ctx);                                             // a concurrent vp_round on this context appends to (and may reallocate) rlog
     *n = (int) ctx->rlog.size();
     for (int i = 0; i < *n && i < capacity; ++i) out[i] = ctx->rlog[i];
     return VP_OK;
@@ -1528,6 +1562,7 @@ int vp_set_profiling(vp_ctx *ctx, int level) {
 }
 int vp_get_launch_stats(vp_ctx *ctx, vp_launch_stat *out, int capacity, int *n) {
     if (!ctx || !n || (capacity > 0 && !out)) return VP_EINVAL;
+    VP_LOCK(ctx);
     *n = (int) ctx->lstats.size();
     for (int i = 0; i < *n && i < capacity; ++i) out[i] = ctx->lstats[i];
     return VP_OK;
@@ -1535,7 +1570,7 @@ int vp_get_launch_stats(vp_ctx *ctx, vp_launch_stat *out, int capacity, int *n) 
 const char *vp_kernel_name(int kind) {
     static const char *names[VP_K_COUNT] = {"k_beta_half_direct", "k_light_multi", "k_chunks_multi", "k_combine_multi", "k_dot_multi", "k_dotfin_multi",
         "k_sumfold3b_gen_multi", "k_sumfold3b_multi", "k_seg_multi", "k_emit_multi", "k_fixup", "k_ntt_split", "k_ntt_lds", "k_ntt_unsplit",
-        "k_leaf_hash", "k_merkle", "k_pc_pointwise", "k_fri_fold", "k_round", "k_init3_multi"};
+        "k_leaf_hash", "k_merkle", "k_pc_pointwise", "k_fri_fold", "k_round", "k_init3_multi", "k_ntt8_cols", "k_ntt8_rows"};
     return (kind >= 0 && kind < VP_K_COUNT) ? names[kind] : "?";
 }
 

@@ -316,6 +316,18 @@ std::vector<F> prover::fftGkr(int lg, const std::vector<F> &tape) {
     msgs.resize(written);
     return msgs;
 }
+void prover::fftGkrBegin(int lg, const std::vector<F> &tape) {
+    check(vp_fft_gkr_begin(ctx, lg, cF(tape.data()), tape.size()), "vp_fft_gkr_begin");
+}
+std::vector<F> prover::fftGkrEnd(int lg) {
+    uint64_t nt = 0, nm = 0;
+    check(vp_fft_gkr_sizes(lg, &nt, &nm), "vp_fft_gkr_sizes");
+    std::vector<F> msgs(nm);
+    uint64_t written = 0;
+    check(vp_fft_gkr_end(ctx, mF(msgs.data()), nm, &written), "vp_fft_gkr_end");
+    msgs.resize(written);
+    return msgs;
+}
 double prover::commitDeviceMs() { double ms = 0; check(vp_commit_stats(ctx, &ms), "vp_commit_stats"); return ms; }
 
 void prover::gkrSizes(u64 &n_tape, u64 &n_bytes) {

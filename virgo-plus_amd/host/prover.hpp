@@ -71,6 +71,9 @@ public:
     // fft_circuit_gkr::fft_gkr (lib/virgo/src/fft_circuit_GKR.cpp:833-849), prover side on the device (vp_fft_gkr): tape = the verifier's
     // draws in the reference's order; returns every prover message (layouts: include/vpgpu.h)
     std::vector<F> fftGkr(int lg, const std::vector<F> &tape);
+    // the same in two halves (vp_fft_gkr_begin / _end): queued on a stream of its own, collected later; other prover calls may run in between
+    void fftGkrBegin(int lg, const std::vector<F> &tape);
+    std::vector<F> fftGkrEnd(int lg);
     double commitDeviceMs();
 
     double proveTime() const { return prove_timer.elapse_sec(); }

@@ -1,6 +1,7 @@
 #include "vphost.h"
 
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -401,6 +402,12 @@ int vph_prove_protocol(vph_session *s, uint8_t *transcript, uint64_t capacity, u
         std::vector<uint8_t> out;
         out.reserve(capacity);
         auto t = clk::now();
+        // fft_gkr (vpd_verifier.cpp:92) depends on the verifier's draws only: queued first on its own stream, collected last — its small
+        // launches run in the gaps of everything below (VPH_FFT_GKR_SYNC=1: in the reference's place, between commit_public and the FRI folds)
+        static const bool fft_sync = getenv("VPH_FFT_GKR_SYNC") != nullptr;
+        if (!fft_sync) s->p->fftGkrBegin(ln, s->ptape_fft);
+        double s_fft = since(t);
+        t = clk::now();
         const prover::hhash_digest rl = s->p->commit_private();                       // src/verifier.cpp:137
         out.insert(out.end(), rl.b, rl.b + 32);
         const double s_priv = since(t);
@@ -418,13 +425,12 @@ int vph_prove_protocol(vph_session *s, uint8_t *transcript, uint64_t capacity, u
         out.insert(out.end(), ib, ib + 16);
         const uint8_t *ab = reinterpret_cast<const uint8_t *>(all_sum.data());
         out.insert(out.end(), ab, ab + 65 * 16);
-        t = clk::now();
-        s->fft_gkr_msgs = s->p->fftGkr(ln, s->ptape_fft);                             // vpd_verifier.cpp:92
-        const double s_fft = since(t);
+        if (fft_sync) { t = clk::now(); s->fft_gkr_msgs = s->p->fftGkr(ln, s->ptape_fft); s_fft = since(t); }
         t = clk::now();
         const std::vector<prover::hhash_digest> ds = s->p->friCommit(s->ptape_fri);   // vpd_verifier.cpp:44-74
         s->fri_final = s->p->friFinal();
         const double s_fri = since(t);
+        if (!fft_sync) { t = clk::now(); s->fft_gkr_msgs = s->p->fftGkrEnd(ln); s_fft += since(t); }
         s->fri_roots.clear();
         for (auto &d : ds) s->fri_roots.insert(s->fri_roots.end(), d.b, d.b + 32);
         s->fri_r = s->ptape_fri;
