@@ -75,7 +75,8 @@ __device__ __forceinline__ void lz_dft2(F (&u)[2]) {
 
 struct Ntt8Args {
     const F *in; F *out;            // cols: source rows -> scratch [row x coset][k1][j2];   rows: scratch -> destination (natural order)
-    const F *RT; u32 half_m;        // w_M^e, e < M/2 (pc_root_table): the coset twist and the w_N^(j2 k1) twiddles between the passes
+    const F *RT; u32 half_m;        // FULL circle of order M: w_M^e, e < M = 2 half_m (no sign logic at the gathers): the coset twist and the w_N^(j2 k1)
+                                    // twiddles between the passes.  Exponents are formed in 32-bit arithmetic: M divides 2^32, so wrapping is harmless
     const F *RTn;                   // FULL circle of the pass's own order (N1 entries for cols, 512 for rows): w^k, k < order
     int ln, l1;                     // N = 2^ln, N1 = 2^l1 (4 <= l1 <= 8), N2 = 2^(ln - l1) = 512
     u32 in_stride;                  // cols: elements between input rows
@@ -108,17 +109,16 @@ __global__ void __launch_bounds__(NTT8_THREADS) __attribute__((amdgpu_waves_per_
 #pragma unroll
         for (u32 m = 0; m < 8; ++m) u[m] = src[(size_t) (q + m * (N1 >> 3)) * N2];
         if (a.twist && coset) {
+            // the j1 share of w_M^(j coset), j1 = q + m N1 / 8 (j2's share joins the output twiddle): exponents e0 + m step (mod M)
+            const u32 e0 = q * N2 * coset, step = (N1 >> 3) * N2 * coset;
 #pragma unroll
             for (u32 g = 0; g < 8; g += 4) {                    // four root gathers in flight at a time (register budget: 128 VGPRs, 4 waves per SIMD)
-                F w[4]; u32 e[4];
+                F w[4];
 #pragma unroll
-                for (u32 m = 0; m < 4; ++m) {
-                    e[m] = (u32) (((unsigned long long) (q + (g + m) * (N1 >> 3)) * N2 * coset) & (M - 1));      // the j1 share of w_M^(j coset); j2's joins the output twiddle
-                    w[m] = root_raw(a.RT, a.half_m, e[m]);
-                }
+                for (u32 m = 0; m < 4; ++m) w[m] = a.RT[(e0 + (g + m) * step) & (M - 1)];
                 loads_first();
 #pragma unroll
-                for (u32 m = 0; m < 4; ++m) u[g + m] = lz_mul(root_fin(w[m], a.half_m, e[m]), u[g + m]);
+                for (u32 m = 0; m < 4; ++m) u[g + m] = lz_mul(w[m], u[g + m]);
             }
         }
         lz_dft8<INV>(u);
@@ -151,11 +151,9 @@ __global__ void __launch_bounds__(NTT8_THREADS) __attribute__((amdgpu_waves_per_
     }
     // ---- last pass: radix 8, 4 or 2; outputs multiplied by w_N^(j2 k1) (and the column's share of the twist) and stored [k1][j2]
     const u32 ec = (a.twist && coset) ? coset : 0u;
-    auto out_twiddle = [&](u32 k1) -> u32 {                     // exponent of w_M
-        unsigned long long e = (unsigned long long) j2 * ((unsigned long long) k1 * wN);
-        if (INV) e = (M - (e & (M - 1))) & (M - 1);
-        return (u32) ((e + (unsigned long long) j2 * ec) & (M - 1));
-    };
+    // output k1 takes w_M^(j2 (k1 wN' + coset)), wN' = wN (forward) or M - wN (inverse): exponent base + k1 stepk (mod M), 32-bit
+    const u32 wNs = INV ? (M - wN) & (M - 1) : wN;
+    const u32 ebase = j2 * ec, stepk = j2 * wNs;
     if (rem == 0) {
         const u32 q = tid >> lc, k = q & (s - 1);               // s = N1 / 8: k = q
         F u[8];
@@ -170,14 +168,15 @@ __global__ void __launch_bounds__(NTT8_THREADS) __attribute__((amdgpu_waves_per_
             for (u32 m = 1; m < 8; ++m) u[m] = lz_mul(w[m], u[m]);
         }
         lz_dft8<INV>(u);
+        const u32 k1_0 = (q - k) * 8 + k, eo = ebase + k1_0 * stepk, so = s * stepk;
 #pragma unroll
         for (u32 g = 0; g < 8; g += 4) {
-            F w[4]; u32 e[4];
+            F w[4];
 #pragma unroll
-            for (u32 m = 0; m < 4; ++m) { e[m] = out_twiddle((q - k) * 8 + k + (g + m) * s); w[m] = root_raw(a.RT, a.half_m, e[m]); }
+            for (u32 m = 0; m < 4; ++m) w[m] = a.RT[(eo + (g + m) * so) & (M - 1)];
             loads_first();
 #pragma unroll
-            for (u32 m = 0; m < 4; ++m) dst[(size_t) ((q - k) * 8 + k + (g + m) * s) * N2] = lz_mul(root_fin(w[m], a.half_m, e[m]), u[g + m]);     // weakly reduced: pass B folds
+            for (u32 m = 0; m < 4; ++m) dst[(size_t) (k1_0 + (g + m) * s) * N2] = lz_mul(w[m], u[g + m]);     // weakly reduced: pass B folds
         }
     } else if (rem == 2) {
         // radix 4 at s = N1 / 4: two butterflies per thread
@@ -194,12 +193,13 @@ __global__ void __launch_bounds__(NTT8_THREADS) __attribute__((amdgpu_waves_per_
 #pragma unroll
             for (u32 m = 1; m < 4; ++m) u[m] = lz_mul(w[m], u[m]);
             lz_dft4<INV>(u);
-            F ww[4]; u32 e[4];
+            const u32 k1_0 = (q - k) * 4 + k, eo = ebase + k1_0 * stepk, so = s * stepk;
+            F ww[4];
 #pragma unroll
-            for (u32 m = 0; m < 4; ++m) { e[m] = out_twiddle((q - k) * 4 + k + m * s); ww[m] = root_raw(a.RT, a.half_m, e[m]); }
+            for (u32 m = 0; m < 4; ++m) ww[m] = a.RT[(eo + m * so) & (M - 1)];
             loads_first();
 #pragma unroll
-            for (u32 m = 0; m < 4; ++m) dst[(size_t) ((q - k) * 4 + k + m * s) * N2] = lz_mul(root_fin(ww[m], a.half_m, e[m]), u[m]);
+            for (u32 m = 0; m < 4; ++m) dst[(size_t) (k1_0 + m * s) * N2] = lz_mul(ww[m], u[m]);
         }
     } else {
         // radix 2 at s = N1 / 2: four butterflies per thread
@@ -210,12 +210,13 @@ __global__ void __launch_bounds__(NTT8_THREADS) __attribute__((amdgpu_waves_per_
             u[0] = L[(q << lc) + c]; u[1] = L[((q + (N1 >> 1)) << lc) + c];
             { const u32 e = k & (N1 - 1); u[1] = lz_mul(a.RTn[INV ? ((N1 - e) & (N1 - 1)) : e], u[1]); }      // w_(2 s)^k = w_N1^k
             lz_dft2(u);
-            F ww[2]; u32 e[2];
+            const u32 k1_0 = (q - k) * 2 + k, eo = ebase + k1_0 * stepk, so = s * stepk;
+            F ww[2];
 #pragma unroll
-            for (u32 m = 0; m < 2; ++m) { e[m] = out_twiddle((q - k) * 2 + k + m * s); ww[m] = root_raw(a.RT, a.half_m, e[m]); }
+            for (u32 m = 0; m < 2; ++m) ww[m] = a.RT[(eo + m * so) & (M - 1)];
             loads_first();
 #pragma unroll
-            for (u32 m = 0; m < 2; ++m) dst[(size_t) ((q - k) * 2 + k + m * s) * N2] = lz_mul(root_fin(ww[m], a.half_m, e[m]), u[m]);
+            for (u32 m = 0; m < 2; ++m) dst[(size_t) (k1_0 + m * s) * N2] = lz_mul(ww[m], u[m]);
         }
     }
 }
