@@ -1656,3 +1656,30 @@ def test_cli_fiat_shamir_mode(vp, pws_path, tmp_path):
     c = vp.Circuit.from_pws(pws_path, 1, seed=1)  # the same witness as the CLI drew
     assert c.verify_fs(dump.read_bytes())
     c.close()
+
+
+def test_plan_tuner_choice_is_shared_between_sessions_of_a_circuit(vp, pws_path):
+    """The plan tuner runs once per plan shape and process: a second session of the same circuit takes the first one's choice (same options in
+    effect, a much cheaper first proof) and proves the same transcript; a session with a field pinned by the caller tunes for itself.  (x5: a
+    block count no other test of this process proves — the table is process-wide.)"""
+    import time
+    c = vp.Circuit.from_pws(pws_path, 5, seed=1)
+    first, opts, trs = [], [], []
+    for k in range(2):
+        s = vp.Session(c)
+        s.draw_tape()
+        t0 = time.perf_counter()
+        tr, _ = s.prove_gkr()
+        first.append(time.perf_counter() - t0)
+        assert s.check(tr, device_predicates=True)[0]
+        trs.append(tr)
+        o = s.options_in_effect()
+        opts.append(tuple(getattr(o, f) for f in ("fuse_combine", "fold_branches", "plan_align", "fuse_min_log", "sf3b_grid", "graph_explicit")))
+        s.close()
+    assert trs[0] == trs[1] and opts[0] == opts[1]
+    assert first[1] < 0.6 * first[0], first
+    s = vp.Session(c, options=vp.Options(sf3b_grid=448))          # another plan shape as far as the tuner is concerned
+    s.draw_tape()
+    tr, _ = s.prove_gkr()
+    assert tr == trs[0] and s.options_in_effect().sf3b_grid == 448
+    s.close(); c.close()

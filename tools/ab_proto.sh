@@ -12,6 +12,9 @@ d = json.load(open("gpurun_out/ab_proto_%s.json" % sys.argv[1]))
 ps = d["prover_sec"]
 print("[%s] %-40s step %.2f ms | priv %.2f gkr %.2f pub %.2f fft %.2f fri %.2f | exact %s" % (sys.argv[1], sys.argv[2] or "defaults", 1e3 * ps["step_wall"], 1e3 * ps["commit_private"],
       1e3 * ps["gkr"], 1e3 * ps["commit_public"], 1e3 * ps["fft_gkr"], 1e3 * ps["fri_commit"], all(v is not False for v in d["bit_exact"].values())))
+ip = d["interactive_path"]
+print("     interactive %.2f ms (init %.2f, rounds %.2f) equal %s | " % (1e3 * ip["prover_sec"], 1e3 * ip["init_calls_sec"], 1e3 * ip["round_calls_sec"], ip["transcript_equals_batched"])
+      + "  ".join("%s: %d x %.1f us" % (c["served_by"][:22], c["rounds"], c["avg_us"]) for c in ip["per_round"]["by_path"]))
 print("     " + "  ".join("%s %.2f" % (k["kernel"], k["total_us"] / 1e3) for k in d["kernels"][:9]))
 PY
 done
