@@ -141,8 +141,7 @@ def per_round_summary(stats, full=False):
     bytes of the round / wall time of vp_round as the verifier sees it (vp_get_round_stats)."""
     if not stats:
         return None
-    names = {0: "one launch per round", 1: "resident kernel (pinned mailbox)", 2: "round 1, computed behind the init call",
-             3: "answered on the host from the previous pass's sums (no launch)", 4: "one table pass for this round and the next (k_round2)"}
+    names = {0: "one launch per round", 1: "resident kernel (pinned mailbox)", 2: "round 1, computed behind the init call"}
     by = {}
     for e in stats:
         k = by.setdefault(e["how"], {"rounds": 0, "us": 0.0, "bytes": 0})
@@ -154,7 +153,7 @@ def per_round_summary(stats, full=False):
         g = e["bytes"] / (e["us"] * 1e-6) / 1e9 if e["us"] > 0 else 0.0
         return {"layer": e["layer"], "phase": e["phase"], "round": e["round"], "tables": e["tables"], "served_by": e["how"], "MB": round(e["bytes"] / 1e6, 3),
                 "us": round(e["us"], 2), "GBps": round(g, 1), "hbm_frac": round(g / HBM_PEAK_GBPS, 4)}
-    big = sorted((e for e in stats if e["how"] in (0, 4)), key=lambda e: -e["bytes"])[:12]
+    big = sorted((e for e in stats if e["how"] == 0), key=lambda e: -e["bytes"])[:12]
     tot_b, tot_us = sum(e["bytes"] for e in stats), sum(e["us"] for e in stats)
     out = {"rounds": len(stats), "algorithmic_MB": round(tot_b / 1e6, 2), "total_us": round(tot_us, 1), "GBps_overall": round(tot_b / (tot_us * 1e-6) / 1e9, 1),
            "hbm_frac_overall": round(tot_b / (tot_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4), "by_path": classes, "largest_rounds": [row(e) for e in big],

@@ -140,10 +140,6 @@ typedef struct {
                                        k_ntt_lds of rounds 2-3 (kept as the cross-check)                                             [1] */
     int32_t fri_vo_fused;           /* VP_FRI_VO_FUSED: vp_fri_commit folds the first FRI level straight from the committed codewords l, q, h (k_fri_fold0_vo); the
                                        virtual oracle of poly_commit.h:294-318 is never written to HBM and read back.  0: separate k_pc_virtual_oracle pass [1] */
-    int32_t double_rounds;          /* VP_DOUBLE_ROUNDS: interactive path, large rounds — a table pass answers its round AND leaves the next round's sums as
-                                       quadratics in the coming challenge (answered on the host, no launch); the following pass folds by both
-                                       challenges on its way in (k_round2): one launch and 1.25 table reads+writes per TWO rounds instead of 2.25.
-                                       0: one launch per round                                                                     [1] */
 } vp_options;
 void vp_options_default(vp_options *opt);
 

@@ -543,123 +543,6 @@ __global__ void __launch_bounds__(VP_BLOCK) k_round_main(RoundArgs a, F *__restr
     round_final_tail(a, t, o.add_term, o.scalarV, o.poly_dev, o.poly_host, o.seq_host, o.seq);
 }
 
-// ---- Round 4: two rounds per table pass on the interactive path ---------------------------------------------------------------------------
-// A round's polynomial depends on the previous challenge only through the fold, and quadratically: with (e0, e1, e2, e3) a quad of the table at
-// level j, the pair of level j + 1 it folds to is x0(r) = e0 + r (e1 - e0), x1(r) = e2 + r (e3 - e2), so the sums of round j + 2
-//     X(r) = sum (m1(r) - m0(r)) (v1(r) - v0(r)) = P0 + P1 r + P2 r^2,      Z(r) = sum m0(r) v0(r) + a0(r) = C0 + C1 r + C2 r^2
-// are known as soon as level j is: the pass that answers round j + 1 leaves the nine sums, the host answers round j + 2 from them at once
-// (b from S(0) + S(1) = the previous polynomial at its challenge, src/verifier.cpp:208,249,295), and the NEXT pass folds level j by BOTH
-// challenges on its way in (16 entries -> 4): rounds 1, 3, 5, ... launch, rounds 2, 4, 6, ... cost no device work at all; a table is read once
-// and written at a quarter of its length per TWO rounds (one launch per round: read once, written at half its length per round).
-//   sums left by a pass over quads (e0..e3) of its OUTPUT level (first pairs (e0, e1) = "a", second pairs (e2, e3) = "b"):
-//     [0] Xa = sum (m1 - m0)(v1 - v0)   [1] Ya = sum m1 v1 + a1   [2] Za = sum m0 v0 + a0   [3] Xb = sum (m3 - m2)(v3 - v2)   [4] Zb = sum m2 v2 + a2
-//     [5] Yb = sum m3 v3 + a3 (LEVELS = 0 only: round 1 has no previous claim to take b from)
-//     [6] P0 = sum (m2 - m0)(v2 - v0)   [7] P2 = sum ((m3 - m2) - (m1 - m0)) ((v3 - v2) - (v1 - v0))   [8] B = sum (m3 - m1)(v3 - v1) = P0 + P1 + P2
-//   this round:  a = Xa + Xb,  c = Za + Zb + add_term;   next round:  C0 = Za, C2 = Xa, C1 = Ya - Za - Xa  (the first pairs ARE the next round's x0).
-// No table may retire inside such a pass or the round it answers ahead (the host checks: every live table keeps >= 4 entries at the output level).
-struct Round2Args {
-    const F *inV, *inM, *inA;
-    F *outV, *outM, *outA;
-    F r1, r2;         // LEVELS = 2: fold by r1, then by r2.  LEVELS = 0: the tables are read as they are (round 1)
-    int n_tab, has_a;
-    u32 total_quads;
-    TabDesc t[VP_MAX_TAB];      // len_in / valid_in at the INPUT level; pair_start = first global QUAD index of the table
-};
-struct Round2Out { F *add_term; F *res_host; unsigned long long *seq_host; unsigned long long seq; };
-constexpr int VP_R2_SUMS = 9;
-template <int LEVELS>
-__device__ __forceinline__ void r2_quad(const F *__restrict__ in, F *__restrict__ out, const TabDesc &td, u32 p, const F &r1, const F &r2, F (&e)[4]) {
-    if (LEVELS == 0) {
-        const u32 i0 = td.off + 4 * p, vi = td.off + td.valid_in;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) e[q] = ld_or_zero(in, i0 + q, vi);
-    } else {
-        const u32 i0 = td.off + 16 * p, vi = td.off + td.valid_in;
-        const u32 vo = (td.valid_in + 3) >> 2;                // valid length two levels down
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const F f0 = fold_entry(ld_or_zero(in, i0 + 4 * q, vi), ld_or_zero(in, i0 + 4 * q + 1, vi), r1);
-            const F f1 = fold_entry(ld_or_zero(in, i0 + 4 * q + 2, vi), ld_or_zero(in, i0 + 4 * q + 3, vi), r1);
-            e[q] = fold_entry(f0, f1, r2);
-            if (4 * p + q < vo) out[td.off + 4 * p + q] = e[q];
-        }
-    }
-}
-// LOOK = false: the pass that ENDS a chain — two-level fold, this round's sums only (Xa + Xb in [0], Za + Zb in [2]); the next round is an
-// ordinary one on the tables this pass leaves.
-template <int LEVELS, bool LOOK>
-__global__ void __launch_bounds__(VP_BLOCK) k_round2(Round2Args a, F *__restrict__ part, unsigned int *__restrict__ arrivals, Round2Out o) {
-    __shared__ F lds[4 * VP_R2_SUMS];
-    __shared__ int s_last;
-    Lz S[VP_R2_SUMS];
-#pragma unroll
-    for (int i = 0; i < VP_R2_SUMS; ++i) S[i] = Lz{0, 0};
-    for (u32 q = blockIdx.x * blockDim.x + threadIdx.x; q < a.total_quads; q += gridDim.x * blockDim.x) {
-        int j = 0;
-        while (j + 1 < a.n_tab && q >= a.t[j + 1].pair_start) ++j;
-        const TabDesc td = a.t[j];
-        const u32 p = q - td.pair_start;
-        F v[4], m[4], ad[4];
-        r2_quad<LEVELS>(a.inV, a.outV, td, p, a.r1, a.r2, v);
-        r2_quad<LEVELS>(a.inM, a.outM, td, p, a.r1, a.r2, m);
-        if (a.has_a) r2_quad<LEVELS>(a.inA, a.outA, td, p, a.r1, a.r2, ad);
-        else { ad[0] = ad[1] = ad[2] = ad[3] = f_zero(); }
-        if (LOOK) {
-            const F dam = f_sub(m[1], m[0]), dbm = f_sub(m[3], m[2]), dav = f_sub(v[1], v[0]), dbv = f_sub(v[3], v[2]);     // canonical: they are subtracted again
-            lz_add(S[0], f_mad_c<true>(dam, dav, f_zero()));
-            lz_add(S[1], f_mad_c<true>(m[1], v[1], ad[1]));
-            lz_add(S[2], f_mad_c<true>(m[0], v[0], ad[0]));
-            lz_add(S[3], f_mad_c<true>(dbm, dbv, f_zero()));
-            lz_add(S[4], f_mad_c<true>(m[2], v[2], ad[2]));
-            if (LEVELS == 0) lz_add(S[5], f_mad_c<true>(m[3], v[3], ad[3]));
-            lz_add(S[6], f_mad_lazy<true>(f_sub_lazy(m[2], m[0]), f_sub_lazy(v[2], v[0]), f_zero()));
-            lz_add(S[7], f_mad_lazy<true>(f_sub_lazy(dbm, dam), f_sub_lazy(dbv, dav), f_zero()));
-            lz_add(S[8], f_mad_lazy<true>(f_sub_lazy(m[3], m[1]), f_sub_lazy(v[3], v[1]), f_zero()));
-        } else {
-            lz_add(S[0], f_mad_lazy<true>(f_sub_lazy(m[1], m[0]), f_sub_lazy(v[1], v[0]), f_zero()));
-            lz_add(S[2], f_mad_c<true>(m[0], v[0], ad[0]));
-            lz_add(S[3], f_mad_lazy<true>(f_sub_lazy(m[3], m[2]), f_sub_lazy(v[3], v[2]), f_zero()));
-            lz_add(S[4], f_mad_c<true>(m[2], v[2], ad[2]));
-        }
-#pragma unroll
-        for (int i = 0; i < VP_R2_SUMS; ++i) lz_fold(S[i]);
-    }
-    F acc[VP_R2_SUMS];
-#pragma unroll
-    for (int i = 0; i < VP_R2_SUMS; ++i) acc[i] = lz_canon(S[i]);
-    block_sum<VP_R2_SUMS>(acc, lds);
-    // the workgroup that arrives last adds the partials up and closes the pass (same hand-off as k_round_main)
-    if (threadIdx.x == 0) {
-        unsigned long long *w = reinterpret_cast<unsigned long long *>(part + (size_t) blockIdx.x * VP_R2_SUMS);
-#pragma unroll
-        for (int i = 0; i < VP_R2_SUMS; ++i) { cf_st(w + 2 * i, acc[i].re); cf_st(w + 2 * i + 1, acc[i].im); }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        s_last = __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    F t[VP_R2_SUMS];
-#pragma unroll
-    for (int i = 0; i < VP_R2_SUMS; ++i) t[i] = f_zero();
-    for (u32 b = threadIdx.x; b < gridDim.x; b += blockDim.x) {
-        const unsigned long long *w = reinterpret_cast<const unsigned long long *>(part + (size_t) b * VP_R2_SUMS);
-#pragma unroll
-        for (int i = 0; i < VP_R2_SUMS; ++i) t[i] = f_add(t[i], f_make(cf_ld(w + 2 * i), cf_ld(w + 2 * i + 1)));
-    }
-    __syncthreads();
-    block_sum<VP_R2_SUMS>(t, lds);
-    if (threadIdx.x != 0) return;
-    __hip_atomic_store(arrivals, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // add_term * (1 - x) per round (src/prover.cpp:448): this pass stands for two rounds' folds
-    F at = *o.add_term;
-    if (LEVELS == 2 && !f_is_zero(at)) { at = f_mul(f_mul(at, f_sub(f_one(), a.r1)), f_sub(f_one(), a.r2)); *o.add_term = at; }
-#pragma unroll
-    for (int i = 0; i < VP_R2_SUMS; ++i) o.res_host[i] = t[i];
-    o.res_host[VP_R2_SUMS] = at;
-    __threadfence_system();
-    __hip_atomic_store(o.seq_host, o.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
 // Closing kernel of a round without pairs (every live table has a single entry left): one block, nothing to sum.
 __global__ void __launch_bounds__(VP_BLOCK) k_round_final(RoundArgs a, RoundOut o) {
     if (threadIdx.x != 0) return;

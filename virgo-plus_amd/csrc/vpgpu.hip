@@ -158,15 +158,6 @@ struct vp_ctx {
     std::vector<vp_launch_stat> lstats;   // per-launch table of the last profiled call (vp_get_launch_stats)
     std::vector<vp_round_stat> rlog;      // interactive path: one entry per vp_round since the last vp_vres (vp_get_round_stats)
     int rlog_round = 0;                   // vp_round calls since the last phase init
-    // interactive path, two rounds per table pass (vp_kernels_round.h, k_round2): which physical buffer pair the conventional index 0 names,
-    // and the chain's state between a pass and the round the host answers from its sums
-    int tab_flip = 0;
-    struct DblState {
-        bool have_q = false;              // the sums of the next round (quadratics in its challenge) are at hand: answer it on the host
-        bool need_fold = false;           // a challenge has been answered on the host but not folded into the tables yet (r_pend)
-        bool r1_l0 = false;               // round 1 was queued as a look-ahead pass
-        F C0, C1, C2, P0, P1, P2, at, r_pend, last[3];
-    } dbl;
     u64 rec_gen_bytes = 0, rec_gen_work = 0;      // record mode: algorithmic bytes / contributions of the init fused into the next fold launch
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<void *> allocs;
@@ -359,7 +350,6 @@ int do_phase1_init(vp_ctx *ctx, int i, const F *d_rliu, const F *d_assert) {
     a.M = ctx->tab[0][1]; a.A = ctx->tab[0][2];
     VPCHK(run_init_rows<1>(ctx, cur.c1, a));
     SumcheckState &s = ctx->sc;
-    ctx->tab_flip = 0; ctx->dbl = vp_ctx::DblState{};
     s.phase = 1; s.layer = i; s.n_tab = 1; s.round = 0; s.total_rounds = pre.bl; s.has_a = 1;
     s.off[0] = 0; s.len0[0] = 1u << pre.bl; s.valid0[0] = (u32) pre.size; s.bl[0] = pre.bl;
     s.V0 = pre.val; s.M0 = ctx->tab[0][1]; s.A0 = ctx->tab[0][2];
@@ -384,7 +374,6 @@ int do_phase2_init(vp_ctx *ctx, int i, const F *d_ru) {
     a.M = ctx->tab[0][1]; a.A = ctx->tab[0][2];
     VPCHK(run_init_rows<2>(ctx, cur.c2, a));
     SumcheckState &s = ctx->sc;
-    ctx->tab_flip = 0; ctx->dbl = vp_ctx::DblState{};
     s.phase = 2; s.layer = i; s.n_tab = i; s.round = 0; s.total_rounds = cur.max_dad_bl; s.has_a = 1;
     for (int j = 0; j < i; ++j) {
         s.off[j] = cur.t_off[j]; s.len0[j] = cur.t_len[j];
@@ -415,7 +404,6 @@ int do_liu_init(vp_ctx *ctx, int i) {
         count_launch(ctx);
     }
     SumcheckState &s = ctx->sc;
-    ctx->tab_flip = 0; ctx->dbl = vp_ctx::DblState{};
     s.phase = 3; s.layer = i; s.n_tab = 1; s.round = 0; s.total_rounds = pre.bl; s.has_a = 0;
     s.off[0] = 0; s.len0[0] = 1u << pre.bl; s.valid0[0] = (u32) pre.size; s.bl[0] = pre.bl;
     s.V0 = pre.val; s.M0 = M; s.A0 = ctx->tab[0][2];
@@ -436,91 +424,14 @@ int wait_ticket(vp_ctx *ctx) {
     }
 }
 
-// the ping-pong table set that the round arithmetic calls `idx` (ctx->tab[idx & 1] unless a two-level pass had to swap the roles)
-static inline F **vt(vp_ctx *ctx, int idx) { return ctx->tab[(idx ^ ctx->tab_flip) & 1]; }
-
-// ---- two rounds per table pass (k_round2) ----------------------------------------------------------------------------------------------------
-// May the launch that answers round k be a look-ahead pass?  levels 0: round 1, tables read as they are; levels 2: k >= 3, the tables at level
-// k - 3 are folded by the two challenges r_(k-2), r_(k-1).  Every live table must keep >= 4 entries at the output level (no table retires in the
-// pass or in the round answered ahead), and the pass must be large enough not to belong to the one-workgroup / resident regimes.
-static bool r2_eligible(const vp_ctx *ctx, int k, int levels) {
-    const SumcheckState &s = ctx->sc;
-    if (!ctx->opt.double_rounds || !ctx->poll || ctx->profiling || s.n_tab < 1) return false;
-    if (s.total_rounds < k + 1) return false;
-    const int lvl = levels == 0 ? 0 : k - 3;
-    if (lvl < 0 || lvl > 30) return false;
-    u64 out_entries = 0;
-    for (int j = 0; j < s.n_tab; ++j) {
-        const u32 len_in = s.len0[j] >> lvl;
-        if (len_in < 2) { if (lvl == 0 && s.len0[j] == 1) return false; continue; }      // retired earlier (a single-entry table retires in round 1: normal path)
-        if ((len_in >> levels) < 4) return false;
-        out_entries += (((u64) s.valid0[j] + (1ull << (lvl + levels)) - 1) >> (lvl + levels));
-    }
-    return out_entries > 2 * (u64) VP_PH_PMAX;               // otherwise round k belongs to the resident kernel
-}
-// queue the pass that answers round k = s.round + 1; results (VP_R2_SUMS sums, add_term) arrive in h_pin behind the ticket
-static int do_round2(vp_ctx *ctx, int levels, const F &r1, const F &r2, bool look) {
-    SumcheckState &s = ctx->sc;
-    const int k = s.round + 1;
-    Round2Args a{};
-    a.r1 = r1; a.r2 = r2; a.n_tab = s.n_tab; a.has_a = s.has_a;
-    const int lvl = levels == 0 ? 0 : k - 3;
-    if (lvl == 0) { a.inV = s.V0; a.inM = s.M0; a.inA = s.A0; }
-    else { F **t = vt(ctx, (k - 1) & 1); a.inV = t[0]; a.inM = t[1]; a.inA = t[2]; }      // written by the pass of round k - 2
-    if (levels) {
-        ctx->tab_flip ^= 1;                                   // the conventional slot of this round's output has the parity of its input: swap the roles
-        F **t = vt(ctx, (k + 1) & 1);
-        a.outV = t[0]; a.outM = t[1]; a.outA = t[2];
-    }
-    u32 quads = 0; u64 bytes = 0;
-    for (int j = 0; j < s.n_tab; ++j) {
-        TabDesc &t = a.t[j];
-        t.off = s.off[j]; t.pair_start = quads;
-        t.len_in = s.len0[j] >> lvl;
-        if (t.len_in < 2) { t.len_in = 0; t.valid_in = 0; continue; }
-        t.valid_in = (u32) (((u64) s.valid0[j] + (1ull << lvl) - 1) >> lvl);
-        const u32 vo = (u32) (((u64) t.valid_in + (1u << levels) - 1) >> levels);
-        quads += (vo + 3) >> 2;
-        bytes += (u64) (t.valid_in + (levels ? vo : 0)) * (s.has_a ? 48 : 32);
-    }
-    a.total_quads = quads;
-    const Round2Out ro{ctx->add_term(), ctx->h_pin, ctx->h_seq, ++ctx->seq};
-    const u32 grid = grid_for(quads);
-    const int sl = prof_begin(ctx, ctx->stream, VP_K_ROUND, grid, 1, bytes, quads, 2, (u32) k);
-    if (levels && look) hipLaunchKernelGGL((k_round2<2, true>), dim3(grid), dim3(VP_BLOCK), 0, ctx->stream, a, ctx->partials, ctx->round_arrivals, ro);
-    else if (levels) hipLaunchKernelGGL((k_round2<2, false>), dim3(grid), dim3(VP_BLOCK), 0, ctx->stream, a, ctx->partials, ctx->round_arrivals, ro);
-    else hipLaunchKernelGGL((k_round2<0, true>), dim3(grid), dim3(VP_BLOCK), 0, ctx->stream, a, ctx->partials, ctx->round_arrivals, ro);
-    prof_end(ctx, ctx->stream, sl);
-    count_launch(ctx);
-    s.round = k;
-    ++ctx->st.rounds;
-    return VP_OK;
-}
-static inline F poly_eval(const F (&p)[3], const F &x) { return f_add(f_mul(f_add(f_mul(p[0], x), p[1]), x), p[2]); }     // quadratic_poly::eval (src/polynomial.cpp)
-// the sums of a finished pass -> this round's polynomial and the next round's quadratics.  prev: the challenge the previous polynomial is
-// evaluated at (levels 2); round 1 (levels 0) takes b from its own Y sums.
-static void r2_collect(vp_ctx *ctx, int levels, const F &prev, F out_poly[3], bool look) {
-    const F *R = ctx->h_pin;
-    vp_ctx::DblState &d = ctx->dbl;
-    const F X = f_add(R[0], R[3]), Z = f_add(R[2], R[4]), at = R[VP_R2_SUMS];
-    F pa = X, pc = f_add(Z, at), pb;
-    if (levels == 0) pb = f_sub(f_sub(f_sub(f_add(R[1], R[5]), X), Z), at);
-    else pb = f_sub(f_sub(f_sub(poly_eval(d.last, prev), pa), pc), pc);
-    d.C0 = R[2]; d.C2 = R[0]; d.C1 = f_sub(f_sub(R[1], R[2]), R[0]);
-    d.P0 = R[6]; d.P2 = R[7]; d.P1 = f_sub(f_sub(R[8], R[6]), R[7]);
-    d.at = at; d.last[0] = pa; d.last[1] = pb; d.last[2] = pc;
-    d.have_q = look; d.need_fold = false;
-    out_poly[0] = pa; out_poly[1] = pb; out_poly[2] = pc;
-}
-
 int do_round(vp_ctx *ctx, const F *rp, const F &rv, F *poly_dev, F *poly_host) {
     SumcheckState &s = ctx->sc;
     const int k = s.round + 1;
     RoundArgs a{};
     a.rp = rp; a.rv = rv; a.n_tab = s.n_tab; a.fold = (k >= 2); a.has_a = s.has_a;
     if (k <= 2) { a.inV = s.V0; a.inM = s.M0; a.inA = s.A0; }
-    else { F **t = vt(ctx, k & 1); a.inV = t[0]; a.inM = t[1]; a.inA = t[2]; }       // out of round k-1
-    { F **t = vt(ctx, (k + 1) & 1); a.outV = t[0]; a.outM = t[1]; a.outA = t[2]; }
+    else { F **t = ctx->tab[k & 1]; a.inV = t[0]; a.inM = t[1]; a.inA = t[2]; }       // out of round k-1
+    { F **t = ctx->tab[(k + 1) & 1]; a.outV = t[0]; a.outM = t[1]; a.outA = t[2]; }
     u32 pairs = 0;
     u64 bytes = 0;
     for (int j = 0; j < s.n_tab; ++j) {
@@ -571,7 +482,7 @@ int do_finalize(vp_ctx *ctx, const F *rp, const F &rv, F *claims_dev, F *claims_
     FinArgs a{};
     a.rp = rp; a.rv = rv; a.n_tab = s.n_tab; a.rounds_done = s.round;
     const int R = s.round;
-    a.curV = (R <= 1) ? s.V0 : vt(ctx, (R + 1) & 1)[0];
+    a.curV = (R <= 1) ? s.V0 : ctx->tab[(R + 1) & 1][0];
     const int sh = R >= 1 ? R - 1 : 0;
     for (int j = 0; j < s.n_tab; ++j) {
         a.off[j] = s.off[j]; a.bl[j] = s.bl[j];
@@ -714,7 +625,7 @@ int tail_try_launch(vp_ctx *ctx, const F &rv) {
         if (hipMemsetAsync(ctx->d_msync, 0, sizeof(MultiSync), ctx->stream) != hipSuccess) return 0;
         a.G = G; a.kc = kc; a.off = s.off[0]; a.len0 = len0; a.valid0 = s.valid0[0]; a.B1 = B1;
         a.V0 = s.V0; a.M0 = s.M0; a.A0 = s.A0;
-        for (int b = 0; b < 2; ++b) for (int t = 0; t < 3; ++t) a.buf[b][t] = vt(ctx, b)[t];
+        for (int b = 0; b < 2; ++b) for (int t = 0; t < 3; ++t) a.buf[b][t] = ctx->tab[b][t];
         a.sync = ctx->d_msync; a.arrive0 = 0;
         a.k0 = 1; a.R = s.total_rounds; a.n_tab = 1; a.has_a = s.has_a; a.cap = 2 * VP_PH_PMAX;
         a.aux = ctx->h_aux;
@@ -736,7 +647,7 @@ int tail_try_launch(vp_ctx *ctx, const F &rv) {
     a.aux = ctx->h_aux;
     a.rv = rv; a.fold = (k >= 2) ? 1 : 0;
     if (k <= 2) { a.inV = s.V0; a.inM = s.M0; a.inA = s.A0; }
-    else { F **t = vt(ctx, k & 1); a.inV = t[0]; a.inM = t[1]; a.inA = t[2]; }
+    else { F **t = ctx->tab[k & 1]; a.inV = t[0]; a.inM = t[1]; a.inA = t[2]; }
     u32 pairs = 0, ents = 0;
     for (int j = 0; j < s.n_tab; ++j) {
         TabDesc &t = ax.t[j];
@@ -816,7 +727,6 @@ void vp_options_default(vp_options *o) {
     o->graph_explicit = 0;
     o->ntt_r8 = 1;
     o->fri_vo_fused = 1;
-    o->double_rounds = 1;
 }
 // defaults <- the caller's struct (as many bytes as its header knew) <- VP_* environment variables (test-only override, read here and nowhere else)
 static void resolve_options(vp_options *o, const vp_options *user, uint32_t *pinned) {
@@ -843,7 +753,6 @@ static void resolve_options(vp_options *o, const vp_options *user, uint32_t *pin
     flag("VP_NTT_SCATTER", o->ntt_scatter);
     flag("VP_NTT_R8", o->ntt_r8);
     flag("VP_FRI_VO_FUSED", o->fri_vo_fused);
-    flag("VP_DOUBLE_ROUNDS", o->double_rounds);
     flag("VP_PC_TENSOR", o->pc_tensor_pub);
     num("VP_PERSIST_TIMEOUT_MS", o->persistent_timeout_ms);
     num("VP_GRAPH_EXPLICIT", o->graph_explicit);
@@ -1020,7 +929,7 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
     VPCHK(dalloc(ctx, &ctx->bf, (size_t) ctx->half_cap));
     VPCHK(dalloc(ctx, &ctx->bs, (size_t) ctx->half_cap));
     VPCHK(dalloc(ctx, &ctx->liu_half, (size_t) 2 * (n_layers + 1) * ctx->half_cap));
-    VPCHK(dalloc(ctx, &ctx->partials, (size_t) (VP_R2_SUMS > 3 ? VP_R2_SUMS : 3) * MAX_BLOCKS));
+    VPCHK(dalloc(ctx, &ctx->partials, (size_t) 3 * MAX_BLOCKS));
     VPCHK(dalloc(ctx, &ctx->round_arrivals, (size_t) 16)); HIPCHK(hipMemsetAsync(ctx->round_arrivals, 0, 64, ctx->stream));
     VPCHK(dalloc(ctx, &ctx->chunk_part, (size_t) 2 * std::max<u32>(1, ctx->chunk_cap)));
     VPCHK(dalloc(ctx, &ctx->small, (size_t) 32 + VP_MAX_TAB));
@@ -1226,11 +1135,6 @@ static int round1_prefetch(vp_ctx *ctx) {
     if (!ctx->opt.prefetch_round1 || ctx->sc.total_rounds < 1 || ctx->profiling) return check_stream(ctx);
     const F zero = f_zero();
     if (tail_try_launch(ctx, zero)) { ctx->r1_pending = 1; return VP_OK; }
-    if (r2_eligible(ctx, 1, 0) && r2_eligible(ctx, 3, 2)) {   // round 1 also leaves round 2's sums: the chain of two-round passes starts here (round 3 can fold twice)
-        VPCHK(do_round2(ctx, 0, zero, zero, true));
-        ctx->r1_pending = 4;
-        return VP_OK;
-    }
     VPCHK(do_round(ctx, nullptr, zero, ctx->d_tr + ctx->n_tr, ctx->h_pin));
     ctx->r1_pending = 2;
     return VP_OK;
@@ -1434,52 +1338,11 @@ static int vp_round_impl(vp_ctx *ctx, const vp_F *previous_random, vp_F out_poly
             VPCHK(tail_wait_resumed(ctx, ctx->tail_seq));
             tail_poly(ctx, out_poly);
             ++ctx->sc.round; ++ctx->st.rounds;
-        } else if (how1 == 4) {                               // a look-ahead pass: round 1's polynomial from its sums, round 2's quadratics kept
-            VPCHK(wait_ticket(ctx));
-            F p[3];
-            r2_collect(ctx, 0, f_zero(), p, true);
-            memcpy(out_poly, p, sizeof p);
         } else {
             VPCHK(wait_ticket(ctx));
             memcpy(out_poly, ctx->h_pin, 3 * sizeof(F));
         }
         return VP_OK;
-    }
-    // ---- two rounds per table pass: answer from the previous pass's sums / fold by two challenges at once / hand back to the paths below
-    if (ctx->dbl.have_q) {
-        vp_ctx::DblState &d = ctx->dbl;
-        const F r = rv;
-        const F X = f_add(d.P0, f_mul(r, f_add(d.P1, f_mul(r, d.P2)))), Zq = f_add(d.C0, f_mul(r, f_add(d.C1, f_mul(r, d.C2))));
-        const F at = f_is_zero(d.at) ? d.at : f_mul(d.at, f_sub(f_one(), r));            // add_term * (1 - x), src/prover.cpp:448
-        const F pa = X, pc = f_add(Zq, at), pb = f_sub(f_sub(f_sub(poly_eval(d.last, r), pa), pc), pc);
-        d.at = at; d.last[0] = pa; d.last[1] = pb; d.last[2] = pc; d.r_pend = r;
-        d.have_q = false; d.need_fold = true;
-        F p[3] = {pa, pb, pc};
-        memcpy(out_poly, p, sizeof p);
-        ++ctx->sc.round; ++ctx->st.rounds;
-        *how = 3;                                             // no device work
-        return VP_OK;
-    }
-    if (ctx->dbl.need_fold) {
-        const int k = ctx->sc.round + 1;
-        if (r2_eligible(ctx, k, 2)) {
-            // look ahead again only if the pass after the next round can fold twice as well; otherwise this pass ends the chain: it folds by
-            // both challenges, answers this round, and leaves the tables exactly where an ordinary round k would have
-            const bool look = r2_eligible(ctx, k + 2, 2);
-            VPCHK(do_round2(ctx, 2, ctx->dbl.r_pend, rv, look));
-            VPCHK(wait_ticket(ctx));
-            F p[3];
-            r2_collect(ctx, 2, rv, p, look);
-            memcpy(out_poly, p, sizeof p);
-            *how = 4;                                         // one pass for two challenges
-            return VP_OK;
-        }
-        // the chain ends here: fold the challenge that was answered on the host into the tables — exactly the launch round k - 1 would have been
-        // (it also brings add_term up to date) — and carry on with the ordinary paths
-        --ctx->sc.round;
-        VPCHK(do_round(ctx, nullptr, ctx->dbl.r_pend, ctx->d_tr + ctx->n_tr, nullptr));
-        --ctx->st.rounds;
-        ctx->dbl.need_fold = false;
     }
     // small rounds: one resident kernel answers every remaining message of the phase through a mailbox (vp_kernels_persist.h)
     if (ctx->tail_lost) { ctx->err = "the resident round kernel was told to leave by another context before it could save its phase"; return VP_EHIP; }
@@ -1524,12 +1387,6 @@ int vp_finalize(vp_ctx *ctx, const vp_F *previous_random, vp_F *claims, int n_cl
     if (rv.re >= P61 || rv.im >= P61) { ctx->err = "vp_finalize: previous_random is not canonical (limb >= 2^61 - 1)"; return VP_EINVAL; }
     // the live level of a lost phase was in LDS only: the tables in HBM are stale, claims from them would be wrong (vp_round refuses the same way)
     if (ctx->tail_lost) { ctx->err = "the resident round kernel was told to leave by another context before it could save its phase"; return VP_EHIP; }
-    if (ctx->dbl.need_fold) {                                 // the last round was answered on the host: its challenge is not in the tables yet
-        --ctx->sc.round;
-        VPCHK(do_round(ctx, nullptr, ctx->dbl.r_pend, ctx->d_tr + ctx->n_tr, nullptr));
-        --ctx->st.rounds;
-        ctx->dbl.need_fold = false;
-    }
     if (ctx->tail_suspended) VPCHK(tail_resume(ctx, false));
     if (ctx->tail_active) {                                   // the resident kernel holds the tables: it computes the claims and leaves
         int rc = tail_send(ctx, 2, rv);
