@@ -502,7 +502,27 @@ def gather_floats(world, rank, x):
     return [float(v) for v in t]
 
 
-def sharded_leg(vp, pws, golden, a, world, rank, local, blocks):
+def sharded_prepare(vp, pws, golden, a, world, rank, local, blocks):
+    """The LOCAL half of the `sharded` sub-leg — instance, session, the unsharded proof the shards must assemble to; no collective in here, so a
+    rank that fails here can still tell the others at the flag exchange that follows (main)."""
+    name = "sha256_x%d" % blocks
+    g = golden[name]
+    # test hook (tests/test_gpu_parity.py: a rank that fails / never arrives before the first collective): "raise:<rank>" | "hang:<rank>"
+    inj = os.environ.get("VP_BENCH_INJECT", "")
+    if inj and int(inj.split(":")[1]) == rank:
+        if inj.startswith("raise"):
+            raise RuntimeError("injected failure on rank %d before the first collective" % rank)
+        time.sleep(10 ** 6)
+    circ = vp.Circuit.from_pws(pws, blocks, seed=1)
+    sess = vp.Session(circ, device=local)
+    sess.draw_tape()
+    full, okf = sess.prove_full(batched=True)                     # unsharded, on every rank: the answer the shards must assemble to
+    point = sess.last_point()
+    return {"name": name, "g": g, "circ": circ, "sess": sess, "full": full, "point": point, "inputs": sess.layer_values(0), "pub": sess.eq_table(point),
+            "n_bits": circ.layer_bitlen(0)}
+
+
+def sharded_leg(vp, prep, golden, a, world, rank, local, blocks):
     """One proof over the GPUs of the node (north_star: "independent sumcheck instances / FFT subtrees shard across the GPUs with a single RCCL
     reduce"): the chains of ONE proof dealt to the ranks (vp_set_shard; long chains also cut by index when the in-library communicator is
     there), ONE all-reduce of the transcript per proof; then the commitment of the same instance sharded over the ranks (vp_pc_set_shard:
@@ -511,19 +531,10 @@ def sharded_leg(vp, pws, golden, a, world, rank, local, blocks):
     transcript goes through torch/gloo and the commitment's collectives through the host transport (vp_shard_exchange_get / _put)."""
     import numpy as np
     import torch.distributed as dist
-    name = "sha256_x%d" % blocks
-    g = golden[name]
+    g, circ, sess, full, point, inputs, pub, n_bits = (prep[k] for k in ("g", "circ", "sess", "full", "point", "inputs", "pub", "n_bits"))
     rccl = "nccl" in dist.get_backend()
-    circ = vp.Circuit.from_pws(pws, blocks, seed=1)
-    sess = vp.Session(circ, device=local)
-    sess.draw_tape()
-    full, okf = sess.prove_full(batched=True)                     # unsharded, on every rank: the answer the shards must assemble to
     gold_full = open(os.path.join(ROOT, "tests", "golden", g["transcript"]), "rb").read()
     gold = gold_full[g["gkr_slice"][0]:g["gkr_slice"][1]]
-    point = sess.last_point()
-    inputs = sess.layer_values(0)
-    pub = sess.eq_table(point)
-    n_bits = circ.layer_bitlen(0)
     sess.set_shard(rank, world)
     mode = "gloo"
     rccl_ranks = None
@@ -1170,6 +1181,7 @@ def main():
     if a.randomize:
         a.no_cpu_baseline = True
     out = OneLine()
+    failed_subleg = False
     with tempfile.TemporaryDirectory() as tmp:
         pws = unpack_pws(tmp)
         # one-time cost of the process (HIP context, code objects: ~0.25 s) paid by a 3-gate circuit first, so that circuit_upload_sec is
@@ -1221,14 +1233,25 @@ def main():
 
             wd = Watchdog(a.subleg_timeout, on_timeout)
             failed = None
-            sub = None
-            try:
-                sub = sharded_leg(vp, pws, golden, a, world, rank, local, a.blocks)
-            except Exception as e:          # a rank that fails outside a collective: the others find out at the flag exchange
+            sub = prep = None
+            try:                                # local work only: a failure here is reported at the flag exchange below, nobody is left in a collective
+                prep = sharded_prepare(vp, pws, golden, a, world, rank, local, a.blocks)
+            except Exception as e:
                 failed = "%s: %s" % (type(e).__name__, e)
-                sub = {"error": failed}
-            if not allreduce_min_flag(world, failed is None) and "error" not in sub:
-                sub = {"error": "another rank failed in this leg", "partial": sub}
+            if not allreduce_min_flag(world, failed is None):
+                sub = {"error": failed or "another rank failed before the first collective of this leg"}
+            else:
+                try:
+                    sub = sharded_leg(vp, prep, golden, a, world, rank, local, a.blocks)
+                except Exception as e:
+                    # inside the collective part there is nothing graceful left: the peers sit in a collective this rank will never join.  Say so
+                    # (rank 0 prints the line it has) and leave with an error code; the peers' collectives fail or their watchdogs fire.
+                    sys.stderr.write("bench.py rank %d: sharded sub-leg failed inside its collective part: %s: %s\n" % (rank, type(e).__name__, e))
+                    if rank == 0:
+                        detail["multi_gpu_sublegs_error"] = "%s: %s" % (type(e).__name__, e)
+                        out.emit(detail, world, a.detail_file)
+                        sys.stdout.flush()
+                    os._exit(3)
             wd.cancel()
             if rank == 0:
                 detail["sharded"] = sub
@@ -1237,9 +1260,12 @@ def main():
                     detail["multi_gpu_sublegs_error"] = sub["error"]
         if rank == 0:
             out.emit(detail, world, a.detail_file)
+        failed_subleg = allreduce_min_flag(world, not (rank == 0 and detail.get("multi_gpu_sublegs_error"))) is False
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+    if failed_subleg:               # the line is out (with multi_gpu_sublegs_error); the launcher must still see that the run was not whole
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -82,12 +82,10 @@ typedef struct {
     int32_t fuse_init;              /* VP_FUSE_INIT: phase-1 / Liu init inside the first fold launch of large tables             [1] */
     int32_t fuse_min_log;           /* VP_FUSE_MIN_LOG: ... from 2^this entries on; 0 = clamp(largest layer's bit length - 1, 20, 22)    [0] */
     int32_t fuse_dot;               /* VP_FUSE_DOT: V_u rides on the fused launch                                                [0] */
-    int32_t init3;                  /* VP_INIT3: entry-parallel init kernels (measured slower)                                   [0] */
     int32_t drop_y;                 /* VP_DROP_Y: rounds >= 2 derive b from the previous claim (five products per pair)          [1] */
     int32_t drop_y_round1;          /* VP_DROP_Y1: round 1 too, restored by k_fixup                                              [0] */
     int32_t real_values;            /* VP_REAL_V: real x complex products when every circuit value is real                       [1] */
     int32_t seg_tiny;               /* VP_SEG_TINY: tables <= 2^e entries are folded by the first k_seg launch                   [1] */
-    int32_t sf_rounds;              /* VP_SF_ROUNDS: rounds per fold launch, 3 or 4                                              [3] */
     int32_t sf_big_log;             /* VP_SF_BIG_LOG: fold kernel from 2^this entries on (plan path)                             [14] */
     int32_t sf3b;                   /* VP_SF3B: block-cooperative fold kernel on the non-plan paths                              [1] */
     int32_t sf3b_grid;              /* VP_SF3B_GRID: its workgroups per launch                                                   [512] */
@@ -411,7 +409,7 @@ int vp_set_profiling(vp_ctx *, int level);
  * launch on every table it holds; closing kernels: the remaining ones), `first_round` the earliest of them (1-based).   */
 enum { VP_K_BETA = 0, VP_K_LIGHT, VP_K_CHUNKS, VP_K_COMBINE, VP_K_DOT, VP_K_DOTFIN, VP_K_SFGEN, VP_K_SF, VP_K_SEG, VP_K_EMIT,
        VP_K_FIXUP, VP_K_NTT_SPLIT, VP_K_NTT_LDS, VP_K_NTT_UNSPLIT, VP_K_LEAF_HASH, VP_K_MERKLE, VP_K_PC_POINTWISE, VP_K_FRI_FOLD,
-       VP_K_ROUND, VP_K_INIT3, VP_K_NTT8_COLS, VP_K_NTT8_ROWS, VP_K_COUNT };
+       VP_K_ROUND, VP_K_NTT8_COLS, VP_K_NTT8_ROWS, VP_K_COUNT };
 typedef struct {
     int32_t kind;             /* VP_K_*                                                          */
     int32_t step;             /* position in the launch order of the call                        */

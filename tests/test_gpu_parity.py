@@ -111,39 +111,19 @@ def test_fused_init_plan_matches_reference(vp, golden, gold_gkr, pws_path, name,
     s2.draw_tape()
     tr2, _ = s2.prove_gkr()
     assert tr2 == tr
-    monkeypatch.setenv("VP_INIT3", "1")             # entry-parallel init kernels (k_init3_multi, GenI3P1 / GenI3Liu) instead of the row-per-lane lists
-    s2b = vp.Session(c)
-    s2b.draw_tape()
-    assert s2b.prove_gkr()[0] == tr
     monkeypatch.delenv("VP_FUSE_MIN_LOG"); monkeypatch.delenv("VP_FUSE_DOT")
-    s2c = vp.Session(c)
-    s2c.draw_tape()
-    assert s2c.prove_gkr()[0] == tr
-    s2b.close(); s2c.close()
-    monkeypatch.delenv("VP_INIT3")
-    monkeypatch.setenv("VP_SF_ROUNDS", "4")         # four-round fold launches (k_sumfold4b_multi)
-    s3 = vp.Session(c)
-    s3.draw_tape()
-    tr3, _ = s3.prove_gkr()
-    assert tr3 == tr
-    monkeypatch.delenv("VP_SF_ROUNDS")
     monkeypatch.setenv("VP_DROP_Y", "0")            # every round sums m1 v1 + a1 itself instead of deriving b from the previous claim
     s4 = vp.Session(c)
     s4.draw_tape()
     tr4, _ = s4.prove_gkr()
     assert tr4 == tr
-    monkeypatch.setenv("VP_SF_ROUNDS", "4")
-    s5 = vp.Session(c)
-    s5.draw_tape()
-    tr5, _ = s5.prove_gkr()
-    assert tr5 == tr
-    monkeypatch.delenv("VP_SF_ROUNDS"); monkeypatch.delenv("VP_DROP_Y")
+    monkeypatch.delenv("VP_DROP_Y")
     monkeypatch.setenv("VP_DROP_Y1", "1")           # round 1 leaves its b to the fix-up pass over the finished transcript (k_fixup)
     s6 = vp.Session(c)
     s6.draw_tape()
     tr6, res6 = s6.prove_gkr()
     assert tr6 == tr
-    s.close(); s2.close(); s3.close(); s4.close(); s5.close(); s6.close(); c.close()
+    s.close(); s2.close(); s4.close(); s6.close(); c.close()
 
 
 def _sharded_parts(vp, s, world):
@@ -402,7 +382,7 @@ def test_launch_stats_table_covers_every_launch(vp, gold_gkr):
     s.set_profiling(0)
     assert tr_p == tr
     kinds = {e["kernel"] for e in st}
-    assert {"k_beta_half_direct", "k_seg_multi", "k_emit_multi"} <= kinds and ({"k_init3_multi", "k_light_multi"} & kinds)
+    assert {"k_beta_half_direct", "k_seg_multi", "k_emit_multi"} <= kinds and ("k_light_multi" in kinds)
     assert len(st) == res_p["launches"]
     assert all(e["us"] > 0 for e in st)
     assert all(e["bytes"] > 0 for e in st if e["kernel"] not in ("k_beta_half_direct", "k_fixup"))
@@ -1316,9 +1296,9 @@ def test_options_struct_selects_the_same_alternatives_as_the_test_environment(vp
     c = vp.Circuit.from_pws(pws_path, 16, seed=1)
     gold = gold_gkr("sha256_x16")
     d = vp.Options()
-    assert d.struct_size == ctypes.sizeof(vp.Options) and d.sf_rounds == 3 and d.drop_y == 1 and d.persistent_rounds == 1
+    assert d.struct_size == ctypes.sizeof(vp.Options) and d.drop_y == 1 and d.persistent_rounds == 1
     launches = {}
-    for name, kw in (("default", {}), ("four_rounds", {"sf_rounds": 4}), ("keep_y", {"drop_y": 0}), ("complex_products", {"real_values": 0}),
+    for name, kw in (("default", {}), ("keep_y", {"drop_y": 0}), ("complex_products", {"real_values": 0}),
                      ("lanes", {"gkr_path": vp.PATH_LANES}), ("simple", {"gkr_path": vp.PATH_SIMPLE}), ("no_graph", {"use_graph": 0, "serial": 1}),
                      ("copy_engine", {"kernel_copies": 0}), ("blocking_wait", {"poll": 0}), ("fixed_layout", {"plan_autotune": 0}),
                      ("combine_node", {"plan_autotune": 0, "fuse_combine": 0}), ("one_fold_stream", {"plan_autotune": 0, "fold_branches": 0})):
@@ -1331,11 +1311,10 @@ def test_options_struct_selects_the_same_alternatives_as_the_test_environment(vp
             tr_i, _, ok = s.prove_interactive()
             assert ok and tr_i == gold
         s.close()
-    # the alternatives really ran: one launch per round on the simple path, one stream per chain (no batched nodes) on the lanes path,
-    # fewer fold launches with four rounds each
+    # the alternatives really ran: one launch per round on the simple path, one stream per chain (no batched nodes) on the lanes path
     assert launches["simple"] > 10 * launches["default"] and launches["lanes"] > launches["default"]
     # (the default session picks its plan layout by measurement on the first proof: compare launch counts against the fixed layout)
-    assert launches["four_rounds"] <= launches["fixed_layout"] + 2 and launches["no_graph"] == launches["fixed_layout"]
+    assert launches["no_graph"] == launches["fixed_layout"]
     assert launches["combine_node"] > launches["fixed_layout"]
     s = vp.Session(c, options=vp.Options(persistent_rounds=0))
     tr_i, _, ok = s.prove_interactive()
@@ -1350,7 +1329,7 @@ def test_options_struct_selects_the_same_alternatives_as_the_test_environment(vp
     assert tr == gold and eff.plan_autotune == 1 and (eff.fuse_combine, eff.sf3b_grid, eff.fuse_min_log) == (1, 448, 21)
     s.close()
     # a caller built against an older header passes a shorter struct: the fields it does not know keep the library's defaults
-    old = vp.Options(gkr_path=vp.PATH_SIMPLE, sf_rounds=4)
+    old = vp.Options(gkr_path=vp.PATH_SIMPLE, drop_y=0)
     old.struct_size = 8                                   # struct_size + gkr_path only
     s = vp.Session(c, options=old)
     s.draw_tape()
@@ -1478,6 +1457,39 @@ def test_two_processes_share_a_sharded_proof_and_commitment_host_transport(vp):
     r = _run_ranks(2, "host", 16)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     assert "RANK 0 OK" in r.stdout and "RANK 1 OK" in r.stdout
+
+
+def _bench_two_ranks(extra_env, timeout_s, *flags):
+    """bench.py --gpus 2 as the driver starts it (torch.distributed.run, one process per rank), both ranks on this box's GPU (gloo control plane,
+    host transport: the rehearsal mode)."""
+    import subprocess, sys
+    env = dict(os.environ, VP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29577",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--blocks", "16", "--no-cpu-baseline"] + list(flags)
+    return subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout_s, env=env, cwd=ROOT)
+
+
+@pytest.mark.parametrize("inject", [None, "raise:1", "hang:1"])
+def test_bench_multi_rank_line_and_exit_code_when_a_rank_fails(vp, tmp_path, inject):
+    """The multi-rank run of bench.py prints exactly ONE parseable line whatever happens in its `sharded` sub-leg, and its exit code tells the
+    launcher when the run was not whole: a rank that raises before the first collective (the others learn at the flag exchange), a rank that never
+    arrives (the watchdog prints what there is and every rank leaves with code 3), and the healthy run (code 0, sub-leg bit-exact)."""
+    import json
+    detail = str(tmp_path / "detail.json")
+    env = {"VP_BENCH_INJECT": inject} if inject else {}
+    flags = ["--detail-file", detail] + (["--subleg-timeout", "25"] if inject and inject.startswith("hang") else [])
+    r = _bench_two_ranks(env, 600, *flags)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (r.stdout[-800:], r.stderr[-2500:])
+    o = json.loads(lines[0])
+    assert len(lines[0].encode()) <= 4096 and o["ranks"] == 2 and o["n_gpus"] == 1      # two ranks on ONE card: a rehearsal never reads as two GPUs
+    assert o["bit_exact"] is True and o["config"]["proofs_per_step"] == 2
+    if inject is None:
+        assert r.returncode == 0, (r.returncode, r.stderr[-2500:])
+        assert "multi_gpu_sublegs_error" not in o and o["sharded"]["bit_exact"] is True and o["sharded"]["commitment_bit_exact"] is True
+    else:
+        assert r.returncode != 0
+        assert "multi_gpu_sublegs_error" in o and ("failed" in o["multi_gpu_sublegs_error"] or "timed out" in o["multi_gpu_sublegs_error"])
 
 
 _EXIT_WORKER = r"""

@@ -11,14 +11,13 @@
 // assembled from pairs (T_k[2p], T_k[2p+1]).  Same field values, half the bytes.
 //
 // Files: vp_kernels_round.h (reductions, eq tables, evaluation, per-round kernels)  vp_kernels_batch.h (batched init +
-// fold kernels)  vp_kernels_init3.h (entry-parallel inits)  vp_kernels_plan.h (segment / closing kernels, batched launches)  vp_kernels_pc.h (polynomial commitment)  vp_kernels_fftgkr.h (circuit and tables of fft_gkr).
+// fold kernels)  vp_kernels_plan.h (segment / closing kernels, batched launches)  vp_kernels_pc.h (polynomial commitment)  vp_kernels_fftgkr.h (circuit and tables of fft_gkr).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "vp_field.h"
 #include "vp_kernels_round.h"
 #include "vp_kernels_persist.h"
 #include "vp_kernels_batch.h"
-#include "vp_kernels_init3.h"
 #include "vp_kernels_plan.h"
 #include "vp_kernels_pc.h"
 #include "vp_kernels_fftgkr.h"

@@ -589,19 +589,6 @@ __device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb,
                     if (HAS_A) { a0 = ld_or_zero(a.inA, i0, vend); a1 = ld_or_zero(a.inA, i0 + 1, vend); }
                 }
 #endif
-            } else if constexpr (Gen::MODE >= 3) {          // entry-parallel init of this 512-row chunk into LDS (vp_kernels_init3.h), then the pair from there
-                gen.chunk(cl, i0, vend, m0, a0, m1, a1);
-                if constexpr (Gen::MODE == 3) {
-                    if (gen.dot_part) {
-                        if (vreal) {
-                            if (i0 < vend) dacc = f_mad31c_rb<false>(half_at(gen.dot_h, i0), v0.re, dacc);
-                            if (i0 + 1 < vend) dacc = f_mad31c_rb<false>(half_at(gen.dot_h, i0 + 1), v1.re, dacc);
-                        } else {
-                            if (i0 < vend) dacc = f_add(dacc, f_mul(half_at(gen.dot_h, i0), v0));
-                            if (i0 + 1 < vend) dacc = f_add(dacc, f_mul(half_at(gen.dot_h, i0 + 1), v1));
-                        }
-                    }
-                }
             } else {                      // generated tables: one table per job, offset 0
 #ifdef VP_GEN_ROW1
                 gen.row(i0, vend, m0, a0);
@@ -688,96 +675,6 @@ __device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb,
             block_sum<1>(d, sm.dred);
             if (t == 0) gen.dot_part[bid] = d[0];
         }
-    }
-}
-// Four rounds per launch on 1024-entry chunks: round k is two pairs per thread (entries 2t, 2t+1 and 512+2t, 512+2t+1), round
-// k+1 one pair per thread on all four waves, rounds k+2 / k+3 on two waves / one wave.  One launch folds a table 16x (one
-// fold level less on the critical path of the long chains), 15 wave pair-steps per 1024 entries (the three-round kernel: 14).
-struct Sf4bLds { F s1[3][512]; F s2[3][256]; F s3[3][128]; F red[4][12]; Lz acc3[3][128]; Lz acc4[3][64]; };
-template <bool HAS_A>
-__device__ __forceinline__ void sumfold4b_body(const SfArgs &a, u32 bid, u32 nb, Sf4bLds &sm) {
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    Lz acc[6];                                             // rounds k and k+1: every thread works in both
-#pragma unroll
-    for (int i = 0; i < 6; ++i) acc[i].re = acc[i].im = 0;
-    if (t < 128) { for (int i = 0; i < 3; ++i) { sm.acc3[i][t].re = 0; sm.acc3[i][t].im = 0; } }
-    if (t < 64) { for (int i = 0; i < 3; ++i) { sm.acc4[i][t].re = 0; sm.acc4[i][t].im = 0; } }
-    const F r0 = a.r[0], r1 = a.r[1], r2 = a.r[2], r3 = a.r[3];
-    const bool keep_y0 = (a.keep_y0 & 1) != 0, keep_rest = (a.keep_y0 & 2) != 0;
-    for (u32 c = bid; c < a.total_chunks; c += nb) {
-        int j = 0;
-        while (j + 1 < a.n_tab && c >= a.t[j + 1].chunk_start) ++j;
-        const SfTab td = a.t[j];
-        const u32 cl = c - td.chunk_start;
-        const u32 vend = td.off + td.valid;
-#pragma unroll 1
-        for (int h = 0; h < 2; ++h) {                      // round k: two pairs per thread (not unrolled: register pressure)
-            const u32 i0 = td.off + cl * 1024 + 512 * h + 2 * t;
-            const F v0 = ld_or_zero(a.inV, i0, vend), v1 = ld_or_zero(a.inV, i0 + 1, vend);
-            const F m0 = ld_or_zero(a.inM, i0, vend), m1 = ld_or_zero(a.inM, i0 + 1, vend);
-            F a0 = f_zero(), a1 = f_zero();
-            if (HAS_A) { a0 = ld_or_zero(a.inA, i0, vend); a1 = ld_or_zero(a.inA, i0 + 1, vend); }
-            F vo, mo, ao = f_zero();
-            sf_pair_step<HAS_A>(v0, v1, m0, m1, a0, a1, r0, acc[0], acc[1], acc[2], vo, mo, ao, keep_y0);
-            sm.s1[0][256 * h + t] = vo; sm.s1[1][256 * h + t] = mo;
-            if (HAS_A) sm.s1[2][256 * h + t] = ao;
-        }
-        __syncthreads();
-        {   // round k+1: 256 pairs
-            F vo, mo, ao = f_zero();
-            sf_pair_step<HAS_A>(sm.s1[0][2 * t], sm.s1[0][2 * t + 1], sm.s1[1][2 * t], sm.s1[1][2 * t + 1],
-                                HAS_A ? sm.s1[2][2 * t] : f_zero(), HAS_A ? sm.s1[2][2 * t + 1] : f_zero(), r1,
-                                acc[3], acc[4], acc[5], vo, mo, ao, keep_rest);
-            sm.s2[0][t] = vo; sm.s2[1][t] = mo;
-            if (HAS_A) sm.s2[2][t] = ao;
-        }
-        __syncthreads();
-        if (w < 2) {   // round k+2: 128 pairs
-            F vo, mo, ao = f_zero();
-            Lz x = sm.acc3[0][t], y = sm.acc3[1][t], z = sm.acc3[2][t];
-            sf_pair_step<HAS_A>(sm.s2[0][2 * t], sm.s2[0][2 * t + 1], sm.s2[1][2 * t], sm.s2[1][2 * t + 1],
-                                HAS_A ? sm.s2[2][2 * t] : f_zero(), HAS_A ? sm.s2[2][2 * t + 1] : f_zero(), r2,
-                                x, y, z, vo, mo, ao, keep_rest);
-            lz_fold(x); lz_fold(y); lz_fold(z);
-            sm.acc3[0][t] = x; sm.acc3[1][t] = y; sm.acc3[2][t] = z;
-            sm.s3[0][t] = vo; sm.s3[1][t] = mo;
-            if (HAS_A) sm.s3[2][t] = ao;
-        }
-        __syncthreads();
-        if (w == 0) {  // round k+3: 64 pairs, results are the folded table
-            F vo, mo, ao = f_zero();
-            Lz x = sm.acc4[0][t], y = sm.acc4[1][t], z = sm.acc4[2][t];
-            sf_pair_step<HAS_A>(sm.s3[0][2 * t], sm.s3[0][2 * t + 1], sm.s3[1][2 * t], sm.s3[1][2 * t + 1],
-                                HAS_A ? sm.s3[2][2 * t] : f_zero(), HAS_A ? sm.s3[2][2 * t + 1] : f_zero(), r3,
-                                x, y, z, vo, mo, ao, keep_rest);
-            lz_fold(x); lz_fold(y); lz_fold(z);
-            sm.acc4[0][t] = x; sm.acc4[1][t] = y; sm.acc4[2][t] = z;
-            const u32 oi = cl * 64 + t;
-            if (oi < ((td.valid + 15) >> 4)) {
-                a.outV[td.off + oi] = vo;
-                a.outM[td.off + oi] = mo;
-                if (HAS_A) a.outA[td.off + oi] = ao;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) lz_fold(acc[i]);
-    }
-    // block partials: rounds k, k+1 in all waves, k+2 in waves 0-1, k+3 in wave 0
-#pragma unroll
-    for (int i = 0; i < 12; ++i) {
-        if (i >= 6 && w >= 2) break;
-        if (i >= 9 && w >= 1) break;
-        const Lz v = i < 6 ? acc[i] : i < 9 ? sm.acc3[i - 6][t] : sm.acc4[i - 9][t];
-        const F x = wave_sum63(lz_canon(v));
-        if (lane == 63) sm.red[w][i] = x;
-    }
-    __syncthreads();
-    if (t < 4) {
-        const int nw = t < 2 ? 4 : t == 2 ? 2 : 1;
-        F X = sm.red[0][3 * t], Y = sm.red[0][3 * t + 1], Z = sm.red[0][3 * t + 2];
-        for (int k = 1; k < nw; ++k) { X = f_add(X, sm.red[k][3 * t]); Y = f_add(Y, sm.red[k][3 * t + 1]); Z = f_add(Z, sm.red[k][3 * t + 2]); }
-        F *o = a.part + (size_t) t * a.part_stride + bid * 3;
-        o[0] = X; o[1] = (t == 0 ? keep_y0 : keep_rest) ? f_sub(f_sub(Y, X), Z) : f_zero(); o[2] = Z;
     }
 }
 

@@ -488,23 +488,21 @@ k_fri_fold(const F *__restrict__ in, F *__restrict__ out, u32 Nk, int k, const F
 // and the folded levels), so nothing else needs it.  Unsharded commitment only (lw = 0).
 __global__ void __launch_bounds__(VP_BLOCK)
 k_fri_fold0_vo(const F *__restrict__ lcw, const F *__restrict__ qcw, const F *__restrict__ hcw, const F *__restrict__ S0, F *__restrict__ out, u32 N,
-               const F *__restrict__ RT, u32 half_m, F r, F half_n /* N / 2 */, const F *__restrict__ q0, const F *__restrict__ qscal) {
+               const F *__restrict__ RTn /* w_N^k, k < N */, const F *__restrict__ cb /* [b] = w_M^-b, [32 + b] = w_32^b - 1 */, F r, F half_n /* N / 2 */,
+               const F *__restrict__ q0, const F *__restrict__ qscal) {
     const size_t t = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
     const u32 No = N >> 1;
     if (t >= (size_t) 64 * 32 * No) return;
     const u32 al = (u32) (t % No), sb = (u32) (t / No), b = sb & 31, i = sb >> 5;
-    const u32 M = 2 * half_m;
     const size_t p0 = (size_t) sb * N + al, p1 = p0 + No;
-    const u32 e = 32 * al + b;                                               // x = w_M^e
-    const u32 ex = e ? M - e : 0, exn = (u32) (((size_t) b * N) & (M - 1));
-    const F wx = root_raw(RT, half_m, ex), wn = root_raw(RT, half_m, exn);
+    const F wa = RTn[(N - al) & (N - 1)];                                     // w_N^-a = w_M^-(32 a): contiguous along the lanes
     F qa, qb;
     if (q0) { const F sc = qscal[i]; const size_t o = (size_t) b * N + al; qa = f_mul(sc, q0[o]); qb = f_mul(sc, q0[o + No]); }
     else { qa = qcw[p0]; qb = qcw[p1]; }
     const F la = lcw[p0], lb = lcw[p1], ha = hcw[p0], hb = hcw[p1];
     loads_first();
-    const F inv_x = root_fin(wx, half_m, ex);
-    const F xn_m1 = f_sub(root_fin(wn, half_m, exn), f_one());              // x^N - 1 = w_M^(N b) - 1: the same for both positions
+    const F inv_x = f_mul(wa, cb[b]);                                         // x^-1, x = w_M^(32 a + b)
+    const F xn_m1 = cb[32 + b];                                               // x^N - 1 = w_32^b - 1: the same for both positions
     const F s0 = S0[i];
     const F Ga = f_sub(f_sub(f_mul(la, qa), f_mul(xn_m1, ha)), s0), Gb = f_sub(f_sub(f_mul(lb, qb), f_mul(xn_m1, hb)), s0);
     const F D = f_sub(Ga, Gb), S = f_add(Ga, Gb);

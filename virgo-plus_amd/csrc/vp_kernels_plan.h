@@ -2,7 +2,6 @@
 // Part of the single translation unit vpgpu.hip (see vp_kernels.h for the overall layout rules).
 #pragma once
 #include "vp_kernels_batch.h"
-#include "vp_kernels_init3.h"
 
 // ===================================================================================================
 // Segment kernels (default batched path).
@@ -514,15 +513,6 @@ __global__ void __launch_bounds__(VP_BLOCK) k_light_multi(const LightJob *__rest
         if (threadIdx.x == 0) j.dot_part[m.bid] = acc[0];
     }
 }
-// Entry-parallel inits (vp_kernels_init3.h): block b -> (job, 512-row chunk of its target rows)
-__global__ void __launch_bounds__(VP_BLOCK) k_init3_multi(const I3Job *__restrict__ jobs, const BlkMap *__restrict__ map) {
-    __shared__ I3Lds sm;
-    const BlkMap m = map[blockIdx.x];
-    const I3Job &j = jobs[m.job];
-    if (j.phase == 1) i3_body<1>(j, m.bid, sm);
-    else if (j.phase == 2) i3_body<2>(j, m.bid, sm);
-    else i3_body<0>(j, m.bid, sm);
-}
 // Verifier-side wiring predicates (reference: verifier::betaInitPhase1/2 + predicatePhase1/2, src/verifier.cpp:50-113): for
 // layer i,  coeff_l[t] = sum over unary gates g of type t of beta_g[g] beta_u[u_g] (x c_g for Mulc),  bias = the Addc sum
 // x c_g,  coeff_r[t][l] = sum over binary gates of type t with second operand in layer l of beta_g[g] beta_u[u_g] beta_v[lv_g].
@@ -612,14 +602,8 @@ __global__ void __launch_bounds__(VP_BLOCK, VP_SF_MINB) k_sumfold3b_multi(const 
     const SfArgs &a = jobs[m.job];
     if (a.has_a) sumfold3b_body<true>(a, m.bid, a.nblk, sm, GenLoad()); else sumfold3b_body<false>(a, m.bid, a.nblk, sm, GenLoad());
 }
-__global__ void __launch_bounds__(VP_BLOCK, 3) k_sumfold4b_multi(const SfArgs *__restrict__ jobs, const BlkMap *__restrict__ map) {
-    __shared__ Sf4bLds sm;
-    const BlkMap m = map[blockIdx.x];
-    const SfArgs &a = jobs[m.job];
-    if (a.has_a) sumfold4b_body<true>(a, m.bid, a.nblk, sm); else sumfold4b_body<false>(a, m.bid, a.nblk, sm);
-}
 // First fold launch of a phase-1 / Liu sumcheck with its init fused in (see GenP1 / GenLiu).
-struct SfGenJob { SfArgs sf; InitArgs2 a; GatherJob g; Half dot_h; F *dot_part; int mode; int pad; Csr3 c3; Csr3L l3; };   // mode 1 / 2: row-per-lane lists; 3 / 4: entry-parallel (c3 / l3)
+struct SfGenJob { SfArgs sf; InitArgs2 a; GatherJob g; Half dot_h; F *dot_part; int mode; int pad; };   // mode 1: phase-1 init (GenP1), 2: Liu gather (GenLiu)
 __global__ void __launch_bounds__(VP_BLOCK, VP_SF_MINB) k_sumfold3b_gen_multi(const SfGenJob *__restrict__ jobs, const BlkMap *__restrict__ map) {
     __shared__ Sf3bLds sm;
     const BlkMap m = map[blockIdx.x];
@@ -629,20 +613,6 @@ __global__ void __launch_bounds__(VP_BLOCK, VP_SF_MINB) k_sumfold3b_gen_multi(co
         sumfold3b_body<true>(j.sf, m.bid, j.sf.nblk, sm, g);
     } else {
         GenLiu g; g.rowptr = j.g.rowptr; g.e_q = j.g.e_q; g.e_g = j.g.e_g; g.H = j.g.H;
-        sumfold3b_body<false>(j.sf, m.bid, j.sf.nblk, sm, g);
-    }
-}
-// The same with the entry-parallel init (vp_kernels_init3.h): a fold chunk of 512 entries is one init chunk of 512 target rows.
-__global__ void __launch_bounds__(VP_BLOCK, VP_SF_MINB) k_sumfold3b_gen3_multi(const SfGenJob *__restrict__ jobs, const BlkMap *__restrict__ map) {
-    __shared__ Sf3bLds sm;
-    __shared__ I3Lds sm3;
-    const BlkMap m = map[blockIdx.x];
-    const SfGenJob &j = jobs[m.job];
-    if (j.mode == 3) {
-        GenI3P1 g; g.a = &j.a; g.c = &j.c3; g.dot_h = j.dot_h; g.dot_part = j.dot_part; g.sm = &sm3;
-        sumfold3b_body<true>(j.sf, m.bid, j.sf.nblk, sm, g);
-    } else {
-        GenI3Liu g; g.cl = &j.l3; g.H = j.g.H; g.sm = &sm3;
         sumfold3b_body<false>(j.sf, m.bid, j.sf.nblk, sm, g);
     }
 }

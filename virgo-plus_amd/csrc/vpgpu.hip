@@ -28,7 +28,6 @@ struct Csr {                 // contributions of one layer sorted by target row 
     uint16_t *e_tl = nullptr;
     u32 *heavy_row = nullptr, *heavy_cptr = nullptr, *chunk_beg = nullptr, *chunk_end = nullptr;
     u32 *chunk_h = nullptr, *heavy_cnt = nullptr;      // heavy-row index of every chunk; arrival counters of the rows cut into several chunks (zero between proofs)
-    Csr3 c3{};               // the same light contributions cut into 512-row chunks for the entry-parallel kernels
     std::vector<u32> h_heavy_row, h_heavy_cptr;      // host copies (a handful of rows): row-range init jobs of the index-split proof
 };
 
@@ -51,7 +50,6 @@ struct LayerDev {
     // batched path: per-slot V gather map, Liu gather lists, half tables of this layer's sumchecks
     uint8_t *s_layer = nullptr; u32 *s_idx = nullptr;
     u32 *lrow = nullptr, *l_g = nullptr; uint8_t *l_q = nullptr; u32 l_n = 0;      // l_n: entries of the Liu gather lists
-    Csr3L l3{};              // the Liu gather lists cut into 512-row chunks (entry-parallel kernels)
     Half hg{}, hu{};
     Half *liu_H = nullptr;
     // verifier-side predicates (vp_predicates): gates listed by bucket, pieces of <= 512
@@ -87,7 +85,7 @@ struct Lane {
 enum { NK_LIGHT = 0, NK_CHUNKS, NK_COMBINE, NK_DOT, NK_DOTFIN, NK_SFGEN, NK_SF, NK_SEG, NK_EMIT, NK_COUNT };
 struct PStep { int kind; u32 idx, grid, lds; u64 bytes; int rounds; int xchain; u64 work = 0; int first_round = 0, n_rounds = 0; };   // kind -1: placeholder step; xchain: also wait for that chain's latest node
 struct PlanRec {
-    std::vector<LightJob> light; std::vector<I3Job> init3; std::vector<ChunkJob> chunks; std::vector<CombineJob> combine; std::vector<DotJob> dot;
+    std::vector<LightJob> light; std::vector<ChunkJob> chunks; std::vector<CombineJob> combine; std::vector<DotJob> dot;
     std::vector<SfArgs> sf; std::vector<SfGenJob> sfgen; std::vector<SegArgs> seg; std::vector<EmitArgs> emit;
     std::vector<std::vector<PStep>> chains; int cur = -1;
     void push(int kind, u32 idx, u32 grid, u32 lds = 0, u64 bytes = 0, u64 work = 0, int first_round = 0, int n_rounds = 0) {
@@ -100,12 +98,11 @@ struct PNode { int kind = 0, step = 0, stream = 0; u32 first = 0, count = 0, gri
                std::vector<int> deps; hipEvent_t ev = nullptr; bool record = false; bool p2 = false; };     // p2: every job belongs to a phase-2 chain
 struct Plan {
     std::vector<PNode> nodes;
-    I3Job *d_init3 = nullptr; bool init3 = false;
     DotJob *d_dot = nullptr, *d_dotfin = nullptr; LightJob *d_light = nullptr; ChunkJob *d_chunks = nullptr; CombineJob *d_combine = nullptr;
     SfGenJob *d_sfgen = nullptr; SfArgs *d_sf = nullptr; SegArgs *d_seg = nullptr; EmitArgs *d_emit = nullptr; BlkMap *d_map = nullptr;
     hipStream_t streams[4] = {nullptr, nullptr, nullptr, nullptr};   // [0] = ctx->stream; [1..3] owned: fold (low priority), seg, emit (high)
     hipEvent_t ev_root = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
-    u64 rounds = 0; int n_steps = 0, sf_rounds = 3;
+    u64 rounds = 0; int n_steps = 0;
     FixJob *d_fix = nullptr; u32 n_fix = 0;          // k_fixup jobs (when round 1 of the sumchecks leaves its b to the fix-up pass)
     std::vector<void *> allocs;                      // device arrays owned by the plan (freed with it)
 };
@@ -165,7 +162,7 @@ struct vp_ctx {
     // polynomial commitment
     F *pc_rt = nullptr, *pc_coef = nullptr, *pc_cw = nullptr; Dig *pc_tree = nullptr; int pc_lm = -1; double commit_ms = 0;
     std::map<std::pair<const void *, int>, F *> pc_rtc;   // compact root tables of smaller orders, keyed by (source table, log2 order)
-    F *pc_q0 = nullptr, *pc_eq = nullptr; int *pc_flag = nullptr; bool pc_q_tensor = false;   // tensor public vector: its one encoded slice (commit_public)
+    F *pc_q0 = nullptr, *pc_eq = nullptr, *pc_cbuf = nullptr; int pc_cbuf_lm = -1; int *pc_flag = nullptr; bool pc_q_tensor = false;   // tensor public vector: its one encoded slice (commit_public)
     F *pc_pub = nullptr, *pc_qcw = nullptr, *pc_hcw = nullptr, *pc_tmp = nullptr, *pc_small = nullptr; Dig *pc_tree_h = nullptr; bool pc_private_done = false;
     F *pc_scr = nullptr; size_t pc_scr_cap = 0;
     F *pc_fri_all = nullptr; std::vector<size_t> fri_cw_off, fri_tree_off; F *pc_open_buf = nullptr;
@@ -186,7 +183,6 @@ struct vp_ctx {
     DotJob rec_dot{};                 // record mode: the V_u inner product the next phase-1 init job carries
     SfGenJob rec_gen{};               // record mode: init to be fused into the first fold launch of the next sumcheck (mode != 0)
     int fuse_init = 1;                // VP_FUSE_INIT=0: separate init launches for every sumcheck
-    int use_init3 = 0;                // VP_INIT3=1: entry-parallel init kernels (k_init3_multi, vp_kernels_init3.h) instead of the row-per-lane ones.
                                       // Measured (profiles/r02_b_*): stand-alone equal (x64 278 vs 277 us, x1024 1.54 vs 1.56 ms: the init launches are
                                       // bound by writing the mult/add tables and the operand gathers, not by lane divergence), fused into the fold
                                       // launch slower (x1024 4.7 vs 3.5 ms: two more barriers per chunk at 3 workgroups per CU) -> off by default
@@ -718,8 +714,8 @@ void vp_options_default(vp_options *o) {
     if (!o) return;
     memset(o, 0, sizeof *o);
     o->struct_size = (uint32_t) sizeof *o;
-    o->gkr_path = VP_PATH_PLAN; o->use_graph = 1; o->serial = 0; o->fuse_init = 1; o->fuse_min_log = 0; o->fuse_dot = 0; o->init3 = 0;
-    o->drop_y = 1; o->drop_y_round1 = 0; o->real_values = 1; o->seg_tiny = 1; o->sf_rounds = 3; o->sf_big_log = 14; o->sf3b = 1;
+    o->gkr_path = VP_PATH_PLAN; o->use_graph = 1; o->serial = 0; o->fuse_init = 1; o->fuse_min_log = 0; o->fuse_dot = 0;
+    o->drop_y = 1; o->drop_y_round1 = 0; o->real_values = 1; o->seg_tiny = 1; o->sf_big_log = 14; o->sf3b = 1;
     o->sf3b_grid = 512; o->sf_min_waves = 1; o->dot_blocks = 1024; o->plan_align = 0; o->xcd_map = 0; o->round_fused_max = 512;
     o->persistent_rounds = 1; o->persistent_multi = 0; o->persistent_multi_shift = 13; o->poll = 1; o->debug = 0; o->prefetch_round1 = 1; o->split_cost_percent = 50; o->kernel_copies = 1; o->fold_branches = 1; o->ntt_scatter = 1; o->fuse_combine = 2; o->plan_autotune = 1;
     o->pc_tensor_pub = 1;
@@ -741,10 +737,10 @@ static void resolve_options(vp_options *o, const vp_options *user, uint32_t *pin
         o->gkr_path = !strcmp(p, "lanes") ? VP_PATH_LANES : !strcmp(p, "sumfold") ? VP_PATH_SUMFOLD : !strcmp(p, "simple") ? VP_PATH_SIMPLE : VP_PATH_PLAN;
     if (const char *p = getenv("VP_PLAN_ALIGN")) o->plan_align = !strcmp(p, "left") ? 1 : !strcmp(p, "right") ? 2 : 0;
     flag("VP_GKR_GRAPH", o->use_graph); flag("VP_GKR_SERIAL", o->serial); flag("VP_FUSE_INIT", o->fuse_init); flag("VP_FUSE_DOT", o->fuse_dot);
-    flag("VP_INIT3", o->init3); flag("VP_DROP_Y", o->drop_y); flag("VP_DROP_Y1", o->drop_y_round1); flag("VP_REAL_V", o->real_values);
+    flag("VP_DROP_Y", o->drop_y); flag("VP_DROP_Y1", o->drop_y_round1); flag("VP_REAL_V", o->real_values);
     flag("VP_SEG_TINY", o->seg_tiny); flag("VP_XCD_MAP", o->xcd_map); flag("VP_PERSIST", o->persistent_rounds);
     flag("VP_PERSIST_MULTI", o->persistent_multi); flag("VP_POLL", o->poll); flag("VP_PREFETCH_R1", o->prefetch_round1);
-    num("VP_FUSE_MIN_LOG", o->fuse_min_log); num("VP_SF_ROUNDS", o->sf_rounds); num("VP_SF_BIG_LOG", o->sf_big_log); num("VP_SF3B", o->sf3b);
+    num("VP_FUSE_MIN_LOG", o->fuse_min_log); num("VP_SF_BIG_LOG", o->sf_big_log); num("VP_SF3B", o->sf3b);
     num("VP_SF3B_GRID", o->sf3b_grid); num("VP_SF_MINW", o->sf_min_waves); num("VP_DOT_BLOCKS", o->dot_blocks);
     num("VP_ROUND_FUSED_MAX", o->round_fused_max); num("VP_MULTI_SHIFT", o->persistent_multi_shift);
     num("VP_SPLIT_COST_PERCENT", o->split_cost_percent);
@@ -760,7 +756,6 @@ static void resolve_options(vp_options *o, const vp_options *user, uint32_t *pin
     flag("VP_PLAN_AUTOTUNE", o->plan_autotune);
     if (getenv("VP_DEBUG")) o->debug |= 1;
     if (getenv("VP_DEBUG_UPLOAD")) o->debug |= 2;                       // bit 1: phase times of vp_circuit_upload
-    if (o->sf_rounds != 4) o->sf_rounds = 3;
     o->dot_blocks = std::max(1, o->dot_blocks); o->sf3b_grid = std::max(1, o->sf3b_grid);
     vp_options d; vp_options_default(&d);
     *pinned = (o->fuse_combine != d.fuse_combine ? 1u : 0u) | (o->fold_branches != d.fold_branches ? 2u : 0u) | (o->plan_align != d.plan_align ? 4u : 0u) |
@@ -885,7 +880,7 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
     ctx->pred_r = ctx->pred_pool = ctx->pred_part = ctx->pred_out = nullptr; ctx->pred_jobs = nullptr; ctx->pred_dot = nullptr; ctx->pred_map = nullptr;
     ctx->pc_rt = ctx->pc_coef = ctx->pc_cw = nullptr; ctx->pc_tree = nullptr; ctx->pc_lm = -1; ctx->pc_rtc.clear();
     ctx->pc_pub = ctx->pc_qcw = ctx->pc_hcw = ctx->pc_tmp = ctx->pc_small = nullptr; ctx->pc_tree_h = nullptr; ctx->pc_private_done = false;
-    ctx->pc_q0 = nullptr; ctx->pc_eq = nullptr; ctx->pc_flag = nullptr; ctx->pc_q_tensor = false;
+    ctx->pc_q0 = nullptr; ctx->pc_eq = nullptr; ctx->pc_cbuf = nullptr; ctx->pc_cbuf_lm = -1; ctx->pc_flag = nullptr; ctx->pc_q_tensor = false;
     ctx->pc_scr = nullptr; ctx->pc_scr_cap = 0; ctx->pc_fri_all = nullptr; ctx->pc_open_buf = nullptr; ctx->fri_cw_off.clear(); ctx->fri_tree_off.clear();
     ctx->pc_fri[0] = ctx->pc_fri[1] = nullptr; ctx->pc_fri_tree = nullptr; ctx->pc_fri_roots = nullptr; ctx->fri_step = -1; ctx->pc_public_done = false;
     int max_bl = 0;
@@ -896,7 +891,6 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
     }
     ctx->max_bl = max_bl;
     // ---- per-layer uploads: the raw gate arrays go to HBM as they are, every per-gate structure is built there (vpgpu_upload.inc) ----
-    ctx->use_init3 = ctx->opt.init3;
     UpScratch S;
     const bool up_dbg = (ctx->opt.debug & 2) != 0;
     const auto up_t0 = std::chrono::steady_clock::now();
@@ -1571,7 +1565,7 @@ int vp_get_launch_stats(vp_ctx *ctx, vp_launch_stat *out, int capacity, int *n) 
 const char *vp_kernel_name(int kind) {
     static const char *names[VP_K_COUNT] = {"k_beta_half_direct", "k_light_multi", "k_chunks_multi", "k_combine_multi", "k_dot_multi", "k_dotfin_multi",
         "k_sumfold3b_gen_multi", "k_sumfold3b_multi", "k_seg_multi", "k_emit_multi", "k_fixup", "k_ntt_split", "k_ntt_lds", "k_ntt_unsplit",
-        "k_leaf_hash", "k_merkle", "k_pc_pointwise", "k_fri_fold", "k_round", "k_init3_multi", "k_ntt8_cols", "k_ntt8_rows"};
+        "k_leaf_hash", "k_merkle", "k_pc_pointwise", "k_fri_fold", "k_round", "k_ntt8_cols", "k_ntt8_rows"};
     return (kind >= 0 && kind < VP_K_COUNT) ? names[kind] : "?";
 }
 
