@@ -1229,6 +1229,8 @@ def main():
                     detail["multi_gpu_sublegs_error"] = "timed out after %.0f s in %s" % (a.subleg_timeout, state["leg"])
                     out.emit(detail, world, a.detail_file)
                     sys.stdout.flush()
+                else:
+                    time.sleep(5.0)             # rank 0 prints first: a rank that leaves takes the launcher (and with it rank 0) down
                 os._exit(3)
 
             wd = Watchdog(a.subleg_timeout, on_timeout)
@@ -1238,7 +1240,16 @@ def main():
                 prep = sharded_prepare(vp, pws, golden, a, world, rank, local, a.blocks)
             except Exception as e:
                 failed = "%s: %s" % (type(e).__name__, e)
-            if not allreduce_min_flag(world, failed is None):
+            try:
+                all_ready = allreduce_min_flag(world, failed is None)
+            except Exception as e:              # a peer went away while this rank waited for it
+                sys.stderr.write("bench.py rank %d: flag exchange failed: %s: %s\n" % (rank, type(e).__name__, e))
+                if rank == 0:
+                    detail["multi_gpu_sublegs_error"] = "a peer rank went away before the first collective (%s)" % type(e).__name__
+                    out.emit(detail, world, a.detail_file)
+                    sys.stdout.flush()
+                os._exit(3)
+            if not all_ready:
                 sub = {"error": failed or "another rank failed before the first collective of this leg"}
             else:
                 try:
