@@ -138,6 +138,9 @@ typedef struct {
                                        k_ntt_lds of rounds 2-3 (kept as the cross-check)                                             [1] */
     int32_t fri_vo_fused;           /* VP_FRI_VO_FUSED: vp_fri_commit folds the first FRI level straight from the committed codewords l, q, h (k_fri_fold0_vo); the
                                        virtual oracle of poly_commit.h:294-318 is never written to HBM and read back.  0: separate k_pc_virtual_oracle pass [1] */
+    int32_t interactive_fast_init;  /* VP_FAST_INIT: vp_phase1_init / vp_phase2_init / vp_liu_init run the batched path's init kernels (closed-form eq half
+                                       tables of the one sumcheck, eq values as products of two half-table entries, V gather and assert scaling inside the
+                                       row kernel) instead of the per-sumcheck kernels of round 1 (expanded eq tables, separate gather / scatter launches)  [1] */
 } vp_options;
 void vp_options_default(vp_options *opt);
 

@@ -52,6 +52,7 @@ struct LayerDev {
     u32 *lrow = nullptr, *l_g = nullptr; uint8_t *l_q = nullptr; u32 l_n = 0;      // l_n: entries of the Liu gather lists
     Half hg{}, hu{};
     Half *liu_H = nullptr;
+    int job_hg = -1, job_hu = -1, job_liu0 = -1, job_liun = 0;      // this layer's entries of vp_ctx::all_jobs (eq half tables of its three sumchecks)
     // verifier-side predicates (vp_predicates): gates listed by bucket, pieces of <= 512
     u32 *p_idx = nullptr, *p_cbeg = nullptr, *p_cend = nullptr, *p_bptr = nullptr, *glv = nullptr; uint8_t *p_flag = nullptr;
     u32 p_chunks = 0, p_buckets = 0;
@@ -408,6 +409,12 @@ int do_liu_init(vp_ctx *ctx, int i) {
 
 // one sumcheck round; rp (device) or rv (by value) is the previous challenge
 int check_stream(vp_ctx *ctx);
+// the same three inits through the batched path's kernels (vpgpu_batched.inc): closed-form eq half tables of THIS sumcheck only, eq values as
+// products of two half-table entries (no expanded table), the V gather of phase 2 and the assert scaling inside the row kernel
+int do_phase1_init_fast(vp_ctx *ctx, int i);
+int do_phase2_init_fast(vp_ctx *ctx, int i);
+int do_liu_init_fast(vp_ctx *ctx, int i);
+
 // Per-round path: wait for the ticket the closing kernel publishes in pinned memory (a few microseconds sooner than the
 // runtime's stream wait, once per round x ~700 rounds per proof); falls back to the stream wait after 2 s or when VP_POLL=0.
 int wait_ticket(vp_ctx *ctx) {
@@ -723,6 +730,7 @@ void vp_options_default(vp_options *o) {
     o->graph_explicit = 0;
     o->ntt_r8 = 1;
     o->fri_vo_fused = 1;
+    o->interactive_fast_init = 1;
 }
 // defaults <- the caller's struct (as many bytes as its header knew) <- VP_* environment variables (test-only override, read here and nowhere else)
 static void resolve_options(vp_options *o, const vp_options *user, uint32_t *pinned) {
@@ -749,6 +757,7 @@ static void resolve_options(vp_options *o, const vp_options *user, uint32_t *pin
     flag("VP_NTT_SCATTER", o->ntt_scatter);
     flag("VP_NTT_R8", o->ntt_r8);
     flag("VP_FRI_VO_FUSED", o->fri_vo_fused);
+    flag("VP_FAST_INIT", o->interactive_fast_init);
     flag("VP_PC_TENSOR", o->pc_tensor_pub);
     num("VP_PERSIST_TIMEOUT_MS", o->persistent_timeout_ms);
     num("VP_GRAPH_EXPLICIT", o->graph_explicit);
@@ -999,6 +1008,7 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
         for (int i = 1; i < n_layers; ++i) {
             LayerDev &D = ctx->L[i];
             D.hg = half_of(hg_id[i]); D.hu = half_of(hu_id[i]);
+            D.job_hg = hg_id[i]; D.job_hu = hu_id[i]; D.job_liu0 = liu_id[i].front(); D.job_liun = (int) liu_id[i].size();
             std::vector<Half> hs;
             for (int q : liu_id[i]) hs.push_back(half_of(q));
             VPCHK(dupload(ctx, &D.liu_H, hs));
@@ -1257,7 +1267,8 @@ int vp_phase1_init(vp_ctx *ctx, int layer, const vp_F *r_liu, const vp_F *assert
     const u64 off = layer == ctx->n_layers - 1 ? 0 : ctx->rliu_off[layer + 1];
     VPCHK(stage(ctx, off, r_liu, ctx->L[layer].bl));
     VPCHK(stage(ctx, ctx->as_off[layer], assert_random, 1));
-    VPCHK(do_phase1_init(ctx, layer, ctx->d_tape + off, ctx->d_tape + ctx->as_off[layer]));
+    if (ctx->opt.interactive_fast_init) VPCHK(do_phase1_init_fast(ctx, layer));
+    else VPCHK(do_phase1_init(ctx, layer, ctx->d_tape + off, ctx->d_tape + ctx->as_off[layer]));
     ctx->rlog_round = 0;
     return round1_prefetch(ctx);
 }
@@ -1268,7 +1279,8 @@ int vp_phase2_init(vp_ctx *ctx, int layer, const vp_F *r_u) {
     if (ctx->sc.layer != layer || ctx->L[layer].max_dad_bl == -1) { ctx->err = "phase2 out of order"; return VP_EINVAL; }
     VP_ENTER(ctx);
     VPCHK(stage(ctx, ctx->ru_off[layer], r_u, ctx->L[layer - 1].bl));
-    VPCHK(do_phase2_init(ctx, layer, ctx->d_tape + ctx->ru_off[layer]));
+    if (ctx->opt.interactive_fast_init) VPCHK(do_phase2_init_fast(ctx, layer));
+    else VPCHK(do_phase2_init(ctx, layer, ctx->d_tape + ctx->ru_off[layer]));
     ctx->rlog_round = 0;
     return round1_prefetch(ctx);
 }
@@ -1285,7 +1297,8 @@ int vp_liu_init(vp_ctx *ctx, int layer, const vp_F *r_u, const vp_F *const *r_v,
             if (!r_v || !r_v[k]) return VP_EINVAL;
             VPCHK(stage(ctx, ctx->rv_off[k], r_v[k], ctx->L[k].dad_bl[layer - 1]));
         }
-    VPCHK(do_liu_init(ctx, layer));
+    if (ctx->opt.interactive_fast_init) VPCHK(do_liu_init_fast(ctx, layer));
+    else VPCHK(do_liu_init(ctx, layer));
     ctx->rlog_round = 0;
     return round1_prefetch(ctx);
 }
