@@ -153,6 +153,12 @@ int vp_get_options(const vp_ctx *, vp_options *out);                   /* the co
 void vp_destroy(vp_ctx *);
 const char *vp_last_error(const vp_ctx *);     /* static/ctx-owned string, never NULL */
 const char *vp_version(void);
+/* 1 when the library was built with -DVP_CHECKED: device-side index checks in the gather / scatter kernels (csrc/vp_check.h: operand and slot
+ * gathers against the layer sizes, row pointers of the target-sorted lists, stores of folded entries against the table capacity, LDS slots of a
+ * transform tile, codeword positions of a leaf).  A violated check never traps: the access is skipped, the FIRST violation is recorded on the device,
+ * and the entry point during which it happened returns VP_EHIP with "device check failed: site N (...)".  A checked process holds one circuit at a
+ * time.  The product library (0) compiles every check away.                                                                                    */
+int vp_checked_build(void);
 
 /* prover::prover(const layeredCircuit&) (src/prover.cpp:14) — the circuit is copied to HBM together
  * with the per-layer target-sorted gate indices the init kernels use.  May be called again to replace

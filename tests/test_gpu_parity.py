@@ -1695,3 +1695,55 @@ def test_plan_tuner_choice_is_shared_between_sessions_of_a_circuit(vp, pws_path)
     tr, _ = s.prove_gkr()
     assert tr == trs[0] and s.options_in_effect().sf3b_grid == 448
     s.close(); c.close()
+
+
+_CHECKED_WORKER = r"""
+import os, sys
+sys.path.insert(0, %r)
+import vp_loader
+vp = vp_loader.load()
+vp.lib_host()
+assert vp.lib_gpu().vp_checked_build() == 1, "VP_LIBGPU did not select the checked library"
+pws, gold_path, inject = sys.argv[1], sys.argv[2], sys.argv[3] == "1"
+c = vp.Circuit.from_pws(pws, 1, seed=1)
+s = vp.Session(c)
+if inject:
+    s.draw_tape()
+    try:
+        s.prove_gkr()
+    except RuntimeError as e:
+        print("REFUSED:", e, flush=True)
+        sys.exit(0)
+    print("NOT REFUSED", flush=True)
+    sys.exit(1)
+gold = open(gold_path, "rb").read()
+tr, ok = s.prove_full(batched=True)
+assert ok and tr == gold, "checked build: batched protocol transcript differs"
+tr_i, _, ok_i = s.prove_interactive()
+assert ok_i and tr_i == gold[32:32 + len(tr_i)], "checked build: interactive transcript differs"
+s.draw_protocol_tape()
+tr_p, roots, fin, sec = s.prove_protocol()
+assert tr_p == gold
+print("CHECKED OK", flush=True)
+"""
+
+
+@pytest.mark.parametrize("inject", [False, True])
+def test_checked_build_passes_the_protocol_and_reports_a_violated_index_check(vp, golden, pws_path, inject):
+    """The -DVP_CHECKED flavour of libvpgpu.so (csrc/vp_check.h; built by vp.build() under tools/_build/checked, loaded through VP_LIBGPU in a
+    fresh process): device-side index checks in the gather / scatter kernels.  With them compiled in, the whole protocol at x1 — batched proof with
+    the commitment, interactive proof, the one-pass prover — still reproduces the real reference's transcript and no check fires; with layer 0's
+    bound shrunk to one wire (VP_CHECKED_INJECT) the first proof is refused with VP_EHIP and the site of the violated check, without a trap."""
+    import subprocess, sys
+    assert os.path.exists(vp.LIB_GPU_CHECKED), "vp.build() did not produce the checked library"
+    env = dict(os.environ, VP_LIBGPU=vp.LIB_GPU_CHECKED)
+    if inject:
+        env["VP_CHECKED_INJECT"] = "1"
+    gold = os.path.join(GOLDEN_DIR, golden["sha256_x1"]["transcript"])
+    r = subprocess.run([sys.executable, "-c", _CHECKED_WORKER % ROOT, pws_path, gold, "1" if inject else "0"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout[-800:], r.stderr[-2000:])
+    if inject:
+        assert "REFUSED" in r.stdout and "device check failed: site" in r.stdout
+    else:
+        assert "CHECKED OK" in r.stdout

@@ -21,11 +21,12 @@ HOST = os.path.join(PKG_DIR, "host")
 # VP_LIBGPU: development override (A/B builds of the kernels under tools/_build/<variant>/libvpgpu.so are measured without touching the
 # product library; build() never writes to an overridden path)
 LIB_GPU = os.environ.get("VP_LIBGPU") or os.path.join(CSRC, "libvpgpu.so")
+LIB_GPU_CHECKED = os.path.join(ROOT, "tools", "_build", "checked", "libvpgpu.so")      # -DVP_CHECKED flavour (csrc/vp_check.h), loaded through VP_LIBGPU by its test
 LIB_HOST = os.path.join(HOST, "libvphost.so")
 CLI = os.path.join(HOST, "virgo_plus_run")
 
 GPU_SRC = [os.path.join(CSRC, f) for f in ("vpgpu.hip", "vpgpu_batched.inc", "vpgpu_pc.inc", "vpgpu_pc_shard.inc", "vpgpu_fftgkr.inc", "vpgpu_upload.inc", "vp_kernels_fftgkr.h", "vp_kernels.h", "vp_kernels_round.h", "vp_kernels_persist.h", "vp_kernels_batch.h",
-                                              "vp_kernels_plan.h", "vp_kernels_pc.h", "vp_kernels_ntt8.h", "vp_field.h")] + [
+                                              "vp_kernels_plan.h", "vp_kernels_pc.h", "vp_kernels_ntt8.h", "vp_check.h", "vp_field.h")] + [
     os.path.join(ROOT, "include", "vpgpu.h")]
 HOST_SRC = [os.path.join(HOST, f) for f in ("circuit.cpp", "prover.cpp", "verifier.cpp", "vphost.cpp")]
 HOST_HDR = [os.path.join(HOST, f) for f in ("circuit.hpp", "prover.hpp", "verifier.hpp", "vphost.h", "field.hpp",
@@ -63,6 +64,10 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc not found and no prebuilt libvpgpu.so")
         run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
              "-o", LIB_GPU, os.path.join(CSRC, "vpgpu.hip")])
+    if (force or _stale(LIB_GPU_CHECKED, GPU_SRC)) and _hipcc() is not None:
+        os.makedirs(os.path.dirname(LIB_GPU_CHECKED), exist_ok=True)
+        run([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-DVP_CHECKED",
+             "-o", LIB_GPU_CHECKED, os.path.join(CSRC, "vpgpu.hip")])
     if force or _stale(LIB_HOST, HOST_SRC + HOST_HDR + [LIB_GPU]):
         run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-pthread", "-o", LIB_HOST] + HOST_SRC +
             ["-L" + CSRC, "-lvpgpu", "-Wl,-rpath,$ORIGIN/../csrc", "-Wl,-rpath,/opt/rocm/lib"])

@@ -15,6 +15,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "vp_field.h"
+#include "vp_check.h"
 #include "vp_kernels_round.h"
 #include "vp_kernels_persist.h"
 #include "vp_kernels_batch.h"

@@ -47,7 +47,7 @@ __device__ __forceinline__ void contrib2(const InitArgs2 &a, u32 e, F &m, F &ad,
     if (PHASE == 1) {
         const int l = tl & 0xff;
         F ty_ = f_zero();
-        if (l != 0xff) ty_ = mul_val(a, a.vals[l][x], t);
+        if (l != 0xff && VP_CHK_LAYER(l, x)) ty_ = mul_val(a, a.vals[l][x], t);
         switch (ty) {
             case T_ADD: ad = f_add(ad, ty_); m = f_add(m, t); break;
             case T_SUB: ad = f_sub(ad, ty_); m = f_add(m, t); break;
@@ -91,7 +91,7 @@ __device__ __forceinline__ P1Vals p1_gather(const InitArgs2 &a, const P1Entry &c
     P1Vals v;
     v.bf = a.hg.bf[c.g & ((1u << a.hg.h1) - 1)]; v.bs = a.hg.bs[c.g >> a.hg.h1];
     const int l = c.tl & 0xff;
-    v.y = l != 0xff ? a.vals[l][c.x] : f_zero();
+    v.y = (l != 0xff && VP_CHK_LAYER(l, c.x)) ? a.vals[l][c.x] : f_zero();
     return v;
 }
 __device__ __forceinline__ void p1_apply(const InitArgs2 &a, const P1Entry &c, const P1Vals &v, F &m, F &ad) {       // == contrib2<1>
@@ -122,9 +122,10 @@ __device__ __forceinline__ void init2_light_body(const InitArgs2 &a, u32 bid) {
     if (row >= a.n_rows) return;
     if (PHASE == 2) {
         const int l = a.s_layer[row];
-        if (l != 0xfe) a.V[row] = (l == 0xff) ? f_zero() : a.vals[l][a.s_idx[row]];   // 0xfe: padding slot, never read
+        if (l != 0xfe) a.V[row] = (l == 0xff || !VP_CHK((unsigned) l < g_vp_chk_layers() && a.s_idx[row] < g_vp_chk_lsize(l), 2, l, a.s_idx[row], row)) ? f_zero() : a.vals[l][a.s_idx[row]];   // 0xfe: padding slot, never read
     }
     u32 b = a.rowptr[row], e = a.rowptr[row + 1];
+    if (!VP_CHK(b <= e, 3, row, b, e)) return;
     if (e - b > VP_LIGHT_MAX) return;
     F m = f_zero(), ad = f_zero();
     const F vu = PHASE == 2 ? *a.Vu : f_zero();
@@ -182,7 +183,8 @@ __device__ __forceinline__ void liu_gather_body(const u32 *__restrict__ rowptr, 
     u32 u = bid * blockDim.x + threadIdx.x;
     if (u >= size) return;
     F m = half_at(H[0], u0 + u);
-    for (u32 k = rowptr[u]; k < rowptr[u + 1]; ++k) m = f_add(m, half_at(H[e_q[k]], e_g[k]));
+    if (!VP_CHK(rowptr[u] <= rowptr[u + 1], 4, u, rowptr[u], rowptr[u + 1])) return;
+    for (u32 k = rowptr[u]; k < rowptr[u + 1]; ++k) if (VP_CHK(e_q[k] < g_vp_chk_liu(), 4, u, k, e_q[k])) m = f_add(m, half_at(H[e_q[k]], e_g[k]));
     M[u] = m;
 }
 __global__ void __launch_bounds__(VP_BLOCK)
@@ -643,9 +645,11 @@ __device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb,
             if (keep_rest) { lz_fold(y); sm.acc3[1][lane] = y; }
             const u32 oi = cl * 64 + lane;
             if (oi < ((td.valid + 7) >> 3)) {
-                a.outV[td.off + oi] = vo;
-                a.outM[td.off + oi] = mo;
-                if (HAS_A) a.outA[td.off + oi] = ao;
+                if (VP_CHK((unsigned long long) td.off + oi < g_vp_chk_cap(), 5, td.off, oi, 0)) {     // (a failed check skips the store, never the barriers below)
+                    a.outV[td.off + oi] = vo;
+                    a.outM[td.off + oi] = mo;
+                    if (HAS_A) a.outA[td.off + oi] = ao;
+                }
             }
         }
 #pragma unroll

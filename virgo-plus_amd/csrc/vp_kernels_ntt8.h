@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(NTT8_THREADS) __attribute__((amdgpu_waves_per_
         }
         lz_dft8<INV>(u);
 #pragma unroll
-        for (u32 m = 0; m < 8; ++m) L[((q * 8 + m) << lc) + c] = u[m];
+        for (u32 m = 0; m < 8; ++m) if (VP_CHK((((q * 8 + m) << lc) + c) < NTT8_TILE, 6, q, m, c)) L[((q * 8 + m) << lc) + c] = u[m];
     }
     __syncthreads();
     u32 s = 8;

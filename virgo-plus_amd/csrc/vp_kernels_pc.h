@@ -291,7 +291,8 @@ k_leaf_hash(const F *__restrict__ cw, u32 N, int n_slices, Dig *__restrict__ lea
     Dig h; h.w[0] = h.w[1] = h.w[2] = h.w[3] = 0;
     for (int s = 0; s < n_slices; ++s) {
         const F *row = cw + ((size_t) s * 32 + b) * N;
-        const F x = row[a], y = row[a + halfN];
+        F x = f_zero(), y = f_zero();
+        if (VP_CHK(a + halfN < N && b < 32, 7, a, b, N)) { x = row[a]; y = row[a + halfN]; }
         h = hhash64(x.re, x.im, y.re, y.im, h);
     }
     h = hhash64(0, 0, 0, 0, h);                       // mask slice (zero polynomial)

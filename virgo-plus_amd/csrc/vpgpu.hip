@@ -409,6 +409,7 @@ int do_liu_init(vp_ctx *ctx, int i) {
 
 // one sumcheck round; rp (device) or rv (by value) is the previous challenge
 int check_stream(vp_ctx *ctx);
+int vp_check_collect(vp_ctx *ctx);
 // the same three inits through the batched path's kernels (vpgpu_batched.inc): closed-form eq half tables of THIS sumcheck only, eq values as
 // products of two half-table entries (no expanded table), the V gather of phase 2 and the assert scaling inside the row kernel
 int do_phase1_init_fast(vp_ctx *ctx, int i);
@@ -497,6 +498,23 @@ int do_finalize(vp_ctx *ctx, const F *rp, const F &rv, F *claims_dev, F *claims_
     return VP_OK;
 }
 
+// checked build: the first violated device check of the calls since the last collection -> an error of THIS call
+int vp_check_collect(vp_ctx *ctx) {
+#ifdef VP_CHECKED
+    unsigned int e[4] = {0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(e, HIP_SYMBOL(g_vp_chk_err), sizeof e) != hipSuccess) return VP_OK;
+    if (e[0]) {
+        const unsigned int z[4] = {0, 0, 0, 0};
+        (void) hipMemcpyToSymbol(HIP_SYMBOL(g_vp_chk_err), z, sizeof z);
+        char buf[160];
+        snprintf(buf, sizeof buf, "device check failed: site %u (%u, %u, %u) — see vp_check.h", e[0], e[1], e[2], e[3]);
+        ctx->err = buf;
+        return VP_EHIP;
+    }
+#endif
+    (void) ctx;
+    return VP_OK;
+}
 int check_stream(vp_ctx *ctx) {
     const hipError_t e1 = hipStreamSynchronize(ctx->stream), e2 = e1 == hipSuccess ? hipGetLastError() : e1;
     if (e2 != hipSuccess) {
@@ -506,7 +524,7 @@ int check_stream(vp_ctx *ctx) {
         ctx->err = std::string("stream: ") + hipGetErrorString(e2);
         return VP_EHIP;
     }
-    return VP_OK;
+    return vp_check_collect(ctx);
 }
 
 // ---- persistent round kernel (vp_kernels_persist.h): host side of the mailbox ---------------------------------------
@@ -714,6 +732,13 @@ const F *rliu_ptr(vp_ctx *ctx, int i) {
 
 extern "C" {
 
+int vp_checked_build(void) {
+#ifdef VP_CHECKED
+    return 1;
+#else
+    return 0;
+#endif
+}
 const char *vp_version(void) { return "vpgpu 0.1 (gfx950)"; }
 const char *vp_last_error(const vp_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
@@ -1064,6 +1089,25 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
         ctx->fuse_init = ctx->opt.fuse_init;
     }
     if (up_dbg) fprintf(stderr, "  total %.3f s\n", up_since());
+#ifdef VP_CHECKED
+    {   // bounds for the device-side checks (vp_check.h): this circuit's layer sizes, the largest table any fold launch may write, the most eq
+        // tables a Liu gather selects from.  VP_CHECKED_INJECT=1 (test hook) shrinks layer 0's bound to ONE wire, so that a correct gather trips site 1 / 2.
+        VpChkDesc d{};
+        d.n_layers = (unsigned) n_layers;
+        unsigned long long cap = 1;
+        for (int i = 0; i < n_layers; ++i) {
+            d.lsize[i] = (unsigned) ctx->L[i].size;
+            cap = std::max<unsigned long long>(cap, 1ull << ctx->L[i].bl);
+            cap = std::max<unsigned long long>(cap, ctx->L[i].p2_total);
+            d.n_liu_tables_max = std::max<unsigned>(d.n_liu_tables_max, (unsigned) ctx->L[i].job_liun);
+        }
+        d.table_cap = cap;
+        if (getenv("VP_CHECKED_INJECT")) d.lsize[0] = 1;
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_vp_chk), &d, sizeof d));
+        const unsigned int z[4] = {0, 0, 0, 0};
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_vp_chk_err), z, sizeof z));
+    }
+#endif
     // event pool for the profiled launches
     if (ctx->ev_pool.empty()) {
         ctx->ev_pool.resize(1024);
