@@ -1150,7 +1150,7 @@ def main():
     ap.add_argument("--per-launch", action="store_true", help="detail file: per-launch table of every call and every interactive round")
     ap.add_argument("--no-two-in-flight", action="store_true", help="GKR-only legs: skip the `two_in_flight` sub-leg (two sessions of the circuit, two host threads)")
     ap.add_argument("--no-sharded-leg", action="store_true", help="N > 1: skip the `sharded` sub-leg (one proof + its commitment over all ranks, RCCL)")
-    ap.add_argument("--subleg-timeout", type=float, default=900.0, help="N > 1: seconds the multi-rank sub-leg may take before the line is printed without it and the ranks exit 3")
+    ap.add_argument("--subleg-timeout", type=float, default=300.0, help="N > 1: seconds the multi-rank sub-leg may take before the line is printed without it and the ranks exit 3")
     ap.add_argument("--detail-file", default=None, help="where everything the line leaves out goes (default gpurun_out/bench_detail_n<N>.json)")
     a = ap.parse_args()
 

@@ -72,11 +72,11 @@ typedef struct {
  * copies the struct into the context.  `struct_size` = sizeof(vp_options) of the caller's header: a library built from a newer header
  * keeps its defaults for the fields the caller does not know.  The VP_* environment variables named below are a TEST-ONLY override,
  * read once per vp_create / vp_create_with_options AFTER the struct (tests/ flip them per session); production callers use the struct. */
-enum { VP_PATH_PLAN = 0, VP_PATH_LANES = 1, VP_PATH_SUMFOLD = 2, VP_PATH_SIMPLE = 3 };
+enum { VP_PATH_PLAN = 0, VP_PATH_LANES = 1, VP_PATH_SIMPLE = 3 };
 typedef struct {
     uint32_t struct_size;
-    int32_t gkr_path;               /* VP_GKR_PATH=plan|lanes|sumfold|simple: batched driver (launch plan + hipGraph; one stream per chain;
-                                       shuffle-fold + single-CU tail; one launch per round)                                   [plan] */
+    int32_t gkr_path;               /* VP_GKR_PATH=plan|lanes|simple: batched driver (launch plan + hipGraph; one stream per chain;
+                                       one launch per round; lanes / simple are the tests' cross-checks)                     [plan] */
     int32_t use_graph;              /* VP_GKR_GRAPH: replay the plan as a hipGraph                                               [1] */
     int32_t serial;                 /* VP_GKR_SERIAL: all chains on one stream (profiling)                                       [0] */
     int32_t fuse_init;              /* VP_FUSE_INIT: phase-1 / Liu init inside the first fold launch of large tables             [1] */
@@ -87,16 +87,12 @@ typedef struct {
     int32_t real_values;            /* VP_REAL_V: real x complex products when every circuit value is real                       [1] */
     int32_t seg_tiny;               /* VP_SEG_TINY: tables <= 2^e entries are folded by the first k_seg launch                   [1] */
     int32_t sf_big_log;             /* VP_SF_BIG_LOG: fold kernel from 2^this entries on (plan path)                             [14] */
-    int32_t sf3b;                   /* VP_SF3B: block-cooperative fold kernel on the non-plan paths                              [1] */
     int32_t sf3b_grid;              /* VP_SF3B_GRID: its workgroups per launch                                                   [512] */
-    int32_t sf_min_waves;           /* VP_SF_MINW: launch-bounds variant of k_sumfold<R>                                         [1] */
     int32_t dot_blocks;             /* VP_DOT_BLOCKS: workgroups of a stand-alone inner product                                  [1024] */
     int32_t plan_align;             /* VP_PLAN_ALIGN=left|right: 0 closing launches aligned at the end, 1 all left, 2 all right  [0] */
     int32_t xcd_map;                /* VP_XCD_MAP: XCD-aware block map of the plan nodes (measured: no gain)                     [0] */
     int32_t round_fused_max;        /* VP_ROUND_FUSED_MAX: interactive rounds with at most this many pairs take one launch       [512] */
     int32_t persistent_rounds;      /* VP_PERSIST: interactive rounds that fit one CU run in the resident mailbox kernel         [1] */
-    int32_t persistent_multi;       /* VP_PERSIST_MULTI: distributed rounds of the resident kernel                               [0] */
-    int32_t persistent_multi_shift; /* VP_MULTI_SHIFT: log2 entries per workgroup there                                          [13] */
     int32_t poll;                   /* VP_POLL: spin on the pinned reply instead of hipStreamSynchronize (interactive path)      [1] */
     int32_t debug;                  /* bit 0 (VP_DEBUG): diagnostics on stderr; bit 1 (VP_DEBUG_UPLOAD): phase times of vp_circuit_upload [0] */
     int32_t prefetch_round1;        /* VP_PREFETCH_R1: an init call queues round 1 of its sumcheck (it takes no challenge) behind its own kernels

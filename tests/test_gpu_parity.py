@@ -74,7 +74,7 @@ def _both_modes(vp, c, gold):
     # the alternative batched drivers (per-round launches; shuffle-fold + single-CU tail; one stream per sumcheck chain
     # instead of the batched launch plan) must agree
     import os
-    for path in ("simple", "sumfold", "lanes"):
+    for path in ("simple", "lanes"):
         os.environ["VP_GKR_PATH"] = path
         try:
             s2 = vp.Session(c)
@@ -1069,16 +1069,16 @@ def test_index_split_refuses_more_than_eight_slices(vp):
     s.close(); c.close()
 
 
-@pytest.mark.parametrize("mode", ["launch_per_round", "resident", "resident_distributed"])
+@pytest.mark.parametrize("mode", ["launch_per_round", "resident", "round1_kernels"])
 def test_interactive_path_variants(vp, golden, gold_gkr, pws_path, monkeypatch, mode):
-    """The drop-in entry points (vp_round per verifier message) in their three forms — one launch per round (VP_PERSIST=0), the
-    resident mailbox kernel for the rounds that fit one CU (default), and the same with the distributed rounds of the large
-    single-table phases (VP_PERSIST_MULTI=1): the real reference's transcript in every case, on SHA-256 x16 (tables up to 2^20:
-    distributed rounds with 128 workgroups, the hand-over to the solo regime, multi-table phase 2) and on a ragged small circuit."""
+    """The drop-in entry points (vp_round per verifier message) in their forms — one launch per round (VP_PERSIST=0), the resident mailbox
+    kernel for the rounds that fit one CU (default), and the init calls through the per-sumcheck kernels of round 1 instead of the batched
+    path's (VP_FAST_INIT=0): the real reference's transcript in every case, on SHA-256 x16 (tables up to 2^20, multi-table phase 2) and on a
+    ragged small circuit."""
     if mode == "launch_per_round":
         monkeypatch.setenv("VP_PERSIST", "0")
-    elif mode == "resident_distributed":
-        monkeypatch.setenv("VP_PERSIST_MULTI", "1")
+    elif mode == "round1_kernels":
+        monkeypatch.setenv("VP_FAST_INIT", "0")
     c = vp.Circuit.from_pws(pws_path, 16, seed=1)
     s = vp.Session(c)
     tr, res, ok = s.prove_interactive()

@@ -21,7 +21,7 @@ int main() {
     aux->t[0].off = 0; aux->t[0].len_in = len0; aux->t[0].valid_in = len0; aux->t[0].pair_start = 0;
     aux->bl[0] = 8; aux->len_out0[0] = len0; aux->loff[0] = 0;
     a.add_term = small; a.scalarV = small + 8; a.claims_dev = small + 80; a.Vu = nullptr; a.poly_dev = small + 4;
-    a.req = req; a.rep = rep; a.claims_host = claims; a.seq0 = 1; a.G = 1;
+    a.req = req; a.rep = rep; a.claims_host = claims; a.seq0 = 1;
     printf("sizeof(PTailArgs) = %zu\n", sizeof(PTailArgs));
     hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     hipLaunchKernelGGL(k_phase, dim3(1), dim3(VP_PH_THREADS), (size_t) 3 * a.cap * sizeof(F), st, a);

@@ -227,105 +227,6 @@ __device__ __forceinline__ F shfl_xor_F(const F &x, int mask) {
 
 // One level: regs x[0..2n) -> x[0..n).  Lane keeps the pair (lo, hi) = two neighbouring table entries:
 // lanes with bit s clear take theirs from the even register, the others from the odd register.
-template <int N2>
-__device__ __forceinline__ void sf_pairs(F (&x)[8], int s, int lane, F (&lo)[4], F (&hi)[4]) {
-    const bool up = (lane >> s) & 1;
-#pragma unroll
-    for (int j = 0; j < N2; ++j) {
-        const F A = x[2 * j], B = x[2 * j + 1];
-        const F recv = shfl_xor_F(up ? A : B, 1 << s);
-        lo[j] = up ? recv : A;
-        hi[j] = up ? B : recv;
-    }
-}
-
-template <int R, int MINW>
-__global__ void __launch_bounds__(VP_BLOCK, MINW) k_sumfold(SfArgs a) {
-    constexpr int G = 1 << R;
-    __shared__ F lds[4 * 3 * R];
-    const int lane = threadIdx.x & 63;
-    const u32 wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const u32 n_waves = gridDim.x * (blockDim.x >> 6);
-    F acc[3 * R];
-#pragma unroll
-    for (int i = 0; i < 3 * R; ++i) acc[i] = f_zero();
-    F rr[R];
-#pragma unroll
-    for (int s = 0; s < R; ++s) rr[s] = a.r[s];
-    // final lane -> element offset inside the 64 outputs of a chunk
-    u32 o_fin = (u32) lane >> R;
-#pragma unroll
-    for (int t = 0; t < R; ++t) o_fin += ((lane >> t) & 1u) << (6 - R + t);
-
-    for (u32 c = wave; c < a.total_chunks; c += n_waves) {
-        int j = 0;
-        while (j + 1 < a.n_tab && c >= a.t[j + 1].chunk_start) ++j;
-        const SfTab td = a.t[j];
-        const u32 cl = c - td.chunk_start;
-        const u32 base = td.off + cl * 64 * G, vend = td.off + td.valid;
-        F v[8], m[8], ad[8];
-#pragma unroll
-        for (int q = 0; q < G; ++q) {
-            const u32 idx = base + 64 * q + lane;
-            v[q] = ld_or_zero(a.inV, idx, vend);
-            m[q] = ld_or_zero(a.inM, idx, vend);
-            ad[q] = a.has_a ? ld_or_zero(a.inA, idx, vend) : f_zero();
-        }
-#pragma unroll
-        for (int s = 0; s < R; ++s) {
-            constexpr int dummy = 0; (void) dummy;
-            const int n2 = G >> (s + 1);
-            F vl[4], vh[4], ml[4], mh[4], al[4], ah[4];
-            if (n2 == 4) { sf_pairs<4>(v, s, lane, vl, vh); sf_pairs<4>(m, s, lane, ml, mh); if (a.has_a) sf_pairs<4>(ad, s, lane, al, ah); }
-            else if (n2 == 2) { sf_pairs<2>(v, s, lane, vl, vh); sf_pairs<2>(m, s, lane, ml, mh); if (a.has_a) sf_pairs<2>(ad, s, lane, al, ah); }
-            else { sf_pairs<1>(v, s, lane, vl, vh); sf_pairs<1>(m, s, lane, ml, mh); if (a.has_a) sf_pairs<1>(ad, s, lane, al, ah); }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (q >= n2) break;
-                const F dm = f_sub(mh[q], ml[q]), dv = f_sub(vh[q], vl[q]);
-                // X += dm*dv, Y += m1*v1 + a1, Z += m0*v0 + a0: the round polynomial is (X, Y - X - Z, Z), combined once
-                // per block instead of per pair
-                acc[3 * s] = f_add(acc[3 * s], f_mul(dm, dv));
-                F e1 = f_mul(mh[q], vh[q]), e0 = f_mul(ml[q], vl[q]);
-                if (a.has_a) {
-                    e1 = f_add(e1, ah[q]); e0 = f_add(e0, al[q]);
-                    ad[q] = f_lerp(al[q], ah[q], rr[s]);
-                }
-                acc[3 * s + 1] = f_add(acc[3 * s + 1], e1);
-                acc[3 * s + 2] = f_add(acc[3 * s + 2], e0);
-                v[q] = f_add(vl[q], f_mul(rr[s], dv));
-                m[q] = f_add(ml[q], f_mul(rr[s], dm));
-            }
-        }
-        const u32 oi = cl * 64 + o_fin;                    // element of the folded table
-        const u32 vout = (td.valid + G - 1) >> R;
-        if (oi < vout) {
-            a.outV[td.off + oi] = v[0];
-            a.outM[td.off + oi] = m[0];
-            if (a.has_a) a.outA[td.off + oi] = ad[0];
-        }
-    }
-    // block partials
-    const int w = threadIdx.x >> 6;
-#pragma unroll
-    for (int i = 0; i < 3 * R; ++i) acc[i] = wave_sum(acc[i]);
-    if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < 3 * R; ++i) lds[w * 3 * R + i] = acc[i];
-    }
-    __syncthreads();
-    if (threadIdx.x < R) {
-        const int s = threadIdx.x;
-        F X = lds[3 * s], Y = lds[3 * s + 1], Z = lds[3 * s + 2];
-        for (int k = 1; k < (int) (blockDim.x >> 6); ++k) {
-            X = f_add(X, lds[k * 3 * R + 3 * s]); Y = f_add(Y, lds[k * 3 * R + 3 * s + 1]); Z = f_add(Z, lds[k * 3 * R + 3 * s + 2]);
-        }
-        F *o = a.part + (size_t) s * a.part_stride + blockIdx.x * 3;
-        o[0] = X; o[1] = f_sub(f_sub(Y, X), Z); o[2] = Z;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
 // k_sumfold3b: the same three rounds per launch, laid out for parallelism instead of per-lane work.
 //
 // k_sumfold<3> gives a lane 8 entries of each table (7 dependent pair steps, ~250 VGPRs): a 2^20-entry table
@@ -692,117 +593,4 @@ __global__ void __launch_bounds__(VP_BLOCK, VP_SF_MINB) k_sumfold3b(SfArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// k_tail: one workgroup finishes a sumcheck.
-// ---------------------------------------------------------------------------------------------------
-#define VP_TAIL_THREADS 1024
-struct TailTab {
-    u32 off;          // table offset inside the ping-pong buffers
-    u32 len0;         // logical length at round 1
-    u32 valid0;       // valid length at round 1
-    int enter;        // first round (1-based) this kernel handles for the table
-    int cur;          // buffer (0/1) that holds the table at round `enter`
-    int v_from_v0;    // V of round `enter` is read from V0 instead of buf[cur][0] (phase 1 / Liu, enter == 1)
-};
-struct TailArgs {
-    const F *V0;
-    F *buf[2][3];
-    const F *r;                 // r[k-1] = challenge of round k
-    const F *part;              // block partials written by k_sumfold: part[(k-1)*part_stride + b*3 + c]
-    u32 part_stride;
-    int n_tab, rounds, has_a;
-    F *poly_out;                // rounds * 3
-    F *claims_out;              // n_tab
-    F *Vu;                      // phase 1: receives claims[0]
-    uint16_t nblk[32];          // partial blocks per round
-    TailTab t[VP_MAX_TAB];
-};
-
-__global__ void __launch_bounds__(VP_TAIL_THREADS) k_tail(TailArgs a) {
-    __shared__ F lds[16 * 3];
-    __shared__ F s_claim[VP_MAX_TAB];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nth = blockDim.x;
-    if (tid < a.n_tab) s_claim[tid] = f_zero();
-    F at = f_zero();                                        // add_term (thread 0)
-    __syncthreads();
-    // tables that consist of a single entry from the start: their value is the claim (bl == 0)
-    for (int k = 1; k <= (a.rounds > 0 ? a.rounds : 1); ++k) {
-        const bool real_round = k <= a.rounds;
-        const F rk = real_round ? a.r[k - 1] : f_zero();
-        const F rprev = (k >= 2) ? a.r[k - 2] : f_zero();
-        F acc[3] = {f_zero(), f_zero(), f_zero()};
-        if (real_round) {
-            const u32 nb = a.nblk[k - 1];
-            const F *pp = a.part + (size_t) (k - 1) * a.part_stride;
-            for (u32 i = tid; i < nb; i += nth) {
-                acc[0] = f_add(acc[0], pp[3 * i]); acc[1] = f_add(acc[1], pp[3 * i + 1]); acc[2] = f_add(acc[2], pp[3 * i + 2]);
-            }
-        }
-        F retire = f_zero();                                // thread 0: sum of V*M + A of tables retiring this round
-        for (int j = 0; j < a.n_tab; ++j) {
-            const TailTab td = a.t[j];
-            if (k < td.enter) continue;
-            const int sh = k - 1;
-            const u32 len = sh < 32 ? (td.len0 >> sh) : 0;
-            if (len == 0) continue;
-            const u32 valid = (u32) (((unsigned long long) td.valid0 + (1ull << sh) - 1) >> sh);
-            const int cb = td.cur ^ ((k - td.enter) & 1);       // a live table changes buffer every round
-            const F *inV = (td.v_from_v0 && k == td.enter) ? a.V0 + td.off : a.buf[cb][0] + td.off;
-            const F *inM = a.buf[cb][1] + td.off, *inA = a.buf[cb][2] + td.off;
-            if (len == 1) {
-                if (tid == 0) {
-                    // always-initialised single entry (see k_round_final)
-                    const F v = (td.len0 == 1) ? inV[0] : ld_or_zero(inV, 0, valid);
-                    const F m = (td.len0 == 1) ? inM[0] : ld_or_zero(inM, 0, valid);
-                    const F ad = a.has_a ? ((td.len0 == 1) ? inA[0] : ld_or_zero(inA, 0, valid)) : f_zero();
-                    s_claim[j] = v;
-                    if (real_round) retire = f_add(retire, f_add(f_mul(v, m), ad));
-                }
-                continue;
-            }
-            if (!real_round) continue;
-            F *oV = a.buf[cb ^ 1][0] + td.off, *oM = a.buf[cb ^ 1][1] + td.off, *oA = a.buf[cb ^ 1][2] + td.off;
-            const u32 npairs = (valid + 1) >> 1;
-            for (u32 p = tid; p < npairs; p += nth) {
-                const F v0 = ld_or_zero(inV, 2 * p, valid), v1 = ld_or_zero(inV, 2 * p + 1, valid);
-                const F m0 = ld_or_zero(inM, 2 * p, valid), m1 = ld_or_zero(inM, 2 * p + 1, valid);
-                F a0 = f_zero(), a1 = f_zero();
-                if (a.has_a) { a0 = ld_or_zero(inA, 2 * p, valid); a1 = ld_or_zero(inA, 2 * p + 1, valid); }
-                const F dm = f_sub(m1, m0), dv = f_sub(v1, v0);
-                const F qa = f_mul(dm, dv), qc = f_mul(m0, v0), qe = f_mul(m1, v1);
-                acc[0] = f_add(acc[0], qa);
-                acc[1] = f_add(acc[1], f_add(f_sub(f_sub(qe, qa), qc), f_sub(a1, a0)));
-                acc[2] = f_add(acc[2], f_add(qc, a0));
-                const F fv = f_add(v0, f_mul(rk, dv));
-                oV[p] = fv;
-                oM[p] = f_add(m0, f_mul(rk, dm));
-                if (a.has_a) oA[p] = f_lerp(a0, a1, rk);
-                if (len == 2 && k == a.rounds) s_claim[j] = fv;      // the last fold of a full-length table is its claim
-            }
-        }
-        if (!real_round) break;
-        // block reduction of the three coefficients
-#pragma unroll
-        for (int i = 0; i < 3; ++i) acc[i] = wave_sum(acc[i]);
-        if (lane == 0) { lds[w * 3] = acc[0]; lds[w * 3 + 1] = acc[1]; lds[w * 3 + 2] = acc[2]; }
-        __syncthreads();                                    // also publishes the folded tables
-        if (tid == 0) {
-            F s0 = lds[0], s1 = lds[1], s2 = lds[2];
-            for (int q = 1; q < (nth >> 6); ++q) { s0 = f_add(s0, lds[3 * q]); s1 = f_add(s1, lds[3 * q + 1]); s2 = f_add(s2, lds[3 * q + 2]); }
-            if (!f_is_zero(at)) at = f_mul(at, f_sub(f_one(), rprev));
-            at = f_add(at, retire);
-            a.poly_out[3 * (k - 1)] = s0;
-            a.poly_out[3 * (k - 1) + 1] = f_sub(s1, at);
-            a.poly_out[3 * (k - 1) + 2] = f_add(s2, at);
-        }
-        __syncthreads();                                    // lds reuse
-    }
-    // claims: tables shorter than the sumcheck left their value when they retired; a table whose last
-    // fold happened in the final round stored it above; single-entry tables of a zero-round phase too.
-    __syncthreads();
-    if (tid < a.n_tab) {
-        a.claims_out[tid] = s_claim[tid];
-        if (a.Vu && tid == 0) *a.Vu = s_claim[0];
-    }
-}
-
 }  // namespace vp

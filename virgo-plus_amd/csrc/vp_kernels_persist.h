@@ -17,17 +17,11 @@
 //   Every wait is bounded: the kernel leaves after VP_PH_TIMEOUT_TICKS (100 MHz s_memrealtime) without a message (status 2,
 //   the next call reports VP_EHIP); the host gives up after 15 s.
 //
-// Two regimes inside the launch:
-//   * distributed rounds (single-table phases — phase 1 and the Liu sumcheck — while the table has more than 2 * VP_PH_PMAX
-//     entries): G workgroups, workgroup g owns a fixed power-of-two slice of the table; a fold pairs ADJACENT entries
-//     (src/prover.cpp:470-487), so the slice a workgroup folds in round k is exactly what it wrote in round k-1 — no table data
-//     crosses workgroups and no fence is needed for it.  Per round: workgroup 0 takes the challenge from the host mailbox and
-//     re-publishes it in device memory (the others poll that word, not the PCIe link), every workgroup leaves its three partial
-//     sums with write-through (sc1) stores and arrives on a counter, workgroup 0 adds them up and answers the host.
-//   * solo rounds (every live table of the phase fits one CU's LDS: <= VP_PH_PMAX pairs): workgroup 0 alone; tables in LDS at
-//     full power-of-two length, folded in place; wave-uniform roles split a pair's nine multiplications over three waves (fold V /
-//     mult / add, then one product each), waves that can never have work again exit.  Entered directly for multi-table phases
-//     (phase 2) once they are small enough, and by the distributed regime after ONE release/acquire hand-over of the table.
+// One regime: SOLO rounds — every live table of the phase fits one CU's LDS (<= VP_PH_PMAX pairs): one workgroup; tables in LDS at full
+// power-of-two length, folded in place; wave-uniform roles split a pair's nine multiplications over three waves (fold V / mult / add, then
+// one product each), waves that can never have work again exit.  (Rounds 2-3 also had a distributed regime — G workgroups folding slices of a
+// large single table, challenge relayed through device memory, partial sums through agent-scope stores and an arrival counter; measured equal
+// to one launch per round, 18-20 us, and removed in round 4 together with its cross-workgroup spin waits.)
 // Semantics (retiring single-entry tables into add_term, src/prover.cpp:445,462-467; claims, :494-521) are those of k_round_final /
 // k_finalize, which stay the path for the rounds of multi-table phases that are too large for one CU.
 // ===================================================================================================
@@ -38,7 +32,6 @@ namespace vp {
 #define VP_PH_SLOTS 256                         // pair slots per pass (4 groups x 64 lanes)
 #define VP_PH_MAXIT (VP_PH_PMAX / VP_PH_SLOTS)
 #define VP_PH_TIMEOUT_TICKS 1000000000ull       // 10 s of s_memrealtime (100 MHz)
-#define VP_MULTI_MAXG 256
 
 struct TailMail { unsigned long long w[3], pad[5]; };                     // r.re | r.im | cmd, each | (seq & 7) << 61
 struct TailReply { unsigned long long w[7]; unsigned long long dead;     // poly limbs a.re a.im b.re b.im c.re c.im | status, tagged; dead = 1: the kernel has left on its own (time-out)
@@ -50,13 +43,6 @@ struct TailReply { unsigned long long w[7]; unsigned long long dead;     // poly
 #else
 #define TSTAMP(i) do { } while (0)
 #endif
-struct MultiSync {                                // device memory, one per context
-    unsigned long long arrive;                    // monotonic arrival counter of the workgroups other than 0
-    unsigned long long pad0[7];
-    unsigned long long bseq, br_re, br_im, bcmd;  // challenge re-published by workgroup 0
-    unsigned long long pad1[4];
-    unsigned long long part[VP_MULTI_MAXG][8];    // per workgroup: 3 partial sums (6 words)
-};
 
 // per-table data of a launch: written by the host into pinned memory, read once by the kernel (kernel arguments indexed per lane
 // would be copied to scratch)
@@ -74,19 +60,11 @@ struct PTailArgs {
     F *add_term, *scalarV, *claims_dev, *Vu, *poly_dev;
     TailMail *req; TailReply *rep; F *claims_host;
     unsigned long long seq0;      // the reply to the first round of the launch carries seq0, message i after it seq0 + i
-    // distributed regime (G > 1): one table, rounds 1 .. kc-1 on G workgroups, solo from round kc
-    int G, kc;
-    u32 off, len0, valid0, B1;    // table offset in the buffers, length / valid entries at round 1, slice of table_1 per workgroup (power of two)
-    const F *V0, *M0, *A0;        // round-1 sources
-    F *buf[2][3];                 // ping-pong buffers (ctx->tab)
-    F *hand[3];                   // hand-over copy of the table the LAST distributed round writes (<= 4096 entries per family): addresses
-                                  // workgroup 0 has not read earlier in this launch, so its XCD's L2 cannot hold stale lines of them
-    MultiSync *sync; unsigned long long arrive0;     // counter value before the launch
     // Suspend / resume (round 3).  A resident kernel that is told to leave in the middle of a phase (another context of the process needs
     // the device for a synchronising call) or that waited longer than `timeout_ticks` for the verifier saves the phase — the LDS tables of
     // the current level, their lengths, the round counter, add_term and the polynomial answered last — into `save` ([3][cap] entries, then
     // a header) and leaves with status 5; the next vp_round / vp_finalize relaunches it with resume = 1 and the sumcheck continues where it
-    // was.  Solo regime only (the distributed regime, off by default, still gives up with status 2).
+    // was.
     F *save; int resume;
     unsigned long long timeout_ticks;                // s_memrealtime ticks (100 MHz) without a message before the kernel leaves
 };
@@ -160,142 +138,6 @@ __global__ void __launch_bounds__(VP_PH_THREADS) k_phase(PTailArgs a) {
     unsigned long long expect = a.seq0;                            // sequence number of the message answered last
     int k = a.k0;                                                  // round answered last (after the first round below)
 
-    // ======================= distributed rounds: k = 1 .. kc-1 on G workgroups ==========================================
-    if (a.G > 1 && !a.resume) {
-        const u32 g = blockIdx.x, G = (u32) a.G;
-        unsigned long long arrive = a.arrive0;
-        for (k = 1; k < a.kc; ++k) {
-            F r = f_zero();
-            if (k >= 2) {                                          // challenge r_{k-1}: host -> workgroup 0 -> everybody
-                ++expect;
-                if (tid == 0) {
-                    int cmd;
-                    if (g == 0) {
-                        cmd = tail_poll(a, expect, r);
-                        st_sc1(&a.sync->br_re, r.re); st_sc1(&a.sync->br_im, r.im); st_sc1(&a.sync->bcmd, (unsigned long long) (long long) cmd);
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        st_sc1(&a.sync->bseq, expect);
-                    } else {
-                        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                        cmd = -1;
-                        for (;;) {
-                            if (ld_sc1(&a.sync->bseq) == expect) { cmd = (int) (long long) ld_sc1(&a.sync->bcmd); r = f_make(ld_sc1(&a.sync->br_re), ld_sc1(&a.sync->br_im)); break; }
-                            if (__builtin_amdgcn_s_memrealtime() - t0 > VP_PH_TIMEOUT_TICKS + 100000000ull) break;
-                            __builtin_amdgcn_s_sleep(2);
-                        }
-                    }
-                    s_r = r; s_cmd = cmd;
-                }
-                __syncthreads();
-                r = s_r;
-                if (s_cmd != 1) {                                  // quit / timeout / finalize out of order: everybody leaves
-                    if (g == 0 && boss) { *a.add_term = at; tail_leave(a, expect, s_cmd, s_cmd == 3 ? 1 : s_cmd == -1 ? 2 : 3); }
-                    return;
-                }
-            }
-            // slice of table_k owned by this workgroup: entries [g B_k, (g+1) B_k), pairs [g B_k / 2, (g+1) B_k / 2)
-            const u32 Bk = a.B1 >> (k - 1);
-            const u32 valid_k = (u32) (((u64) a.valid0 + (1ull << (k - 1)) - 1) >> (k - 1));
-            const u32 p_lo = g * (Bk >> 1), p_hi = min((g + 1) * (Bk >> 1), (valid_k + 1) >> 1);
-            F acc[3] = {f_zero(), f_zero(), f_zero()};
-            if (k == 1) {
-                const u32 vi = a.off + a.valid0;
-                for (u32 p = p_lo + tid; p < p_hi; p += blockDim.x) {
-                    const u32 i0 = a.off + 2 * p;
-                    const F v0 = ld_or_zero(a.V0, i0, vi), v1 = ld_or_zero(a.V0, i0 + 1, vi), m0 = ld_or_zero(a.M0, i0, vi), m1 = ld_or_zero(a.M0, i0 + 1, vi);
-                    F a0 = f_zero(), a1 = f_zero();
-                    if (a.has_a) { a0 = ld_or_zero(a.A0, i0, vi); a1 = ld_or_zero(a.A0, i0 + 1, vi); }
-                    const F dm = f_sub(m1, m0), dv = f_sub(v1, v0);
-                    const F qa = f_mul(dm, dv), qc = f_mul(m0, v0), qe = f_mul(m1, v1);
-                    acc[0] = f_add(acc[0], qa);
-                    acc[1] = f_add(acc[1], f_add(f_sub(f_sub(qe, qa), qc), f_sub(a1, a0)));
-                    acc[2] = f_add(acc[2], f_add(qc, a0));
-                }
-            } else {
-                const F *inV = k == 2 ? a.V0 : a.buf[k & 1][0], *inM = k == 2 ? a.M0 : a.buf[k & 1][1], *inA = k == 2 ? a.A0 : a.buf[k & 1][2];
-                const bool to_hand = k == a.kc - 1;                     // the table workgroup 0 takes over: written to the hand-over buffers (offset 0)
-                F *oV = to_hand ? a.hand[0] - a.off : a.buf[(k + 1) & 1][0], *oM = to_hand ? a.hand[1] - a.off : a.buf[(k + 1) & 1][1], *oA = to_hand ? a.hand[2] - a.off : a.buf[(k + 1) & 1][2];
-                const u32 valid_in = (u32) (((u64) a.valid0 + (1ull << (k - 2)) - 1) >> (k - 2));
-                const u32 vi = a.off + valid_in;
-                for (u32 p = p_lo + tid; p < p_hi; p += blockDim.x) {
-                    const u32 i0 = a.off + 4 * p, o0 = a.off + 2 * p;
-                    const bool w1 = 2 * p + 1 < valid_k;
-                    const F v0 = f_lerp(ld_or_zero(inV, i0, vi), ld_or_zero(inV, i0 + 1, vi), r), v1 = f_lerp(ld_or_zero(inV, i0 + 2, vi), ld_or_zero(inV, i0 + 3, vi), r);
-                    const F m0 = f_lerp(ld_or_zero(inM, i0, vi), ld_or_zero(inM, i0 + 1, vi), r), m1 = f_lerp(ld_or_zero(inM, i0 + 2, vi), ld_or_zero(inM, i0 + 3, vi), r);
-                    oV[o0] = v0; oM[o0] = m0;
-                    if (w1) { oV[o0 + 1] = v1; oM[o0 + 1] = m1; }
-                    F a0 = f_zero(), a1 = f_zero();
-                    if (a.has_a) {
-                        a0 = f_lerp(ld_or_zero(inA, i0, vi), ld_or_zero(inA, i0 + 1, vi), r); a1 = f_lerp(ld_or_zero(inA, i0 + 2, vi), ld_or_zero(inA, i0 + 3, vi), r);
-                        oA[o0] = a0; if (w1) oA[o0 + 1] = a1;
-                    }
-                    const F dm = f_sub(m1, m0), dv = f_sub(v1, v0);
-                    const F qa = f_mul(dm, dv), qc = f_mul(m0, v0), qe = f_mul(m1, v1);
-                    acc[0] = f_add(acc[0], qa);
-                    acc[1] = f_add(acc[1], f_add(f_sub(f_sub(qe, qa), qc), f_sub(a1, a0)));
-                    acc[2] = f_add(acc[2], f_add(qc, a0));
-                }
-            }
-            const bool last = k == a.kc - 1;                       // the table written now is read by workgroup 0 alone next round
-            if (g != 0) {
-                // block totals (two stages), left with write-through stores by one lane; the workgroup arrives once they are acknowledged
-                tail_wave_partials(acc, red);
-                __syncthreads();
-                F tot[3];
-                if (w == 0) tail_wave0_total(red, (int) (blockDim.x >> 6), tot);
-                if (boss) {
-                    unsigned long long *pp = a.sync->part[g];
-                    st_sc1(pp, tot[0].re); st_sc1(pp + 1, tot[0].im); st_sc1(pp + 2, tot[1].re); st_sc1(pp + 3, tot[1].im); st_sc1(pp + 4, tot[2].re); st_sc1(pp + 5, tot[2].im);
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the partial (and, in the last round, every wave's table stores) are out
-                if (last) __syncthreads();
-                if (boss) {
-                    if (last) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }      // write back this XCD's L2 once: the hand-over of the table
-                    __hip_atomic_fetch_add(&a.sync->arrive, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                if (last) return;
-            } else {
-                arrive += G - 1;
-                if (tid == 0) {
-                    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                    int ok = 1;
-                    while (ld_sc1(&a.sync->arrive) < arrive) {
-                        if (__builtin_amdgcn_s_memrealtime() - t0 > VP_PH_TIMEOUT_TICKS) { ok = 0; break; }
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                    s_cmd = ok;
-                }
-                __syncthreads();
-                if (!s_cmd) {
-                    if (boss) { *a.add_term = at; tail_leave(a, expect, 0, 4); }
-                    return;
-                }
-                // the totals of the other workgroups join this thread's own sums: ONE two-stage reduction for everything
-                const u32 nw = blockDim.x >> 6;
-                for (u32 q = 1 + tid; q < G; q += blockDim.x) {
-                    const unsigned long long *pp = a.sync->part[q];
-                    acc[0] = f_add(acc[0], f_make(ld_sc1(pp), ld_sc1(pp + 1)));
-                    acc[1] = f_add(acc[1], f_make(ld_sc1(pp + 2), ld_sc1(pp + 3)));
-                    acc[2] = f_add(acc[2], f_make(ld_sc1(pp + 4), ld_sc1(pp + 5)));
-                }
-                tail_wave_partials(acc, red);
-                __syncthreads();
-                F tot[3];
-                if (w == 0) tail_wave0_total(red, (int) nw, tot);
-                if (boss) {
-                    if (k >= 2 && !f_is_zero(at)) at = f_mul(at, f_sub(f_one(), r));
-                    tail_reply(a, expect, tot[0], f_sub(tot[1], at), f_add(tot[2], at));
-                }
-                __syncthreads();
-            }
-        }
-        // hand-over: workgroup 0 continues alone with round kc; the table of round kc-1 was written by all workgroups
-        if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        k = a.kc - 1;
-    }
-
     // ======================= solo regime (workgroup 0) =====================================================================
     const u32 cap = a.cap;
     F *LV = L, *LM = L + cap, *LA = L + 2 * (size_t) cap;
@@ -311,44 +153,13 @@ __global__ void __launch_bounds__(VP_PH_THREADS) k_phase(PTailArgs a) {
     }
     // ---- first solo round: sources in global memory, folded tables into LDS (plain one-thread-per-pair form) ----
     if (!a.resume) {
-        const bool multi = a.G > 1;
         F r;
         int n_tab, fold;
         u32 total_pairs;
         const F *inV, *inM, *inA;
-        if (multi) {
-            // round kc of the single table: wait for its challenge like any later round
-            ++expect;
-            if (tid == 0) { F rr = f_zero(); s_cmd = tail_poll(a, expect, rr); s_r = rr; }
-            __syncthreads();
-            if (s_cmd != 1) {
-                if (boss) { *a.add_term = at; tail_leave(a, expect, s_cmd, s_cmd == 3 ? 1 : s_cmd == -1 ? 2 : 3); }
-                return;
-            }
-            r = s_r;
-            const int kk = a.kc;                                   // >= 2
-            if (tid == 0) {
-                TabDesc td; td.off = a.off; td.pair_start = 0;
-                td.len_in = a.len0 >> (kk - 2);
-                td.valid_in = (u32) (((u64) a.valid0 + (1ull << (kk - 2)) - 1) >> (kk - 2));
-                s_t[0] = td;
-                s_len[0] = td.len_in >> 1;
-            }
-            __syncthreads();
-            n_tab = 1; fold = 1; total_pairs = s_t[0].len_in >> 2;
-            inV = a.hand[0] - a.off; inM = a.hand[1] - a.off; inA = a.hand[2] - a.off;        // kc >= 3: written by the last distributed round
-            k = kk;
-        } else {
-            r = a.rv; n_tab = a.n_tab; fold = a.fold; total_pairs = a.total_pairs;
-            inV = a.inV; inM = a.inM; inA = a.inA;
-        }
-        // hand-over reads go past the L1 (agent-scope loads): the entries were written by other workgroups, possibly on other XCDs
-        auto ldz = [&](const F *p, u32 i, u32 valid) -> F {
-            if (i >= valid) return f_zero();
-            if (!multi) return p[i];
-            const unsigned long long *w = reinterpret_cast<const unsigned long long *>(p + i);
-            return f_make(ld_sc1(w), ld_sc1(w + 1));
-        };
+        r = a.rv; n_tab = a.n_tab; fold = a.fold; total_pairs = a.total_pairs;
+        inV = a.inV; inM = a.inM; inA = a.inA;
+        auto ldz = [&](const F *p, u32 i, u32 valid) -> F { return i < valid ? p[i] : f_zero(); };
         F acc[3] = {f_zero(), f_zero(), f_zero()};
         for (u32 q = tid; q < total_pairs; q += blockDim.x) {
             int j = 0;
@@ -383,8 +194,7 @@ __global__ void __launch_bounds__(VP_PH_THREADS) k_phase(PTailArgs a) {
         if (w == 0) tail_wave0_total(red, (int) (blockDim.x >> 6), tot);
         if (boss) {
             if (fold && !f_is_zero(at)) at = f_mul(at, f_sub(f_one(), r));
-            if (!multi)
-                for (int j = 0; j < n_tab; ++j) {                   // tables that reach length one in this round (k_round_final's loop)
+            for (int j = 0; j < n_tab; ++j) {                   // tables that reach length one in this round (k_round_final's loop)
                     const TabDesc td = s_t[j];
                     const u32 len_out = fold ? (td.len_in >> 1) : td.len_in;
                     if (len_out != 1) continue;

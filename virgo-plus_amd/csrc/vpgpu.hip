@@ -133,8 +133,6 @@ struct vp_ctx {
     // into, and whether such a saved phase is waiting for the next vp_round / vp_finalize
     PTailArgs tail_args{}; F *tail_save = nullptr; bool tail_suspended = false, tail_lost = false; u64 tail_resumes = 0;
     TailAux *h_aux = nullptr;            // pinned: per-table data of the resident kernel's launch
-    F *d_hand = nullptr;                 // hand-over buffers of the distributed -> solo switch (3 x 4096 entries)
-    MultiSync *d_msync = nullptr; int multi_enabled = 0;      // VP_PERSIST=0: one launch per round; VP_PERSIST_MULTI=0: no distributed rounds
     int poll = 1;                                     // VP_POLL=0: wait with hipStreamSynchronize instead
     F *h_io = nullptr; size_t h_io_cap = 0;   // pinned staging of the batched path: tape in, transcript out
     int r1_pending = 0;                // interactive path: round 1 of the phase was queued behind its init (1: in the resident kernel, 2: per-round launch,
@@ -174,7 +172,7 @@ struct vp_ctx {
     FgkState *fgk = nullptr;             // vp_fft_gkr: circuit layers and sumcheck tables of the last size used
     VpComm *cm = nullptr;                // RCCL communicator (vp_comm_init)
     F *part2 = nullptr;                  // [32][MAX_BLOCKS*3] block partials of the batched path
-    int simple_path = 0, sumfold_path = 0, serial = 0;
+    int simple_path = 0, serial = 0;
     Lane lane0; Lane *ln = nullptr;
     std::vector<Lane> lanes;          // [2*(i-1)] = phases 1+2 of layer i, [2*(i-1)+1] = Liu of layer i
     std::vector<hipStream_t> lane_streams; std::vector<hipEvent_t> lane_events; hipEvent_t ev_fork = nullptr;
@@ -596,7 +594,7 @@ int tail_wait_resumed(vp_ctx *ctx, unsigned long long want) {
 }
 int tail_resume(vp_ctx *ctx, bool already_sent) {
     PTailArgs a = ctx->tail_args;
-    a.resume = 1; a.G = 1;
+    a.resume = 1;
     a.seq0 = already_sent ? ctx->tail_seq : ctx->tail_seq + 1;
     // the reply words still carry the leaving kernel's message with the tag the relaunched kernel will answer under: give them another one
     if (already_sent) for (int q = 0; q < 7; ++q) __atomic_store_n(&ctx->h_rep->w[q], VP_TAG(ctx->tail_seq + 1), __ATOMIC_RELAXED);
@@ -632,38 +630,6 @@ int tail_try_launch(vp_ctx *ctx, const F &rv) {
     const int k = s.round + 1;
     if (!ctx->tail_enabled || s.total_rounds - k < 1) return 0;
     PTailArgs a{};
-    a.G = 1;
-    // single-table phase (phase 1, Liu) with a table too large for one CU: distributed rounds on G workgroups, solo from round kc
-    if (ctx->multi_enabled && k == 1 && s.n_tab == 1 && s.len0[0] >= 8192 && s.bl[0] == s.total_rounds) {
-        const u32 len0 = s.len0[0];
-        const int gshift = ctx->opt.persistent_multi_shift;      // entries of table_1 per workgroup (log2)
-        const int G = (int) std::max<u32>(2, std::min<u32>(VP_MULTI_MAXG, len0 >> gshift));
-        u32 B1 = 2; while ((u64) B1 * G < s.valid0[0]) B1 <<= 1;
-        const int kc = s.bl[0] - 10;                               // first round whose source table has <= 4096 entries
-        if (!ctx->d_msync) { if (dalloc(ctx, &ctx->d_msync, (size_t) 1) != VP_OK) return 0; }
-        if (!ctx->d_hand) { if (dalloc(ctx, &ctx->d_hand, (size_t) 3 * 4096) != VP_OK) return 0; }
-        for (int t = 0; t < 3; ++t) a.hand[t] = ctx->d_hand + (size_t) t * 4096;
-        if (hipMemsetAsync(ctx->d_msync, 0, sizeof(MultiSync), ctx->stream) != hipSuccess) return 0;
-        a.G = G; a.kc = kc; a.off = s.off[0]; a.len0 = len0; a.valid0 = s.valid0[0]; a.B1 = B1;
-        a.V0 = s.V0; a.M0 = s.M0; a.A0 = s.A0;
-        for (int b = 0; b < 2; ++b) for (int t = 0; t < 3; ++t) a.buf[b][t] = ctx->tab[b][t];
-        a.sync = ctx->d_msync; a.arrive0 = 0;
-        a.k0 = 1; a.R = s.total_rounds; a.n_tab = 1; a.has_a = s.has_a; a.cap = 2 * VP_PH_PMAX;
-        a.aux = ctx->h_aux;
-        ctx->h_aux->bl[0] = s.bl[0]; ctx->h_aux->loff[0] = 0; ctx->h_aux->len_out0[0] = 0; ctx->h_aux->t[0] = TabDesc{};
-        a.rv = rv;
-        a.add_term = ctx->add_term(); a.scalarV = ctx->scalarV(); a.claims_dev = ctx->d_tr + ctx->n_tr + 3; a.poly_dev = ctx->d_tr + ctx->n_tr;
-        a.Vu = s.phase == 1 ? ctx->Vu() : nullptr;
-        a.req = ctx->h_req; a.rep = ctx->h_rep; a.claims_host = ctx->h_pin + 4;
-        a.seq0 = ++ctx->tail_seq; ctx->h_rep->dead = 0;
-        a.save = ctx->tail_save; a.resume = 0; a.timeout_ticks = (unsigned long long) std::max(1, ctx->opt.persistent_timeout_ms) * 100000ull;
-        ctx->tail_args = a;
-        hipLaunchKernelGGL(k_phase, dim3(G), dim3(VP_PH_THREADS), (size_t) 3 * a.cap * sizeof(F), ctx->stream, a);
-        { const hipError_t e = hipGetLastError(); if (e != hipSuccess) { if ((ctx->opt.debug & 1)) fprintf(stderr, "[vp] k_phase (G=%d) launch failed: %s\n", G, hipGetErrorString(e)); --ctx->tail_seq; return 0; } }
-        count_launch(ctx);
-        ctx->tail_active = true;
-        return 1;
-    }
     TailAux &ax = *ctx->h_aux;
     a.aux = ctx->h_aux;
     a.rv = rv; a.fold = (k >= 2) ? 1 : 0;
@@ -747,9 +713,9 @@ void vp_options_default(vp_options *o) {
     memset(o, 0, sizeof *o);
     o->struct_size = (uint32_t) sizeof *o;
     o->gkr_path = VP_PATH_PLAN; o->use_graph = 1; o->serial = 0; o->fuse_init = 1; o->fuse_min_log = 0; o->fuse_dot = 0;
-    o->drop_y = 1; o->drop_y_round1 = 0; o->real_values = 1; o->seg_tiny = 1; o->sf_big_log = 14; o->sf3b = 1;
-    o->sf3b_grid = 512; o->sf_min_waves = 1; o->dot_blocks = 1024; o->plan_align = 0; o->xcd_map = 0; o->round_fused_max = 512;
-    o->persistent_rounds = 1; o->persistent_multi = 0; o->persistent_multi_shift = 13; o->poll = 1; o->debug = 0; o->prefetch_round1 = 1; o->split_cost_percent = 50; o->kernel_copies = 1; o->fold_branches = 1; o->ntt_scatter = 1; o->fuse_combine = 2; o->plan_autotune = 1;
+    o->drop_y = 1; o->drop_y_round1 = 0; o->real_values = 1; o->seg_tiny = 1; o->sf_big_log = 14;
+    o->sf3b_grid = 512; o->dot_blocks = 1024; o->plan_align = 0; o->xcd_map = 0; o->round_fused_max = 512;
+    o->persistent_rounds = 1; o->poll = 1; o->debug = 0; o->prefetch_round1 = 1; o->split_cost_percent = 50; o->kernel_copies = 1; o->fold_branches = 1; o->ntt_scatter = 1; o->fuse_combine = 2; o->plan_autotune = 1;
     o->pc_tensor_pub = 1;
     o->persistent_timeout_ms = 10000;
     o->graph_explicit = 0;
@@ -767,15 +733,15 @@ static void resolve_options(vp_options *o, const vp_options *user, uint32_t *pin
     auto flag = [](const char *name, int32_t &v) { const char *e = getenv(name); if (e && (e[0] == '0' || e[0] == '1')) v = e[0] - '0'; };
     auto num = [](const char *name, int32_t &v) { const char *e = getenv(name); if (e && *e) v = atoi(e); };
     if (const char *p = getenv("VP_GKR_PATH"))
-        o->gkr_path = !strcmp(p, "lanes") ? VP_PATH_LANES : !strcmp(p, "sumfold") ? VP_PATH_SUMFOLD : !strcmp(p, "simple") ? VP_PATH_SIMPLE : VP_PATH_PLAN;
+        o->gkr_path = !strcmp(p, "lanes") ? VP_PATH_LANES : !strcmp(p, "simple") ? VP_PATH_SIMPLE : VP_PATH_PLAN;
     if (const char *p = getenv("VP_PLAN_ALIGN")) o->plan_align = !strcmp(p, "left") ? 1 : !strcmp(p, "right") ? 2 : 0;
     flag("VP_GKR_GRAPH", o->use_graph); flag("VP_GKR_SERIAL", o->serial); flag("VP_FUSE_INIT", o->fuse_init); flag("VP_FUSE_DOT", o->fuse_dot);
     flag("VP_DROP_Y", o->drop_y); flag("VP_DROP_Y1", o->drop_y_round1); flag("VP_REAL_V", o->real_values);
     flag("VP_SEG_TINY", o->seg_tiny); flag("VP_XCD_MAP", o->xcd_map); flag("VP_PERSIST", o->persistent_rounds);
-    flag("VP_PERSIST_MULTI", o->persistent_multi); flag("VP_POLL", o->poll); flag("VP_PREFETCH_R1", o->prefetch_round1);
-    num("VP_FUSE_MIN_LOG", o->fuse_min_log); num("VP_SF_BIG_LOG", o->sf_big_log); num("VP_SF3B", o->sf3b);
-    num("VP_SF3B_GRID", o->sf3b_grid); num("VP_SF_MINW", o->sf_min_waves); num("VP_DOT_BLOCKS", o->dot_blocks);
-    num("VP_ROUND_FUSED_MAX", o->round_fused_max); num("VP_MULTI_SHIFT", o->persistent_multi_shift);
+    flag("VP_POLL", o->poll); flag("VP_PREFETCH_R1", o->prefetch_round1);
+    num("VP_FUSE_MIN_LOG", o->fuse_min_log); num("VP_SF_BIG_LOG", o->sf_big_log);
+    num("VP_SF3B_GRID", o->sf3b_grid); num("VP_DOT_BLOCKS", o->dot_blocks);
+    num("VP_ROUND_FUSED_MAX", o->round_fused_max);
     num("VP_SPLIT_COST_PERCENT", o->split_cost_percent);
     flag("VP_KERNEL_COPIES", o->kernel_copies);
     flag("VP_FOLD_BRANCHES", o->fold_branches);
@@ -844,7 +810,6 @@ int vp_create_with_options(int device, const vp_options *user, vp_ctx **out) {
     ctx->poll = ctx->opt.poll; ctx->tail_enabled = ctx->opt.persistent_rounds;
     // distributed rounds (G workgroups of the resident kernel): measured equal to one launch per round on MI355X (x64 interactive proof
     // 12.6 vs 12.7 ms: profiles/r02_interactive_*), and they need G idle CUs for as long as the verifier takes — opt-in
-    ctx->multi_enabled = ctx->opt.persistent_multi;
     hipEventCreate(&ctx->ev0); hipEventCreate(&ctx->ev1);
     (void) hipFuncSetAttribute(reinterpret_cast<const void *>(k_emit_multi), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
     (void) hipFuncSetAttribute(reinterpret_cast<const void *>(k_emit), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
@@ -910,7 +875,7 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
     ctx->n_layers = n_layers;
     ctx->evaluated = false;
     ctx->chain_owner.clear(); ctx->chain_cost.clear();
-    ctx->chunk_cap = 0; ctx->d_msync = nullptr; ctx->d_hand = nullptr;
+    ctx->chunk_cap = 0;
     ctx->pred_r = ctx->pred_pool = ctx->pred_part = ctx->pred_out = nullptr; ctx->pred_jobs = nullptr; ctx->pred_dot = nullptr; ctx->pred_map = nullptr;
     ctx->pc_rt = ctx->pc_coef = ctx->pc_cw = nullptr; ctx->pc_tree = nullptr; ctx->pc_lm = -1; ctx->pc_rtc.clear();
     ctx->pc_pub = ctx->pc_qcw = ctx->pc_hcw = ctx->pc_tmp = ctx->pc_small = nullptr; ctx->pc_tree_h = nullptr; ctx->pc_private_done = false;
@@ -1084,7 +1049,7 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
             }
         }
         ctx->serial = ctx->opt.serial; ctx->use_graph = ctx->opt.use_graph;
-        ctx->simple_path = ctx->opt.gkr_path == VP_PATH_SIMPLE; ctx->sumfold_path = ctx->opt.gkr_path == VP_PATH_SUMFOLD;
+        ctx->simple_path = ctx->opt.gkr_path == VP_PATH_SIMPLE;
         ctx->plan_path = ctx->opt.gkr_path == VP_PATH_LANES ? 0 : 1;
         ctx->fuse_init = ctx->opt.fuse_init;
     }
@@ -1478,7 +1443,7 @@ int vp_gkr_sizes(vp_ctx *ctx, uint64_t *n_tape, uint64_t *n_bytes) {
 
 int vp_set_shard(vp_ctx *ctx, int rank, int world) {
     if (!ctx || world < 1 || rank < 0 || rank >= world) return VP_EINVAL;
-    if (world > 1 && ctx->n_layers >= 2 && (!ctx->plan_path || ctx->simple_path || ctx->sumfold_path)) {
+    if (world > 1 && ctx->n_layers >= 2 && (!ctx->plan_path || ctx->simple_path)) {
         ctx->err = "vp_set_shard: only the launch-plan path shards (unset VP_GKR_PATH)"; return VP_EINVAL;
     }
     if (world > 1 && vp_comm_attached(ctx) && !vp_comm_matches(ctx, rank, world)) { ctx->err = "vp_set_shard: rank/world differ from the attached communicator's"; return VP_EINVAL; }
