@@ -482,6 +482,41 @@ class Watchdog:
         self.t.cancel()
 
 
+class TermGuard:
+    """A launcher that sees one rank die sends SIGTERM to the others (torch.distributed.run does).  Rank 0 may sit inside a collective of
+    the C library at that moment, where a Python-level handler would never run: the signal's C handler writes to a wake-up pipe instead, and a
+    helper thread that reads the pipe prints the line this rank has (with the sub-leg marked) and ends the process with code 3."""
+
+    def __init__(self, on_term):
+        import signal
+        import threading
+        self.r, self.w = os.pipe()
+        os.set_blocking(self.w, False)
+        self.old_fd = signal.set_wakeup_fd(self.w, warn_on_full_buffer=False)
+        self.old_handler = signal.signal(signal.SIGTERM, lambda *_: None)
+        self.armed = True
+
+        def waiter():
+            while True:
+                b = os.read(self.r, 1)
+                if not b or not self.armed:
+                    return
+                if b[0] == int(signal.SIGTERM):
+                    on_term()
+
+        threading.Thread(target=waiter, daemon=True).start()
+
+    def disarm(self):
+        import signal
+        self.armed = False
+        signal.set_wakeup_fd(self.old_fd)
+        signal.signal(signal.SIGTERM, self.old_handler if self.old_handler is not None else signal.SIG_DFL)
+        try:
+            os.write(self.w, b"\0")
+        except OSError:
+            pass
+
+
 def allreduce_min_flag(world, ok):
     if world == 1:
         return bool(ok)
@@ -507,11 +542,13 @@ def sharded_prepare(vp, pws, golden, a, world, rank, local, blocks):
     rank that fails here can still tell the others at the flag exchange that follows (main)."""
     name = "sha256_x%d" % blocks
     g = golden[name]
-    # test hook (tests/test_gpu_parity.py: a rank that fails / never arrives before the first collective): "raise:<rank>" | "hang:<rank>"
+    # test hook (tests/test_gpu_parity.py: a rank that fails / never arrives before the first collective): "raise:<rank>" | "hang:<rank>" | "die:<rank>" (killed: the launcher then ends the other ranks with SIGTERM)
     inj = os.environ.get("VP_BENCH_INJECT", "")
     if inj and int(inj.split(":")[1]) == rank:
         if inj.startswith("raise"):
             raise RuntimeError("injected failure on rank %d before the first collective" % rank)
+        if inj.startswith("die"):
+            os.kill(os.getpid(), 9)
         time.sleep(10 ** 6)
     circ = vp.Circuit.from_pws(pws, blocks, seed=1)
     sess = vp.Session(circ, device=local)
@@ -859,7 +896,7 @@ def protocol_workload(vp, a, pws, golden, world, rank, local, blocks):
     pc_rows, _, pc_us = launch_table(st_priv + st_pub + st_fri)
     roof = keccak_roofline(allst, blocks)
     roof_gkr = roofline_of(gkr_rows, blocks, res_g["gkr_device_ms"])
-    ntt = [e for e in allst if e["kernel"] in ("k_ntt_lds", "k_ntt_split", "k_ntt_r8")]
+    ntt = [e for e in allst if e["kernel"] in ("k_ntt_lds", "k_ntt_split", "k_ntt8_cols", "k_ntt8_rows")]
     roof_ntt = None
     if ntt:
         w, us = sum(e["work"] for e in ntt), sum(e["us"] for e in ntt)
@@ -1234,6 +1271,22 @@ def main():
                 os._exit(3)
 
             wd = Watchdog(a.subleg_timeout, on_timeout)
+
+            def on_term():
+                if rank == 0:
+                    detail["multi_gpu_sublegs_error"] = "terminated by the launcher in %s (a peer rank died)" % state["leg"]
+                    out.emit(detail, world, a.detail_file)
+                    sys.stdout.flush()
+                os._exit(3)
+
+            tg = TermGuard(on_term)
+            # rank 0 alone ran the profiled / interactive / verifier legs of the headline: nobody enters the sub-leg before its detail is complete,
+            # so whatever happens to a peer from here on, the line exists
+            try:
+                barrier(world)
+            except Exception as e:
+                sys.stderr.write("bench.py rank %d: barrier before the sharded sub-leg failed: %s: %s\n" % (rank, type(e).__name__, e))
+                on_term()
             failed = None
             sub = prep = None
             try:                                # local work only: a failure here is reported at the flag exchange below, nobody is left in a collective
@@ -1264,6 +1317,7 @@ def main():
                         sys.stdout.flush()
                     os._exit(3)
             wd.cancel()
+            tg.disarm()
             if rank == 0:
                 detail["sharded"] = sub
                 detail["rccl_ranks"] = sub.get("rccl_ranks") if isinstance(sub, dict) else None

@@ -137,6 +137,9 @@ typedef struct {
     int32_t interactive_fast_init;  /* VP_FAST_INIT: vp_phase1_init / vp_phase2_init / vp_liu_init run the batched path's init kernels (closed-form eq half
                                        tables of the one sumcheck, eq values as products of two half-table entries, V gather and assert scaling inside the
                                        row kernel) instead of the per-sumcheck kernels of round 1 (expanded eq tables, separate gather / scatter launches)  [1] */
+    int32_t fuse_p2;                /* VP_FUSE_P2: launch plan — with fuse_init, the phase-2 init of a layer (src/prover.cpp:282-367) runs inside the first fold launch of its
+                                       sumcheck too (GenP2): V through the slot map, mult / add entries from the v-sorted contribution list; the tables of the long
+                                       subsets are never written at full length.  0: k_light_multi writes them, the fold launch reads them back  [1] */
 } vp_options;
 void vp_options_default(vp_options *opt);
 

@@ -1469,11 +1469,13 @@ def _bench_two_ranks(extra_env, timeout_s, *flags):
     return subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout_s, env=env, cwd=ROOT)
 
 
-@pytest.mark.parametrize("inject", [None, "raise:1", "hang:1"])
+@pytest.mark.parametrize("inject", [None, "raise:1", "hang:1", "die:1"])
 def test_bench_multi_rank_line_and_exit_code_when_a_rank_fails(vp, tmp_path, inject):
     """The multi-rank run of bench.py prints exactly ONE parseable line whatever happens in its `sharded` sub-leg, and its exit code tells the
     launcher when the run was not whole: a rank that raises before the first collective (the others learn at the flag exchange), a rank that never
-    arrives (the watchdog prints what there is and every rank leaves with code 3), and the healthy run (code 0, sub-leg bit-exact)."""
+    arrives (the watchdog prints what there is and every rank leaves with code 3), a rank that is killed (the launcher ends rank 0 with SIGTERM — or
+    rank 0 sees the peer vanish at the flag exchange, whichever comes first: either way it prints its line before it leaves), and the healthy run
+    (code 0, sub-leg bit-exact)."""
     import json
     detail = str(tmp_path / "detail.json")
     env = {"VP_BENCH_INJECT": inject} if inject else {}
@@ -1489,7 +1491,7 @@ def test_bench_multi_rank_line_and_exit_code_when_a_rank_fails(vp, tmp_path, inj
         assert "multi_gpu_sublegs_error" not in o and o["sharded"]["bit_exact"] is True and o["sharded"]["commitment_bit_exact"] is True
     else:
         assert r.returncode != 0
-        assert "multi_gpu_sublegs_error" in o and any(w in o["multi_gpu_sublegs_error"] for w in ("failed", "timed out", "went away"))
+        assert "multi_gpu_sublegs_error" in o and any(w in o["multi_gpu_sublegs_error"] for w in ("failed", "timed out", "went away", "terminated"))
 
 
 _EXIT_WORKER = r"""

@@ -15,3 +15,14 @@ s = vp.Session(c)
 for _ in range(2):
     tr, res, ok = s.prove_interactive()
 print("interactive prover_sec %.4f init %.4f rounds %.4f ok %s" % (res["prove_sec"], res["init_sec"], res["round_sec"], ok))
+# round classes: wall time of the vp_round calls by how the round ran and by the size of its tables
+import collections, math
+cls = collections.OrderedDict()
+for e in s.round_stats():
+    k = (e["how"], int(math.log2(max(1, e["bytes"]))))
+    c = cls.setdefault(k, [0, 0.0, 0])
+    c[0] += 1; c[1] += e["us"]; c[2] += e["bytes"]
+print("how  log2(bytes)  rounds   total us   us/round   GB/s")
+for (how, lb), (n, us, by) in sorted(cls.items()):
+    print("%3d  %10d  %6d  %9.1f  %9.2f  %7.1f" % (how, lb, n, us, us / n, by / us / 1e3))
+print("sum of round calls %.3f ms over %d rounds" % (sum(c[1] for c in cls.values()) / 1e3, sum(c[0] for c in cls.values())))

@@ -401,6 +401,44 @@ struct GenLiu {
     }
 };
 
+// Phase 2 (round 4): the mult / add entries of slot `row` from the v-sorted contribution list (contrib2<2>: eq(r_liu, g) eq(r_u, u) and V_u), and the
+// slot's V entry gathered through the slot map, inside the first fold launch of the sumcheck — the three tables of the long subsets are never
+// written nor read back (x1024: 48 B written + 48 B read per slot).  The tables of a phase 2 lie side by side in one slot space (t_off), so a
+// row index is the global slot; the short subsets (< one chunk) keep their light-row init (they are folded by k_seg / k_emit from memory).
+struct GenP2 {
+    static constexpr int MODE = 3;
+    const InitArgs2 *a;
+    __device__ __forceinline__ F vrow(u32 row, u32 vend) const {
+        if (row >= vend || row >= a->n_rows) return f_zero();
+        const int l = a->s_layer[row];
+        if (l == 0xff || l == 0xfe) return f_zero();
+        const u32 x = a->s_idx[row];
+        if (!VP_CHK((unsigned) l < g_vp_chk_layers() && x < g_vp_chk_lsize(l), 2, l, x, row)) return f_zero();
+        return a->vals[l][x];
+    }
+    __device__ __forceinline__ void ptrs(u32 r0, u32 valid, u32 &b0, u32 &e0, u32 &e1) const {
+        const u32 lim = min(valid, a->n_rows);
+        b0 = e0 = e1 = 0;
+        if (r0 >= lim) return;
+        b0 = a->rowptr[r0]; e0 = a->rowptr[r0 + 1];
+        e1 = r0 + 1 < lim ? a->rowptr[r0 + 2] : e0;
+    }
+    __device__ __forceinline__ void row2(u32 r0, u32 valid, u32 b0, u32 e0, u32 e1, F &m0, F &a0, F &m1, F &a1) const {
+        m0 = f_zero(); a0 = f_zero(); m1 = f_zero(); a1 = f_zero();
+        const u32 lim = min(valid, a->n_rows);
+        if (r0 >= lim) return;
+        const bool heavy0 = e0 - b0 > VP_LIGHT_MAX, heavy1 = e1 - e0 > VP_LIGHT_MAX;
+        if (heavy0) { m0 = a->M[r0]; a0 = a->A[r0]; }
+        if (heavy1) { m1 = a->M[r0 + 1]; a1 = a->A[r0 + 1]; }
+        const F vu = *a->Vu;
+        // the two rows' lists side by side: two dependent chains (record -> half-table entries -> products) in flight per lane
+        u32 k0 = heavy0 ? e0 : b0, k1 = heavy1 ? e1 : e0;
+        while (k0 < e0 && k1 < e1) { contrib2<2>(*a, k0++, m0, a0, vu); contrib2<2>(*a, k1++, m1, a1, vu); }
+        for (; k0 < e0; ++k0) contrib2<2>(*a, k0, m0, a0, vu);
+        for (; k1 < e1; ++k1) contrib2<2>(*a, k1, m1, a1, vu);
+    }
+};
+
 // Measured on this kernel (tools/micro_sumfold.hip and its -DVP_EXP_* probes, 2^24 entries, profiles/r01_j_micro_*.txt): 327 us
 // as is; 257 us with the global loads replaced by synthesised values (pure instruction issue: ~758 VALU instructions per wave
 // pair-step, 528 of them in the six multiply-adds); 175 us with the multiply-adds replaced by three cheap ops (memory + LDS +
@@ -435,7 +473,7 @@ __device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb,
         const SfTab td = a.t[j];
         const u32 cl = c - td.chunk_start;
         // logical wave / thread of this chunk: the waves that stay busy in rounds k+1 and k+2 change from chunk to chunk
-        const int wl = (VP_SF_ROTATE && Gen::MODE < 3 && !VP_SF_LDSPF) ? ((w + rot) & 3) : w;
+        const int wl = (VP_SF_ROTATE && !VP_SF_LDSPF) ? ((w + rot) & 3) : w;
         const int tl = (wl << 6) | lane;
         rot = (rot + 1) & 3;
         const u32 i0 = td.off + cl * 512 + 2 * tl, vend = td.off + td.valid;
@@ -477,7 +515,8 @@ __device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb,
                 }
             } else
 #endif
-            {
+            if constexpr (Gen::MODE == 3) { v0 = gen.vrow(i0, vend); v1 = gen.vrow(i0 + 1, vend); }      // phase 2: V through the slot map
+            else {
                 // a chunk that lies completely inside the table (all but the last one) is loaded without the per-entry bounds selects
                 if (cl * 512 + 512 <= td.valid) { v0 = a.inV[i0]; v1 = a.inV[i0 + 1]; }
                 else { v0 = ld_or_zero(a.inV, i0, vend); v1 = ld_or_zero(a.inV, i0 + 1, vend); }
@@ -492,7 +531,7 @@ __device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb,
                     if (HAS_A) { a0 = ld_or_zero(a.inA, i0, vend); a1 = ld_or_zero(a.inA, i0 + 1, vend); }
                 }
 #endif
-            } else {                      // generated tables: one table per job, offset 0
+            } else {                      // generated tables (GenP1 / GenLiu: one table per job, offset 0; GenP2: rows = global slots)
 #ifdef VP_GEN_ROW1
                 gen.row(i0, vend, m0, a0);
                 gen.row(i0 + 1, vend, m1, a1);
@@ -574,7 +613,7 @@ __device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb,
         F *o = a.part + (size_t) t * a.part_stride + bid * 3;
         o[0] = X; o[1] = (t == 0 ? keep_y0 : keep_rest) ? f_sub(f_sub(Y, X), Z) : f_zero(); o[2] = Z;       // b of the other rounds: derived by k_emit
     }
-    if constexpr (Gen::MODE == 1 || Gen::MODE == 3) {
+    if constexpr (Gen::MODE == 1) {
         if (gen.dot_part) {                              // uniform per launch
             F d[1] = {dacc};
             block_sum<1>(d, sm.dred);

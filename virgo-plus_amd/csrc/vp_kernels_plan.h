@@ -602,14 +602,17 @@ __global__ void __launch_bounds__(VP_BLOCK, VP_SF_MINB) k_sumfold3b_multi(const 
     const SfArgs &a = jobs[m.job];
     if (a.has_a) sumfold3b_body<true>(a, m.bid, a.nblk, sm, GenLoad()); else sumfold3b_body<false>(a, m.bid, a.nblk, sm, GenLoad());
 }
-// First fold launch of a phase-1 / Liu sumcheck with its init fused in (see GenP1 / GenLiu).
-struct SfGenJob { SfArgs sf; InitArgs2 a; GatherJob g; Half dot_h; F *dot_part; int mode; int pad; };   // mode 1: phase-1 init (GenP1), 2: Liu gather (GenLiu)
+// First fold launch of a phase-1 / Liu / phase-2 sumcheck with its init fused in (see GenP1 / GenLiu / GenP2).
+struct SfGenJob { SfArgs sf; InitArgs2 a; GatherJob g; Half dot_h; F *dot_part; int mode; int pad; };   // mode 1: phase-1 init (GenP1), 2: Liu gather (GenLiu), 3: phase-2 init (GenP2)
 __global__ void __launch_bounds__(VP_BLOCK, VP_SF_MINB) k_sumfold3b_gen_multi(const SfGenJob *__restrict__ jobs, const BlkMap *__restrict__ map) {
     __shared__ Sf3bLds sm;
     const BlkMap m = map[blockIdx.x];
     const SfGenJob &j = jobs[m.job];
     if (j.mode == 1) {
         GenP1 g; g.a = &j.a; g.dot_h = j.dot_h; g.dot_part = j.dot_part;
+        sumfold3b_body<true>(j.sf, m.bid, j.sf.nblk, sm, g);
+    } else if (j.mode == 3) {
+        GenP2 g; g.a = &j.a;
         sumfold3b_body<true>(j.sf, m.bid, j.sf.nblk, sm, g);
     } else {
         GenLiu g; g.rowptr = j.g.rowptr; g.e_q = j.g.e_q; g.e_g = j.g.e_g; g.H = j.g.H;
