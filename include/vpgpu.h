@@ -140,6 +140,9 @@ typedef struct {
     int32_t fuse_p2;                /* VP_FUSE_P2: launch plan — with fuse_init, the phase-2 init of a layer (src/prover.cpp:282-367) runs inside the first fold launch of its
                                        sumcheck too (GenP2): V through the slot map, mult / add entries from the v-sorted contribution list; the tables of the long
                                        subsets are never written at full length.  0: k_light_multi writes them, the fold launch reads them back  [1] */
+    int32_t leaf_asm;               /* VP_LEAF_ASM: the leaf-hash chains of the commitment (fri.cpp:96-124) by the generated fixed-register block (csrc/vp_keccak_asm.h,
+                                       tools/gen_keccak_asm.py): workgroups of 1024 threads whose waves rotate and do logic in phase.  0: the compiler's Keccak-f in
+                                       workgroups of 256 (the cross-check; always in the checked build)  [1] */
 } vp_options;
 void vp_options_default(vp_options *opt);
 

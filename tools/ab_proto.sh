@@ -1,11 +1,11 @@
 #!/bin/bash
 # A/B of run-time switches on the headline (x1024 + commitment): one bench run per setting, same box, same call.
-#   tools/ab_proto.sh "VAR=val ..." "VAR=val ..." ...      ("-" = defaults)
+#   [AB_BLOCKS=64] tools/ab_proto.sh "VAR=val ..." "VAR=val ..." ...      ("-" = defaults)
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$R"; mkdir -p gpurun_out
 i=0
 for E in "$@"; do
   i=$((i+1)); [ "$E" = "-" ] && E=""
-  env $E python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-x64-leg --detail-file gpurun_out/ab_proto_$i.json > gpurun_out/ab_proto_$i.line 2> gpurun_out/ab_proto_$i.err || { tail -5 gpurun_out/ab_proto_$i.err; exit 1; }
+  env $E python3 bench.py ${AB_BLOCKS:+--blocks $AB_BLOCKS} --steps 10 --warmup 3 --no-cpu-baseline --no-x64-leg --detail-file gpurun_out/ab_proto_$i.json > gpurun_out/ab_proto_$i.line 2> gpurun_out/ab_proto_$i.err || { tail -5 gpurun_out/ab_proto_$i.err; exit 1; }
   python3 - "$i" "$E" <<'PY'
 import json, sys
 d = json.load(open("gpurun_out/ab_proto_%s.json" % sys.argv[1]))

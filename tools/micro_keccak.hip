@@ -21,20 +21,15 @@ __global__ void __launch_bounds__(256) k_chain_c(const F *__restrict__ cw, u32 n
     h = hhash64(0, 0, 0, 0, h);
     out[t] = h;
 }
-__global__ void __launch_bounds__(256) k_chain_asm(const F *__restrict__ cw, u32 n, int n_slices, Dig *__restrict__ out) {
+#include "_build/vp_keccak_asm_fast.h"
+#include "_build/vp_keccak_asm_nobar.h"
+template <int V>
+__global__ void __launch_bounds__(1024) k_chain_asm(const F *__restrict__ cw, u32 n, int n_slices, Dig *__restrict__ out) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    unsigned h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    F x = cw[t], y = cw[n + t];
-    for (int s = 0; s <= n_slices; ++s) {                       // the last block is the mask slice's pair: zeros.  ONE instance of the 33 KB block
-        const unsigned m[8] = {(unsigned) x.re, (unsigned) (x.re >> 32), (unsigned) x.im, (unsigned) (x.im >> 32), (unsigned) y.re, (unsigned) (y.re >> 32), (unsigned) y.im, (unsigned) (y.im >> 32)};
-        if (s + 1 < n_slices) { x = cw[(size_t) (s + 1) * 2 * n + t]; y = cw[(size_t) (s + 1) * 2 * n + n + t]; }      // next slice's pair: in flight during the block
-        else { x = f_zero(); y = f_zero(); }
-        vp_hhash64_asm(h, m);
-    }
-    Dig d;
-    for (int i = 0; i < 4; ++i) d.w[i] = ((u64) h[2 * i + 1] << 32) | h[2 * i];
-    out[t] = d;
+    const u32 tc = t < n ? t : n - 1;
+    if (V == 0) vp_leaf_chain_asm(tc * 16u, cw, cw + n, 2u * n * 16u, (unsigned) n_slices, tc * 32u, out, t < n ? 1u : 0u);
+    else if (V == 1) vp_leaf_chain_asm_fast(tc * 16u, cw, cw + n, 2u * n * 16u, (unsigned) n_slices, tc * 32u, out, t < n ? 1u : 0u);
+    else vp_leaf_chain_asm_nobar(tc * 16u, cw, cw + n, 2u * n * 16u, (unsigned) n_slices, tc * 32u, out, t < n ? 1u : 0u);
 }
 int main() {
     const u32 n = 1u << 20; const int S = 64;
@@ -59,23 +54,28 @@ int main() {
         }
         printf("compiler version, at most %d waves per SIMD (LDS %zu B per workgroup): %.3f ms\n", wps, lds, bestw);
     }
-    const size_t lds_c = 0;
-    float best[2] = {1e9f, 1e9f};
-    for (int rep = 0; rep < 6; ++rep) {
-        for (int v = 0; v < 2; ++v) {
+    const char *names[4] = {"compiler (256-thread workgroups)", "asm, rot1 by alignbit, barriers", "asm, rot1 by add/shift/bitop3, barriers", "asm, rot1 by alignbit, NO barriers"};
+    float best[4] = {1e9f, 1e9f, 1e9f, 1e9f};
+    Dig *o3; CK(hipMalloc(&o3, n * sizeof(Dig)));
+    for (int rep = 0; rep < 5; ++rep) {
+        for (int v = 0; v < 4; ++v) {
             CK(hipEventRecord(e0));
-            if (v == 0) hipLaunchKernelGGL(k_chain_c, dim3(n / 256), dim3(256), lds_c, 0, cw, n, S, o1);
-            else hipLaunchKernelGGL(k_chain_asm, dim3(n / 256), dim3(256), 0, 0, cw, n, S, o2);
+            if (v == 0) hipLaunchKernelGGL(k_chain_c, dim3(n / 256), dim3(256), 0, 0, cw, n, S, o1);
+            else if (v == 1) hipLaunchKernelGGL(k_chain_asm<0>, dim3((n + 1023) / 1024), dim3(1024), 0, 0, cw, n, S, o2);
+            else if (v == 2) hipLaunchKernelGGL(k_chain_asm<1>, dim3((n + 1023) / 1024), dim3(1024), 0, 0, cw, n, S, o3);
+            else hipLaunchKernelGGL(k_chain_asm<2>, dim3((n + 1023) / 1024), dim3(1024), 0, 0, cw, n, S, o3);
             CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             if (rep) best[v] = ms < best[v] ? ms : best[v];
-            printf("rep %d %s %.3f ms  %.3e Keccak-f/s\n", rep, v ? "asm     " : "compiler", ms, (double) n * (S + 1) / (ms * 1e-3));
         }
     }
+    for (int v = 0; v < 4; ++v) printf("%-44s %.3f ms  %.3e Keccak-f/s  (%+.1f %% vs compiler)\n", names[v], best[v], (double) n * (S + 1) / (best[v] * 1e-3), 100.0 * (best[v] / best[0] - 1));
     std::vector<Dig> a(n), b(n);
     CK(hipMemcpy(a.data(), o1, n * sizeof(Dig), hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), o2, n * sizeof(Dig), hipMemcpyDeviceToHost));
     size_t bad = 0;
     for (u32 i = 0; i < n; ++i) for (int k = 0; k < 4; ++k) if (a[i].w[k] != b[i].w[k]) ++bad;
-    printf("digests differing words: %zu of %u   best compiler %.3f ms, asm %.3f ms (%.1f %%)\n", bad, 4 * n, best[0], best[1], 100.0 * (best[1] / best[0] - 1));
+    std::vector<Dig> c3(n); CK(hipMemcpy(c3.data(), o3, n * sizeof(Dig), hipMemcpyDeviceToHost));
+    size_t bad3 = 0; for (u32 i = 0; i < n; ++i) for (int k = 0; k < 4; ++k) if (a[i].w[k] != c3[i].w[k]) ++bad3;
+    printf("digests differing words: %zu (rot1 alignbit) %zu (no barriers) of %u\n", bad, bad3, 4 * n);
     return bad != 0;
 }

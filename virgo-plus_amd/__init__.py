@@ -26,7 +26,7 @@ LIB_HOST = os.path.join(HOST, "libvphost.so")
 CLI = os.path.join(HOST, "virgo_plus_run")
 
 GPU_SRC = [os.path.join(CSRC, f) for f in ("vpgpu.hip", "vpgpu_batched.inc", "vpgpu_pc.inc", "vpgpu_pc_shard.inc", "vpgpu_fftgkr.inc", "vpgpu_upload.inc", "vp_kernels_fftgkr.h", "vp_kernels.h", "vp_kernels_round.h", "vp_kernels_persist.h", "vp_kernels_batch.h",
-                                              "vp_kernels_plan.h", "vp_kernels_pc.h", "vp_kernels_ntt8.h", "vp_check.h", "vp_field.h")] + [
+                                              "vp_kernels_plan.h", "vp_kernels_pc.h", "vp_kernels_ntt8.h", "vp_keccak_asm.h", "vp_check.h", "vp_field.h")] + [
     os.path.join(ROOT, "include", "vpgpu.h")]
 HOST_SRC = [os.path.join(HOST, f) for f in ("circuit.cpp", "prover.cpp", "verifier.cpp", "vphost.cpp")]
 HOST_HDR = [os.path.join(HOST, f) for f in ("circuit.hpp", "prover.hpp", "verifier.hpp", "vphost.h", "field.hpp",
@@ -525,7 +525,7 @@ class Options(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_uint32)] + [(n, ctypes.c_int32) for n in (
         "gkr_path", "use_graph", "serial", "fuse_init", "fuse_min_log", "fuse_dot", "drop_y", "drop_y_round1", "real_values",
         "seg_tiny", "sf_big_log", "sf3b_grid", "dot_blocks", "plan_align", "xcd_map",
-        "round_fused_max", "persistent_rounds", "poll", "debug", "prefetch_round1", "split_cost_percent", "kernel_copies", "fold_branches", "ntt_scatter", "fuse_combine", "plan_autotune", "pc_tensor_pub", "persistent_timeout_ms", "graph_explicit", "ntt_r8", "fri_vo_fused", "interactive_fast_init", "fuse_p2")]
+        "round_fused_max", "persistent_rounds", "poll", "debug", "prefetch_round1", "split_cost_percent", "kernel_copies", "fold_branches", "ntt_scatter", "fuse_combine", "plan_autotune", "pc_tensor_pub", "persistent_timeout_ms", "graph_explicit", "ntt_r8", "fri_vo_fused", "interactive_fast_init", "fuse_p2", "leaf_asm")]
 
     def __init__(self, **kw):
         super().__init__()

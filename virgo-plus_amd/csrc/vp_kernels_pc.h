@@ -2,6 +2,7 @@
 // Part of the single translation unit vpgpu.hip (see vp_kernels.h for the overall layout rules).
 #pragma once
 #include "vp_kernels_round.h"
+#include "vp_keccak_asm.h"
 // Every product in this file is the plain split form: with the multiplier-shift form of the GKR kernels (vp_field.h, c31_add) the transforms
 // lose more than the pointwise kernels gain (commit side 70.8 -> 88.9 ms at x1024, same call).  Undone at the end of the file.
 #define f_mul f_mul_plain
@@ -283,7 +284,7 @@ __device__ __forceinline__ Dig hhash64(u64 m0, u64 m1, u64 m2, u64 m3, const Dig
 // The codeword is coset-major: cw[(s*32 + b)*N + a] = value at position 32a + b; position j + half is (a + N/2, b).
 // Thread t -> (b, a) with a fastest (coalesced loads); the digest goes to the natural leaf index 32a + b.
 __global__ void __launch_bounds__(VP_BLOCK)
-k_leaf_hash(const F *__restrict__ cw, u32 N, int n_slices, Dig *__restrict__ leaves) {
+k_leaf_hash_c(const F *__restrict__ cw, u32 N, int n_slices, Dig *__restrict__ leaves) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     const u32 halfN = N >> 1;
     if (t >= 32 * halfN) return;
@@ -304,8 +305,8 @@ k_leaf_hash(const F *__restrict__ cw, u32 N, int n_slices, Dig *__restrict__ lea
 // ONE launch hashes the leaves of all levels — the 65 chained Keccak-f of a leaf are a fixed latency (~0.8 ms for a lone
 // wave) that the per-step path pays once per level.
 #define VP_FRI_MAX 32
-struct FriLeafArgs { const F *cw[VP_FRI_MAX]; Dig *leaves[VP_FRI_MAX]; u32 N[VP_FRI_MAX]; u32 blk_start[VP_FRI_MAX + 1]; int n; };
-__global__ void __launch_bounds__(VP_BLOCK) k_leaf_hash_multi(FriLeafArgs a) {
+struct FriLeafArgs { const F *cw[VP_FRI_MAX]; Dig *leaves[VP_FRI_MAX]; u32 N[VP_FRI_MAX]; u32 blk_start[VP_FRI_MAX + 1]; u32 leaf_start[VP_FRI_MAX + 1]; int n; };     // blk_start: k_leaf_hash_multi_c, leaf_start: k_leaf_hash_multi
+__global__ void __launch_bounds__(VP_BLOCK) k_leaf_hash_multi_c(FriLeafArgs a) {
     int j = 0;
     while (j + 1 < a.n && blockIdx.x >= a.blk_start[j + 1]) ++j;
     const u32 t = (blockIdx.x - a.blk_start[j]) * blockDim.x + threadIdx.x;
@@ -333,6 +334,36 @@ __global__ void __launch_bounds__(VP_BLOCK) k_leaf_hash_multi(FriLeafArgs a) {
     a.leaves[j][32 * p + b] = h;
 }
 struct MerkleArgs { Dig *tree[VP_FRI_MAX]; u32 count[VP_FRI_MAX]; u32 blk_start[VP_FRI_MAX + 1]; int n; };
+// Round 4: the same leaf chains by the generated fixed-register block (vp_keccak_asm.h, tools/gen_keccak_asm.py): workgroups of 1024 threads, one per
+// CU, whose sixteen waves rotate (v_alignbit_b32, half rate) and do logic (v_bitop3_b32 / v_xor_b32, full rate) IN PHASE — a SIMD with waves in
+// both kinds of code at once issues everything at the rotation's rate.  x1024: 14.3 -> 11.6 ms per 2^21-leaf tree, digests unchanged.  A thread past
+// the end runs the chain of the last leaf (it must keep step with its workgroup) and stores nothing.  k_leaf_hash_c / k_leaf_hash_multi_c above are
+// the compiler's form of the same chains: the cross-check (leaf_asm = 0) and the checked build.
+__global__ void __launch_bounds__(VP_LEAF_ASM_THREADS)
+k_leaf_hash(const F *__restrict__ cw, u32 N, int n_slices, Dig *__restrict__ leaves) {
+    const u32 halfN = N >> 1, total = 32 * halfN;
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 tc = t < total ? t : total - 1;
+    const u32 a = tc % halfN, b = tc / halfN;
+    const F *x = cw + (size_t) b * N + a;
+    vp_leaf_chain_asm(x, x + halfN, 32u * N * 16u, (unsigned) n_slices, leaves + (32 * a + b), t < total ? 1u : 0u);
+}
+// All levels of the FRI commit phase in one launch: thread g takes leaf g of the levels laid end to end (leaf_start), so that the launch is exactly
+// ceil(leaves / workgroup) workgroups — a level of 16 leaves does not cost a workgroup (and with it a CU for the whole chain) of its own.
+__global__ void __launch_bounds__(VP_LEAF_ASM_THREADS) k_leaf_hash_multi(FriLeafArgs a) {
+    const u32 total = a.leaf_start[a.n];
+    const u32 g = blockIdx.x * blockDim.x + threadIdx.x, gc = g < total ? g : total - 1;
+    int j = 0;
+    while (j + 1 < a.n && gc >= a.leaf_start[j + 1]) ++j;
+    const u32 t = gc - a.leaf_start[j], N = a.N[j];
+    const F *cw = a.cw[j];
+    // the last level (one value per coset, leaf t pairs cosets t and t + 16 of every slice) is the same chain with other strides
+    const bool last = N == 1;
+    const u32 halfN = last ? 16u : N >> 1;
+    const u32 p = last ? t : t % halfN, b = last ? 0u : t / halfN;
+    const F *x = cw + (size_t) b * N + p;
+    vp_leaf_chain_asm(x, x + halfN, 32u * N * 16u, 64u, a.leaves[j] + (last ? t : 32 * p + b), g < total ? 1u : 0u);
+}
 __global__ void __launch_bounds__(VP_BLOCK) k_merkle_level_multi(MerkleArgs a) {
     int j = 0;
     while (j + 1 < a.n && blockIdx.x >= a.blk_start[j + 1]) ++j;
