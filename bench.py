@@ -51,7 +51,8 @@ FMUL_PEAK_PER_S = 7.0e11        # f_mul: 224.8 SIMD-cycles per wave-multiply
 KECCAK_INSTR_PER_ROUND = 180
 KECCAK_BEST_ISSUE_CYCLES = 2.78
 KECCAK_PEAK_PER_S = 1024 * 64 * 2.4e9 / (24 * KECCAK_INSTR_PER_ROUND * KECCAK_BEST_ISSUE_CYCLES)
-KECCAK_MIX_CYCLES_PER_WAVE_PERM = 24 * (120 * 3.20 + 58 * 4.43 + 2 * 2.78)      # the kernel's own mix at its measured per-instruction costs
+KECCAK_MIX_CYCLES_PER_WAVE_PERM = 24 * (122 * 2.26 + 58 * 4.21)      # the 180-instruction round with each class at its own best measured rate: 122 logic instructions (v_bitop3_b32 / v_xor_b32)
+                                                                      # at 2.26 cycles, 58 rotation halves (v_alignbit_b32, half rate) at 4.21 (tools/micro_keccak_parts.py, profiles/r04_micro_keccak_instruction_classes.txt)
 
 
 def pmc_traffic(blocks, kernel):
@@ -368,10 +369,10 @@ def pc_leg(vp, sess, circ, golden, gname, full_fixture=None):
         w, us = sum(e["work"] for e in leaf), sum(e["us"] for e in leaf)
         rl["k_leaf_hash"] = {"bound": "valu", "achieved": w / (us * 1e-6), "peak": KECCAK_PEAK_PER_S, "unit": "Keccak-f[1600]/s",
                              "frac": w / (us * 1e-6) / KECCAK_PEAK_PER_S, "time_share": us / tot,
-                             "frac_of_own_instruction_mix": w / (us * 1e-6) / (1024 * 64 * 2.4e9 / KECCAK_MIX_CYCLES_PER_WAVE_PERM),
+                             "frac_of_class_rate_floor": w / (us * 1e-6) / (1024 * 64 * 2.4e9 / KECCAK_MIX_CYCLES_PER_WAVE_PERM),
                              "peak_definition": "instruction-count floor x best issue rate: 24 rounds x %d VALU instructions (the 32-bit minimum: 120 v_bitop3_b32 + 58 v_alignbit_b32 + 2 v_xor_b32) "
                                                 "x %.2f SIMD-cycles per wave-instruction (the cheapest measured, tools/micro_rates.hip) on 1024 SIMDs x 64 lanes at 2.4 GHz; "
-                                                "frac_of_own_instruction_mix prices the same instructions at their own measured costs (3.20 / 4.43 / 2.78)" % (KECCAK_INSTR_PER_ROUND, KECCAK_BEST_ISSUE_CYCLES)}
+                                                "frac_of_class_rate_floor prices the 122 logic instructions of a round at 2.26 cycles and its 58 rotation halves at 4.21 (each class at its best measured rate)" % (KECCAK_INSTR_PER_ROUND, KECCAK_BEST_ISSUE_CYCLES)}
     if ntt:
         w, us = sum(e["work"] for e in ntt), sum(e["us"] for e in ntt)
         rl["k_ntt"] = {"bound": "valu", "achieved": w / (us * 1e-6), "peak": FMUL_PEAK_PER_S, "unit": "F_p^2 multiplications/s",
@@ -811,13 +812,14 @@ def keccak_roofline(stats, blocks):
     traffic, src = pmc_traffic(blocks, "k_leaf_hash")
     return {"kernel": "k_leaf_hash", "bound": "valu", "achieved": w / (us * 1e-6), "peak": KECCAK_PEAK_PER_S, "unit": "Keccak-f[1600]/s",
             "frac": w / (us * 1e-6) / KECCAK_PEAK_PER_S,
-            "frac_of_own_instruction_mix": w / (us * 1e-6) / (1024 * 64 * 2.4e9 / KECCAK_MIX_CYCLES_PER_WAVE_PERM),
+            "frac_of_class_rate_floor": w / (us * 1e-6) / (1024 * 64 * 2.4e9 / KECCAK_MIX_CYCLES_PER_WAVE_PERM),
             "launches": len(leaf), "avg_launch_us": us / len(leaf), "algorithmic_bytes_per_launch": by / len(leaf),
             "hbm_GBps": by / (us * 1e-6) / 1e9, "hbm_frac": by / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "hbm_peak_GBps": HBM_PEAK_GBPS,
             "traffic": traffic, "traffic_source": src, "kernel_time_share": us / tot,
             "peak_definition": "instruction-count floor x best issue rate: 24 rounds x %d VALU instructions (32-bit minimum: 120 v_bitop3_b32 + 58 v_alignbit_b32 + 2 v_xor_b32) x %.2f "
                                "SIMD-cycles per wave-instruction (cheapest measured, tools/micro_rates.hip), 1024 SIMDs x 64 lanes, 2.4 GHz; 65 chained permutations per leaf: "
-                               "integer-ALU-bound (SURVEY 8d: report hashes/s, not GB/s)" % (KECCAK_INSTR_PER_ROUND, KECCAK_BEST_ISSUE_CYCLES),
+                               "integer-ALU-bound (SURVEY 8d: report hashes/s, not GB/s).  Unchanged since round 2 so that `frac` compares across rounds; frac_of_class_rate_floor prices the 122 logic "
+                               "instructions of a round at 2.26 cycles and its 58 rotation halves (v_alignbit_b32, half rate) at 4.21 — what round 4's kernel (waves in phase, csrc/vp_keccak_asm.h) can reach" % (KECCAK_INSTR_PER_ROUND, KECCAK_BEST_ISSUE_CYCLES),
             "how": "HIP events around every launch on the library stream (vp_set_profiling), commit_private + commit_public + FRI commit phase of the same session"}
 
 
@@ -1045,7 +1047,7 @@ def compact_line(d, detail_file=None):
     roof = d.get("roofline")
     if isinstance(roof, dict):
         line["roofline"] = pick(roof, ("kernel", "bound", "achieved", "peak", "unit", "frac", "hbm_frac", "hbm_GBps", "traffic", "algorithmic_bytes_per_launch",
-                                       "avg_launch_us", "launches", "kernel_time_share", "frac_of_own_instruction_mix"))
+                                       "avg_launch_us", "launches", "kernel_time_share", "frac_of_class_rate_floor"))
         line["roofline"].setdefault("traffic", None)
     else:
         line["roofline"] = None

@@ -610,6 +610,23 @@ def test_protocol_pass_matches_reference(vp, golden, pws_path, name, blocks):
     s.close(); c.close()
 
 
+def test_leaf_hash_generated_chains_equal_the_compilers_at_every_workgroup_size(vp, pws_path):
+    """The leaf-hash chains of the commitment by the generated fixed-register block (csrc/vp_keccak_asm.h: workgroups of 1024 threads from 2^18 leaves on, of
+    512 at 2^17, waves in phase) against the compiler's Keccak-f in workgroups of 256 (leaf_asm = 0), on the whole prover pass of the protocol: x256 (2^19-leaf
+    trees; the FRI levels of 2^18 ... 16 leaves end to end in one launch) and x64 (2^17): transcript, Merkle roots, FRI roots and final codeword are equal."""
+    for blocks in (256, 64):
+        c = vp.Circuit.from_pws(pws_path, blocks, seed=1)
+        out = []
+        for asm in (1, 0):
+            s = vp.Session(c, options=vp.Options(leaf_asm=asm))
+            s.draw_protocol_tape()
+            tr, roots, fin, _ = s.prove_protocol()
+            out.append((tr, roots, fin.copy()))
+            s.close()
+        assert out[0][0] == out[1][0] and out[0][1] == out[1][1] and np.array_equal(out[0][2], out[1][2])
+        c.close()
+
+
 def test_commit_public_eq_equals_commit_public_on_the_table(vp, pws_path):
     """vp_commit_public_eq(point) == vp_commit_public(eq(point, .)): root, inner product, all_sum — for a random point, a point with a zero
     coordinate and a point with a coordinate 1 (pub[0] = 0: the tensor shortcut must step aside)."""

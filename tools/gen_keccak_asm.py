@@ -316,7 +316,7 @@ def emit_header(out, rot1, barriers):
         out.write('        "%s\\n\\t"\n' % t)
     out.write('        :\n')
     out.write('        : [addr0] "v"(addr0), [addr1] "v"(addr1), [stride] "v"(stride), [count] "s"(count), [out] "v"(out), [active] "v"(active)\n')
-    out.write('        : "memory", "vcc", "s44", "s45", "s46", "s47", %s);\n' % ", ".join('"v%d"' % r for r in regs["used"]))
+    out.write('        : "memory", "vcc", "scc", "s44", "s45", "s46", "s47", %s);\n' % ", ".join('"v%d"' % r for r in regs["used"]))
     out.write("}\n")
     sys.stderr.write("per block: %s; fixed registers %d\n" % (n, len(regs["used"])))
 

@@ -190,6 +190,7 @@ struct vp_ctx {
     std::recursive_mutex mu;         // held by every entry point for the duration of its call (CtxLock)
     bool plan_tuned = false;         // the plan layouts have been tried on this circuit (plan_autotune)
     bool plan_tune_cached = false;   // ... or taken from the process-wide table of an earlier context with the same plan shape
+    int leaf_attr_done = 0;          // leaf-hash kernels' dynamic-LDS attribute set on this context's device (1) / failed (-1)
     uint32_t opt_pinned = 0;         // tuner fields the caller (struct or environment) moved off their defaults: bit 0 fuse_combine, 1 fold_branches,
                                      // 2 plan_align, 3 fuse_min_log, 4 sf3b_grid, 5 graph_explicit — plan_autotune leaves those alone
     hipGraphExec_t gkr_graph = nullptr; int use_graph = 1; bool graph_failed = false; u64 graph_launches = 0, graph_rounds = 0;
