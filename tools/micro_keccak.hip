@@ -21,15 +21,15 @@ __global__ void __launch_bounds__(256) k_chain_c(const F *__restrict__ cw, u32 n
     h = hhash64(0, 0, 0, 0, h);
     out[t] = h;
 }
-#include "_build/vp_keccak_asm_fast.h"
-#include "_build/vp_keccak_asm_nobar.h"
+#include "_build/vp_keccak_asm_variants.h"      // tools/build_micro_keccak.sh: the generator's other variants under other names
 template <int V>
 __global__ void __launch_bounds__(1024) k_chain_asm(const F *__restrict__ cw, u32 n, int n_slices, Dig *__restrict__ out) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     const u32 tc = t < n ? t : n - 1;
-    if (V == 0) vp_leaf_chain_asm(tc * 16u, cw, cw + n, 2u * n * 16u, (unsigned) n_slices, tc * 32u, out, t < n ? 1u : 0u);
-    else if (V == 1) vp_leaf_chain_asm_fast(tc * 16u, cw, cw + n, 2u * n * 16u, (unsigned) n_slices, tc * 32u, out, t < n ? 1u : 0u);
-    else vp_leaf_chain_asm_nobar(tc * 16u, cw, cw + n, 2u * n * 16u, (unsigned) n_slices, tc * 32u, out, t < n ? 1u : 0u);
+    const F *x = cw + tc;
+    if (V == 0) vp_leaf_chain_asm(x, x + n, 2u * n * 16u, (unsigned) n_slices, out + tc, t < n ? 1u : 0u);
+    else if (V == 1) vp_leaf_chain_asm_rot1_alignbit(x, x + n, 2u * n * 16u, (unsigned) n_slices, out + tc, t < n ? 1u : 0u);
+    else vp_leaf_chain_asm_nobar(x, x + n, 2u * n * 16u, (unsigned) n_slices, out + tc, t < n ? 1u : 0u);
 }
 int main() {
     const u32 n = 1u << 20; const int S = 64;
@@ -54,7 +54,7 @@ int main() {
         }
         printf("compiler version, at most %d waves per SIMD (LDS %zu B per workgroup): %.3f ms\n", wps, lds, bestw);
     }
-    const char *names[4] = {"compiler (256-thread workgroups)", "asm, rot1 by alignbit, barriers", "asm, rot1 by add/shift/bitop3, barriers", "asm, rot1 by alignbit, NO barriers"};
+    const char *names[4] = {"compiler (256-thread workgroups)", "asm (product: rot1 by add/shift/bitop3), barriers", "asm, rot1 by alignbit, barriers", "asm (product form), NO barriers"};
     float best[4] = {1e9f, 1e9f, 1e9f, 1e9f};
     Dig *o3; CK(hipMalloc(&o3, n * sizeof(Dig)));
     for (int rep = 0; rep < 5; ++rep) {
@@ -76,6 +76,6 @@ int main() {
     for (u32 i = 0; i < n; ++i) for (int k = 0; k < 4; ++k) if (a[i].w[k] != b[i].w[k]) ++bad;
     std::vector<Dig> c3(n); CK(hipMemcpy(c3.data(), o3, n * sizeof(Dig), hipMemcpyDeviceToHost));
     size_t bad3 = 0; for (u32 i = 0; i < n; ++i) for (int k = 0; k < 4; ++k) if (a[i].w[k] != c3[i].w[k]) ++bad3;
-    printf("digests differing words: %zu (rot1 alignbit) %zu (no barriers) of %u\n", bad, bad3, 4 * n);
+    printf("digests differing words: %zu (product form) %zu (no barriers) of %u\n", bad, bad3, 4 * n);
     return bad != 0;
 }
