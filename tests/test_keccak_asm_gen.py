@@ -20,11 +20,12 @@ def test_generated_block_chains_sha3_256(rot1, dce):
 
 
 def test_bank_placement_of_the_generated_block():
-    code, regs = gen.build_body("fast", True)
+    code, regs = gen.build_body("alignbit", True)
     n = gen.stats(code)
     assert n["bitop3_bank_pairs"] <= 10 * 24          # chi's one forced pair per row and half, nothing else
     assert len(regs["used"]) <= 112 and max(regs["used"]) < gen.BASE + gen.SPAN
-    # phases: between two barriers either only rotations or no rotation at all
+    # with a barrier at both ends of a rotation phase: between two barriers either only rotations or no rotation at all
+    code, _ = gen.build_body("alignbit", True, bar_mode="both")
     kinds = set()
     for ins in code:
         if ins.text == "s_barrier":
@@ -32,10 +33,17 @@ def test_bank_placement_of_the_generated_block():
             kinds = set()
         elif ins.cls in ("slow", "fast"):
             kinds.add(ins.cls)
+    # the default keeps the one at the end of the rotation phase: every barrier is preceded by a rotation and followed by logic
+    code, _ = gen.build_body("alignbit", True)
+    valu = [i for i in code if i.cls in ("slow", "fast") or i.text == "s_barrier"]
+    for k, ins in enumerate(valu):
+        if ins.text == "s_barrier":
+            assert valu[k - 1].cls == "slow" and valu[k + 1].cls == "fast"
+    assert sum(1 for i in code if i.text == "s_barrier") == 48
 
 
 def test_committed_header_is_the_generators_output():
     buf = io.StringIO()
-    gen.emit_header(buf, "fast", True)
+    gen.emit_header(buf, "alignbit", True)
     with open(os.path.join(ROOT, "virgo-plus_amd", "csrc", "vp_keccak_asm.h")) as f:
         assert f.read() == buf.getvalue()

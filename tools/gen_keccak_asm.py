@@ -12,9 +12,12 @@ Why (measured, tools/micro_bank.py, tools/micro_keccak_parts.py, tools/micro_pha
   * a v_bitop3_b32 whose three DISTINCT sources have two registers in one bank (index mod 4) costs ~4.2 instead of ~2.5 in the logic phases: the state
     lanes and chi's staging registers are placed so that theta's sums have none and chi has the one pair per row that five lanes in four banks force;
   * the thirteen constant lanes of the padded block are folded at generation time and the last round keeps only what reaches the digest.
-Round structure (barrier = s_barrier, workgroup-wide):  [chi of the previous round + column sums C] | barrier | [rot(C, 1): 10 v_alignbit_b32] |
-barrier | [D = C ^ rot C, A ^= D: v_xor_b32] | barrier | [rho/pi: 48 v_alignbit_b32 into the staging registers] | barrier | ...
-(--rot1 fast: rot(C, 1) from v_add_u32 / v_lshrrev_b32 / v_bitop3_b32 inside the logic phase, two barriers per round.)
+Round structure (default: --rot1 alignbit --barrier-at after):  [chi of the previous round + column sums C] | [rot(C, 1): 10 v_alignbit_b32] | s_barrier |
+[D = C ^ rot C and A ^= D as v_xor_b32] | [rho/pi: 46 v_alignbit_b32 into the staging registers] | s_barrier | ...   A workgroup barrier at the END of every
+rotation phase is what measures best: the waves must START a logic phase together; a wave that reaches its rotations early only slows the others' last
+logic instructions.  Isolated, 2^20 leaves, same run (tools/micro_keccak.hip): this form 5.12-5.14 ms; rot(C, 1) from v_add_u32 / v_lshrrev_b32 /
+v_bitop3_b32 inside the logic phase (--rot1 fast, one barrier per round) 5.26-5.29; barriers at both ends of the rotation phases 5.59-5.65; a barrier only
+BEFORE the rotation phase 8.30; after rho only 5.81; every second round 6.22; none 8.06-8.26; the compiler's kernel 6.72.
 
     python3 tools/gen_keccak_asm.py [--rot1 alignbit|fast] [--no-barriers] > virgo-plus_amd/csrc/vp_keccak_asm.h
 """
@@ -64,7 +67,7 @@ class Ins:
         self.text, self.dst, self.srcs, self.keep, self.cls = text, dst, list(srcs), keep, cls
 
 
-def build_body(rot1="alignbit", barriers=True, rounds=24, dce=True):
+def build_body(rot1="alignbit", barriers=True, rounds=24, dce=True, msg_after_barrier=True, bar_mode="after", bar_every=1):
     """-> (instructions of ONE block of the chain, register map).  In: the message in M[0..8) (lanes 0-3), the previous digest in the state registers
     of lanes (0..3, 0); out: the digest in the same registers.  The marker instruction 'MSG_DEAD' sits where M is free for the next block's loads."""
     pool = Pool(BASE, SPAN)
@@ -90,8 +93,11 @@ def build_body(rot1="alignbit", barriers=True, rounds=24, dce=True):
     def emit(text, dst, srcs, cls="fast"):
         code.append(Ins(text, dst, [s for s in srcs if s is not None and s.startswith("v")], cls=cls))
 
-    def barrier():
-        if barriers:
+    cur_round = [0]
+
+    def barrier(kind="before", phase="rho"):           # the barrier stands before / after a rotation phase (rho's, or the one of the ten rotations by 1);
+        on = bar_mode in ("both", kind) or ("%s_%s" % (phase, kind)) in bar_mode.split(",")      # bar_mode: both | before | after | a list like rho_after,rot1_after
+        if barriers and on and cur_round[0] % bar_every == bar_every - 1:
             code.append(Ins("s_barrier", keep=True, cls="sync"))
 
     def xor_into(dst, vals, force=False):
@@ -148,6 +154,7 @@ def build_body(rot1="alignbit", barriers=True, rounds=24, dce=True):
     S[8 % 5][8 // 5] = [Val(const=0x06), Val(const=0)]
     S[16 % 5][16 // 5] = [Val(const=0), Val(const=0x80000000)]
     for rnd in range(rounds):
+        cur_round[0] = rnd
         # ---- logic: column sums
         Cv = []
         for x in range(5):
@@ -165,9 +172,9 @@ def build_body(rot1="alignbit", barriers=True, rounds=24, dce=True):
         # ---- rot(C, 1) and D
         Dv = []
         if rot1 == "alignbit":
-            barrier()
+            barrier("before", "rot1")
             Rv = [rot64(Cv[x][0], Cv[x][1], 1, R[x][0], R[x][1]) for x in range(5)]
-            barrier()
+            barrier("after", "rot1")
             for x in range(5):
                 Dv.append([xor_into(D[x][h], [Cv[(x + 4) % 5][h], Rv[(x + 1) % 5][h]], force=True) for h in range(2)])
         else:
@@ -193,8 +200,10 @@ def build_body(rot1="alignbit", barriers=True, rounds=24, dce=True):
             for h in range(2):
                 S[x][y][h] = xor_into(A[x][y][h], [S[x][y][h], Dv[x][h]], force=True)
         # ---- rho + pi: every lane into its staging register
-        barrier()
-        if rnd == 0:                       # the message registers are free from here on; the address arithmetic and the loads of the next block sit at the
+        if rnd == 0 and not msg_after_barrier:
+            code.append(Ins("MSG_DEAD", keep=True, cls="sync"))
+        barrier("before")
+        if rnd == 0 and msg_after_barrier: # the message registers are free from here on; the address arithmetic and the loads of the next block sit at the
             code.append(Ins("MSG_DEAD", keep=True, cls="sync"))      # start of a rotation phase (whatever their issue class, they do not slow a logic phase)
         Bv = [[None] * 5 for _ in range(5)]
         for Y in range(5):
@@ -203,7 +212,7 @@ def build_body(rot1="alignbit", barriers=True, rounds=24, dce=True):
                 x = next(xx for xx in range(5) if (2 * xx + 3 * y) % 5 == Y)
                 d = B[X][Y] if B[X][Y][0] else [None, None]
                 Bv[X][Y] = rot64(S[x][y][0], S[x][y][1], ROT[x][y], d[0], d[1])
-        barrier()
+        barrier("after")
         # ---- chi (+ iota), in place in the state registers.  B[0][0] IS the state register of lane (0,0) (rotation by 0): in row 0 the lane X = 0
         # is written last, after the lanes X = 3, 4 that read it
         for Y in range(5):
@@ -255,8 +264,8 @@ def stats(code):
     return n
 
 
-def emit_header(out, rot1, barriers):
-    code, regs = build_body(rot1, barriers)
+def emit_header(out, rot1, barriers, msg_after=True, addr="mad", bar_mode="after", bar_every=1):
+    code, regs = build_body(rot1, barriers, msg_after_barrier=msg_after, bar_mode=bar_mode, bar_every=bar_every)
     n = stats(code)
     M, dig = regs["M"], regs["digest"]
     mlo, mhi = int(M[0][1:]), int(M[7][1:])
@@ -264,6 +273,7 @@ def emit_header(out, rot1, barriers):
     L = []                                       # asm lines
     L.append("v_mov_b64 v[%d:%d], %%[addr0]" % (a0, a0h))
     L.append("v_mov_b64 v[%d:%d], %%[addr1]" % (a1, a1h))
+    L.append("s_mov_b32 s45, 0")
     L.append("s_add_u32 s44, %[count], 1")       # blocks of the chain: the slices' pairs and the mask slice's (all zero, src/prover.cpp:526)
     L.append("global_load_dwordx4 v[%d:%d], v[%d:%d], off" % (mlo, mlo + 3, a0, a0h))
     L.append("global_load_dwordx4 v[%d:%d], v[%d:%d], off" % (mlo + 4, mhi, a1, a1h))
@@ -276,10 +286,15 @@ def emit_header(out, rot1, barriers):
             # the message registers are free: the next block's pair on its way (or zeros for the mask slice's block)
             L.append("s_cmp_le_u32 s44, 2")
             L.append("s_cbranch_scc1 2f")
-            L.append("v_add_co_u32 v%d, vcc, %%[stride], v%d" % (a0, a0))
-            L.append("v_addc_co_u32 v%d, vcc, 0, v%d, vcc" % (a0h, a0h))
-            L.append("v_add_co_u32 v%d, vcc, %%[stride], v%d" % (a1, a1))
-            L.append("v_addc_co_u32 v%d, vcc, 0, v%d, vcc" % (a1h, a1h))
+            if addr == "add":
+                L.append("v_add_co_u32 v%d, vcc, %%[stride], v%d" % (a0, a0))
+                L.append("v_addc_co_u32 v%d, vcc, 0, v%d, vcc" % (a0h, a0h))
+                L.append("v_add_co_u32 v%d, vcc, %%[stride], v%d" % (a1, a1))
+                L.append("v_addc_co_u32 v%d, vcc, 0, v%d, vcc" % (a1h, a1h))
+            else:                                    # address of block k = address of block 0 + k * stride: one multiply-add per address
+                L.append("s_add_u32 s45, s45, 1")
+                L.append("v_mad_u64_u32 v[%d:%d], vcc, s45, %%[stride], %%[addr0]" % (a0, a0h))
+                L.append("v_mad_u64_u32 v[%d:%d], vcc, s45, %%[stride], %%[addr1]" % (a1, a1h))
             L.append("global_load_dwordx4 v[%d:%d], v[%d:%d], off" % (mlo, mlo + 3, a0, a0h))
             L.append("global_load_dwordx4 v[%d:%d], v[%d:%d], off" % (mlo + 4, mhi, a1, a1h))
             L.append("s_branch 3f")
@@ -300,7 +315,8 @@ def emit_header(out, rot1, barriers):
     L.append("global_store_dwordx4 %%[out], v[%d:%d], off" % (mlo, mlo + 3))
     L.append("global_store_dwordx4 %%[out], v[%d:%d], off offset:16" % (mlo + 4, mhi))
     L.append("s_mov_b64 exec, s[46:47]")
-    out.write("// GENERATED by tools/gen_keccak_asm.py --rot1 %s%s — do not edit.\n" % (rot1, "" if barriers else " --no-barriers"))
+    flags = ("" if rot1 == "alignbit" else "--rot1 " + rot1) + ("" if barriers else " --no-barriers") + ("" if msg_after else " --msg-before-barrier") + ("" if addr == "mad" else " --addr add") + ("" if bar_mode == "after" else " --barrier-at " + bar_mode) + ("" if bar_every == 1 else " --barrier-every %d" % bar_every)
+    out.write("// GENERATED by tools/gen_keccak_asm.py%s — do not edit.\n" % ((" " + flags.strip()) if flags.strip() else ""))
     out.write("// The leaf-hash chain (fri.cpp:96-124: SHA3-256 over (pair of slice s || previous digest), s = 0 .. count-1, then the all-zero pair of the mask slice) for\n")
     out.write("// workgroups of up to VP_LEAF_ASM_THREADS threads, ONE per CU, waves in phase.  Per block of the chain: %d v_bitop3_b32 (%d with two sources in one bank),\n"
               % (n["bitop3"], n["bitop3_bank_pairs"]))
@@ -329,4 +345,7 @@ if __name__ == "__main__":
         rot1 = args[args.index("--rot1") + 1]
     if "--no-barriers" in args:
         barriers = False
-    emit_header(sys.stdout, rot1, barriers)
+    addr = args[args.index("--addr") + 1] if "--addr" in args else "mad"
+    bar_mode = args[args.index("--barrier-at") + 1] if "--barrier-at" in args else "after"
+    bar_every = int(args[args.index("--barrier-every") + 1]) if "--barrier-every" in args else 1
+    emit_header(sys.stdout, rot1, barriers, "--msg-before-barrier" not in args, addr, bar_mode, bar_every)
