@@ -32,7 +32,7 @@ def canned_detail(n_kernels=40, n_launches=400):
         "bit_exact": {"transcript": True, "fri_roots": True, "fri_final_codeword": True, "complete_protocol_accepted": True, "interactive_run_equals_batched": True},
         "bit_exact_all_ranks": True,
         "roofline": {"kernel": "k_leaf_hash", "bound": "valu", "achieved": 9.33e9, "peak": 1.3096722621e10, "unit": "Keccak-f[1600]/s", "frac": 0.7125274069844166,
-                     "frac_of_class_rate_floor": 0.86, "launches": 3, "avg_launch_us": 14607.57, "algorithmic_bytes_per_launch": 4362065000.0, "hbm_GBps": 298.6,
+                     "frac_of_round3_peak_definition": 0.92, "launches": 3, "avg_launch_us": 14607.57, "algorithmic_bytes_per_launch": 4362065000.0, "hbm_GBps": 298.6,
                      "hbm_frac": 0.0373, "traffic": None, "traffic_source": None, "kernel_time_share": 0.55, "peak_definition": "p" * 700, "how": "h" * 300},
         "roofline_gkr_dominant": {"kernel": "k_sumfold3b_gen_multi", "bound": "valu", "frac": 0.38, "hbm_frac": 0.28, "avg_launch_us": 1616.0, "kernel_time_share": 0.5,
                                   "measured_limiter": "m" * 600},
