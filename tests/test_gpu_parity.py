@@ -177,6 +177,22 @@ def test_chain_sharded_proof_randomize_and_fused_init(vp, golden, gold_gkr, monk
     s.close(); c.close()
 
 
+@pytest.mark.parametrize("ge", [1, 2, 3])
+def test_every_explicit_graph_form_on_sharded_plans(vp, golden, gold_gkr, pws_path, ge):
+    """The plan tuner picks among the graph forms (vp_options.graph_explicit 0-3) on unsharded plans only; a caller may pin any of them, so each explicit
+    form is instantiated and replayed here on the plans the tuner never sees: the chain shards of 3 ranks and the index-split shards of 2 (every rank in
+    turn on this GPU, graph replayed twice), assembling to the real reference's transcript."""
+    c = vp.Circuit.from_pws(pws_path, 16, seed=1)
+    s = vp.Session(c, options=vp.Options(graph_explicit=ge, plan_autotune=0))
+    s.draw_tape()
+    gold = gold_gkr("sha256_x16")
+    assert vp.sum_transcripts(_sharded_parts(vp, s, 3)) == gold
+    assert _split_parts(vp, s, 2) == gold
+    tr, _ = s.prove_gkr()
+    assert tr == gold and s.options_in_effect().graph_explicit == ge
+    s.close(); c.close()
+
+
 def _split_parts(vp, s, world, min_log=11):
     """The outputs (partial transcript + export area) of all ranks of an index-split proof, one after the other on this GPU."""
     parts = []
