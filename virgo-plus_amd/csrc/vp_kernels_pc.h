@@ -518,27 +518,40 @@ k_fri_fold(const F *__restrict__ in, F *__restrict__ out, u32 Nk, int k, const F
 // — the same field element as k_fri_fold(k = 0) on the materialised oracle (every operation is exact), ten multiplications per output instead
 // of thirteen, and 64 M x 16 B less written and read back (x1024: 8.6 GB).  Openings never read the oracle itself (fri.cpp:148-287 open l, h
 // and the folded levels), so nothing else needs it.  Unsharded commitment only (lw = 0).
+// A thread takes VP_VO_SPT slices of one position (b, a): x^-1, x^-1 r and (N/2) x^-1 depend on the position only (three of the eleven multiplications per
+// output), and with a tensor public vector so do the two loads of its one encoded slice.
+#define VP_VO_SPT 4
 __global__ void __launch_bounds__(VP_BLOCK)
 k_fri_fold0_vo(const F *__restrict__ lcw, const F *__restrict__ qcw, const F *__restrict__ hcw, const F *__restrict__ S0, F *__restrict__ out, u32 N,
                const F *__restrict__ RTn /* w_N^k, k < N */, const F *__restrict__ cb /* [b] = w_M^-b, [32 + b] = w_32^b - 1 */, F r, F half_n /* N / 2 */,
                const F *__restrict__ q0, const F *__restrict__ qscal) {
     const size_t t = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
     const u32 No = N >> 1;
-    if (t >= (size_t) 64 * 32 * No) return;
-    const u32 al = (u32) (t % No), sb = (u32) (t / No), b = sb & 31, i = sb >> 5;
-    const size_t p0 = (size_t) sb * N + al, p1 = p0 + No;
+    if (t >= (size_t) (64 / VP_VO_SPT) * 32 * No) return;
+    const u32 al = (u32) (t % No), sb = (u32) (t / No), b = sb & 31, ig = sb >> 5;
     const F wa = RTn[(N - al) & (N - 1)];                                     // w_N^-a = w_M^-(32 a): contiguous along the lanes
-    F qa, qb;
-    if (q0) { const F sc = qscal[i]; const size_t o = (size_t) b * N + al; qa = f_mul(sc, q0[o]); qb = f_mul(sc, q0[o + No]); }
-    else { qa = qcw[p0]; qb = qcw[p1]; }
-    const F la = lcw[p0], lb = lcw[p1], ha = hcw[p0], hb = hcw[p1];
+    F q0a = f_zero(), q0b = f_zero();
+    if (q0) { const size_t o = (size_t) b * N + al; q0a = q0[o]; q0b = q0[o + No]; }
+    F la[VP_VO_SPT], lb[VP_VO_SPT], ha[VP_VO_SPT], hb[VP_VO_SPT], qa[VP_VO_SPT], qb[VP_VO_SPT];
+#pragma unroll
+    for (int k = 0; k < VP_VO_SPT; ++k) {
+        const size_t p0 = ((size_t) (ig * VP_VO_SPT + k) * 32 + b) * N + al, p1 = p0 + No;
+        la[k] = lcw[p0]; lb[k] = lcw[p1]; ha[k] = hcw[p0]; hb[k] = hcw[p1];
+        if (!q0) { qa[k] = qcw[p0]; qb[k] = qcw[p1]; }
+    }
     loads_first();
     const F inv_x = f_mul(wa, cb[b]);                                         // x^-1, x = w_M^(32 a + b)
     const F xn_m1 = cb[32 + b];                                               // x^N - 1 = w_32^b - 1: the same for both positions
-    const F s0 = S0[i];
-    const F Ga = f_sub(f_sub(f_mul(la, qa), f_mul(xn_m1, ha)), s0), Gb = f_sub(f_sub(f_mul(lb, qb), f_mul(xn_m1, hb)), s0);
-    const F D = f_sub(Ga, Gb), S = f_add(Ga, Gb);
-    out[t] = f_mul(f_mul(half_n, inv_x), f_add(D, f_mul(f_mul(inv_x, r), S)));
+    const F xr = f_mul(inv_x, r), hx = f_mul(half_n, inv_x);
+#pragma unroll
+    for (int k = 0; k < VP_VO_SPT; ++k) {
+        const u32 i = ig * VP_VO_SPT + k;
+        if (q0) { const F sc = qscal[i]; qa[k] = f_mul(sc, q0a); qb[k] = f_mul(sc, q0b); }
+        const F s0 = S0[i];
+        const F Ga = f_sub(f_sub(f_mul(la[k], qa[k]), f_mul(xn_m1, ha[k])), s0), Gb = f_sub(f_sub(f_mul(lb[k], qb[k]), f_mul(xn_m1, hb[k])), s0);
+        const F D = f_sub(Ga, Gb), S = f_add(Ga, Gb);
+        out[((size_t) i * 32 + b) * No + al] = f_mul(hx, f_add(D, f_mul(xr, S)));
+    }
 }
 // The last fold leaves ONE value per coset (32 per slice); its 16 leaves pair coset b with coset b + 16.
 __global__ void k_leaf_hash_final(const F *__restrict__ cw, int n_slices, Dig *__restrict__ leaves) {
