@@ -496,21 +496,35 @@ k_pc_virtual_oracle(const F *__restrict__ lcw, F *__restrict__ qcw, const F *__r
 // mu = w_k^(32a+b) with w_k = w_M^(2^k) the generator of the current domain (fri.cpp:312-331).
 // Position-sharded commitment (vpgpu_pc_shard.inc): a rank holds the positions a = a' * 2^lw + rank of every coset; Nk is then the
 // LOCAL per-coset length and the twiddle uses the global position.  lw = rank = 0: the whole codeword.
+// x / 2 for canonical limbs: (x + p) / 2 when x is odd — the same field element as x * 2^-1, without the multiplier
+__device__ __forceinline__ u64 m_half(u64 x) { return (x + ((x & 1) ? P61 : 0ull)) >> 1; }
+__device__ __forceinline__ F f_half(const F &x) { return f_make(m_half(x.re), m_half(x.im)); }
+// A thread takes VP_FOLD_SPT slices of one position: mu^-1 r / 2 is per position, so a fold costs ONE multiplication per output (and a halving) instead of three.
+#define VP_FOLD_SPT 4
 __global__ void __launch_bounds__(VP_BLOCK)
 k_fri_fold(const F *__restrict__ in, F *__restrict__ out, u32 Nk, int k, const F *__restrict__ RT, u32 half_m, F r, F inv2, int lw, u32 rank) {
     const size_t t = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
     const u32 No = Nk >> 1;                                   // per-coset length of the output (>= 1)
-    if (t >= (size_t) 64 * 32 * No) return;
-    const u32 al = (u32) (t % No), sb = (u32) (t / No);       // sb = slice * 32 + coset
+    if (t >= (size_t) (64 / VP_FOLD_SPT) * 32 * No) return;
+    const u32 al = (u32) (t % No), gb = (u32) (t / No), b = gb & 31, ig = gb >> 5;
     const u32 a = (al << lw) + rank;
-    const u32 b = sb & 31;
     const u32 M = 2 * half_m;
     const u32 e = (u32) ((((unsigned long long) (32 * a + b)) << k) & (M - 1));
     const F inv_mu = root_pow(RT, half_m, e ? M - e : 0);
-    F p, q;
-    if (Nk >= 2) { p = in[(size_t) sb * Nk + al]; q = in[(size_t) sb * Nk + al + No]; }
-    else { p = f_zero(); q = f_zero(); }
-    out[t] = f_mul(inv2, f_add(f_add(p, q), f_mul(f_mul(inv_mu, r), f_sub(p, q))));
+    F p[VP_FOLD_SPT], q[VP_FOLD_SPT];
+#pragma unroll
+    for (int j = 0; j < VP_FOLD_SPT; ++j) {
+        const size_t sb = (size_t) (ig * VP_FOLD_SPT + j) * 32 + b;
+        if (Nk >= 2) { p[j] = in[sb * Nk + al]; q[j] = in[sb * Nk + al + No]; }
+        else { p[j] = f_zero(); q[j] = f_zero(); }
+    }
+    loads_first();
+    const F c = f_mul(inv2, f_mul(inv_mu, r));                // mu^-1 r / 2
+#pragma unroll
+    for (int j = 0; j < VP_FOLD_SPT; ++j) {
+        const size_t sb = (size_t) (ig * VP_FOLD_SPT + j) * 32 + b;
+        out[sb * No + al] = f_add(f_half(f_add(p[j], q[j])), f_mul(c, f_sub(p[j], q[j])));      // 1/2 ((p + q) + mu^-1 r (p - q))
+    }
 }
 // Round 4: the FIRST fold straight from the three committed codewords — the virtual oracle (k_pc_virtual_oracle) is never written.  With
 // G(a) = l q - (x^N - 1) h - S0 at position (b, a) and X = N x^-1, the oracle is G X; its partner at a + N/2 sits at -x (w_M^(16 N) = -1), so
