@@ -143,6 +143,9 @@ typedef struct {
     int32_t leaf_asm;               /* VP_LEAF_ASM: the leaf-hash chains of the commitment (fri.cpp:96-124) by the generated fixed-register block (csrc/vp_keccak_asm.h,
                                        tools/gen_keccak_asm.py): workgroups of 1024 threads whose waves rotate and do logic in phase.  0: the compiler's Keccak-f in
                                        workgroups of 256 (the cross-check; always in the checked build)  [1] */
+    int32_t real_pairs;             /* VP_REAL_PAIRS: vp_commit_private of a REAL witness (every circuit value real) sends two slices through each transform as one complex
+                                       sequence x + i x' (the coefficients of a real sequence are Hermitian, so a coset's values of both slices separate again at the
+                                       encoder's last store): half the transforms of the call, the same codeword.  0: one transform per slice  [1] */
 } vp_options;
 void vp_options_default(vp_options *opt);
 

@@ -643,6 +643,25 @@ def test_leaf_hash_generated_chains_equal_the_compilers_at_every_workgroup_size(
         c.close()
 
 
+@pytest.mark.parametrize("blocks", [64, 256])
+def test_commit_private_two_real_slices_per_transform(vp, golden, pws_path, blocks):
+    """vp_commit_private of a real witness sends slices p and p + 32 through each transform as ONE complex sequence (real_pairs; the encoder's last store
+    separates the two slices' values on every coset): the root equals the one-transform-per-slice form's (and, at x64, the real reference's)."""
+    c = vp.Circuit.from_pws(pws_path, blocks, seed=1)
+    roots = []
+    for rp in (1, 0):
+        s = vp.Session(c, options=vp.Options(real_pairs=rp))
+        root, _ = s.commit_private()
+        roots.append(root)
+        s.close()
+    assert roots[0] == roots[1]
+    if blocks == 64:
+        import os
+        from conftest import GOLDEN
+        assert roots[0] == open(os.path.join(GOLDEN, golden["sha256_x64"]["transcript"]), "rb").read()[:32]
+    c.close()
+
+
 def test_commit_public_eq_equals_commit_public_on_the_table(vp, pws_path):
     """vp_commit_public_eq(point) == vp_commit_public(eq(point, .)): root, inner product, all_sum — for a random point, a point with a zero
     coordinate and a point with a coordinate 1 (pub[0] = 0: the tensor shortcut must step aside)."""

@@ -49,6 +49,9 @@ VP_HD F f_add(const F &a, const F &b) { return f_make(m_add(a.re, b.re), m_add(a
 VP_HD F f_sub(const F &a, const F &b) { return f_make(m_sub(a.re, b.re), m_sub(a.im, b.im)); }
 VP_HD F f_neg(const F &a) { return f_make(a.re ? P61 - a.re : 0, a.im ? P61 - a.im : 0); }
 VP_HD F f_dbl(const F &a) { return f_add(a, a); }
+// x / 2 for canonical limbs: (x + p) / 2 when x is odd — the same field element as x * 2^-1, without the multiplier
+VP_HD u64 m_half(u64 x) { return (x + ((x & 1) ? P61 : 0ull)) >> 1; }
+VP_HD F f_half(const F &x) { return f_make(m_half(x.re), m_half(x.im)); }
 
 VP_HD F f_mul128(const F &a, const F &b) {      // Karatsuba on 128-bit products (host code, and the reference point of the tests)
     const u128 C = ((u128) P61) << 61;           // multiple of p, >= any product of two canonical limbs

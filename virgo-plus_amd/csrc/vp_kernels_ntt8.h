@@ -83,6 +83,12 @@ struct Ntt8Args {
     u32 ncoset;                     // forward encoder: cosets per row (blockIdx.z); otherwise 1
     int twist;                      // cols: multiply input j by w_M^(j coset)
     int do_scale; F scale;          // rows: multiply by N^-1 on the way out (inverse transforms)
+    // Two REAL sequences per complex transform (commit_private of a real witness, round 4): row p carries slices p and p + pair_rows as x_p + i x_(p + pair_rows).
+    //   cols, inverse: in2 != nullptr — the eight inputs of the first pass are (in[..].re, in2[..].re); the output E = c + i c' (coefficients of both slices);
+    //   rows, forward: pair_rows != 0 — a transform of E on coset b gives Y = E_0 + sigma_b (rho + i rho'), rho, rho' REAL (the coefficients of a real sequence are
+    //     Hermitian, c_(N-j) = conj(c_j), and x^N = zeta_b = sigma_b^2 on the coset), so with Z = zeta_b conj(Y - E_0):
+    //     slice p: Re(E_0) + ((Y - E_0) + Z) / 2,   slice p + pair_rows: Im(E_0) + (-i) ((Y - E_0) - Z) / 2   — the same field elements as two transforms.
+    const F *in2; u32 pair_rows; const F *e0;        // e0: E_0 of row p at e0[p << ln] (the coefficient array the transform reads)
 };
 
 constexpr u32 NTT8_TILE = 4096;     // elements of a workgroup's tile (64 KiB of LDS; two workgroups per CU)
@@ -110,6 +116,11 @@ __global__ void __launch_bounds__(NTT8_THREADS) __attribute__((amdgpu_waves_per_
         F u[8];
 #pragma unroll
         for (u32 m = 0; m < 8; ++m) u[m] = src[(size_t) (q + m * (N1 >> 3)) * N2];
+        if (a.in2) {                                            // uniform: two real slices as one complex sequence
+            const F *src2 = a.in2 + (size_t) row * a.in_stride + j2;
+#pragma unroll
+            for (u32 m = 0; m < 8; ++m) u[m].im = src2[(size_t) (q + m * (N1 >> 3)) * N2].re;
+        }
         if (a.twist && coset) {
             // the j1 share of w_M^(j coset), j1 = q + m N1 / 8 (j2's share joins the output twiddle): exponents e0 + m step (mod M)
             const u32 e0 = q * N2 * coset, step = (N1 >> 3) * N2 * coset;
@@ -274,6 +285,23 @@ __global__ void __launch_bounds__(NTT8_THREADS, 2) k_ntt8_rows(Ntt8Args a) {
         __syncthreads();
     }
     // natural order: element k2 of row k1 goes to k1 + N1 k2 — the tile's eight k1 are consecutive: 128 contiguous bytes per k2
+    if (a.pair_rows) {                                            // uniform: the two real slices of this row, see Ntt8Args
+        const u32 pr = rt / a.ncoset, coset = rt - pr * a.ncoset, M = 2 * a.half_m;
+        const F E0 = a.e0[(size_t) pr << a.ln];
+        const F zeta = a.RT[(coset * (M / a.ncoset)) & (M - 1)];  // w_ncoset^coset = x^N on the coset
+        F *d1 = a.out + (((size_t) pr * a.ncoset + coset) << a.ln) + k1_0;
+        F *d2 = a.out + (((size_t) (pr + a.pair_rows) * a.ncoset + coset) << a.ln) + k1_0;
+#pragma unroll
+        for (u32 it = 0; it < 8; ++it) {
+            const u32 e = it * NTT8_THREADS + tid, cc = e & 7, k2 = e >> 3;
+            const F Y = f_sub(lz_canon(L[cc * NTT8_PITCH + ntt8_pad(k2)]), E0);
+            const F Z = f_mul_plain(zeta, f_make(Y.re, Y.im ? P61 - Y.im : 0));
+            const F s = f_half(f_add(Y, Z)), d = f_half(f_sub(Y, Z));
+            d1[(size_t) k2 * N1 + cc] = f_make(m_add(s.re, E0.re), s.im);
+            d2[(size_t) k2 * N1 + cc] = f_make(m_add(d.im, E0.im), d.re ? P61 - d.re : 0);       // -i (x + i y) = y - i x
+        }
+        return;
+    }
     F *dst = a.out + ((size_t) rt << a.ln) + k1_0;
 #pragma unroll
     for (u32 it = 0; it < 8; ++it) {

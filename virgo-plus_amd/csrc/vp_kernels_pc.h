@@ -496,9 +496,6 @@ k_pc_virtual_oracle(const F *__restrict__ lcw, F *__restrict__ qcw, const F *__r
 // mu = w_k^(32a+b) with w_k = w_M^(2^k) the generator of the current domain (fri.cpp:312-331).
 // Position-sharded commitment (vpgpu_pc_shard.inc): a rank holds the positions a = a' * 2^lw + rank of every coset; Nk is then the
 // LOCAL per-coset length and the twiddle uses the global position.  lw = rank = 0: the whole codeword.
-// x / 2 for canonical limbs: (x + p) / 2 when x is odd — the same field element as x * 2^-1, without the multiplier
-__device__ __forceinline__ u64 m_half(u64 x) { return (x + ((x & 1) ? P61 : 0ull)) >> 1; }
-__device__ __forceinline__ F f_half(const F &x) { return f_make(m_half(x.re), m_half(x.im)); }
 // A thread takes VP_FOLD_SPT slices of one position: mu^-1 r / 2 is per position, so a fold costs ONE multiplication per output (and a halving) instead of three.
 #define VP_FOLD_SPT 4
 __global__ void __launch_bounds__(VP_BLOCK)
