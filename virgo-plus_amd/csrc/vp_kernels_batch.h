@@ -33,9 +33,13 @@ struct InitArgs2 {
     const uint8_t *s_layer; const u32 *s_idx;    // phase 2: slot -> (source layer, index) for the V gather
     u32 n_rows;
     int vreal;                // 1: every circuit value is real (vp_evaluate), beta * V[v] takes the half-price product
+    const unsigned long long *const *valsr;      // vreal: the same values as dense arrays of their real parts — a gathered operand is 8 bytes, eight to a cache line
 };
 __device__ __forceinline__ F mul_val(const InitArgs2 &a, const F &y, const F &t) {       // V[v] * t
     return a.vreal ? f_mad31c_rb<false>(t, y.re, f_zero()) : f_mul(y, t);
+}
+__device__ __forceinline__ F val_at(const InitArgs2 &a, int l, u32 x) {                  // circuit value x of layer l
+    return (a.vreal && a.valsr) ? f_make(a.valsr[l][x], 0) : a.vals[l][x];
 }
 
 template <int PHASE>
@@ -47,7 +51,7 @@ __device__ __forceinline__ void contrib2(const InitArgs2 &a, u32 e, F &m, F &ad,
     if (PHASE == 1) {
         const int l = tl & 0xff;
         F ty_ = f_zero();
-        if (l != 0xff && VP_CHK_LAYER(l, x)) ty_ = mul_val(a, a.vals[l][x], t);
+        if (l != 0xff && VP_CHK_LAYER(l, x)) ty_ = mul_val(a, val_at(a, l, x), t);
         switch (ty) {
             case T_ADD: ad = f_add(ad, ty_); m = f_add(m, t); break;
             case T_SUB: ad = f_sub(ad, ty_); m = f_add(m, t); break;
@@ -91,7 +95,7 @@ __device__ __forceinline__ P1Vals p1_gather(const InitArgs2 &a, const P1Entry &c
     P1Vals v;
     v.bf = a.hg.bf[c.g & ((1u << a.hg.h1) - 1)]; v.bs = a.hg.bs[c.g >> a.hg.h1];
     const int l = c.tl & 0xff;
-    v.y = (l != 0xff && VP_CHK_LAYER(l, c.x)) ? a.vals[l][c.x] : f_zero();
+    v.y = (l != 0xff && VP_CHK_LAYER(l, c.x)) ? val_at(a, l, c.x) : f_zero();
     return v;
 }
 __device__ __forceinline__ void p1_apply(const InitArgs2 &a, const P1Entry &c, const P1Vals &v, F &m, F &ad) {       // == contrib2<1>
@@ -122,7 +126,7 @@ __device__ __forceinline__ void init2_light_body(const InitArgs2 &a, u32 bid) {
     if (row >= a.n_rows) return;
     if (PHASE == 2) {
         const int l = a.s_layer[row];
-        if (l != 0xfe) a.V[row] = (l == 0xff || !VP_CHK((unsigned) l < g_vp_chk_layers() && a.s_idx[row] < g_vp_chk_lsize(l), 2, l, a.s_idx[row], row)) ? f_zero() : a.vals[l][a.s_idx[row]];   // 0xfe: padding slot, never read
+        if (l != 0xfe) a.V[row] = (l == 0xff || !VP_CHK((unsigned) l < g_vp_chk_layers() && a.s_idx[row] < g_vp_chk_lsize(l), 2, l, a.s_idx[row], row)) ? f_zero() : val_at(a, l, a.s_idx[row]);   // 0xfe: padding slot, never read
     }
     u32 b = a.rowptr[row], e = a.rowptr[row + 1];
     if (!VP_CHK(b <= e, 3, row, b, e)) return;
@@ -206,6 +210,7 @@ k_vres2(Half h, const F *__restrict__ val, u32 size, F *out_dev) {
 struct SfTab { u32 off, len, valid, chunk_start; };
 struct SfArgs {
     const F *inV, *inM, *inA;
+    const unsigned long long *inVr;      // keep_y0 bit 2 (all-real first round): the V entries as a dense array of their real parts, or nullptr
     F *outV, *outM, *outA;
     const F *r;               // r[s] = challenge of the s-th round of this launch
     F *part;                  // part[(s * part_stride) + block*3 + c]
@@ -414,7 +419,7 @@ struct GenP2 {
         if (l == 0xff || l == 0xfe) return f_zero();
         const u32 x = a->s_idx[row];
         if (!VP_CHK((unsigned) l < g_vp_chk_layers() && x < g_vp_chk_lsize(l), 2, l, x, row)) return f_zero();
-        return a->vals[l][x];
+        return val_at(*a, l, x);
     }
     __device__ __forceinline__ void ptrs(u32 r0, u32 valid, u32 &b0, u32 &e0, u32 &e1) const {
         const u32 lim = min(valid, a->n_rows);
@@ -516,7 +521,9 @@ __device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb,
             } else
 #endif
             if constexpr (Gen::MODE == 3) { v0 = gen.vrow(i0, vend); v1 = gen.vrow(i0 + 1, vend); }      // phase 2: V through the slot map
-            else {
+            else if (vreal && a.inVr) {                                   // uniform: 8-byte real circuit values (i0 is even: one 16-byte load per pair)
+                v0 = f_make(i0 < vend ? a.inVr[i0] : 0ull, 0); v1 = f_make(i0 + 1 < vend ? a.inVr[i0 + 1] : 0ull, 0);
+            } else {
                 // a chunk that lies completely inside the table (all but the last one) is loaded without the per-entry bounds selects
                 if (cl * 512 + 512 <= td.valid) { v0 = a.inV[i0]; v1 = a.inV[i0 + 1]; }
                 else { v0 = ld_or_zero(a.inV, i0, vend); v1 = ld_or_zero(a.inV, i0 + 1, vend); }

@@ -115,6 +115,7 @@ struct vp_ctx {
     int n_layers = 0, max_bl = 0;
     std::vector<LayerDev> L;
     F **d_vals = nullptr;
+    unsigned long long **d_valsr = nullptr;      // per layer: the real parts of its values as a dense array (all-real circuits, vp_evaluate), else nullptr
     F *beta_g = nullptr, *beta_u = nullptr, *bf = nullptr, *bs = nullptr, *liu_half = nullptr;
     u32 half_cap = 0;
     F *tab[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
@@ -1113,11 +1114,16 @@ int vp_evaluate(vp_ctx *ctx, const vp_F *inputs, uint64_t n_inputs) {
     VPCHK(check_stream(ctx));
     ctx->vreal = (vcplx == 0 && ctx->opt.real_values) ? 1 : 0;
     if (ctx->vreal) {
+        std::vector<unsigned long long *> vr(ctx->n_layers);
         for (int i = 0; i < ctx->n_layers; ++i) {
             LayerDev &D = ctx->L[i];
             if (!D.valr) VPCHK(dalloc(ctx, &D.valr, (size_t) D.size));
             hipLaunchKernelGGL(k_real_parts, dim3(nblk(D.size)), dim3(VP_BLOCK), 0, ctx->stream, D.val, (u32) D.size, D.valr);
+            vr[i] = D.valr;
         }
+        if (!ctx->d_valsr) VPCHK(dalloc(ctx, &ctx->d_valsr, (size_t) ctx->n_layers));
+        HIPCHK(hipMemcpyAsync(ctx->d_valsr, vr.data(), vr.size() * sizeof(unsigned long long *), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));      // vr lives on this frame
     }
     float ms = 0;
     hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
