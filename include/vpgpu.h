@@ -146,6 +146,9 @@ typedef struct {
     int32_t real_pairs;             /* VP_REAL_PAIRS: vp_commit_private of a REAL witness (every circuit value real) sends two slices through each transform as one complex
                                        sequence x + i x' (the coefficients of a real sequence are Hermitian, so a coset's values of both slices separate again at the
                                        encoder's last store): half the transforms of the call, the same codeword.  0: one transform per slice  [1] */
+    int32_t fft_gkr_batched;        /* VP_FFT_GKR_BATCHED: vp_fft_gkr runs the 2 lg sumchecks of the inverse FFT (fft_circuit_GKR.cpp:458-768) as ONE batch — given the
+                                       tape they are independent (v_u of a phase 2 is an inner product) — three table launches and one launch per step of their
+                                       common shape instead of ~6 launches per sumcheck.  0: one sumcheck after the other  [1] */
 } vp_options;
 void vp_options_default(vp_options *opt);
 

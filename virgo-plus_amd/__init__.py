@@ -525,7 +525,7 @@ class Options(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_uint32)] + [(n, ctypes.c_int32) for n in (
         "gkr_path", "use_graph", "serial", "fuse_init", "fuse_min_log", "fuse_dot", "drop_y", "drop_y_round1", "real_values",
         "seg_tiny", "sf_big_log", "sf3b_grid", "dot_blocks", "plan_align", "xcd_map",
-        "round_fused_max", "persistent_rounds", "poll", "debug", "prefetch_round1", "split_cost_percent", "kernel_copies", "fold_branches", "ntt_scatter", "fuse_combine", "plan_autotune", "pc_tensor_pub", "persistent_timeout_ms", "graph_explicit", "ntt_r8", "fri_vo_fused", "interactive_fast_init", "fuse_p2", "leaf_asm", "real_pairs")]
+        "round_fused_max", "persistent_rounds", "poll", "debug", "prefetch_round1", "split_cost_percent", "kernel_copies", "fold_branches", "ntt_scatter", "fuse_combine", "plan_autotune", "pc_tensor_pub", "persistent_timeout_ms", "graph_explicit", "ntt_r8", "fri_vo_fused", "interactive_fast_init", "fuse_p2", "leaf_asm", "real_pairs", "fft_gkr_batched")]
 
     def __init__(self, **kw):
         super().__init__()

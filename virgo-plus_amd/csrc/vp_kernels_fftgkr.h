@@ -141,4 +141,51 @@ __global__ void __launch_bounds__(VP_BLOCK) k_fg_ifft_p2(const F *__restrict__ g
     M[u] = f_zero(); A[u] = f_zero();
 }
 
+// ---- the 2 lg sumchecks of the inverse FFT as ONE batch (round 4) ------------------------------------------------------------------------------
+// Given the tape they are independent of each other: depth d's tables come from the layer values (all kept), from eq tables of tape entries, and — phase 2 —
+// from v_u = the layer's extension at r_u, which is an inner product with eq(r_u, .) instead of phase 1's last fold.  The kernels above, one job per blockIdx.y:
+struct FgTabJob { const F *r0, *r1, *alpha, *beta; F *out; };
+__global__ void __launch_bounds__(VP_BLOCK) k_fg_gtab_multi(const FgTabJob *__restrict__ jobs, int n) {
+    const FgTabJob j = jobs[blockIdx.y];
+    const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= (1u << n)) return;
+    F a = j.alpha ? *j.alpha : f_one();
+    for (int b = 0; b < n; ++b) { const F rb = j.r0[b]; a = f_mul(a, ((x >> b) & 1u) ? rb : f_sub(f_one(), rb)); }
+    if (j.beta) {
+        F c = *j.beta;
+        for (int b = 0; b < n; ++b) { const F rb = j.r1[b]; c = f_mul(c, ((x >> b) & 1u) ? rb : f_sub(f_one(), rb)); }
+        a = f_add(a, c);
+    }
+    j.out[x] = a;
+}
+struct FgDotJob { const F *x, *y; F *out; };
+__global__ void __launch_bounds__(VP_BLOCK) k_fg_dot_multi(const FgDotJob *__restrict__ jobs, u32 n) {      // one workgroup per inner product (2^lg <= 2^20 terms)
+    __shared__ F lds[4];
+    const FgDotJob j = jobs[blockIdx.x];
+    F v[1] = {f_zero()};
+    for (u32 i = threadIdx.x; i < n; i += blockDim.x) v[0] = f_add(v[0], f_mul(j.x[i], j.y[i]));
+    block_sum<1>(v, lds);
+    if (threadIdx.x == 0) *j.out = v[0];
+}
+struct FgIfftJob { const F *g, *pre, *eu, *vu; F *M, *A; int dep, phase; };
+__global__ void __launch_bounds__(VP_BLOCK) k_fg_ifft_multi(const FgIfftJob *__restrict__ jobs, const F *__restrict__ winv, int lg) {
+    const FgIfftJob jb = jobs[blockIdx.y];
+    const u32 p = blockIdx.x * blockDim.x + threadIdx.x, halfN = 1u << (lg - 1);
+    if (p >= halfN) return;
+    const int dep = jb.dep;
+    const u32 J = 1u << dep, j = p & (J - 1), k = p >> dep, half = halfN >> dep;
+    const u32 u = (k << (dep + 1)) | j, v = u | J;
+    const F t1 = jb.g[(k << dep) | j], t2 = jb.g[((k + half) << dep) | j];
+    if (jb.phase == 1) {                                                   // k_fg_ifft_p1
+        jb.M[u] = f_add(t1, t2);
+        jb.A[u] = f_mul(f_mul(f_sub(t1, t2), winv[k << dep]), jb.pre[v]);
+        jb.M[v] = f_zero(); jb.A[v] = f_zero();
+    } else {                                                               // k_fg_ifft_p2
+        const F e = jb.eu[u];
+        jb.M[v] = f_mul(f_mul(f_sub(t1, t2), e), winv[k << dep]);
+        jb.A[v] = f_mul(f_mul(f_add(t1, t2), e), *jb.vu);
+        jb.M[u] = f_zero(); jb.A[u] = f_zero();
+    }
+}
+
 }  // namespace vp

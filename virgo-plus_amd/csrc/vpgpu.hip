@@ -727,6 +727,7 @@ void vp_options_default(vp_options *o) {
     o->fuse_p2 = 1;
     o->leaf_asm = 1;
     o->real_pairs = 1;
+    o->fft_gkr_batched = 1;
 }
 // defaults <- the caller's struct (as many bytes as its header knew) <- VP_* environment variables (test-only override, read here and nowhere else)
 static void resolve_options(vp_options *o, const vp_options *user, uint32_t *pinned) {
@@ -757,6 +758,7 @@ static void resolve_options(vp_options *o, const vp_options *user, uint32_t *pin
     flag("VP_FUSE_P2", o->fuse_p2);
     flag("VP_LEAF_ASM", o->leaf_asm);
     flag("VP_REAL_PAIRS", o->real_pairs);
+    flag("VP_FFT_GKR_BATCHED", o->fft_gkr_batched);
     flag("VP_PC_TENSOR", o->pc_tensor_pub);
     num("VP_PERSIST_TIMEOUT_MS", o->persistent_timeout_ms);
     num("VP_GRAPH_EXPLICIT", o->graph_explicit);
