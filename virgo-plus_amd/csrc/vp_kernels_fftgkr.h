@@ -62,12 +62,26 @@ __device__ __forceinline__ F fg_xpow(const F *__restrict__ xsq_i, int lg, u32 j)
     for (int b = 0; b < lg; ++b) if ((j >> b) & 1u) acc = f_mul(acc, xsq_i[b]);
     return acc;
 }
+// Powers of the 64 points by table (round 4): x_i^j = Q_i[j >> lb] * P_i[j & (2^lb - 1)], lb = min(lg, 9) — two multiplications per power instead of one per
+// set bit of j.  xt: [64][2^lb] P then [64][2^(lg - lb)] Q.
+__device__ __forceinline__ int fg_lb(int lg) { return lg < 9 ? lg : 9; }
+__global__ void __launch_bounds__(VP_BLOCK) k_fg_xtab(const F *__restrict__ xsq, int lg, F *__restrict__ xt) {
+    const int lb = fg_lb(lg), hb = lg - lb;
+    const u32 nP = 64u << lb, nQ = 64u << hb, t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < nP) { const u32 i = t >> lb, b = t & ((1u << lb) - 1); xt[t] = fg_xpow(xsq + i * lg, lg, b); }
+    else if (t < nP + nQ) { const u32 q = t - nP, i = q >> hb, a = q & ((1u << hb) - 1); xt[t] = fg_xpow(xsq + i * lg, lg, a << lb); }
+}
+__device__ __forceinline__ F fg_xpow_tab(const F *__restrict__ xt, int lg, u32 i, u32 j) {
+    const int lb = fg_lb(lg), hb = lg - lb;
+    const F p = xt[((size_t) i << lb) | (j & ((1u << lb) - 1))];
+    return hb ? f_mul(xt[((size_t) 64 << lb) + ((size_t) i << hb) + (j >> lb)], p) : p;
+}
 // Pm[i << lg | j] = S[j] * x_i^j (:79-90), and the block's share of O[i] = sum_j Pm[i << lg | j] (:91-100): grid (ceil(N / 256), 64)
-__global__ void __launch_bounds__(VP_BLOCK) k_fg_polyeval(const F *__restrict__ S, const F *__restrict__ xsq, int lg, F *__restrict__ Pm, F *__restrict__ part) {
+__global__ void __launch_bounds__(VP_BLOCK) k_fg_polyeval(const F *__restrict__ S, const F *__restrict__ xt, int lg, F *__restrict__ Pm, F *__restrict__ part) {
     __shared__ F lds[4];
     const u32 j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y, N = 1u << lg;
     F v[1] = {f_zero()};
-    if (j < N) { v[0] = f_mul(S[j], fg_xpow(xsq + i * lg, lg, j)); Pm[((size_t) i << lg) | j] = v[0]; }
+    if (j < N) { v[0] = f_mul(S[j], fg_xpow_tab(xt, lg, i, j)); Pm[((size_t) i << lg) | j] = v[0]; }
     block_sum<1>(v, lds);
     if (threadIdx.x == 0) part[(size_t) i * gridDim.x + blockIdx.x] = v[0];
 }
@@ -103,14 +117,14 @@ __global__ void __launch_bounds__(VP_BLOCK) k_fg_add_init(const F *__restrict__ 
 }
 // multiplication layer (:347-359) with alpha = 1, beta = 0:  mult[i] = sum_j g(j 2^lg + i) x_j^i = lo[i] * sum_j hi[j] x_j^i, g = eq(r0, .) split
 // into lo = eq(r0[0..lg), .) and hi = eq(r0[lg..lg+6), .)
-__global__ void __launch_bounds__(VP_BLOCK) k_fg_mul_init(const F *__restrict__ lo, const F *__restrict__ hi, const F *__restrict__ xsq, int lg, F *__restrict__ M) {
+__global__ void __launch_bounds__(VP_BLOCK) k_fg_mul_init(const F *__restrict__ lo, const F *__restrict__ hi, const F *__restrict__ xt, int lg, F *__restrict__ M) {
     __shared__ F s_hi[64];
     if (threadIdx.x < 64) s_hi[threadIdx.x] = hi[threadIdx.x];
     __syncthreads();
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (1u << lg)) return;
     F acc = f_zero();
-    for (int j = 0; j < 64; ++j) acc = f_add(acc, f_mul(s_hi[j], fg_xpow(xsq + j * lg, lg, i)));
+    for (int j = 0; j < 64; ++j) acc = f_add(acc, f_mul(s_hi[j], fg_xpow_tab(xt, lg, (u32) j, i)));
     M[i] = f_mul(lo[i], acc);
 }
 
