@@ -847,20 +847,41 @@ def protocol_workload(vp, a, pws, golden, world, rank, local, blocks):
     t_f = time.perf_counter()
     sess.prove_protocol()                          # first complete pass: the commitment's buffers and root tables
     first_pass = time.perf_counter() - t_f
-    for _ in range(a.warmup):
-        sess.prove_protocol()
+    # How the passes follow each other (a.pass_mode; vphost.h): "sync" (default) = every call of a pass waits for its result, as the reference's call sequence does;
+    # "deferred" = the calls of a pass are queued without a host wait (vp_set_deferred) and collected at its end; "pipelined" = deferred, and each pass queues the
+    # next pass's commit_private behind its own FRI folds (no idle device between two proofs; same work per step: the head of step 1 runs during the last
+    # warm-up step, the head queued by the last timed step is inside the timed region).  All three give the same bytes.  Measured (round 5): at
+    # x1024 the three are within 1.5 % of each other either way, box by box — the chip holds ~2.1 GHz under this load whatever the gaps — at x16 the queued forms are
+    # 9 % faster; the other two are timed beside the headline's (ms_per_step_by_pass_mode).
+    kw = {"pipelined": dict(queue_next=True), "deferred": dict(deferred=True), "sync": dict(deferred=False)}[a.pass_mode]
+    for _ in range(max(1, a.warmup)):
+        sess.prove_protocol(**kw)
     gpu_sync(local)
     barrier(world)
     acc = {}
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        tr, roots, fin, sec = sess.prove_protocol()
+        tr, roots, fin, sec = sess.prove_protocol(**kw)
         for k, v in sec.items():
             acc[k] = acc.get(k, 0.0) + v
     gpu_sync(local)
     barrier(world)
     elapsed = time.perf_counter() - t0
     elapsed_max, proofs = aggregate(world, elapsed, float(a.steps))
+    # the other two forms, a few passes each (rank 0's own numbers, outside the headline's timed region): what the queueing is worth on this box
+    modes = {a.pass_mode: 1e3 * elapsed / a.steps}
+    if rank == 0 and not a.no_pass_modes:
+        for mname, mkw in (("sync", dict(deferred=False)), ("deferred", dict(deferred=True)), ("pipelined", dict(queue_next=True))):
+            if mname == a.pass_mode:
+                continue
+            for _ in range(2):
+                sess.prove_protocol(**mkw)
+            gpu_sync(local)
+            t_m = time.perf_counter()
+            for _ in range(max(4, a.steps // 3)):
+                sess.prove_protocol(**mkw)
+            gpu_sync(local)
+            modes[mname] = 1e3 * (time.perf_counter() - t_m) / max(4, a.steps // 3)
     # ---- parity: rank 0 against the REAL reference's files; every rank through the complete protocol's host verifier
     exact = {}
     if g and rank == 0:
@@ -927,12 +948,18 @@ def protocol_workload(vp, a, pws, golden, world, rank, local, blocks):
         "config": {"workload": "SHA-256 %d-block circuit (SHA256_64.pws x%d, %d gates, %d layers, 2^%d input wires), GKR sumcheck + Virgo FFT/LDT commit on GPU (BASELINE configs[%d]%s)"
                                % (blocks, blocks, circ.gates, circ.layers, circ.layer_bitlen(0), 2 if world == 1 else 3,
                                   "" if world == 1 else ": %d independent proofs, one per GPU, witness seeds 1..%d" % (world, world)),
-                   "mode": "one prover pass per step: commit_private -> GKR (batched, tape pre-drawn) -> commit_public(eq(r_liu,.) built on device) -> fft_gkr -> FRI commit phase",
+                   "mode": "one prover pass per step: commit_private -> GKR (batched, tape pre-drawn) -> commit_public(eq(r_liu,.) built on device) -> fft_gkr -> FRI commit phase; "
+                           + {"pipelined": "calls queued without host waits, each pass queues the next pass's commit_private behind its FRI folds (same work per step, no idle device between proofs)",
+                              "deferred": "calls queued without host waits inside a pass", "sync": "every call waits for its result"}[a.pass_mode],
+                   "pass_mode": a.pass_mode,
                    "proofs_per_step": world, "field_ops_per_proof": ref_ops},
         "prover_sec": {"step_wall": elapsed_max / a.steps, "gkr": per.get("gkr"), "commit_private": per.get("commit_private"), "commit_public": per.get("commit_public"),
                        "fft_gkr": per.get("fft_gkr"), "fri_commit": per.get("fri_commit"),
                        "pc_prove_reference_definition": per.get("commit_private", 0) + per.get("commit_public", 0) + per.get("fft_gkr", 0) + per.get("fri_commit", 0),
-                       "note": "host wall clock per call, mean over the timed steps (rank 0); the reference prints `Prove Time` (GKR) and `Polynomial commitment: prove time` (the other four)",
+                       "note": ("device time per call (events around each call's launches; fft_gkr: host time of its begin + end, its launches run beside the other calls)"
+                                if a.pass_mode != "sync" else "host wall clock per call") + ", mean over the timed steps (rank 0); the reference prints `Prove Time` (GKR) and "
+                               "`Polynomial commitment: prove time` (the other four)",
+                       "ms_per_step_by_pass_mode": modes,
                        "step_wall_per_rank": steps_sec},
         "gkr_field_ops_per_sec": (ref_ops / per["gkr"]) if ref_ops and per.get("gkr") else None,
         "first_proof_sec": {"gkr_first_call_incl_plan_tuner_and_graph_capture": first_gkr, "first_complete_pass_incl_commitment_buffers": first_pass},
@@ -955,32 +982,54 @@ def protocol_workload(vp, a, pws, golden, world, rank, local, blocks):
     return detail
 
 
-def cpu_protocol_baseline(pws, ref_ops_headline, blocks_sample=64):
-    """cpu_baseline of the configs[2] headline: the REAL reference (oracle/_ref/ref_run: /root/reference compiled in place) running the
-    same protocol — GKR + Virgo commitment — on a BOUNDED sample: the x64 circuit (1/16 of the headline's blocks), one thread (the reference
-    has no threading).  value = the reference's own field-op count / (its Prove Time + its commitment prove time), the headline's unit."""
+def reference_start(pws, blocks, pc):
+    """The REAL reference (oracle/_ref/ref_run: /root/reference compiled in place) on one host core, as a background process: it runs while the GPU legs
+    do (the box has hundreds of cores; nothing of it is inside a timed GPU region's critical path) and is collected at the end of the run."""
     ref_run = os.path.join(ROOT, "oracle", "_ref", "ref_run")
     if not os.path.exists(ref_run):
         return None
-    t0 = time.perf_counter()
     try:
-        out = subprocess.run([ref_run, "--pws", pws, "--blocks", str(blocks_sample), "--pc", "1"], stdout=subprocess.PIPE,
-                             stderr=subprocess.DEVNULL, text=True, timeout=900)
+        return {"t0": time.perf_counter(), "blocks": blocks, "pc": pc,
+                "proc": subprocess.Popen([ref_run, "--pws", pws, "--blocks", str(blocks), "--pc", "1" if pc else "0"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)}
     except Exception:
         return None
-    wall = time.perf_counter() - t0
-    m = re.search(r"Prove Time ([0-9.]+)", out.stdout)
-    pm = re.search(r"Polynomial commitment: prove time ([0-9.]+)", out.stdout)
-    c = re.search(r"mult counter (-?\d+), add counter (-?\d+)", out.stdout)
-    if out.returncode != 0 or not (m and pm and c):
+
+
+def reference_collect(h, timeout=900):
+    """-> dict of the reference's own printed numbers, or None."""
+    if not h:
         return None
-    gkr, pcs = float(m.group(1)), float(pm.group(1))
+    try:
+        out, _ = h["proc"].communicate(timeout=timeout)
+    except Exception:
+        try:
+            h["proc"].kill()
+        except Exception:
+            pass
+        return None
+    wall = time.perf_counter() - h["t0"]
+    m = re.search(r"Prove Time ([0-9.]+)", out)
+    pm = re.search(r"Polynomial commitment: prove time ([0-9.]+)", out)
+    c = re.search(r"mult counter (-?\d+), add counter (-?\d+)", out)
+    if h["proc"].returncode != 0 or not (m and c) or (h["pc"] and not pm):
+        return None
+    gkr, pcs = float(m.group(1)), float(pm.group(1)) if (pm and h["pc"]) else 0.0
     ops = int(c.group(1)) + int(c.group(2))
+    return {"blocks": h["blocks"], "gkr_prove_sec": gkr, "pc_prove_sec": pcs, "field_ops": ops, "process_wall_sec_incl_waiting_to_be_collected": wall}
+
+
+def cpu_protocol_baseline(r, blocks_headline=1024):
+    """cpu_baseline of the configs[2] headline from a collected run of the REAL reference on the same protocol — GKR + Virgo commitment — on a BOUNDED sample
+    (round 5: the x256 circuit, a quarter of the headline's blocks, ~16 GB, ~75 s on one core; the full x1024 run takes 63 GB and 13 minutes,
+    tests/golden/golden.json holds it).  value = the reference's own field-op count / (its Prove Time + its commitment prove time), the headline's unit."""
+    if not r or not r.get("pc_prove_sec"):
+        return None
+    gkr, pcs, ops = r["gkr_prove_sec"], r["pc_prove_sec"], r["field_ops"]
     return {"value": ops / (gkr + pcs), "unit": "field-ops/s", "cores": 1, "kind": "reference",
-            "sample": "the real reference binary, SHA-256 x%d (1/%d of the headline's blocks), complete protocol (GKR + commitment, verifier::verify), single thread"
-                      % (blocks_sample, max(1, 1024 // blocks_sample)),
+            "sample": "the real reference binary, SHA-256 x%d (1/%d of the headline's blocks), complete protocol (GKR + commitment, verifier::verify), single thread, "
+                      "run beside the GPU legs on another core" % (r["blocks"], max(1, blocks_headline // r["blocks"])),
             "prover_sec": gkr + pcs, "gkr_prove_sec": gkr, "pc_prove_sec": pcs, "field_ops": ops, "gkr_field_ops_per_sec": ops / gkr,
-            "process_wall_sec": wall, "host_cpu": cpu_model(), "host_cores_visible": os.cpu_count()}
+            "process_wall_sec": r["process_wall_sec_incl_waiting_to_be_collected"], "host_cpu": cpu_model(), "host_cores_visible": os.cpu_count()}
 
 
 def cpu_port_x1024(pws, tr_gpu):
@@ -1045,7 +1094,7 @@ def compact_line(d, detail_file=None):
     line = {k: d.get(k) for k in ("metric", "value", "unit", "n_gpus", "ranks", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                                   "dtype", "data")}
     cfg = d.get("config") or {}
-    line["config"] = {k: cfg[k] for k in ("workload", "mode", "proofs_per_step", "field_ops_per_proof") if k in cfg}
+    line["config"] = {k: cfg[k] for k in ("workload", "mode", "pass_mode", "proofs_per_step", "field_ops_per_proof") if k in cfg}
     roof = d.get("roofline")
     if isinstance(roof, dict):
         line["roofline"] = pick(roof, ("kernel", "bound", "achieved", "peak", "unit", "frac", "hbm_frac", "hbm_GBps", "traffic", "algorithmic_bytes_per_launch",
@@ -1057,6 +1106,8 @@ def compact_line(d, detail_file=None):
     line["cpu_baseline"] = pick(cb, ("value", "unit", "cores", "kind", "sample", "prover_sec", "gkr_prove_sec", "pc_prove_sec", "host_cpu",
                                      "reference_over_port_ratio_x64_same_box")) if isinstance(cb, dict) else None
     line["rccl_ranks"] = d.get("rccl_ranks")
+    if d.get("bench_wall_sec") is not None:
+        line["bench_wall_sec"] = d["bench_wall_sec"]
     be = d.get("bit_exact")
     if isinstance(be, dict):
         line["bit_exact"] = all(v is not False for v in be.values()) and bool(d.get("bit_exact_all_ranks", True))
@@ -1066,7 +1117,7 @@ def compact_line(d, detail_file=None):
     optional = []
     ps = d.get("prover_sec")
     if isinstance(ps, dict):
-        optional.append(("prover_sec", pick(ps, ("step_wall", "gkr", "commit_private", "commit_public", "fft_gkr", "fri_commit", "pc_prove_reference_definition"))))
+        optional.append(("prover_sec", pick(ps, ("step_wall", "gkr", "commit_private", "commit_public", "fft_gkr", "fri_commit", "pc_prove_reference_definition", "ms_per_step_by_pass_mode"))))
         optional.append(("gkr_field_ops_per_sec", d.get("gkr_field_ops_per_sec")))
     else:
         optional.append(("prover_sec", ps))
@@ -1097,6 +1148,13 @@ def compact_line(d, detail_file=None):
                                      "interactive_prover_sec": i64.get("prover_sec"), "first_proof_sec": x64.get("first_proof_sec"),
                                      "cpu_reference_prover_sec": (x64.get("cpu_baseline") or {}).get("prover_sec"),
                                      "two_in_flight_ms_per_proof": (x64.get("two_in_flight") or {}).get("ms_per_proof")}))
+    rz = d.get("randomize_16_20")
+    if isinstance(rz, dict):
+        rr = rz.get("roofline") or {}
+        optional.append(("randomize_16_20", {"workload": "BASELINE configs[4]: randomize(16,20), 2^24 gates, GKR on GPU, PC off", "value": rz.get("value"), "ms_per_step": rz.get("ms_per_step"),
+                                             "prover_sec_device": rz.get("prover_sec_device"), "steps": rz.get("steps"), "bit_exact": rz.get("bit_exact_vs_reference_golden"),
+                                             "roofline_kernel": rr.get("kernel"), "roofline_frac": rr.get("frac"), "hbm_frac": rr.get("hbm_frac"),
+                                             "interactive_prover_sec": (rz.get("interactive_path") or {}).get("prover_sec")}))
     cp = d.get("cpu_port_x1024_gkr")
     if isinstance(cp, dict):
         optional.append(("cpu_port_x1024_gkr", pick(cp, ("kind", "gkr_prove_sec", "gkr_field_ops_per_sec", "transcript_equals_gpu"))))
@@ -1188,6 +1246,12 @@ def main():
                     help="with --shard-sim or --shard-chains: also split tables of at least 2^(log2 W + MIN_LOG) entries by index over the ranks (vp_set_shard_split; 11 is the smallest useful value)")
     ap.add_argument("--with-pc", action="store_true", help="GKR-only headline: also time the Virgo commitment calls one by one (detail file)")
     ap.add_argument("--no-x64-leg", action="store_true", help="N = 1 default run: skip the nested x64 GKR-only leg (BASELINE configs[1])")
+    ap.add_argument("--no-randomize-leg", action="store_true", help="N = 1 default run: skip the nested randomize(16, 20) GKR-only leg (BASELINE configs[4])")
+    ap.add_argument("--pass-mode", choices=("pipelined", "deferred", "sync"), default="sync",
+                    help="how the protocol passes of the headline are queued (see protocol_workload); all three give the same bytes")
+    ap.add_argument("--no-pass-modes", action="store_true", help="do not time the other two pass modes beside the headline's")
+    ap.add_argument("--cpu-sample-blocks", type=int, default=256, help="cpu_baseline: SHA-256 blocks of the circuit the REAL reference proves on one host core (256: ~16 GB, ~75 s, "
+                    "started in the background at the beginning of the run; 64 = round 4's sample)")
     ap.add_argument("--per-launch", action="store_true", help="detail file: per-launch table of every call and every interactive round")
     ap.add_argument("--no-two-in-flight", action="store_true", help="GKR-only legs: skip the `two_in_flight` sub-leg (two sessions of the circuit, two host threads)")
     ap.add_argument("--no-sharded-leg", action="store_true", help="N > 1: skip the `sharded` sub-leg (one proof + its commitment over all ranks, RCCL)")
@@ -1223,8 +1287,15 @@ def main():
         a.no_cpu_baseline = True
     out = OneLine()
     failed_subleg = False
+    t_bench0 = time.perf_counter()
     with tempfile.TemporaryDirectory() as tmp:
         pws = unpack_pws(tmp)
+        # CPU legs exist at N = 1 only (no rank of a multi-GPU run spends a second on them); the two runs of the real reference start now, on cores of their own
+        ref_big = ref_64 = None
+        if a.gpus == 1 and not gkr_only and not a.no_cpu_baseline and a.blocks == 1024:
+            ref_big = reference_start(pws, a.cpu_sample_blocks, True)
+            if not a.no_x64_leg:
+                ref_64 = reference_start(pws, 64, False)
         # one-time cost of the process (HIP context, code objects: ~0.25 s) paid by a 3-gate circuit first, so that circuit_upload_sec is
         # what a caller sees per circuit (host flatten + vp_circuit_upload with its device-side list building + vp_evaluate)
         t_up = time.perf_counter()
@@ -1237,16 +1308,29 @@ def main():
         if rank == 0:
             detail["process_first_use_sec"] = first_use_sec
             detail["rccl_ranks"] = None
-            if world == 1 and not gkr_only and not a.no_cpu_baseline:
-                detail["cpu_baseline"] = cpu_protocol_baseline(pws, detail["config"].get("field_ops_per_proof"))
+            r64 = None
         # ---- N = 1 default run: BASELINE configs[1] (x64, GKR only) as a nested leg, with the real reference's GKR proof of it on one host core
         if world == 1 and not gkr_only and a.blocks == 1024 and not a.no_x64_leg:
             x64 = gkr_workload(vp, a, pws, golden, 1, 0, local, 64, False, cpu_base=False, nested=True)
             detail["x64_gkr"] = x64
+        # ---- N = 1 default run: BASELINE configs[4] ("synthetic random unlayered circuit, 2^24 gates, HBM-roofline run") as a nested GKR-only leg
+        if world == 1 and not gkr_only and a.blocks == 1024 and not a.no_randomize_leg:
+            import copy
+            a_r = copy.copy(a)
+            a_r.randomize = [16, 20]
+            rz = gkr_workload(vp, a_r, pws, golden, 1, 0, local, 0, False, cpu_base=False, nested=True)
+            g_r = golden.get("randomize_16_20") or {}
+            rz["cpu_reference_prover_sec_build_container"] = g_r.get("reference_prove_sec_here")
+            detail["randomize_16_20"] = rz
+        # ---- the CPU side (N = 1): the real reference's runs started at the beginning are collected here, then the port's full-size GKR proof
+        if world == 1 and not gkr_only and a.blocks == 1024 and not a.no_cpu_baseline:
+            r64 = reference_collect(ref_64)
+            detail["cpu_baseline"] = cpu_protocol_baseline(reference_collect(ref_big))
             cb = detail.get("cpu_baseline")
-            if isinstance(cb, dict):      # the reference's x64 GKR proof was timed inside the cpu_baseline run (same circuit, same box)
-                x64["cpu_baseline"] = {"kind": "reference", "cores": 1, "prover_sec": cb["gkr_prove_sec"], "value": cb["gkr_field_ops_per_sec"], "unit": "field-ops/s"}
-            if not a.no_cpu_baseline and not a.no_cpu_port_x1024:
+            x64 = detail.get("x64_gkr")
+            if isinstance(r64, dict) and isinstance(x64, dict):      # the reference's x64 GKR proof (PC off), same box
+                x64["cpu_baseline"] = {"kind": "reference", "cores": 1, "prover_sec": r64["gkr_prove_sec"], "value": r64["field_ops"] / r64["gkr_prove_sec"], "unit": "field-ops/s"}
+            if not a.no_cpu_port_x1024:
                 import oracle_binding as ob
                 gold = open(os.path.join(ROOT, "tests", "golden", golden["sha256_x1024"]["transcript"]), "rb").read()
                 gs = golden["sha256_x1024"]["gkr_slice"]
@@ -1255,9 +1339,11 @@ def main():
                 _, st64 = oc.prove_gkr()
                 oc.close()
                 port["port_x64_gkr_prove_sec_same_box"] = st64["prove_sec"]
-                if isinstance(cb, dict):
-                    port["reference_over_port_ratio_x64_same_box"] = cb["gkr_prove_sec"] / st64["prove_sec"]
-                    cb["reference_over_port_ratio_x64_same_box"] = port["reference_over_port_ratio_x64_same_box"]
+                if isinstance(r64, dict):
+                    port["reference_over_port_ratio_x64_same_box"] = r64["gkr_prove_sec"] / st64["prove_sec"]
+                    if isinstance(cb, dict):
+                        cb["reference_over_port_ratio_x64_same_box"] = port["reference_over_port_ratio_x64_same_box"]
+                        cb["reference_x64_gkr_prove_sec_same_box"] = r64["gkr_prove_sec"]
                 detail["cpu_port_x1024_gkr"] = port
         # ---- N > 1: ONE proof + its commitment sharded over all ranks (RCCL inside the C ABI), in the SAME line.  Every rank takes part; a
         # watchdog prints the line without it and ends the ranks with a non-zero code if a collective does not come back.
@@ -1268,6 +1354,7 @@ def main():
                 # never restart anything from here: print what there is (rank 0) and leave with an error code, so that the launcher reports the hang
                 if rank == 0:
                     detail["multi_gpu_sublegs_error"] = "timed out after %.0f s in %s" % (a.subleg_timeout, state["leg"])
+                    detail["bench_wall_sec"] = time.perf_counter() - t_bench0
                     out.emit(detail, world, a.detail_file)
                     sys.stdout.flush()
                 else:
@@ -1328,6 +1415,7 @@ def main():
                 if isinstance(sub, dict) and "error" in sub:
                     detail["multi_gpu_sublegs_error"] = sub["error"]
         if rank == 0:
+            detail["bench_wall_sec"] = time.perf_counter() - t_bench0
             out.emit(detail, world, a.detail_file)
         failed_subleg = allreduce_min_flag(world, not (rank == 0 and detail.get("multi_gpu_sublegs_error"))) is False
     if world > 1:

@@ -324,8 +324,31 @@ int vp_fft_gkr(vp_ctx *, int lg, const vp_F *tape, uint64_t n_tape, vp_F *msgs, 
  * one-call form, before the end is VP_EINVAL.                                                                                             */
 int vp_fft_gkr_begin(vp_ctx *, int lg, const vp_F *tape, uint64_t n_tape);
 int vp_fft_gkr_end(vp_ctx *, vp_F *msgs, uint64_t capacity, uint64_t *n_written);
+/* Drop a run begun with vp_fft_gkr_begin without reading its messages (the caller's pass failed between begin and end); VP_OK when none is pending.
+ * vp_fft_gkr_begin itself drains and drops a run that was never collected, so a failed pass cannot wedge the context. */
+int vp_fft_gkr_cancel(vp_ctx *);
 /* Device time of the last vp_commit_private / vp_commit_public / vp_fri_step / vp_fft_gkr in milliseconds (hipEvents). */
 int vp_commit_stats(vp_ctx *, double *commit_ms);
+
+/* ---- deferred completion: a prover pass without a host wait between its calls (round 5) -------------------------------------------------
+ * Measured on MI355X (tools/leaf_in_step.py, profiles/r05_leaf_hash_in_step.txt): a GPU that idles for a fraction of a millisecond runs the next ~10 ms at a
+ * lower shader clock (the leaf-hash launch, same cycles per workgroup: 10.1 ms back to back, 10.5 ms behind 0.5 ms of idling, 11.7 ms behind 5 ms).  Each
+ * synchronous entry point ends in such a gap: the host wakes up, copies the result, makes the next call.  With vp_set_deferred(ctx, 1) the entry points of the
+ * reference's prover pass whose results the HOST does not need before the next call —
+ *     vp_commit_private, vp_prove_gkr (launch plan, unsharded, not profiled), vp_commit_public_eq, vp_fri_commit, vp_fri_final
+ * — queue their launches, stage their results in pinned memory and return VP_OK at once; the output pointers are written by vp_flush, which waits for
+ * the first `count` pending calls (count < 0: all) in the order they were made and returns the first error (the calls behind a failed one are dropped).
+ * Output buffers and *n_written must stay valid until then.  Every other entry point of the context finishes what is pending before it runs, so a caller
+ * that never calls vp_flush sees the synchronous behaviour one call late at worst (vp_set_deferred(ctx, 0) itself leaves what is pending pending).  Stream order is the order of the calls: a vp_commit_private queued
+ * BEHIND a proof's vp_fri_commit (the head of the next proof, so that the device never idles between two proofs) starts when the folds are done and
+ * overwrites the committed codeword — vp_fri_open answers for a proof only until the next vp_commit_private is queued.                               */
+int vp_set_deferred(vp_ctx *, int on);
+int vp_flush(vp_ctx *, int count);
+int vp_pending(vp_ctx *, int *n);
+/* device time in ms of the last finished vp_commit_private | vp_prove_gkr | vp_commit_public(_eq) | vp_fri_commit | vp_fri_final of the context */
+int vp_phase_ms(vp_ctx *, double out[5]);
+/* how many vp_commit_private calls the context has queued so far, and whether the latest one still stands (no upload / evaluate / vp_pc_load_input since) */
+int vp_commit_private_state(vp_ctx *, uint64_t *epoch, int *valid);
 
 /* ---- commitment sharded over the GPUs of a node (SURVEY.md §8e "PC sharding"; north_star "FFT subtrees shard") ---------------- */
 /* After vp_pc_set_shard(rank, world) (world a power of two <= 64 with 2^(n-6) >= 2 world) the SAME entry points vp_commit_private /

@@ -643,7 +643,7 @@ def test_leaf_hash_generated_chains_equal_the_compilers_at_every_workgroup_size(
         c.close()
 
 
-@pytest.mark.parametrize("blocks", [64, 256])
+@pytest.mark.parametrize("blocks", [64, 256, 512])
 def test_commit_private_two_real_slices_per_transform(vp, golden, pws_path, blocks):
     """vp_commit_private of a real witness sends slices p and p + 32 through each transform as ONE complex sequence (real_pairs; the encoder's last store
     separates the two slices' values on every coset): the root equals the one-transform-per-slice form's (and, at x64, the real reference's)."""
@@ -1801,3 +1801,110 @@ def test_checked_build_passes_the_protocol_and_reports_a_violated_index_check(vp
         assert "REFUSED" in r.stdout and "device check failed: site" in r.stdout
     else:
         assert "CHECKED OK" in r.stdout
+
+
+# ---- round 5 -------------------------------------------------------------------------------------------------------------------------------------
+def test_commit_private_after_pc_load_input_of_complex_data_on_an_evaluated_context(vp, pws_path):
+    """a context that evaluated a REAL witness (vreal = 1: vp_commit_private pairs two slices per transform and reads .re only) and is then handed
+    COMPLEX inputs through vp_pc_load_input must commit to all of them: the root equals a fresh context's, bit length 19 (the paired path's sizes)."""
+    L = vp.lib_gpu()
+    c = vp.Circuit.from_pws(pws_path, 64, seed=1)          # input layer 2^19
+    s = vp.Session(c)
+    r_real, _ = s.commit_private()
+    n = c.layer_bitlen(0)
+    rng = np.random.default_rng(31)
+    inp = rng.integers(0, P, size=(1 << n, 2), dtype=np.uint64)
+    ctx = s.gpu_ctx()
+    assert L.vp_pc_load_input(ctx, inp.ctypes.data, inp.shape[0], n) == 0
+    root = ctypes.create_string_buffer(32)
+    assert L.vp_commit_private(ctx, ctypes.cast(root, ctypes.c_void_p)) == 0, L.vp_last_error(ctx)
+    fresh = ctypes.c_void_p()
+    assert L.vp_create(0, ctypes.byref(fresh)) == 0
+    assert L.vp_pc_load_input(fresh, inp.ctypes.data, inp.shape[0], n) == 0
+    root2 = ctypes.create_string_buffer(32)
+    assert L.vp_commit_private(fresh, ctypes.cast(root2, ctypes.c_void_p)) == 0
+    L.vp_destroy(fresh)
+    assert root.raw == root2.raw and root.raw != r_real
+    s.close(); c.close()
+
+
+@pytest.mark.parametrize("blocks", [16, 256])
+def test_protocol_pass_forms_give_the_same_bytes(vp, golden, pws_path, blocks):
+    """vph_prove_protocol_ex (vphost.h): synchronous calls | deferred completion (vp_set_deferred: every call queued without a host wait, collected by vp_flush) |
+    deferred + the next pass's commit_private queued behind this pass's FRI folds — the same transcript, FRI roots and final codeword (x16: the real reference's),
+    pass after pass, and the context serves a synchronous entry point afterwards (what is pending is finished first)."""
+    c = vp.Circuit.from_pws(pws_path, blocks, seed=1)
+    s = vp.Session(c)
+    s.draw_protocol_tape()
+    ref = s.prove_protocol(deferred=False)
+    if blocks == 16:
+        g = golden["sha256_x16"]
+        assert ref[0] == open(os.path.join(GOLDEN_DIR, g["transcript"]), "rb").read()
+        fri = open(os.path.join(GOLDEN_DIR, g["fri"]), "rb").read()
+        assert ref[1] == b"".join(fri[48 * k + 16:48 * k + 48] for k in range(g["fri_steps"]))
+    same = lambda a: a[0] == ref[0] and a[1] == ref[1] and np.array_equal(a[2], ref[2])
+    for _ in range(2):
+        assert same(s.prove_protocol(deferred=True))
+    for _ in range(3):
+        assert same(s.prove_protocol(queue_next=True))
+    n = ctypes.c_int(-1)
+    assert vp.lib_gpu().vp_pending(s.gpu_ctx(), ctypes.byref(n)) == 0 and n.value == 1          # the next pass's commit_private
+    assert same(s.prove_protocol(deferred=True))                                                 # finds it, starts at the GKR part
+    assert vp.lib_gpu().vp_pending(s.gpu_ctx(), ctypes.byref(n)) == 0 and n.value == 0
+    assert same(s.prove_protocol(queue_next=True))
+    tr_i, _, ok_i = s.prove_interactive()                                                        # a synchronous entry point with a head pending
+    assert ok_i and tr_i == ref[0][32:32 + len(tr_i)]
+    s.draw_protocol_tape()
+    assert same(s.prove_protocol(deferred=False))
+    root, _ = s.commit_private()
+    assert root == ref[0][:32]
+    s.close(); c.close()
+
+
+def test_deferred_calls_return_at_once_and_flush_fills_the_outputs(vp, pws_path):
+    """The C ABI of the deferred mode on its own: with vp_set_deferred(ctx, 1) vp_commit_private returns before its root is there (the buffer is untouched until
+    vp_flush), vp_pending counts it, vp_flush(ctx, -1) writes the synchronous call's bytes; a vp_evaluate in between finishes what is pending by itself."""
+    L = vp.lib_gpu()
+    L.vp_set_deferred.argtypes = [ctypes.c_void_p, ctypes.c_int]; L.vp_flush.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    c = vp.Circuit.from_pws(pws_path, 64, seed=1)
+    s = vp.Session(c)
+    ctx = s.gpu_ctx()
+    want, _ = s.commit_private()
+    assert L.vp_set_deferred(ctx, 1) == 0
+    root = ctypes.create_string_buffer(b"\xee" * 32, 32)
+    n = ctypes.c_int(0)
+    assert L.vp_commit_private(ctx, ctypes.cast(root, ctypes.c_void_p)) == 0
+    assert L.vp_pending(ctx, ctypes.byref(n)) == 0 and n.value == 1
+    assert root.raw == b"\xee" * 32
+    assert L.vp_flush(ctx, -1) == 0
+    assert root.raw == want
+    root2 = ctypes.create_string_buffer(b"\xee" * 32, 32)
+    assert L.vp_commit_private(ctx, ctypes.cast(root2, ctypes.c_void_p)) == 0
+    vals = s.layer_values(1)                                    # any other entry point: finishes the pending call first
+    assert root2.raw == want and len(vals)
+    assert L.vp_pending(ctx, ctypes.byref(n)) == 0 and n.value == 0
+    assert L.vp_set_deferred(ctx, 0) == 0
+    s.close(); c.close()
+
+
+def test_fft_gkr_begun_and_never_collected_does_not_wedge_the_context(vp, ctx):
+    """a pass that fails between vp_fft_gkr_begin and vp_fft_gkr_end used to leave every later begin on the context failing with "not collected".
+    Now vp_fft_gkr_cancel drops such a run, and a second begin without it drains and drops the stale one by itself; the messages of the run that follows are
+    the synchronous call's."""
+    L = vp.lib_gpu()
+    L.vp_fft_gkr_cancel.argtypes = [ctypes.c_void_p]
+    lg = 7
+    nt, nm = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    assert L.vp_fft_gkr_sizes(lg, ctypes.byref(nt), ctypes.byref(nm)) == 0
+    tape = np.random.default_rng(5).integers(0, P, size=(nt.value, 2), dtype=np.uint64)
+    want = np.zeros((nm.value, 2), dtype=np.uint64); w = ctypes.c_uint64(0)
+    assert L.vp_fft_gkr(ctx, lg, tape.ctypes.data, nt.value, want.ctypes.data, nm.value, ctypes.byref(w)) == 0
+    assert L.vp_fft_gkr_begin(ctx, lg, tape.ctypes.data, nt.value) == 0
+    assert L.vp_fft_gkr_begin(ctx, lg, tape.ctypes.data, nt.value) == 0              # the first run is dropped, not an error
+    assert L.vp_fft_gkr_cancel(ctx) == 0
+    assert L.vp_fft_gkr_cancel(ctx) == 0                                             # nothing pending: still VP_OK
+    got = np.zeros_like(want)
+    assert L.vp_fft_gkr_end(ctx, got.ctypes.data, nm.value, ctypes.byref(w)) != 0    # nothing to collect
+    assert L.vp_fft_gkr_begin(ctx, lg, tape.ctypes.data, nt.value) == 0
+    assert L.vp_fft_gkr_end(ctx, got.ctypes.data, nm.value, ctypes.byref(w)) == 0
+    assert np.array_equal(got, want)

@@ -118,6 +118,17 @@ def lib_gpu():
         L.vp_shard_finish.argtypes = [vp, vp, ctypes.c_uint64, vp]
         L.vp_gkr_sizes.argtypes = [vp, vp, vp]
         L.vp_options_default.argtypes = [vp]
+        u64_ = ctypes.c_uint64
+        L.vp_set_deferred.argtypes = [vp, ctypes.c_int]
+        L.vp_flush.argtypes = [vp, ctypes.c_int]
+        L.vp_pending.argtypes = [vp, ctypes.POINTER(ctypes.c_int)]
+        L.vp_phase_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
+        L.vp_commit_private.argtypes = [vp, vp]
+        L.vp_fft_gkr_sizes.argtypes = [ctypes.c_int, vp, vp]
+        L.vp_fft_gkr.argtypes = [vp, ctypes.c_int, vp, u64_, vp, u64_, vp]
+        L.vp_fft_gkr_begin.argtypes = [vp, ctypes.c_int, vp, u64_]
+        L.vp_fft_gkr_end.argtypes = [vp, vp, u64_, vp]
+        L.vp_fft_gkr_cancel.argtypes = [vp]
         L.vp_options_default.restype = None
         L.vp_destroy.argtypes = [vp]
         L.vp_last_error.argtypes = [vp]
@@ -196,6 +207,7 @@ def lib_host():
         L.vph_last_fri.argtypes = [vp, vp, u64, vp, vp]
         L.vph_draw_protocol_tape.argtypes = [vp]
         L.vph_prove_protocol.argtypes = [vp, vp, u64, ctypes.POINTER(u64), vp, u64, vp, ctypes.POINTER(ctypes.c_double), ctypes.c_char_p, ctypes.c_int]
+        L.vph_prove_protocol_ex.argtypes = [vp, vp, u64, ctypes.POINTER(u64), vp, u64, vp, ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
         L.vph_last_point.argtypes = [vp, vp, ctypes.c_int]
         L.vph_last_fft_gkr.restype = ctypes.c_int64
         L.vph_last_fft_gkr.argtypes = [vp, vp, u64]
@@ -767,18 +779,21 @@ class Session:
         if lib_host().vph_draw_protocol_tape(self.h):
             raise RuntimeError("draw_protocol_tape: the commitment needs an input layer of at least 2^7 wires")
 
-    def prove_protocol(self):
+    def prove_protocol(self, deferred=False, queue_next=False):
         """The prover side of the complete protocol in one pass (no verifier work): commit_private -> batched GKR -> commit_public on
         eq(r_liu, .) -> fft_gkr -> FRI commit phase.  Returns (transcript in the golden layout, FRI roots bytes, final codeword (2048, 2),
-        seconds dict {total, commit_private, gkr, commit_public, fft_gkr, fri_commit})."""
+        seconds dict {total, commit_private, gkr, commit_public, fft_gkr, fri_commit}).
+        deferred: the calls are queued back to back and collected at the end (vp_set_deferred: no idle device between them); the per-call seconds are then
+        device times.  queue_next: the pass also queues the next pass's commit_private behind its own folds (vphost.h, VPH_PASS_QUEUE_NEXT): for a
+        session that proves back to back; this pass's commitment cannot be opened afterwards."""
         import numpy as np
         if not hasattr(self, "_pp"):
             cap = self._cap + 32 + 32 + 16 + 65 * 16
             self._pp = (ctypes.create_string_buffer(cap), cap, ctypes.create_string_buffer(32 * 32), np.zeros((2048, 2), dtype=np.uint64),
                         (ctypes.c_double * 6)(), ctypes.c_uint64(0), ctypes.create_string_buffer(512))
         buf, cap, roots, fin, sec, n, err = self._pp
-        rc = lib_host().vph_prove_protocol(self.h, ctypes.cast(buf, ctypes.c_void_p), cap, ctypes.byref(n), ctypes.cast(roots, ctypes.c_void_p), len(roots),
-                                           fin.ctypes.data, sec, err, len(err))
+        rc = lib_host().vph_prove_protocol_ex(self.h, ctypes.cast(buf, ctypes.c_void_p), cap, ctypes.byref(n), ctypes.cast(roots, ctypes.c_void_p), len(roots),
+                                              fin.ctypes.data, sec, (1 if deferred or queue_next else 0) | (2 if queue_next else 0), err, len(err))
         if rc:
             raise RuntimeError("prove_protocol failed: " + err.value.decode())
         st = self.circuit.layer_bitlen(0) - 6

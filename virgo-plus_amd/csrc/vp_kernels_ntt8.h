@@ -234,6 +234,149 @@ __global__ void __launch_bounds__(NTT8_THREADS) __attribute__((amdgpu_waves_per_
     }
 }
 
+// ---- pass A of the ENCODER (forward, rate 1 / ncoset), round 5: one workgroup runs ALL (or a chunk of) the cosets of its tile ---------------------
+// k_ntt8_cols reads its 64 KB input tile once per coset (32 times) and gathers, per coset, 4096 roots w_M^(j2 (ncoset k1 + b)) that no other tile or coset
+// shares — the whole 64 MB circle of order M once per row (PMC, round 4: 2.05 bytes fetched per byte written, SQ_WAIT_ANY 0.36).  Here
+//   * the eight inputs of a thread are loaded ONCE and stay in registers for every coset of the workgroup (the twist changes, the data does not);
+//   * the twiddle between the passes w_N^(j2 k1) does not depend on the coset: eight roots per thread, loaded once, in registers;
+//   * the column's share w_M^(j2 b) of the twist is common to every element of the column, so it commutes with the column transform: it rides on the
+//     twiddles of the SECOND pass (s = 8: w_64^(k m), 64 values) as ONE table T2[b][tile][m][k][c] = w_M^(j2 b) w_64^(k m) — 64 ncoset N2 entries (16 MB at
+//     x1024) read as whole 1 KB runs per wave, shared by every row — at the price of the m = 0 product (8 instead of 7 multiplications in that pass:
+//     30 instead of 29 per eight points for N1 = 256);
+//   * the j1 share of the twist w_M^(j1 N2 b) = w_(ncoset N1)^(j1 b) comes from the compact circle of that order (128 KB).
+// Per coset a workgroup touches global memory for 8 + 8 cached root loads per thread and its stores; nothing it waits for comes from HBM.
+// 256 threads on a 2048-element tile (2048 / N1 columns, 32 KB of LDS), 168 VGPRs: three workgroups per CU at different points of their loops.
+// N1 = 64, 128, 256 (N = 2^15 .. 2^17): radix 8, radix 8, then nothing / radix 2 / radix 4 — the Stockham schedule of k_ntt8_cols.
+struct Ntt8xArgs {
+    const F *in; F *out;            // source rows -> scratch [row x coset][k1][j2] (weakly reduced; pass B folds)
+    const F *TW;                    // w_(ncoset N1)^e, e < ncoset N1
+    const F *T2;                    // see above
+    const F *W1;                    // w_N^e, e < N
+    const F *RTn;                   // w_N1^e, e < N1 (third pass)
+    int ln; u32 in_stride, ncoset, cpw;     // cpw: cosets per workgroup (blockIdx.z = chunk)
+};
+constexpr u32 NTT8X_THREADS = 256, NTT8X_TILE = 2048;
+#ifndef VP_NTT8X_WAVES
+#define VP_NTT8X_WAVES 2
+#endif
+#ifndef VP_NTT8X_G
+#define VP_NTT8X_G 4
+#endif
+constexpr u32 NTT8X_G = VP_NTT8X_G;          // products whose roots are loaded, and which the scheduler may interleave, at a time (register budget: inputs and
+                                             // output twiddles of the thread stay in registers, 64 of the 168)
+// output slot o < 8 of a thread -> k1 (the Stockham schedule's last pass): N1 = 64: radix 8 at s = 8; N1 = 128 / 256: butterfly h = o / 2 (o / 4) of the radix-2 (radix-4)
+// pass at s = 64, output o % 2 (o % 4); q2 = tid >> LC of the first butterfly (the others sit 256 >> LC = N1 / 8 further)
+template <int L1> __device__ __forceinline__ u32 ntt8x_k1(u32 q, u32 o) {
+    constexpr u32 Q8 = (1u << L1) >> 3;
+    if (L1 == 6) return (q - (q & 7)) * 8 + (q & 7) + o * 8;
+    if (L1 == 7) return q + (o >> 1) * Q8 + (o & 1) * 64;
+    return q + (o >> 2) * Q8 + (o & 3) * 64;
+}
+template <int L1>
+__global__ void __launch_bounds__(NTT8X_THREADS) __attribute__((amdgpu_waves_per_eu(VP_NTT8X_WAVES, VP_NTT8X_WAVES))) k_ntt8_colsx(Ntt8xArgs a) {
+    __shared__ __align__(16) F L[NTT8X_TILE];
+    constexpr u32 N1 = 1u << L1, LC = 11 - L1, COLS = 1u << LC, Q8 = N1 >> 3, N2 = 512;       // N = N1 x 512 (the caller's split)
+    const u32 NM = (1u << a.ln) - 1;
+    const u32 tid = threadIdx.x, c = tid & (COLS - 1), q = tid >> LC;                    // q < N1 / 8
+    const u32 row = blockIdx.x, tile = blockIdx.y, j2 = tile * COLS + c, b0 = blockIdx.z * a.cpw;
+    const F *src = a.in + (size_t) row * a.in_stride + j2;
+    F uin[8], w1[8];
+#pragma unroll
+    for (u32 m = 0; m < 8; ++m) uin[m] = src[(size_t) (q + m * Q8) * N2];
+#pragma unroll
+    for (u32 m = 0; m < 8; ++m) w1[m] = a.W1[(j2 * ntt8x_k1<L1>(q, m)) & NM];              // w_N^(j2 k1): the same for every coset
+    const u32 TWM = a.ncoset * N1 - 1, ntiles = N2 >> LC, k = q & 7;
+    F *dst = a.out + (((size_t) row * a.ncoset + b0) << a.ln) + j2;
+    for (u32 bi = 0; bi < a.cpw; ++bi, dst += (size_t) 1 << a.ln) {
+        const u32 b = b0 + bi;
+        F u[8];
+        // ---- first pass (radix 8, s = 1): the inputs from registers, twisted by w^(j1 b), j1 = q + m N1 / 8
+        {
+            const u32 e0 = q * b, step = Q8 * b;
+#pragma unroll
+            for (u32 g = 0; g < 8; g += NTT8X_G) {
+                F w[NTT8X_G];
+#pragma unroll
+                for (u32 m = 0; m < NTT8X_G; ++m) w[m] = a.TW[(e0 + (g + m) * step) & TWM];
+                loads_first();
+#pragma unroll
+                for (u32 m = 0; m < NTT8X_G; ++m) u[g + m] = lz_mul(w[m], uin[g + m]);
+                loads_first();
+            }
+            lz_dft8<false>(u);
+#pragma unroll
+            for (u32 m = 0; m < 8; ++m) if (VP_CHK((((q * 8 + m) << LC) + c) < NTT8X_TILE, 6, q, m, c)) L[((q * 8 + m) << LC) + c] = u[m];
+        }
+        __syncthreads();
+        // ---- second pass (radix 8, s = 8): twiddles x the column's share of the twist, one table
+        {
+            const F *t2 = a.T2 + ((((size_t) b * ntiles + tile) * 64 + k) << LC) + c;              // [m] at stride 8 COLS
+#pragma unroll
+            for (u32 m = 0; m < 8; ++m) u[m] = L[((q + m * Q8) << LC) + c];
+#pragma unroll
+            for (u32 g = 0; g < 8; g += NTT8X_G) {
+                F w[NTT8X_G];
+#pragma unroll
+                for (u32 m = 0; m < NTT8X_G; ++m) w[m] = t2[(size_t) (g + m) * 8 * COLS];
+                loads_first();
+#pragma unroll
+                for (u32 m = 0; m < NTT8X_G; ++m) u[g + m] = lz_mul(w[m], u[g + m]);
+                loads_first();
+            }
+            lz_dft8<false>(u);
+        }
+        if (L1 == 6) {
+#pragma unroll
+            for (u32 m = 0; m < 8; ++m) { dst[(size_t) ntt8x_k1<L1>(q, m) * N2] = lz_mul(w1[m], u[m]); if ((m & (NTT8X_G - 1)) == NTT8X_G - 1) loads_first(); }
+            __syncthreads();                                    // the tile is free for the next coset's first pass
+            continue;
+        }
+        __syncthreads();
+#pragma unroll
+        for (u32 m = 0; m < 8; ++m) L[(((q - k) * 8 + k + m * 8) << LC) + c] = u[m];
+        __syncthreads();
+        // ---- third pass at s = 64: radix 2 (N1 = 128, four butterflies per thread) or radix 4 (N1 = 256, two)
+        if (L1 == 7) {
+#pragma unroll
+            for (u32 h = 0; h < 4; ++h) {
+                const u32 qq = q + h * Q8;                                                // < 64 = s: k = qq
+                F v[2];
+                v[0] = L[(qq << LC) + c]; v[1] = L[((qq + 64) << LC) + c];
+                v[1] = lz_mul(a.RTn[qq], v[1]);
+                lz_dft2(v);
+                dst[(size_t) ntt8x_k1<L1>(q, 2 * h) * N2] = lz_mul(w1[2 * h], v[0]);
+                dst[(size_t) ntt8x_k1<L1>(q, 2 * h + 1) * N2] = lz_mul(w1[2 * h + 1], v[1]);
+                loads_first();
+            }
+        } else {
+#pragma unroll
+            for (u32 h = 0; h < 2; ++h) {
+                const u32 qq = q + h * Q8;
+                F v[4], w[4];
+#pragma unroll
+                for (u32 m = 0; m < 4; ++m) v[m] = L[((qq + 64 * m) << LC) + c];
+#pragma unroll
+                for (u32 m = 1; m < 4; ++m) w[m] = a.RTn[(qq * m) & (N1 - 1)];
+                loads_first();
+#pragma unroll
+                for (u32 m = 1; m < 4; ++m) v[m] = lz_mul(w[m], v[m]);
+                lz_dft4<false>(v);
+#pragma unroll
+                for (u32 m = 0; m < 4; ++m) { dst[(size_t) ntt8x_k1<L1>(q, 4 * h + m) * N2] = lz_mul(w1[4 * h + m], v[m]); if (m & 1) loads_first(); }
+            }
+        }
+        __syncthreads();                                        // every read of the tile is done before the next coset's first pass writes it
+    }
+}
+// T2[b][tile][m][k][c] = w_M^(j2 b + (k m mod 64) M / 64), j2 = tile 2^lc + c: the second-pass roots of k_ntt8_colsx, from the half table of order M
+__global__ void __launch_bounds__(VP_BLOCK) k_ntt8x_t2(const F *__restrict__ RT, u32 half_m, u32 lc, u32 n2, u32 total, F *__restrict__ out) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const u32 c = i & ((1u << lc) - 1), k = (i >> lc) & 7, m = (i >> (lc + 3)) & 7, bt = i >> (lc + 6), ntiles = n2 >> lc;
+    const u32 tile = bt % ntiles, b = bt / ntiles, j2 = (tile << lc) + c, M = 2 * half_m;
+    out[i] = root_pow(RT, half_m, (j2 * b + ((k * m) & 63) * (M >> 6)) & (M - 1));
+}
+
 // ---- pass B: 512-point transforms along 8 neighbouring rows k1, one wave per row; natural-order store -----------------------------------------
 constexpr u32 NTT8_PITCH = 578;     // elements per row in LDS: 512 * 9 / 8 padded positions, + 2 so that the transposed read-out spreads over the banks
 __device__ __forceinline__ u32 ntt8_pad(u32 i) { return i + (i >> 3); }

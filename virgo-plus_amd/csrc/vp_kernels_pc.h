@@ -339,18 +339,35 @@ struct MerkleArgs { Dig *tree[VP_FRI_MAX]; u32 count[VP_FRI_MAX]; u32 blk_start[
 // both kinds of code at once issues everything at the rotation's rate.  x1024: 14.3 -> 11.6 ms per 2^21-leaf tree, digests unchanged.  A thread past
 // the end runs the chain of the last leaf (it must keep step with its workgroup) and stores nothing.  k_leaf_hash_c / k_leaf_hash_multi_c above are
 // the compiler's form of the same chains: the cross-check (leaf_asm = 0) and the checked build.
+#ifdef VP_LEAF_STAMPS
+// Diagnostic build only (tools/leaf_in_step.py; MI355X_MICROARCH.md, DVFS item 6): every workgroup of the leaf-hash kernels leaves
+// {s_memtime, s_memrealtime} from before and after its chains in a buffer of its own that nothing else reads; the effective shader clock of the
+// workgroup is d(memtime) / d(memrealtime) x 100 MHz.  The product build has none of this.
+__device__ unsigned long long g_leaf_stamps[4 * 65536];
+__device__ unsigned int g_leaf_stamp_n;
+#define VP_LEAF_STAMP_BEGIN const u64 st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#define VP_LEAF_STAMP_END(tag) if (threadIdx.x == 0) { const u64 st_t1 = __builtin_amdgcn_s_memtime(), st_r1 = __builtin_amdgcn_s_memrealtime(); \
+        const u32 sl = atomicAdd(&g_leaf_stamp_n, 1u) & 65535u; g_leaf_stamps[4 * sl] = st_t0; g_leaf_stamps[4 * sl + 1] = st_r0; g_leaf_stamps[4 * sl + 2] = st_t1; \
+        g_leaf_stamps[4 * sl + 3] = (st_r1 << 1) | (tag); }
+#else
+#define VP_LEAF_STAMP_BEGIN
+#define VP_LEAF_STAMP_END(tag)
+#endif
 __global__ void __launch_bounds__(VP_LEAF_ASM_THREADS)
 k_leaf_hash(const F *__restrict__ cw, u32 N, int n_slices, Dig *__restrict__ leaves) {
+    VP_LEAF_STAMP_BEGIN
     const u32 halfN = N >> 1, total = 32 * halfN;
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     const u32 tc = t < total ? t : total - 1;
     const u32 a = tc % halfN, b = tc / halfN;
     const F *x = cw + (size_t) b * N + a;
     vp_leaf_chain_asm(x, x + halfN, 32u * N * 16u, (unsigned) n_slices, leaves + (32 * a + b), t < total ? 1u : 0u);
+    VP_LEAF_STAMP_END(0u)
 }
 // All levels of the FRI commit phase in one launch: thread g takes leaf g of the levels laid end to end (leaf_start), so that the launch is exactly
 // ceil(leaves / workgroup) workgroups — a level of 16 leaves does not cost a workgroup (and with it a CU for the whole chain) of its own.
 __global__ void __launch_bounds__(VP_LEAF_ASM_THREADS) k_leaf_hash_multi(FriLeafArgs a) {
+    VP_LEAF_STAMP_BEGIN
     const u32 total = a.leaf_start[a.n];
     const u32 g = blockIdx.x * blockDim.x + threadIdx.x, gc = g < total ? g : total - 1;
     int j = 0;
@@ -363,6 +380,7 @@ __global__ void __launch_bounds__(VP_LEAF_ASM_THREADS) k_leaf_hash_multi(FriLeaf
     const u32 p = last ? t : t % halfN, b = last ? 0u : t / halfN;
     const F *x = cw + (size_t) b * N + p;
     vp_leaf_chain_asm(x, x + halfN, 32u * N * 16u, 64u, a.leaves[j] + (last ? t : 32 * p + b), g < total ? 1u : 0u);
+    VP_LEAF_STAMP_END(1u)
 }
 __global__ void __launch_bounds__(VP_BLOCK) k_merkle_level_multi(MerkleArgs a) {
     int j = 0;

@@ -7,6 +7,8 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <deque>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <atomic>
@@ -169,6 +171,20 @@ struct vp_ctx {
     Dig *pc_fri_roots = nullptr;
     F *pc_fri[2] = {nullptr, nullptr}; Dig *pc_fri_tree = nullptr; int fri_step = -1; size_t fri_tree_used = 0; bool pc_public_done = false;
 
+    // Deferred completion (vp_set_deferred / vp_flush; round 5).  A GPU that goes idle for a fraction of a millisecond — a host synchronisation between two
+    // prover calls, the host work between two proofs — runs the NEXT ten milliseconds at a lower clock (tools/leaf_in_step.py: k_leaf_hash alone 10.1 ms
+    // back to back, 10.5 ms behind 0.5 ms of idling, 11.7 ms behind 5 ms).  In deferred mode vp_commit_private, vp_prove_gkr (launch plan, unsharded),
+    // vp_commit_public_eq, vp_fri_commit and vp_fri_final queue their launches, stage their results in pinned memory, record what is left to do once the
+    // stream has got there, and return; vp_flush waits and finishes them in order (copies into the caller's buffers, device times).  Every other entry point
+    // flushes first.
+    int deferred = 0;
+    struct Pending { hipEvent_t a, b; int phase; std::function<int(float)> fin; };
+    std::deque<Pending> pending;
+    std::vector<hipEvent_t> ev_spare;
+    unsigned char *h_ring = nullptr; size_t ring_cap = 0, ring_at = 0;      // pinned ring: results on their way out, small arrays on their way in
+    double phase_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};                         // device time of the last call of each kind (VP_PH_*)
+    u64 private_epoch = 0;                                                  // vp_commit_private calls queued on this context so far
+
     PcShard *pcs = nullptr;              // non-null while the commitment is sharded over ranks (vp_pc_set_shard, world > 1)
     FgkState *fgk = nullptr;             // vp_fft_gkr: circuit layers and sumcheck tables of the last size used
     VpComm *cm = nullptr;                // RCCL communicator (vp_comm_init)
@@ -253,7 +269,10 @@ struct CtxLock {
     CtxLock(const CtxLock &) = delete; CtxLock &operator=(const CtxLock &) = delete;
 };
 #define VP_LOCK(ctx) CtxLock vp_ctx_lock_(ctx, false)
-#define VP_ENTER(ctx) CtxLock vp_ctx_lock_(ctx, true); do { HIPCHK(hipSetDevice((ctx)->device)); if ((ctx)->tail_active) (void) tail_quit(ctx); (ctx)->tail_suspended = false; (ctx)->tail_lost = false; } while (0)
+int flush_pending(vp_ctx *ctx, size_t count);
+// VP_ENTER_Q: the entry points that can leave their completion pending (deferred mode); everything else finishes what is pending first
+#define VP_ENTER_Q(ctx) CtxLock vp_ctx_lock_(ctx, true); do { HIPCHK(hipSetDevice((ctx)->device)); if ((ctx)->tail_active) (void) tail_quit(ctx); (ctx)->tail_suspended = false; (ctx)->tail_lost = false; } while (0)
+#define VP_ENTER(ctx) VP_ENTER_Q(ctx); do { if (!(ctx)->pending.empty()) VPCHK(flush_pending((ctx), (size_t) -1)); } while (0)
 
 constexpr u32 MAX_BLOCKS = 2048;     // 256 CUs x 8 resident 256-thread blocks
 
@@ -525,6 +544,78 @@ int check_stream(vp_ctx *ctx) {
         return VP_EHIP;
     }
     return vp_check_collect(ctx);
+}
+
+// ---- deferred completion (see vp_ctx::deferred) -----------------------------------------------------------------------
+enum { VP_PH_PRIVATE = 0, VP_PH_GKR = 1, VP_PH_PUBLIC = 2, VP_PH_FRI = 3, VP_PH_FRI_FINAL = 4 };
+hipEvent_t ev_take(vp_ctx *ctx) {
+    if (!ctx->ev_spare.empty()) { hipEvent_t e = ctx->ev_spare.back(); ctx->ev_spare.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void) hipEventCreate(&e);
+    return e;
+}
+// pinned bytes that stay untouched until the stream has consumed / produced them: a ring far larger than what two proofs in flight stage (< 100 KB each)
+int ring_alloc(vp_ctx *ctx, size_t bytes, void **out) {
+    if (!ctx->h_ring) {
+        HIPCHK(hipHostMalloc((void **) &ctx->h_ring, (size_t) 8 << 20, hipHostMallocDefault));
+        ctx->ring_cap = (size_t) 8 << 20; ctx->ring_at = 0;
+    }
+    bytes = (bytes + 63) & ~(size_t) 63;
+    if (bytes > ctx->ring_cap / 8) { ctx->err = "internal: staging request too large"; return VP_ELIMIT; }
+    if (ctx->ring_at + bytes > ctx->ring_cap) ctx->ring_at = 0;
+    *out = ctx->h_ring + ctx->ring_at;
+    ctx->ring_at += bytes;
+    return VP_OK;
+}
+int defer_begin(vp_ctx *ctx, hipEvent_t *a) {
+    *a = ev_take(ctx);
+    if (!*a) { ctx->err = "hipEventCreate"; return VP_EHIP; }
+    HIPCHK(hipEventRecord(*a, ctx->stream));
+    return VP_OK;
+}
+// fin(ms): what the entry point does once its work is done (ms = device time between defer_begin and here).  Not deferred: waits and runs it now.
+template <class Fn>
+int defer_end(vp_ctx *ctx, hipEvent_t a, int phase, Fn fin) {
+    hipEvent_t b = ev_take(ctx);
+    if (!b) { ctx->ev_spare.push_back(a); ctx->err = "hipEventCreate"; return VP_EHIP; }
+    if (hipEventRecord(b, ctx->stream) != hipSuccess) { ctx->ev_spare.push_back(a); ctx->ev_spare.push_back(b); ctx->err = "hipEventRecord"; return VP_EHIP; }
+    if (!ctx->deferred || ctx->profiling) {
+        const int rc = check_stream(ctx);
+        float ms = 0;
+        if (rc == VP_OK) { if (ctx->profiling) prof_collect(ctx); (void) hipEventElapsedTime(&ms, a, b); }
+        ctx->ev_spare.push_back(a); ctx->ev_spare.push_back(b);
+        if (rc != VP_OK) return rc;
+        ctx->phase_ms[phase] = ms;
+        return fin(ms);
+    }
+    ctx->pending.push_back(vp_ctx::Pending{a, b, phase, std::function<int(float)>(fin)});
+    return VP_OK;
+}
+// finish the first `count` pending calls in order ((size_t) -1: all).  After a failure the rest are dropped (their outputs stay unwritten).
+int flush_pending(vp_ctx *ctx, size_t count) {
+    int rc = VP_OK;
+    while (count-- && !ctx->pending.empty()) {
+        vp_ctx::Pending p = std::move(ctx->pending.front());
+        ctx->pending.pop_front();
+        hipError_t e = hipEventSynchronize(p.b);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e != hipSuccess) { ctx->err = std::string("stream: ") + hipGetErrorString(e); rc = VP_EHIP; }
+        if (rc == VP_OK) {
+            float ms = 0;
+            (void) hipEventElapsedTime(&ms, p.a, p.b);
+            ctx->phase_ms[p.phase] = ms;
+            rc = p.fin(ms);
+        }
+        ctx->ev_spare.push_back(p.a); ctx->ev_spare.push_back(p.b);
+        if (rc != VP_OK) break;
+    }
+    if (rc != VP_OK) {
+        (void) hipStreamSynchronize(ctx->stream);
+        for (auto &p : ctx->pending) { ctx->ev_spare.push_back(p.a); ctx->ev_spare.push_back(p.b); }
+        ctx->pending.clear();
+        return rc;
+    }
+    return ctx->pending.empty() ? vp_check_collect(ctx) : VP_OK;
 }
 
 // ---- persistent round kernel (vp_kernels_persist.h): host side of the mailbox ---------------------------------------
@@ -863,6 +954,9 @@ void vp_destroy(vp_ctx *ctx) {
     if (ctx->h_aux) (void) hipHostFree(ctx->h_aux);
     if (ctx->h_stage) (void) hipHostFree(ctx->h_stage);
     if (ctx->h_io) (void) hipHostFree(ctx->h_io);
+    if (ctx->h_ring) (void) hipHostFree(ctx->h_ring);
+    for (auto &p : ctx->pending) { (void) hipEventDestroy(p.a); (void) hipEventDestroy(p.b); }
+    for (auto e : ctx->ev_spare) (void) hipEventDestroy(e);
     for (auto st : ctx->lane_streams) (void) hipStreamDestroy(st);
     for (auto ev : ctx->lane_events) (void) hipEventDestroy(ev);
     if (ctx->ev_fork) (void) hipEventDestroy(ctx->ev_fork);
@@ -1095,6 +1189,7 @@ int vp_evaluate(vp_ctx *ctx, const vp_F *inputs, uint64_t n_inputs) {
     if (!ctx || !inputs || ctx->n_layers < 2 || n_inputs != ctx->L[0].size) return VP_EINVAL;
     VP_ENTER(ctx);
     LayerDev &L0 = ctx->L[0];
+    ctx->pc_private_done = false; ctx->pc_public_done = false;          // a commitment to the previous witness does not stand for this one
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     HIPCHK(hipMemsetAsync(L0.val, 0, (sizeof(F) << L0.bl), ctx->stream));
     HIPCHK(hipMemcpyAsync(L0.val, inputs, n_inputs * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
@@ -1585,6 +1680,36 @@ int vp_get_round_stats(vp_ctx *ctx, vp_round_stat *out, int capacity, int *n) {
     VP_LOCK(ctx);                                             // a concurrent vp_round on this context appends to (and may reallocate) rlog
     *n = (int) ctx->rlog.size();
     for (int i = 0; i < *n && i < capacity; ++i) out[i] = ctx->rlog[i];
+    return VP_OK;
+}
+int vp_set_deferred(vp_ctx *ctx, int on) {
+    if (!ctx) return VP_EINVAL;
+    VP_ENTER_Q(ctx);
+    ctx->deferred = on ? 1 : 0;                               // (what is pending stays pending: vp_flush, or the next entry point that cannot defer, finishes it)
+    return VP_OK;
+}
+int vp_pending(vp_ctx *ctx, int *n) {
+    if (!ctx || !n) return VP_EINVAL;
+    VP_LOCK(ctx);
+    *n = (int) ctx->pending.size();
+    return VP_OK;
+}
+int vp_flush(vp_ctx *ctx, int count) {
+    if (!ctx) return VP_EINVAL;
+    VP_ENTER_Q(ctx);
+    return flush_pending(ctx, count < 0 ? (size_t) -1 : (size_t) count);
+}
+int vp_phase_ms(vp_ctx *ctx, double out[5]) {
+    if (!ctx || !out) return VP_EINVAL;
+    VP_LOCK(ctx);
+    for (int i = 0; i < 5; ++i) out[i] = ctx->phase_ms[i];
+    return VP_OK;
+}
+int vp_commit_private_state(vp_ctx *ctx, uint64_t *epoch, int *valid) {
+    if (!ctx || !epoch || !valid) return VP_EINVAL;
+    VP_LOCK(ctx);
+    *epoch = ctx->private_epoch;
+    *valid = ctx->pc_private_done && !ctx->pcs ? 1 : 0;
     return VP_OK;
 }
 int vp_set_profiling(vp_ctx *ctx, int level) {

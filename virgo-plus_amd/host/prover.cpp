@@ -328,6 +328,7 @@ std::vector<F> prover::fftGkrEnd(int lg) {
     msgs.resize(written);
     return msgs;
 }
+void prover::fftGkrCancel() noexcept { (void) vp_fft_gkr_cancel(ctx); }
 double prover::commitDeviceMs() { double ms = 0; check(vp_commit_stats(ctx, &ms), "vp_commit_stats"); return ms; }
 
 void prover::gkrSizes(u64 &n_tape, u64 &n_bytes) {

@@ -74,6 +74,7 @@ public:
     // the same in two halves (vp_fft_gkr_begin / _end): queued on a stream of its own, collected later; other prover calls may run in between
     void fftGkrBegin(int lg, const std::vector<F> &tape);
     std::vector<F> fftGkrEnd(int lg);
+    void fftGkrCancel() noexcept;                   // drop a begun run (a pass that failed between begin and end)
     double commitDeviceMs();
 
     double proveTime() const { return prove_timer.elapse_sec(); }

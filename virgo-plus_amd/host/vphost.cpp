@@ -20,6 +20,10 @@ struct vph_session {
     double t_init = 0, t_round = 0, t_fin = 0;
     std::vector<F> last_point;                                           // r_liu after the last Liu sumcheck of the last complete-protocol run
     std::vector<F> ptape_fft, ptape_fri;                                 // vph_draw_protocol_tape: the draws after the GKR tape (fft_gkr, FRI folds)
+    // vph_prove_protocol_ex: where the device's results land (the calls of a deferred pass write them when the pass is collected)
+    std::vector<uint8_t> pp_gkr, pp_roots; std::vector<F> pp_all, pp_final; F pp_inner; uint64_t pp_written = 0;
+    uint8_t pp_root_l[32], pp_root_h[32], pp_root_next[32];
+    bool head_queued = false; uint64_t head_epoch = 0;                   // the previous pass queued this one's commit_private (VPH_PASS_QUEUE_NEXT)
 };
 
 static void set_err(char *err, int errlen, const std::string &m) {
@@ -385,11 +389,21 @@ int vph_draw_protocol_tape(vph_session *s) {
 }
 // commit_private -> GKR (one batched device pass) -> commit_public on eq(r_liu, .) built on the device -> fft_gkr -> FRI commit phase +
 // final codeword: every prover call of verifier::verify() except answering the queries, nothing of the verifier.  transcript = the golden
-// layout (merkle_root_l | GKR | merkle_root_h | input_0 | all_sum[65]); fri_roots: 32 bytes per fold step; final_pairs: 2048 elements;
-// sec[6] = whole pass | commit_private | GKR | commit_public | fft_gkr | FRI commit phase + final (host wall clock).  The fft_gkr
-// messages stay with the session (vph_last_fft_gkr), the FRI data too (vph_last_fri).  0 = done, < 0 = error.
-int vph_prove_protocol(vph_session *s, uint8_t *transcript, uint64_t capacity, uint64_t *n_written, uint8_t *fri_roots, uint64_t roots_cap,
-                       uint64_t *final_pairs, double sec[6], char *err, int errlen) {
+// layout (merkle_root_l | GKR | merkle_root_h | input_0 | all_sum[65]); fri_roots: 32 bytes per fold step; final_pairs: 2048 elements.
+// flags (vphost.h): VPH_PASS_DEFERRED — the calls are queued back to back without a host wait between them (vp_set_deferred) and collected at the end;
+// VPH_PASS_QUEUE_NEXT — before it waits, the pass queues the HEAD of the next one (commit_private of the same witness) behind its own folds, so
+// that the device goes from this proof's last kernel straight into the next proof's first (the next pass finds it and starts at the GKR part).
+// sec[6] = whole pass (host wall clock) | commit_private | GKR | commit_public | fft_gkr (host time of its begin + end) | FRI commit phase + final;
+// synchronous: host wall clock of each call, deferred: device time of each call (vp_phase_ms).  The fft_gkr messages stay with the session
+// (vph_last_fft_gkr), the FRI data too (vph_last_fri).  0 = done, < 0 = error.
+int vph_prove_protocol_ex(vph_session *s, uint8_t *transcript, uint64_t capacity, uint64_t *n_written, uint8_t *fri_roots, uint64_t roots_cap,
+                          uint64_t *final_pairs, double sec[6], int flags, char *err, int errlen) {
+    vp_ctx *ctx = s->p->context();
+    const bool defer = (flags & VPH_PASS_DEFERRED) != 0, queue_next = defer && (flags & VPH_PASS_QUEUE_NEXT) != 0;
+    // a run of fft_gkr that is begun and not collected when this function leaves, for whatever reason, is dropped (it would make every later pass of the
+    // session fail with "not collected")
+    struct FftGuard { prover *p; bool armed; ~FftGuard() { if (armed) p->fftGkrCancel(); } } fft_guard{s->p.get(), false};
+    auto chk = [&](int rc, const char *what) { if (rc != VP_OK) throw std::runtime_error(std::string(what) + ": " + vp_last_error(ctx)); };
     try {
         const layeredCircuit &C = s->circ->c;
         const int n = C.circuit[0].bitLength, ln = n - 6;
@@ -399,53 +413,94 @@ int vph_prove_protocol(vph_session *s, uint8_t *transcript, uint64_t capacity, u
         using clk = std::chrono::high_resolution_clock;
         auto since = [](clk::time_point t) { return std::chrono::duration<double>(clk::now() - t).count(); };
         const auto t0 = clk::now();
-        std::vector<uint8_t> out;
-        out.reserve(capacity);
-        auto t = clk::now();
-        // fft_gkr (vpd_verifier.cpp:92) depends on the verifier's draws only: queued first on its own stream, collected last — its small
-        // launches run in the gaps of everything below (VPH_FFT_GKR_SYNC=1: in the reference's place, between commit_public and the FRI folds)
         static const bool fft_sync = getenv("VPH_FFT_GKR_SYNC") != nullptr;
-        if (!fft_sync) s->p->fftGkrBegin(ln, s->ptape_fft);
-        double s_fft = since(t);
+        u64 nt = 0, nb = 0;
+        s->p->gkrSizes(nt, nb);
+        if (s->tape.size() != nt) throw std::runtime_error("the tape has the wrong length");
+        s->pp_gkr.resize(nb); s->pp_all.resize(65); s->pp_roots.resize((size_t) 32 * ln); s->pp_final.resize(2048);
+        chk(vp_set_deferred(ctx, defer ? 1 : 0), "vp_set_deferred");
+        // ---- head: fft_gkr (depends on the verifier's draws only: queued on its own stream, its small launches run in the gaps of everything below;
+        // VPH_FFT_GKR_SYNC=1: in the reference's place, between commit_public and the FRI folds) and commit_private (src/verifier.cpp:137) —
+        // unless the previous pass queued them for this one and that commitment still stands
+        uint64_t epoch = 0; int valid = 0;
+        chk(vp_commit_private_state(ctx, &epoch, &valid), "vp_commit_private_state");
+        const bool have_head = s->head_queued && valid && epoch == s->head_epoch;
+        s->head_queued = false;
+        auto t = clk::now();
+        double s_fft = 0, s_priv = 0, s_gkr = 0, s_pub = 0, s_fri = 0;
+        if (!have_head) {
+            chk(vp_commit_private(ctx, s->pp_root_l), "vp_commit_private");
+            s_priv = since(t);
+        }
+        // ---- GKR (src/verifier.cpp:144-169)
         t = clk::now();
-        const prover::hhash_digest rl = s->p->commit_private();                       // src/verifier.cpp:137
-        out.insert(out.end(), rl.b, rl.b + 32);
-        const double s_priv = since(t);
+        chk(vp_prove_gkr(ctx, reinterpret_cast<const vp_F *>(s->tape.data()), nt, s->pp_gkr.data(), nb, &s->pp_written), "vp_prove_gkr");
+        s_gkr = since(t);
+        // ---- fft_gkr (vpd_verifier.cpp:92) depends on the verifier's draws only.  It is queued on a stream of its own BEHIND the proof (vp_fft_gkr_begin starts
+        // behind what the context has queued so far) and collected last: its ~100 few-workgroup launches then run beside commit_public's transforms, which do not
+        // notice them.  Beside a leaf-hash launch they cost that launch a ninth round of workgroups (11.4 instead of 10.2 ms), beside the proof's graph 0.9 ms
+        // of its critical path (measured, tools/pass_modes.py / tools/leaf_in_step.py).  VPH_FFT_GKR_SYNC=1: in the reference's place, on the main stream
         t = clk::now();
-        s->p->proveGKR(s->tape, out);                                                 // :144-169
-        const double s_gkr = since(t);
+        if (!fft_sync) { s->p->fftGkrBegin(ln, s->ptape_fft); fft_guard.armed = true; }
+        s_fft = since(t);
         // r_liu after the last Liu sumcheck = the last max_bl draws of the GKR tape (verifier::drawTape), its first n coordinates
         s->last_point.assign(s->tape.end() - max_bl, s->tape.end() - max_bl + n);
+        // ---- commit_public on eq(r_liu, .) (:368-379)
         t = clk::now();
-        F inner; std::vector<F> all_sum;
-        const prover::hhash_digest rh = s->p->commit_public_eq(s->last_point, inner, all_sum);   // :368-379
-        const double s_pub = since(t);
-        out.insert(out.end(), rh.b, rh.b + 32);
-        const uint8_t *ib = reinterpret_cast<const uint8_t *>(&inner);
-        out.insert(out.end(), ib, ib + 16);
-        const uint8_t *ab = reinterpret_cast<const uint8_t *>(all_sum.data());
-        out.insert(out.end(), ab, ab + 65 * 16);
+        chk(vp_commit_public_eq(ctx, reinterpret_cast<const vp_F *>(s->last_point.data()), n, reinterpret_cast<vp_F *>(&s->pp_inner),
+                                reinterpret_cast<vp_F *>(s->pp_all.data()), s->pp_root_h), "vp_commit_public_eq");
+        s_pub = since(t);
         if (fft_sync) { t = clk::now(); s->fft_gkr_msgs = s->p->fftGkr(ln, s->ptape_fft); s_fft = since(t); }
+        // ---- FRI commit phase (vpd_verifier.cpp:44-74) + final codeword
         t = clk::now();
-        const std::vector<prover::hhash_digest> ds = s->p->friCommit(s->ptape_fri);   // vpd_verifier.cpp:44-74
-        s->fri_final = s->p->friFinal();
-        const double s_fri = since(t);
-        if (!fft_sync) { t = clk::now(); s->fft_gkr_msgs = s->p->fftGkrEnd(ln); s_fft += since(t); }
-        s->fri_roots.clear();
-        for (auto &d : ds) s->fri_roots.insert(s->fri_roots.end(), d.b, d.b + 32);
+        chk(vp_fri_commit(ctx, reinterpret_cast<const vp_F *>(s->ptape_fri.data()), ln, s->pp_roots.data()), "vp_fri_commit");
+        chk(vp_fri_final(ctx, reinterpret_cast<vp_F *>(s->pp_final.data())), "vp_fri_final");
+        s_fri = since(t);
+        int n_mine = 0;
+        chk(vp_pending(ctx, &n_mine), "vp_pending");
+        if (queue_next) {
+            // the next pass's commit_private, behind this pass's folds in stream order; this pass's results are collected below while the device runs it
+            chk(vp_commit_private(ctx, s->pp_root_next), "vp_commit_private (next pass)");
+            uint64_t e2 = 0; int v2 = 0;
+            chk(vp_commit_private_state(ctx, &e2, &v2), "vp_commit_private_state");
+            s->head_queued = true; s->head_epoch = e2;
+        }
+        if (defer) {
+            chk(vp_flush(ctx, n_mine), "vp_flush");
+            double ms[5] = {0, 0, 0, 0, 0};
+            chk(vp_phase_ms(ctx, ms), "vp_phase_ms");
+            s_priv = ms[0] * 1e-3; s_gkr = ms[1] * 1e-3; s_pub = ms[2] * 1e-3; s_fri = (ms[3] + ms[4]) * 1e-3;
+        }
+        chk(vp_set_deferred(ctx, 0), "vp_set_deferred");      // the mode belongs to this pass: whatever the session calls next waits for its results as usual
+        // fft_gkr is collected last: its launches had the whole pass to run beside the main stream's
+        if (!fft_sync) { t = clk::now(); fft_guard.armed = false; s->fft_gkr_msgs = s->p->fftGkrEnd(ln); s_fft += since(t); }
+        const uint64_t total = 32 + s->pp_written + 32 + 16 + 65 * 16;
+        if (total > capacity || (fri_roots && roots_cap < s->pp_roots.size())) { set_err(err, errlen, "output buffer too small"); return -1; }
+        uint8_t *o = transcript;
+        memcpy(o, have_head ? s->pp_root_next : s->pp_root_l, 32); o += 32;      // (a head queued by the previous pass left its root in pp_root_next)
+        memcpy(o, s->pp_gkr.data(), s->pp_written); o += s->pp_written;
+        memcpy(o, s->pp_root_h, 32); o += 32;
+        memcpy(o, &s->pp_inner, 16); o += 16;
+        memcpy(o, s->pp_all.data(), 65 * 16);
+        if (n_written) *n_written = total;
+        s->fri_roots = s->pp_roots;
+        s->fri_final = s->pp_final;
         s->fri_r = s->ptape_fri;
-        const double s_all = since(t0);
-        if (out.size() > capacity || (fri_roots && roots_cap < s->fri_roots.size())) { set_err(err, errlen, "output buffer too small"); return -1; }
-        memcpy(transcript, out.data(), out.size());
-        if (n_written) *n_written = out.size();
         if (fri_roots) memcpy(fri_roots, s->fri_roots.data(), s->fri_roots.size());
         if (final_pairs) memcpy(final_pairs, s->fri_final.data(), s->fri_final.size() * sizeof(F));
-        if (sec) { sec[0] = s_all; sec[1] = s_priv; sec[2] = s_gkr; sec[3] = s_pub; sec[4] = s_fft; sec[5] = s_fri; }
+        if (sec) { sec[0] = since(t0); sec[1] = s_priv; sec[2] = s_gkr; sec[3] = s_pub; sec[4] = s_fft; sec[5] = s_fri; }
         return 0;
     } catch (const std::exception &e) {
+        (void) vp_flush(ctx, -1);                        // nothing of a failed pass stays queued
+        (void) vp_set_deferred(ctx, 0);
+        s->head_queued = false;
         set_err(err, errlen, e.what());
         return -2;
     }
+}
+int vph_prove_protocol(vph_session *s, uint8_t *transcript, uint64_t capacity, uint64_t *n_written, uint8_t *fri_roots, uint64_t roots_cap,
+                       uint64_t *final_pairs, double sec[6], char *err, int errlen) {
+    return vph_prove_protocol_ex(s, transcript, capacity, n_written, fri_roots, roots_cap, final_pairs, sec, 0, err, errlen);
 }
 
 int vph_verify_transcript(vph_circuit *c, const uint8_t *transcript, uint64_t n, int skip_predicates) {

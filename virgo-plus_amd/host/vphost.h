@@ -107,7 +107,16 @@ int vph_prove_full(vph_session *, uint8_t *transcript, uint64_t capacity, uint64
  * final_pairs: 2048 elements; sec[6] = whole pass | commit_private | GKR | commit_public | fft_gkr | FRI commit (host wall clock).   */
 int vph_draw_protocol_tape(vph_session *);
 int vph_prove_protocol(vph_session *, uint8_t *transcript, uint64_t capacity, uint64_t *n_written, uint8_t *fri_roots, uint64_t roots_cap,
-                       uint64_t *final_pairs, double sec[6], char *err, int errlen);
+                       uint64_t *final_pairs, double sec[6], char *err, int errlen);            /* = _ex with flags 0 */
+/* flags: 0 = every call waits for its result before the next is made (sec[1..5]: host wall clock per call);
+ * VPH_PASS_DEFERRED = the calls are queued back to back and collected at the end (vp_set_deferred, include/vpgpu.h: a device that idles between two calls
+ *   runs the following milliseconds at a lower clock); sec[1..5]: device time per call;
+ * | VPH_PASS_QUEUE_NEXT = before it waits, the pass queues the next pass's head (commit_private of the same witness) behind its own FRI folds, and
+ *   the next vph_prove_protocol_ex of the session starts at its GKR part: no idle device between two proofs of a session that proves back to back.  The
+ *   openings of THIS pass's commitment are gone once that head runs (it overwrites the codeword); a pass that will be opened is made without the flag. */
+enum { VPH_PASS_DEFERRED = 1, VPH_PASS_QUEUE_NEXT = 2 };
+int vph_prove_protocol_ex(vph_session *, uint8_t *transcript, uint64_t capacity, uint64_t *n_written, uint8_t *fri_roots, uint64_t roots_cap,
+                          uint64_t *final_pairs, double sec[6], int flags, char *err, int errlen);
 /* No GPU needed: F::init(), draw the tape for `circuit`, replay the host verifier over `transcript`
  * (GKR slice).  0 = accepted, 1 = rejected.                                                            */
 int vph_verify_transcript(vph_circuit *, const uint8_t *transcript, uint64_t n, int skip_predicates);
