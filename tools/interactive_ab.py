@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Drop-in (interactive) path: init and round 1 as separate launches (VP_FUSE_R1=0) against the init pass that also sums round 1 (k_round1_gen), same process,
-alternating sessions:  python tools/interactive_ab.py [BLOCKS ...]"""
+alternating sessions:  python tools/interactive_ab.py [BLOCKS ...]
+(the fused pass was measured neutral and removed again: commit eff9a98 holds it, profiles/r05_ab_interactive_init_with_round1_x16_x64_x1024.txt the numbers)"""
 import gzip, os, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -619,92 +619,6 @@ __global__ void __launch_bounds__(VP_BLOCK, VP_SF_MINB) k_sumfold3b_gen_multi(co
         sumfold3b_body<false>(j.sf, m.bid, j.sf.nblk, sm, g);
     }
 }
-// ---- interactive (drop-in) path, round 5: the init of a sumcheck and its FIRST ROUND in one pass -------------------------------------------------------
-// vp_phase1_init / vp_phase2_init / vp_liu_init queue round 1 behind their init kernels (it takes no challenge).  As two launches that is: write the
-// mult / add tables (32 B per entry; phase 2 also V), read all three back (48 B per entry) and sum the pairs — at x1024 the 42 read-only round-1 passes were
-// 6.8 ms of a 26 ms proof (profiles/r04_interactive_round_classes_x1024.txt).  Here a thread generates the mult / add entries of a PAIR of rows from the
-// target-sorted lists (the Gen structs of the batched path's fused launches: the same field elements as k_init2_light / k_liu_gather), stores them for the
-// later rounds and adds the pair's three products to the round's sums on the spot; the workgroup that finishes last closes the round (k_round_main's
-// hand-off).  Rows with more than VP_LIGHT_MAX contributions are summed by the chunk launches BEFORE this one and read from the tables; tables that
-// start with a single entry are written by k_init2_rows before it (the closing reads them).
-struct Round1Gen { InitArgs2 a; GatherJob g; const unsigned long long *inVr; int mode; int pad; };     // mode 1 / 2 / 3 as SfGenJob
-template <bool HAS_A, class Gen>
-__device__ __forceinline__ void round1_gen_body(const RoundArgs &a, const Gen &gen, const unsigned long long *inVr, u32 bid, u32 nb, F (&acc)[3], F *lds) {
-    Lz X{0, 0}, Y{0, 0}, Z{0, 0};
-    for (u32 q = bid * blockDim.x + threadIdx.x; q < a.total_pairs; q += nb * blockDim.x) {
-        int j = 0;
-        while (j + 1 < a.n_tab && q >= a.t[j + 1].pair_start) ++j;
-        const TabDesc td = a.t[j];
-        const u32 i0 = td.off + 2 * (q - td.pair_start), vend = td.off + td.valid_in;
-        u32 cb0, ce0, ce1;
-        gen.ptrs(i0, vend, cb0, ce0, ce1);
-        F v0, v1, m0, m1, a0, a1;
-        if constexpr (Gen::MODE == 3) { v0 = gen.vrow(i0, vend); v1 = gen.vrow(i0 + 1, vend); }
-        else if (inVr) { v0 = f_make(i0 < vend ? inVr[i0] : 0ull, 0); v1 = f_make(i0 + 1 < vend ? inVr[i0 + 1] : 0ull, 0); }
-        else { v0 = ld_or_zero(a.inV, i0, vend); v1 = ld_or_zero(a.inV, i0 + 1, vend); }
-        gen.row2(i0, vend, cb0, ce0, ce1, m0, a0, m1, a1);
-        if (i0 < vend && VP_CHK((unsigned long long) i0 < g_vp_chk_cap(), 5, td.off, i0, 0)) {
-            a.outM[i0] = m0;
-            if (HAS_A) a.outA[i0] = a0;
-            if constexpr (Gen::MODE == 3) a.outV[i0] = v0;
-        }
-        if (i0 + 1 < vend && VP_CHK((unsigned long long) i0 + 1 < g_vp_chk_cap(), 5, td.off, i0 + 1, 0)) {
-            a.outM[i0 + 1] = m1;
-            if (HAS_A) a.outA[i0 + 1] = a1;
-            if constexpr (Gen::MODE == 3) a.outV[i0 + 1] = v1;
-        }
-        lz_add(X, f_mad_lazy<true>(f_sub_lazy(m1, m0), f_sub_lazy(v1, v0), f_zero()));
-        lz_add(Y, f_mad_c<true>(m1, v1, HAS_A ? a1 : f_zero()));
-        lz_add(Z, f_mad_c<true>(m0, v0, HAS_A ? a0 : f_zero()));
-        lz_fold(X); lz_fold(Y); lz_fold(Z);
-    }
-    acc[0] = lz_canon(X); acc[1] = lz_canon(Y); acc[2] = lz_canon(Z);
-    block_sum<3>(acc, lds);
-}
-__global__ void __launch_bounds__(VP_BLOCK, VP_SF_MINB) k_round1_gen(RoundArgs a, Round1Gen rg, F *__restrict__ part, unsigned int *__restrict__ arrivals, RoundOut o) {
-    __shared__ F lds[12];
-    __shared__ int s_last;
-    F acc[3] = {f_zero(), f_zero(), f_zero()};
-    if (rg.mode == 1) { GenP1 g; g.a = &rg.a; g.dot_part = nullptr; round1_gen_body<true>(a, g, rg.inVr, blockIdx.x, gridDim.x, acc, lds); }
-    else if (rg.mode == 3) { GenP2 g; g.a = &rg.a; round1_gen_body<true>(a, g, nullptr, blockIdx.x, gridDim.x, acc, lds); }
-    else { GenLiu g; g.rowptr = rg.g.rowptr; g.e_q = rg.g.e_q; g.e_g = rg.g.e_g; g.H = rg.g.H; round1_gen_body<false>(a, g, rg.inVr, blockIdx.x, gridDim.x, acc, lds); }
-    if (threadIdx.x == 0) {            // the hand-off of k_round_main (vp_kernels_round.h), word for word
-        unsigned long long *w = reinterpret_cast<unsigned long long *>(part + (size_t) blockIdx.x * 3);
-        cf_st(w, acc[0].re); cf_st(w + 1, acc[0].im); cf_st(w + 2, acc[1].re); cf_st(w + 3, acc[1].im); cf_st(w + 4, acc[2].re); cf_st(w + 5, acc[2].im);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        s_last = __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    F t[3] = {f_zero(), f_zero(), f_zero()};
-    for (u32 i = threadIdx.x; i < gridDim.x; i += blockDim.x) {
-        const unsigned long long *w = reinterpret_cast<const unsigned long long *>(part + (size_t) i * 3);
-        t[0] = f_add(t[0], f_make(cf_ld(w), cf_ld(w + 1)));
-        t[1] = f_add(t[1], f_make(cf_ld(w + 2), cf_ld(w + 3)));
-        t[2] = f_add(t[2], f_make(cf_ld(w + 4), cf_ld(w + 5)));
-    }
-    __syncthreads();
-    block_sum<3>(t, lds);
-    if (threadIdx.x != 0) return;
-    __hip_atomic_store(arrivals, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    round_final_tail(a, t, o.add_term, o.scalarV, o.poly_dev, o.poly_host, o.seq_host, o.seq);
-}
-// the rows of a short list (the single-entry tables of a phase 2) through the light-row init
-struct RowList { u32 n; u32 row[VP_MAX_TAB]; };
-__global__ void __launch_bounds__(64) k_init2_rows(InitArgs2 a, RowList rl) {
-    if (threadIdx.x >= rl.n) return;
-    const u32 row = rl.row[threadIdx.x];
-    if (row >= a.n_rows) return;
-    const int l = a.s_layer[row];
-    if (l != 0xfe) a.V[row] = (l == 0xff || !VP_CHK((unsigned) l < g_vp_chk_layers() && a.s_idx[row] < g_vp_chk_lsize(l), 2, l, a.s_idx[row], row)) ? f_zero() : val_at(a, l, a.s_idx[row]);
-    const u32 b = a.rowptr[row], e = a.rowptr[row + 1];
-    if (!VP_CHK(b <= e, 3, row, b, e)) return;
-    if (e - b > VP_LIGHT_MAX) return;                      // a heavy row: the chunk launches have written it
-    F m = f_zero(), ad = f_zero();
-    const F vu = *a.Vu;
-    for (u32 k = b; k < e; ++k) contrib2<2>(a, k, m, ad, vu);
-    a.M[row] = m; a.A[row] = ad;
-}
 __global__ void __launch_bounds__(VP_SEG_THREADS) k_seg_multi(const SegArgs *__restrict__ jobs, const BlkMap *__restrict__ map) {
     __shared__ SegLds sm;
     const BlkMap m = map[blockIdx.x];

@@ -138,8 +138,6 @@ struct vp_ctx {
     TailAux *h_aux = nullptr;            // pinned: per-table data of the resident kernel's launch
     int poll = 1;                                     // VP_POLL=0: wait with hipStreamSynchronize instead
     F *h_io = nullptr; size_t h_io_cap = 0;   // pinned staging of the batched path: tape in, transcript out
-    Round1Gen r1gen{};                 // interactive path: the init call left the light rows of its tables to the pass that also sums round 1 (mode != 0)
-    int fuse_r1 = 1;                   // VP_FUSE_R1=0 (test / A-B override): init and round 1 as separate launches
     int r1_pending = 0;                // interactive path: round 1 of the phase was queued behind its init (1: in the resident kernel, 2: per-round launch,
                                        // 3: collected into r1_stash when the resident kernel was suspended before the first vp_round)
     vp_F r1_stash[3];
@@ -911,7 +909,6 @@ int vp_create_with_options(int device, const vp_options *user, vp_ctx **out) {
     memset(ctx->h_req, 0, sizeof(TailMail)); memset(ctx->h_rep, 0, sizeof(TailReply)); memset(ctx->h_aux, 0, sizeof(TailAux));
     (void) hipFuncSetAttribute(reinterpret_cast<const void *>(k_phase), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 2 * VP_PH_PMAX * (int) sizeof(F));
     ctx->poll = ctx->opt.poll; ctx->tail_enabled = ctx->opt.persistent_rounds;
-    { const char *e = getenv("VP_FUSE_R1"); ctx->fuse_r1 = (e && *e) ? atoi(e) : 1; }      // test / A-B override only
     // distributed rounds (G workgroups of the resident kernel): measured equal to one launch per round on MI355X (x64 interactive proof
     // 12.6 vs 12.7 ms: profiles/r02_interactive_*), and they need G idle CUs for as long as the verifier takes — opt-in
     hipEventCreate(&ctx->ev0); hipEventCreate(&ctx->ev1);
@@ -1260,27 +1257,6 @@ static int round1_prefetch(vp_ctx *ctx) {
     ctx->r1_pending = 0;
     if (!ctx->opt.prefetch_round1 || ctx->sc.total_rounds < 1 || ctx->profiling) return check_stream(ctx);
     const F zero = f_zero();
-    if (ctx->r1gen.mode) {                                   // the init left its light rows to this pass (do_*_init_fast, r1_fusable)
-        SumcheckState &s = ctx->sc;
-        RoundArgs a{};
-        a.rp = nullptr; a.rv = zero; a.n_tab = s.n_tab; a.fold = 0; a.has_a = s.has_a;
-        a.inV = s.V0; a.inM = s.M0; a.inA = s.A0;
-        a.outV = ctx->tab[0][0]; a.outM = ctx->tab[0][1]; a.outA = ctx->tab[0][2];            // = s.M0 / s.A0 (and s.V0 in phase 2): the tables round 2 folds
-        u32 pairs = 0;
-        for (int j = 0; j < s.n_tab; ++j) {
-            TabDesc &t = a.t[j];
-            t.off = s.off[j]; t.pair_start = pairs; t.len_in = s.len0[j]; t.valid_in = s.valid0[j];
-            if (t.len_in >= 2) pairs += (t.valid_in + 1) >> 1;
-        }
-        a.total_pairs = pairs;
-        const RoundOut ro{ctx->add_term(), ctx->scalarV(), ctx->d_tr + ctx->n_tr, ctx->h_pin, ctx->poll ? ctx->h_seq : nullptr, ++ctx->seq};
-        hipLaunchKernelGGL(k_round1_gen, dim3(grid_for(pairs)), dim3(VP_BLOCK), 0, ctx->stream, a, ctx->r1gen, ctx->partials, ctx->round_arrivals, ro);
-        ctx->r1gen.mode = 0;
-        count_launch(ctx);
-        s.round = 1; ++ctx->st.rounds;
-        ctx->r1_pending = 2;
-        return VP_OK;
-    }
     if (tail_try_launch(ctx, zero)) { ctx->r1_pending = 1; return VP_OK; }
     VPCHK(do_round(ctx, nullptr, zero, ctx->d_tr + ctx->n_tr, ctx->h_pin));
     ctx->r1_pending = 2;
