@@ -67,97 +67,46 @@ typedef struct {
 } vp_layer_desc;
 
 /* ---- options -------------------------------------------------------------------------------------
- * Everything that steers HOW the library computes (never WHAT: every combination gives the same field elements; the parity tests run
- * the alternatives against the same golden transcripts).  vp_options_default fills the shipped configuration; vp_create_with_options
- * copies the struct into the context.  `struct_size` = sizeof(vp_options) of the caller's header: a library built from a newer header
- * keeps its defaults for the fields the caller does not know.  The VP_* environment variables named below are a TEST-ONLY override,
- * read once per vp_create / vp_create_with_options AFTER the struct (tests/ flip them per session); production callers use the struct. */
-enum { VP_PATH_PLAN = 0, VP_PATH_LANES = 1, VP_PATH_SIMPLE = 3 };
+ * What a caller can sensibly choose about HOW the library computes (never WHAT: every combination gives the same field elements; the parity tests run
+ * the alternatives against the same golden transcripts).  vp_options_default fills the shipped configuration; vp_create_with_options copies the struct
+ * into the context.  Layout rule (round 5): `abi` names the layout — a struct with another value, or a struct_size that is not this header's, is refused
+ * with VP_EINVAL instead of being read field by field at the wrong offsets; new fields take the reserved slots, a field that goes away bumps VP_OPTIONS_ABI.
+ * Everything else that steers the kernels — launch-plan layout, fold-kernel grids, which transform / hash / init kernel runs, the tests' cross-check
+ * drivers — is INTERNAL tuning: the VP_* environment variables listed in DESIGN.md section 4 (read once per vp_create, test / bench / A-B use only) and
+ * vp_tuning_get to read one back (what plan_autotune kept, say).                                                                                      */
+#define VP_OPTIONS_ABI 0x76700005u
 typedef struct {
-    uint32_t struct_size;
-    int32_t gkr_path;               /* VP_GKR_PATH=plan|lanes|simple: batched driver (launch plan + hipGraph; one stream per chain;
-                                       one launch per round; lanes / simple are the tests' cross-checks)                     [plan] */
-    int32_t use_graph;              /* VP_GKR_GRAPH: replay the plan as a hipGraph                                               [1] */
-    int32_t serial;                 /* VP_GKR_SERIAL: all chains on one stream (profiling)                                       [0] */
-    int32_t fuse_init;              /* VP_FUSE_INIT: phase-1 / Liu init inside the first fold launch of large tables             [1] */
-    int32_t fuse_min_log;           /* VP_FUSE_MIN_LOG: ... from 2^this entries on; 0 = clamp(largest layer's bit length - 1, 20, 22)    [0] */
-    int32_t fuse_dot;               /* VP_FUSE_DOT: V_u rides on the fused launch                                                [0] */
-    int32_t drop_y;                 /* VP_DROP_Y: rounds >= 2 derive b from the previous claim (five products per pair)          [1] */
-    int32_t drop_y_round1;          /* VP_DROP_Y1: round 1 too, restored by k_fixup                                              [0] */
-    int32_t real_values;            /* VP_REAL_V: real x complex products when every circuit value is real                       [1] */
-    int32_t seg_tiny;               /* VP_SEG_TINY: tables <= 2^e entries are folded by the first k_seg launch                   [1] */
-    int32_t sf_big_log;             /* VP_SF_BIG_LOG: fold kernel from 2^this entries on (plan path)                             [14] */
-    int32_t sf3b_grid;              /* VP_SF3B_GRID: its workgroups per launch                                                   [512] */
-    int32_t dot_blocks;             /* VP_DOT_BLOCKS: workgroups of a stand-alone inner product                                  [1024] */
-    int32_t plan_align;             /* VP_PLAN_ALIGN=left|right: 0 closing launches aligned at the end, 1 all left, 2 all right  [0] */
-    int32_t xcd_map;                /* VP_XCD_MAP: XCD-aware block map of the plan nodes (measured: no gain)                     [0] */
-    int32_t round_fused_max;        /* VP_ROUND_FUSED_MAX: interactive rounds with at most this many pairs take one launch       [512] */
-    int32_t persistent_rounds;      /* VP_PERSIST: interactive rounds that fit one CU run in the resident mailbox kernel         [1] */
-    int32_t poll;                   /* VP_POLL: spin on the pinned reply instead of hipStreamSynchronize (interactive path)      [1] */
-    int32_t debug;                  /* bit 0 (VP_DEBUG): diagnostics on stderr; bit 1 (VP_DEBUG_UPLOAD): phase times of vp_circuit_upload [0] */
-    int32_t prefetch_round1;        /* VP_PREFETCH_R1: an init call queues round 1 of its sumcheck (it takes no challenge) behind its own kernels
-                                       and returns without waiting; the first vp_round of the phase collects the answer          [1] */
-    int32_t split_cost_percent;     /* VP_SPLIT_COST_PERCENT: vp_set_shard_split cuts a chain by index only if its cost estimate exceeds this
-                                       percentage of one rank's fair share of the proof (total / world); 0 = every chain with a long table  [50] */
-    int32_t kernel_copies;          /* VP_KERNEL_COPIES: vp_prove_gkr moves the tape in and the transcript out with two small kernels on pinned host
-                                       memory (the second one also publishes the completion ticket) instead of two copy-engine commands  [1] */
-    int32_t fold_branches;          /* VP_FOLD_BRANCHES: a fold node of the launch plan that does not depend on the fold node queued before it runs on
-                                       another stream instead of behind it                                                         [1] */
-    int32_t ntt_scatter;            /* VP_NTT_SCATTER: the second pass of a long transform (> 2^13 points) stores its results in natural order itself
-                                       (16-byte pieces at stride N1, merged into whole lines in the L2 of the XCD that runs all N1 sub-transforms of
-                                       one transform) instead of a third, transposing pass                                        [1] */
-    int32_t fuse_combine;           /* VP_FUSE_COMBINE: launch plan — the heavy rows of an init (> 16 contributions) are finished by the chunk launch itself
-                                       (single-chunk rows written directly, the last-arriving wave of a multi-chunk row adds the partials) instead of a
-                                       separate k_combine node; 2: the same, and the chain keeps the (now empty) step of that node — which launches of
-                                       different chains share a node depends on the chains' alignment, and with the step removed the replay was
-                                       slower at x64 (0.61 -> 0.64 ms) although a node had gone; 0: separate k_combine node       [2] */
-    int32_t plan_autotune;          /* VP_PLAN_AUTOTUNE: the first vp_prove_gkr of a circuit replays the launch plan in the few layouts that fuse_combine,
-                                       fold_branches and plan_align offer, then with fuse_min_log one step either way, with sf3b_grid 384 / 320 and with graph_explicit, and
-                                       keeps the fastest for this circuit (one-off: a plan, a graph capture and six replays per candidate; a candidate
-                                       that does not build is skipped; the transcript does not depend on the choice).  A field named here that the
-                                       caller (struct or environment) moved off its default is taken as given, the tuner only chooses among the
-                                       others; 0: all of them are taken as given.  Not used for sharded proofs                       [1] */
-    int32_t pc_tensor_pub;          /* VP_PC_TENSOR: vp_commit_public checks (exactly, on the device) whether the public vector is a tensor — every
-                                       slice a scalar multiple of slice 0, which the protocol's own vector eq(r, .) always is — and then encodes ONE
-                                       slice instead of 64 (q_i = c_i q_0 formed where it is consumed): same field elements, a third fewer
-                                       transforms per commitment.  0: always encode all 64 slices                                    [1] */
-    int32_t persistent_timeout_ms;  /* VP_PERSIST_TIMEOUT_MS: how long the resident round kernel waits for the verifier's next message before it saves
-                                       its phase and leaves the CU; the next vp_round / vp_finalize relaunches it on the saved phase              [10000] */
-    int32_t graph_explicit;         /* VP_GRAPH_EXPLICIT: the launch plan's hipGraph is built node by node with exactly the plan's dependencies
-                                       (hipGraphAddKernelNode) instead of captured from four streams, where the order of unrelated launches on a stream
-                                       becomes a dependency too.  2: built node by node in the captured shape (stream order kept as edges) except that
-                                       the inner products V_u get a stream of their own; 3: and the phase-2 init launches another.  Faster or slower depending on the circuit (the runtime places
-                                       the branches of such a graph itself): plan_autotune tries the forms last and keeps what replays fastest    [0] */
-    int32_t ntt_r8;                 /* VP_NTT_R8: transforms of 2^13 .. 2^17 points as two LDS passes of radix-8 Stockham butterflies with lazy arithmetic
-                                       (k_ntt8_cols / k_ntt8_rows: the eighth root of unity is 2^30 (1 -+ i) in F_p[i], p = 2^61 - 1, so three stages cost
-                                       seven multiplications per eight points; sums stay unreduced between folds).  0: the radix-4 pair k_ntt_split /
-                                       k_ntt_lds of rounds 2-3 (kept as the cross-check)                                             [1] */
-    int32_t fri_vo_fused;           /* VP_FRI_VO_FUSED: vp_fri_commit folds the first FRI level straight from the committed codewords l, q, h (k_fri_fold0_vo); the
-                                       virtual oracle of poly_commit.h:294-318 is never written to HBM and read back.  0: separate k_pc_virtual_oracle pass [1] */
-    int32_t interactive_fast_init;  /* VP_FAST_INIT: vp_phase1_init / vp_phase2_init / vp_liu_init run the batched path's init kernels (closed-form eq half
-                                       tables of the one sumcheck, eq values as products of two half-table entries, V gather and assert scaling inside the
-                                       row kernel) instead of the per-sumcheck kernels of round 1 (expanded eq tables, separate gather / scatter launches)  [1] */
-    int32_t fuse_p2;                /* VP_FUSE_P2: launch plan — with fuse_init, the phase-2 init of a layer (src/prover.cpp:282-367) runs inside the first fold launch of its
-                                       sumcheck too (GenP2): V through the slot map, mult / add entries from the v-sorted contribution list; the tables of the long
-                                       subsets are never written at full length.  0: k_light_multi writes them, the fold launch reads them back  [1] */
-    int32_t leaf_asm;               /* VP_LEAF_ASM: the leaf-hash chains of the commitment (fri.cpp:96-124) by the generated fixed-register block (csrc/vp_keccak_asm.h,
-                                       tools/gen_keccak_asm.py): workgroups of 1024 threads whose waves rotate and do logic in phase.  0: the compiler's Keccak-f in
-                                       workgroups of 256 (the cross-check; always in the checked build)  [1] */
-    int32_t real_pairs;             /* VP_REAL_PAIRS: vp_commit_private of a REAL witness (every circuit value real) sends two slices through each transform as one complex
-                                       sequence x + i x' (the coefficients of a real sequence are Hermitian, so a coset's values of both slices separate again at the
-                                       encoder's last store): half the transforms of the call, the same codeword.  0: one transform per slice  [1] */
-    int32_t fft_gkr_batched;        /* VP_FFT_GKR_BATCHED: vp_fft_gkr runs the 2 lg sumchecks of the inverse FFT (fft_circuit_GKR.cpp:458-768) as ONE batch — given the
-                                       tape they are independent (v_u of a phase 2 is an inner product) — three table launches and one launch per step of their
-                                       common shape instead of ~6 launches per sumcheck.  0: one sumcheck after the other  [1] */
+    uint32_t struct_size;           /* sizeof(vp_options)                                                                               */
+    uint32_t abi;                   /* VP_OPTIONS_ABI                                                                                   */
+    int32_t use_graph;              /* VP_GKR_GRAPH: vp_prove_gkr replays its launch plan as a hipGraph                                              [1] */
+    int32_t plan_autotune;          /* VP_PLAN_AUTOTUNE: the first vp_prove_gkr of a circuit replays the plan in the few layouts it can take and keeps the
+                                       fastest (one-off: ~0.9 s at x1024; shared between contexts of one process with the same plan shape)          [1] */
+    int32_t real_values;            /* VP_REAL_V: real x complex products wherever vp_evaluate found every circuit value real                        [1] */
+    int32_t real_pairs;             /* VP_REAL_PAIRS: vp_commit_private of a real witness sends two slices through each transform as one complex sequence [1] */
+    int32_t pc_tensor_pub;          /* VP_PC_TENSOR: vp_commit_public checks (exactly, on the device) whether the public vector is a tensor — the protocol's
+                                       own eq(r, .) always is — and then encodes ONE slice instead of 64                                             [1] */
+    int32_t persistent_rounds;      /* VP_PERSIST: interactive rounds that fit one CU are answered by a resident kernel through a pinned mailbox      [1] */
+    int32_t persistent_timeout_ms;  /* VP_PERSIST_TIMEOUT_MS: how long that kernel waits for the next message before it saves its phase and leaves    [10000] */
+    int32_t poll;                   /* VP_POLL: spin on pinned replies instead of hipStreamSynchronize (a core per waiting call)                      [1] */
+    int32_t prefetch_round1;        /* VP_PREFETCH_R1: an interactive init call queues round 1 of its sumcheck and returns without waiting            [1] */
+    int32_t interactive_fast_init;  /* VP_FAST_INIT: the interactive init calls run the batched path's init kernels                                   [1] */
+    int32_t split_cost_percent;     /* VP_SPLIT_COST_PERCENT: vp_set_shard_split cuts a chain by index only above this share of a rank's fair load    [50] */
+    int32_t debug;                  /* bit 0 (VP_DEBUG): diagnostics on stderr; bit 1 (VP_DEBUG_UPLOAD): phase times of vp_circuit_upload             [0] */
+    int32_t reserved[4];            /* zero                                                                                                            */
 } vp_options;
 void vp_options_default(vp_options *opt);
 
 /* ---- life cycle ---------------------------------------------------------------------------------- */
 int vp_create(int device, vp_ctx **out);                                 /* = vp_create_with_options(device, NULL, out) */
 int vp_create_with_options(int device, const vp_options *opt, vp_ctx **out);
-int vp_get_options(const vp_ctx *, vp_options *out);                   /* the configuration in effect: defaults <- struct <- environment, and after the
-                                                                           first vp_prove_gkr of a circuit what plan_autotune kept; out->struct_size (set by
-                                                                           the caller) bounds the bytes written */
+int vp_get_options(const vp_ctx *, vp_options *out);                   /* the configuration in effect: defaults <- struct <- environment */
+/* one internal tuning knob by the name DESIGN.md lists it under ("fuse_combine", "sf3b_grid", "gkr_path", ...), e.g. what plan_autotune kept after the
+ * first vp_prove_gkr of a circuit.  VP_EINVAL for a name the library does not have.  Tests / benches only.                                           */
+int vp_tuning_get(const vp_ctx *, const char *name, int32_t *value);
+/* 1 when the library was built with -DVP_TEST_DRIVERS: the two extra drivers of vp_prove_gkr the tests cross-check the launch plan against (VP_GKR_PATH=lanes:
+ * the plan's recorder run live, one stream per sumcheck chain; =simple: one launch per round through the interactive path's kernels).  The product library
+ * (0) ships the launch plan alone and refuses VP_GKR_PATH.                                                                                            */
+int vp_test_drivers(void);
 void vp_destroy(vp_ctx *);
 const char *vp_last_error(const vp_ctx *);     /* static/ctx-owned string, never NULL */
 const char *vp_version(void);

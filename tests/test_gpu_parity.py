@@ -74,7 +74,7 @@ def _both_modes(vp, c, gold):
     # the alternative batched drivers (per-round launches; shuffle-fold + single-CU tail; one stream per sumcheck chain
     # instead of the batched launch plan) must agree
     import os
-    for path in ("simple", "lanes"):
+    for path in (("simple", "lanes") if vp.lib_gpu().vp_test_drivers() else ()):      # -DVP_TEST_DRIVERS flavour only (test_cross_check_drivers_flavour runs these tests under it)
         os.environ["VP_GKR_PATH"] = path
         try:
             s2 = vp.Session(c)
@@ -1348,12 +1348,17 @@ def test_options_struct_selects_the_same_alternatives_as_the_test_environment(vp
     c = vp.Circuit.from_pws(pws_path, 16, seed=1)
     gold = gold_gkr("sha256_x16")
     d = vp.Options()
-    assert d.struct_size == ctypes.sizeof(vp.Options) and d.drop_y == 1 and d.persistent_rounds == 1
+    assert d.struct_size == ctypes.sizeof(vp.Options) and d.abi == vp.VP_OPTIONS_ABI and d.real_values == 1 and d.persistent_rounds == 1
+    drivers = bool(vp.lib_gpu().vp_test_drivers())
     launches = {}
     for name, kw in (("default", {}), ("keep_y", {"drop_y": 0}), ("complex_products", {"real_values": 0}),
                      ("lanes", {"gkr_path": vp.PATH_LANES}), ("simple", {"gkr_path": vp.PATH_SIMPLE}), ("no_graph", {"use_graph": 0, "serial": 1}),
                      ("copy_engine", {"kernel_copies": 0}), ("blocking_wait", {"poll": 0}), ("fixed_layout", {"plan_autotune": 0}),
                      ("combine_node", {"plan_autotune": 0, "fuse_combine": 0}), ("one_fold_stream", {"plan_autotune": 0, "fold_branches": 0})):
+        if name in ("lanes", "simple") and not drivers:
+            with pytest.raises(RuntimeError):                    # the product library ships the launch plan alone: vp_create refuses the other drivers
+                vp.Session(c, options=vp.Options(**kw))
+            continue
         s = vp.Session(c, options=vp.Options(**kw))
         s.draw_tape()
         tr, res = s.prove_gkr()
@@ -1364,7 +1369,8 @@ def test_options_struct_selects_the_same_alternatives_as_the_test_environment(vp
             assert ok and tr_i == gold
         s.close()
     # the alternatives really ran: one launch per round on the simple path, one stream per chain (no batched nodes) on the lanes path
-    assert launches["simple"] > 10 * launches["default"] and launches["lanes"] > launches["default"]
+    if drivers:
+        assert launches["simple"] > 10 * launches["default"] and launches["lanes"] > launches["default"]
     # (the default session picks its plan layout by measurement on the first proof: compare launch counts against the fixed layout)
     assert launches["no_graph"] == launches["fixed_layout"]
     assert launches["combine_node"] > launches["fixed_layout"]
@@ -1380,14 +1386,34 @@ def test_options_struct_selects_the_same_alternatives_as_the_test_environment(vp
     eff = s.options_in_effect()
     assert tr == gold and eff.plan_autotune == 1 and (eff.fuse_combine, eff.sf3b_grid, eff.fuse_min_log) == (1, 448, 21)
     s.close()
-    # a caller built against an older header passes a shorter struct: the fields it does not know keep the library's defaults
-    old = vp.Options(gkr_path=vp.PATH_SIMPLE, drop_y=0)
-    old.struct_size = 8                                   # struct_size + gkr_path only
-    s = vp.Session(c, options=old)
-    s.draw_tape()
-    tr, res = s.prove_gkr()
-    assert tr == gold and res["launches"] == launches["simple"]
-    s.close(); c.close()
+    # a struct of another layout (a caller built against another header) is refused, not read field by field at shifted offsets
+    for bad in ("size", "abi"):
+        old = vp.Options()
+        if bad == "size":
+            old.struct_size = 8
+        else:
+            old.abi = 0
+        with pytest.raises(RuntimeError):
+            vp.Session(c, options=old)
+    c.close()
+
+
+_DRIVER_TESTS = ("test_sha256_transcript_matches_reference or test_randomize_transcript_matches_reference or test_small_and_ragged or test_all_gate_types_and_assert_gates_vs_oracle "
+                 "or test_all_gate_types_full_protocol_vs_reference or test_options_struct_selects_the_same_alternatives_as_the_test_environment")
+
+
+def test_cross_check_drivers_flavour(vp):
+    """The launch plan's two cross-check drivers (VP_GKR_PATH=lanes: the plan's recorder run live, one stream per sumcheck chain; =simple: one launch per
+    round through the interactive kernels) are compiled into a tests flavour only (-DVP_TEST_DRIVERS, tools/_build/testdrv; the product library refuses
+    VP_GKR_PATH).  The tests that compare them with the plan run here under that flavour, in a fresh process."""
+    import subprocess, sys
+    if vp.lib_gpu().vp_test_drivers():
+        pytest.skip("already running under the drivers flavour")
+    assert os.path.exists(vp.LIB_GPU_TESTDRV), "vp.build() did not produce the drivers flavour"
+    env = dict(os.environ, VP_LIBGPU=vp.LIB_GPU_TESTDRV)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu", "-k", _DRIVER_TESTS],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert r.returncode == 0 and " passed" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
 
 
 def test_reference_binary_drives_the_device_prover(pws_path, tmp_path, golden):

@@ -22,6 +22,7 @@ HOST = os.path.join(PKG_DIR, "host")
 # product library; build() never writes to an overridden path)
 LIB_GPU = os.environ.get("VP_LIBGPU") or os.path.join(CSRC, "libvpgpu.so")
 LIB_GPU_CHECKED = os.path.join(ROOT, "tools", "_build", "checked", "libvpgpu.so")      # -DVP_CHECKED flavour (csrc/vp_check.h), loaded through VP_LIBGPU by its test
+LIB_GPU_TESTDRV = os.path.join(ROOT, "tools", "_build", "testdrv", "libvpgpu.so")      # -DVP_TEST_DRIVERS flavour: the launch plan's two cross-check drivers (VP_GKR_PATH=lanes|simple), loaded through VP_LIBGPU by their test
 LIB_HOST = os.path.join(HOST, "libvphost.so")
 CLI = os.path.join(HOST, "virgo_plus_run")
 
@@ -68,6 +69,10 @@ def build(force=False, verbose=False):
         os.makedirs(os.path.dirname(LIB_GPU_CHECKED), exist_ok=True)
         run([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-DVP_CHECKED",
              "-o", LIB_GPU_CHECKED, os.path.join(CSRC, "vpgpu.hip")])
+    if (force or _stale(LIB_GPU_TESTDRV, GPU_SRC)) and _hipcc() is not None:
+        os.makedirs(os.path.dirname(LIB_GPU_TESTDRV), exist_ok=True)
+        run([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-DVP_TEST_DRIVERS",
+             "-o", LIB_GPU_TESTDRV, os.path.join(CSRC, "vpgpu.hip")])
     if force or _stale(LIB_HOST, HOST_SRC + HOST_HDR + [LIB_GPU]):
         run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-pthread", "-o", LIB_HOST] + HOST_SRC +
             ["-L" + CSRC, "-lvpgpu", "-Wl,-rpath,$ORIGIN/../csrc", "-Wl,-rpath,/opt/rocm/lib"])
@@ -118,6 +123,7 @@ def lib_gpu():
         L.vp_shard_finish.argtypes = [vp, vp, ctypes.c_uint64, vp]
         L.vp_gkr_sizes.argtypes = [vp, vp, vp]
         L.vp_options_default.argtypes = [vp]
+        L.vp_tuning_get.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int32)]
         u64_ = ctypes.c_uint64
         L.vp_set_deferred.argtypes = [vp, ctypes.c_int]
         L.vp_flush.argtypes = [vp, ctypes.c_int]
@@ -532,20 +538,45 @@ class Circuit:
             self.h = None
 
 
+_PUBLIC_OPTIONS = ("use_graph", "plan_autotune", "real_values", "real_pairs", "pc_tensor_pub", "persistent_rounds", "persistent_timeout_ms", "poll", "prefetch_round1",
+                   "interactive_fast_init", "split_cost_percent", "debug")
+# internal tuning knobs (csrc/vpgpu.hip, VpOpt): name -> the VP_* environment variable the library reads once per vp_create (tests / benches / A-B only)
+_TUNING_ENV = {"gkr_path": "VP_GKR_PATH", "serial": "VP_GKR_SERIAL", "fuse_init": "VP_FUSE_INIT", "fuse_min_log": "VP_FUSE_MIN_LOG", "fuse_dot": "VP_FUSE_DOT",
+               "drop_y": "VP_DROP_Y", "drop_y_round1": "VP_DROP_Y1", "seg_tiny": "VP_SEG_TINY", "sf_big_log": "VP_SF_BIG_LOG", "sf3b_grid": "VP_SF3B_GRID",
+               "dot_blocks": "VP_DOT_BLOCKS", "plan_align": "VP_PLAN_ALIGN", "xcd_map": "VP_XCD_MAP", "round_fused_max": "VP_ROUND_FUSED_MAX",
+               "kernel_copies": "VP_KERNEL_COPIES", "fold_branches": "VP_FOLD_BRANCHES", "ntt_scatter": "VP_NTT_SCATTER", "fuse_combine": "VP_FUSE_COMBINE",
+               "graph_explicit": "VP_GRAPH_EXPLICIT", "ntt_r8": "VP_NTT_R8", "fri_vo_fused": "VP_FRI_VO_FUSED", "fuse_p2": "VP_FUSE_P2", "leaf_asm": "VP_LEAF_ASM",
+               "fft_gkr_batched": "VP_FFT_GKR_BATCHED"}
+VP_OPTIONS_ABI = 0x76700005
+
+
 class Options(ctypes.Structure):
-    """vp_options of include/vpgpu.h (how the library computes, never what).  Options() holds the shipped defaults."""
-    _fields_ = [("struct_size", ctypes.c_uint32)] + [(n, ctypes.c_int32) for n in (
-        "gkr_path", "use_graph", "serial", "fuse_init", "fuse_min_log", "fuse_dot", "drop_y", "drop_y_round1", "real_values",
-        "seg_tiny", "sf_big_log", "sf3b_grid", "dot_blocks", "plan_align", "xcd_map",
-        "round_fused_max", "persistent_rounds", "poll", "debug", "prefetch_round1", "split_cost_percent", "kernel_copies", "fold_branches", "ntt_scatter", "fuse_combine", "plan_autotune", "pc_tensor_pub", "persistent_timeout_ms", "graph_explicit", "ntt_r8", "fri_vo_fused", "interactive_fast_init", "fuse_p2", "leaf_asm", "real_pairs", "fft_gkr_batched")]
+    """vp_options of include/vpgpu.h — what a caller can sensibly choose about how the library computes (never what).  Options() holds the shipped defaults.
+    Keywords that are not fields of the struct but INTERNAL tuning knobs (the names of csrc/vpgpu.hip's VpOpt: fuse_combine, sf3b_grid, ntt_r8, gkr_path ...)
+    are accepted too, for the tests: Session() sets the VP_* environment variable of each around its vp_create, which is the only way the library takes them."""
+    _fields_ = [("struct_size", ctypes.c_uint32), ("abi", ctypes.c_uint32)] + [(n, ctypes.c_int32) for n in _PUBLIC_OPTIONS] + [("reserved", ctypes.c_int32 * 4)]
 
     def __init__(self, **kw):
         super().__init__()
         lib_gpu().vp_options_default(ctypes.byref(self))
+        self.tuning = {}
         for k, v in kw.items():
-            if not hasattr(self, k):
+            if k in _PUBLIC_OPTIONS:
+                setattr(self, k, v)
+            elif k in _TUNING_ENV:
+                self.tuning[k] = v
+            else:
                 raise TypeError("unknown option " + k)
-            setattr(self, k, v)
+
+    def tuning_env(self):
+        env = {}
+        for k, v in getattr(self, "tuning", {}).items():
+            if k == "gkr_path":
+                v = {PATH_PLAN: "plan", PATH_LANES: "lanes", PATH_SIMPLE: "simple"}[v]
+            elif k == "plan_align":
+                v = {0: "", 1: "left", 2: "right"}[v]
+            env[_TUNING_ENV[k]] = str(v)
+        return env
 
 
 PATH_PLAN, PATH_LANES, PATH_SIMPLE = 0, 1, 3
@@ -557,7 +588,18 @@ class Session:
     def __init__(self, circuit, device=0, options=None):
         err = ctypes.create_string_buffer(512)
         self.circuit = circuit
-        self.h = lib_host().vph_session_create_opts(circuit.h, device, ctypes.byref(options) if options is not None else None, err, len(err))
+        keep = {}
+        for k, v in (options.tuning_env() if options is not None else {}).items():          # internal knobs: the library reads them from the environment at vp_create
+            keep[k] = os.environ.get(k)
+            os.environ[k] = v
+        try:
+            self.h = lib_host().vph_session_create_opts(circuit.h, device, ctypes.byref(options) if options is not None else None, err, len(err))
+        finally:
+            for k, v in keep.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
         if not self.h:
             raise RuntimeError("Session: " + err.value.decode())
         self._cap = int(lib_host().vph_transcript_bytes(self.h)) + 4096
@@ -659,11 +701,17 @@ class Session:
 
     def options_in_effect(self):
         """vp_get_options: the configuration this session runs with (after the plan tuner, once a proof has run)."""
+        import types
         o = Options()
         ctx = lib_host().vph_session_ctx(self.h)
         if lib_gpu().vp_get_options(ctx, ctypes.byref(o)):
             raise RuntimeError("vp_get_options failed")
-        return o
+        eff = types.SimpleNamespace(**{k: getattr(o, k) for k in _PUBLIC_OPTIONS})
+        v = ctypes.c_int32(0)
+        for name in _TUNING_ENV:                               # the internal knobs, by name (vp_tuning_get)
+            if lib_gpu().vp_tuning_get(ctx, name.encode(), ctypes.byref(v)) == 0:
+                setattr(eff, name, v.value)
+        return eff
 
     def set_shard(self, rank, world):
         """One proof over `world` GPUs: prove_gkr() then runs only the sumcheck chains dealt to `rank` and leaves the rest of the

@@ -110,6 +110,42 @@ struct Plan {
     std::vector<void *> allocs;                      // device arrays owned by the plan (freed with it)
 };
 
+// Every switch of the library, public options (include/vpgpu.h) and internal tuning alike: resolved once per vp_create (defaults <- the caller's vp_options <-
+// VP_* environment variables, the latter for tests / benches / A-B runs only).  The internal fields, by the name vp_tuning_get knows them under:
+enum { VP_PATH_PLAN = 0, VP_PATH_LANES = 1, VP_PATH_SIMPLE = 3 };
+struct VpOpt {
+    int32_t gkr_path;               // VP_GKR_PATH=plan|lanes|simple (lanes / simple: -DVP_TEST_DRIVERS builds only)                                     [plan]
+    int32_t use_graph;              // public
+    int32_t serial;                 // VP_GKR_SERIAL: all chains on one stream (profiling)                                                               [0]
+    int32_t fuse_init;              // VP_FUSE_INIT: phase-1 / Liu init inside the first fold launch of large tables                                     [1]
+    int32_t fuse_min_log;           // VP_FUSE_MIN_LOG: ... from 2^this entries on; 0 = clamp(largest layer's bit length - 1, 20, 22)                    [0]
+    int32_t fuse_dot;               // VP_FUSE_DOT: V_u rides on the fused launch                                                                        [0]
+    int32_t drop_y;                 // VP_DROP_Y: rounds >= 2 derive b from the previous claim (five products per pair)                                  [1]
+    int32_t drop_y_round1;          // VP_DROP_Y1: round 1 too, restored by k_fixup                                                                      [0]
+    int32_t real_values;            // public
+    int32_t seg_tiny;               // VP_SEG_TINY: tables <= 2^e entries are folded by the first k_seg launch                                           [1]
+    int32_t sf_big_log;             // VP_SF_BIG_LOG: fold kernel from 2^this entries on (plan path)                                                     [14]
+    int32_t sf3b_grid;              // VP_SF3B_GRID: its workgroups per launch                                                                           [512]
+    int32_t dot_blocks;             // VP_DOT_BLOCKS: workgroups of a stand-alone inner product                                                          [1024]
+    int32_t plan_align;             // VP_PLAN_ALIGN=left|right: 0 closing launches aligned at the end, 1 all left, 2 all right                          [0]
+    int32_t xcd_map;                // VP_XCD_MAP: XCD-aware block map of the plan nodes (measured: no gain)                                             [0]
+    int32_t round_fused_max;        // VP_ROUND_FUSED_MAX: interactive rounds with at most this many pairs take one launch                               [512]
+    int32_t persistent_rounds, poll, debug, prefetch_round1, split_cost_percent;          // public
+    int32_t kernel_copies;          // VP_KERNEL_COPIES: tape in / transcript out by two small kernels on pinned memory instead of copy-engine commands  [1]
+    int32_t fold_branches;          // VP_FOLD_BRANCHES: an independent fold node of the plan runs on another stream                                     [1]
+    int32_t ntt_scatter;            // VP_NTT_SCATTER: radix-4 long transforms store in natural order themselves                                         [1]
+    int32_t fuse_combine;           // VP_FUSE_COMBINE: heavy rows finished by the chunk launch (2: and the chain keeps the empty step)                   [2]
+    int32_t plan_autotune, pc_tensor_pub, persistent_timeout_ms;                          // public
+    int32_t graph_explicit;         // VP_GRAPH_EXPLICIT: the plan's hipGraph built node by node (1..3: forms, see plan_graph_explicit)                   [0]
+    int32_t ntt_r8;                 // VP_NTT_R8: transforms of 2^13..2^17 points by the radix-8 Stockham pair (0: radix-4 pair, the cross-check)        [1]
+    int32_t fri_vo_fused;           // VP_FRI_VO_FUSED: first FRI fold straight from the committed codewords                                              [1]
+    int32_t interactive_fast_init;  // public
+    int32_t fuse_p2;                // VP_FUSE_P2: phase-2 init inside the first fold launch too                                                          [1]
+    int32_t leaf_asm;               // VP_LEAF_ASM: leaf chains by the generated fixed-register block (0: the compiler's Keccak-f, the cross-check)       [1]
+    int32_t real_pairs;             // public
+    int32_t fft_gkr_batched;        // VP_FFT_GKR_BATCHED: the 2 lg inverse-FFT sumchecks of vp_fft_gkr as one batch                                      [1]
+};
+
 struct vp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -142,7 +178,7 @@ struct vp_ctx {
                                        // 3: collected into r1_stash when the resident kernel was suspended before the first vp_round)
     vp_F r1_stash[3];
     F *h_stage = nullptr; u32 stage_at = 0;         // pinned ring the challenges are staged through (an init call no longer waits for its copies)
-    vp_options opt{};                  // resolved at vp_create: defaults <- caller's struct <- VP_* environment (test-only override)
+    VpOpt opt{};                       // resolved at vp_create: defaults <- caller's vp_options <- VP_* environment (test-only override)
     int *d_flag = nullptr;
     u32 *d_vcplx = nullptr;            // non-zero: some circuit value of the last vp_evaluate has an imaginary part
     int vreal = 0, plan_vreal = 0;     // 1: every circuit value is real — round 1 of every sumcheck and the phase-1 inits take the half-price products (vp_field.h, f_mad31c_rb)
@@ -801,10 +837,8 @@ int vp_checked_build(void) {
 const char *vp_version(void) { return "vpgpu 0.1 (gfx950)"; }
 const char *vp_last_error(const vp_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
-void vp_options_default(vp_options *o) {
-    if (!o) return;
+static void opt_defaults(VpOpt *o) {
     memset(o, 0, sizeof *o);
-    o->struct_size = (uint32_t) sizeof *o;
     o->gkr_path = VP_PATH_PLAN; o->use_graph = 1; o->serial = 0; o->fuse_init = 1; o->fuse_min_log = 0; o->fuse_dot = 0;
     o->drop_y = 1; o->drop_y_round1 = 0; o->real_values = 1; o->seg_tiny = 1; o->sf_big_log = 14;
     o->sf3b_grid = 512; o->dot_blocks = 1024; o->plan_align = 0; o->xcd_map = 0; o->round_fused_max = 512;
@@ -820,17 +854,60 @@ void vp_options_default(vp_options *o) {
     o->real_pairs = 1;
     o->fft_gkr_batched = 1;
 }
-// defaults <- the caller's struct (as many bytes as its header knew) <- VP_* environment variables (test-only override, read here and nowhere else)
-static void resolve_options(vp_options *o, const vp_options *user, uint32_t *pinned) {
-    vp_options_default(o);
-    if (user && user->struct_size >= sizeof(uint32_t)) {
-        memcpy(o, user, std::min<size_t>(user->struct_size, sizeof *o));
-        o->struct_size = (uint32_t) sizeof *o;
+static void opt_to_public(const VpOpt &o, vp_options *p) {
+    memset(p, 0, sizeof *p);
+    p->struct_size = (uint32_t) sizeof *p; p->abi = VP_OPTIONS_ABI;
+    p->use_graph = o.use_graph; p->plan_autotune = o.plan_autotune; p->real_values = o.real_values; p->real_pairs = o.real_pairs; p->pc_tensor_pub = o.pc_tensor_pub;
+    p->persistent_rounds = o.persistent_rounds; p->persistent_timeout_ms = o.persistent_timeout_ms; p->poll = o.poll; p->prefetch_round1 = o.prefetch_round1;
+    p->interactive_fast_init = o.interactive_fast_init; p->split_cost_percent = o.split_cost_percent; p->debug = o.debug;
+}
+void vp_options_default(vp_options *p) {
+    if (!p) return;
+    VpOpt o; opt_defaults(&o);
+    opt_to_public(o, p);
+}
+int vp_test_drivers(void) {
+#ifdef VP_TEST_DRIVERS
+    return 1;
+#else
+    return 0;
+#endif
+}
+// internal tuning by name (vp_tuning_get; DESIGN.md section 4 lists the names)
+struct OptName { const char *name; int32_t VpOpt::*field; };
+static const OptName g_opt_names[] = {
+    {"gkr_path", &VpOpt::gkr_path}, {"use_graph", &VpOpt::use_graph}, {"serial", &VpOpt::serial}, {"fuse_init", &VpOpt::fuse_init}, {"fuse_min_log", &VpOpt::fuse_min_log},
+    {"fuse_dot", &VpOpt::fuse_dot}, {"drop_y", &VpOpt::drop_y}, {"drop_y_round1", &VpOpt::drop_y_round1}, {"real_values", &VpOpt::real_values}, {"seg_tiny", &VpOpt::seg_tiny},
+    {"sf_big_log", &VpOpt::sf_big_log}, {"sf3b_grid", &VpOpt::sf3b_grid}, {"dot_blocks", &VpOpt::dot_blocks}, {"plan_align", &VpOpt::plan_align}, {"xcd_map", &VpOpt::xcd_map},
+    {"round_fused_max", &VpOpt::round_fused_max}, {"persistent_rounds", &VpOpt::persistent_rounds}, {"poll", &VpOpt::poll}, {"debug", &VpOpt::debug},
+    {"prefetch_round1", &VpOpt::prefetch_round1}, {"split_cost_percent", &VpOpt::split_cost_percent}, {"kernel_copies", &VpOpt::kernel_copies},
+    {"fold_branches", &VpOpt::fold_branches}, {"ntt_scatter", &VpOpt::ntt_scatter}, {"fuse_combine", &VpOpt::fuse_combine}, {"plan_autotune", &VpOpt::plan_autotune},
+    {"pc_tensor_pub", &VpOpt::pc_tensor_pub}, {"persistent_timeout_ms", &VpOpt::persistent_timeout_ms}, {"graph_explicit", &VpOpt::graph_explicit}, {"ntt_r8", &VpOpt::ntt_r8},
+    {"fri_vo_fused", &VpOpt::fri_vo_fused}, {"interactive_fast_init", &VpOpt::interactive_fast_init}, {"fuse_p2", &VpOpt::fuse_p2}, {"leaf_asm", &VpOpt::leaf_asm},
+    {"real_pairs", &VpOpt::real_pairs}, {"fft_gkr_batched", &VpOpt::fft_gkr_batched}};
+int vp_tuning_get(const vp_ctx *ctx, const char *name, int32_t *value) {
+    if (!ctx || !name || !value) return VP_EINVAL;
+    for (const OptName &n : g_opt_names) if (!strcmp(n.name, name)) { *value = ctx->opt.*(n.field); return VP_OK; }
+    return VP_EINVAL;
+}
+// defaults <- the caller's struct (refused unless it is THIS header's layout) <- VP_* environment variables (test-only override, read here and nowhere else).
+// VP_OK, or VP_EINVAL for a struct of another layout / a driver this build does not have.
+static int resolve_options(VpOpt *o, const vp_options *user, uint32_t *pinned) {
+    opt_defaults(o);
+    if (user) {
+        if (user->struct_size != sizeof(vp_options) || user->abi != VP_OPTIONS_ABI) return VP_EINVAL;
+        o->use_graph = user->use_graph; o->plan_autotune = user->plan_autotune; o->real_values = user->real_values; o->real_pairs = user->real_pairs;
+        o->pc_tensor_pub = user->pc_tensor_pub; o->persistent_rounds = user->persistent_rounds; o->persistent_timeout_ms = user->persistent_timeout_ms;
+        o->poll = user->poll; o->prefetch_round1 = user->prefetch_round1; o->interactive_fast_init = user->interactive_fast_init;
+        o->split_cost_percent = user->split_cost_percent; o->debug = user->debug;
     }
     auto flag = [](const char *name, int32_t &v) { const char *e = getenv(name); if (e && (e[0] == '0' || e[0] == '1')) v = e[0] - '0'; };
     auto num = [](const char *name, int32_t &v) { const char *e = getenv(name); if (e && *e) v = atoi(e); };
     if (const char *p = getenv("VP_GKR_PATH"))
         o->gkr_path = !strcmp(p, "lanes") ? VP_PATH_LANES : !strcmp(p, "simple") ? VP_PATH_SIMPLE : VP_PATH_PLAN;
+#ifndef VP_TEST_DRIVERS
+    if (o->gkr_path != VP_PATH_PLAN) return VP_EINVAL;                   // the cross-check drivers are not in this build (vp_test_drivers)
+#endif
     if (const char *p = getenv("VP_PLAN_ALIGN")) o->plan_align = !strcmp(p, "left") ? 1 : !strcmp(p, "right") ? 2 : 0;
     flag("VP_GKR_GRAPH", o->use_graph); flag("VP_GKR_SERIAL", o->serial); flag("VP_FUSE_INIT", o->fuse_init); flag("VP_FUSE_DOT", o->fuse_dot);
     flag("VP_DROP_Y", o->drop_y); flag("VP_DROP_Y1", o->drop_y_round1); flag("VP_REAL_V", o->real_values);
@@ -858,17 +935,16 @@ static void resolve_options(vp_options *o, const vp_options *user, uint32_t *pin
     if (getenv("VP_DEBUG")) o->debug |= 1;
     if (getenv("VP_DEBUG_UPLOAD")) o->debug |= 2;                       // bit 1: phase times of vp_circuit_upload
     o->dot_blocks = std::max(1, o->dot_blocks); o->sf3b_grid = std::max(1, o->sf3b_grid);
-    vp_options d; vp_options_default(&d);
+    VpOpt d; opt_defaults(&d);
     *pinned = (o->fuse_combine != d.fuse_combine ? 1u : 0u) | (o->fold_branches != d.fold_branches ? 2u : 0u) | (o->plan_align != d.plan_align ? 4u : 0u) |
               (o->fuse_min_log != d.fuse_min_log ? 8u : 0u) | (o->sf3b_grid != d.sf3b_grid ? 16u : 0u) | (o->graph_explicit != d.graph_explicit ? 32u : 0u);
+    return VP_OK;
 }
 
 int vp_create(int device, vp_ctx **out) { return vp_create_with_options(device, nullptr, out); }
 int vp_get_options(const vp_ctx *ctx, vp_options *out) {
-    if (!ctx || !out || out->struct_size < sizeof(uint32_t)) return VP_EINVAL;
-    const uint32_t n = std::min<uint32_t>(out->struct_size, (uint32_t) sizeof ctx->opt);
-    memcpy(out, &ctx->opt, n);
-    out->struct_size = n;
+    if (!ctx || !out) return VP_EINVAL;
+    opt_to_public(ctx->opt, out);
     return VP_OK;
 }
 
@@ -895,7 +971,7 @@ int vp_create_with_options(int device, const vp_options *user, vp_ctx **out) {
     if (hipSetDevice(device) != hipSuccess) return VP_ENOGPU;
     vp_ctx *ctx = new vp_ctx();
     ctx->device = device;
-    resolve_options(&ctx->opt, user, &ctx->opt_pinned);
+    if (resolve_options(&ctx->opt, user, &ctx->opt_pinned) != VP_OK) { delete ctx; return VP_EINVAL; }       // a vp_options of another layout, or a driver this build lacks
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return VP_EHIP; }
     if (hipHostMalloc((void **) &ctx->h_pin, (4 + VP_MAX_TAB) * sizeof(F), hipHostMallocDefault) != hipSuccess) {
         delete ctx; return VP_EHIP;
@@ -1603,6 +1679,10 @@ int vp_prove_gkr(vp_ctx *ctx, const vp_F *tape, uint64_t n_tape, uint8_t *transc
     if (!ctx || !ctx->evaluated || !tape || !transcript || n_tape != ctx->n_tape) return VP_EINVAL;
     { uint64_t need = 0; (void) vp_gkr_sizes(ctx, nullptr, &need); if (ctx->opt.debug & 1) fprintf(stderr, "[vp] vp_prove_gkr: capacity %llu need %llu\n", (unsigned long long) capacity, (unsigned long long) need); if (capacity < need) return VP_EINVAL; }
     if (!ctx->simple_path) return prove_gkr_fused(ctx, tape, n_tape, transcript, n_written);
+#ifndef VP_TEST_DRIVERS
+    ctx->err = "the per-round driver is not in this build (vp_test_drivers)";        // unreachable: vp_create refuses VP_GKR_PATH in the product build
+    return VP_EINVAL;
+#else
     VP_ENTER(ctx);
     const int n = ctx->n_layers;
     ctx->st.launches = 0; ctx->st.rounds = 0; ctx->ev_used = 0;
@@ -1660,6 +1740,7 @@ int vp_prove_gkr(vp_ctx *ctx, const vp_F *tape, uint64_t n_tape, uint8_t *transc
     }
     if (n_written) *n_written = pos * sizeof(F);
     return VP_OK;
+#endif
 }
 
 int vp_get_stats(vp_ctx *ctx, vp_stats *out) {
