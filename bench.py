@@ -96,7 +96,7 @@ def launch_table(stats, total_us=None):
 
 # F_p^2 multiplications per pair step of the fold kernels (one pair of entries of one table family in one round): the three folds
 # x0 + r (x1 - x0) of V, mult and add, and the products of the round polynomial — dm dv and m0 v0; the third product (m1 v1) only in round 1
-# of a sumcheck, afterwards b comes from the previous claim (DESIGN.md §4 "five products per pair").  4 without an add table (Liu phase).
+# of a sumcheck, afterwards b comes from the previous claim (HISTORY.md section 4, "five products per pair").  4 without an add table (Liu phase).
 FMUL_PER_PAIR_STEP = 5
 
 
@@ -1163,7 +1163,8 @@ def compact_line(d, detail_file=None):
         cm = sh.get("commitment") or {}
         optional.append(("sharded", {"workload": (sh.get("config") or {}).get("workload"), "ms_per_step": sh.get("ms_per_step"), "value": sh.get("value"), "scaling": sh.get("scaling"),
                                      "rccl_ranks": sh.get("rccl_ranks"), "transport": sh.get("transport"), "bit_exact": sh.get("assembled_transcript_bit_exact_vs_reference"),
-                                     "commitment_wall_sec": cm.get("wall_sec"),
+                                     # the rehearsal's commitment moves 4.4 GB per oracle through host memory and gloo: its wall time says nothing about a device
+                                     ("commitment_wall_sec" if sh.get("rccl_ranks") else "commitment_wall_sec_HOST_TRANSPORT_rehearsal_not_a_device_number"): cm.get("wall_sec"),
                                      "commitment_bit_exact": cm.get("roots_input0_allsum_fri_bit_exact_vs_reference_on_every_rank"), "error": sh.get("error")}))
     for k in ("sharded_proof", "sharded_proof_simulation"):
         if isinstance(d.get(k), dict):

@@ -7,7 +7,7 @@ O=$R/gpurun_out/prof_$1
 shift
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-x64-leg $*"
+B="python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-x64-leg --no-randomize-leg --no-pass-modes $*"
 rocprofv3 --kernel-trace --stats -d "$O/stats" -o stats -- $B > "$O/bench_stats.json" 2> "$O/stats.err" || exit 1
 VP_GKR_SERIAL=1 rocprofv3 --kernel-trace --stats -d "$O/stats_serial" -o stats -- $B > "$O/bench_stats_serial.json" 2> "$O/stats_serial.err" || exit 1
 rocprofv3 --pmc FETCH_SIZE -d "$O/fetch" -o pmc -- $B > /dev/null 2> "$O/fetch.err" || exit 1

@@ -522,7 +522,7 @@ __global__ void __launch_bounds__(VP_BLOCK) k_round_main(RoundArgs a, F *__restr
         // s_waitcnt vmcnt(0) holds this wave until the memory system has acknowledged them, and only then is the arrival counted; the closing
         // workgroup reads them with agent-scope atomic loads behind __syncthreads() (a compiler barrier as well).  A release / acquire pair on the
         // counter would make the same guarantee through an L2 write-back + invalidate per WORKGROUP — measured on this chip at 4x the kernel's time
-        // ("finishing an inner product inside k_dot_multi": 22 -> 99 us) — for data that never sat in a non-coherent line.  A launch
+        // (HISTORY.md section 4, "finishing an inner product inside k_dot_multi": 22 -> 99 us) — for data that never sat in a non-coherent line.  A launch
         // that faults leaves the counter dirty: check_stream clears it on any stream error.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // the sums are out before they are counted
         s_last = __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
