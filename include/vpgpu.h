@@ -107,6 +107,13 @@ int vp_tuning_get(const vp_ctx *, const char *name, int32_t *value);
  * the plan's recorder run live, one stream per sumcheck chain; =simple: one launch per round through the interactive path's kernels).  The product library
  * (0) ships the launch plan alone and refuses VP_GKR_PATH.                                                                                            */
 int vp_test_drivers(void);
+/* The launch-plan layout plan_autotune kept for this circuit — v = { fuse_combine, fold_branches, plan_align, fuse_min_log, sf3b_grid, graph_explicit } — readable
+ * after the first vp_prove_gkr, and the way to carry it to another process: vp_plan_tuning_set on a fresh context after vp_circuit_upload and BEFORE its first
+ * proof; the tuner then has nothing left to try (first proof of a x1024 circuit 0.9 s -> the plan recording and one graph capture).  A layout tuned on another
+ * circuit or device is still correct (every layout gives the same transcript), only not necessarily the fastest.  VP_EINVAL for values out of range or a
+ * context that has already recorded its plan.                                                                                                         */
+int vp_plan_tuning_get(const vp_ctx *, int32_t v[6]);
+int vp_plan_tuning_set(vp_ctx *, const int32_t v[6]);
 void vp_destroy(vp_ctx *);
 const char *vp_last_error(const vp_ctx *);     /* static/ctx-owned string, never NULL */
 const char *vp_version(void);

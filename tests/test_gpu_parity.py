@@ -1774,7 +1774,23 @@ def test_plan_tuner_choice_is_shared_between_sessions_of_a_circuit(vp, pws_path)
     s.draw_tape()
     tr, _ = s.prove_gkr()
     assert tr == trs[0] and s.options_in_effect().sf3b_grid == 448
-    s.close(); c.close()
+    s.close()
+    # the choice carried by hand (what another PROCESS would do): vp_plan_tuning_get on a tuned context, vp_plan_tuning_set on a fresh one before its first
+    # proof; a layout nobody measured here is taken as given too, and the transcript does not depend on it
+    L = vp.lib_gpu()
+    L.vp_plan_tuning_get.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)]; L.vp_plan_tuning_set.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)]
+    for lay in (None, (0, 0, 1, 19, 320, 0)):
+        s = vp.Session(c, options=vp.Options(plan_autotune=1))
+        v = (ctypes.c_int32 * 6)(*(lay if lay else opts[0]))
+        assert L.vp_plan_tuning_set(s.gpu_ctx(), v) == 0
+        s.draw_tape()
+        tr, _ = s.prove_gkr()
+        got = (ctypes.c_int32 * 6)()
+        assert L.vp_plan_tuning_get(s.gpu_ctx(), got) == 0
+        assert tr == trs[0] and tuple(got) == tuple(v)
+        assert L.vp_plan_tuning_set(s.gpu_ctx(), v) != 0              # too late: the plan is recorded
+        s.close()
+    c.close()
 
 
 _CHECKED_WORKER = r"""

@@ -941,6 +941,23 @@ static int resolve_options(VpOpt *o, const vp_options *user, uint32_t *pinned) {
     return VP_OK;
 }
 
+// What plan_autotune chose for this circuit (after the first vp_prove_gkr), and the way to hand such a choice to another process: vp_plan_tuning_set on a
+// fresh context before its first proof (the tuner then has nothing left to try; values the library does not accept are refused).
+// v = { fuse_combine, fold_branches, plan_align, fuse_min_log, sf3b_grid, graph_explicit }.
+int vp_plan_tuning_get(const vp_ctx *ctx, int32_t v[6]) {
+    if (!ctx || !v) return VP_EINVAL;
+    v[0] = ctx->opt.fuse_combine; v[1] = ctx->opt.fold_branches; v[2] = ctx->opt.plan_align; v[3] = ctx->opt.fuse_min_log; v[4] = ctx->opt.sf3b_grid; v[5] = ctx->opt.graph_explicit;
+    return VP_OK;
+}
+int vp_plan_tuning_set(vp_ctx *ctx, const int32_t v[6]) {
+    if (!ctx || !v) return VP_EINVAL;
+    if (v[0] < 0 || v[0] > 2 || v[1] < 0 || v[1] > 1 || v[2] < 0 || v[2] > 2 || v[3] < 0 || v[3] > 30 || v[4] < 1 || v[4] > 4096 || v[5] < 0 || v[5] > 3) return VP_EINVAL;
+    VP_ENTER(ctx);
+    if (ctx->plan || ctx->gkr_graph) { ctx->err = "vp_plan_tuning_set: the context has already recorded its launch plan"; return VP_EINVAL; }
+    ctx->opt.fuse_combine = v[0]; ctx->opt.fold_branches = v[1]; ctx->opt.plan_align = v[2]; ctx->opt.fuse_min_log = v[3]; ctx->opt.sf3b_grid = v[4]; ctx->opt.graph_explicit = v[5];
+    ctx->plan_tuned = true;
+    return VP_OK;
+}
 int vp_create(int device, vp_ctx **out) { return vp_create_with_options(device, nullptr, out); }
 int vp_get_options(const vp_ctx *ctx, vp_options *out) {
     if (!ctx || !out) return VP_EINVAL;
