@@ -24,6 +24,28 @@ def test_cabi_exports_every_declared_symbol(vp):
     assert b"gfx950" in lib.vp_version()
 
 
+def test_options_struct_layout_and_library_flavours(vp):
+    """vp_options is twelve fields behind struct_size + abi (include/vpgpu.h); the three flavours of the library identify themselves (no GPU needed)."""
+    o = vp.Options()
+    assert ctypes.sizeof(vp.Options) == 4 * (2 + 12 + 4) == o.struct_size and o.abi == vp.VP_OPTIONS_ABI
+    hdr = open(os.path.join(ROOT, "include", "vpgpu.h")).read()
+    assert int(re.search(r"#define VP_OPTIONS_ABI (0x[0-9a-f]+)u", hdr).group(1), 16) == vp.VP_OPTIONS_ABI
+    body = re.sub(r"/\*.*?\*/", "", hdr[hdr.index("typedef struct {\n    uint32_t struct_size;"):hdr.index("} vp_options;")], flags=re.S)
+    fields = re.findall(r"(?<!u)int32_t\s+(\w+)\s*(?:\[\d+\])?;", body)
+    assert tuple(f for f in fields if f != "reserved") == vp._PUBLIC_OPTIONS
+    assert (o.use_graph, o.plan_autotune, o.real_values, o.real_pairs, o.pc_tensor_pub, o.persistent_rounds, o.poll, o.prefetch_round1, o.interactive_fast_init) == (1,) * 9
+    assert o.persistent_timeout_ms == 10000 and o.split_cost_percent == 50 and o.debug == 0 and list(o.reserved) == [0, 0, 0, 0]
+    with pytest.raises(TypeError):
+        vp.Options(no_such_option=1)
+    assert vp.Options(sf3b_grid=448, gkr_path=vp.PATH_LANES).tuning_env() == {"VP_SF3B_GRID": "448", "VP_GKR_PATH": "lanes"}
+    lib = vp.lib_gpu()
+    assert lib.vp_test_drivers() == 0 and lib.vp_checked_build() == 0
+    for path, drv, chk in ((vp.LIB_GPU_TESTDRV, 1, 0), (vp.LIB_GPU_CHECKED, 0, 1)):
+        if os.path.exists(path):
+            L = ctypes.CDLL(path)
+            assert (L.vp_test_drivers(), L.vp_checked_build()) == (drv, chk)
+
+
 def test_library_contains_gfx950_code_object(vp):
     data = open(vp.LIB_GPU, "rb").read()
     assert b"gfx950" in data and b"k_round_main" in data
