@@ -681,6 +681,17 @@ def gkr_workload(vp, a, pws, golden, world, rank, local, blocks, shard_req, cpu_
         # per-rank compute of a chain-sharded proof on W GPUs, measured shard by shard on this one GPU (no collective here)
         per = []
         parts = []
+        import numpy as np
+        vu_sums = None
+        if a.shard_split and not a.no_vu_exchange:
+            # index split: V_u of the split phase-2 chains from the ranks' partial inner products — the exchange a W-rank run does with one small
+            # all-reduce ahead of the graph, done here by hand (vp_shard_vu_partials -> u64 sum -> vp_shard_vu_set)
+            vus = []
+            for r in range(a.shard_sim):
+                sess.set_shard(r, a.shard_sim)
+                sess.set_shard_split(a.shard_split)
+                vus.append(sess.shard_vu_partials())
+            vu_sums = np.sum(np.stack(vus), axis=0, dtype=np.uint64)
         for r in range(a.shard_sim):
             sess.set_shard(r, a.shard_sim)
             if a.shard_split:
@@ -689,6 +700,9 @@ def gkr_workload(vp, a, pws, golden, world, rank, local, blocks, shard_req, cpu_
                 sess.prove_gkr()
             ms = []
             for _ in range(max(3, a.steps // 2)):
+                if vu_sums is not None and len(vu_sums):
+                    sess.shard_vu_partials()                # (its device time is part of the proof's gkr_device_ms)
+                    sess.shard_vu_set(vu_sums)
                 t_s = time.perf_counter()
                 tr_s, res_s = sess.prove_gkr()
                 ms.append((res_s["gkr_device_ms"], 1e3 * (time.perf_counter() - t_s)))
@@ -703,6 +717,7 @@ def gkr_workload(vp, a, pws, golden, world, rank, local, blocks, shard_req, cpu_
         shard_sim = {"world": a.shard_sim, "per_rank": per, "max_device_ms": max(x["device_ms"] for x in per),
                      "max_wall_ms": max(x["wall_ms"] for x in per),
                      "index_split_min_log": a.shard_split or None, "chains_split_by_index": int((owner == -1).sum()),
+                     "v_u_by_partial_inner_products": None if vu_sums is None else int(len(vu_sums)),
                      "host_finish_ms": finish_ms if a.shard_split else None,
                      "cost_share_per_rank": [float(cost[owner == r].sum() / cost.sum()) for r in range(a.shard_sim)],
                      "assembled_equals_unsharded": assembled == tr,
@@ -1241,6 +1256,7 @@ def main():
     ap.add_argument("--shard-chains", action="store_true",
                     help="strong scaling, GKR only: ONE proof per step; its independent sumcheck chains are dealt out to the ranks (vp_set_shard) and the "
                          "transcript is assembled by one RCCL all-reduce per proof (launch under torch.distributed.run)")
+    ap.add_argument("--no-vu-exchange", action="store_true", help="with --shard-sim --shard-split: every rank of a split phase 2 adds up the whole layer for V_u (round 4) instead of exchanging partial inner products")
     ap.add_argument("--shard-sim", type=int, default=0, metavar="W",
                     help="single GPU, GKR only: run the W shards of a chain-sharded proof one after the other and report each shard's device time")
     ap.add_argument("--shard-split", type=int, default=0, metavar="MIN_LOG",

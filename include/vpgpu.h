@@ -215,6 +215,17 @@ int vp_set_shard(vp_ctx *, int rank, int world);
  * same bound holds for the caller-side u64 sum handed to vp_shard_finish.  vp_set_shard alone (disjoint slices) has no such bound.           */
 int vp_set_shard_split(vp_ctx *, int min_log);
 int vp_shard_finish(vp_ctx *, uint8_t *summed, uint64_t n_bytes, uint64_t *n_transcript_bytes);
+/* V_u of the index-split phase-2 chains (src/prover.cpp:494-500: what phase 1's last fold leaves in V, = <eq(r_u, .), V_{i-1}>).  It depends on
+ * the tape and the witness only, so it is taken ahead of the proof: every rank adds up its share of the previous layer (1 / W' of it), ONE exchange
+ * of 16 bytes per split phase-2 chain completes the sums, and no rank reads a whole layer for a V_u of its own.
+ *   with a communicator attached: vp_prove_gkr does all of it (one extra all-reduce of *n * 16 bytes before its graph);
+ *   without one:  vp_shard_vu_partials(ctx, tape, n_tape, partials, capacity, &n)   this rank's n partial sums (n may be 0: nothing to exchange),
+ *                 [the caller adds the ranks' arrays up as u64 — at most 8 addends < 2^61 each, as for vp_shard_finish]
+ *                 vp_shard_vu_set(ctx, sums, n)                                    on every rank, then vp_prove_gkr with the SAME tape;
+ *   a vp_prove_gkr without either adds up the whole layer on every rank of the chain (correct, slower: the round-4 behaviour).
+ * vp_stats' gkr_device_ms of the proof that follows includes the device time of vp_shard_vu_partials.                                          */
+int vp_shard_vu_partials(vp_ctx *, const vp_F *tape, uint64_t n_tape, vp_F *partials, uint64_t capacity, uint64_t *n);
+int vp_shard_vu_set(vp_ctx *, const vp_F *sums, uint64_t n);
 /* The assignment: owner rank and cost estimate of every chain, in the order phase-1(layer 1), Liu(layer 1), phase-1(layer 2),
  * Liu(layer 2), ... then phase-2(layer 1..n-1), then Vres; *n_chains = 3*(n_layers-1) + 1.  Chains that do not exist (layers
  * without a phase 2) have cost 0.                                                                                      */

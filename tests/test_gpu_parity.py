@@ -193,14 +193,30 @@ def test_every_explicit_graph_form_on_sharded_plans(vp, golden, gold_gkr, pws_pa
     s.close(); c.close()
 
 
-def _split_parts(vp, s, world, min_log=11):
-    """The outputs (partial transcript + export area) of all ranks of an index-split proof, one after the other on this GPU."""
+def _split_parts(vp, s, world, min_log=11, exchange=True, vu_info=None):
+    """The outputs (partial transcript + export area) of all ranks of an index-split proof, one after the other on this GPU.  exchange: V_u of the
+    split phase-2 chains from the ranks' partial inner products (vp_shard_vu_partials -> u64 sum -> vp_shard_vu_set), as a W-rank caller with its
+    own transport does it; the replay after it has no sums handed in and adds up the whole layer itself — both must give the same bytes."""
+    import numpy as np
+    sums = None
+    if exchange:
+        vus = []
+        for r in range(world):
+            s.set_shard(r, world)
+            s.set_shard_split(min_log)
+            vus.append(s.shard_vu_partials())
+        assert len({v.shape for v in vus}) == 1, "the ranks disagree on the number of split phase-2 chains"
+        sums = np.sum(np.stack(vus), axis=0, dtype=np.uint64)
+        if vu_info is not None:
+            vu_info.append((world, vus, sums))
     parts = []
     for r in range(world):
         s.set_shard(r, world)
         s.set_shard_split(min_log)
+        if sums is not None and len(sums):
+            s.shard_vu_set(sums)
         tr, _ = s.prove_gkr()
-        tr2, _ = s.prove_gkr()            # graph replay of the rank's plan
+        tr2, _ = s.prove_gkr()            # graph replay of the rank's plan (whole inner products: nothing handed in)
         assert tr2 == tr
         parts.append(tr)
     out = s.shard_finish(vp.sum_transcripts(parts))
@@ -226,11 +242,18 @@ def test_index_split_proof_assembles_to_reference(vp, golden, gold_gkr, pws_path
     s = vp.Session(c)
     s.draw_tape()
     gold = gold_gkr(name)
+    info = []
     for w in worlds:
         s.set_shard(0, w); s.set_shard_split(11)
         owner, _ = s.shard_chains()
         assert (owner == -1).any(), "nothing was split"
-        assert _split_parts(vp, s, w) == gold, "W=%d" % w
+        assert _split_parts(vp, s, w, vu_info=info) == gold, "W=%d" % w
+        assert _split_parts(vp, s, w, exchange=False) == gold, "W=%d, every rank adds up the whole layer" % w
+    # the exchange is a real one: there are split phase-2 chains, and no single rank's share is the sum
+    P = (1 << 61) - 1
+    for w, vus, sums in info:
+        assert len(sums) > 0, "no split phase-2 chain at W=%d" % w
+        assert all((v % P != sums % P).any() for v in vus), "a rank's partial inner products already are V_u (W=%d)" % w
     tr, _ = s.prove_gkr()                  # back to the unsharded proof on the same context
     assert tr == gold
     s.close(); c.close()

@@ -230,6 +230,8 @@ def lib_host():
         L.vph_commit_device_ms.argtypes = [vp]
         L.vph_set_shard.argtypes = [vp, ctypes.c_int, ctypes.c_int]
         L.vph_shard_chains.argtypes = [vp, vp, vp, ctypes.c_int]
+        L.vph_shard_vu_partials.argtypes = [vp, vp, ctypes.c_int]
+        L.vph_shard_vu_set.argtypes = [vp, vp, ctypes.c_int]
         L.vph_transcript_bytes.restype = u64
         L.vph_transcript_bytes.argtypes = [vp]
         _host = L
@@ -546,7 +548,7 @@ _TUNING_ENV = {"gkr_path": "VP_GKR_PATH", "serial": "VP_GKR_SERIAL", "fuse_init"
                "dot_blocks": "VP_DOT_BLOCKS", "plan_align": "VP_PLAN_ALIGN", "xcd_map": "VP_XCD_MAP", "round_fused_max": "VP_ROUND_FUSED_MAX",
                "kernel_copies": "VP_KERNEL_COPIES", "fold_branches": "VP_FOLD_BRANCHES", "ntt_scatter": "VP_NTT_SCATTER", "fuse_combine": "VP_FUSE_COMBINE",
                "graph_explicit": "VP_GRAPH_EXPLICIT", "ntt_r8": "VP_NTT_R8", "fri_vo_fused": "VP_FRI_VO_FUSED", "fuse_p2": "VP_FUSE_P2", "leaf_asm": "VP_LEAF_ASM",
-               "fft_gkr_batched": "VP_FFT_GKR_BATCHED"}
+               "fft_gkr_batched": "VP_FFT_GKR_BATCHED", "split_vu": "VP_SPLIT_VU"}
 VP_OPTIONS_ABI = 0x76700005
 
 
@@ -755,6 +757,23 @@ class Session:
             self._buf = ctypes.create_string_buffer(self._cap)
             if hasattr(self, "_n"):
                 self._bufp = ctypes.cast(self._buf, ctypes.c_void_p)
+
+    def shard_vu_partials(self):
+        """Index-split proof without a communicator: this rank's partial inner products for the V_u of the split phase-2 chains (include/vpgpu.h:
+        vp_shard_vu_partials) as a numpy array of shape (n, 2), uint64; n may be 0."""
+        import numpy as np
+        out = np.zeros((64, 2), dtype=np.uint64)
+        n = lib_host().vph_shard_vu_partials(self.h, out.ctypes.data, 64)
+        if n < 0:
+            raise RuntimeError("shard_vu_partials refused")
+        return out[:n].copy()
+
+    def shard_vu_set(self, sums):
+        """... and their u64 sum over the ranks, for this rank's next prove_gkr() (vp_shard_vu_set)."""
+        import numpy as np
+        a = np.ascontiguousarray(sums, dtype=np.uint64).reshape(-1, 2)
+        if lib_host().vph_shard_vu_set(self.h, a.ctypes.data, int(a.shape[0])):
+            raise RuntimeError("shard_vu_set refused")
 
     def shard_finish(self, summed):
         """The transcript of an index-split proof from the u64 sum of the ranks' prove_gkr() outputs (vp_shard_finish)."""

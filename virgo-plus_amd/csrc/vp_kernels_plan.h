@@ -552,7 +552,8 @@ __global__ void __launch_bounds__(VP_BLOCK) k_pred_combine(const u32 *__restrict
 
 // V_u = V(r_u) = sum_u eq(r_u, u) * V[u] (what phase 1's last fold leaves in the V table, src/prover.cpp:494-500) as an inner
 // product: with it phase 2 of a layer no longer waits for phase 1's sumcheck, every sumcheck of the proof is independent.
-struct DotJob { Half h; const F *val; F *part; F *out; u32 size, nblk; int vreal, pad; const unsigned long long *valr; };     // vreal: val[] are real circuit values; valr: their real parts as a dense array
+// beg: first entry of the range [beg, size) the job adds up (a multiple of 2^h1; 0 everywhere but in the per-rank partial inner products of an index-split proof)
+struct DotJob { Half h; const F *val; F *part; F *out; u32 size, nblk; int vreal; u32 beg; const unsigned long long *valr; };     // vreal: val[] are real circuit values; valr: their real parts as a dense array
 __global__ void __launch_bounds__(VP_BLOCK) k_dot_multi(const DotJob *__restrict__ jobs, const BlkMap *__restrict__ map) {
     __shared__ F lds[4];
     const BlkMap m = map[blockIdx.x];
@@ -564,7 +565,7 @@ __global__ void __launch_bounds__(VP_BLOCK) k_dot_multi(const DotJob *__restrict
         // runs — every thread adds up bf[lo] * V[hi H + lo] over its share of a run and multiplies by bs[hi] once (real values: 8 + 16/k
         // multiplier instructions per entry instead of 24; the kernel was as much multiplier- as memory-bound)
         const u32 runs = (j.size + H - 1) >> j.h.h1;
-        for (u32 hb = m.bid; hb < runs; hb += j.nblk) {
+        for (u32 hb = (j.beg >> j.h.h1) + m.bid; hb < runs; hb += j.nblk) {
             const u32 base = hb << j.h.h1, lim = min(H, j.size - base);
             F in = f_zero();
             if (j.vreal && j.valr) for (u32 lo = threadIdx.x; lo < lim; lo += blockDim.x) in = f_mad31c_rb<false>(j.h.bf[lo], j.valr[base + lo], in);
@@ -572,8 +573,8 @@ __global__ void __launch_bounds__(VP_BLOCK) k_dot_multi(const DotJob *__restrict
             else for (u32 lo = threadIdx.x; lo < lim; lo += blockDim.x) in = f_add(in, f_mul(j.h.bf[lo], j.val[base + lo]));
             acc[0] = f_add(acc[0], f_mul(in, j.h.bs[hb]));
         }
-    } else if (j.vreal) for (u32 i = m.bid * blockDim.x + threadIdx.x; i < j.size; i += j.nblk * blockDim.x) acc[0] = f_mad31c_rb<false>(half_at(j.h, i), j.val[i].re, acc[0]);
-    else for (u32 i = m.bid * blockDim.x + threadIdx.x; i < j.size; i += j.nblk * blockDim.x) acc[0] = f_add(acc[0], f_mul(half_at(j.h, i), j.val[i]));
+    } else if (j.vreal) for (u32 i = j.beg + m.bid * blockDim.x + threadIdx.x; i < j.size; i += j.nblk * blockDim.x) acc[0] = f_mad31c_rb<false>(half_at(j.h, i), j.val[i].re, acc[0]);
+    else for (u32 i = j.beg + m.bid * blockDim.x + threadIdx.x; i < j.size; i += j.nblk * blockDim.x) acc[0] = f_add(acc[0], f_mul(half_at(j.h, i), j.val[i]));
     block_sum<1>(acc, lds);
     if (threadIdx.x == 0) j.part[m.bid] = acc[0];
 }
@@ -584,6 +585,15 @@ __global__ void __launch_bounds__(VP_BLOCK) k_dotfin_multi(const DotJob *__restr
     for (u32 i = threadIdx.x; i < j.nblk; i += blockDim.x) acc[0] = f_add(acc[0], j.part[i]);
     block_sum<1>(acc, lds);
     if (threadIdx.x == 0) *j.out = acc[0];
+}
+// Index-split proof: the V_u of the split phase-2 chains, complete (u64 sums of the ranks' partial inner products, < 2^64) -> canonical, each into
+// the slot its phase-2 init reads.
+__global__ void k_vu_place(const F *__restrict__ sums, F *const *__restrict__ dst, u32 n) {
+    const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    F v = sums[c];
+    v.re = m_red128((u128) v.re); v.im = m_red128((u128) v.im);
+    *dst[c] = v;
 }
 __global__ void __launch_bounds__(VP_BLOCK) k_chunks_multi(const ChunkJob *__restrict__ jobs, const BlkMap *__restrict__ map) {
     const BlkMap m = map[blockIdx.x];

@@ -108,6 +108,12 @@ struct Plan {
     u64 rounds = 0; int n_steps = 0;
     FixJob *d_fix = nullptr; u32 n_fix = 0;          // k_fixup jobs (when round 1 of the sumchecks leaves its b to the fix-up pass)
     std::vector<void *> allocs;                      // device arrays owned by the plan (freed with it)
+    // index-split proof: V_u of the split phase-2 chains ahead of the graph (vu_pre_*): per chain one inner-product job over this rank's share of
+    // the previous layer's values (d_vu_slice) or over all of it (d_vu_whole: no exchange available), results side by side in d_vu_sum (one small
+    // all-reduce), k_vu_place reduces them mod p into the slots the phase-2 inits read (d_vu_dst)
+    std::vector<int> vu_layers;
+    DotJob *d_vu_slice = nullptr, *d_vu_whole = nullptr; BlkMap *d_vu_map = nullptr; u32 vu_grid = 0;
+    F *d_vu_sum = nullptr; F **d_vu_dst = nullptr;
 };
 
 // Every switch of the library, public options (include/vpgpu.h) and internal tuning alike: resolved once per vp_create (defaults <- the caller's vp_options <-
@@ -144,6 +150,7 @@ struct VpOpt {
     int32_t leaf_asm;               // VP_LEAF_ASM: leaf chains by the generated fixed-register block (0: the compiler's Keccak-f, the cross-check)       [1]
     int32_t real_pairs;             // public
     int32_t fft_gkr_batched;        // VP_FFT_GKR_BATCHED: the 2 lg inverse-FFT sumchecks of vp_fft_gkr as one batch                                      [1]
+    int32_t split_vu;               // VP_SPLIT_VU: index-split proof: V_u of a split phase 2 from per-rank partial inner products ahead of the graph      [1]
 };
 
 struct vp_ctx {
@@ -263,6 +270,7 @@ struct vp_ctx {
     bool drop_round1 = false;         // plan being recorded: round 1 of every sumcheck also leaves out the product sum (k_fixup restores b)
     std::vector<FixJob> rec_fix;      // record mode: one job per sumcheck, in protocol order
     bool owned(int chain) const { return shard_world <= 1 || chain_owner.empty() || chain_owner[chain] == shard_rank; }
+    bool vu_supplied = false; float vu_pre_ms = 0;     // index-split proof, caller-side exchange: vp_shard_vu_set has handed in the summed V_u for the next proof
 
     F *zero() const { return small; }
     F *one() const { return small + 1; }
@@ -853,6 +861,7 @@ static void opt_defaults(VpOpt *o) {
     o->leaf_asm = 1;
     o->real_pairs = 1;
     o->fft_gkr_batched = 1;
+    o->split_vu = 1;
 }
 static void opt_to_public(const VpOpt &o, vp_options *p) {
     memset(p, 0, sizeof *p);
@@ -884,7 +893,7 @@ static const OptName g_opt_names[] = {
     {"fold_branches", &VpOpt::fold_branches}, {"ntt_scatter", &VpOpt::ntt_scatter}, {"fuse_combine", &VpOpt::fuse_combine}, {"plan_autotune", &VpOpt::plan_autotune},
     {"pc_tensor_pub", &VpOpt::pc_tensor_pub}, {"persistent_timeout_ms", &VpOpt::persistent_timeout_ms}, {"graph_explicit", &VpOpt::graph_explicit}, {"ntt_r8", &VpOpt::ntt_r8},
     {"fri_vo_fused", &VpOpt::fri_vo_fused}, {"interactive_fast_init", &VpOpt::interactive_fast_init}, {"fuse_p2", &VpOpt::fuse_p2}, {"leaf_asm", &VpOpt::leaf_asm},
-    {"real_pairs", &VpOpt::real_pairs}, {"fft_gkr_batched", &VpOpt::fft_gkr_batched}};
+    {"real_pairs", &VpOpt::real_pairs}, {"fft_gkr_batched", &VpOpt::fft_gkr_batched}, {"split_vu", &VpOpt::split_vu}};
 int vp_tuning_get(const vp_ctx *ctx, const char *name, int32_t *value) {
     if (!ctx || !name || !value) return VP_EINVAL;
     for (const OptName &n : g_opt_names) if (!strcmp(n.name, name)) { *value = ctx->opt.*(n.field); return VP_OK; }
@@ -927,6 +936,7 @@ static int resolve_options(VpOpt *o, const vp_options *user, uint32_t *pinned) {
     flag("VP_LEAF_ASM", o->leaf_asm);
     flag("VP_REAL_PAIRS", o->real_pairs);
     flag("VP_FFT_GKR_BATCHED", o->fft_gkr_batched);
+    flag("VP_SPLIT_VU", o->split_vu);
     flag("VP_PC_TENSOR", o->pc_tensor_pub);
     num("VP_PERSIST_TIMEOUT_MS", o->persistent_timeout_ms);
     num("VP_GRAPH_EXPLICIT", o->graph_explicit);

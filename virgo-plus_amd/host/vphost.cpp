@@ -197,6 +197,18 @@ double vph_commit_device_ms(vph_session *s) { double ms = -1; vp_commit_stats(s-
 
 int vph_set_shard(vph_session *s, int rank, int world) { return vp_set_shard(s->p->context(), rank, world) == VP_OK ? 0 : -1; }
 
+// index-split proof, caller-side exchange of V_u (include/vpgpu.h: vp_shard_vu_partials / vp_shard_vu_set) on the session's tape; -> n, < 0: refused
+int vph_shard_vu_partials(vph_session *s, uint64_t *partials /* 2 per entry */, int capacity) {
+    if (s->tape.empty()) vph_draw_tape(s);
+    uint64_t n = 0;
+    static_assert(sizeof(F) == sizeof(vp_F), "field element layout");
+    const int rc = vp_shard_vu_partials(s->p->context(), reinterpret_cast<const vp_F *>(s->tape.data()), s->tape.size(), reinterpret_cast<vp_F *>(partials), (uint64_t) capacity, &n);
+    return rc == VP_OK ? (int) n : -1;
+}
+int vph_shard_vu_set(vph_session *s, const uint64_t *sums, int n) {
+    return vp_shard_vu_set(s->p->context(), reinterpret_cast<const vp_F *>(sums), (uint64_t) n) == VP_OK ? 0 : -1;
+}
+
 int vph_shard_chains(vph_session *s, int32_t *owner, double *cost, int capacity) {
     int n = 0;
     return vp_shard_chains(s->p->context(), owner, cost, capacity, &n) == VP_OK ? n : -1;

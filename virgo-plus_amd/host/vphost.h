@@ -132,6 +132,10 @@ double vph_commit_device_ms(vph_session *);
 /* One proof over `world` GPUs (vp_set_shard): vph_prove_gkr on this session then proves only the sumchecks dealt to `rank`
  * and leaves the rest of the transcript zero; the u64 sum of all ranks' transcripts is the proof.      */
 int vph_set_shard(vph_session *, int rank, int world);
+/* Index-split proof without a communicator: V_u of the split phase-2 chains by a caller-side exchange (include/vpgpu.h: vp_shard_vu_partials /
+ * vp_shard_vu_set) on the session's tape.  partials: 2 u64 per entry; returns the number of entries (0: nothing to exchange), < 0: refused.     */
+int vph_shard_vu_partials(vph_session *, uint64_t *partials, int capacity);
+int vph_shard_vu_set(vph_session *, const uint64_t *sums, int n);
 /* vp_shard_chains: owner and cost estimate per sumcheck chain; returns the number of chains (< 0 on error). */
 int vph_shard_chains(vph_session *, int32_t *owner, double *cost, int capacity);
 
