@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Same-call A/B of builds of libvpgpu.so on the commitment:  python tools/pc_ab.py BLOCKS [lib.so | - ] ...   ("-" = the product library).
+"""Same-call A/B of builds of libvpgpu.so on the commitment:  python tools/pc_ab.py BLOCKS [lib.so | - | VP_NAME=value] ...   ("-" = the product library;
+VP_NAME=value = the product library with that tuning variable set).
 Each variant runs in its own process (VP_LIBGPU), commits the x BLOCKS input layer twice (private + public on the protocol's eq table + FRI)
 and prints the per-kernel totals of a profiled pass and the three calls' device times; roots are compared between the variants."""
 import json
@@ -57,7 +58,10 @@ if __name__ == "__main__":
         blocks = sys.argv[1]
         for lib in sys.argv[2:] * 2:
             env = dict(os.environ)
-            if lib != "-":
+            if "=" in lib and lib.startswith("VP_"):
+                env[lib.split("=", 1)[0]] = lib.split("=", 1)[1]
+                env.pop("VP_LIBGPU", None)
+            elif lib != "-":
                 env["VP_LIBGPU"] = os.path.abspath(lib)
             else:
                 env.pop("VP_LIBGPU", None)

@@ -548,7 +548,7 @@ _TUNING_ENV = {"gkr_path": "VP_GKR_PATH", "serial": "VP_GKR_SERIAL", "fuse_init"
                "dot_blocks": "VP_DOT_BLOCKS", "plan_align": "VP_PLAN_ALIGN", "xcd_map": "VP_XCD_MAP", "round_fused_max": "VP_ROUND_FUSED_MAX",
                "kernel_copies": "VP_KERNEL_COPIES", "fold_branches": "VP_FOLD_BRANCHES", "ntt_scatter": "VP_NTT_SCATTER", "fuse_combine": "VP_FUSE_COMBINE",
                "graph_explicit": "VP_GRAPH_EXPLICIT", "ntt_r8": "VP_NTT_R8", "fri_vo_fused": "VP_FRI_VO_FUSED", "fuse_p2": "VP_FUSE_P2", "leaf_asm": "VP_LEAF_ASM",
-               "fft_gkr_batched": "VP_FFT_GKR_BATCHED", "split_vu": "VP_SPLIT_VU"}
+               "fft_gkr_batched": "VP_FFT_GKR_BATCHED", "split_vu": "VP_SPLIT_VU", "fri_fold3": "VP_FRI_FOLD3"}
 VP_OPTIONS_ABI = 0x76700005
 
 

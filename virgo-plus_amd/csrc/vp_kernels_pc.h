@@ -582,6 +582,73 @@ k_fri_fold0_vo(const F *__restrict__ lcw, const F *__restrict__ qcw, const F *__
         out[((size_t) i * 32 + b) * No + al] = f_mul(hx, f_add(D, f_mul(xr, S)));
     }
 }
+// Round 5: the first THREE folds in one pass (vp_fri_commit has every challenge before it starts).  A workgroup owns 64 consecutive positions al of one coset at
+// the eight offsets al + j N/8: wave v (of four) does fold 0 on the pair (v, v + 4) exactly as k_fri_fold0_vo does — same loads, 1 KB contiguous per wave and
+// instruction — then hands its level-1 values through LDS: waves 0, 1 do fold 1 on (v, v + 2), wave 0 fold 2 on (0, 1).  The level-1 and level-2 codewords are
+// written (they are oracles: leaf hashes and openings read them) but never read back: 10.7 + 3.2 + 1.6 GB -> 12.4 GB at x1024, and two launches less.  Every
+// operation is the exact field operation of k_fri_fold0_vo / k_fri_fold(k = 1, 2) on the same operands (mu_1^-1 = x^-2 and mu_2^-1 = x^-4 by squaring instead of
+// a table read: the same field elements), so the three codewords are the same bytes.
+template <bool TENSOR> __global__ void __launch_bounds__(256)
+k_fri_fold0_vo3(const F *__restrict__ lcw, const F *__restrict__ qcw, const F *__restrict__ hcw, const F *__restrict__ S0, F *__restrict__ out1, F *__restrict__ out2,
+                F *__restrict__ out3, u32 N, const F *__restrict__ RTn, const F *__restrict__ cb, F r0, F r1, F r2, F half_n, F inv2,
+                const F *__restrict__ q0, const F *__restrict__ qscal) {
+    __shared__ F x1[VP_VO_SPT][2][64], x2[VP_VO_SPT][64];
+    const u32 E = N >> 3, No = N >> 1, N2 = N >> 2;
+    const u32 lane = threadIdx.x & 63, v = threadIdx.x >> 6;
+    const u32 per = E >> 6;                                                   // workgroups per (slice group, coset): E >= 64
+    const u32 al = (blockIdx.x % per) * 64 + lane, sb = blockIdx.x / per, b = sb & 31, ig = sb >> 5;
+    const u32 a = al + v * E;                                                 // level-0 position (< N / 2) and level-1 position of its fold
+    const F inv_x = f_mul(RTn[(N - a) & (N - 1)], cb[b]);                     // x^-1, x = w_M^(32 a + b)
+    F q0a = f_zero(), q0b = f_zero();
+    if (TENSOR) { const size_t o = (size_t) b * N + a; q0a = q0[o]; q0b = q0[o + No]; }
+    F la[VP_VO_SPT], lb[VP_VO_SPT], ha[VP_VO_SPT], hb[VP_VO_SPT], qa[VP_VO_SPT], qb[VP_VO_SPT];
+#pragma unroll
+    for (int k = 0; k < VP_VO_SPT; ++k) {
+        const size_t p0 = ((size_t) (ig * VP_VO_SPT + k) * 32 + b) * N + a, p1 = p0 + No;
+        la[k] = lcw[p0]; lb[k] = lcw[p1]; ha[k] = hcw[p0]; hb[k] = hcw[p1];
+        if (!TENSOR) { qa[k] = qcw[p0]; qb[k] = qcw[p1]; }
+    }
+    loads_first();
+    const F xn_m1 = cb[32 + b];
+    const F xr = f_mul(inv_x, r0), hx = f_mul(half_n, inv_x);
+    F f1[VP_VO_SPT];
+#pragma unroll
+    for (int k = 0; k < VP_VO_SPT; ++k) {
+        const u32 i = ig * VP_VO_SPT + k;
+        if (TENSOR) { const F sc = qscal[i]; qa[k] = f_mul(sc, q0a); qb[k] = f_mul(sc, q0b); }
+        const F s0 = S0[i];
+        const F Ga = f_sub(f_sub(f_mul(la[k], qa[k]), f_mul(xn_m1, ha[k])), s0), Gb = f_sub(f_sub(f_mul(lb[k], qb[k]), f_mul(xn_m1, hb[k])), s0);
+        const F D = f_sub(Ga, Gb), S = f_add(Ga, Gb);
+        f1[k] = f_mul(hx, f_add(D, f_mul(xr, S)));
+        out1[((size_t) i * 32 + b) * No + a] = f1[k];
+        if (v >= 2) x1[k][v - 2][lane] = f1[k];
+    }
+    __syncthreads();
+    if (v >= 2) return;
+    // fold 1 (Nk = N / 2): level-1 positions a = al + v E and a + N / 4 = al + (v + 2) E;  mu^-1 = w_M^-(2 (32 a + b)) = x^-2
+    const F m1 = f_mul(inv_x, inv_x);
+    const F c1 = f_mul(inv2, f_mul(m1, r1));
+    F f2[VP_VO_SPT];
+#pragma unroll
+    for (int k = 0; k < VP_VO_SPT; ++k) {
+        const u32 i = ig * VP_VO_SPT + k;
+        const F g = x1[k][v][lane];
+        f2[k] = f_add(f_half(f_add(f1[k], g)), f_mul(c1, f_sub(f1[k], g)));
+        out2[((size_t) i * 32 + b) * N2 + a] = f2[k];
+        if (v == 1) x2[k][lane] = f2[k];
+    }
+    // fold 2 (Nk = N / 4): level-2 positions al and al + E;  mu^-1 = x^-4 at al.  Waves 0 and 1 only: a barrier of their own would need named barriers —
+    // wave 1 is done after its stores, wave 0 waits for the LDS writes with the workgroup barrier below, which waves 2 and 3 have left already
+    __syncthreads();
+    if (v == 1) return;
+    const F c2 = f_mul(inv2, f_mul(f_mul(m1, m1), r2));
+#pragma unroll
+    for (int k = 0; k < VP_VO_SPT; ++k) {
+        const u32 i = ig * VP_VO_SPT + k;
+        const F g = x2[k][lane];
+        out3[((size_t) i * 32 + b) * E + al] = f_add(f_half(f_add(f2[k], g)), f_mul(c2, f_sub(f2[k], g)));
+    }
+}
 // The last fold leaves ONE value per coset (32 per slice); its 16 leaves pair coset b with coset b + 16.
 __global__ void k_leaf_hash_final(const F *__restrict__ cw, int n_slices, Dig *__restrict__ leaves) {
     const u32 j = threadIdx.x;

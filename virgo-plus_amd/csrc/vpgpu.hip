@@ -150,6 +150,7 @@ struct VpOpt {
     int32_t leaf_asm;               // VP_LEAF_ASM: leaf chains by the generated fixed-register block (0: the compiler's Keccak-f, the cross-check)       [1]
     int32_t real_pairs;             // public
     int32_t fft_gkr_batched;        // VP_FFT_GKR_BATCHED: the 2 lg inverse-FFT sumchecks of vp_fft_gkr as one batch                                      [1]
+    int32_t fri_fold3;              // VP_FRI_FOLD3: vp_fri_commit folds levels 0, 1, 2 in one pass                                                        [1]
     int32_t split_vu;               // VP_SPLIT_VU: index-split proof: V_u of a split phase 2 from per-rank partial inner products ahead of the graph      [1]
 };
 
@@ -862,6 +863,7 @@ static void opt_defaults(VpOpt *o) {
     o->real_pairs = 1;
     o->fft_gkr_batched = 1;
     o->split_vu = 1;
+    o->fri_fold3 = 1;
 }
 static void opt_to_public(const VpOpt &o, vp_options *p) {
     memset(p, 0, sizeof *p);
@@ -893,7 +895,7 @@ static const OptName g_opt_names[] = {
     {"fold_branches", &VpOpt::fold_branches}, {"ntt_scatter", &VpOpt::ntt_scatter}, {"fuse_combine", &VpOpt::fuse_combine}, {"plan_autotune", &VpOpt::plan_autotune},
     {"pc_tensor_pub", &VpOpt::pc_tensor_pub}, {"persistent_timeout_ms", &VpOpt::persistent_timeout_ms}, {"graph_explicit", &VpOpt::graph_explicit}, {"ntt_r8", &VpOpt::ntt_r8},
     {"fri_vo_fused", &VpOpt::fri_vo_fused}, {"interactive_fast_init", &VpOpt::interactive_fast_init}, {"fuse_p2", &VpOpt::fuse_p2}, {"leaf_asm", &VpOpt::leaf_asm},
-    {"real_pairs", &VpOpt::real_pairs}, {"fft_gkr_batched", &VpOpt::fft_gkr_batched}, {"split_vu", &VpOpt::split_vu}};
+    {"real_pairs", &VpOpt::real_pairs}, {"fft_gkr_batched", &VpOpt::fft_gkr_batched}, {"split_vu", &VpOpt::split_vu}, {"fri_fold3", &VpOpt::fri_fold3}};
 int vp_tuning_get(const vp_ctx *ctx, const char *name, int32_t *value) {
     if (!ctx || !name || !value) return VP_EINVAL;
     for (const OptName &n : g_opt_names) if (!strcmp(n.name, name)) { *value = ctx->opt.*(n.field); return VP_OK; }
@@ -937,6 +939,7 @@ static int resolve_options(VpOpt *o, const vp_options *user, uint32_t *pinned) {
     flag("VP_REAL_PAIRS", o->real_pairs);
     flag("VP_FFT_GKR_BATCHED", o->fft_gkr_batched);
     flag("VP_SPLIT_VU", o->split_vu);
+    flag("VP_FRI_FOLD3", o->fri_fold3);
     flag("VP_PC_TENSOR", o->pc_tensor_pub);
     num("VP_PERSIST_TIMEOUT_MS", o->persistent_timeout_ms);
     num("VP_GRAPH_EXPLICIT", o->graph_explicit);
