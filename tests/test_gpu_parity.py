@@ -259,6 +259,37 @@ def test_index_split_proof_assembles_to_reference(vp, golden, gold_gkr, pws_path
     s.close(); c.close()
 
 
+def test_index_split_vu_exchange_refusals(vp, pws_path, monkeypatch):
+    """vp_shard_vu_set takes exactly the number of split phase-2 chains; sums taken on one tape are refused by a proof on another (they would give a
+    transcript that is wrong without any sign of it); an unsplit context has nothing to exchange."""
+    import numpy as np
+    monkeypatch.setenv("VP_SPLIT_COST_PERCENT", "0")
+    c = vp.Circuit.from_pws(pws_path, 16, seed=1)
+    s = vp.Session(c)
+    s.draw_tape()
+    assert len(s.shard_vu_partials()) == 0                    # not sharded: nothing
+    s.set_shard(0, 2); s.set_shard_split(11)
+    part = s.shard_vu_partials()
+    assert len(part) > 0
+    with pytest.raises(RuntimeError):
+        s.shard_vu_set(np.zeros((len(part) + 1, 2), dtype=np.uint64))
+    s.shard_vu_set(part)                                      # (not the sum: never used — the tape changes first)
+    s.draw_tape()                                             # same draws again = the same tape: accepted
+    s.prove_gkr()
+    s.shard_vu_set(part)
+    ctx = vp.lib_host().vph_session_ctx(s.h)
+    n_tape = ctypes.c_uint64(0); n_tr = ctypes.c_uint64(0)
+    assert vp.lib_gpu().vp_gkr_sizes(ctx, ctypes.byref(n_tape), ctypes.byref(n_tr)) == 0
+    other = np.ones((n_tape.value, 2), dtype=np.uint64)
+    out = ctypes.create_string_buffer(int(n_tr.value) + 4096)
+    w = ctypes.c_uint64(0)
+    vp.lib_gpu().vp_prove_gkr.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
+    rc = vp.lib_gpu().vp_prove_gkr(ctx, other.ctypes.data, n_tape.value, out, len(out), ctypes.byref(w))
+    assert rc != 0 and b"another tape" in vp.lib_gpu().vp_last_error(ctx)
+    s.set_shard(0, 1)
+    s.close(); c.close()
+
+
 def test_index_split_multi_table_chains_and_complex_values(vp, ob, monkeypatch):
     """Phase-2 chains with several long tables, short tables riding with one rank, complex circuit values, assert gates: random circuits
     with every gate type (custom_circuits) and the reference's `randomize`, W = 2, 4, 8 against the oracle."""

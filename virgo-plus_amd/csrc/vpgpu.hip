@@ -271,7 +271,7 @@ struct vp_ctx {
     bool drop_round1 = false;         // plan being recorded: round 1 of every sumcheck also leaves out the product sum (k_fixup restores b)
     std::vector<FixJob> rec_fix;      // record mode: one job per sumcheck, in protocol order
     bool owned(int chain) const { return shard_world <= 1 || chain_owner.empty() || chain_owner[chain] == shard_rank; }
-    bool vu_supplied = false; float vu_pre_ms = 0;     // index-split proof, caller-side exchange: vp_shard_vu_set has handed in the summed V_u for the next proof
+    bool vu_supplied = false; float vu_pre_ms = 0; u64 vu_tape_tag = 0;     // index-split proof, caller-side exchange: vp_shard_vu_set has handed in the summed V_u for the next proof
 
     F *zero() const { return small; }
     F *one() const { return small + 1; }
