@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-launch device time of the Merkle-tree kernels of one commit_private / FRI commit phase (vp_set_profiling): python tools/merkle_levels.py [BLOCKS]"""
+"""Per-launch device time of the Merkle-tree kernels of one commit_private / FRI commit phase (vp_set_profiling): python tools/merkle_levels.py [BLOCKS [all]]"""
 import gzip, os, sys, tempfile
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -26,6 +26,6 @@ for name, call in (("commit_private", lambda: s.commit_private()), ("commit_publ
     tot = sum(e["us"] for e in ls)
     print("%s: %d launches, %.3f ms" % (name, len(ls), tot / 1e3))
     for e in ls:
-        if e["kernel"] in ("k_merkle", "k_fri_fold", "k_pc_pointwise"):
+        if len(sys.argv) > 2 or e["kernel"] in ("k_merkle", "k_fri_fold", "k_pc_pointwise"):
             print("    %-16s grid %7d jobs %3d  %9.1f us  %s" % (e["kernel"], e.get("grid", 0), e.get("jobs", 0), e["us"], {k: v for k, v in e.items() if k not in ("kernel", "grid", "jobs", "us")}))
 s.set_profiling(0)
