@@ -762,8 +762,9 @@ class Session:
         """Index-split proof without a communicator: this rank's partial inner products for the V_u of the split phase-2 chains (include/vpgpu.h:
         vp_shard_vu_partials) as a numpy array of shape (n, 2), uint64; n may be 0."""
         import numpy as np
-        out = np.zeros((64, 2), dtype=np.uint64)
-        n = lib_host().vph_shard_vu_partials(self.h, out.ctypes.data, 64)
+        cap = max(1, int(self.circuit.layers))
+        out = np.zeros((cap, 2), dtype=np.uint64)
+        n = lib_host().vph_shard_vu_partials(self.h, out.ctypes.data, cap)
         if n < 0:
             raise RuntimeError("shard_vu_partials refused")
         return out[:n].copy()
