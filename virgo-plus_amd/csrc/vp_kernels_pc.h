@@ -549,7 +549,9 @@ k_fri_fold(const F *__restrict__ in, F *__restrict__ out, u32 Nk, int k, const F
 // and the folded levels), so nothing else needs it.  Unsharded commitment only (lw = 0).
 // A thread takes VP_VO_SPT slices of one position (b, a): x^-1, x^-1 r and (N/2) x^-1 depend on the position only (three of the eleven multiplications per
 // output), and with a tensor public vector so do the two loads of its one encoded slice.
+#ifndef VP_VO_SPT
 #define VP_VO_SPT 4
+#endif
 __global__ void __launch_bounds__(VP_BLOCK)
 k_fri_fold0_vo(const F *__restrict__ lcw, const F *__restrict__ qcw, const F *__restrict__ hcw, const F *__restrict__ S0, F *__restrict__ out, u32 N,
                const F *__restrict__ RTn /* w_N^k, k < N */, const F *__restrict__ cb /* [b] = w_M^-b, [32 + b] = w_32^b - 1 */, F r, F half_n /* N / 2 */,
