@@ -55,6 +55,16 @@ def main():
         sess.set_shard_split(11)                       # long chains cut by index: same collective, export area included
         tr, _ = sess.prove_gkr()
         assert tr == gold, "index-split proof (RCCL) differs"
+        # the same index-split proof without the V_u exchange ahead of the graph (VP_SPLIT_VU=0: every rank adds up the whole layer; no extra
+        # all-reduce) — both forms over the same communicator, the same bytes
+        os.environ["VP_SPLIT_VU"] = "0"
+        s0 = vp.Session(circ, device=dev)
+        del os.environ["VP_SPLIT_VU"]
+        s0.draw_tape()                                  # the same tape: F::init() reseeds (fieldElement.cpp:362-367)
+        s0.set_shard(rank, world); s0.attach_comm(rank, world); s0.set_shard_split(11)
+        tr0, _ = s0.prove_gkr()
+        assert tr0 == gold, "index-split proof (RCCL, VP_SPLIT_VU=0) differs"
+        s0.close()
     else:
         part, _ = sess.prove_gkr()
         assert part != gold                            # this rank's slices only

@@ -254,20 +254,11 @@ __device__ __forceinline__ F shfl_xor_F(const F &x, int mask) {
 // S_k(0) + S_k(1) = S_{k-1}(r_{k-1}) (src/verifier.cpp:208,249,295) gives Y = S_{k-1}(r_{k-1}) - Z for the totals over all tables
 // of the phase, add_term included, and the closing kernel has both (k_emit, derive_mask).  KEEP_Y = false leaves the product
 // out: five multiply-adds per pair instead of six, the same field elements in the transcript.
-#ifndef VP_SF_FOLD31
-#define VP_SF_FOLD31 0         // 1: the three folds use f_fold31 (the negated challenge limb instead of a negated difference per element)
-#endif
 // (Round 3, built and measured: M and A entries travelling through LDS weakly reduced (<= p + 3) between the rounds of a launch, so that the
 // conditional subtraction disappears from two of the three folds.  The lazy difference of two such values needs an offset that is a multiple
 // of p AND at least p + 3, i.e. 2p, and then exceeds the 2^62 the split multiply takes; with the extra fold that brings it back the net gain
-// is ~3 % of the fold arithmetic.  Not kept.)
-template <bool WEAK> __device__ __forceinline__ F sf_fold(const F &r, const F &d, const F &x0) {
-#if VP_SF_FOLD31
-    return f_fold31<WEAK, VP_MADSHIFT>(r, d, x0);
-#else
-    return f_mad_c<WEAK>(r, d, x0);
-#endif
-}
+// is ~3 % of the fold arithmetic.  Not kept.  Nor the fold through f_fold31, the negated challenge limb instead of a negated difference: HISTORY.md.)
+template <bool WEAK> __device__ __forceinline__ F sf_fold(const F &r, const F &d, const F &x0) { return f_mad_c<WEAK>(r, d, x0); }
 template <bool HAS_A>
 __device__ __forceinline__ void sf_pair_step(const F &v0, const F &v1, const F &m0, const F &m1, const F &a0, const F &a1,
                                              const F &r, Lz &X, Lz &Y, Lz &Z, F &vo, F &mo, F &ao, bool keep_y) {
@@ -295,26 +286,9 @@ __device__ __forceinline__ void sf_pair_step_rv(u64 v0, u64 v1, const F &m0, con
     if (HAS_A) ao = sf_fold<false>(r, f_sub_lazy(a1, a0), a0);
 }
 
-#ifndef VP_SF_ROTATE
-#define VP_SF_ROTATE 0         // 1: the waves that carry rounds k+1 / k+2 of a chunk rotate from chunk to chunk, and round k+2 runs on a wave that sat out
-                               // round k+1.  With fixed roles wave 0 of a workgroup does three pair steps per chunk, wave 1 two, waves 2-3 one; if wave w of
-                               // every workgroup sat on SIMD w, SIMD 0 would carry 3/1.75 of the mean load.  Measured, round 2, same call, alternating builds
-                               // (tools/ab_bench.sh): one 2^24-entry table alone 278 -> 261 us, but whole proofs x64 0.7188 -> 0.7233 ms and x1024
-                               // 6.79 -> 6.76 ms device: within the noise, the dispatcher already spreads the waves.  Off.
-#endif
-// (Requesting the six entries of the workgroup's NEXT chunk into registers before the arithmetic of the current one was built and measured
-// as well, round 2: +24 VGPRs, 298 us against 279 us at 2^24 entries in the same run — like the LDS staging below, it buys nothing: the
-// kernel waits for its multiplier, not for memory.)
-#ifndef VP_SF_LDSPF
-#define VP_SF_LDSPF 0          // 1: the streaming variant stages the NEXT chunk in LDS with global_load_lds_dwordx4 (no VGPRs) while it computes.
-                               // Built and measured (tools/micro_sumfold.hip -DVP_SF_LDSPF=1): outputs identical, 318 us against 280 us at 2^24
-                               // entries, 218 vs 212 us on 3 x 2^22 — the 24 KB of staging cost a workgroup per CU and the overlap buys nothing.
-#endif
-struct Sf3bLds { F s1[3][256]; F s2[3][128]; F red[4][9]; Lz acc2[3][128]; Lz acc3[3][64]; F dred[4];   // acc2/acc3: per-thread sums of rounds k+1, k+2
-#if VP_SF_LDSPF
-                 F pre[3][512];                       // staged chunk: wave w owns entries [128 w, 128 w + 128) of each table
-#endif
-};
+// (Measured and dropped, HISTORY.md: rotating the wave roles from chunk to chunk; requesting the next chunk's six entries into registers ahead of
+// the arithmetic; staging the next chunk in LDS with global_load_lds_dwordx4 — the kernel waits for its multiplier, not for memory.)
+struct Sf3bLds { F s1[3][256]; F s2[3][128]; F red[4][9]; Lz acc2[3][128]; Lz acc3[3][64]; F dred[4]; };   // acc2/acc3: per-thread sums of rounds k+1, k+2
 
 // Where round k takes its mult / add entries from.  GenLoad: the tables in HBM.  GenP1 / GenLiu: computed on the spot from
 // the target-sorted contribution lists (the phase-1 init / the Liu gather), so that these tables are never written at full
@@ -468,58 +442,15 @@ __device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb,
     const bool keep_y0 = (a.keep_y0 & 1) != 0, keep_rest = (a.keep_y0 & 2) != 0;              // uniform
     const bool vreal = (a.keep_y0 & 4) != 0;             // the V entries of this launch's first round are real circuit values (uniform)
     F dacc = f_zero();                                   // GenP1: this thread's share of the V_u inner product
-#if VP_SF_LDSPF
-    bool staged = false;                                 // the chunk of this iteration sits in sm.pre (uniform)
-#endif
-    int rot = 0;                                         // see VP_SF_ROTATE
     for (u32 c = bid; c < a.total_chunks; c += nb) {
         int j = 0;
         while (j + 1 < a.n_tab && c >= a.t[j + 1].chunk_start) ++j;
         const SfTab td = a.t[j];
         const u32 cl = c - td.chunk_start;
-        // logical wave / thread of this chunk: the waves that stay busy in rounds k+1 and k+2 change from chunk to chunk
-        const int wl = (VP_SF_ROTATE && !VP_SF_LDSPF) ? ((w + rot) & 3) : w;
-        const int tl = (wl << 6) | lane;
-        rot = (rot + 1) & 3;
+        const int wl = w, tl = t;
         const u32 i0 = td.off + cl * 512 + 2 * tl, vend = td.off + td.valid;
         {   // round k: one pair per thread
             F v0, v1, m0, m1, a0 = f_zero(), a1 = f_zero();
-#if VP_SF_LDSPF
-            if constexpr (Gen::MODE == 0) {
-                // LDS-direct prefetch (gfx950 global_load_lds_dwordx4): a wave stages exactly the 128 entries per table that its own
-                // lanes read (entries 2t, 2t+1), 64 lanes x 16 B per instruction, so the only synchronisation is its own vmcnt.
-                // Chunks that are not completely valid (the tail of a table) take the register path with its bounds checks.
-                const bool full = cl * 512 + 512 <= td.valid;                    // uniform
-                if (full && staged) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the staged chunk is in LDS (and the compiler may not move the reads up)
-                    v0 = sm.pre[0][2 * t]; v1 = sm.pre[0][2 * t + 1]; m0 = sm.pre[1][2 * t]; m1 = sm.pre[1][2 * t + 1];
-                    if (HAS_A) { a0 = sm.pre[2][2 * t]; a1 = sm.pre[2][2 * t + 1]; }
-                } else {
-                    v0 = ld_or_zero(a.inV, i0, vend); v1 = ld_or_zero(a.inV, i0 + 1, vend);
-                    m0 = ld_or_zero(a.inM, i0, vend); m1 = ld_or_zero(a.inM, i0 + 1, vend);
-                    if (HAS_A) { a0 = ld_or_zero(a.inA, i0, vend); a1 = ld_or_zero(a.inA, i0 + 1, vend); }
-                }
-                // stage the next chunk of this workgroup (if it is a full one) behind the reads above
-                staged = false;
-                const u32 cn = c + nb;
-                if (cn < a.total_chunks) {
-                    int jn = 0;
-                    while (jn + 1 < a.n_tab && cn >= a.t[jn + 1].chunk_start) ++jn;
-                    const u32 cln = cn - a.t[jn].chunk_start;
-                    if (cln * 512 + 512 <= a.t[jn].valid) {
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the LDS reads of this wave are done before its region is overwritten
-                        const u32 gb = a.t[jn].off + cln * 512 + 128 * w + lane;
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            __builtin_amdgcn_global_load_lds(a.inV + gb + 64 * h, &sm.pre[0][128 * w + 64 * h], 16, 0, 0);
-                            __builtin_amdgcn_global_load_lds(a.inM + gb + 64 * h, &sm.pre[1][128 * w + 64 * h], 16, 0, 0);
-                            if (HAS_A) __builtin_amdgcn_global_load_lds(a.inA + gb + 64 * h, &sm.pre[2][128 * w + 64 * h], 16, 0, 0);
-                        }
-                        staged = true;
-                    }
-                }
-            } else
-#endif
             if constexpr (Gen::MODE == 3) { v0 = gen.vrow(i0, vend); v1 = gen.vrow(i0 + 1, vend); }      // phase 2: V through the slot map
             else if (vreal && a.inVr) {                                   // uniform: 8-byte real circuit values (i0 is even: one 16-byte load per pair)
                 v0 = f_make(i0 < vend ? a.inVr[i0] : 0ull, 0); v1 = f_make(i0 + 1 < vend ? a.inVr[i0 + 1] : 0ull, 0);
@@ -529,7 +460,6 @@ __device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb,
                 else { v0 = ld_or_zero(a.inV, i0, vend); v1 = ld_or_zero(a.inV, i0 + 1, vend); }
             }
             if constexpr (Gen::MODE == 0) {
-#if !VP_SF_LDSPF
                 if (cl * 512 + 512 <= td.valid) {                            // uniform
                     m0 = a.inM[i0]; m1 = a.inM[i0 + 1];
                     if (HAS_A) { a0 = a.inA[i0]; a1 = a.inA[i0 + 1]; }
@@ -537,16 +467,10 @@ __device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb,
                     m0 = ld_or_zero(a.inM, i0, vend); m1 = ld_or_zero(a.inM, i0 + 1, vend);
                     if (HAS_A) { a0 = ld_or_zero(a.inA, i0, vend); a1 = ld_or_zero(a.inA, i0 + 1, vend); }
                 }
-#endif
             } else {                      // generated tables (GenP1 / GenLiu: one table per job, offset 0; GenP2: rows = global slots)
-#ifdef VP_GEN_ROW1
-                gen.row(i0, vend, m0, a0);
-                gen.row(i0 + 1, vend, m1, a1);
-#else
                 u32 cb0, ce0, ce1;                       // (requesting them one chunk ahead was measured: no gain)
                 gen.ptrs(i0, vend, cb0, ce0, ce1);
                 gen.row2(i0, vend, cb0, ce0, ce1, m0, a0, m1, a1);
-#endif
                 if constexpr (Gen::MODE == 1) {
                     if (gen.dot_part) {
                         if (vreal) {
@@ -580,7 +504,7 @@ __device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb,
             if (HAS_A) s2[2][tl] = ao;
         }
         __syncthreads();
-        if (wl == (VP_SF_ROTATE ? 2 : 0)) {  // round k+2: 64 pairs, results are the folded table (on a wave that sat out round k+1)
+        if (wl == 0) {  // round k+2: 64 pairs, results are the folded table
             F vo, mo, ao = f_zero();
             Lz x = sm.acc3[0][lane], y{0, 0}, z = sm.acc3[2][lane];
             if (keep_rest) y = sm.acc3[1][lane];
@@ -602,8 +526,7 @@ __device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb,
 #pragma unroll
         for (int i = 0; i < 3; ++i) lz_fold(acc[i]);
     }
-    // block partials: the sums of rounds k+1 and k+2 sit in the LDS slots of threads 0-127 and 0-63 (written by whichever wave had the role)
-    if (VP_SF_ROTATE) __syncthreads();
+    // block partials: the sums of rounds k+1 and k+2 sit in the LDS slots of threads 0-127 and 0-63
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
         if (i >= 3 && w >= 2) break;
@@ -617,6 +540,147 @@ __device__ __forceinline__ void sumfold3b_body(const SfArgs &a, u32 bid, u32 nb,
         const int nw = t == 0 ? 4 : t == 1 ? 2 : 1;
         F X = red[0][3 * t], Y = red[0][3 * t + 1], Z = red[0][3 * t + 2];
         for (int k = 1; k < nw; ++k) { X = f_add(X, red[k][3 * t]); Y = f_add(Y, red[k][3 * t + 1]); Z = f_add(Z, red[k][3 * t + 2]); }
+        F *o = a.part + (size_t) t * a.part_stride + bid * 3;
+        o[0] = X; o[1] = (t == 0 ? keep_y0 : keep_rest) ? f_sub(f_sub(Y, X), Z) : f_zero(); o[2] = Z;       // b of the other rounds: derived by k_emit
+    }
+    if constexpr (Gen::MODE == 1) {
+        if (gen.dot_part) {                              // uniform per launch
+            F d[1] = {dacc};
+            block_sum<1>(d, sm.dred);
+            if (t == 0) gen.dot_part[bid] = d[0];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_sumfold3c (round 6): the same three rounds per launch with NO idle waves, no LDS traffic and no workgroup barrier inside the chunk loop.
+// k_sumfold3b parks waves by construction: of a chunk's four waves two sit out round k+1 and three round k+2 at its two barriers (7 of 12
+// wave-slots busy; SQ_WAIT_ANY 0.56 of the wave cycles, profiles/r05_pmc_summary_b1024.json).  Here a WAVE owns a 512-entry chunk: every
+// lane folds four pairs in round k (four independent pair steps), the partner entries of round k+1 sit in lane ^ 32 and arrive with
+// v_permlane32_swap (one instruction transposes a 2 x 2 block of registers between the wave's halves: afterwards BOTH lanes hold a complete
+// pair, each of a different local slot), two pair steps per lane; round k+2's partners sit in lane ^ 16: v_permlane16_swap, one pair step.
+// 7 pair steps per lane and 8 entries, as many instructions as the dense schedule, every wave busy in every round.
+//   pair p (0..255) of the chunk = entries 2p, 2p+1;  lane l, local slot k (0..3) holds  p = l5 | l4 << 1 | (l & 15) << 2 | (k >> 1) << 6 | (k & 1) << 7:
+//   round k+1 pairs p with p ^ 1 (lane ^ 32, same slot), round k+2 pairs (p >> 1) with (p >> 1) ^ 1 (lane ^ 16), and lane l ends with the folded
+//   entry p >> 2 = l of the chunk (slot k = l5 | l4 << 1 is the one whose results landed in this lane): the stores are one 1 KiB run per wave.
+// A load instruction still covers a contiguous 2 KiB (slot k fixed), in permuted lane order.  The sums of the three rounds stay in registers
+// (lazy, folded once per chunk) and are reduced once per wave at the end of the launch.
+// MEASURED (profiles/r06_ab_sumfold3c_x1024_x64_randomize.txt, same call, transcripts identical): SLOWER — x1024 proof 6.43-6.62 -> 7.14-7.16 ms, the
+// fused-init fold launches 5.03 -> 5.91 ms: four pairs and nine lazy sums per lane are 168 registers (10 / 58 dwords spilled) = 3 waves per SIMD against 3b's 4,
+// and at 2 waves without spills 8.1 ms.  The fold is bound by the issue of dependent v_mad_u64_u32 chains; resident waves hide that, work per lane does not.
+// Kept as the A/B partner (VP_SF3C=1), off by default.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void swap32_u64(u64 &a, u64 &b) {        // lanes 32-63 of a <-> lanes 0-31 of b
+    u32 al = (u32) a, ah = (u32) (a >> 32), bl = (u32) b, bh = (u32) (b >> 32);
+    auto r0 = __builtin_amdgcn_permlane32_swap(al, bl, false, false); al = r0[0]; bl = r0[1];
+    auto r1 = __builtin_amdgcn_permlane32_swap(ah, bh, false, false); ah = r1[0]; bh = r1[1];
+    a = ((u64) ah << 32) | al; b = ((u64) bh << 32) | bl;
+}
+__device__ __forceinline__ void swap16_u64(u64 &a, u64 &b) {        // rows 1, 3 of a <-> rows 0, 2 of b (rows of 16 lanes)
+    u32 al = (u32) a, ah = (u32) (a >> 32), bl = (u32) b, bh = (u32) (b >> 32);
+    auto r0 = __builtin_amdgcn_permlane16_swap(al, bl, false, false); al = r0[0]; bl = r0[1];
+    auto r1 = __builtin_amdgcn_permlane16_swap(ah, bh, false, false); ah = r1[0]; bh = r1[1];
+    a = ((u64) ah << 32) | al; b = ((u64) bh << 32) | bl;
+}
+__device__ __forceinline__ void swap32_F(F &a, F &b) { swap32_u64(a.re, b.re); swap32_u64(a.im, b.im); }
+__device__ __forceinline__ void swap16_F(F &a, F &b) { swap16_u64(a.re, b.re); swap16_u64(a.im, b.im); }
+
+struct Sf3cLds { F red[4][9]; F dred[4]; };
+
+template <bool HAS_A, class Gen>
+__device__ __forceinline__ void sumfold3c_body(const SfArgs &a, u32 bid, u32 nb, Sf3cLds &sm, const Gen &gen) {
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    Lz acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) acc[i].re = acc[i].im = 0;
+    const F r0 = a.r[0], r1 = a.r[1], r2 = a.r[2];
+    const bool keep_y0 = (a.keep_y0 & 1) != 0, keep_rest = (a.keep_y0 & 2) != 0;              // uniform
+    const bool vreal = (a.keep_y0 & 4) != 0;             // the V entries of this launch's first round are real circuit values (uniform)
+    F dacc = f_zero();                                   // GenP1: this thread's share of the V_u inner product
+    const u32 lp = (u32) ((lane >> 5) | (((lane >> 4) & 1) << 1) | ((lane & 15) << 2));
+    for (u32 c = bid * 4 + w; c < a.total_chunks; c += nb * 4) {           // wave-uniform: the swaps below run with all lanes on
+        int j = 0;
+        while (j + 1 < a.n_tab && c >= a.t[j + 1].chunk_start) ++j;
+        const SfTab td = a.t[j];
+        const u32 cl = c - td.chunk_start;
+        const u32 vend = td.off + td.valid;
+        const bool full = cl * 512 + 512 <= td.valid;                        // uniform
+        // round k of local slot k_: one pair of this lane
+        auto round_k = [&](const int k_, F &fv, F &fm, F &fa) {
+            const u32 p = lp | (u32) ((k_ >> 1) << 6) | (u32) ((k_ & 1) << 7);
+            const u32 i0 = td.off + cl * 512 + 2 * p;
+            F v0, v1, m0, m1, a0 = f_zero(), a1 = f_zero();
+            if constexpr (Gen::MODE == 3) { v0 = gen.vrow(i0, vend); v1 = gen.vrow(i0 + 1, vend); }      // phase 2: V through the slot map
+            else if (vreal && a.inVr) {                                   // uniform: 8-byte real circuit values (i0 is even: one 16-byte load per pair)
+                v0 = f_make(i0 < vend ? a.inVr[i0] : 0ull, 0); v1 = f_make(i0 + 1 < vend ? a.inVr[i0 + 1] : 0ull, 0);
+            } else if (full) { v0 = a.inV[i0]; v1 = a.inV[i0 + 1]; }
+            else { v0 = ld_or_zero(a.inV, i0, vend); v1 = ld_or_zero(a.inV, i0 + 1, vend); }
+            if constexpr (Gen::MODE == 0) {
+                if (full) {
+                    m0 = a.inM[i0]; m1 = a.inM[i0 + 1];
+                    if (HAS_A) { a0 = a.inA[i0]; a1 = a.inA[i0 + 1]; }
+                } else {
+                    m0 = ld_or_zero(a.inM, i0, vend); m1 = ld_or_zero(a.inM, i0 + 1, vend);
+                    if (HAS_A) { a0 = ld_or_zero(a.inA, i0, vend); a1 = ld_or_zero(a.inA, i0 + 1, vend); }
+                }
+            } else {                      // generated tables (GenP1 / GenLiu: one table per job, offset 0; GenP2: rows = global slots)
+                u32 cb0, ce0, ce1;
+                gen.ptrs(i0, vend, cb0, ce0, ce1);
+                gen.row2(i0, vend, cb0, ce0, ce1, m0, a0, m1, a1);
+                if constexpr (Gen::MODE == 1) {
+                    if (gen.dot_part) {
+                        if (vreal) {
+                            if (i0 < vend) dacc = f_mad31c_rb<false>(half_at(gen.dot_h, i0), v0.re, dacc);
+                            if (i0 + 1 < vend) dacc = f_mad31c_rb<false>(half_at(gen.dot_h, i0 + 1), v1.re, dacc);
+                        } else {
+                            if (i0 < vend) dacc = f_add(dacc, f_mul(half_at(gen.dot_h, i0), v0));
+                            if (i0 + 1 < vend) dacc = f_add(dacc, f_mul(half_at(gen.dot_h, i0 + 1), v1));
+                        }
+                    }
+                }
+            }
+            fa = f_zero();
+            if (vreal) sf_pair_step_rv<HAS_A>(v0.re, v1.re, m0, m1, a0, a1, r0, acc[0], acc[1], acc[2], fv, fm, fa, keep_y0);
+            else sf_pair_step<HAS_A>(v0, v1, m0, m1, a0, a1, r0, acc[0], acc[1], acc[2], fv, fm, fa, keep_y0);
+        };
+        // rounds k and k+1 of two local slots (s, s + 1): after the swap both lanes of a pair (l, l ^ 32) hold one complete pair of round k+1
+        auto two_slots = [&](const int s_, F &ov, F &om, F &oa) {
+            F xv, xm, xa, yv, ym, ya;
+            round_k(s_, xv, xm, xa);
+            round_k(s_ + 1, yv, ym, ya);
+            swap32_F(xv, yv); swap32_F(xm, ym);
+            if (HAS_A) swap32_F(xa, ya);
+            oa = f_zero();
+            sf_pair_step<HAS_A>(xv, yv, xm, ym, xa, ya, r1, acc[3], acc[4], acc[5], ov, om, oa, keep_rest);
+        };
+        F ev, em, ea, gv, gm, ga;
+        two_slots(0, ev, em, ea);
+        two_slots(2, gv, gm, ga);
+        // round k+2: partners in lane ^ 16; the result is entry `lane` of the chunk's 64 folded entries
+        swap16_F(ev, gv); swap16_F(em, gm);
+        if (HAS_A) swap16_F(ea, ga);
+        F vo, mo, ao = f_zero();
+        sf_pair_step<HAS_A>(ev, gv, em, gm, ea, ga, r2, acc[6], acc[7], acc[8], vo, mo, ao, keep_rest);
+        const u32 oi = cl * 64 + lane;
+        if (oi < ((td.valid + 7) >> 3)) {
+            if (VP_CHK((unsigned long long) td.off + oi < g_vp_chk_cap(), 5, td.off, oi, 0)) {
+                a.outV[td.off + oi] = vo;
+                a.outM[td.off + oi] = mo;
+                if (HAS_A) a.outA[td.off + oi] = ao;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) lz_fold(acc[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const F x = wave_sum63(lz_canon(acc[i]));
+        if (lane == 63) sm.red[w][i] = x;
+    }
+    __syncthreads();
+    if (t < 3) {
+        F X = sm.red[0][3 * t], Y = sm.red[0][3 * t + 1], Z = sm.red[0][3 * t + 2];
+        for (int k = 1; k < 4; ++k) { X = f_add(X, sm.red[k][3 * t]); Y = f_add(Y, sm.red[k][3 * t + 1]); Z = f_add(Z, sm.red[k][3 * t + 2]); }
         F *o = a.part + (size_t) t * a.part_stride + bid * 3;
         o[0] = X; o[1] = (t == 0 ? keep_y0 : keep_rest) ? f_sub(f_sub(Y, X), Z) : f_zero(); o[2] = Z;       // b of the other rounds: derived by k_emit
     }

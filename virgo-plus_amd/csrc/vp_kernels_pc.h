@@ -81,17 +81,8 @@ __device__ __forceinline__ F mul_iota(const F &x, bool plus) {
 // MEASURED (round 3, same-call A/B at x1024, tools/pc_ab.py): k_ntt_lds 10.6 ms without, 10.8 ms with — the bank conflicts are not what the
 // kernel waits for (neither are the root-table gathers: compact tables changed nothing): ~500 VALU instructions per radix-4 butterfly (three
 // multiplications at ~85, eight canonical add/sub at ~20) at the ~5 cycles per wave-instruction every kernel of this library issues at ARE
-// its 41 us per 2^12-point workgroup.  Off by default; kept as the switch that measured it.
-#ifndef VP_NTT_SWZ
-#define VP_NTT_SWZ 0
-#endif
-__device__ __forceinline__ u32 ntt_slot(u32 i) {
-#if VP_NTT_SWZ
-    return i ^ (((i >> 3) ^ (i >> 6) ^ (i >> 9) ^ (i >> 12)) & 7u);
-#else
-    return i;
-#endif
-}
+// its 41 us per 2^12-point workgroup.  The swizzle is gone; ntt_slot stays as the one place it would go.
+__device__ __forceinline__ u32 ntt_slot(u32 i) { return i; }
 __global__ void __launch_bounds__(1024) k_ntt_lds(NttArgs a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     F *L = reinterpret_cast<F *>(smem_raw);
@@ -246,23 +237,15 @@ __device__ __forceinline__ void keccak_rounds4(u32 (&al)[25], u32 (&ah)[25], int
 }
 // The first and the last group of four rounds are peeled out of the loop: in the first one the compiler folds the thirteen lanes of
 // the padded 64-byte message that are constants (hhash64), in the last one it drops everything that does not reach the four output
-// lanes of SHA3-256 (most of round 24's rho / pi / chi).  VP_KECCAK_PEEL=0: all 24 rounds in the rolled loop (A/B).
-#ifndef VP_KECCAK_PEEL
-#define VP_KECCAK_PEEL 1
-#endif
+// lanes of SHA3-256 (most of round 24's rho / pi / chi).
 __device__ __forceinline__ void keccak_f1600(u64 (&A)[25]) {
     u32 al[25], ah[25];
 #pragma unroll
     for (int i = 0; i < 25; ++i) { al[i] = (u32) A[i]; ah[i] = (u32) (A[i] >> 32); }
-#if VP_KECCAK_PEEL
     keccak_rounds4(al, ah, 0);
 #pragma unroll 1
     for (int rnd0 = 4; rnd0 < 20; rnd0 += 4) keccak_rounds4(al, ah, rnd0);
     keccak_rounds4(al, ah, 20);
-#else
-#pragma unroll 1
-    for (int rnd0 = 0; rnd0 < 24; rnd0 += 4) keccak_rounds4(al, ah, rnd0);
-#endif
 #pragma unroll
     for (int i = 0; i < 25; ++i) A[i] = ((u64) ah[i] << 32) | al[i];
 }

@@ -629,6 +629,31 @@ __global__ void __launch_bounds__(VP_BLOCK, VP_SF_MINB) k_sumfold3b_gen_multi(co
         sumfold3b_body<false>(j.sf, m.bid, j.sf.nblk, sm, g);
     }
 }
+// The same two launches with a WAVE per chunk (sumfold3c_body): block b of a job takes chunks 4 b + wave, 4 b + wave + 4 nblk, ...
+#ifndef VP_SF3C_MINB
+#define VP_SF3C_MINB 3
+#endif
+__global__ void __launch_bounds__(VP_BLOCK, VP_SF3C_MINB) k_sumfold3c_multi(const SfArgs *__restrict__ jobs, const BlkMap *__restrict__ map) {
+    __shared__ Sf3cLds sm;
+    const BlkMap m = map[blockIdx.x];
+    const SfArgs &a = jobs[m.job];
+    if (a.has_a) sumfold3c_body<true>(a, m.bid, a.nblk, sm, GenLoad()); else sumfold3c_body<false>(a, m.bid, a.nblk, sm, GenLoad());
+}
+__global__ void __launch_bounds__(VP_BLOCK, VP_SF3C_MINB) k_sumfold3c_gen_multi(const SfGenJob *__restrict__ jobs, const BlkMap *__restrict__ map) {
+    __shared__ Sf3cLds sm;
+    const BlkMap m = map[blockIdx.x];
+    const SfGenJob &j = jobs[m.job];
+    if (j.mode == 1) {
+        GenP1 g; g.a = &j.a; g.dot_h = j.dot_h; g.dot_part = j.dot_part;
+        sumfold3c_body<true>(j.sf, m.bid, j.sf.nblk, sm, g);
+    } else if (j.mode == 3) {
+        GenP2 g; g.a = &j.a;
+        sumfold3c_body<true>(j.sf, m.bid, j.sf.nblk, sm, g);
+    } else {
+        GenLiu g; g.rowptr = j.g.rowptr; g.e_q = j.g.e_q; g.e_g = j.g.e_g; g.H = j.g.H;
+        sumfold3c_body<false>(j.sf, m.bid, j.sf.nblk, sm, g);
+    }
+}
 __global__ void __launch_bounds__(VP_SEG_THREADS) k_seg_multi(const SegArgs *__restrict__ jobs, const BlkMap *__restrict__ map) {
     __shared__ SegLds sm;
     const BlkMap m = map[blockIdx.x];

@@ -391,16 +391,8 @@ struct RoundArgs {
 //   a*b + c  with a, b in [0, 2p], c in [0, p]:  f_mad31 (vp_field.h), canonical result unless <true> (then < 2^61 + 4, for unreduced sums)
 __device__ __forceinline__ F f_sub_lazy(const F &a, const F &b) { return f_make(a.re + P61 - b.re, a.im + P61 - b.im); }
 // f_mad_lazy: a, b lazy.  f_mad_c: a canonical (one accumulator for L + 2H).  <true>: weakly reduced result for the lazy sums.
-#ifdef VP_EXP_NOMUL       // development probe (tools/micro_sumfold.hip): the multiply-add replaced by three cheap ops, results meaningless
-template <bool WEAK = false> __device__ __forceinline__ F f_mad_lazy(const F &a, const F &b, const F &c) { return f_make(((a.re ^ b.re) + c.re) & P61, ((a.im ^ b.im) + c.im) & P61); }
-template <bool WEAK = false> __device__ __forceinline__ F f_mad_c(const F &a, const F &b, const F &c) { return f_mad_lazy<WEAK>(a, b, c); }
-#elif defined(VP_EXP_OLDMAD)   // development probe: the general multiply-add with canonical results everywhere (the arithmetic before f_mad31c)
-template <bool WEAK = false> __device__ __forceinline__ F f_mad_lazy(const F &a, const F &b, const F &c) { return f_mad31<false>(a, b, c); }
-template <bool WEAK = false> __device__ __forceinline__ F f_mad_c(const F &a, const F &b, const F &c) { return f_mad31<false>(a, b, c); }
-#else
 template <bool WEAK = false> __device__ __forceinline__ F f_mad_lazy(const F &a, const F &b, const F &c) { return f_mad31<WEAK, VP_MADSHIFT>(a, b, c); }
 template <bool WEAK = false> __device__ __forceinline__ F f_mad_c(const F &a, const F &b, const F &c) { return f_mad31c<WEAK, VP_MADSHIFT>(a, b, c); }
-#endif
 struct Lz { u64 re, im; };                                           // unreduced sum of canonical values
 __device__ __forceinline__ void lz_add(Lz &s, const F &x) { s.re += x.re; s.im += x.im; }
 __device__ __forceinline__ void lz_fold(Lz &s) { s.re = (s.re & P61) + (s.re >> 61); s.im = (s.im & P61) + (s.im >> 61); }
@@ -408,11 +400,7 @@ __device__ __forceinline__ F lz_canon(const Lz &s) { return f_make(m_fold(s.re),
 // agent-scope word accesses: partial results that another workgroup (possibly on another XCD, behind another L2) picks up inside the same launch
 __device__ __forceinline__ unsigned long long cf_ld(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void cf_st(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-#ifdef VP_EXP_NOLOAD      // development probe (tools/micro_sumfold.hip): no global loads, results meaningless
-__device__ __forceinline__ F ld_or_zero(const F *p, u32 i, u32 valid) { return i < valid ? f_make(i * 0x9E3779B97F4A7C15ull >> 3, (u64) (size_t) p + i) : f_zero(); }
-#else
 __device__ __forceinline__ F ld_or_zero(const F *p, u32 i, u32 valid) { return i < valid ? p[i] : f_zero(); }
-#endif
 
 // Main kernel: one thread per output pair, grid-stride.  For fold=1 a thread reads 4 consecutive
 // entries per table (64 B), writes 2 (32 B) and accumulates the three sums X = sum dm*dv, Y = sum m1*v1 + a1, Z = sum m0*v0 + a0

@@ -106,6 +106,7 @@ struct Plan {
     hipStream_t streams[4] = {nullptr, nullptr, nullptr, nullptr};   // [0] = ctx->stream; [1..3] owned: fold (low priority), seg, emit (high)
     hipEvent_t ev_root = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     u64 rounds = 0; int n_steps = 0;
+    int sf3c = 0;                                    // the fold nodes were sized for k_sumfold3c (a wave per chunk): fixed when the plan is recorded
     FixJob *d_fix = nullptr; u32 n_fix = 0;          // k_fixup jobs (when round 1 of the sumchecks leaves its b to the fix-up pass)
     std::vector<void *> allocs;                      // device arrays owned by the plan (freed with it)
     // index-split proof: V_u of the split phase-2 chains ahead of the graph (vu_pre_*): per chain one inner-product job over this rank's share of
@@ -151,6 +152,7 @@ struct VpOpt {
     int32_t real_pairs;             // public
     int32_t fft_gkr_batched;        // VP_FFT_GKR_BATCHED: the 2 lg inverse-FFT sumchecks of vp_fft_gkr as one batch                                      [1]
     int32_t fri_fold3;              // VP_FRI_FOLD3: vp_fri_commit folds levels 0, 1, 2 in one pass                                                        [1]
+    int32_t sf3c;                   // VP_SF3C: the fold launches of the plan give a WAVE a chunk (k_sumfold3c: permlane swaps, no LDS, no barriers; measured slower) [0]
     int32_t split_vu;               // VP_SPLIT_VU: index-split proof: V_u of a split phase 2 from per-rank partial inner products ahead of the graph      [1]
 };
 
@@ -226,6 +228,7 @@ struct vp_ctx {
     std::deque<Pending> pending;
     std::vector<hipEvent_t> ev_spare;
     unsigned char *h_ring = nullptr; size_t ring_cap = 0, ring_at = 0;      // pinned ring: results on their way out, small arrays on their way in
+    size_t ring_live = 0, ring_call = 0;                                    // bytes behind ring_at that queued calls (ring_live) / the running entry point (ring_call) still use
     double phase_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};                         // device time of the last call of each kind (VP_PH_*)
     u64 private_epoch = 0;                                                  // vp_commit_private calls queued on this context so far
 
@@ -316,7 +319,7 @@ struct CtxLock {
 #define VP_LOCK(ctx) CtxLock vp_ctx_lock_(ctx, false)
 int flush_pending(vp_ctx *ctx, size_t count);
 // VP_ENTER_Q: the entry points that can leave their completion pending (deferred mode); everything else finishes what is pending first
-#define VP_ENTER_Q(ctx) CtxLock vp_ctx_lock_(ctx, true); do { HIPCHK(hipSetDevice((ctx)->device)); if ((ctx)->tail_active) (void) tail_quit(ctx); (ctx)->tail_suspended = false; (ctx)->tail_lost = false; } while (0)
+#define VP_ENTER_Q(ctx) CtxLock vp_ctx_lock_(ctx, true); do { HIPCHK(hipSetDevice((ctx)->device)); if ((ctx)->tail_active) (void) tail_quit(ctx); (ctx)->tail_suspended = false; (ctx)->tail_lost = false; (ctx)->ring_call = 0; } while (0)
 #define VP_ENTER(ctx) VP_ENTER_Q(ctx); do { if (!(ctx)->pending.empty()) VPCHK(flush_pending((ctx), (size_t) -1)); } while (0)
 
 constexpr u32 MAX_BLOCKS = 2048;     // 256 CUs x 8 resident 256-thread blocks
@@ -599,19 +602,32 @@ hipEvent_t ev_take(vp_ctx *ctx) {
     (void) hipEventCreate(&e);
     return e;
 }
-// pinned bytes that stay untouched until the stream has consumed / produced them: a ring far larger than what two proofs in flight stage (< 100 KB each)
+// pinned bytes that stay untouched until the stream has consumed / produced them: a ring far larger than what two proofs in flight stage (< 100 KB each).
+// The ring_live bytes behind ring_at belong to calls that are still queued (deferred completion) or to the running entry point (ring_call of them): a
+// request that would run into them first finishes the queued calls in order and lets the stream take what this call has staged, so a caller that
+// queues hundreds of calls without a vp_flush gets slower, never wrong bytes.
 int ring_alloc(vp_ctx *ctx, size_t bytes, void **out) {
     if (!ctx->h_ring) {
         HIPCHK(hipHostMalloc((void **) &ctx->h_ring, (size_t) 8 << 20, hipHostMallocDefault));
-        ctx->ring_cap = (size_t) 8 << 20; ctx->ring_at = 0;
+        ctx->ring_cap = (size_t) 8 << 20; ctx->ring_at = 0; ctx->ring_live = ctx->ring_call = 0;
     }
     bytes = (bytes + 63) & ~(size_t) 63;
     if (bytes > ctx->ring_cap / 8) { ctx->err = "internal: staging request too large"; return VP_ELIMIT; }
-    if (ctx->ring_at + bytes > ctx->ring_cap) ctx->ring_at = 0;
+    const size_t skip = ctx->ring_at + bytes > ctx->ring_cap ? ctx->ring_cap - ctx->ring_at : 0;       // the tail that a wrap leaves unused
+    if (ctx->ring_live + skip + bytes > ctx->ring_cap) {
+        VPCHK(flush_pending(ctx, (size_t) -1));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        ctx->ring_live = ctx->ring_call;
+        if (ctx->ring_live + skip + bytes > ctx->ring_cap) { ctx->err = "staging ring exhausted by one call"; return VP_ELIMIT; }
+    }
+    if (skip) ctx->ring_at = 0;
     *out = ctx->h_ring + ctx->ring_at;
     ctx->ring_at += bytes;
+    ctx->ring_live += skip + bytes; ctx->ring_call += skip + bytes;
     return VP_OK;
 }
+// returns the begin event of a deferred bracket to the pool when an entry point leaves early (HIPCHK / VPCHK between defer_begin and defer_end)
+struct EvGuard { vp_ctx *ctx; hipEvent_t *ev; ~EvGuard() { if (ev && *ev) { ctx->ev_spare.push_back(*ev); *ev = nullptr; } } };
 int defer_begin(vp_ctx *ctx, hipEvent_t *a) {
     *a = ev_take(ctx);
     if (!*a) { ctx->err = "hipEventCreate"; return VP_EHIP; }
@@ -619,8 +635,11 @@ int defer_begin(vp_ctx *ctx, hipEvent_t *a) {
     return VP_OK;
 }
 // fin(ms): what the entry point does once its work is done (ms = device time between defer_begin and here).  Not deferred: waits and runs it now.
+constexpr size_t VP_MAX_PENDING = 256;            // queued calls per context; one more finishes them all first
 template <class Fn>
-int defer_end(vp_ctx *ctx, hipEvent_t a, int phase, Fn fin) {
+int defer_end(vp_ctx *ctx, hipEvent_t &a_ref, int phase, Fn fin) {
+    const hipEvent_t a = a_ref;
+    a_ref = nullptr;                               // the bracket owns it from here (EvGuard of the caller has nothing left to return)
     hipEvent_t b = ev_take(ctx);
     if (!b) { ctx->ev_spare.push_back(a); ctx->err = "hipEventCreate"; return VP_EHIP; }
     if (hipEventRecord(b, ctx->stream) != hipSuccess) { ctx->ev_spare.push_back(a); ctx->ev_spare.push_back(b); ctx->err = "hipEventRecord"; return VP_EHIP; }
@@ -631,7 +650,14 @@ int defer_end(vp_ctx *ctx, hipEvent_t a, int phase, Fn fin) {
         ctx->ev_spare.push_back(a); ctx->ev_spare.push_back(b);
         if (rc != VP_OK) return rc;
         ctx->phase_ms[phase] = ms;
-        return fin(ms);
+        if (ctx->pending.empty()) ctx->ring_live = 0;             // the stream is idle: nothing staged is still in use once fin has copied
+        const int rf = fin(ms);
+        ctx->ring_call = 0;
+        return rf;
+    }
+    if (ctx->pending.size() >= VP_MAX_PENDING) {
+        const int rc = flush_pending(ctx, (size_t) -1);
+        if (rc != VP_OK) { ctx->ev_spare.push_back(a); ctx->ev_spare.push_back(b); return rc; }
     }
     ctx->pending.push_back(vp_ctx::Pending{a, b, phase, std::function<int(float)>(fin)});
     return VP_OK;
@@ -642,8 +668,7 @@ int flush_pending(vp_ctx *ctx, size_t count) {
     while (count-- && !ctx->pending.empty()) {
         vp_ctx::Pending p = std::move(ctx->pending.front());
         ctx->pending.pop_front();
-        hipError_t e = hipEventSynchronize(p.b);
-        if (e == hipSuccess) e = hipGetLastError();
+        const hipError_t e = hipEventSynchronize(p.b);          // (its own result only: the sticky last error may belong to a tolerated capture / instantiate failure)
         if (e != hipSuccess) { ctx->err = std::string("stream: ") + hipGetErrorString(e); rc = VP_EHIP; }
         if (rc == VP_OK) {
             float ms = 0;
@@ -658,8 +683,10 @@ int flush_pending(vp_ctx *ctx, size_t count) {
         (void) hipStreamSynchronize(ctx->stream);
         for (auto &p : ctx->pending) { ctx->ev_spare.push_back(p.a); ctx->ev_spare.push_back(p.b); }
         ctx->pending.clear();
+        ctx->ring_live = ctx->ring_call;
         return rc;
     }
+    if (ctx->pending.empty()) ctx->ring_live = ctx->ring_call;
     return ctx->pending.empty() ? vp_check_collect(ctx) : VP_OK;
 }
 
@@ -864,6 +891,7 @@ static void opt_defaults(VpOpt *o) {
     o->fft_gkr_batched = 1;
     o->split_vu = 1;
     o->fri_fold3 = 1;
+    o->sf3c = 0;
 }
 static void opt_to_public(const VpOpt &o, vp_options *p) {
     memset(p, 0, sizeof *p);
@@ -895,7 +923,7 @@ static const OptName g_opt_names[] = {
     {"fold_branches", &VpOpt::fold_branches}, {"ntt_scatter", &VpOpt::ntt_scatter}, {"fuse_combine", &VpOpt::fuse_combine}, {"plan_autotune", &VpOpt::plan_autotune},
     {"pc_tensor_pub", &VpOpt::pc_tensor_pub}, {"persistent_timeout_ms", &VpOpt::persistent_timeout_ms}, {"graph_explicit", &VpOpt::graph_explicit}, {"ntt_r8", &VpOpt::ntt_r8},
     {"fri_vo_fused", &VpOpt::fri_vo_fused}, {"interactive_fast_init", &VpOpt::interactive_fast_init}, {"fuse_p2", &VpOpt::fuse_p2}, {"leaf_asm", &VpOpt::leaf_asm},
-    {"real_pairs", &VpOpt::real_pairs}, {"fft_gkr_batched", &VpOpt::fft_gkr_batched}, {"split_vu", &VpOpt::split_vu}, {"fri_fold3", &VpOpt::fri_fold3}};
+    {"real_pairs", &VpOpt::real_pairs}, {"fft_gkr_batched", &VpOpt::fft_gkr_batched}, {"split_vu", &VpOpt::split_vu}, {"fri_fold3", &VpOpt::fri_fold3}, {"sf3c", &VpOpt::sf3c}};
 int vp_tuning_get(const vp_ctx *ctx, const char *name, int32_t *value) {
     if (!ctx || !name || !value) return VP_EINVAL;
     for (const OptName &n : g_opt_names) if (!strcmp(n.name, name)) { *value = ctx->opt.*(n.field); return VP_OK; }
@@ -940,6 +968,7 @@ static int resolve_options(VpOpt *o, const vp_options *user, uint32_t *pinned) {
     flag("VP_FFT_GKR_BATCHED", o->fft_gkr_batched);
     flag("VP_SPLIT_VU", o->split_vu);
     flag("VP_FRI_FOLD3", o->fri_fold3);
+    flag("VP_SF3C", o->sf3c);
     flag("VP_PC_TENSOR", o->pc_tensor_pub);
     num("VP_PERSIST_TIMEOUT_MS", o->persistent_timeout_ms);
     num("VP_GRAPH_EXPLICIT", o->graph_explicit);
