@@ -35,40 +35,77 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
-# PMC summaries of this command (tools/gpu_profile.sh -> tools/pmc_summary.py: separate rocprofv3 --pmc passes for FETCH_SIZE and
-# WRITE_SIZE, FETCH_SIZE doubled for gfx950 as the guide's HBM section prescribes), newest first
-PMC_SUMMARIES = ("r04_pmc_summary_b%d.json", "r03_pmc_summary_b%d.json", "r02_pmc_summary_b%d.json", "r01_l_pmc_summary_b%d.json")
+# PMC summaries of this command (tools/gpu_profile.sh -> tools/pmc_summary.py: separate rocprofv3 --pmc passes for FETCH_SIZE, WRITE_SIZE and the SQ
+# counters, FETCH_SIZE doubled for gfx950 as the guide's HBM section prescribes): profiles/r<NN>_*pmc_summary_<tag>.json, the NEWEST round's file wins.
+# tag = b<blocks> for the SHA-256 circuits, randomize_<layers>_<log> for BASELINE configs[4].
+
+
+def pmc_files(tag):
+    import glob
+    fs = glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_*pmc_summary_%s.json" % tag)) + glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_summary_%s.json" % tag))
+    return sorted(set(fs), key=lambda f: os.path.basename(f), reverse=True)
+
+
+def pmc_tag(blocks, randomize=None):
+    return ("randomize_%d_%d" % tuple(randomize)) if randomize else ("b%d" % blocks)
+
+
 # Issue-rate ceilings of the two compute-bound kernel families of the commitment, measured with tools/micro_rates.hip on MI355X
 # (profiles/r02_micro_rates.txt; 256 CUs x 4 SIMDs at 2.4 GHz, 8 waves per SIMD):
 #   F_p^2 multiply (31-bit split form, 16 v_mad_u64_u32 + Mersenne folds): 6.1e11 per second for the whole chip;
 #   Keccak-f[1600] as 24 rounds x 180 VALU instructions (v_bitop3_b32 / v_alignbit_b32) at the measured issue cost of those two.
 FMUL_PEAK_PER_S = 7.0e11        # f_mul: 224.8 SIMD-cycles per wave-multiply
 # Keccak-f[1600] on 32-bit lanes: 180 VALU instructions per round is the instruction-count FLOOR (theta parity 20 three-input xors, 10 rotations by 1,
-# 50 theta-apply, rho 48 64-bit rotations = 2 v_alignbit each... counted as 48 here + the 10 above = 58 v_alignbit_b32, chi 50 v_bitop3_b32, iota 2) —
-# 120 v_bitop3_b32 + 58 v_alignbit_b32 + 2 v_xor_b32.  The peak prices EVERY one of those at the fastest issue cost measured for any of them
-# (v_xor_b32: 2.78 SIMD-cycles per wave-instruction, tools/micro_rates.hip) — not at the cost of the kernel's own mix, against which any
-# kernel would score ~1.
+# 50 theta-apply, rho 48 rotation halves + the 10 above = 58 v_alignbit_b32, chi 50 v_bitop3_b32, iota 2) — 120 v_bitop3_b32 + 58 v_alignbit_b32 + 2 v_xor_b32.
+# PEAK (round 6): every one of the 180 at the guide's uniform issue floor of 2 cycles per wave64 instruction (MI355X_MICROARCH.md: VALU, 1024 SIMDs x 64 lanes x
+# 2.4 GHz) = 360 cycles per wave-round — a bound no kernel can beat per cycle.  (Rounds 4-5 priced the 58 rotation halves at their MEASURED 4 cycles: 476 cycles
+# per wave-round, which the kernel's in-kernel clocks undercut at 435.6 — a "peak" that is not a floor; rounds 2-3 priced all 180 at 2.78.  Both ratios stay in
+# the object under their own names.)  The kernel's distance from the floor is three measured factors, printed with it (roofline.factors):
+#   issue : 360 / cycles per wave-round the kernel really takes (s_memtime stamps of the -DVP_LEAF_STAMPS flavour: LEAF_WG_KCYCLES per 1024-thread workgroup
+#           = 4 waves per SIMD x 65 permutations x 24 rounds; the rotation halves are half-rate instructions on gfx950, profiles/r04_micro_keccak_instruction_classes.txt);
+#   clock : the shader clock under this load / 2.4 GHz (same stamps: d(memtime) / d(memrealtime));
+#   tail  : 8 rounds of workgroups x one workgroup's time / the launch's time (clock ramp at the start of a launch, the last round's stragglers).
 KECCAK_INSTR_PER_ROUND = 180
-# peak of the leaf hash: the 32-bit instruction minimum of a round — 122 logic instructions (120 v_bitop3_b32 + 2 v_xor_b32) and 58 rotation halves (v_alignbit_b32) —
-# at the two issue rates of a gfx950 SIMD: 2 cycles per wave-instruction for the full-rate class, 4 for the half-rate class that every rotate / funnel-shift
-# belongs to (measured 2.26 / 4.21 in homogeneous streams, tools/micro_keccak_parts.py; round 4's kernel, waves in phase, runs at 2.0 / 4.0 within 1 %).
-# Rounds 2-3 priced all 180 at 2.78 cycles (1.31e10/s) — a bound round 4's kernel exceeds in isolation, hence the re-statement.
-KECCAK_CYCLES_PER_ROUND = 122 * 2.0 + 58 * 4.0
-KECCAK_PEAK_PER_S = 1024 * 64 * 2.4e9 / (24 * KECCAK_CYCLES_PER_ROUND)
+KECCAK_FLOOR_CYCLES_PER_ROUND = 180 * 2.0
+KECCAK_PEAK_PER_S = 1024 * 64 * 2.4e9 / (24 * KECCAK_FLOOR_CYCLES_PER_ROUND)
+KECCAK_PEAK_PER_S_R05 = 1024 * 64 * 2.4e9 / (24 * (122 * 2.0 + 58 * 4.0))
 KECCAK_PEAK_PER_S_R03 = 1024 * 64 * 2.4e9 / (24 * 180 * 2.78)
+# in-kernel stamps of the shipped leaf-hash kernel (tools/leaf_in_step.py with the -DVP_LEAF_STAMPS flavour); tests/test_bench_line.py checks the file says the same
+LEAF_STAMPS_FILE = "profiles/r06_leaf_hash_in_step.txt"
+LEAF_WG_KCYCLES = 2718.0            # shader cycles of one 1024-thread workgroup (16 waves, 4 per SIMD, 65 chained permutations each)
+LEAF_CYCLES_PER_WAVE_ROUND = LEAF_WG_KCYCLES * 1e3 / (4 * 65 * 24)
 
 
-def pmc_traffic(blocks, kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC summary of this command at this size, or (None, None)."""
-    for pat in PMC_SUMMARIES:
-        f = os.path.join(ROOT, "profiles", pat % blocks)
+def pmc_kernel(tag, kernel):
+    """The newest committed PMC summary's record of `kernel` for this workload -> (record, file name), or (None, None)."""
+    for f in pmc_files(tag):
         try:
             for k in json.load(open(f))["kernels"]:
                 if k["kernel"].replace("vp::", "") == kernel and "hbm_bytes_per_launch" in k:
-                    return k["hbm_bytes_per_launch"], "profiles/" + os.path.basename(f)
+                    return k, "profiles/" + os.path.basename(f)
         except Exception:
             continue
     return None, None
+
+
+def pmc_traffic(tag, kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC summary of this command at this size, or (None, None)."""
+    k, src = pmc_kernel(tag, kernel)
+    return (k["hbm_bytes_per_launch"], src) if k else (None, None)
+
+
+def pmc_limiter(tag, kernel, avg_launch_us):
+    """`measured_limiter` of a VALU-bound kernel, derived from the counters of the file it names (nothing quoted from an older round)."""
+    k, src = pmc_kernel(tag, kernel)
+    if not k or "SQ_INSTS_VALU_per_launch" not in k or not k.get("SQ_WAVE_CYCLES_per_launch"):
+        return None
+    insts, waitf = k["SQ_INSTS_VALU_per_launch"], k.get("SQ_WAIT_ANY_per_launch", 0.0) / k["SQ_WAVE_CYCLES_per_launch"]
+    s = "%s: %.3g VALU wave-instructions per launch (SQ_INSTS_VALU) = %.3g per SIMD; SQ_WAIT_ANY / SQ_WAVE_CYCLES = %.2f" % (src, insts, insts / 1024, waitf)
+    if avg_launch_us:
+        cyc = avg_launch_us * 1e-6 * 2.4e9
+        s += "; at this run's %.0f us per launch one wave-instruction per %.1f cycles (2.4 GHz) per SIMD, against the guide's 2-cycle issue floor" % (avg_launch_us, cyc / (insts / 1024))
+    s += "; HBM traffic per launch %.3g B (counters) — the bytes moved are about the algorithmic bytes, the integer multiply-add of F_p^2 (16 v_mad_u64_u32 + Mersenne folds) sets the time" % k["hbm_bytes_per_launch"]
+    return s
 
 
 def launch_table(stats, total_us=None):
@@ -100,21 +137,16 @@ def launch_table(stats, total_us=None):
 FMUL_PER_PAIR_STEP = 5
 
 
-def roofline_of(rows, blocks, serial_ms, note=None):
+def roofline_of(rows, tag, serial_ms, note=None):
     """The `roofline` object for the kernel with the largest share of the (single-stream) proof time.  The fold family is bound by VALU issue,
     not by HBM (PMC: traffic = algorithmic bytes, VALU busy ~80 %): its `achieved` is F_p^2-multiply-equivalents per second against the
     chip's measured F-multiply issue rate; the HBM figure of the same launches is kept beside it (hbm_frac)."""
     if not rows:
         return None
     d = rows[0]
-    traffic, src = pmc_traffic(blocks, d["kernel"])
+    traffic, src = pmc_traffic(tag, d["kernel"])
     fold = "sumfold" in d["kernel"]
-    limiter = None
-    if fold or "light" in d["kernel"]:
-        limiter = ("VALU issue: SQ_INSTS_VALU per launch / 1024 SIMDs / launch cycles = one wave-instruction per 5.9-6.5 cycles per SIMD "
-                   "(profiles/r02_pmc_summary_b64.json, r02_pmc_summary_b1024.json) where this instruction mix issues at 4.3-5 cycles when nothing "
-                   "stalls (tools/micro_rates.hip: v_mad_u64_u32 7.0, 64-bit add 5.2, 32-bit ops 2.8-3.2): 75-85 % of the issue slots; the bytes "
-                   "moved equal the algorithmic bytes, the integer multiply-add of F_p^2 (16 v_mad_u64_u32 + Mersenne folds) sets the time")
+    limiter = pmc_limiter(tag, d["kernel"], d["avg_launch_us"]) if (fold or "light" in d["kernel"]) else None
     accounting = None
     out = {"kernel": d["kernel"], "kernel_time_share": d["time_share"], "launches": d["launches"], "avg_launch_us": d["avg_launch_us"],
            "algorithmic_bytes_per_launch": d["algorithmic_MB_per_launch"] * 1e6, "single_stream_proof_ms": serial_ms,
@@ -282,7 +314,7 @@ def cpu_model():
     return "unknown"
 
 
-def profile_gkr(sess, tr_expected, blocks):
+def profile_gkr(sess, tr_expected, tag):
     """Roofline pass (outside the timed region, same process, same resident state): the proof is replayed on ONE stream with HIP
     events around EVERY launch (in the timed steps the independent sumchecks overlap on several streams, which makes per-kernel
     event times meaningless there).  Returns (per-kernel rows, per-launch rows, roofline object, single-stream device ms)."""
@@ -292,7 +324,7 @@ def profile_gkr(sess, tr_expected, blocks):
     sess.set_profiling(0)
     assert tr_p == tr_expected, "profiled replay produced a different transcript"
     rows, per_launch, _ = launch_table(stats)
-    return rows, per_launch, roofline_of(rows, blocks, res_p["gkr_device_ms"]), res_p
+    return rows, per_launch, roofline_of(rows, tag, res_p["gkr_device_ms"]), res_p
 
 
 def pc_leg(vp, sess, circ, golden, gname, full_fixture=None):
@@ -674,7 +706,10 @@ def gkr_workload(vp, a, pws, golden, world, rank, local, blocks, shard_req, cpu_
         sess.set_shard(0, 1)                       # the roofline / verifier legs below run the whole proof on every rank
         tr_full, _ = sess.prove_gkr()
         assert tr_full == tr, "assembled sharded transcript differs from the unsharded proof"
-    rows, per_launch, roof, res_p = profile_gkr(sess, tr, blocks if not a.randomize else 0)
+    if a.batched_only:            # profiling runs: the timed batched proofs and nothing else on the device (no profiled replay, no interactive run, no second session)
+        rows, per_launch, roof, res_p = [], [], None, None
+    else:
+        rows, per_launch, roof, res_p = profile_gkr(sess, tr, pmc_tag(blocks, a.randomize))
 
     shard_sim = None
     if a.shard_sim > 1 and world == 1 and not nested:
@@ -724,12 +759,12 @@ def gkr_workload(vp, a, pws, golden, world, rank, local, blocks, shard_req, cpu_
                      "note": "each shard run alone on this GPU; a W-GPU run adds one all-reduce of the transcript (and, with the index split, of the export area) per proof"}
 
     pipelined = None
-    if rank == 0 and world == 1 and not shard and not a.no_two_in_flight and not nested:
+    if rank == 0 and world == 1 and not shard and not a.no_two_in_flight and not nested and not a.batched_only:
         g_ = golden.get(gname)
         pipelined = two_in_flight_leg(vp, circ, sess, tr, a.steps, a.warmup, local, (g_["mult_counter"] + g_["add_counter"]) if g_ else None)
 
     interactive = None
-    if rank == 0:
+    if rank == 0 and not a.batched_only:
         # the drop-in path of the reference's own call pattern (one vp_round per verifier message), outside the timed region
         t_i = time.perf_counter()
         tr_i, res_i, ok_i = sess.prove_interactive()
@@ -754,9 +789,9 @@ def gkr_workload(vp, a, pws, golden, world, rank, local, blocks, shard_req, cpu_
             bit_exact = (tr == gold)
     # the reported flag is the FULL replay check (per-round identities, wiring predicates and getFinalValue on the device, Liu
     # check, input check): the per-round identities alone hold by construction for the rounds whose b is derived
-    ok, sec_d = sess.check(tr, device_predicates=True)
+    ok, sec_d = (True, None) if a.batched_only else sess.check(tr, device_predicates=True)
     verify = None
-    if rank == 0:      # the verifier's side of the same proof (outside the timed region): O(|C|) predicate loops on host vs on the GPU
+    if rank == 0 and not a.batched_only:      # the verifier's side of the same proof (outside the timed region): O(|C|) predicate loops on host vs on the GPU
         ok_h, sec_h = sess.check(tr)
         verify = {"host_predicates_sec": sec_h, "device_predicates_sec": sec_d, "accepted": bool(ok_h and ok),
                   "note": "the verifier's O(|C|) loops on the device: wiring predicates (vp_predicates), gr of verifyLiu (vp_liu_gr), input-layer MLE (vp_layer_mle); the per-round checks stay on the host"}
@@ -819,7 +854,7 @@ def distinct_gpus(world):
     return min(world, n) if n else world
 
 
-def keccak_roofline(stats, blocks):
+def keccak_roofline(stats, tag):
     """roofline object of the leaf-hash launches (k_leaf_hash): integer-ALU-bound — Keccak-f[1600]/s against the instruction-count floor; the
     HBM side of the same launches (bytes read / time against 8 TB/s) beside it."""
     leaf = [e for e in stats if e["kernel"] == "k_leaf_hash"]
@@ -827,16 +862,29 @@ def keccak_roofline(stats, blocks):
         return None
     tot = sum(e["us"] for e in stats) or 1e-9
     w, us, by = sum(e["work"] for e in leaf), sum(e["us"] for e in leaf), sum(e["bytes"] for e in leaf)
-    traffic, src = pmc_traffic(blocks, "k_leaf_hash")
-    return {"kernel": "k_leaf_hash", "bound": "valu", "achieved": w / (us * 1e-6), "peak": KECCAK_PEAK_PER_S, "unit": "Keccak-f[1600]/s",
-            "frac": w / (us * 1e-6) / KECCAK_PEAK_PER_S,
-            "frac_of_round3_peak_definition": w / (us * 1e-6) / KECCAK_PEAK_PER_S_R03,
-            "launches": len(leaf), "avg_launch_us": us / len(leaf), "algorithmic_bytes_per_launch": by / len(leaf),
+    traffic, src = pmc_traffic(tag, "k_leaf_hash")
+    ach = w / (us * 1e-6)
+    frac = ach / KECCAK_PEAK_PER_S
+    f_issue = KECCAK_FLOOR_CYCLES_PER_ROUND / LEAF_CYCLES_PER_WAVE_ROUND
+    avg_us = us / len(leaf)
+    # a launch of 2048 workgroups on 256 CUs is eight rounds of one workgroup per CU: shader cycles the launch needs / cycles it got at 2.4 GHz
+    units = (w / len(leaf)) / (65.0 * 1024)                       # 1024-thread workgroups per launch
+    rounds_of_wgs = units / 256.0
+    f_clock_tail = (rounds_of_wgs * LEAF_WG_KCYCLES * 1e3) / (avg_us * 1e-6 * 2.4e9) if avg_us > 0 else None
+    return {"kernel": "k_leaf_hash", "bound": "valu", "achieved": ach, "peak": KECCAK_PEAK_PER_S, "unit": "Keccak-f[1600]/s",
+            "frac": frac,
+            "factors": {"issue_floor_over_measured_cycles": f_issue, "cycles_per_wave_round": {"floor": KECCAK_FLOOR_CYCLES_PER_ROUND, "measured": LEAF_CYCLES_PER_WAVE_ROUND},
+                        "clock_times_tail_this_run": f_clock_tail, "product": (f_issue * f_clock_tail) if f_clock_tail else None,
+                        "clock_and_tail_separately": "stamps of the flavour build: " + LEAF_STAMPS_FILE + " (effective clock / 2.4 GHz, and 8 x workgroup time / launch time)",
+                        "stamps_file": LEAF_STAMPS_FILE},
+            "frac_of_round5_peak_definition": ach / KECCAK_PEAK_PER_S_R05,
+            "frac_of_round3_peak_definition": ach / KECCAK_PEAK_PER_S_R03,
+            "launches": len(leaf), "avg_launch_us": avg_us, "algorithmic_bytes_per_launch": by / len(leaf),
             "hbm_GBps": by / (us * 1e-6) / 1e9, "hbm_frac": by / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "hbm_peak_GBps": HBM_PEAK_GBPS,
             "traffic": traffic, "traffic_source": src, "kernel_time_share": us / tot,
-            "peak_definition": "24 rounds x (122 logic instructions x 2 cycles + 58 rotation halves x 4 cycles): the 32-bit instruction minimum of Keccak-f[1600] (120 v_bitop3_b32 + 2 v_xor_b32; 58 v_alignbit_b32) at the two issue rates of a gfx950 SIMD "
-                               "(full-rate class 2 cycles per wave-instruction, half-rate class 4: tools/micro_keccak_parts.py), 1024 SIMDs x 64 lanes, 2.4 GHz; 65 chained permutations per leaf: integer-ALU-bound "
-                               "(SURVEY 8d: report hashes/s, not GB/s).  frac_of_round3_peak_definition keeps rounds 2-3's bound (all 180 instructions at 2.78 cycles), which round 4's kernel exceeds in isolation",
+            "peak_definition": "24 rounds x 180 VALU instructions (the 32-bit instruction minimum of Keccak-f[1600]: 120 v_bitop3_b32 + 2 v_xor_b32 + 58 v_alignbit_b32) x 2 cycles per wave64 instruction, "
+                               "the uniform issue floor of MI355X_MICROARCH.md; 1024 SIMDs x 64 lanes, 2.4 GHz; 65 chained permutations per leaf: integer-ALU-bound (SURVEY 8d: report hashes/s, not GB/s). "
+                               "factors: issue = 360 / the cycles per wave-round of the kernel's own in-kernel clocks (rotation halves issue at half rate), clock x tail = the rest, measured in this run",
             "how": "HIP events around every launch on the library stream (vp_set_profiling), commit_private + commit_public + FRI commit phase of the same session"}
 
 
@@ -857,10 +905,13 @@ def protocol_workload(vp, a, pws, golden, world, rank, local, blocks):
     upload_sec = time.perf_counter() - t_up
     sess.draw_protocol_tape()
     t_f = time.perf_counter()
-    sess.prove_gkr()                               # first GKR proof of the circuit: plan recorded, tuner, graph capture
+    sess.warm()                                    # vp_warm: the commitment's buffers, root tables, scratch, pinned staging — where the reference has its namespace-scope arrays
+    warm_sec = time.perf_counter() - t_f
+    t_f = time.perf_counter()
+    sess.prove_gkr()                               # first GKR proof of the circuit: plan recorded, tuner (unless VP_PLAN_CACHE knows the shape), graph capture
     first_gkr = time.perf_counter() - t_f
     t_f = time.perf_counter()
-    sess.prove_protocol()                          # first complete pass: the commitment's buffers and root tables
+    sess.prove_protocol()                          # first complete pass after vp_warm
     first_pass = time.perf_counter() - t_f
     # How the passes follow each other (a.pass_mode; vphost.h): "sync" (default) = every call of a pass waits for its result, as the reference's call sequence does;
     # "deferred" = the calls of a pass are queued without a host wait (vp_set_deferred) and collected at its end; "pipelined" = deferred, and each pass queues the
@@ -910,6 +961,20 @@ def protocol_workload(vp, a, pws, golden, world, rank, local, blocks):
         fx = os.path.join(GOLDEN, "oracle_sha256_x1024_gkr_seed2.bin")
         if os.path.exists(fx):
             exact["gkr_slice_vs_oracle_seed2"] = tr[32:32 + os.path.getsize(fx)] == open(fx, "rb").read()
+    if a.batched_only:
+        # profiling runs (tools/gpu_profile.sh): nothing but the batched passes in this process — the line carries the contract fields and the parity of the passes
+        sess.close(); circ.close()
+        if rank != 0:
+            return None
+        ref_ops = (g["mult_counter"] + g["add_counter"]) if g else None
+        per = {k: v / a.steps for k, v in acc.items()}
+        return {"metric": METRIC, "value": (ref_ops * proofs / elapsed_max) if ref_ops else None, "unit": "field-ops/s", "n_gpus": distinct_gpus(world), "ranks": world,
+                "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed_max / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE,
+                "data": "synthetic", "config": {"workload": "SHA-256 %d-block circuit, GKR + commitment, batched passes only (--batched-only: a profiling run)" % blocks, "pass_mode": a.pass_mode},
+                "prover_sec": {"step_wall": elapsed_max / a.steps, "gkr": per.get("gkr"), "commit_private": per.get("commit_private"), "commit_public": per.get("commit_public"),
+                               "fft_gkr": per.get("fft_gkr"), "fri_commit": per.get("fri_commit")},
+                "bit_exact": exact, "bit_exact_all_ranks": True, "roofline": None, "cpu_baseline": None,
+                "first_proof_sec": {"gkr_first_call_incl_plan_tuner_and_graph_capture": first_gkr, "vp_warm_commitment_sec": warm_sec, "first_complete_pass_after_vp_warm": first_pass}}
     trf, ok_full, times = sess.prove_and_verify_full(reps=33)      # interactive GKR + commitment verification, 33 query repetitions
     exact["complete_protocol_accepted"] = bool(ok_full)
     exact["interactive_run_equals_batched"] = trf == tr
@@ -934,8 +999,8 @@ def protocol_workload(vp, a, pws, golden, world, rank, local, blocks):
     rows, per_launch, tot_us = launch_table(allst)
     gkr_rows, gkr_per_launch, _ = launch_table(st_gkr)
     pc_rows, _, pc_us = launch_table(st_priv + st_pub + st_fri)
-    roof = keccak_roofline(allst, blocks)
-    roof_gkr = roofline_of(gkr_rows, blocks, res_g["gkr_device_ms"])
+    roof = keccak_roofline(allst, pmc_tag(blocks))
+    roof_gkr = roofline_of(gkr_rows, pmc_tag(blocks), res_g["gkr_device_ms"])
     ntt = [e for e in allst if e["kernel"] in ("k_ntt_lds", "k_ntt_split", "k_ntt8_cols", "k_ntt8_rows")]
     roof_ntt = None
     if ntt:
@@ -977,7 +1042,7 @@ def protocol_workload(vp, a, pws, golden, world, rank, local, blocks):
                        "ms_per_step_by_pass_mode": modes,
                        "step_wall_per_rank": steps_sec},
         "gkr_field_ops_per_sec": (ref_ops / per["gkr"]) if ref_ops and per.get("gkr") else None,
-        "first_proof_sec": {"gkr_first_call_incl_plan_tuner_and_graph_capture": first_gkr, "first_complete_pass_incl_commitment_buffers": first_pass},
+        "first_proof_sec": {"gkr_first_call_incl_plan_tuner_and_graph_capture": first_gkr, "vp_warm_commitment_sec": warm_sec, "first_complete_pass_after_vp_warm": first_pass},
         "bit_exact": exact, "bit_exact_all_ranks": all_ok,
         "golden_origin": g.get("origin") if g else None,
         "reference_prove_sec_build_container": g.get("reference_prove_sec_here") if g else None,
@@ -997,23 +1062,62 @@ def protocol_workload(vp, a, pws, golden, world, rank, local, blocks):
     return detail
 
 
-def reference_start(pws, blocks, pc):
-    """The REAL reference (oracle/_ref/ref_run: /root/reference compiled in place) on one host core, as a background process: it runs while the GPU legs
-    do (the box has hundreds of cores; nothing of it is inside a timed GPU region's critical path) and is collected at the end of the run."""
+_REF_PROCS = []          # every reference child ever started: main() ends them in a finally, whatever happens to the GPU legs
+
+
+def reserve_cores(n):
+    """Take the last `n` CPUs of this process's affinity set away from it (and from every thread it starts later) and return them: each reference run gets a
+    core of its own that nothing of the GPU legs — host threads of the library, the plan tuner, the circuit builder — is ever scheduled on."""
+    try:
+        avail = sorted(os.sched_getaffinity(0))
+        if len(avail) < n + 2:
+            return [None] * n
+        mine, theirs = avail[:-n], avail[-n:]
+        os.sched_setaffinity(0, mine)
+        return theirs
+    except (AttributeError, OSError):
+        return [None] * n
+
+
+def reference_start(pws, blocks, pc, cpu=None):
+    """The REAL reference (oracle/_ref/ref_run: /root/reference compiled in place) on one host core, as a background process pinned to `cpu` (a core
+    reserved with reserve_cores: the bench's own threads never run there); collected at the end of the run."""
     ref_run = os.path.join(ROOT, "oracle", "_ref", "ref_run")
     if not os.path.exists(ref_run):
         return None
+
+    def pin():
+        if cpu is not None:
+            try:
+                os.sched_setaffinity(0, {cpu})
+            except OSError:
+                pass
     try:
-        return {"t0": time.perf_counter(), "blocks": blocks, "pc": pc,
-                "proc": subprocess.Popen([ref_run, "--pws", pws, "--blocks", str(blocks), "--pc", "1" if pc else "0"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)}
+        h = {"t0": time.perf_counter(), "blocks": blocks, "pc": pc, "cpu": cpu,
+             "proc": subprocess.Popen([ref_run, "--pws", pws, "--blocks", str(blocks), "--pc", "1" if pc else "0"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
+                                      preexec_fn=pin)}
+        _REF_PROCS.append(h["proc"])
+        return h
     except Exception:
         return None
+
+
+def reference_kill_all():
+    for p in _REF_PROCS:
+        try:
+            if p.poll() is None:
+                p.kill()
+                p.wait(timeout=10)
+        except Exception:
+            pass
 
 
 def reference_collect(h, timeout=900):
     """-> dict of the reference's own printed numbers, or None."""
     if not h:
         return None
+    import resource
+    ru0 = resource.getrusage(resource.RUSAGE_CHILDREN)
     try:
         out, _ = h["proc"].communicate(timeout=timeout)
     except Exception:
@@ -1023,6 +1127,8 @@ def reference_collect(h, timeout=900):
             pass
         return None
     wall = time.perf_counter() - h["t0"]
+    ru1 = resource.getrusage(resource.RUSAGE_CHILDREN)
+    cpu_sec = (ru1.ru_utime + ru1.ru_stime) - (ru0.ru_utime + ru0.ru_stime)       # this child's own CPU time (children are reaped one at a time)
     m = re.search(r"Prove Time ([0-9.]+)", out)
     pm = re.search(r"Polynomial commitment: prove time ([0-9.]+)", out)
     c = re.search(r"mult counter (-?\d+), add counter (-?\d+)", out)
@@ -1030,7 +1136,8 @@ def reference_collect(h, timeout=900):
         return None
     gkr, pcs = float(m.group(1)), float(pm.group(1)) if (pm and h["pc"]) else 0.0
     ops = int(c.group(1)) + int(c.group(2))
-    return {"blocks": h["blocks"], "gkr_prove_sec": gkr, "pc_prove_sec": pcs, "field_ops": ops, "process_wall_sec_incl_waiting_to_be_collected": wall}
+    return {"blocks": h["blocks"], "gkr_prove_sec": gkr, "pc_prove_sec": pcs, "field_ops": ops, "process_wall_sec_incl_waiting_to_be_collected": wall,
+            "process_cpu_sec": cpu_sec, "pinned_to_cpu": h.get("cpu")}
 
 
 def cpu_protocol_baseline(r, blocks_headline=1024):
@@ -1042,9 +1149,12 @@ def cpu_protocol_baseline(r, blocks_headline=1024):
     gkr, pcs, ops = r["gkr_prove_sec"], r["pc_prove_sec"], r["field_ops"]
     return {"value": ops / (gkr + pcs), "unit": "field-ops/s", "cores": 1, "kind": "reference",
             "sample": "the real reference binary, SHA-256 x%d (1/%d of the headline's blocks), complete protocol (GKR + commitment, verifier::verify), single thread, "
-                      "run beside the GPU legs on another core" % (r["blocks"], max(1, blocks_headline // r["blocks"])),
+                      "%s" % (r["blocks"], max(1, blocks_headline // r["blocks"]),
+                              ("pinned to CPU %d, which the bench's own threads are kept off (sched_setaffinity), while the GPU legs run" % r["pinned_to_cpu"])
+                              if r.get("pinned_to_cpu") is not None else "run beside the GPU legs on another core"),
             "prover_sec": gkr + pcs, "gkr_prove_sec": gkr, "pc_prove_sec": pcs, "field_ops": ops, "gkr_field_ops_per_sec": ops / gkr,
-            "process_wall_sec": r["process_wall_sec_incl_waiting_to_be_collected"], "host_cpu": cpu_model(), "host_cores_visible": os.cpu_count()}
+            "process_wall_sec": r["process_wall_sec_incl_waiting_to_be_collected"], "process_cpu_sec": r.get("process_cpu_sec"), "pinned_to_cpu": r.get("pinned_to_cpu"),
+            "host_cpu": cpu_model(), "host_cores_visible": os.cpu_count()}
 
 
 def cpu_port_x1024(pws, tr_gpu):
@@ -1060,6 +1170,38 @@ def cpu_port_x1024(pws, tr_gpu):
     return {"kind": "port", "cores": 1, "gkr_prove_sec": st["prove_sec"], "field_ops": ops, "gkr_field_ops_per_sec": ops / st["prove_sec"],
             "circuit_build_sec": t1 - t0, "transcript_equals_gpu": (otr == tr_gpu) if tr_gpu is not None else None,
             "sample": "one full GKR proof of the 1024-block circuit by the oracle port (commitment off), single thread"}
+
+
+def first_proof_child(blocks):
+    """`bench.py --first-proof-child B`: a FRESH process with VP_PLAN_CACHE pointing at the file the parent's tuner has written — what the first proof of a
+    circuit costs a process that starts with a tuning record (one plan recording + one graph capture instead of ~14 candidates), and the first complete pass
+    behind vp_warm.  Prints one JSON object."""
+    import vp_loader
+    vp = vp_loader.load()
+    vp.lib_host()
+    with tempfile.TemporaryDirectory() as tmp:
+        pws = unpack_pws(tmp)
+        circ = vp.Circuit.from_pws(pws, blocks, seed=1)
+    c0 = vp.Circuit.randomize(2, 1, seed=1); s0 = vp.Session(c0, device=0); s0.close(); c0.close()      # process first use (HIP context, code objects)
+    sess = vp.Session(circ, device=0)
+    sess.draw_protocol_tape()
+    t = time.perf_counter(); sess.warm(); warm = time.perf_counter() - t
+    t = time.perf_counter(); tr, _ = sess.prove_gkr(); first = time.perf_counter() - t
+    t = time.perf_counter(); sess.prove_protocol(); first_pass = time.perf_counter() - t
+    t = time.perf_counter(); sess.prove_protocol(); second_pass = time.perf_counter() - t
+    import hashlib
+    print(json.dumps({"gkr_first_call_with_plan_cache": first, "vp_warm_commitment_sec": warm, "first_complete_pass_after_vp_warm": first_pass, "second_complete_pass": second_pass,
+                      "plan_cache": os.environ.get("VP_PLAN_CACHE"), "transcript_sha256_16": hashlib.sha256(tr).hexdigest()[:16]}), flush=True)
+    sess.close(); circ.close()
+
+
+def first_proof_in_fresh_process(blocks, timeout=180):
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--first-proof-child", str(blocks)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        return json.loads(line[-1]) if (r.returncode == 0 and line) else {"error": (r.stderr or "")[-300:]}
+    except Exception as e:
+        return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
 def _finite(x):
@@ -1113,8 +1255,14 @@ def compact_line(d, detail_file=None):
     roof = d.get("roofline")
     if isinstance(roof, dict):
         line["roofline"] = pick(roof, ("kernel", "bound", "achieved", "peak", "unit", "frac", "hbm_frac", "hbm_GBps", "traffic", "algorithmic_bytes_per_launch",
-                                       "avg_launch_us", "launches", "kernel_time_share", "frac_of_round3_peak_definition"))
+                                       "avg_launch_us", "launches", "kernel_time_share", "frac_of_round5_peak_definition"))
         line["roofline"].setdefault("traffic", None)
+        if roof.get("traffic_source"):
+            line["roofline"]["traffic_source"] = str(roof["traffic_source"]).split(" ")[0]
+        fc = roof.get("factors")
+        if isinstance(fc, dict):
+            line["roofline"]["factors"] = {"issue": fc.get("issue_floor_over_measured_cycles"), "clock_x_tail": fc.get("clock_times_tail_this_run"),
+                                           "cycles_per_wave_round": (fc.get("cycles_per_wave_round") or {}).get("measured"), "floor_cycles": (fc.get("cycles_per_wave_round") or {}).get("floor")}
     else:
         line["roofline"] = None
     cb = d.get("cpu_baseline")
@@ -1139,6 +1287,12 @@ def compact_line(d, detail_file=None):
         optional.append(("prover_sec_device", d.get("prover_sec_device")))
     optional.append(("host_verifier_accepts", d.get("host_verifier_accepts", ((d.get("verifier") or {}).get("complete_protocol") or {}).get("accepted"))))
     fp = d.get("first_proof_sec")
+    if isinstance(fp, dict):
+        fr = fp.get("fresh_process_with_plan_cache_file") or {}
+        fp = {k: v for k, v in fp.items() if not isinstance(v, dict)}
+        fp.update({"fresh_process_gkr_first_call_with_plan_cache": fr.get("gkr_first_call_with_plan_cache"),
+                   "fresh_process_first_complete_pass_after_vp_warm": fr.get("first_complete_pass_after_vp_warm"), "fresh_process_error": fr.get("error")})
+        fp = {k: v for k, v in fp.items() if v is not None}
     optional.append(("first_proof_sec", fp))
     ip = d.get("interactive_path")
     if isinstance(ip, dict):
@@ -1160,6 +1314,7 @@ def compact_line(d, detail_file=None):
         optional.append(("x64_gkr", {"workload": "BASELINE configs[1]: SHA-256 x64, GKR on GPU, PC off", "value": x64.get("value"), "ms_per_step": x64.get("ms_per_step"),
                                      "prover_sec_device": x64.get("prover_sec_device"), "steps": x64.get("steps"), "bit_exact": x64.get("bit_exact_vs_reference_golden"),
                                      "roofline_kernel": r64.get("kernel"), "roofline_frac": r64.get("frac"), "roofline_hbm_frac": r64.get("hbm_frac"),
+                                     "roofline_traffic": r64.get("traffic"), "traffic_source": (str(r64.get("traffic_source")).split(" ")[0] if r64.get("traffic_source") else None),
                                      "interactive_prover_sec": i64.get("prover_sec"), "first_proof_sec": x64.get("first_proof_sec"),
                                      "cpu_reference_prover_sec": (x64.get("cpu_baseline") or {}).get("prover_sec"),
                                      "two_in_flight_ms_per_proof": (x64.get("two_in_flight") or {}).get("ms_per_proof")}))
@@ -1169,6 +1324,8 @@ def compact_line(d, detail_file=None):
         optional.append(("randomize_16_20", {"workload": "BASELINE configs[4]: randomize(16,20), 2^24 gates, GKR on GPU, PC off", "value": rz.get("value"), "ms_per_step": rz.get("ms_per_step"),
                                              "prover_sec_device": rz.get("prover_sec_device"), "steps": rz.get("steps"), "bit_exact": rz.get("bit_exact_vs_reference_golden"),
                                              "roofline_kernel": rr.get("kernel"), "roofline_frac": rr.get("frac"), "hbm_frac": rr.get("hbm_frac"),
+                                             "roofline_traffic": rr.get("traffic"), "roofline_algorithmic_bytes_per_launch": rr.get("algorithmic_bytes_per_launch"),
+                                             "traffic_source": (str(rr.get("traffic_source")).split(" ")[0] if rr.get("traffic_source") else None),
                                              "interactive_prover_sec": (rz.get("interactive_path") or {}).get("prover_sec")}))
     cp = d.get("cpu_port_x1024_gkr")
     if isinstance(cp, dict):
@@ -1274,7 +1431,16 @@ def main():
     ap.add_argument("--no-sharded-leg", action="store_true", help="N > 1: skip the `sharded` sub-leg (one proof + its commitment over all ranks, RCCL)")
     ap.add_argument("--subleg-timeout", type=float, default=300.0, help="N > 1: seconds the multi-rank sub-leg may take before the line is printed without it and the ranks exit 3")
     ap.add_argument("--detail-file", default=None, help="where everything the line leaves out goes (default gpurun_out/bench_detail_n<N>.json)")
+    ap.add_argument("--first-proof-child", type=int, default=0, metavar="BLOCKS", help="internal: the fresh-process leg of first_proof_sec (see first_proof_child)")
+    ap.add_argument("--no-fresh-process-leg", action="store_true", help="N = 1 headline: skip the fresh-process first proof with the plan cache file")
+    ap.add_argument("--batched-only", action="store_true", help="profiling runs: the headline's setup, warm-up and timed batched passes and NOTHING else in the process (no profiled "
+                    "replay, no interactive run, no verification, no nested legs) — per-kernel counters of such a run are the headline's launches alone")
     a = ap.parse_args()
+    if a.first_proof_child:
+        first_proof_child(a.first_proof_child)
+        return
+    if a.batched_only:
+        a.no_cpu_baseline = a.no_x64_leg = a.no_randomize_leg = a.no_pass_modes = a.no_fresh_process_leg = True
 
     # ---- one process per GPU, always.  N > 1 without a launcher: start the ranks (before anything of this process touches the GPU).
     env_world = int(os.environ.get("WORLD_SIZE", "0") or 0)
@@ -1307,12 +1473,16 @@ def main():
     t_bench0 = time.perf_counter()
     with tempfile.TemporaryDirectory() as tmp:
         pws = unpack_pws(tmp)
+        # the plan tuner's choices of this run go to a file (VP_PLAN_CACHE, read by vp_create): the fresh-process leg starts from it
+        if "VP_PLAN_CACHE" not in os.environ:
+            os.environ["VP_PLAN_CACHE"] = os.path.join(tmp, "plan_cache_rank%d.txt" % int(os.environ.get("RANK", "0")))
         # CPU legs exist at N = 1 only (no rank of a multi-GPU run spends a second on them); the two runs of the real reference start now, on cores of their own
         ref_big = ref_64 = None
         if a.gpus == 1 and not gkr_only and not a.no_cpu_baseline and a.blocks == 1024:
-            ref_big = reference_start(pws, a.cpu_sample_blocks, True)
+            cores = reserve_cores(2)
+            ref_big = reference_start(pws, a.cpu_sample_blocks, True, cores[0])
             if not a.no_x64_leg:
-                ref_64 = reference_start(pws, 64, False)
+                ref_64 = reference_start(pws, 64, False, cores[1])
         # one-time cost of the process (HIP context, code objects: ~0.25 s) paid by a 3-gate circuit first, so that circuit_upload_sec is
         # what a caller sees per circuit (host flatten + vp_circuit_upload with its device-side list building + vp_evaluate)
         t_up = time.perf_counter()
@@ -1326,6 +1496,8 @@ def main():
             detail["process_first_use_sec"] = first_use_sec
             detail["rccl_ranks"] = None
             r64 = None
+        if world == 1 and not gkr_only and not a.no_fresh_process_leg and isinstance(detail.get("first_proof_sec"), dict):
+            detail["first_proof_sec"]["fresh_process_with_plan_cache_file"] = first_proof_in_fresh_process(a.blocks)
         # ---- N = 1 default run: BASELINE configs[1] (x64, GKR only) as a nested leg, with the real reference's GKR proof of it on one host core
         if world == 1 and not gkr_only and a.blocks == 1024 and not a.no_x64_leg:
             x64 = gkr_workload(vp, a, pws, golden, 1, 0, local, 64, False, cpu_base=False, nested=True)
@@ -1443,4 +1615,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    finally:
+        reference_kill_all()             # a GPU leg that raised (or sys.exit) must not leave a 16 GB reference run behind

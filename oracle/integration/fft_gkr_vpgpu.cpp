@@ -26,6 +26,7 @@ int fft_gkr(int lg_size, double &vt, int &ps, double &pt) {
     const auto t0 = std::chrono::high_resolution_clock::now();
     {
         vpi_rand_guard guard("vp_fft_gkr");
+        vpi_stopwatch sw(&g_vpi_sec.fft_gkr);
         uint64_t written = 0;
         vpi_must(vp_fft_gkr(vpi_ctx(), lg_size, reinterpret_cast<const vp_F *>(tape.data()), n_tape, reinterpret_cast<vp_F *>(msgs.data()), n_msgs, &written),
                  "vp_fft_gkr");

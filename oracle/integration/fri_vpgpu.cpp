@@ -180,6 +180,7 @@ __hhash_digest fri::commit_phase_step(fieldElement r) {
     vp_F rr; rr.real = r.real; rr.img = r.img;
     {
         vpi_rand_guard guard("vp_fri_step");
+        vpi_stopwatch sw(current_step_no == 0 ? &g_vpi_sec.first_fri_step : &g_vpi_sec.fri_step);
         vpi_must(vp_fri_step(vpi_ctx(), &rr, reinterpret_cast<uint8_t *>(&root)), "vp_fri_step");
     }
     ++g_vpi_count.fri_step;
@@ -203,6 +204,7 @@ fieldElement *fri::commit_phase_final() {
     if (cpd.rs_codeword[last] == NULL) cpd.rs_codeword[last] = new fieldElement[n_final];
     if (cpd.rs_codeword_msk[last] == NULL) cpd.rs_codeword_msk[last] = new fieldElement[1 << rs_code_rate];
     vpi_rand_guard guard("vp_fri_final / vp_fri_open");
+    vpi_stopwatch sw(&g_vpi_sec.fri_final);
     vpi_must(vp_fri_final(vpi_ctx(), reinterpret_cast<vp_F *>(cpd.rs_codeword[last])), "vp_fri_final");
     ++g_vpi_count.fri_final;
     for (int i = 0; i < (1 << rs_code_rate) / 2; ++i) {

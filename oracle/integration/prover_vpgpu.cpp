@@ -25,6 +25,7 @@ static inline const vp_F *cF(const F *p) { return reinterpret_cast<const vp_F *>
 static inline vp_F *mF(F *p) { return reinterpret_cast<vp_F *>(p); }
 static vp_ctx *g_ctx = nullptr;
 vpi_counters g_vpi_count;
+vpi_seconds g_vpi_sec;
 void vpi_must(int rc, const char *what) {
     if (rc == VP_OK) return;
     fprintf(stderr, "vpgpu: %s failed (%d): %s\n", what, rc, g_ctx ? vp_last_error(g_ctx) : "no context");
@@ -71,6 +72,8 @@ static void trace_at_exit() {
     fprintf(stderr, "vpgpu calls: commit_private %lu commit_public %lu fri_step %lu fri_final %lu open_init %lu open_step %lu round %lu finalize %lu rand_consumers %lu fft_gkr %lu\n",
             g_vpi_count.commit_private, g_vpi_count.commit_public, g_vpi_count.fri_step, g_vpi_count.fri_final, g_vpi_count.open_init,
             g_vpi_count.open_step, g_vpi_count.round, g_vpi_count.finalize, g_vpi_count.rand_consumers, g_vpi_count.fft_gkr);
+    fprintf(stderr, "vpgpu seconds inside device calls: commit_private %.4f commit_public %.4f fri_step (all) %.4f (first %.4f) fri_final %.4f fft_gkr %.4f\n",
+            g_vpi_sec.commit_private, g_vpi_sec.commit_public, g_vpi_sec.fri_step, g_vpi_sec.first_fri_step, g_vpi_sec.fri_final, g_vpi_sec.fft_gkr);
 }
 static_assert(sizeof(F) == sizeof(vp_F), "virgo::fieldElement is two u64 limbs (fieldElement.hpp:96-97)");
 
@@ -111,6 +114,10 @@ prover::prover(const layeredCircuit &cir) : C(cir) {              // src/prover.
     }
     GUARDED(vp_circuit_upload(g_ctx, n, desc.data()), "vp_circuit_upload");
     evaluate();
+#ifdef USE_VIRGO
+    // the commitment's tables and buffers exist before the first prover call, as the reference's namespace-scope arrays do (poly_commit.cpp:4-13, fri.cpp:13-34)
+    GUARDED(vp_warm(g_ctx, VP_WARM_COMMITMENT), "vp_warm");
+#endif
 }
 
 void prover::evaluate() {                                           // src/prover.cpp:27-91: the layers are evaluated in HBM
@@ -236,7 +243,7 @@ virgo::__hhash_digest prover::commit_private() {
     poly_prover.all_pri_mask.assign(1, fieldElement(0));
     init_scratch_pad(poly_commit::slice_size);
     __hhash_digest d;
-    GUARDED(vp_commit_private(g_ctx, reinterpret_cast<uint8_t *>(&d)), "vp_commit_private");
+    { vpi_stopwatch sw(&g_vpi_sec.commit_private); GUARDED(vp_commit_private(g_ctx, reinterpret_cast<uint8_t *>(&d)), "vp_commit_private"); }
     ++g_vpi_count.commit_private;
     vpi_oracle_committed(0, n, reinterpret_cast<const unsigned char *>(&d));
     dumpH(&d);
@@ -258,8 +265,9 @@ virgo::__hhash_digest prover::commit_public(vector<F> &pub, F &inner_product_sum
         if (!(m == F_ZERO)) { fprintf(stderr, "vpgpu: commit_public with a non-zero mask is not supported (the reference passes one zero, verifier.cpp:376)\n"); exit(EXIT_FAILURE); }
     if (all_sum.size() < (size_t) slice_number + 1) all_sum.resize(slice_number + 1);
     __hhash_digest d;
-    GUARDED(vp_commit_public(g_ctx, cF(pub.data()), pub.size(), mF(&inner_product_sum), mF(all_sum.data()), reinterpret_cast<uint8_t *>(&d)),
-            "vp_commit_public");
+    { vpi_stopwatch sw(&g_vpi_sec.commit_public);
+      GUARDED(vp_commit_public(g_ctx, cF(pub.data()), pub.size(), mF(&inner_product_sum), mF(all_sum.data()), reinterpret_cast<uint8_t *>(&d)),
+              "vp_commit_public"); }
     ++g_vpi_count.commit_public;
     vpi_oracle_committed(1, n, reinterpret_cast<const unsigned char *>(&d));
     dumpH(&d); dumpF(inner_product_sum);

@@ -8,6 +8,7 @@
 // process-wide object owned by prover_vpgpu.cpp.
 #pragma once
 #include <vpgpu.h>
+#include <chrono>
 #include <cstdio>
 
 vp_ctx *vpi_ctx();                                   // the context prover::prover() created (exits if there is none)
@@ -40,3 +41,8 @@ FILE *vpi_dump_fri_file();
 FILE *vpi_dump_fft_file();
 struct vpi_counters { unsigned long commit_private, commit_public, fri_step, fri_final, open_init, open_step, round, finalize, rand_consumers, fft_gkr; };
 extern vpi_counters g_vpi_count;
+// VPI_TRACE: wall seconds spent inside the device calls of each kind (what the reference adds up into its prove times)
+struct vpi_seconds { double commit_private, commit_public, fri_step, fri_final, fft_gkr, first_fri_step; };
+extern vpi_seconds g_vpi_sec;
+struct vpi_stopwatch { double *acc; std::chrono::high_resolution_clock::time_point t0; explicit vpi_stopwatch(double *a) : acc(a), t0(std::chrono::high_resolution_clock::now()) {}
+                       ~vpi_stopwatch() { *acc += std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count(); } };

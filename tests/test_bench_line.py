@@ -130,3 +130,36 @@ def test_committed_detail_files_rebuild_into_a_valid_line():
         d = json.load(open(f))
         o = check_line(bench.compact_line(d, "x"), "x")
         assert o["value"] is None or math.isfinite(o["value"])
+
+
+def test_roofline_reads_the_newest_pmc_summary_per_config_and_a_floor_peak():
+    """the line's `traffic` comes from the NEWEST committed PMC summary of the same workload (round 5's line still read round 4's file), per
+    config — the SHA-256 sizes AND BASELINE configs[4]; the Keccak peak is the guide's uniform 2-cycle floor (a kernel cannot beat it per cycle) and the stamps
+    file the `factors` quote says what bench.py says."""
+    import re
+    import bench
+    newest = {}
+    for tag in ("b1024", "b64", "randomize_16_20"):
+        files = bench.pmc_files(tag)
+        assert files, tag
+        rounds = [int(os.path.basename(f)[1:3]) for f in files]
+        assert rounds == sorted(rounds, reverse=True) and rounds[0] >= 6, (tag, rounds)
+        newest[tag] = os.path.basename(files[0])
+    t, src = bench.pmc_traffic("b1024", "k_leaf_hash")
+    assert src == "profiles/" + newest["b1024"] and 4.2e9 < t < 4.6e9
+    t, src = bench.pmc_traffic("randomize_16_20", "k_sumfold3b_gen_multi")
+    assert src == "profiles/" + newest["randomize_16_20"] and t > 1e8
+    lim = bench.pmc_limiter("b1024", "k_sumfold3b_gen_multi", 1450.0)
+    assert newest["b1024"] in lim and "SQ_WAIT_ANY" in lim and "r02" not in lim
+    # the floor: 24 rounds x 180 instructions x 2 cycles; the kernel's own cycles per wave-round (stamps) are ABOVE it
+    assert bench.KECCAK_FLOOR_CYCLES_PER_ROUND == 360.0 and bench.LEAF_CYCLES_PER_WAVE_ROUND > bench.KECCAK_FLOOR_CYCLES_PER_ROUND
+    assert abs(bench.KECCAK_PEAK_PER_S - 1024 * 64 * 2.4e9 / (24 * 360.0)) < 1.0
+    txt = open(os.path.join(ROOT, bench.LEAF_STAMPS_FILE)).read()
+    kc = [int(x) for x in re.findall(r"workgroup\s+(\d+) kcycles", txt)]
+    assert kc and abs(sorted(kc)[len(kc) // 2] - bench.LEAF_WG_KCYCLES) <= 2
+    # and the line carries source and factors
+    d = canned_detail()
+    d["roofline"].update({"peak": bench.KECCAK_PEAK_PER_S, "achieved": 0.68 * bench.KECCAK_PEAK_PER_S, "frac": 0.68, "traffic": t, "traffic_source": src + " (FETCH_SIZE x2)",
+                          "factors": {"issue_floor_over_measured_cycles": 0.826, "clock_times_tail_this_run": 0.82, "cycles_per_wave_round": {"floor": 360.0, "measured": 435.6}}})
+    o = check_line(bench.compact_line(d, "gpurun_out/bench_detail_n1.json"))
+    assert o["roofline"]["traffic_source"] == src and o["roofline"]["factors"]["issue"] == pytest.approx(0.826)

@@ -2004,3 +2004,59 @@ def test_fft_gkr_begun_and_never_collected_does_not_wedge_the_context(vp, ctx):
     assert L.vp_fft_gkr_begin(ctx, lg, tape.ctypes.data, nt.value) == 0
     assert L.vp_fft_gkr_end(ctx, got.ctypes.data, nm.value, ctypes.byref(w)) == 0
     assert np.array_equal(got, want)
+
+
+def test_hundreds_of_deferred_calls_without_a_flush_keep_their_bytes(vp, pws_path):
+    """the pinned staging ring (8 MB) used to wrap over regions that still-pending deferred calls had staged their results in — ~256 deferred
+    vp_fri_final calls (32 KB each) without a vp_flush returned VP_OK with the bytes of LATER calls.  Now a request that would run into live regions finishes the
+    queued calls first (and the queue itself is capped): 600 calls, every output the synchronous call's bytes."""
+    L = vp.lib_gpu()
+    L.vp_fri_final.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    c = vp.Circuit.from_pws(pws_path, 16, seed=1)
+    s = vp.Session(c)
+    s.draw_protocol_tape()
+    s.prove_protocol()
+    _, fin, _ = s.last_fri()
+    want = np.ascontiguousarray(fin).tobytes()
+    ctx = s.gpu_ctx()
+    n_calls = 600
+    outs = [np.full((2048, 2), 0xEE, dtype=np.uint64) for _ in range(n_calls)]
+    assert L.vp_set_deferred(ctx, 1) == 0
+    for o in outs:
+        assert L.vp_fri_final(ctx, o.ctypes.data) == 0
+    n = ctypes.c_int(0)
+    assert L.vp_pending(ctx, ctypes.byref(n)) == 0 and 0 < n.value <= 256          # the queue is capped; the ring made earlier calls finish
+    assert L.vp_flush(ctx, -1) == 0
+    assert L.vp_set_deferred(ctx, 0) == 0
+    bad = [i for i, o in enumerate(outs) if o.tobytes() != want]
+    assert not bad, "deferred calls with wrong bytes: %s" % bad[:10]
+    s.close(); c.close()
+
+
+def test_vp_warm_changes_no_byte_and_plan_cache_file_round_trips(vp, golden, pws_path, tmp_path, monkeypatch):
+    """vp_warm(VP_WARM_COMMITMENT) sets up the commitment's tables / buffers / pinned staging ahead of the first prover call (include/vpgpu.h): the pass behind it and
+    vp_commit_public from the caller's (pageable) vector through the pinned staging give the reference's bytes.  VP_PLAN_CACHE: the first session writes the
+    tuner's choice to the file, a second context (plan table of the process cleared by using another circuit size is not needed: the line is there) reads it."""
+    g = golden["sha256_x64"]
+    gold = open(os.path.join(GOLDEN, g["transcript"]), "rb").read()
+    cache = tmp_path / "plan_cache.txt"
+    monkeypatch.setenv("VP_PLAN_CACHE", str(cache))
+    c = vp.Circuit.from_pws(pws_path, 64, seed=1)
+    s = vp.Session(c)
+    s.warm(); s.warm()                                               # idempotent
+    s.draw_protocol_tape()
+    tr, roots, fin, _ = s.prove_protocol()
+    assert tr == gold
+    lines = [l.split() for l in open(cache).read().splitlines() if l.strip()]
+    assert len(lines) >= 1 and all(len(l) == 7 for l in lines)      # key + six values
+    # commit_public with the vector handed over from host memory (the reference's boundary): staged through pinned memory in pieces
+    pub = s.eq_table(s.last_point())
+    s.commit_private()
+    root_h, inner, all_sum, _ = s.commit_public(pub)
+    assert root_h + inner + all_sum == gold[len(gold) - (32 + 16 + 65 * 16):]
+    s.close()
+    s2 = vp.Session(c)                                               # the tuner's choice comes from the table / file: same bytes
+    s2.draw_tape()
+    tr2, _ = s2.prove_gkr()
+    assert tr2 == gold[g["gkr_slice"][0]:g["gkr_slice"][1]]
+    s2.close(); c.close()

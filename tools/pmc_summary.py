@@ -66,8 +66,12 @@ def main():
     if sys.argv[1] == "--stats":          # pmc_summary.py --stats RESULTS.db OUT.csv
         kernel_stats_csv(sys.argv[2], sys.argv[3])
         return
-    out_path, fetch_d, write_d = sys.argv[1:4]
-    sq_d = sys.argv[4] if len(sys.argv) > 4 else None
+    argv = list(sys.argv)
+    command = None
+    if "--command" in argv:
+        i = argv.index("--command"); command = argv[i + 1]; del argv[i:i + 2]
+    out_path, fetch_d, write_d = argv[1:4]
+    sq_d = argv[4] if len(argv) > 4 else None
     fe, wr = load(fetch_d), load(write_d)
     sq = load(sq_d) if sq_d else {}
     kernels = []
@@ -86,8 +90,8 @@ def main():
         for c, v in sq.get(name, {}).items():
             k[c + "_per_launch"] = sum(v) / len(v)
         kernels.append(k)
-    summary = {"note": "rocprofv3 --pmc, separate passes (FETCH_SIZE | WRITE_SIZE | SQ_*) of `python3 bench.py --steps 3 --warmup 2 "
-                       "--no-cpu-baseline`; FETCH_SIZE corrected x2 for gfx950 (MI355X_MICROARCH.md, HBM section)",
+    summary = {"note": "rocprofv3 --pmc, separate passes (FETCH_SIZE | WRITE_SIZE | SQ_*) of `python3 %s`; FETCH_SIZE corrected x2 for gfx950 (MI355X_MICROARCH.md, HBM section)"
+                       % (command or "bench.py --steps 3 --warmup 2 --no-cpu-baseline"),
                "kernels": kernels}
     for k in kernels:
         if "sumfold3b_multi" in k["kernel"] and "hbm_bytes_per_launch" in k:

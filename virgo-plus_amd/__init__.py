@@ -126,6 +126,7 @@ def lib_gpu():
         L.vp_tuning_get.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int32)]
         u64_ = ctypes.c_uint64
         L.vp_set_deferred.argtypes = [vp, ctypes.c_int]
+        L.vp_warm.argtypes = [vp, ctypes.c_uint32]
         L.vp_flush.argtypes = [vp, ctypes.c_int]
         L.vp_pending.argtypes = [vp, ctypes.POINTER(ctypes.c_int)]
         L.vp_phase_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
@@ -548,7 +549,7 @@ _TUNING_ENV = {"gkr_path": "VP_GKR_PATH", "serial": "VP_GKR_SERIAL", "fuse_init"
                "dot_blocks": "VP_DOT_BLOCKS", "plan_align": "VP_PLAN_ALIGN", "xcd_map": "VP_XCD_MAP", "round_fused_max": "VP_ROUND_FUSED_MAX",
                "kernel_copies": "VP_KERNEL_COPIES", "fold_branches": "VP_FOLD_BRANCHES", "ntt_scatter": "VP_NTT_SCATTER", "fuse_combine": "VP_FUSE_COMBINE",
                "graph_explicit": "VP_GRAPH_EXPLICIT", "ntt_r8": "VP_NTT_R8", "fri_vo_fused": "VP_FRI_VO_FUSED", "fuse_p2": "VP_FUSE_P2", "leaf_asm": "VP_LEAF_ASM",
-               "fft_gkr_batched": "VP_FFT_GKR_BATCHED", "split_vu": "VP_SPLIT_VU", "fri_fold3": "VP_FRI_FOLD3"}
+               "fft_gkr_batched": "VP_FFT_GKR_BATCHED", "split_vu": "VP_SPLIT_VU", "fri_fold3": "VP_FRI_FOLD3", "sf3c": "VP_SF3C"}
 VP_OPTIONS_ABI = 0x76700005
 
 
@@ -841,6 +842,12 @@ class Session:
         if rc:
             raise RuntimeError("vp_commit_public_eq failed: %d %s" % (rc, (lib_gpu().vp_last_error(ctx) or b"").decode()))
         return out.raw[:32], out.raw[32:48], out.raw[48:], self.commit_device_ms()
+
+    def warm(self):
+        """vp_warm(VP_WARM_COMMITMENT): the commitment's tables, buffers and pinned staging exist before the first prover call (include/vpgpu.h)."""
+        ctx = lib_host().vph_session_ctx(self.h)
+        if lib_gpu().vp_warm(ctx, 1):
+            raise RuntimeError("vp_warm failed: " + (lib_gpu().vp_last_error(ctx) or b"").decode())
 
     def draw_protocol_tape(self):
         """F::init() + every draw of verifier::verify() up front, in its order: GKR, fft_gkr, FRI fold challenges."""

@@ -45,6 +45,37 @@ __device__ __forceinline__ F lz_canon(const F &x) {                      // weak
 }
 // root (canonical) x data (limbs < 2^62): weak product, limbs < 2^61 + 4
 __device__ __forceinline__ F lz_mul(const F &root, const F &x) { return f_mad31c<true, false>(root, x, f_make(0, 0)); }
+// Round 6: the same product with a PRE-SPLIT root.  The root tables of k_ntt8_colsx / k_ntt8_rows hold each limb w = hi 2^31 + lo as the word (hi << 32) | lo
+// (still 16 bytes per root: lz_presplit): the two 31-bit halves are the two dwords of the register pair, no instruction splits them; and the negated imaginary
+// part the real limb needs is taken on the ROOT side — p - w.im = (2^30 - 1 - hi) 2^31 + (2^31 - 1 - lo), two 32-bit xors, no borrow — instead of a 64-bit
+// subtraction and a third split on the data side.  Per product 3 v_alignbit_b32 (half rate), 3 v_and_b32 and a v_sub_co / v_subb_co pair less; the same field
+// element (the weak form's value depends on the operands only through their residues and the split is exact).
+#ifndef VP_NTT_PS
+#define VP_NTT_PS 1
+#endif
+__host__ __device__ __forceinline__ F lz_presplit(const F &w) {          // canonical root -> packed halves
+    return f_make(((w.re >> 31) << 32) | (w.re & 0x7fffffffull), ((w.im >> 31) << 32) | (w.im & 0x7fffffffull));
+}
+__device__ __forceinline__ F lz_mul_ps(const F &wp, const F &x) {
+    Sp31 ar, ai, nai;
+    ar.lo = (u32) wp.re; ar.hi = (u32) (wp.re >> 32);
+    ai.lo = (u32) wp.im; ai.hi = (u32) (wp.im >> 32);
+    nai.lo = ai.lo ^ 0x7fffffffu; nai.hi = ai.hi ^ 0x3fffffffu;          // p - w.im in [0, p]: hi < 2^30 as dot2_31c wants
+    const Sp31 br = split31(x.re), bi = split31(x.im);
+    return f_make(dot2_31c<true, false>(ar, br, nai, bi, 0), dot2_31c<true, false>(ar, bi, ai, br, 0));
+}
+// root x data through whichever form the tables of this build hold
+__device__ __forceinline__ F lz_mul_t(const F &w, const F &x) {
+#if VP_NTT_PS
+    return lz_mul_ps(w, x);
+#else
+    return lz_mul(w, x);
+#endif
+}
+__global__ void __launch_bounds__(256) k_root_presplit(const F *__restrict__ in, F *__restrict__ out, u32 n) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = lz_presplit(in[i]);
+}
 
 // Eight-point DFT in place: u[m'] <- sum_m u[m] w_8^(m m').  Inputs: limbs < 2^61 + 8.  Outputs: limbs < 2^61 + 8 (folded), congruent mod p.
 template <bool INV> __device__ __forceinline__ void lz_dft8(F (&u)[8]) {
@@ -300,7 +331,7 @@ __global__ void __launch_bounds__(NTT8X_THREADS) __attribute__((amdgpu_waves_per
                 for (u32 m = 0; m < NTT8X_G; ++m) w[m] = a.TW[(e0 + (g + m) * step) & TWM];
                 loads_first();
 #pragma unroll
-                for (u32 m = 0; m < NTT8X_G; ++m) u[g + m] = lz_mul(w[m], uin[g + m]);
+                for (u32 m = 0; m < NTT8X_G; ++m) u[g + m] = lz_mul_t(w[m], uin[g + m]);
                 loads_first();
             }
             lz_dft8<false>(u);
@@ -320,14 +351,14 @@ __global__ void __launch_bounds__(NTT8X_THREADS) __attribute__((amdgpu_waves_per
                 for (u32 m = 0; m < NTT8X_G; ++m) w[m] = t2[(size_t) (g + m) * 8 * COLS];
                 loads_first();
 #pragma unroll
-                for (u32 m = 0; m < NTT8X_G; ++m) u[g + m] = lz_mul(w[m], u[g + m]);
+                for (u32 m = 0; m < NTT8X_G; ++m) u[g + m] = lz_mul_t(w[m], u[g + m]);
                 loads_first();
             }
             lz_dft8<false>(u);
         }
         if (L1 == 6) {
 #pragma unroll
-            for (u32 m = 0; m < 8; ++m) { dst[(size_t) ntt8x_k1<L1>(q, m) * N2] = lz_mul(w1[m], u[m]); if ((m & (NTT8X_G - 1)) == NTT8X_G - 1) loads_first(); }
+            for (u32 m = 0; m < 8; ++m) { dst[(size_t) ntt8x_k1<L1>(q, m) * N2] = lz_mul_t(w1[m], u[m]); if ((m & (NTT8X_G - 1)) == NTT8X_G - 1) loads_first(); }
             __syncthreads();                                    // the tile is free for the next coset's first pass
             continue;
         }
@@ -342,10 +373,10 @@ __global__ void __launch_bounds__(NTT8X_THREADS) __attribute__((amdgpu_waves_per
                 const u32 qq = q + h * Q8;                                                // < 64 = s: k = qq
                 F v[2];
                 v[0] = L[(qq << LC) + c]; v[1] = L[((qq + 64) << LC) + c];
-                v[1] = lz_mul(a.RTn[qq], v[1]);
+                v[1] = lz_mul_t(a.RTn[qq], v[1]);
                 lz_dft2(v);
-                dst[(size_t) ntt8x_k1<L1>(q, 2 * h) * N2] = lz_mul(w1[2 * h], v[0]);
-                dst[(size_t) ntt8x_k1<L1>(q, 2 * h + 1) * N2] = lz_mul(w1[2 * h + 1], v[1]);
+                dst[(size_t) ntt8x_k1<L1>(q, 2 * h) * N2] = lz_mul_t(w1[2 * h], v[0]);
+                dst[(size_t) ntt8x_k1<L1>(q, 2 * h + 1) * N2] = lz_mul_t(w1[2 * h + 1], v[1]);
                 loads_first();
             }
         } else {
@@ -359,10 +390,10 @@ __global__ void __launch_bounds__(NTT8X_THREADS) __attribute__((amdgpu_waves_per
                 for (u32 m = 1; m < 4; ++m) w[m] = a.RTn[(qq * m) & (N1 - 1)];
                 loads_first();
 #pragma unroll
-                for (u32 m = 1; m < 4; ++m) v[m] = lz_mul(w[m], v[m]);
+                for (u32 m = 1; m < 4; ++m) v[m] = lz_mul_t(w[m], v[m]);
                 lz_dft4<false>(v);
 #pragma unroll
-                for (u32 m = 0; m < 4; ++m) { dst[(size_t) ntt8x_k1<L1>(q, 4 * h + m) * N2] = lz_mul(w1[4 * h + m], v[m]); if (m & 1) loads_first(); }
+                for (u32 m = 0; m < 4; ++m) { dst[(size_t) ntt8x_k1<L1>(q, 4 * h + m) * N2] = lz_mul_t(w1[4 * h + m], v[m]); if (m & 1) loads_first(); }
             }
         }
         __syncthreads();                                        // every read of the tile is done before the next coset's first pass writes it
@@ -405,7 +436,7 @@ __global__ void __launch_bounds__(NTT8_THREADS, 2) k_ntt8_rows(Ntt8Args a) {
 #pragma unroll
         for (u32 m = 1; m < 8; ++m) { const u32 e = 8 * k * m; tw[m] = a.RTn[INV ? ((512 - e) & 511) : e]; }
 #pragma unroll
-        for (u32 m = 1; m < 8; ++m) u[m] = lz_mul(tw[m], u[m]);
+        for (u32 m = 1; m < 8; ++m) u[m] = lz_mul_t(tw[m], u[m]);
         lz_dft8<INV>(u);
         __syncthreads();
 #pragma unroll
@@ -420,11 +451,11 @@ __global__ void __launch_bounds__(NTT8_THREADS, 2) k_ntt8_rows(Ntt8Args a) {
 #pragma unroll
         for (u32 m = 1; m < 8; ++m) { const u32 e = (j * m) & 511; tw[m] = a.RTn[INV ? ((512 - e) & 511) : e]; }
 #pragma unroll
-        for (u32 m = 1; m < 8; ++m) u[m] = lz_mul(tw[m], u[m]);
+        for (u32 m = 1; m < 8; ++m) u[m] = lz_mul_t(tw[m], u[m]);
         lz_dft8<INV>(u);
         __syncthreads();
 #pragma unroll
-        for (u32 m = 0; m < 8; ++m) Lw[ntt8_pad(j) + 72 * m] = a.do_scale ? lz_mul(a.scale, u[m]) : u[m];
+        for (u32 m = 0; m < 8; ++m) Lw[ntt8_pad(j) + 72 * m] = a.do_scale ? lz_mul_t(a.scale, u[m]) : u[m];
         __syncthreads();
     }
     // natural order: element k2 of row k1 goes to k1 + N1 k2 — the tile's eight k1 are consecutive: 128 contiguous bytes per k2

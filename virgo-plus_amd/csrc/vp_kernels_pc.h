@@ -609,29 +609,31 @@ k_fri_fold0_vo3(const F *__restrict__ lcw, const F *__restrict__ qcw, const F *_
         if (v >= 2) x1[k][v - 2][lane] = f1[k];
     }
     __syncthreads();
-    if (v >= 2) return;
-    // fold 1 (Nk = N / 2): level-1 positions a = al + v E and a + N / 4 = al + (v + 2) E;  mu^-1 = w_M^-(2 (32 a + b)) = x^-2
+    // fold 1 (Nk = N / 2): level-1 positions a = al + v E and a + N / 4 = al + (v + 2) E;  mu^-1 = w_M^-(2 (32 a + b)) = x^-2.  Waves 0, 1 work; every
+    // wave stays to the last barrier (a barrier in a workgroup some of whose waves have returned is undefined by HIP's rules, whatever gfx950 does)
     const F m1 = f_mul(inv_x, inv_x);
-    const F c1 = f_mul(inv2, f_mul(m1, r1));
     F f2[VP_VO_SPT];
+    if (v < 2) {
+        const F c1 = f_mul(inv2, f_mul(m1, r1));
 #pragma unroll
-    for (int k = 0; k < VP_VO_SPT; ++k) {
-        const u32 i = ig * VP_VO_SPT + k;
-        const F g = x1[k][v][lane];
-        f2[k] = f_add(f_half(f_add(f1[k], g)), f_mul(c1, f_sub(f1[k], g)));
-        out2[((size_t) i * 32 + b) * N2 + a] = f2[k];
-        if (v == 1) x2[k][lane] = f2[k];
+        for (int k = 0; k < VP_VO_SPT; ++k) {
+            const u32 i = ig * VP_VO_SPT + k;
+            const F g = x1[k][v][lane];
+            f2[k] = f_add(f_half(f_add(f1[k], g)), f_mul(c1, f_sub(f1[k], g)));
+            out2[((size_t) i * 32 + b) * N2 + a] = f2[k];
+            if (v == 1) x2[k][lane] = f2[k];
+        }
     }
-    // fold 2 (Nk = N / 4): level-2 positions al and al + E;  mu^-1 = x^-4 at al.  Waves 0 and 1 only: a barrier of their own would need named barriers —
-    // wave 1 is done after its stores, wave 0 waits for the LDS writes with the workgroup barrier below, which waves 2 and 3 have left already
     __syncthreads();
-    if (v == 1) return;
-    const F c2 = f_mul(inv2, f_mul(f_mul(m1, m1), r2));
+    // fold 2 (Nk = N / 4): level-2 positions al and al + E;  mu^-1 = x^-4 at al.  Wave 0.
+    if (v == 0) {
+        const F c2 = f_mul(inv2, f_mul(f_mul(m1, m1), r2));
 #pragma unroll
-    for (int k = 0; k < VP_VO_SPT; ++k) {
-        const u32 i = ig * VP_VO_SPT + k;
-        const F g = x2[k][lane];
-        out3[((size_t) i * 32 + b) * E + al] = f_add(f_half(f_add(f2[k], g)), f_mul(c2, f_sub(f2[k], g)));
+        for (int k = 0; k < VP_VO_SPT; ++k) {
+            const u32 i = ig * VP_VO_SPT + k;
+            const F g = x2[k][lane];
+            out3[((size_t) i * 32 + b) * E + al] = f_add(f_half(f_add(f2[k], g)), f_mul(c2, f_sub(f2[k], g)));
+        }
     }
 }
 // The last fold leaves ONE value per coset (32 per slice); its 16 leaves pair coset b with coset b + 16.

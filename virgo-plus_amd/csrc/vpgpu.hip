@@ -13,6 +13,7 @@
 #include <mutex>
 #include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/vpgpu.h"
@@ -230,6 +231,9 @@ struct vp_ctx {
     unsigned char *h_ring = nullptr; size_t ring_cap = 0, ring_at = 0;      // pinned ring: results on their way out, small arrays on their way in
     size_t ring_live = 0, ring_call = 0;                                    // bytes behind ring_at that queued calls (ring_live) / the running entry point (ring_call) still use
     double phase_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};                         // device time of the last call of each kind (VP_PH_*)
+    std::string plan_cache_path;                                            // VP_PLAN_CACHE at vp_create: the plan tuner's choices, kept across processes (one line per plan shape)
+    bool pc_dry = false;                                                    // vp_warm: the transform helpers set up their tables and scratch and launch nothing
+    unsigned char *h_pub = nullptr; size_t h_pub_cap = 0;                   // vp_warm: pinned staging of vp_commit_public's vector (uploaded from here in chunks)
     u64 private_epoch = 0;                                                  // vp_commit_private calls queued on this context so far
 
     PcShard *pcs = nullptr;              // non-null while the commitment is sharded over ranks (vp_pc_set_shard, world > 1)
@@ -1031,6 +1035,7 @@ int vp_create_with_options(int device, const vp_options *user, vp_ctx **out) {
     vp_ctx *ctx = new vp_ctx();
     ctx->device = device;
     if (resolve_options(&ctx->opt, user, &ctx->opt_pinned) != VP_OK) { delete ctx; return VP_EINVAL; }       // a vp_options of another layout, or a driver this build lacks
+    if (const char *pcf = getenv("VP_PLAN_CACHE")) ctx->plan_cache_path = pcf;                                // (read here, with the other VP_* variables, and nowhere else)
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return VP_EHIP; }
     if (hipHostMalloc((void **) &ctx->h_pin, (4 + VP_MAX_TAB) * sizeof(F), hipHostMallocDefault) != hipSuccess) {
         delete ctx; return VP_EHIP;
@@ -1090,6 +1095,7 @@ void vp_destroy(vp_ctx *ctx) {
     if (ctx->h_stage) (void) hipHostFree(ctx->h_stage);
     if (ctx->h_io) (void) hipHostFree(ctx->h_io);
     if (ctx->h_ring) (void) hipHostFree(ctx->h_ring);
+    if (ctx->h_pub) (void) hipHostFree(ctx->h_pub);
     for (auto &p : ctx->pending) { (void) hipEventDestroy(p.a); (void) hipEventDestroy(p.b); }
     for (auto e : ctx->ev_spare) (void) hipEventDestroy(e);
     for (auto st : ctx->lane_streams) (void) hipStreamDestroy(st);

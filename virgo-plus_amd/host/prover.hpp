@@ -17,6 +17,7 @@ public:
     void start() { t0 = std::chrono::high_resolution_clock::now(); }
     void stop() { total += std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count(); }
     void clear() { total = 0; }
+    void add(double sec) { total += sec; }       // a span measured elsewhere (the GKR part of a protocol pass, in device time when its completion is deferred)
     double elapse_sec() const { return total; }
 private:
     std::chrono::high_resolution_clock::time_point t0;
@@ -78,6 +79,7 @@ public:
     double commitDeviceMs();
 
     double proveTime() const { return prove_timer.elapse_sec(); }
+    void addProveTime(double sec) { prove_timer.add(sec); }     // vph_prove_protocol_ex calls vp_prove_gkr itself: its GKR span belongs to Prove Time (src/verifier.cpp:177-184)
     // where Prove Time goes on the interactive path: phase inits | round messages | finalize calls | Vres (all inside prove_timer's spans,
     // except sumcheckLiuFinalize, which the reference leaves out of its timer as well)
     double initTime() const { return init_timer.elapse_sec(); }

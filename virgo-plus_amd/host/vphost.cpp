@@ -500,6 +500,7 @@ int vph_prove_protocol_ex(vph_session *s, uint8_t *transcript, uint64_t capacity
         s->fri_r = s->ptape_fri;
         if (fri_roots) memcpy(fri_roots, s->fri_roots.data(), s->fri_roots.size());
         if (final_pairs) memcpy(final_pairs, s->fri_final.data(), s->fri_final.size() * sizeof(F));
+        s->p->addProveTime(s_gkr);
         if (sec) { sec[0] = since(t0); sec[1] = s_priv; sec[2] = s_gkr; sec[3] = s_pub; sec[4] = s_fft; sec[5] = s_fri; }
         return 0;
     } catch (const std::exception &e) {
