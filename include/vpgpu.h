@@ -123,6 +123,7 @@ int vp_plan_tuning_set(vp_ctx *, const int32_t v[6]);
  * constants and a pinned staging area for vp_commit_public's vector (which is then uploaded in pieces at the bus's speed) exist when vp_commit_private starts.
  * Optional: every call still sets up what it finds missing.  VP_EINVAL before vp_evaluate.                                                              */
 #define VP_WARM_COMMITMENT 1u
+#define VP_WARM_FFT_GKR 2u          /* the ~20 device arrays of vp_fft_gkr at lg = input bit length - 6 (the size lib/virgo's verifier runs it at) */
 int vp_warm(vp_ctx *, uint32_t what);
 void vp_destroy(vp_ctx *);
 const char *vp_last_error(const vp_ctx *);     /* static/ctx-owned string, never NULL */

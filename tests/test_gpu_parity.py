@@ -2038,7 +2038,7 @@ def test_vp_warm_changes_no_byte_and_plan_cache_file_round_trips(vp, golden, pws
     vp_commit_public from the caller's (pageable) vector through the pinned staging give the reference's bytes.  VP_PLAN_CACHE: the first session writes the
     tuner's choice to the file, a second context (plan table of the process cleared by using another circuit size is not needed: the line is there) reads it."""
     g = golden["sha256_x64"]
-    gold = open(os.path.join(GOLDEN, g["transcript"]), "rb").read()
+    gold = open(os.path.join(ROOT, "tests", "golden", g["transcript"]), "rb").read()
     cache = tmp_path / "plan_cache.txt"
     monkeypatch.setenv("VP_PLAN_CACHE", str(cache))
     c = vp.Circuit.from_pws(pws_path, 64, seed=1)

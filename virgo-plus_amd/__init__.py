@@ -844,9 +844,9 @@ class Session:
         return out.raw[:32], out.raw[32:48], out.raw[48:], self.commit_device_ms()
 
     def warm(self):
-        """vp_warm(VP_WARM_COMMITMENT): the commitment's tables, buffers and pinned staging exist before the first prover call (include/vpgpu.h)."""
+        """vp_warm(VP_WARM_COMMITMENT | VP_WARM_FFT_GKR): the commitment's tables, buffers and pinned staging (and fft_gkr's arrays) exist before the first prover call (include/vpgpu.h)."""
         ctx = lib_host().vph_session_ctx(self.h)
-        if lib_gpu().vp_warm(ctx, 1):
+        if lib_gpu().vp_warm(ctx, 3):
             raise RuntimeError("vp_warm failed: " + (lib_gpu().vp_last_error(ctx) or b"").decode())
 
     def draw_protocol_tape(self):

@@ -617,14 +617,15 @@ int ring_alloc(vp_ctx *ctx, size_t bytes, void **out) {
     }
     bytes = (bytes + 63) & ~(size_t) 63;
     if (bytes > ctx->ring_cap / 8) { ctx->err = "internal: staging request too large"; return VP_ELIMIT; }
-    const size_t skip = ctx->ring_at + bytes > ctx->ring_cap ? ctx->ring_cap - ctx->ring_at : 0;       // the tail that a wrap leaves unused
+    const bool wrap = ctx->ring_at + bytes > ctx->ring_cap;
+    const size_t skip = wrap ? ctx->ring_cap - ctx->ring_at : 0;                                       // the tail that a wrap leaves unused (possibly none)
     if (ctx->ring_live + skip + bytes > ctx->ring_cap) {
         VPCHK(flush_pending(ctx, (size_t) -1));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         ctx->ring_live = ctx->ring_call;
         if (ctx->ring_live + skip + bytes > ctx->ring_cap) { ctx->err = "staging ring exhausted by one call"; return VP_ELIMIT; }
     }
-    if (skip) ctx->ring_at = 0;
+    if (wrap) ctx->ring_at = 0;
     *out = ctx->h_ring + ctx->ring_at;
     ctx->ring_at += bytes;
     ctx->ring_live += skip + bytes; ctx->ring_call += skip + bytes;
