@@ -153,6 +153,14 @@ def roofline_of(rows, tag, serial_ms, note=None):
            "traffic": traffic, "traffic_source": ("%s (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, per launch)" % src) if traffic else None,
            "hbm_GBps": d["GBps"], "hbm_peak_GBps": HBM_PEAK_GBPS, "hbm_frac": d["hbm_frac"], "measured_limiter": limiter,
            "how": "every launch of the plan bracketed with HIP events in a single-stream replay of the same proof (vp_set_profiling / vp_get_launch_stats)" + (("; " + note) if note else "")}
+    kr, ksrc = pmc_kernel(tag, d["kernel"])
+    if kr and kr.get("SQ_INSTS_VALU_per_launch") and d["avg_launch_us"]:
+        # the same launches against the guide's VALU issue floor (2 cycles per wave64 instruction, 1024 SIMDs, 2.4 GHz): instructions counted by the PMC pass of the
+        # batched passes alone (the same launches per proof as here), time from this run's HIP events
+        floor_us = kr["SQ_INSTS_VALU_per_launch"] / 1024.0 * 2.0 / 2.4e9 * 1e6
+        out["valu_issue_floor"] = {"frac": floor_us / d["avg_launch_us"], "floor_us_per_launch": floor_us, "valu_wave_instructions_per_launch": kr["SQ_INSTS_VALU_per_launch"],
+                                   "wait_share_of_wave_cycles": (kr.get("SQ_WAIT_ANY_per_launch", 0.0) / kr["SQ_WAVE_CYCLES_per_launch"]) if kr.get("SQ_WAVE_CYCLES_per_launch") else None,
+                                   "source": ksrc}
     if fold and d["work_units"]:
         fmul = FMUL_PER_PAIR_STEP * d["work_units"] / (d["total_us"] * 1e-6)
         out.update({"bound": "valu", "achieved": fmul, "peak": FMUL_PEAK_PER_S, "unit": "F_p^2 multiply-equivalents/s", "frac": fmul / FMUL_PEAK_PER_S,
@@ -1187,10 +1195,11 @@ def first_proof_child(blocks):
     sess.draw_protocol_tape()
     t = time.perf_counter(); sess.warm(); warm = time.perf_counter() - t
     t = time.perf_counter(); tr, _ = sess.prove_gkr(); first = time.perf_counter() - t
-    t = time.perf_counter(); sess.prove_protocol(); first_pass = time.perf_counter() - t
-    t = time.perf_counter(); sess.prove_protocol(); second_pass = time.perf_counter() - t
+    t = time.perf_counter(); _, _, _, sec1 = sess.prove_protocol(); first_pass = time.perf_counter() - t
+    t = time.perf_counter(); _, _, _, sec2 = sess.prove_protocol(); second_pass = time.perf_counter() - t
     import hashlib
     print(json.dumps({"gkr_first_call_with_plan_cache": first, "vp_warm_commitment_sec": warm, "first_complete_pass_after_vp_warm": first_pass, "second_complete_pass": second_pass,
+                      "first_pass_by_call": sec1, "second_pass_by_call": sec2,
                       "plan_cache": os.environ.get("VP_PLAN_CACHE"), "transcript_sha256_16": hashlib.sha256(tr).hexdigest()[:16]}), flush=True)
     sess.close(); circ.close()
 
@@ -1286,6 +1295,26 @@ def compact_line(d, detail_file=None):
         optional.append(("prover_sec", ps))
         optional.append(("prover_sec_device", d.get("prover_sec_device")))
     optional.append(("host_verifier_accepts", d.get("host_verifier_accepts", ((d.get("verifier") or {}).get("complete_protocol") or {}).get("accepted"))))
+    x64 = d.get("x64_gkr")
+    if isinstance(x64, dict):
+        r64 = x64.get("roofline") or {}
+        i64 = x64.get("interactive_path") or {}
+        optional.append(("x64_gkr", {"workload": "configs[1]: SHA-256 x64, GKR only", "value": x64.get("value"), "ms_per_step": x64.get("ms_per_step"),
+                                     "prover_sec_device": x64.get("prover_sec_device"), "steps": x64.get("steps"), "bit_exact": x64.get("bit_exact_vs_reference_golden"),
+                                     "roofline_kernel": r64.get("kernel"), "roofline_frac": r64.get("frac"), "roofline_hbm_frac": r64.get("hbm_frac"),
+                                     "roofline_traffic": r64.get("traffic"), "traffic_source": (str(r64.get("traffic_source")).split(" ")[0] if r64.get("traffic_source") else None),
+                                     "interactive_prover_sec": i64.get("prover_sec"), "first_proof_sec": x64.get("first_proof_sec"),
+                                     "cpu_reference_prover_sec": (x64.get("cpu_baseline") or {}).get("prover_sec"),
+                                     "two_in_flight_ms_per_proof": (x64.get("two_in_flight") or {}).get("ms_per_proof")}))
+    rz = d.get("randomize_16_20")
+    if isinstance(rz, dict):
+        rr = rz.get("roofline") or {}
+        optional.append(("randomize_16_20", {"workload": "configs[4]: randomize(16,20), 2^24 gates, GKR only", "value": rz.get("value"), "ms_per_step": rz.get("ms_per_step"),
+                                             "prover_sec_device": rz.get("prover_sec_device"), "steps": rz.get("steps"), "bit_exact": rz.get("bit_exact_vs_reference_golden"),
+                                             "roofline_kernel": rr.get("kernel"), "roofline_frac": rr.get("frac"), "hbm_frac": rr.get("hbm_frac"),
+                                             "roofline_traffic": rr.get("traffic"), "roofline_algorithmic_bytes_per_launch": rr.get("algorithmic_bytes_per_launch"),
+                                             "traffic_source": (str(rr.get("traffic_source")).split(" ")[0] if rr.get("traffic_source") else None),
+                                             "interactive_prover_sec": (rz.get("interactive_path") or {}).get("prover_sec")}))
     fp = d.get("first_proof_sec")
     if isinstance(fp, dict):
         fr = fp.get("fresh_process_with_plan_cache_file") or {}
@@ -1303,30 +1332,13 @@ def compact_line(d, detail_file=None):
     for name in ("roofline_gkr_dominant", "roofline_ntt"):
         r = d.get(name)
         if isinstance(r, dict):
-            optional.append((name, pick(r, ("kernel", "bound", "frac", "hbm_frac", "avg_launch_us", "kernel_time_share", "time_share", "total_us"))))
+            o_ = pick(r, ("kernel", "bound", "frac", "hbm_frac", "avg_launch_us", "kernel_time_share", "time_share", "total_us"))
+            if isinstance(r.get("valu_issue_floor"), dict):
+                o_["valu_floor_frac"] = r["valu_issue_floor"].get("frac"); o_["wait_share"] = r["valu_issue_floor"].get("wait_share_of_wave_cycles")
+            optional.append((name, o_))
     ks = d.get("kernels")
     if isinstance(ks, list):
         optional.append(("kernel_time_share", {k["kernel"]: k["time_share"] for k in ks[:8]}))
-    x64 = d.get("x64_gkr")
-    if isinstance(x64, dict):
-        r64 = x64.get("roofline") or {}
-        i64 = x64.get("interactive_path") or {}
-        optional.append(("x64_gkr", {"workload": "BASELINE configs[1]: SHA-256 x64, GKR on GPU, PC off", "value": x64.get("value"), "ms_per_step": x64.get("ms_per_step"),
-                                     "prover_sec_device": x64.get("prover_sec_device"), "steps": x64.get("steps"), "bit_exact": x64.get("bit_exact_vs_reference_golden"),
-                                     "roofline_kernel": r64.get("kernel"), "roofline_frac": r64.get("frac"), "roofline_hbm_frac": r64.get("hbm_frac"),
-                                     "roofline_traffic": r64.get("traffic"), "traffic_source": (str(r64.get("traffic_source")).split(" ")[0] if r64.get("traffic_source") else None),
-                                     "interactive_prover_sec": i64.get("prover_sec"), "first_proof_sec": x64.get("first_proof_sec"),
-                                     "cpu_reference_prover_sec": (x64.get("cpu_baseline") or {}).get("prover_sec"),
-                                     "two_in_flight_ms_per_proof": (x64.get("two_in_flight") or {}).get("ms_per_proof")}))
-    rz = d.get("randomize_16_20")
-    if isinstance(rz, dict):
-        rr = rz.get("roofline") or {}
-        optional.append(("randomize_16_20", {"workload": "BASELINE configs[4]: randomize(16,20), 2^24 gates, GKR on GPU, PC off", "value": rz.get("value"), "ms_per_step": rz.get("ms_per_step"),
-                                             "prover_sec_device": rz.get("prover_sec_device"), "steps": rz.get("steps"), "bit_exact": rz.get("bit_exact_vs_reference_golden"),
-                                             "roofline_kernel": rr.get("kernel"), "roofline_frac": rr.get("frac"), "hbm_frac": rr.get("hbm_frac"),
-                                             "roofline_traffic": rr.get("traffic"), "roofline_algorithmic_bytes_per_launch": rr.get("algorithmic_bytes_per_launch"),
-                                             "traffic_source": (str(rr.get("traffic_source")).split(" ")[0] if rr.get("traffic_source") else None),
-                                             "interactive_prover_sec": (rz.get("interactive_path") or {}).get("prover_sec")}))
     cp = d.get("cpu_port_x1024_gkr")
     if isinstance(cp, dict):
         optional.append(("cpu_port_x1024_gkr", pick(cp, ("kind", "gkr_prove_sec", "gkr_field_ops_per_sec", "transcript_equals_gpu"))))
