@@ -101,9 +101,9 @@ def pmc_limiter(tag, kernel, avg_launch_us):
         return None
     insts, waitf = k["SQ_INSTS_VALU_per_launch"], k.get("SQ_WAIT_ANY_per_launch", 0.0) / k["SQ_WAVE_CYCLES_per_launch"]
     s = "%s: %.3g VALU wave-instructions per launch (SQ_INSTS_VALU) = %.3g per SIMD; SQ_WAIT_ANY / SQ_WAVE_CYCLES = %.2f" % (src, insts, insts / 1024, waitf)
-    if avg_launch_us:
-        cyc = avg_launch_us * 1e-6 * 2.4e9
-        s += "; at this run's %.0f us per launch one wave-instruction per %.1f cycles (2.4 GHz) per SIMD, against the guide's 2-cycle issue floor" % (avg_launch_us, cyc / (insts / 1024))
+    if k.get("single_stream_avg_launch_us"):
+        cyc = k["single_stream_avg_launch_us"] * 1e-6 * 2.4e9
+        s += "; at the profile's own %.0f us per launch (single stream) one wave-instruction per %.1f cycles (2.4 GHz) per SIMD, against the guide's 2-cycle issue floor" % (k["single_stream_avg_launch_us"], cyc / (insts / 1024))
     s += "; HBM traffic per launch %.3g B (counters) — the bytes moved are about the algorithmic bytes, the integer multiply-add of F_p^2 (16 v_mad_u64_u32 + Mersenne folds) sets the time" % k["hbm_bytes_per_launch"]
     return s
 
@@ -154,11 +154,12 @@ def roofline_of(rows, tag, serial_ms, note=None):
            "hbm_GBps": d["GBps"], "hbm_peak_GBps": HBM_PEAK_GBPS, "hbm_frac": d["hbm_frac"], "measured_limiter": limiter,
            "how": "every launch of the plan bracketed with HIP events in a single-stream replay of the same proof (vp_set_profiling / vp_get_launch_stats)" + (("; " + note) if note else "")}
     kr, ksrc = pmc_kernel(tag, d["kernel"])
-    if kr and kr.get("SQ_INSTS_VALU_per_launch") and d["avg_launch_us"]:
-        # the same launches against the guide's VALU issue floor (2 cycles per wave64 instruction, 1024 SIMDs, 2.4 GHz): instructions counted by the PMC pass of the
-        # batched passes alone (the same launches per proof as here), time from this run's HIP events
-        floor_us = kr["SQ_INSTS_VALU_per_launch"] / 1024.0 * 2.0 / 2.4e9 * 1e6
-        out["valu_issue_floor"] = {"frac": floor_us / d["avg_launch_us"], "floor_us_per_launch": floor_us, "valu_wave_instructions_per_launch": kr["SQ_INSTS_VALU_per_launch"],
+    if kr and kr.get("valu_issue_floor_frac"):
+        # the guide's VALU issue floor (2 cycles per wave64 instruction, 1024 SIMDs, 2.4 GHz) for this kernel's launch mix: instructions from the PMC pass and the
+        # duration from the single-stream kernel trace of the SAME profiled command (tools/pmc_summary.py --add-floor) — one plan on both sides, whatever plan
+        # this run's tuner picked
+        out["valu_issue_floor"] = {"frac": kr["valu_issue_floor_frac"], "valu_wave_instructions_per_launch": kr["SQ_INSTS_VALU_per_launch"],
+                                   "avg_launch_us_in_the_profile": kr.get("single_stream_avg_launch_us"),
                                    "wait_share_of_wave_cycles": (kr.get("SQ_WAIT_ANY_per_launch", 0.0) / kr["SQ_WAVE_CYCLES_per_launch"]) if kr.get("SQ_WAVE_CYCLES_per_launch") else None,
                                    "source": ksrc}
     if fold and d["work_units"]:

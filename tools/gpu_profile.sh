@@ -25,6 +25,7 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES 
 python3 "$R/tools/pmc_summary.py" "$O/pmc_summary.json" "$O/fetch" "$O/write" "$O/sq" --command "bench.py --steps 3 --warmup 2 --batched-only $*" > "$O/pmc_summary.txt"
 python3 "$R/tools/pmc_summary.py" --stats "$O/stats/stats_results.db" "$O/kernel_stats.csv"
 python3 "$R/tools/pmc_summary.py" --stats "$O/stats_serial/stats_results.db" "$O/kernel_stats_serial.csv"
+python3 "$R/tools/pmc_summary.py" --add-floor "$O/pmc_summary.json" "$O/kernel_stats_serial.csv"
 # only the summaries travel back (gpurun merges at most 64 MiB): the raw databases stay on the box
 rm -rf "$O/stats" "$O/stats_serial" "$O/fetch" "$O/write" "$O/sq"
 ls -la "$O"

@@ -58,13 +58,36 @@ def stats_name(n):
 
 
 def short(n):
-    m = re.search(r"(vp::)?k_\w+", n)
+    m = re.search(r"(vp::)?k_\w+(<[\w, ]+>)?", n)          # template arguments kept: k_ntt8_rows<true> and <false> are different kernels
     return m.group(0) if m else n[:48]
+
+
+def add_floor(summary_json, stats_csv):
+    """pmc_summary.py --add-floor SUMMARY.json KERNEL_STATS_SINGLE_STREAM.csv: per kernel, the average launch duration of the SAME command's kernel-trace run
+    with one stream (no overlap stretching the durations) and the VALU issue-floor fraction of that launch mix: SQ_INSTS_VALU per launch / 1024 SIMDs x 2 cycles
+    (MI355X_MICROARCH.md) / 2.4 GHz over that duration — both sides from the same plan, whatever plan a later bench run's tuner picks."""
+    d = json.load(open(summary_json))
+    dur = {}
+    for r in csv.DictReader(open(stats_csv)):
+        dur[short(r["Name"]).replace("vp::", "")] = (int(r["Calls"]), float(r["AverageNs"]))
+    for k in d["kernels"]:
+        name = k["kernel"].replace("vp::", "")
+        if name in dur and k.get("SQ_INSTS_VALU_per_launch"):
+            calls, avg_ns = dur[name]
+            k["single_stream_launches"] = calls
+            k["single_stream_avg_launch_us"] = avg_ns / 1e3
+            # totals over the run on both sides (the two profiled processes replay the same passes; where a switch of the tracing run changes how a proof's work is
+            # cut into launches — VP_GKR_SERIAL=1 skips the tuner: 3 fused fold launches per proof instead of 4 — the totals still cover the same work)
+            k["valu_issue_floor_frac"] = (k["launches"] * k["SQ_INSTS_VALU_per_launch"] / 1024.0 * 2.0 / 2.4e9) / (calls * avg_ns * 1e-9)
+    json.dump(d, open(summary_json, "w"), indent=1)
 
 
 def main():
     if sys.argv[1] == "--stats":          # pmc_summary.py --stats RESULTS.db OUT.csv
         kernel_stats_csv(sys.argv[2], sys.argv[3])
+        return
+    if sys.argv[1] == "--add-floor":
+        add_floor(sys.argv[2], sys.argv[3])
         return
     argv = list(sys.argv)
     command = None

@@ -11,6 +11,7 @@
 #include <functional>
 #include <map>
 #include <mutex>
+#include <set>
 #include <atomic>
 #include <string>
 #include <thread>
