@@ -1166,6 +1166,23 @@ def cpu_protocol_baseline(r, blocks_headline=1024):
             "host_cpu": cpu_model(), "host_cores_visible": os.cpu_count()}
 
 
+def reference_full_size_record():
+    """The REAL reference at the HEADLINE size on the host of a box of this pool, recorded once (tools/ref_x1024_on_box.sh -> profiles/…): 5.5 minutes and 64 GB, too long
+    for a leg of this script; it rides beside cpu_baseline (the x256 sample measured in THIS run) as a labelled record, never as `value`."""
+    import glob
+    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_reference_x1024_on_gpu_box_host.txt")), reverse=True)
+    if not fs:
+        return None
+    try:
+        txt = open(fs[0]).read()
+        g = float(re.search(r"^Prove Time ([0-9.]+)", txt, re.M).group(1)); pc = float(re.search(r"Polynomial commitment: prove time ([0-9.]+)", txt).group(1))
+        ok = "TRANSCRIPT_EQUAL" in txt and "FRI_EQUAL" in txt
+        return {"gkr_prove_sec": g, "pc_prove_sec": pc, "prover_sec": g + pc, "field_ops_per_sec": 8299342697 / (g + pc), "transcript_and_fri_equal_golden": ok,
+                "source": "profiles/" + os.path.basename(fs[0]), "note": "recorded run on a box of this pool (same CPU model), not measured in this run"}
+    except Exception:
+        return None
+
+
 def cpu_port_x1024(pws, tr_gpu):
     """The oracle port's GKR proof of the FULL headline circuit on one host core (the real reference needs 63 GB and 13 minutes for it:
     tests/golden/golden.json holds that run); compared byte for byte with the GPU's GKR slice."""
@@ -1278,6 +1295,9 @@ def compact_line(d, detail_file=None):
     cb = d.get("cpu_baseline")
     line["cpu_baseline"] = pick(cb, ("value", "unit", "cores", "kind", "sample", "prover_sec", "gkr_prove_sec", "pc_prove_sec", "host_cpu",
                                      "reference_over_port_ratio_x64_same_box")) if isinstance(cb, dict) else None
+    if isinstance(cb, dict) and isinstance(cb.get("reference_x1024_recorded_on_a_box_of_this_pool"), dict):
+        fr = cb["reference_x1024_recorded_on_a_box_of_this_pool"]
+        line["cpu_baseline"]["x1024_recorded"] = {"prover_sec": fr.get("prover_sec"), "field_ops_per_sec": fr.get("field_ops_per_sec"), "source": fr.get("source")}
     line["rccl_ranks"] = d.get("rccl_ranks")
     if d.get("bench_wall_sec") is not None:
         line["bench_wall_sec"] = d["bench_wall_sec"]
@@ -1529,6 +1549,8 @@ def main():
             r64 = reference_collect(ref_64)
             detail["cpu_baseline"] = cpu_protocol_baseline(reference_collect(ref_big))
             cb = detail.get("cpu_baseline")
+            if isinstance(cb, dict):
+                cb["reference_x1024_recorded_on_a_box_of_this_pool"] = reference_full_size_record()
             x64 = detail.get("x64_gkr")
             if isinstance(r64, dict) and isinstance(x64, dict):      # the reference's x64 GKR proof (PC off), same box
                 x64["cpu_baseline"] = {"kind": "reference", "cores": 1, "prover_sec": r64["gkr_prove_sec"], "value": r64["field_ops"] / r64["gkr_prove_sec"], "unit": "field-ops/s"}
