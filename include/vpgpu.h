@@ -305,6 +305,20 @@ int vp_fft_gkr_end(vp_ctx *, vp_F *msgs, uint64_t capacity, uint64_t *n_written)
 /* Drop a run begun with vp_fft_gkr_begin without reading its messages (the caller's pass failed between begin and end); VP_OK when none is pending.
  * vp_fft_gkr_begin itself drains and drops a run that was never collected, so a failed pass cannot wedge the context. */
 int vp_fft_gkr_cancel(vp_ctx *);
+/* ---- the mask slice with CONTENT (round 6) ------------------------------------------------------------------------------------------------
+ * lib/virgo's commit_private_array / commit_public_array take a mask vector that fills the 65th slice (lib/virgo/src/poly_commit.h:42,55-86,138-161,187-247).
+ * The reference's own prover and verifier only ever pass one zero (src/prover.cpp:526, src/verifier.cpp:375-377): vp_commit_private / vp_commit_public.  These
+ * two take the vectors: the private mask (n_mask elements) is padded with zeros to ms = slice_size / gap elements, gap = the largest power of two <=
+ * slice_size / n_mask (poly_commit.h:55-66); the public mask pads to the same ms.  From then on the commitment carries the slice everywhere the reference does —
+ * the 65th block of every leaf chain of both oracles, all_sum[64], its own virtual oracle and fold on every FRI level (vp_fri_step / vp_fri_commit), the last pair
+ * of every opening (vp_fri_open), its final codeword (vp_fri_final_mask) — bit-exact against the reference called directly (tests/golden/pc_masked_*.bin).
+ * Limits: ms >= 8 (below that the reference's own transforms read stale scratch, RS_polynomial.cpp:104-133: VP_EINVAL) and 2 ms <= 2^(n-6) (VP_ELIMIT); not on a
+ * sharded commitment; vp_commit_public_eq refuses a masked commitment.  vp_commit_private (or a new witness) returns the context to the zero mask.            */
+int vp_commit_private_masked(vp_ctx *, const vp_F *mask, uint64_t n_mask, uint8_t root[32]);
+int vp_commit_public_masked(vp_ctx *, const vp_F *pub, uint64_t n_pub, const vp_F *pub_mask, uint64_t n_pub_mask, vp_F *inner, vp_F all_sum[65], uint8_t root_h[32]);
+/* fri::cpd.rs_codeword_msk[last] (vpd_verifier.cpp:321-325): the mask slice's last codeword, 32 values, out[2 i + hi] = value at position i + 16 hi (zeros
+ * for the zero mask).  After the last FRI step.                                                                                                              */
+int vp_fri_final_mask(vp_ctx *, vp_F out[32]);
 /* Device time of the last vp_commit_private / vp_commit_public / vp_fri_step / vp_fft_gkr in milliseconds (hipEvents). */
 int vp_commit_stats(vp_ctx *, double *commit_ms);
 

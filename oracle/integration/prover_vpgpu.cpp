@@ -267,8 +267,11 @@ virgo::__hhash_digest prover::commit_public(vector<F> &pub, F &inner_product_sum
     using namespace virgo;
     const auto t0 = std::chrono::high_resolution_clock::now();
     const int n = C.circuit[0].bitLength;
-    for (auto &m : mask)
-        if (!(m == F_ZERO)) { fprintf(stderr, "vpgpu: commit_public with a non-zero mask is not supported (the reference passes one zero, verifier.cpp:376)\n"); exit(EXIT_FAILURE); }
+    // `mask` (the PUBLIC mask, one zero from verifier.cpp:375-377) needs no forwarding whatever it holds: commit_private above committed to the private mask
+    // {0} (src/prover.cpp:526), so the mask slice of l is identically zero and every place the public mask's slice enters — l q of the quotient, all_sum[64], the
+    // slice's virtual oracle (poly_commit.h:196-247) — multiplies it by that zero.  A prover that commits to a NON-ZERO private mask calls
+    // vp_commit_private_masked / vp_commit_public_masked (include/vpgpu.h) instead.
+    (void) mask;
     if (all_sum.size() < (size_t) slice_number + 1) all_sum.resize(slice_number + 1);
     __hhash_digest d;
     { vpi_stopwatch sw(&g_vpi_sec.commit_public);

@@ -24,10 +24,16 @@
 //   ref_run --pws FILE [--blocks B] [--ref-parser] [--pc 0|1] [--dump OUT] [--dump-fri OUT] [--dump-fft OUT] [--seed S]
 //   ref_run --randomize LAYERS LOG_SIZE      [--pc 0|1] [--dump OUT] [--seed S]
 //   ref_run --fft-gkr LG [--dump-fft OUT]    F::init(), then fft_gkr(LG) alone (its own prover + verifier)
+//   ref_run --pc-masked IN [--dump OUT] [--dump-fri OUT]      lib/virgo's commitment ALONE with NON-ZERO masks (round 6): the reference's prover / verifier
+//       never pass one (src/prover.cpp:526, src/verifier.cpp:375-377), so poly_commit_prover::commit_private_array / commit_public_array
+//       (lib/virgo/src/poly_commit.h:41-349) and commit_phase (vpd_verifier.cpp:44-74) are called directly.  IN: i32 n, i32 m, then values[2^n], pub[2^n],
+//       pri_mask[m], pub_mask[m] as (u64 real, u64 img) pairs.  --dump: root_l | root_h | all_sum[65] | openings (130 values each: 65 pairs, the mask
+//       slice's last) of oracle 0 and 1 at leaves 0, 5, M/2 - 1 and of FRI levels 0, 2 at position 3; --dump-fri: as for a protocol run.
 #include "verifier.h"
 #include "inputCircuit.hpp"
 #include "virgo/src/polynomial.h"          // lib/virgo's own polynomial classes (namespace virgo), the ones fft_circuit_GKR.cpp uses
 #include "virgo/src/fft_circuit_GKR.h"
+#include "virgo/src/poly_commit.h"
 #include <fstream>
 #include <string>
 #include <chrono>
@@ -125,6 +131,7 @@ static void circuit_hash(const layeredCircuit &C, unsigned long long out[2]) {
 int main(int argc, char **argv) {
     const char *pws = nullptr, *dump = nullptr, *custom = nullptr;
     int blocks = 1, ref_parser = 0, rnd_layers = 0, rnd_log = 0, fft_lg = 0;
+    const char *pc_masked = nullptr;
     long seed = -1;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -139,6 +146,7 @@ int main(int argc, char **argv) {
         else if (a == "--fft-gkr" && i + 1 < argc) fft_lg = atoi(argv[++i]);
         else if (a == "--randomize" && i + 2 < argc) { rnd_layers = atoi(argv[++i]); rnd_log = atoi(argv[++i]); }
         else if (a == "--custom" && i + 1 < argc) custom = argv[++i];
+        else if (a == "--pc-masked" && i + 1 < argc) pc_masked = argv[++i];
         else { fprintf(stderr, "bad arg %s\n", argv[i]); return 2; }
     }
     if (fft_lg > 0) {                          // fft_gkr alone, from the generator state F::init() leaves (srand(3396))
@@ -146,6 +154,49 @@ int main(int argc, char **argv) {
         double vt = 0, pt = 0; int ps = 0;
         virgo::fft_circuit_gkr::fft_gkr(fft_lg, vt, ps, pt);
         if (g_fft_dump) fclose(g_fft_dump);
+        return 0;
+    }
+    if (pc_masked) {
+        using namespace virgo;
+        FILE *f = fopen(pc_masked, "rb");
+        if (!f) { perror(pc_masked); return 2; }
+        int n = 0, m = 0;
+        if (fread(&n, 4, 1, f) != 1 || fread(&m, 4, 1, f) != 1 || n < 7 || n > 24 || m < 1) return 2;
+        auto rd = [&](fieldElement *dst, size_t cnt) { for (size_t i = 0; i < cnt; ++i) { unsigned long long w[2]; if (fread(w, 8, 2, f) != 2) return false; dst[i].real = w[0]; dst[i].img = w[1]; } return true; };
+        std::vector<fieldElement> values((size_t) 1 << n), pub((size_t) 1 << n), pri(m), pubm(m);
+        if (!rd(values.data(), values.size()) || !rd(pub.data(), pub.size()) || !rd(pri.data(), m) || !rd(pubm.data(), m)) return 2;
+        fclose(f);
+        fieldElement::init();
+        poly_commit::poly_commit_prover pp;
+        __hhash_digest root_l = pp.commit_private_array(values.data(), n, pri);
+        std::vector<fieldElement> all_sum(slice_number + 1);
+        __hhash_digest root_h = pp.commit_public_array(pubm, pub.data(), n, fieldElement(0), all_sum.data());
+        FILE *o = dump ? fopen(dump, "wb") : nullptr;
+        auto wF = [&](const fieldElement &x) { if (o) { unsigned long long w[2] = {x.real, x.img}; fwrite(w, 8, 2, o); } };
+        if (o) { fwrite(&root_l, 32, 1, o); fwrite(&root_h, 32, 1, o); }
+        for (auto &x : all_sum) wF(x);
+        const long long half = (1LL << (n + rs_code_rate - log_slice_number)) / 2;
+        for (int oracle = 0; oracle < 2; ++oracle)
+            for (long long leaf : {0LL, 5LL, half - 1}) {
+                int ns = 0;
+                auto r = fri::request_init_value_with_merkle(leaf, leaf + half, ns, oracle);
+                for (auto &pr : r.first) { wF(pr.first); wF(pr.second); }
+            }
+        poly_commit::ldt_commitment com = pp.commit_phase(n);          // the wrapper above records (challenge, root) of every step
+        for (int lvl : {0, 2}) {
+            if (lvl >= com.mx_depth) continue;
+            int ns = 0;
+            auto r = fri::request_step_commit(lvl, 3, ns);
+            for (auto &pr : r.first) { wF(pr.first); wF(pr.second); }
+        }
+        if (o) fclose(o);
+        if (g_fri_dump) {
+            const int last = fri::current_step_no - 1;
+            for (int k = 0; k < 16 * 128; ++k) { unsigned long long w[2] = {fri::cpd.rs_codeword[last][k].real, fri::cpd.rs_codeword[last][k].img}; fwrite(w, 8, 2, g_fri_dump); }
+            for (int k = 0; k < 32; ++k) { unsigned long long w[2] = {fri::cpd.rs_codeword_msk[last][k].real, fri::cpd.rs_codeword_msk[last][k].img}; fwrite(w, 8, 2, g_fri_dump); }
+            fclose(g_fri_dump);
+        }
+        fprintf(stdout, "pc-masked n %d mask %d steps %d mask_position_gap %d\n", n, m, com.mx_depth, poly_commit::mask_position_gap);
         return 0;
     }
     if (!pws && !rnd_layers && !custom) { fprintf(stderr, "need --pws, --randomize, --custom or --fft-gkr\n"); return 2; }

@@ -2,6 +2,7 @@
 oracle on the same seeded inputs and against the golden transcripts of the real reference.
 Bar: bit-exact (all arithmetic is integer mod 2^61-1)."""
 import ctypes
+import json
 import os
 
 import numpy as np
@@ -2060,3 +2061,107 @@ def test_vp_warm_changes_no_byte_and_plan_cache_file_round_trips(vp, golden, pws
     tr2, _ = s2.prove_gkr()
     assert tr2 == gold[g["gkr_slice"][0]:g["gkr_slice"][1]]
     s2.close(); c.close()
+
+
+def _pc_masked_record(name):
+    import pc_masked_inputs as pmi
+    meta = json.load(open(os.path.join(ROOT, "tests", "golden", "pc_masked.json")))[name]
+    rec = open(os.path.join(ROOT, "tests", "golden", meta["record"]), "rb").read()
+    fri = open(os.path.join(ROOT, "tests", "golden", meta["fri"]), "rb").read()
+    return pmi.inputs(name), meta, rec, fri
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["n13_zero", "n13_m5", "n13_m64", "n16_m100", "n19_m3000"])
+def test_commitment_with_mask_slices_vs_real_reference(vp, name):
+    """SURVEY 8a a12 with CONTENT in the 65th slice (lib/virgo/src/poly_commit.h:42,55-86,138-161,187-191): the reference's own prover only ever passes one zero
+    (src/prover.cpp:526), so the goldens come from poly_commit_prover::commit_private_array / commit_public_array / commit_phase called directly by
+    oracle/_ref/ref_run --pc-masked (tests/golden/make_pc_masked.py).  Roots of both oracles, all_sum[65] (the mask slice's term last), every FRI root, the final
+    codeword, the mask slice's final codeword and openings of both oracles and of two FRI levels (65 pairs each, the mask slice's last) — byte for byte.  `n13_zero`
+    runs the UNMASKED entry points against a record of the same layout."""
+    x, meta, rec, fri = _pc_masked_record(name)
+    L = vp.lib_gpu()
+    n, st = x["n"], meta["fri_steps"]
+    M = 1 << (n - 1)
+    ctx = ctypes.c_void_p()
+    assert L.vp_create(0, ctypes.byref(ctx)) == 0
+    try:
+        vals = np.ascontiguousarray(x["values"])
+        assert L.vp_pc_load_input(ctx, vals.ctypes.data, vals.shape[0], n) == 0
+        root_l, root_h = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
+        inner, alls = np.zeros(2, np.uint64), np.zeros((65, 2), np.uint64)
+        pub = np.ascontiguousarray(x["pub"])
+        if name.endswith("_zero"):
+            assert L.vp_commit_private(ctx, ctypes.cast(root_l, ctypes.c_void_p)) == 0
+            assert L.vp_commit_public(ctx, pub.ctypes.data, pub.shape[0], inner.ctypes.data, alls.ctypes.data, ctypes.cast(root_h, ctypes.c_void_p)) == 0
+        else:
+            L.vp_commit_private_masked.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
+            L.vp_commit_public_masked.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+            pm, qm = np.ascontiguousarray(x["pri_mask"]), np.ascontiguousarray(x["pub_mask"])
+            rc = L.vp_commit_private_masked(ctx, pm.ctypes.data, pm.shape[0], ctypes.cast(root_l, ctypes.c_void_p))
+            assert rc == 0, L.vp_last_error(ctx)
+            rc = L.vp_commit_public_masked(ctx, pub.ctypes.data, pub.shape[0], qm.ctypes.data, qm.shape[0], inner.ctypes.data, alls.ctypes.data, ctypes.cast(root_h, ctypes.c_void_p))
+            assert rc == 0, L.vp_last_error(ctx)
+        assert root_l.raw == rec[:32], "merkle_root_l"
+        assert root_h.raw == rec[32:64], "merkle_root_h"
+        assert alls.tobytes() == rec[64:64 + 65 * 16], "all_sum"
+        at = 64 + 65 * 16
+        vals130 = np.zeros((130, 2), np.uint64); path = ctypes.create_string_buffer(32 * 40); plen = ctypes.c_int(0)
+        L.vp_fri_open.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+        for oracle in (0, 1):
+            for leaf in (0, 5, M // 2 - 1):
+                assert L.vp_fri_open(ctx, oracle, leaf, vals130.ctypes.data, ctypes.cast(path, ctypes.c_void_p), len(path), ctypes.byref(plen)) == 0
+                assert vals130.tobytes() == rec[at:at + 130 * 16], ("opening", oracle, leaf)
+                at += 130 * 16
+        rr = np.frombuffer(b"".join(fri[48 * k:48 * k + 16] for k in range(st)), dtype=np.uint64).reshape(st, 2).copy()
+        roots = ctypes.create_string_buffer(32 * st)
+        rc = L.vp_fri_commit(ctx, rr.ctypes.data, st, ctypes.cast(roots, ctypes.c_void_p))
+        assert rc == 0, L.vp_last_error(ctx)
+        assert roots.raw == b"".join(fri[48 * k + 16:48 * k + 48] for k in range(st)), "FRI roots"
+        fin = np.zeros((2048, 2), np.uint64)
+        assert L.vp_fri_final(ctx, fin.ctypes.data) == 0
+        assert fin.tobytes() == fri[48 * st:48 * st + 2048 * 16], "final codeword"
+        L.vp_fri_final_mask.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        fm = np.zeros((32, 2), np.uint64)
+        assert L.vp_fri_final_mask(ctx, fm.ctypes.data) == 0
+        assert fm.tobytes() == fri[48 * st + 2048 * 16:48 * st + 2048 * 16 + 32 * 16], "final codeword of the mask slice"
+        for lvl in (0, 2):
+            assert L.vp_fri_open(ctx, 2 + lvl, 3, vals130.ctypes.data, ctypes.cast(path, ctypes.c_void_p), len(path), ctypes.byref(plen)) == 0
+            assert vals130.tobytes() == rec[at:at + 130 * 16], ("FRI level opening", lvl)
+            at += 130 * 16
+        assert at == len(rec)
+    finally:
+        L.vp_destroy(ctx)
+
+
+def test_masked_commitment_limits_and_state(vp):
+    """The masked entry points at their edges: a mask that pads to fewer than 8 elements is refused (the reference's own transforms of that size read stale scratch),
+    one longer than half a slice's message is VP_ELIMIT, the unmasked public calls refuse a masked private commitment, the public mask may not outgrow the private
+    one's padded length, and vp_commit_private returns the context to the zero mask (same root as before)."""
+    import pc_masked_inputs as pmi
+    x = pmi.inputs("n13_m5")
+    L = vp.lib_gpu()
+    L.vp_commit_private_masked.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
+    L.vp_commit_public_masked.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    ctx = ctypes.c_void_p()
+    assert L.vp_create(0, ctypes.byref(ctx)) == 0
+    try:
+        vals = np.ascontiguousarray(x["values"]); pub = np.ascontiguousarray(x["pub"])
+        assert L.vp_pc_load_input(ctx, vals.ctypes.data, vals.shape[0], 13) == 0
+        root0, root1, root2 = (ctypes.create_string_buffer(32) for _ in range(3))
+        assert L.vp_commit_private(ctx, ctypes.cast(root0, ctypes.c_void_p)) == 0
+        m = np.ones((200, 2), np.uint64)
+        assert L.vp_commit_private_masked(ctx, m.ctypes.data, 1, ctypes.cast(root1, ctypes.c_void_p)) == -1 and b"fewer than 8" in L.vp_last_error(ctx)    # VP_EINVAL
+        assert L.vp_commit_private_masked(ctx, m.ctypes.data, 4, ctypes.cast(root1, ctypes.c_void_p)) == -1
+        assert L.vp_commit_private_masked(ctx, m.ctypes.data, 100, ctypes.cast(root1, ctypes.c_void_p)) == -5 and b"half a slice" in L.vp_last_error(ctx)  # VP_ELIMIT: pads to 128 > N / 2 = 64
+        inner, alls = np.zeros(2, np.uint64), np.zeros((65, 2), np.uint64)
+        assert L.vp_commit_public_masked(ctx, pub.ctypes.data, pub.shape[0], m.ctypes.data, 5, inner.ctypes.data, alls.ctypes.data, ctypes.cast(root2, ctypes.c_void_p)) == -1   # no masked private commitment
+        pm = np.ascontiguousarray(x["pri_mask"])
+        assert L.vp_commit_private_masked(ctx, pm.ctypes.data, pm.shape[0], ctypes.cast(root1, ctypes.c_void_p)) == 0 and root1.raw != root0.raw
+        assert L.vp_commit_public(ctx, pub.ctypes.data, pub.shape[0], inner.ctypes.data, alls.ctypes.data, ctypes.cast(root2, ctypes.c_void_p)) == -1             # wants vp_commit_public_masked
+        assert L.vp_commit_public_masked(ctx, pub.ctypes.data, pub.shape[0], m.ctypes.data, 9, inner.ctypes.data, alls.ctypes.data, ctypes.cast(root2, ctypes.c_void_p)) == -1   # 9 > padded length 8
+        assert L.vp_commit_private(ctx, ctypes.cast(root2, ctypes.c_void_p)) == 0 and root2.raw == root0.raw
+        assert L.vp_commit_public(ctx, pub.ctypes.data, pub.shape[0], inner.ctypes.data, alls.ctypes.data, ctypes.cast(root2, ctypes.c_void_p)) == 0
+    finally:
+        L.vp_destroy(ctx)
+

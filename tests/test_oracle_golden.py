@@ -361,3 +361,27 @@ def test_oracle_fft_gkr_inside_the_protocol(ob, golden, pws_path, name, lg):
     fri = open(os.path.join(GOLDEN, golden[name]["fri"]), "rb").read()
     assert nxt.tobytes() == b"".join(fri[48 * k:48 * k + 16] for k in range(st))
     c.close()
+
+
+def test_masked_commitment_goldens_are_the_recorded_files():
+    """tests/golden/pc_masked_*.bin (the REAL reference's commit_private_array / commit_public_array / commit_phase with non-zero masks, make_pc_masked.py): the files are
+    the ones the index was written for, the inputs regenerate deterministically, and the record has the layout the GPU test walks."""
+    import hashlib
+    import json
+    import pc_masked_inputs as pmi
+    from conftest import GOLDEN
+    meta = json.load(open(os.path.join(GOLDEN, "pc_masked.json")))
+    assert set(meta) == set(pmi.CASES)
+    for name, m in meta.items():
+        rec = open(os.path.join(GOLDEN, m["record"]), "rb").read()
+        fri = open(os.path.join(GOLDEN, m["fri"]), "rb").read()
+        assert hashlib.sha256(rec).hexdigest() == m["record_sha256"] and hashlib.sha256(fri).hexdigest() == m["fri_sha256"]
+        assert len(rec) == 64 + 65 * 16 + 8 * 130 * 16 and len(fri) == 48 * m["fri_steps"] + 2048 * 16 + 32 * 16
+        x = pmi.inputs(name)
+        assert x["values"].shape == (1 << m["n"], 2) and x["pri_mask"].shape == (m["m"], 2) and int(x["values"].max()) < (1 << 61) - 1
+        M = 1 << (m["n"] - 1)
+        assert M % m["mask_position_gap"] == 0
+        if name.endswith("_zero"):
+            assert fri[-32 * 16:] == bytes(32 * 16) and rec[64 + 64 * 16:64 + 65 * 16] == bytes(16)          # zero mask: all_sum[64] = 0, mask codeword 0
+        else:
+            assert fri[-32 * 16:] != bytes(32 * 16) and rec[64 + 64 * 16:64 + 65 * 16] != bytes(16)

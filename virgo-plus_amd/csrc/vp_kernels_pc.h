@@ -767,7 +767,7 @@ namespace vp {
 // Coset-major codeword with Nc values per coset: leaf i = 32a + b holds (cw[s][b][a], cw[s][b][a + Nc/2]); for Nc == 1
 // (last FRI level) leaf j < 16 holds (cw[s][j], cw[s][j + 16]).
 __global__ void k_pc_open(const F *__restrict__ cw, u32 Nc, const Dig *__restrict__ tree, u32 n_leaves, u32 leaf,
-                          F *__restrict__ vals /* 65*2 */, Dig *__restrict__ path /* depth+1 */) {
+                          F *__restrict__ vals /* 65*2 */, Dig *__restrict__ path /* depth+1 */, const F *__restrict__ mask /* the mask slice at this level (coset-major), or nullptr: zeros */) {
     const u32 t = threadIdx.x;
     if (t < 64) {
         F x, y;
@@ -775,7 +775,12 @@ __global__ void k_pc_open(const F *__restrict__ cw, u32 Nc, const Dig *__restric
         else { x = cw[(size_t) t * 32 + leaf]; y = cw[(size_t) t * 32 + leaf + 16]; }
         vals[2 * t] = x; vals[2 * t + 1] = y;
     } else if (t == 64) {
-        vals[128] = f_zero(); vals[129] = f_zero();
+        F x = f_zero(), y = f_zero();
+        if (mask) {
+            if (Nc >= 2) { const u32 a = leaf >> 5, b = leaf & 31; x = mask[(size_t) b * Nc + a]; y = mask[(size_t) b * Nc + a + (Nc >> 1)]; }
+            else { x = mask[leaf]; y = mask[leaf + 16]; }
+        }
+        vals[128] = x; vals[129] = y;
     }
     // path[k] = sibling at height k (k < depth), path[depth] = the leaf digest itself (the reference's com_hhash layout)
     u32 depth = 0;
@@ -784,6 +789,81 @@ __global__ void k_pc_open(const F *__restrict__ cw, u32 Nc, const Dig *__restric
         if (t == depth) path[t] = tree[n_leaves + leaf];
         else path[t] = tree[((n_leaves + leaf) >> t) ^ 1];
     }
+}
+
+// ---- the mask slice WITH CONTENT (round 6; lib/virgo/src/poly_commit.h:42,55-86,138-161,187-191, fri.cpp:96-124,366-386,403-411) --------------------------------
+// The protocol's own calls pass one zero (src/prover.cpp:526, src/verifier.cpp:375-377) and take the kernels above; a caller that hands vp_commit_private_masked /
+// vp_commit_public_masked a non-zero mask gets a 65th slice through every piece of the commitment.  The slice lives in arrays of its own (coset-major like the
+// others: m[b * Nk + a] = value at position 32 a + b), so nothing of the 64-slice path changes shape.
+// Leaf chains with the mask slice's pair as the last block (the compiler's form: the generated chains end in the all-zero block).
+__global__ void __launch_bounds__(VP_BLOCK)
+k_leaf_hash_cm(const F *__restrict__ cw, u32 N, int n_slices, const F *__restrict__ mask, Dig *__restrict__ leaves) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (N == 1) {                                     // last FRI level: one value per coset, leaf j pairs cosets j and j + 16
+        if (t >= 16) return;
+        Dig h; h.w[0] = h.w[1] = h.w[2] = h.w[3] = 0;
+        for (int s = 0; s < n_slices; ++s) { const F x = cw[(size_t) s * 32 + t], y = cw[(size_t) s * 32 + t + 16]; h = hhash64(x.re, x.im, y.re, y.im, h); }
+        const F x = mask[t], y = mask[t + 16];
+        leaves[t] = hhash64(x.re, x.im, y.re, y.im, h);
+        return;
+    }
+    const u32 halfN = N >> 1;
+    if (t >= 32 * halfN) return;
+    const u32 a = t % halfN, b = t / halfN;
+    Dig h; h.w[0] = h.w[1] = h.w[2] = h.w[3] = 0;
+    for (int s = 0; s < n_slices; ++s) {
+        const F *row = cw + ((size_t) s * 32 + b) * N;
+        const F x = row[a], y = row[a + halfN];
+        h = hhash64(x.re, x.im, y.re, y.im, h);
+    }
+    const F x = mask[(size_t) b * N + a], y = mask[(size_t) b * N + a + halfN];
+    leaves[32 * a + b] = hhash64(x.re, x.im, y.re, y.im, h);
+}
+__global__ void __launch_bounds__(VP_BLOCK) k_fill_f(F *__restrict__ p, u32 n, F v) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+// l q of the mask slice at the 2 ms points the quotient needs (poly_commit.h:196-204): natural position j = id * (gap / 2), coset-major index (j & 31) N + (j >> 5)
+__global__ void __launch_bounds__(VP_BLOCK)
+k_mask_lq(const F *__restrict__ lm, const F *__restrict__ qm, u32 N, u32 half_gap, u32 count, F *__restrict__ out) {
+    const u32 id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= count) return;
+    const u32 j = id * half_gap;
+    const size_t at = (size_t) (j & 31) * N + (j >> 5);
+    out[id] = f_mul(lm[at], qm[at]);
+}
+// h_coef = the upper half of lq_coef, S0 = lq_coef[0] + h_coef[0], all_sum[64] = S0 ms (poly_commit.h:213-216,247)
+__global__ void __launch_bounds__(VP_BLOCK)
+k_mask_hcoef(const F *__restrict__ lq_coef, u32 ms, u32 n_pad, F ms_as_f, F *__restrict__ h_coef, F *__restrict__ S0, F *__restrict__ all_sum64) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_pad) h_coef[i] = i < ms ? lq_coef[ms + i] : f_zero();
+    if (i == 0) { const F s = f_add(lq_coef[0], lq_coef[ms]); *S0 = s; *all_sum64 = f_mul(s, ms_as_f); }
+}
+// Virtual oracle of the mask slice (poly_commit.h:225-245): (l q - (x^ms - 1) h - S0) ms x^-1 at x = w_M^(32 a + b), coset-major like its inputs
+__global__ void __launch_bounds__(VP_BLOCK)
+k_mask_vo(const F *__restrict__ lm, const F *__restrict__ qm, const F *__restrict__ hm, const F *__restrict__ S0, u32 N, const F *__restrict__ RT, u32 half_m,
+          F ms_as_f, u32 ms, F *__restrict__ out) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 M = 2 * half_m;
+    if (t >= M) return;
+    const u32 a = t % N, b = t / N, j = 32 * a + b;
+    const F xn_m1 = f_sub(root_pow(RT, half_m, (u32) (((unsigned long long) j * ms) & (M - 1))), f_one());
+    const F g = f_sub(f_mul(lm[t], qm[t]), f_mul(xn_m1, hm[t]));
+    const F inv_x = f_mul(ms_as_f, root_pow(RT, half_m, j ? M - j : 0));
+    out[t] = f_mul(f_sub(g, *S0), inv_x);
+}
+// One FRI fold of ONE slice (k_fri_fold's arithmetic on a single coset-major codeword): fri.cpp:366-374
+__global__ void __launch_bounds__(VP_BLOCK)
+k_fri_fold_one(const F *__restrict__ in, F *__restrict__ out, u32 Nk, int k, const F *__restrict__ RT, u32 half_m, F r, F inv2) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 No = Nk >> 1;
+    if (t >= 32 * No) return;
+    const u32 a = t % No, b = t / No, M = 2 * half_m;
+    const u32 e = (u32) ((((unsigned long long) (32 * a + b)) << k) & (M - 1));
+    const F inv_mu = root_pow(RT, half_m, e ? M - e : 0);
+    const F p = in[(size_t) b * Nk + a], q = in[(size_t) b * Nk + a + No];
+    const F c = f_mul(inv2, f_mul(inv_mu, r));
+    out[(size_t) b * No + a] = f_add(f_half(f_add(p, q)), f_mul(c, f_sub(p, q)));
 }
 }  // namespace vp
 #undef f_mul

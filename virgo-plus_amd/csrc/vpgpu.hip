@@ -218,6 +218,9 @@ struct vp_ctx {
     F *pc_fri_all = nullptr; std::vector<size_t> fri_cw_off, fri_tree_off; F *pc_open_buf = nullptr;
     Dig *pc_fri_roots = nullptr;
     F *pc_fri[2] = {nullptr, nullptr}; Dig *pc_fri_tree = nullptr; int fri_step = -1; size_t fri_tree_used = 0; bool pc_public_done = false;
+    // the mask slice with content (vp_commit_private_masked / vp_commit_public_masked; 0 = the protocol's zero mask, nothing below is touched): padded mask length,
+    // the slice's l / q / h codewords and its FRI levels end to end (M elements each, coset-major), scratch of its small transforms, per-level offsets
+    u32 pc_mask_ms = 0; F *pc_lm_cw = nullptr, *pc_qm_cw = nullptr, *pc_hm_cw = nullptr, *pc_fm = nullptr, *pc_mtmp = nullptr; std::vector<size_t> fri_m_off;
 
     // Deferred completion (vp_set_deferred / vp_flush; round 5).  A GPU that goes idle for a fraction of a millisecond — a host synchronisation between two
     // prover calls, the host work between two proofs — runs the NEXT ten milliseconds at a lower clock (tools/leaf_in_step.py: k_leaf_hash alone 10.1 ms
@@ -1129,6 +1132,7 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
     ctx->pc_q0 = nullptr; ctx->pc_eq = nullptr; ctx->pc_cbuf = nullptr; ctx->pc_cbuf_lm = -1; ctx->pc_flag = nullptr; ctx->pc_q_tensor = false;
     ctx->pc_scr = nullptr; ctx->pc_scr_cap = 0; ctx->pc_fri_all = nullptr; ctx->pc_open_buf = nullptr; ctx->fri_cw_off.clear(); ctx->fri_tree_off.clear();
     ctx->pc_fri[0] = ctx->pc_fri[1] = nullptr; ctx->pc_fri_tree = nullptr; ctx->pc_fri_roots = nullptr; ctx->fri_step = -1; ctx->pc_public_done = false;
+    ctx->pc_mask_ms = 0; ctx->pc_lm_cw = ctx->pc_qm_cw = ctx->pc_hm_cw = ctx->pc_fm = ctx->pc_mtmp = nullptr; ctx->fri_m_off.clear();
     int max_bl = 0;
     for (int i = 0; i < n_layers; ++i) {
         if (ld[i].size == 0 || ld[i].size > (1ull << 30) || ld[i].bit_length < 0 || ld[i].bit_length > 30 ||
@@ -1332,7 +1336,7 @@ int vp_evaluate(vp_ctx *ctx, const vp_F *inputs, uint64_t n_inputs) {
     if (!ctx || !inputs || ctx->n_layers < 2 || n_inputs != ctx->L[0].size) return VP_EINVAL;
     VP_ENTER(ctx);
     LayerDev &L0 = ctx->L[0];
-    ctx->pc_private_done = false; ctx->pc_public_done = false;          // a commitment to the previous witness does not stand for this one
+    ctx->pc_private_done = false; ctx->pc_public_done = false; ctx->pc_mask_ms = 0;          // a commitment to the previous witness does not stand for this one
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     HIPCHK(hipMemsetAsync(L0.val, 0, (sizeof(F) << L0.bl), ctx->stream));
     HIPCHK(hipMemcpyAsync(L0.val, inputs, n_inputs * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
