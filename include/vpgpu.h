@@ -312,8 +312,9 @@ int vp_fft_gkr_cancel(vp_ctx *);
  * slice_size / n_mask (poly_commit.h:55-66); the public mask pads to the same ms.  From then on the commitment carries the slice everywhere the reference does —
  * the 65th block of every leaf chain of both oracles, all_sum[64], its own virtual oracle and fold on every FRI level (vp_fri_step / vp_fri_commit), the last pair
  * of every opening (vp_fri_open), its final codeword (vp_fri_final_mask) — bit-exact against the reference called directly (tests/golden/pc_masked_*.bin).
- * Limits: ms >= 8 (below that the reference's own transforms read stale scratch, RS_polynomial.cpp:104-133: VP_EINVAL) and 2 ms <= 2^(n-6) (VP_ELIMIT); not on a
- * sharded commitment; vp_commit_public_eq refuses a masked commitment.  vp_commit_private (or a new witness) returns the context to the zero mask.            */
+ * Limits: ms >= 8 (below that the reference's own transforms read stale scratch, RS_polynomial.cpp:104-133: VP_EINVAL), gap >= 2 (the reference asserts it,
+ * poly_commit.h:195: VP_EINVAL) and ms <= 2^16 (the quotient's 2 ms-point transform must be one of this library's: VP_ELIMIT); not on a sharded commitment;
+ * vp_commit_public_eq refuses a masked commitment.  vp_commit_private (or a new witness) returns the context to the zero mask.            */
 int vp_commit_private_masked(vp_ctx *, const vp_F *mask, uint64_t n_mask, uint8_t root[32]);
 int vp_commit_public_masked(vp_ctx *, const vp_F *pub, uint64_t n_pub, const vp_F *pub_mask, uint64_t n_pub_mask, vp_F *inner, vp_F all_sum[65], uint8_t root_h[32]);
 /* fri::cpd.rs_codeword_msk[last] (vpd_verifier.cpp:321-325): the mask slice's last codeword, 32 values, out[2 i + hi] = value at position i + 16 hi (zeros

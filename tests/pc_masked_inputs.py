@@ -5,7 +5,9 @@ import numpy as np
 P61 = (1 << 61) - 1
 # name -> (input bit length n, mask length m, seed).  Masks that pad to fewer than 8 elements are not cases: the reference's own transforms of fewer than 8 points
 # read stale scratch (RS_polynomial.cpp:104-133, and its packed leaf loop runs zero times below 4 coefficients), its commitment is not a function of such a mask.
-CASES = {"n13_zero": (13, 1, 10), "n13_m5": (13, 5, 11), "n13_m64": (13, 64, 13), "n16_m100": (16, 100, 14), "n19_m3000": (19, 3000, 15)}
+CASES = {"n13_zero": (13, 1, 10), "n13_m5": (13, 5, 11), "n13_m64": (13, 64, 13), "n16_m100": (16, 100, 14), "n19_m3000": (19, 3000, 15),
+         # masks longer than a slice's message (2^(n-6) elements): 4 and 16 blocks of it, the longest the reference takes (mask_position_gap = 2)
+         "n13_m300": (13, 300, 16), "n13_m2000": (13, 2000, 17)}
 
 
 def inputs(name):

@@ -2072,7 +2072,7 @@ def _pc_masked_record(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["n13_zero", "n13_m5", "n13_m64", "n16_m100", "n19_m3000"])
+@pytest.mark.parametrize("name", ["n13_zero", "n13_m5", "n13_m64", "n16_m100", "n19_m3000", "n13_m300", "n13_m2000"])
 def test_commitment_with_mask_slices_vs_real_reference(vp, name):
     """SURVEY 8a a12 with CONTENT in the 65th slice (lib/virgo/src/poly_commit.h:42,55-86,138-161,187-191): the reference's own prover only ever passes one zero
     (src/prover.cpp:526), so the goldens come from poly_commit_prover::commit_private_array / commit_public_array / commit_phase called directly by
@@ -2136,7 +2136,7 @@ def test_commitment_with_mask_slices_vs_real_reference(vp, name):
 
 def test_masked_commitment_limits_and_state(vp):
     """The masked entry points at their edges: a mask that pads to fewer than 8 elements is refused (the reference's own transforms of that size read stale scratch),
-    one longer than half a slice's message is VP_ELIMIT, the unmasked public calls refuse a masked private commitment, the public mask may not outgrow the private
+    one longer than half a slice too (mask_position_gap 1), one that pads to more than 2^16 elements is VP_ELIMIT, the unmasked public calls refuse a masked private commitment, the public mask may not outgrow the private
     one's padded length, and vp_commit_private returns the context to the zero mask (same root as before)."""
     import pc_masked_inputs as pmi
     x = pmi.inputs("n13_m5")
@@ -2153,7 +2153,8 @@ def test_masked_commitment_limits_and_state(vp):
         m = np.ones((200, 2), np.uint64)
         assert L.vp_commit_private_masked(ctx, m.ctypes.data, 1, ctypes.cast(root1, ctypes.c_void_p)) == -1 and b"fewer than 8" in L.vp_last_error(ctx)    # VP_EINVAL
         assert L.vp_commit_private_masked(ctx, m.ctypes.data, 4, ctypes.cast(root1, ctypes.c_void_p)) == -1
-        assert L.vp_commit_private_masked(ctx, m.ctypes.data, 100, ctypes.cast(root1, ctypes.c_void_p)) == -5 and b"half a slice" in L.vp_last_error(ctx)  # VP_ELIMIT: pads to 128 > N / 2 = 64
+        m3 = np.ones((3000, 2), np.uint64)
+        assert L.vp_commit_private_masked(ctx, m3.ctypes.data, 3000, ctypes.cast(root1, ctypes.c_void_p)) == -1 and b"half a slice" in L.vp_last_error(ctx)  # gap 1: the reference asserts against it
         inner, alls = np.zeros(2, np.uint64), np.zeros((65, 2), np.uint64)
         assert L.vp_commit_public_masked(ctx, pub.ctypes.data, pub.shape[0], m.ctypes.data, 5, inner.ctypes.data, alls.ctypes.data, ctypes.cast(root2, ctypes.c_void_p)) == -1   # no masked private commitment
         pm = np.ascontiguousarray(x["pri_mask"])
@@ -2162,6 +2163,10 @@ def test_masked_commitment_limits_and_state(vp):
         assert L.vp_commit_public_masked(ctx, pub.ctypes.data, pub.shape[0], m.ctypes.data, 9, inner.ctypes.data, alls.ctypes.data, ctypes.cast(root2, ctypes.c_void_p)) == -1   # 9 > padded length 8
         assert L.vp_commit_private(ctx, ctypes.cast(root2, ctypes.c_void_p)) == 0 and root2.raw == root0.raw
         assert L.vp_commit_public(ctx, pub.ctypes.data, pub.shape[0], inner.ctypes.data, alls.ctypes.data, ctypes.cast(root2, ctypes.c_void_p)) == 0
+        big = np.zeros((1 << 19, 2), np.uint64); big[:, 0] = 1
+        assert L.vp_pc_load_input(ctx, big.ctypes.data, big.shape[0], 19) == 0
+        mb = np.ones((100000, 2), np.uint64)
+        assert L.vp_commit_private_masked(ctx, mb.ctypes.data, 100000, ctypes.cast(root1, ctypes.c_void_p)) == -5 and b"2^16" in L.vp_last_error(ctx)        # VP_ELIMIT: pads to 2^17
     finally:
         L.vp_destroy(ctx)
 

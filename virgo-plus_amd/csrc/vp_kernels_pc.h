@@ -823,6 +823,19 @@ __global__ void __launch_bounds__(VP_BLOCK) k_fill_f(F *__restrict__ p, u32 n, F
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
 }
+// A polynomial of ms = c N coefficients (c = 2 .. 16: a mask longer than a slice's message) on the slice's domain: on coset b, x^N = zeta_b = w_32^b is a constant, so
+// P(x) = sum_t zeta_b^t P_t(x) with P_t the t-th block of N coefficients — one N-coefficient polynomial per coset, twisted by w_M^(b j) so that the plain N-point
+// transform of row b yields P at w_M^(32 k + b): out[b][j] = w_M^(b j) sum_t zeta_b^t coef[t N + j]
+__global__ void __launch_bounds__(VP_BLOCK)
+k_mask_combine(const F *__restrict__ coef, u32 N, u32 c, const F *__restrict__ RT, u32 half_m, F *__restrict__ out) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 32 * N) return;
+    const u32 b = t / N, j = t % N, M = 2 * half_m;
+    const F zeta = root_pow(RT, half_m, (u32) (((unsigned long long) N * b) & (M - 1)));
+    F acc = coef[(size_t) (c - 1) * N + j];
+    for (int q = (int) c - 2; q >= 0; --q) acc = f_add(f_mul(acc, zeta), coef[(size_t) q * N + j]);
+    out[t] = f_mul(acc, root_pow(RT, half_m, (u32) (((unsigned long long) b * j) & (M - 1))));
+}
 // l q of the mask slice at the 2 ms points the quotient needs (poly_commit.h:196-204): natural position j = id * (gap / 2), coset-major index (j & 31) N + (j >> 5)
 __global__ void __launch_bounds__(VP_BLOCK)
 k_mask_lq(const F *__restrict__ lm, const F *__restrict__ qm, u32 N, u32 half_gap, u32 count, F *__restrict__ out) {

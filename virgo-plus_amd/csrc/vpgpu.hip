@@ -221,6 +221,7 @@ struct vp_ctx {
     // the mask slice with content (vp_commit_private_masked / vp_commit_public_masked; 0 = the protocol's zero mask, nothing below is touched): padded mask length,
     // the slice's l / q / h codewords and its FRI levels end to end (M elements each, coset-major), scratch of its small transforms, per-level offsets
     u32 pc_mask_ms = 0; F *pc_lm_cw = nullptr, *pc_qm_cw = nullptr, *pc_hm_cw = nullptr, *pc_fm = nullptr, *pc_mtmp = nullptr; std::vector<size_t> fri_m_off;
+    size_t pc_mtmp_cap = 0, pc_mB = 0;                 // scratch capacity; B = max(ms, N): the scratch is laid out in blocks of B elements (pc_mask_scratch)
 
     // Deferred completion (vp_set_deferred / vp_flush; round 5).  A GPU that goes idle for a fraction of a millisecond — a host synchronisation between two
     // prover calls, the host work between two proofs — runs the NEXT ten milliseconds at a lower clock (tools/leaf_in_step.py: k_leaf_hash alone 10.1 ms
@@ -1132,7 +1133,7 @@ int vp_circuit_upload(vp_ctx *ctx, int n_layers, const vp_layer_desc *ld) {
     ctx->pc_q0 = nullptr; ctx->pc_eq = nullptr; ctx->pc_cbuf = nullptr; ctx->pc_cbuf_lm = -1; ctx->pc_flag = nullptr; ctx->pc_q_tensor = false;
     ctx->pc_scr = nullptr; ctx->pc_scr_cap = 0; ctx->pc_fri_all = nullptr; ctx->pc_open_buf = nullptr; ctx->fri_cw_off.clear(); ctx->fri_tree_off.clear();
     ctx->pc_fri[0] = ctx->pc_fri[1] = nullptr; ctx->pc_fri_tree = nullptr; ctx->pc_fri_roots = nullptr; ctx->fri_step = -1; ctx->pc_public_done = false;
-    ctx->pc_mask_ms = 0; ctx->pc_lm_cw = ctx->pc_qm_cw = ctx->pc_hm_cw = ctx->pc_fm = ctx->pc_mtmp = nullptr; ctx->fri_m_off.clear();
+    ctx->pc_mask_ms = 0; ctx->pc_lm_cw = ctx->pc_qm_cw = ctx->pc_hm_cw = ctx->pc_fm = ctx->pc_mtmp = nullptr; ctx->fri_m_off.clear(); ctx->pc_mtmp_cap = 0; ctx->pc_mB = 0;
     int max_bl = 0;
     for (int i = 0; i < n_layers; ++i) {
         if (ld[i].size == 0 || ld[i].size > (1ull << 30) || ld[i].bit_length < 0 || ld[i].bit_length > 30 ||

@@ -249,6 +249,7 @@ void prover::sumcheckLiuFinalize(const F &previousRandom, F &claim) {           
 }
 
 prover::hhash_digest prover::commit_private() {      // src/prover.cpp:524-530 (mask = one zero element)
+    masked = false;
     hhash_digest d;
     check(vp_commit_private(ctx, d.b), "vp_commit_private");
     return d;
@@ -258,6 +259,28 @@ prover::hhash_digest prover::commit_public(std::vector<F> &pub, F &inner_product
     all_sum.resize(65);
     check(vp_commit_public(ctx, cF(pub.data()), pub.size(), mF(&inner_product_sum), mF(all_sum.data()), d.b), "vp_commit_public");
     return d;
+}
+static bool all_zero(const std::vector<F> &v) { for (auto &x : v) if (x.real | x.img) return false; return true; }
+prover::hhash_digest prover::commit_private(const std::vector<F> &mask) {      // poly_commit.h:41-124 with its mask argument
+    if (mask.empty() || all_zero(mask)) { masked = false; return commit_private(); }
+    hhash_digest d;
+    check(vp_commit_private_masked(ctx, cF(mask.data()), mask.size(), d.b), "vp_commit_private_masked");
+    masked = true;
+    return d;
+}
+prover::hhash_digest prover::commit_public(std::vector<F> &pub, F &inner_product_sum, std::vector<F> &mask, std::vector<F> &all_sum) {      // src/prover.cpp:542-546
+    if (!masked) return commit_public(pub, inner_product_sum, all_sum);      // behind a zero private mask the public mask's slice is multiplied by zero everywhere
+    hhash_digest d;
+    all_sum.resize(65);
+    std::vector<F> one_zero(1, F_ZERO);
+    const std::vector<F> &m = mask.empty() ? one_zero : mask;
+    check(vp_commit_public_masked(ctx, cF(pub.data()), pub.size(), cF(m.data()), m.size(), mF(&inner_product_sum), mF(all_sum.data()), d.b), "vp_commit_public_masked");
+    return d;
+}
+std::vector<F> prover::friFinalMask() {
+    std::vector<F> out(32);
+    check(vp_fri_final_mask(ctx, mF(out.data())), "vp_fri_final_mask");
+    return out;
 }
 prover::hhash_digest prover::commit_public_eq(const std::vector<F> &point, F &inner_product_sum, std::vector<F> &all_sum) {
     hhash_digest d;

@@ -54,6 +54,12 @@ public:
     hhash_digest commit_private();                       // src/prover.cpp:524-530
     // src/prover.cpp:542-546 (the mask argument of the reference is the one-element zero vector and is implied)
     hhash_digest commit_public(std::vector<F> &pub, F &inner_product_sum, std::vector<F> &all_sum);
+    // the same two with the mask vectors lib/virgo's commit_private_array / commit_public_array take (poly_commit.h:41-42,126-128; the reference's own
+    // prover passes one zero, src/prover.cpp:526, and its commit_public has this signature, src/prover.cpp:542): a non-zero private mask puts content into the
+    // 65th slice of every oracle (vp_commit_private_masked / vp_commit_public_masked); an all-zero one is the call above
+    hhash_digest commit_private(const std::vector<F> &mask);
+    hhash_digest commit_public(std::vector<F> &pub, F &inner_product_sum, std::vector<F> &mask, std::vector<F> &all_sum);
+    std::vector<F> friFinalMask();                       // fri::cpd.rs_codeword_msk[last] (vpd_verifier.cpp:321-325)
     // extension: the protocol's own public vector, pub = eq(point, .) (src/verifier.cpp:368-369), built on the device from the point
     // (vp_commit_public_eq) — same outputs as commit_public on that table, nothing of it crosses PCIe
     hhash_digest commit_public_eq(const std::vector<F> &point, F &inner_product_sum, std::vector<F> &all_sum);
@@ -107,5 +113,6 @@ private:
     int round = 0;
     int sumcheckLayerId = 0;
     timer prove_timer, init_timer, round_timer, fin_timer;
+    bool masked = false;                                 // the standing private commitment carries a non-zero mask slice
     u64 proof_size = 0;
 };
