@@ -76,6 +76,11 @@ static void trace_at_exit() {
             g_vpi_sec.commit_private, g_vpi_sec.commit_public, g_vpi_sec.fri_step, g_vpi_sec.first_fri_step, g_vpi_sec.fri_final, g_vpi_sec.fft_gkr);
 }
 static_assert(sizeof(F) == sizeof(vp_F), "virgo::fieldElement is two u64 limbs (fieldElement.hpp:96-97)");
+// a context without a circuit, for a test main that drives the commitment alone (integration/masked_main.cpp)
+vp_ctx *vpi_ctx_standalone() {
+    if (!g_ctx) { GUARDED(vp_create(0, &g_ctx), "vp_create"); atexit(trace_at_exit); }
+    return g_ctx;
+}
 
 prover::prover(const layeredCircuit &cir) : C(cir) {              // src/prover.cpp:14
     proof_size = 0;

@@ -12,6 +12,7 @@
 #include <cstdio>
 
 vp_ctx *vpi_ctx();                                   // the context prover::prover() created (exits if there is none)
+vp_ctx *vpi_ctx_standalone();                        // ... or creates one without a circuit (masked_main.cpp: the commitment alone)
 void vpi_must(int rc, const char *what);             // VP_OK or: print vp_last_error, exit(EXIT_FAILURE) — the reference's own error style
 // commit_private / commit_public tell the FRI side which oracle now exists (its root and the input bit length):
 // fri::request_init_commit(bit_len, oracle) returns exactly this (lib/virgo/src/fri.cpp:36-139 computed it there).

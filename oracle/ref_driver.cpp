@@ -29,6 +29,7 @@
 //       (lib/virgo/src/poly_commit.h:41-349) and commit_phase (vpd_verifier.cpp:44-74) are called directly.  IN: i32 n, i32 m, then values[2^n], pub[2^n],
 //       pri_mask[m], pub_mask[m] as (u64 real, u64 img) pairs.  --dump: root_l | root_h | all_sum[65] | openings (130 values each: 65 pairs, the mask
 //       slice's last) of oracle 0 and 1 at leaves 0, 5, M/2 - 1 and of FRI levels 0, 2 at position 3; --dump-fri: as for a protocol run.
+//       --verify: then poly_commit_verifier::verify_poly_commitment (vpd_verifier.cpp:76-328) with the public mask decides on that commitment; exit code 0 = accepted.
 #include "verifier.h"
 #include "inputCircuit.hpp"
 #include "virgo/src/polynomial.h"          // lib/virgo's own polynomial classes (namespace virgo), the ones fft_circuit_GKR.cpp uses
@@ -132,6 +133,7 @@ int main(int argc, char **argv) {
     const char *pws = nullptr, *dump = nullptr, *custom = nullptr;
     int blocks = 1, ref_parser = 0, rnd_layers = 0, rnd_log = 0, fft_lg = 0;
     const char *pc_masked = nullptr;
+    bool pc_masked_verify = false;
     long seed = -1;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -147,6 +149,7 @@ int main(int argc, char **argv) {
         else if (a == "--randomize" && i + 2 < argc) { rnd_layers = atoi(argv[++i]); rnd_log = atoi(argv[++i]); }
         else if (a == "--custom" && i + 1 < argc) custom = argv[++i];
         else if (a == "--pc-masked" && i + 1 < argc) pc_masked = argv[++i];
+        else if (a == "--verify") pc_masked_verify = true;
         else { fprintf(stderr, "bad arg %s\n", argv[i]); return 2; }
     }
     if (fft_lg > 0) {                          // fft_gkr alone, from the generator state F::init() leaves (srand(3396))
@@ -182,6 +185,21 @@ int main(int argc, char **argv) {
                 auto r = fri::request_init_value_with_merkle(leaf, leaf + half, ns, oracle);
                 for (auto &pr : r.first) { wF(pr.first); wF(pr.second); }
             }
+        if (pc_masked_verify) {
+            // the reference's OWN verifier on that commitment INSTEAD of the recorded commit phase (commit_phase runs once per commitment: fri.cpp's state is not re-entrant) (vpd_verifier.cpp:76-328 with the public mask; `processed` as src/verifier.cpp:346-358,371):
+            // 33 random queries — Merkle paths of l, h and every FRI level, the first-round consistency of all 65 slices (the mask slice against the public
+            // mask's polynomial and all_sum[64]), the later rounds, both final codewords.
+            std::vector<fieldElement> processed((size_t) 1 << n);
+            const int cs = 1 << (n - log_slice_number);
+            for (int i = 0; i < slice_number; ++i)
+                inverse_fast_fourier_transform(pub.data() + (size_t) i * cs, cs, cs, fieldElement::getRootOfUnity(n - log_slice_number), processed.data() + (size_t) i * cs);
+            poly_commit::poly_commit_verifier pv;
+            pv.p = &pp;
+            double vt = 0, pt = 0; int ps = 0;
+            const bool ok = pv.verify_poly_commitment(all_sum.data(), n, processed.data(), pubm, vt, ps, pt, root_l, root_h);
+            fprintf(stdout, "pc-masked verify_poly_commitment %s proof_bytes %d\n", ok ? "ACCEPT" : "REJECT", ps);
+            return ok ? 0 : 1;
+        }
         poly_commit::ldt_commitment com = pp.commit_phase(n);          // the wrapper above records (challenge, root) of every step
         for (int lvl : {0, 2}) {
             if (lvl >= com.mx_depth) continue;

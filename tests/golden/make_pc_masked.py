@@ -27,10 +27,7 @@ def main():
         x = pmi.inputs(name)
         with tempfile.TemporaryDirectory() as tmp:
             inp = os.path.join(tmp, "in.bin")
-            with open(inp, "wb") as f:
-                f.write(struct.pack("<ii", x["n"], x["m"]))
-                for k in ("values", "pub", "pri_mask", "pub_mask"):
-                    f.write(x[k].tobytes())
+            pmi.write_case_file(name, inp)
             rec, fri = os.path.join(HERE, "pc_masked_%s.bin" % name), os.path.join(HERE, "pc_masked_fri_%s.bin" % name)
             r = subprocess.run([REF_RUN, "--pc-masked", inp, "--dump", rec, "--dump-fri", fri], stdout=subprocess.PIPE, text=True, check=True)
         gap = int(r.stdout.split("mask_position_gap")[1].split()[0]); steps = int(r.stdout.split("steps")[1].split()[0])

@@ -18,3 +18,21 @@ def inputs(name):
     if name.endswith("_zero"):               # the protocol's own case (one zero each): what the unmasked entry points must reproduce from the same record layout
         x["pri_mask"][:] = 0; x["pub_mask"][:] = 0
     return x
+
+
+def write_case_file(name, path):
+    """The IN file of `ref_run --pc-masked` / `ref_run_vpgpu_masked` (oracle/ref_driver.cpp): i32 n, i32 m, values[2^n], pub[2^n], pri_mask[m], pub_mask[m]."""
+    import struct
+    x = inputs(name)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<ii", x["n"], x["m"]))
+        for k in ("values", "pub", "pri_mask", "pub_mask"):
+            f.write(x[k].tobytes())
+    return x
+
+
+# what the reference's OWN verifier (poly_commit_verifier::verify_poly_commitment, vpd_verifier.cpp:76-328) says about the reference's own commitment of each
+# case (oracle/_ref/ref_run --pc-masked IN --verify, measured in the build container): a mask that pads to MORE than a slice's message (2^(n-6) elements) is
+# not reduced to a constant by the n - 6 folds, and the verifier's last check ("Fri msk rs code check fail", :318-324) rejects it — prover and verifier of
+# lib/virgo agree only up to that length.  The device prover must get the same verdicts.
+REFERENCE_VERIFIER_ACCEPTS = {"n13_zero": True, "n13_m5": True, "n13_m64": True, "n16_m100": True, "n19_m3000": True, "n13_m300": False, "n13_m2000": False}

@@ -2134,6 +2134,31 @@ def test_commitment_with_mask_slices_vs_real_reference(vp, name):
         L.vp_destroy(ctx)
 
 
+@pytest.mark.parametrize("name", ["n13_m5", "n13_m64", "n16_m100", "n19_m3000", "n13_m300"])
+def test_reference_verifier_decides_device_masked_commitments(name, tmp_path):
+    """The mask slice end to end behind the reference's OWN verifier: oracle/_ref/ref_run_vpgpu_masked (integration/masked_main.cpp) commits with
+    vp_commit_private_masked / vp_commit_public_masked and hands the roots and all_sum[65] to the unmodified poly_commit_verifier::verify_poly_commitment
+    (vpd_verifier.cpp:76-328) with the public mask — 33 random queries, every opening, Merkle path, fold and final codeword (the mask slice's among them) served
+    from HBM through INTEGRATION.md's forwarding files.  The verdict must be the one the reference's verifier gives the reference's own prover
+    (tests/test_oracle_golden.py, pc_masked_inputs.REFERENCE_VERIFIER_ACCEPTS): ACCEPT up to a slice's message length, the same last-check REJECT beyond it."""
+    import subprocess
+    import pc_masked_inputs as pmi
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_run_vpgpu_masked")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_run_vpgpu_masked not built (needs the reference tree at build time)")
+    inp = tmp_path / "in.bin"
+    pmi.write_case_file(name, str(inp))
+    r = subprocess.run([exe, str(inp)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=dict(os.environ, VPI_TRACE="1"))
+    want = pmi.REFERENCE_VERIFIER_ACCEPTS[name]
+    assert ("verify_poly_commitment ACCEPT" in r.stdout) == want and ("verify_poly_commitment REJECT" in r.stdout) == (not want), (r.stdout[-400:], r.stderr[-1500:])
+    assert r.returncode == (0 if want else 1)
+    if want:
+        st = pmi.CASES[name][0] - 6
+        assert "open_init 66 open_step %d " % (33 * st) in r.stderr and "rand_consumers 0" in r.stderr, r.stderr[-1500:]
+    else:
+        assert "Fri msk rs code check fail" in r.stderr
+
+
 def test_masked_commitment_limits_and_state(vp):
     """The masked entry points at their edges: a mask that pads to fewer than 8 elements is refused (the reference's own transforms of that size read stale scratch),
     one longer than half a slice too (mask_position_gap 1), one that pads to more than 2^16 elements is VP_ELIMIT, the unmasked public calls refuse a masked private commitment, the public mask may not outgrow the private

@@ -385,3 +385,25 @@ def test_masked_commitment_goldens_are_the_recorded_files():
             assert fri[-32 * 16:] == bytes(32 * 16) and rec[64 + 64 * 16:64 + 65 * 16] == bytes(16)          # zero mask: all_sum[64] = 0, mask codeword 0
         else:
             assert fri[-32 * 16:] != bytes(32 * 16) and rec[64 + 64 * 16:64 + 65 * 16] != bytes(16)
+
+
+@pytest.mark.parametrize("name", ["n13_m5", "n13_m64", "n16_m100", "n13_m300", "n13_m2000"])
+def test_reference_verifier_on_the_references_own_masked_commitments(name, tmp_path):
+    """Pins what `accepted` means for the mask slice: the reference's own verify_poly_commitment (vpd_verifier.cpp:76-328) on the reference's own
+    commit_private_array / commit_public_array with the masks of the goldens (oracle/_ref/ref_run --pc-masked IN --verify).  Masks up to a slice's message length are
+    accepted; longer ones — which the reference's prover commits without complaint, and which the device reproduces byte for byte — are REJECTED by its own verifier
+    at the last check (the mask slice's final codeword is not constant).  The GPU suite asks the same verdicts of the device prover."""
+    import subprocess
+    import pc_masked_inputs as pmi
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_run")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_run not built (needs the reference tree at build time)")
+    inp = tmp_path / "in.bin"
+    pmi.write_case_file(name, str(inp))
+    r = subprocess.run([exe, "--pc-masked", str(inp), "--verify"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    want = pmi.REFERENCE_VERIFIER_ACCEPTS[name]
+    assert ("verify_poly_commitment ACCEPT" in r.stdout) == want and ("verify_poly_commitment REJECT" in r.stdout) == (not want), (r.stdout[-400:], r.stderr[-400:])
+    assert r.returncode == (0 if want else 1)
+    if not want:
+        assert "Fri msk rs code check fail" in r.stderr
