@@ -314,7 +314,10 @@ int vp_fft_gkr_cancel(vp_ctx *);
  * of every opening (vp_fri_open), its final codeword (vp_fri_final_mask) — bit-exact against the reference called directly (tests/golden/pc_masked_*.bin).
  * Limits: ms >= 8 (below that the reference's own transforms read stale scratch, RS_polynomial.cpp:104-133: VP_EINVAL), gap >= 2 (the reference asserts it,
  * poly_commit.h:195: VP_EINVAL) and ms <= 2^16 (the quotient's 2 ms-point transform must be one of this library's: VP_ELIMIT); not on a sharded commitment;
- * vp_commit_public_eq refuses a masked commitment.  vp_commit_private (or a new witness) returns the context to the zero mask.            */
+ * vp_commit_public_eq refuses a masked commitment.  vp_commit_private (or a new witness) returns the context to the zero mask.
+ * What the reference's VERIFIER makes of it (vpd_verifier.cpp:76-328 with the public mask, oracle/integration/masked_main.cpp): a commitment whose ms is at most a
+ * slice's message length 2^(n-6) is accepted; a longer mask is committed exactly as the reference's prover commits it and rejected exactly as the reference's verifier
+ * rejects that prover's (its last check, :318-324: n - 6 folds do not reduce the mask slice to a constant).                                                        */
 int vp_commit_private_masked(vp_ctx *, const vp_F *mask, uint64_t n_mask, uint8_t root[32]);
 int vp_commit_public_masked(vp_ctx *, const vp_F *pub, uint64_t n_pub, const vp_F *pub_mask, uint64_t n_pub_mask, vp_F *inner, vp_F all_sum[65], uint8_t root_h[32]);
 /* fri::cpd.rs_codeword_msk[last] (vpd_verifier.cpp:321-325): the mask slice's last codeword, 32 values, out[2 i + hi] = value at position i + 16 hi (zeros
