@@ -46,6 +46,19 @@ def pmc_files(tag):
     return sorted(set(fs), key=lambda f: os.path.basename(f), reverse=True)
 
 
+def issue_share(tag):
+    """tools/isa_cycles.py's record for the workload (newest round first): per kernel, the share of a launch the SIMDs spend issuing the kernel's own VALU stream
+    (static mix x measured per-class issue cost x SQ_INSTS_VALU, over the launch's single-stream duration).  ({}, None) when there is none."""
+    import glob
+    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_issue_share_%s.json" % tag)), key=os.path.basename, reverse=True)
+    for f in fs:
+        try:
+            return json.load(open(f)).get("kernels", {}), os.path.relpath(f, ROOT)
+        except (OSError, ValueError):
+            continue
+    return {}, None
+
+
 def pmc_tag(blocks, randomize=None):
     return ("randomize_%d_%d" % tuple(randomize)) if randomize else ("b%d" % blocks)
 
@@ -162,6 +175,9 @@ def roofline_of(rows, tag, serial_ms, note=None):
                                    "avg_launch_us_in_the_profile": kr.get("single_stream_avg_launch_us"),
                                    "wait_share_of_wave_cycles": (kr.get("SQ_WAIT_ANY_per_launch", 0.0) / kr["SQ_WAVE_CYCLES_per_launch"]) if kr.get("SQ_WAVE_CYCLES_per_launch") else None,
                                    "source": ksrc}
+    shares, ssrc = issue_share(tag)
+    if d["kernel"] in shares:
+        out["own_stream_issue"] = dict(shares[d["kernel"]], source=ssrc)
     if fold and d["work_units"]:
         fmul = FMUL_PER_PAIR_STEP * d["work_units"] / (d["total_us"] * 1e-6)
         out.update({"bound": "valu", "achieved": fmul, "peak": FMUL_PEAK_PER_S, "unit": "F_p^2 multiply-equivalents/s", "frac": fmul / FMUL_PEAK_PER_S,
@@ -423,6 +439,11 @@ def pc_leg(vp, sess, circ, golden, gname, full_fixture=None):
                        "frac": w / (us * 1e-6) / FMUL_PEAK_PER_S, "time_share": us / tot,
                        "hbm_GBps": sum(e["bytes"] for e in ntt) / (us * 1e-6) / 1e9,
                        "peak_definition": "chip-wide F_p^2 multiply issue rate of the 31-bit split form (tools/micro_rates.hip, f_mul)"}
+        shares, ssrc = issue_share(pmc_tag(blocks))
+        own = {k: v["issue_share_of_launch"] for k, v in shares.items() if "ntt8" in k}
+        if own:
+            # against the issue cost of the instructions the passes actually execute (not the multiplier-only peak above) they are VALU-bound
+            roof_ntt["own_stream_issue_share_of_launch"] = dict(own, source=ssrc)
     pc["rooflines"] = rl
     return pc
 

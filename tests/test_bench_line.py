@@ -163,3 +163,17 @@ def test_roofline_reads_the_newest_pmc_summary_per_config_and_a_floor_peak():
                           "factors": {"issue_floor_over_measured_cycles": 0.826, "clock_times_tail_this_run": 0.82, "cycles_per_wave_round": {"floor": 360.0, "measured": 435.6}}})
     o = check_line(bench.compact_line(d, "gpurun_out/bench_detail_n1.json"))
     assert o["roofline"]["traffic_source"] == src and o["roofline"]["factors"]["issue"] == pytest.approx(0.826)
+
+
+def test_issue_share_record_is_read_and_is_a_fraction():
+    """tools/isa_cycles.py's record (profiles/r<NN>_issue_share_<tag>.json): bench.py attaches, per kernel, the share of a launch the SIMDs spend issuing the kernel's
+    own VALU stream.  The committed record names the PMC summary it was computed from and covers the two transform passes and the dominant fold launch."""
+    import bench
+    shares, src = bench.issue_share("b1024")
+    assert src and src.startswith("profiles/r") and os.path.exists(os.path.join(ROOT, src))
+    for k in ("k_ntt8_colsx<8>", "k_ntt8_rows<false>", "k_sumfold3b_gen_multi"):
+        v = shares[k]
+        assert 0.3 < v["issue_share_of_launch"] < 1.2 and 3.0 < v["issue_cycles_per_instruction"] < 6.0 and 0.1 < v["multiplier_share_of_issue"] < 0.5
+    rec = json.load(open(os.path.join(ROOT, src)))
+    assert os.path.exists(os.path.join(ROOT, rec["pmc_summary"]))
+    assert bench.issue_share("no_such_workload") == ({}, None)

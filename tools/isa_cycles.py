@@ -59,7 +59,13 @@ def mixes(listing, want):
 
 
 def main():
+    json_out = None
+    if "--json" in sys.argv:
+        k = sys.argv.index("--json"); json_out = sys.argv[k + 1]; del sys.argv[k:k + 2]
     listing, pmc = sys.argv[1], json.load(open(sys.argv[2]))
+    record = {"how": "tools/isa_cycles.py: static VALU mix of the compiled kernel x measured issue cost per instruction class (profiles/r02_micro_rates.txt, "
+                     "r04_micro_keccak_instruction_classes.txt; nominal-clock SIMD cycles) x SQ_INSTS_VALU of the launch / 1024 SIMDs / 2.4 GHz, over the launch's "
+                     "single-stream duration in the same PMC summary", "pmc_summary": sys.argv[2], "kernels": {}}
     kern = {k["kernel"].replace("vp::", "").replace("void ", ""): k for k in pmc["kernels"]}
     want = [a.split("=")[0] for a in sys.argv[3:]]
     pmc_name = {a.split("=")[0]: (a.split("=")[1] if "=" in a else None) for a in sys.argv[3:]}
@@ -83,6 +89,11 @@ def main():
             issue_us = n / 1024.0 * (cyc / tot) / 2400.0
             print("  launch: %.3e VALU wave-instructions (SQ_INSTS_VALU), %.1f us (single-stream trace) -> the SIMDs need %.1f us to issue them: %.2f of the launch"
                   % (n, us, issue_us, issue_us / us))
+            record["kernels"][pk] = {"static_valu_instructions": tot, "issue_cycles_per_instruction": round(cyc / tot, 3), "valu_wave_instructions_per_launch": n,
+                                     "launch_us": us, "issue_us": round(issue_us, 1), "issue_share_of_launch": round(issue_us / us, 3),
+                                     "multiplier_share_of_issue": round(by.get("v_mad_u64_u32", 0.0) / cyc, 3)}
+    if json_out:
+        json.dump(record, open(json_out, "w"), indent=1)
 
 
 if __name__ == "__main__":
