@@ -439,11 +439,6 @@ def pc_leg(vp, sess, circ, golden, gname, full_fixture=None):
                        "frac": w / (us * 1e-6) / FMUL_PEAK_PER_S, "time_share": us / tot,
                        "hbm_GBps": sum(e["bytes"] for e in ntt) / (us * 1e-6) / 1e9,
                        "peak_definition": "chip-wide F_p^2 multiply issue rate of the 31-bit split form (tools/micro_rates.hip, f_mul)"}
-        shares, ssrc = issue_share(pmc_tag(blocks))
-        own = {k: v["issue_share_of_launch"] for k, v in shares.items() if "ntt8" in k}
-        if own:
-            # against the issue cost of the instructions the passes actually execute (not the multiplier-only peak above) they are VALU-bound
-            roof_ntt["own_stream_issue_share_of_launch"] = dict(own, source=ssrc)
     pc["rooflines"] = rl
     return pc
 
@@ -1039,6 +1034,11 @@ def protocol_workload(vp, a, pws, golden, world, rank, local, blocks):
                     "total_us": us, "time_share": us / tot_us, "hbm_GBps": sum(e["bytes"] for e in ntt) / (us * 1e-6) / 1e9,
                     "hbm_frac": sum(e["bytes"] for e in ntt) / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
                     "peak_definition": "chip-wide F_p^2 multiply issue rate of the 31-bit split form (tools/micro_rates.hip, f_mul)"}
+        shares, ssrc = issue_share(pmc_tag(blocks))
+        own = {k: v["issue_share_of_launch"] for k, v in shares.items() if "ntt8" in k}
+        if own:
+            # against the issue cost of the instructions the passes actually execute (not the multiplier-only peak above) they are VALU-bound
+            roof_ntt["own_stream_issue_share_of_launch"] = dict(own, source=ssrc)
     # ---- the drop-in (interactive) path of the GKR part, and the verifier's side
     t_i = time.perf_counter()
     tr_i, res_i, ok_i = sess.prove_interactive()
