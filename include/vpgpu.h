@@ -461,7 +461,8 @@ int vp_get_launch_stats(vp_ctx *, vp_launch_stat *out, int capacity, int *n);
 const char *vp_kernel_name(int kind);
 
 /* ---- primitives exported for parity tests (thin wrappers over the device functions) -------------- */
-/* out[i] = a[i] op b[i], op: 0 add, 1 sub, 2 mul (device arithmetic of fieldElement.cpp:34-104).       */
+/* out[i] = a[i] op b[i], op: 0 add, 1 sub, 2 mul (device arithmetic of fieldElement.cpp:34-104); op 3: out[i] = a[i] b[i] + a[i+1] b[i+1] (cyclic) through the
+ * one-reduction two-product form the FRI fold kernel uses (canonical inputs).                           */
 int vp_test_field(vp_ctx *, int op, const vp_F *a, const vp_F *b, vp_F *out, uint64_t n);
 /* initBetaTable(out, n, r, init) (src/utils.cpp:29-45): out has 2^n entries.                           */
 int vp_test_beta(vp_ctx *, const vp_F *r, int n, const vp_F *init, vp_F *out);

@@ -47,6 +47,28 @@ def test_field_ops(vp, ob, ctx, op, name):
     assert vp.lib_gpu().vp_test_field(ctx, op, a.ctypes.data, b.ctypes.data, out.ctypes.data, 0) == 0   # empty input
 
 
+def test_field_dot2_one_reduction_form(vp, ob, ctx):
+    """f_dot2cc (vp_field.h): a b + c d of canonical operands as ONE sum of split products per limb — the form k_fri_fold0_vo3 computes the virtual oracle with.
+    Against the oracle's f_mul / f_add on random values and on the extremes (0, 1, p - 1 in either limb: the negated imaginary parts p - x reach p itself)."""
+    rng = np.random.default_rng(77)
+    n = 4099
+    a, b = rand_f(rng, n), np.roll(rand_f(rng, n), 3, axis=0)
+    ext = np.array([[P - 1, P - 1], [P - 1, P - 1], [0, 0], [P - 1, 0], [0, P - 1], [1, 0], [0, 1], [P - 1, P - 1]], dtype=np.uint64)
+    a[100:100 + len(ext)] = ext
+    b[100:100 + len(ext)] = ext[::-1]
+    out = np.zeros_like(a)
+    assert vp.lib_gpu().vp_test_field(ctx, 3, a.ctypes.data, b.ctypes.data, out.ctypes.data, n) == 0
+    L = ob.lib()
+    prod = np.zeros_like(a)
+    for i in range(n):
+        L.orc_f_mul(a[i].ctypes.data, b[i].ctypes.data, prod[i].ctypes.data)
+    exp = np.zeros_like(a)
+    for i in range(n):
+        L.orc_f_add(prod[i].ctypes.data, prod[(i + 1) % n].ctypes.data, exp[i].ctypes.data)
+    assert np.array_equal(out, exp)
+    assert int(out.max()) < P
+
+
 @pytest.mark.parametrize("n", [0, 1, 2, 3, 7, 12, 17])
 def test_beta_table(vp, ob, ctx, n):
     rng = np.random.default_rng(n)

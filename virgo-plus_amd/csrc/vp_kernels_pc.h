@@ -573,7 +573,19 @@ k_fri_fold0_vo(const F *__restrict__ lcw, const F *__restrict__ qcw, const F *__
 // written (they are oracles: leaf hashes and openings read them) but never read back: 10.7 + 3.2 + 1.6 GB -> 12.4 GB at x1024, and two launches less.  Every
 // operation is the exact field operation of k_fri_fold0_vo / k_fri_fold(k = 1, 2) on the same operands (mu_1^-1 = x^-2 and mu_2^-1 = x^-4 by squaring instead of
 // a table read: the same field elements), so the three codewords are the same bytes.
-template <bool TENSOR> __global__ void __launch_bounds__(256)
+// Round 6: the launch was VALU-issue bound on its own instruction stream (profiles/r06_isa_mix_and_issue_share.txt: the SIMDs spent the whole launch issuing),
+// so the level-0 value of the tensor form is computed from FEWER products.  With q_i = c_i q0 and u = hx + hx xr, w = hx xr - hx:
+//     f1 = hx (D + xr S),  D = Ga - Gb,  S = Ga + Gb,  Ga = la c q0a - xn ha - s0,  Gb = lb c q0b - xn hb - s0
+//        = c (A la + B lb) - (C ha + E hb) - K s0,      A = u q0a,  B = w q0b,  C = xn u,  E = xn w,  K = 2 hx xr      (position constants)
+// — three two-product sums with ONE reduction each (f_dot2cc) per slice instead of eight F-multiplications; the same field element, so the same bytes.
+// GRP consecutive slice groups per workgroup (a loop) spread the position constants over GRP * VP_VO_SPT slices: VP_VO_GRP (8: same call at x1024, fold family
+// 4.02-4.29 ms -> 3.43 / 3.52 / 3.17-3.27 / 3.01-3.06 / 3.09 ms with 1 / 2 / 4 / 8 / 16 groups, profiles/r06_ab_fri_fold0_dot2_x1024.txt) where the launch still
+// has >= 2048 workgroups, one group per workgroup below that.
+#ifndef VP_VO_GRP
+#define VP_VO_GRP 8
+#endif
+static_assert(64 % (VP_VO_SPT * VP_VO_GRP) == 0, "the 64 slices are dealt to workgroups in groups of VP_VO_SPT * VP_VO_GRP");
+template <bool TENSOR, int GRP> __global__ void __launch_bounds__(256)
 k_fri_fold0_vo3(const F *__restrict__ lcw, const F *__restrict__ qcw, const F *__restrict__ hcw, const F *__restrict__ S0, F *__restrict__ out1, F *__restrict__ out2,
                 F *__restrict__ out3, u32 N, const F *__restrict__ RTn, const F *__restrict__ cb, F r0, F r1, F r2, F half_n, F inv2,
                 const F *__restrict__ q0, const F *__restrict__ qscal) {
@@ -581,59 +593,73 @@ k_fri_fold0_vo3(const F *__restrict__ lcw, const F *__restrict__ qcw, const F *_
     const u32 E = N >> 3, No = N >> 1, N2 = N >> 2;
     const u32 lane = threadIdx.x & 63, v = threadIdx.x >> 6;
     const u32 per = E >> 6;                                                   // workgroups per (slice group, coset): E >= 64
-    const u32 al = (blockIdx.x % per) * 64 + lane, sb = blockIdx.x / per, b = sb & 31, ig = sb >> 5;
+    const u32 al = (blockIdx.x % per) * 64 + lane, sb = blockIdx.x / per, b = sb & 31, ig0 = (sb >> 5) * GRP;
     const u32 a = al + v * E;                                                 // level-0 position (< N / 2) and level-1 position of its fold
     const F inv_x = f_mul(RTn[(N - a) & (N - 1)], cb[b]);                     // x^-1, x = w_M^(32 a + b)
-    F q0a = f_zero(), q0b = f_zero();
-    if (TENSOR) { const size_t o = (size_t) b * N + a; q0a = q0[o]; q0b = q0[o + No]; }
-    F la[VP_VO_SPT], lb[VP_VO_SPT], ha[VP_VO_SPT], hb[VP_VO_SPT], qa[VP_VO_SPT], qb[VP_VO_SPT];
-#pragma unroll
-    for (int k = 0; k < VP_VO_SPT; ++k) {
-        const size_t p0 = ((size_t) (ig * VP_VO_SPT + k) * 32 + b) * N + a, p1 = p0 + No;
-        la[k] = lcw[p0]; lb[k] = lcw[p1]; ha[k] = hcw[p0]; hb[k] = hcw[p1];
-        if (!TENSOR) { qa[k] = qcw[p0]; qb[k] = qcw[p1]; }
-    }
-    loads_first();
     const F xn_m1 = cb[32 + b];
     const F xr = f_mul(inv_x, r0), hx = f_mul(half_n, inv_x);
-    F f1[VP_VO_SPT];
-#pragma unroll
-    for (int k = 0; k < VP_VO_SPT; ++k) {
-        const u32 i = ig * VP_VO_SPT + k;
-        if (TENSOR) { const F sc = qscal[i]; qa[k] = f_mul(sc, q0a); qb[k] = f_mul(sc, q0b); }
-        const F s0 = S0[i];
-        const F Ga = f_sub(f_sub(f_mul(la[k], qa[k]), f_mul(xn_m1, ha[k])), s0), Gb = f_sub(f_sub(f_mul(lb[k], qb[k]), f_mul(xn_m1, hb[k])), s0);
-        const F D = f_sub(Ga, Gb), S = f_add(Ga, Gb);
-        f1[k] = f_mul(hx, f_add(D, f_mul(xr, S)));
-        out1[((size_t) i * 32 + b) * No + a] = f1[k];
-        if (v >= 2) x1[k][v - 2][lane] = f1[k];
+    F cA = f_zero(), cB = f_zero(), cC = f_zero(), cE = f_zero(), cK = f_zero();
+    if (TENSOR) {
+        const size_t o = (size_t) b * N + a;
+        const F hxr = f_mul(hx, xr), u = f_add(hx, hxr), w = f_sub(hxr, hx);
+        cA = f_mul(u, q0[o]); cB = f_mul(w, q0[o + No]); cC = f_mul(xn_m1, u); cE = f_mul(xn_m1, w); cK = f_add(hxr, hxr);
     }
-    __syncthreads();
     // fold 1 (Nk = N / 2): level-1 positions a = al + v E and a + N / 4 = al + (v + 2) E;  mu^-1 = w_M^-(2 (32 a + b)) = x^-2.  Waves 0, 1 work; every
     // wave stays to the last barrier (a barrier in a workgroup some of whose waves have returned is undefined by HIP's rules, whatever gfx950 does)
     const F m1 = f_mul(inv_x, inv_x);
-    F f2[VP_VO_SPT];
-    if (v < 2) {
-        const F c1 = f_mul(inv2, f_mul(m1, r1));
-#pragma unroll
-        for (int k = 0; k < VP_VO_SPT; ++k) {
-            const u32 i = ig * VP_VO_SPT + k;
-            const F g = x1[k][v][lane];
-            f2[k] = f_add(f_half(f_add(f1[k], g)), f_mul(c1, f_sub(f1[k], g)));
-            out2[((size_t) i * 32 + b) * N2 + a] = f2[k];
-            if (v == 1) x2[k][lane] = f2[k];
-        }
-    }
-    __syncthreads();
+    const F c1 = f_mul(inv2, f_mul(m1, r1));
     // fold 2 (Nk = N / 4): level-2 positions al and al + E;  mu^-1 = x^-4 at al.  Wave 0.
-    if (v == 0) {
-        const F c2 = f_mul(inv2, f_mul(f_mul(m1, m1), r2));
+    const F c2 = f_mul(inv2, f_mul(f_mul(m1, m1), r2));
+#pragma unroll 1
+    for (u32 g = 0; g < (u32) GRP; ++g) {
+        const u32 ig = ig0 + g;
+        F la[VP_VO_SPT], lb[VP_VO_SPT], ha[VP_VO_SPT], hb[VP_VO_SPT], qa[VP_VO_SPT], qb[VP_VO_SPT];
+#pragma unroll
+        for (int k = 0; k < VP_VO_SPT; ++k) {
+            const size_t p0 = ((size_t) (ig * VP_VO_SPT + k) * 32 + b) * N + a, p1 = p0 + No;
+            la[k] = lcw[p0]; lb[k] = lcw[p1]; ha[k] = hcw[p0]; hb[k] = hcw[p1];
+            if (!TENSOR) { qa[k] = qcw[p0]; qb[k] = qcw[p1]; }
+        }
+        loads_first();
+        F f1[VP_VO_SPT];
 #pragma unroll
         for (int k = 0; k < VP_VO_SPT; ++k) {
             const u32 i = ig * VP_VO_SPT + k;
-            const F g = x2[k][lane];
-            out3[((size_t) i * 32 + b) * E + al] = f_add(f_half(f_add(f2[k], g)), f_mul(c2, f_sub(f2[k], g)));
+            const F s0 = S0[i];
+            if (TENSOR) {
+                const F X = f_dot2cc(cA, la[k], cB, lb[k]), Y = f_dot2cc(cC, ha[k], cE, hb[k]);
+                f1[k] = f_sub(f_dot2cc(qscal[i], X, f_neg(s0), cK), Y);
+            } else {
+                const F Ga = f_sub(f_sub(f_mul(la[k], qa[k]), f_mul(xn_m1, ha[k])), s0), Gb = f_sub(f_sub(f_mul(lb[k], qb[k]), f_mul(xn_m1, hb[k])), s0);
+                const F D = f_sub(Ga, Gb), S = f_add(Ga, Gb);
+                f1[k] = f_mul(hx, f_add(D, f_mul(xr, S)));
+            }
+            out1[((size_t) i * 32 + b) * No + a] = f1[k];
+            if (v >= 2) x1[k][v - 2][lane] = f1[k];
         }
+        __syncthreads();
+        F f2[VP_VO_SPT];
+        if (v < 2) {
+#pragma unroll
+            for (int k = 0; k < VP_VO_SPT; ++k) {
+                const u32 i = ig * VP_VO_SPT + k;
+                const F gg = x1[k][v][lane];
+                f2[k] = f_add(f_half(f_add(f1[k], gg)), f_mul(c1, f_sub(f1[k], gg)));
+                out2[((size_t) i * 32 + b) * N2 + a] = f2[k];
+                if (v == 1) x2[k][lane] = f2[k];
+            }
+        }
+        __syncthreads();
+        if (v == 0) {
+#pragma unroll
+            for (int k = 0; k < VP_VO_SPT; ++k) {
+                const u32 i = ig * VP_VO_SPT + k;
+                const F gg = x2[k][lane];
+                out3[((size_t) i * 32 + b) * E + al] = f_add(f_half(f_add(f2[k], gg)), f_mul(c2, f_sub(f2[k], gg)));
+            }
+        }
+        // the next group's x1 is written by waves 2, 3 behind the second barrier (waves 0, 1 have read theirs before it), its x2 by wave 1 behind the
+        // next first barrier (which wave 0 reaches after the reads above): no barrier of its own at the end of the loop
     }
 }
 // The last fold leaves ONE value per coset (32 per slice); its 16 leaves pair coset b with coset b + 16.

@@ -626,6 +626,7 @@ __global__ void k_zero_f(F *p, u32 n) {
 __global__ void k_test_field(int op, const F *__restrict__ a, const F *__restrict__ b, F *__restrict__ o, u64 n) {
     u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (op == 3) { const u64 j = i + 1 < n ? i + 1 : 0; o[i] = f_dot2cc(a[i], b[i], a[j], b[j]); return; }      // a_i b_i + a_(i+1) b_(i+1), cyclic
     o[i] = op == 0 ? f_add(a[i], b[i]) : op == 1 ? f_sub(a[i], b[i]) : f_mul(a[i], b[i]);
 }
 

@@ -1885,7 +1885,7 @@ const char *vp_kernel_name(int kind) {
 }
 
 int vp_test_field(vp_ctx *ctx, int op, const vp_F *a, const vp_F *b, vp_F *out, uint64_t n) {
-    if (!ctx || !a || !b || !out || op < 0 || op > 2) return VP_EINVAL;
+    if (!ctx || !a || !b || !out || op < 0 || op > 3) return VP_EINVAL;
     if (n == 0) return VP_OK;
     VP_ENTER(ctx);
     F *da = nullptr, *db = nullptr, *dout = nullptr;
