@@ -194,20 +194,22 @@ VP_HD F f_mad31c_rb(const F &a, u64 y, const F &c) {
 // products — L < 2^64 (four lo*lo, each < 2^62), C < 2^64 (eight lo*hi, each < 2^61), H < 2^62 (four hi*hi, each < 2^60) — folded once.  The same thirty-two
 // multiplier instructions as two F-multiplications, ONE reduction per limb instead of two and no addition between them; the negated imaginary parts are
 // p - x (in [1, p]: high half still < 2^30).  The result is the canonical field element a*b + c*d.
+template <bool MS = false>
 VP_HD u64 dot4_31cc(const Sp31 &x0, const Sp31 &y0, const Sp31 &x1, const Sp31 &y1, const Sp31 &x2, const Sp31 &y2, const Sp31 &x3, const Sp31 &y3) {
     const u64 L = (u64) x0.lo * y0.lo + (u64) x1.lo * y1.lo + (u64) x2.lo * y2.lo + (u64) x3.lo * y3.lo;
     const u64 C = (u64) x0.lo * y0.hi + (u64) x0.hi * y0.lo + (u64) x1.lo * y1.hi + (u64) x1.hi * y1.lo
                 + (u64) x2.lo * y2.hi + (u64) x2.hi * y2.lo + (u64) x3.lo * y3.hi + (u64) x3.hi * y3.lo;
     const u64 H = (u64) x0.hi * y0.hi + (u64) x1.hi * y1.hi + (u64) x2.hi * y2.hi + (u64) x3.hi * y3.hi;
-    u64 s = c31_add<false>(C, (L & P61) + (L >> 61)) + (H << 1);           // C 2^31 + L + H 2^62:  < (2^61 + 2^34 + 2^61 + 8) + 2^63 < 2^64
+    u64 s = c31_add<MS>(C, (L & P61) + (L >> 61)) + (H << 1);              // C 2^31 + L + H 2^62:  < (2^61 + 2^34 + 2^61 + 8) + 2^63 < 2^64
     s = (s & P61) + (s >> 61);                                             // < 2^61 + 8
     return s >= P61 ? s - P61 : s;
 }
+template <bool MS = false>
 VP_HD F f_dot2cc(const F &a, const F &b, const F &c, const F &d) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(VP_MUL128)
     const Sp31 ar = split31(a.re), ai = split31(a.im), nai = split31(P61 - a.im), br = split31(b.re), bi = split31(b.im);
     const Sp31 cr = split31(c.re), ci = split31(c.im), nci = split31(P61 - c.im), dr = split31(d.re), di = split31(d.im);
-    return f_make(dot4_31cc(ar, br, nai, bi, cr, dr, nci, di), dot4_31cc(ar, bi, ai, br, cr, di, ci, dr));
+    return f_make(dot4_31cc<MS>(ar, br, nai, bi, cr, dr, nci, di), dot4_31cc<MS>(ar, bi, ai, br, cr, di, ci, dr));
 #else
     return f_add(f_mul128(a, b), f_mul128(c, d));
 #endif

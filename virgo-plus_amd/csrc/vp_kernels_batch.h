@@ -21,6 +21,10 @@ struct Half { const F *bf; const F *bs; int h1; int pad; };
 __device__ __forceinline__ F half_at(const Half &h, u32 i) {
     return f_mul(h.bf[i & ((1u << h.h1) - 1)], h.bs[i >> h.h1]);
 }
+// half_at(h, i) + c with one reduction (c canonical)
+__device__ __forceinline__ F half_mad(const Half &h, u32 i, const F &c) {
+    return f_mad31c<false, VP_MADSHIFT != 0>(h.bf[i & ((1u << h.h1) - 1)], h.bs[i >> h.h1], c);
+}
 
 struct InitArgs2 {
     const u32 *rowptr; const u32 *e_g; const u32 *e_x; const uint16_t *e_tl;
@@ -371,12 +375,11 @@ struct GenLiu {
         F xf0 = f_zero(), xs0 = f_zero(), xf1 = f_zero(), xs1 = f_zero();
         if (f0) { xf0 = hq0.bf[g0 & ((1u << hq0.h1) - 1)]; xs0 = hq0.bs[g0 >> hq0.h1]; }
         if (f1) { xf1 = hq1.bf[g1 & ((1u << hq1.h1) - 1)]; xs1 = hq1.bs[g1 >> hq1.h1]; }
-        m0 = f_mul(bf0, bs0);
-        if (ok1) m1 = f_mul(bf1, bs1);
-        if (f0) m0 = f_add(m0, f_mul(xf0, xs0));
-        if (f1) m1 = f_add(m1, f_mul(xf1, xs1));
-        for (u32 k = b0 + 1; k < e0; ++k) m0 = f_add(m0, half_at(H[e_q[k]], e_g[k]));
-        for (u32 k = e0 + 1; k < e1; ++k) m1 = f_add(m1, half_at(H[e_q[k]], e_g[k]));
+        // base term + first list term as ONE two-product sum (one reduction per limb; a row without a list adds 0 * 0), the further terms as a*b + c
+        m0 = f_dot2cc<VP_MADSHIFT != 0>(bf0, bs0, xf0, xs0);
+        if (ok1) m1 = f_dot2cc<VP_MADSHIFT != 0>(bf1, bs1, xf1, xs1);
+        for (u32 k = b0 + 1; k < e0; ++k) m0 = half_mad(H[e_q[k]], e_g[k], m0);
+        for (u32 k = e0 + 1; k < e1; ++k) m1 = half_mad(H[e_q[k]], e_g[k], m1);
     }
 };
 
