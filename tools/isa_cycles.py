@@ -84,7 +84,8 @@ def main():
         pk = pmc_name[key]
         rec = kern.get(pk) if pk else None
         if rec and rec.get("single_stream_avg_launch_us"):
-            n = rec["SQ_INSTS_VALU_per_launch"]
+            # run totals on both sides, per launch of the trace: the counter pass and the single-stream trace may replay plans with different launch counts
+            n = rec["SQ_INSTS_VALU_per_launch"] * rec["launches"] / rec.get("single_stream_launches", rec["launches"])
             us = rec["single_stream_avg_launch_us"]
             issue_us = n / 1024.0 * (cyc / tot) / 2400.0
             print("  launch: %.3e VALU wave-instructions (SQ_INSTS_VALU), %.1f us (single-stream trace) -> the SIMDs need %.1f us to issue them: %.2f of the launch"
